@@ -1,0 +1,153 @@
+/* mcl3dl_hip.h — C ABI of the MI355X-native LiDAR measurement-update engine for mcl_3dl.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++/torch types.
+ * Each entry point names the reference interface it replaces (paths relative to the at-wat/mcl_3dl
+ * v0.7.0 tree).  The C++ adapter classes in mcl_3dl_amd/include/mcl_3dl_hip/ (same class names as the
+ * reference's plugins) and the ctypes binding mcl_3dl_amd/capi.py both sit on top of exactly these symbols.
+ *
+ * Conventions
+ *   - every function returning int: 0 = OK, negative = error; mcl3dl_hip_last_error(ctx) has the text.
+ *   - the caller owns every host buffer; the context owns all device memory. One context = one GPU;
+ *     a context is not thread-safe (the reference caller is single-threaded: src/mcl_3dl.cpp:1466).
+ *   - arrays are contiguous, little-endian, float32 unless stated.  pose = 7 floats per particle:
+ *     px,py,pz (State6DOF::pos_), qx,qy,qz,qw (State6DOF::rot_, NOT required to be normalised).
+ *   - "host" entry points take host pointers and are synchronous; "device" entry points take device
+ *     pointers, enqueue on the context's stream and return without synchronising.
+ *   - There is no CPU fallback: without a usable gfx950 device mcl3dl_hip_create fails.
+ */
+#ifndef MCL3DL_HIP_H
+#define MCL3DL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCL3DL_HIP_ABI_VERSION 1
+
+typedef struct mcl3dl_hip_ctx mcl3dl_hip_ctx;
+
+/* BeamStatus, include/mcl_3dl/lidar_measurement_models/lidar_measurement_model_beam.h:64-70 (same order). */
+enum
+{
+  MCL3DL_BEAM_SHORT = 0,
+  MCL3DL_BEAM_HIT = 1,
+  MCL3DL_BEAM_LONG = 2,
+  MCL3DL_BEAM_TOTAL_REFLECTION = 3
+};
+
+/* kernel ids for mcl3dl_hip_get_kernel_time */
+enum
+{
+  MCL3DL_KERNEL_LIKELIHOOD = 0,
+  MCL3DL_KERNEL_BEAM = 1,
+  MCL3DL_KERNEL_PF = 2,
+  MCL3DL_KERNEL_COUNT = 3
+};
+
+int mcl3dl_hip_abi_version(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------------------ */
+/* Replaces: construction of the two LiDAR models + kd-tree in MCL3dlNode (src/mcl_3dl.cpp:1315-1329). */
+int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id);
+void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx);
+const char* mcl3dl_hip_last_error(const mcl3dl_hip_ctx* ctx);
+/* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own stream. */
+int mcl3dl_hip_set_stream(mcl3dl_hip_ctx* ctx, void* hip_stream);
+void* mcl3dl_hip_get_stream(mcl3dl_hip_ctx* ctx);
+int mcl3dl_hip_synchronize(mcl3dl_hip_ctx* ctx);
+
+/* ---- map + parameters ------------------------------------------------------------------------------ */
+/* Replaces: ChunkedKdtree::setInputCloud (include/mcl_3dl/chunked_kdtree.h:124-216, called at
+ * src/mcl_3dl.cpp:1369) and RaycastUsingDDA::updatePointCloud (include/mcl_3dl/raycasts/raycast_using_dda.h:162-190).
+ * dist_weight = the PointRepresentation rescale values (src/mcl_3dl.cpp:1270), NULL = none.
+ * The device structures are (re)built lazily, keyed on `stamp` like raycast_using_dda.h:168. */
+int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz /*n_m*3*/, const uint32_t* label /*n_m or NULL*/,
+                       size_t n_m, uint64_t stamp, const float* dist_weight /*3 or NULL*/);
+/* Replaces: LidarMeasurementModelLikelihoodParameters + refreshParameters
+ * (include/mcl_3dl/parameters.h:64-89, src/lidar_measurement_model_likelihood.cpp:56-61). */
+int mcl3dl_hip_set_likelihood_params(mcl3dl_hip_ctx* ctx, float match_dist_min, float match_dist_flat,
+                                     float match_weight);
+/* Replaces: LidarMeasurementModelBeamParameters + refreshParameters with use_raycast_using_dda = true
+ * (include/mcl_3dl/parameters.h:91-132, src/lidar_measurement_model_beam.cpp:58-80). num_points is
+ * num_points_default_ (it defines beam_likelihood_ = pow(beam_likelihood_min, 1/num_points)). */
+int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_grid_y, float map_grid_z,
+                               float dda_grid_size, float ray_angle_half, float hit_range, float beam_likelihood_min,
+                               uint32_t num_points, float ang_total_ref, uint32_t filter_label_max,
+                               int add_penalty_short_only_mode);
+
+/* ---- host entry points (synchronous) ------------------------------------------------------------- */
+/* Replaces: the N_p calls of LidarMeasurementModelLikelihood::measure
+ * (src/lidar_measurement_model_likelihood.cpp:105-139) and LidarMeasurementModelBeam::measure
+ * (src/lidar_measurement_model_beam.cpp:124-155) made by the measure lambda (src/mcl_3dl.cpp:409-415).
+ * n_s == 0 -> out_lik = 1, out_match_ratio = 0; n_b == 0 -> out_beam = 1 (the (1,0) of an empty cloud).
+ * scan_beam_origin[i] = PointXYZIL::label of beam point i = index into origins. Any out_* may be NULL. */
+int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, size_t n_p,
+                             const float* scan_lik_xyz /*n_s*3*/, size_t n_s, const float* scan_beam_xyz /*n_b*3*/,
+                             const uint32_t* scan_beam_origin /*n_b*/, size_t n_b, const float* origins /*n_o*3*/,
+                             size_t n_o, float* out_lik /*n_p*/, float* out_match_ratio /*n_p*/,
+                             float* out_beam /*n_p*/);
+
+/* Replaces: pf::ParticleFilter::measure (include/mcl_3dl/pf.h:252-279) given the per-particle factors of the
+ * measure lambda (src/mcl_3dl.cpp:402-425): weight *= ((1*beam)*lik)*extra ; sum ; if sum > 0 normalise and
+ * entropy = -sum(w ln w) over w > 0, else weights restored and *restored = 1 (entropy untouched -> NaN here).
+ * beam / extra / match_ratio may be NULL (factor 1 / no min-max). */
+int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout /*n_p*/, const float* lik /*n_p*/,
+                          const float* beam /*n_p or NULL*/, const float* extra /*n_p or NULL*/,
+                          const float* match_ratio /*n_p or NULL*/, size_t n_p, float* entropy,
+                          float* match_ratio_min, float* match_ratio_max, int* restored);
+
+/* Replaces: the whole `pf_->measure(measure_func)` statement (src/mcl_3dl.cpp:398-426): measure_batch +
+ * pf_measure with everything kept on the device in between.  extra = the odometry-error factor
+ * NormalLikelihood(odom_err_integ_lin.norm()) computed by the caller (include/mcl_3dl/nd.h:41-58), or NULL.
+ * out_lik / out_match_ratio / out_beam may be NULL. */
+int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, const float* extra /*n_p or NULL*/,
+                              float* weight_inout /*n_p*/, size_t n_p, const float* scan_lik_xyz, size_t n_s,
+                              const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
+                              const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
+                              float* out_beam, float* entropy, float* match_ratio_min, float* match_ratio_max,
+                              int* restored);
+
+/* Replaces: LidarMeasurementModelBeam::getBeamStatus (src/lidar_measurement_model_beam.cpp:157-192; used for the
+ * debug markers at src/mcl_3dl.cpp:471-478) for n explicit rays. hit_index = map index of CastResult::point_
+ * (-1 when the ray is exhausted). */
+int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz /*n*3*/, const float* end_xyz /*n*3*/,
+                           size_t n, int32_t* status /*n*/, int32_t* hit_index /*n or NULL*/);
+
+/* ---- device entry points (asynchronous on the context's stream) ------------------------------------- */
+/* Upload (and spatially order) the two filtered scans `pc_locals` of one update (src/mcl_3dl.cpp:377-383). */
+int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                           const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o);
+/* measure_batch on device-resident poses against the uploaded scans; outputs are device arrays (may be NULL). */
+int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose /*n_p*7*/, size_t n_p, float* d_lik,
+                              float* d_match_ratio, float* d_beam);
+/* pf::measure split for particle shards (one context per GPU):
+ *   partial: w_new = w*((1*beam)*lik)*extra kept in the context; d_partial4 = { sum w_new, sum w_new*ln(w_new),
+ *            max match_ratio, -min match_ratio } (doubles, this shard only)
+ *   [all-reduce d_partial4 across shards: sum for [0],[1]; max for [2],[3]]
+ *   apply:   weights = w_new / total[0] if total[0] > 0, else untouched; d_stats4 = { entropy, match_ratio_min,
+ *            match_ratio_max, restored } with entropy = ln S - T/S (== -sum p ln p). */
+int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, const float* d_lik, const float* d_beam,
+                                 const float* d_extra, const float* d_match_ratio, size_t n_p, double* d_partial4);
+int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, const double* d_total4,
+                               float* d_stats4);
+
+/* ---- measurement support ------------------------------------------------------------------------------ */
+/* Per-kernel hipEvent timing on the launch stream (off by default). */
+int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable);
+int mcl3dl_hip_get_kernel_time(mcl3dl_hip_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches);
+int mcl3dl_hip_reset_kernel_time(mcl3dl_hip_ctx* ctx);
+/* Exact workload counts of the last measure (re-runs the kernels in counting mode; not for timed regions):
+ * stats[0] = sum over (particle, point) of K = map points in the 27-cell neighbourhood, [1] = evaluations,
+ * [2] = DDA voxel steps, [3] = occupied voxels visited, [4] = map points tested, [5] = rays. */
+int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, double* stats6);
+/* Sizes of the device-resident structures (bytes): [0] likelihood points, [1] likelihood cell index,
+ * [2] DDA occupancy bitmap, [3] DDA voxel index, [4] DDA points. */
+int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCL3DL_HIP_H */

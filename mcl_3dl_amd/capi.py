@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI in include/mcl3dl_hip.h (libmcl3dl_hip.so, built in-tree by __graft_entry__.build()).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is usable, loading / creating an
+engine raises.  The product never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcl3dl_hip.so")
+
+KERNEL_LIKELIHOOD, KERNEL_BEAM, KERNEL_PF = 0, 1, 2
+BEAM_STATUS = {0: "SHORT", 1: "HIT", 2: "LONG", 3: "TOTAL_REFLECTION"}
+
+_f, _d, _sz, _u32, _u64, _i, _p = C.c_float, C.c_double, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/mcl3dl_hip.h declares
+SIGNATURES = {
+    "mcl3dl_hip_abi_version": (_i, []),
+    "mcl3dl_hip_create": (_i, [C.POINTER(_p), _i]),
+    "mcl3dl_hip_destroy": (None, [_p]),
+    "mcl3dl_hip_last_error": (C.c_char_p, [_p]),
+    "mcl3dl_hip_set_stream": (_i, [_p, _p]),
+    "mcl3dl_hip_get_stream": (_p, [_p]),
+    "mcl3dl_hip_synchronize": (_i, [_p]),
+    "mcl3dl_hip_set_map": (_i, [_p, _p, _p, _sz, _u64, _p]),
+    "mcl3dl_hip_set_likelihood_params": (_i, [_p, _f, _f, _f]),
+    "mcl3dl_hip_set_beam_params": (_i, [_p, _f, _f, _f, _f, _f, _f, _f, _u32, _f, _u32, _i]),
+    "mcl3dl_hip_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
+    "mcl3dl_hip_pf_measure": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p]),
+    "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
+    "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
+    "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
+    "mcl3dl_hip_measure_device": (_i, [_p, _p, _sz, _p, _p, _p]),
+    "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mcl3dl_hip_pf_apply_device": (_i, [_p, _p, _sz, _p, _p]),
+    "mcl3dl_hip_set_kernel_timing": (_i, [_p, _i]),
+    "mcl3dl_hip_get_kernel_time": (_i, [_p, _i, C.POINTER(_d), C.POINTER(_u64)]),
+    "mcl3dl_hip_reset_kernel_time": (_i, [_p]),
+    "mcl3dl_hip_workload_stats": (_i, [_p, _p, _sz, _p]),
+    "mcl3dl_hip_memory_footprint": (_i, [_p, _p]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libmcl3dl_hip.so and bind every declared symbol.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _np_f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.data_ptr())  # torch tensor (device memory)
+
+
+class Engine:
+    """One context = one GPU.  Host methods take numpy arrays; *_device methods take torch CUDA tensors."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.mcl3dl_hip_create(C.byref(h), int(device_id))
+        if rc != 0 or not h:
+            raise EngineError("mcl3dl_hip_create(device %d) failed with %d: no usable gfx950 device "
+                              "(this engine has no CPU fallback)" % (device_id, rc))
+        self.h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mcl3dl_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError("mcl3dl_hip error %d: %s" % (rc, self.lib.mcl3dl_hip_last_error(self.h).decode()))
+
+    # ---- configuration -----------------------------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._check(self.lib.mcl3dl_hip_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self._check(self.lib.mcl3dl_hip_synchronize(self.h))
+
+    def set_map(self, xyz, label=None, stamp=1, dist_weight=(1.0, 1.0, 1.0)):
+        xyz = _np_f32(xyz, 3)
+        lab = None if label is None else np.ascontiguousarray(label, dtype=np.uint32)
+        dw = None if dist_weight is None else _np_f32(dist_weight)
+        self._check(self.lib.mcl3dl_hip_set_map(self.h, _ptr(xyz), _ptr(lab), len(xyz), int(stamp), _ptr(dw)))
+
+    def set_likelihood_params(self, match_dist_min=0.2, match_dist_flat=0.05, match_weight=5.0):
+        self._check(self.lib.mcl3dl_hip_set_likelihood_params(self.h, match_dist_min, match_dist_flat, match_weight))
+
+    def set_beam_params(self, map_grid=(0.1, 0.1, 0.1), dda_grid_size=0.2, ray_angle_half=0.25 * np.pi / 180.0,
+                        hit_range=0.3, beam_likelihood_min=0.2, num_points=3, ang_total_ref=np.pi / 6.0,
+                        filter_label_max=0xFFFFFFFF, add_penalty_short_only_mode=True):
+        self._check(self.lib.mcl3dl_hip_set_beam_params(
+            self.h, map_grid[0], map_grid[1], map_grid[2], dda_grid_size, ray_angle_half, hit_range,
+            beam_likelihood_min, int(num_points), ang_total_ref, int(filter_label_max),
+            int(bool(add_penalty_short_only_mode))))
+
+    # ---- host entry points -------------------------------------------------------------------------------------
+    @staticmethod
+    def _scans(scan_lik, scan_beam, scan_beam_origin, origins):
+        sl = _np_f32(scan_lik if scan_lik is not None else np.zeros((0, 3)), 3)
+        sb = _np_f32(scan_beam if scan_beam is not None else np.zeros((0, 3)), 3)
+        so = (np.zeros(len(sb), np.uint32) if scan_beam_origin is None
+              else np.ascontiguousarray(scan_beam_origin, dtype=np.uint32))
+        og = _np_f32(origins if origins is not None else np.zeros((1, 3)), 3)
+        return sl, sb, so, og
+
+    def measure_batch(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
+        poses = _np_f32(poses, 7)
+        sl, sb, so, og = self._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        n_p = len(poses)
+        lik = np.zeros(n_p, np.float32)
+        ratio = np.zeros(n_p, np.float32)
+        beam = np.zeros(n_p, np.float32)
+        self._check(self.lib.mcl3dl_hip_measure_batch(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
+                                                      len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam)))
+        return lik, ratio, beam
+
+    def pf_measure(self, weights, lik, beam=None, extra=None, match_ratio=None):
+        w = _np_f32(weights).copy()
+        lk = _np_f32(lik)
+        bm = None if beam is None else _np_f32(beam)
+        ex = None if extra is None else _np_f32(extra)
+        mr = None if match_ratio is None else _np_f32(match_ratio)
+        ent, rmin, rmax, rest = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        self._check(self.lib.mcl3dl_hip_pf_measure(self.h, _ptr(w), _ptr(lk), _ptr(bm), _ptr(ex), _ptr(mr), len(w),
+                                                   C.byref(ent), C.byref(rmin), C.byref(rmax), C.byref(rest)))
+        return dict(weights=w, entropy=float(ent.value), match_ratio_min=float(rmin.value),
+                    match_ratio_max=float(rmax.value), restored=bool(rest.value))
+
+    def measure_update(self, poses, weights, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None,
+                       extra=None):
+        poses = _np_f32(poses, 7)
+        n_p = len(poses)
+        w = _np_f32(weights).copy()
+        ex = None if extra is None else _np_f32(extra)
+        sl, sb, so, og = self._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        lik = np.zeros(n_p, np.float32)
+        ratio = np.zeros(n_p, np.float32)
+        beam = np.zeros(n_p, np.float32)
+        ent, rmin, rmax, rest = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        self._check(self.lib.mcl3dl_hip_measure_update(
+            self.h, _ptr(poses), _ptr(ex), _ptr(w), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so), len(sb), _ptr(og),
+            len(og), _ptr(lik), _ptr(ratio), _ptr(beam), C.byref(ent), C.byref(rmin), C.byref(rmax), C.byref(rest)))
+        return dict(weights=w, lik=lik, quality=ratio, beam=beam, entropy=float(ent.value),
+                    match_ratio_min=float(rmin.value), match_ratio_max=float(rmax.value), restored=bool(rest.value))
+
+    def beam_status(self, begin, end):
+        b = _np_f32(begin, 3)
+        e = _np_f32(end, 3)
+        st = np.zeros(len(b), np.int32)
+        hit = np.zeros(len(b), np.int32)
+        self._check(self.lib.mcl3dl_hip_beam_status(self.h, _ptr(b), _ptr(e), len(b), _ptr(st), _ptr(hit)))
+        return st, hit
+
+    # ---- device entry points (torch CUDA tensors or raw device addresses) ---------------------------------------
+    def upload_scan(self, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
+        sl, sb, so, og = self._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        self._check(self.lib.mcl3dl_hip_upload_scan(self.h, _ptr(sl), len(sl), _ptr(sb), _ptr(so), len(sb), _ptr(og),
+                                                    len(og)))
+
+    def measure_device(self, d_pose, n_p, d_lik, d_ratio, d_beam):
+        self._check(self.lib.mcl3dl_hip_measure_device(self.h, _ptr(d_pose), n_p, _ptr(d_lik), _ptr(d_ratio),
+                                                       _ptr(d_beam)))
+
+    def pf_partial_device(self, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_partial4):
+        self._check(self.lib.mcl3dl_hip_pf_partial_device(self.h, _ptr(d_weight), _ptr(d_lik), _ptr(d_beam),
+                                                          _ptr(d_extra), _ptr(d_ratio), n_p, _ptr(d_partial4)))
+
+    def pf_apply_device(self, d_weight, n_p, d_total4, d_stats4):
+        self._check(self.lib.mcl3dl_hip_pf_apply_device(self.h, _ptr(d_weight), n_p, _ptr(d_total4), _ptr(d_stats4)))
+
+    # ---- measurement support -----------------------------------------------------------------------------------
+    def set_kernel_timing(self, enable):
+        self._check(self.lib.mcl3dl_hip_set_kernel_timing(self.h, int(bool(enable))))
+
+    def reset_kernel_time(self):
+        self._check(self.lib.mcl3dl_hip_reset_kernel_time(self.h))
+
+    def kernel_time(self, kernel_id):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._check(self.lib.mcl3dl_hip_get_kernel_time(self.h, kernel_id, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def workload_stats(self, d_pose, n_p):
+        st = np.zeros(6, np.float64)
+        self._check(self.lib.mcl3dl_hip_workload_stats(self.h, _ptr(d_pose), n_p, _ptr(st)))
+        return dict(sum_k=st[0], evals=st[1], dda_steps=st[2], dda_occupied=st[3], dda_tested=st[4], rays=st[5])
+
+    def memory_footprint(self):
+        b = np.zeros(5, np.uint64)
+        self._check(self.lib.mcl3dl_hip_memory_footprint(self.h, _ptr(b)))
+        return dict(lik_points=int(b[0]), lik_cells=int(b[1]), dda_bits=int(b[2]), dda_voxels=int(b[3]),
+                    dda_points=int(b[4]))

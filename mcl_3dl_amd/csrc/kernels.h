@@ -1,0 +1,519 @@
+// kernels.h — hand-written gfx950 (CDNA4, wave64) kernels of the LiDAR measurement update.
+//
+//   likelihood_kernel   one work-group per particle; lanes stride the (spatially ordered) scan, transform each
+//                       point by the particle pose, gather the exact nearest map point from the cell-sorted map,
+//                       accumulate the score in fp64 per lane, __shfl reduce per wave, LDS across waves.
+//   beam_kernel         one lane per (particle, beam point) ray: Amanatides-Woo walk through the occupancy bitmap,
+//                       per-voxel point tests, penalty counted with an integer atomic per particle.
+//   beam_finalize       penalty count -> product of penalties (bit-exact table) clamped at beam_likelihood_min.
+//   pf_*                weight update, deterministic fp64 reductions, normalisation + entropy.
+//
+// These are gather / traversal kernels (bound by L2/HBM reads and the texture-addresser, not by MFMA):
+// there is no dense contraction anywhere on this path, so no matrix-core code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+#pragma clang fp contract(off)
+
+namespace mcl3dl
+{
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident map structures
+// ---------------------------------------------------------------------------------------------------------
+// Exact nearest-neighbour grid over the dist_weight-rescaled map (replaces ChunkedKdtree + pcl::KdTreeFLANN).
+// Cells are cubes of edge `cell` >= match_dist_min * 1.01; points are sorted by cell, x fastest, so the 3x3x3
+// neighbourhood of a query is 9 contiguous runs (one per (y,z) row), each delimited by two cell_start entries.
+// Two padding cells on every side make every neighbour index of an in-range query valid.
+struct LikGrid
+{
+  const uint32_t* cell_start;  // [nx*ny*nz + 1]
+  const float4* pts;           // [n_m] rescaled x,y,z ; w = original map index (bits)
+  float ox, oy, oz;            // origin (rescaled coordinates)
+  float inv_cell;
+  int nx, ny, nz;
+};
+
+struct LikParams
+{
+  float wx, wy, wz;  // dist_weight (1,1,1 when unset)
+  int has_weight;
+  float match_dist_min;
+  float r2;  // (float)((double)r*(double)r), pcl::KdTreeFLANN::radiusSearch
+  float match_dist_flat;
+  float match_weight;
+};
+
+// DDA occupancy (replaces RaycastUsingDDA::point_exists_ / points_, raycast_using_dda.h:280-281).
+struct DdaGrid
+{
+  const uint32_t* bits;       // occupancy, 1 bit per voxel, x fastest
+  const uint32_t* vox_start;  // [total + 1] CSR into pts (voxel order, insertion order inside a voxel)
+  const float4* pts;          // x,y,z (unscaled map coordinates), w = label bits
+  const uint32_t* pt_index;   // original map index of pts[k]
+  float min_x, min_y, min_z;
+  float max_x, max_y, max_z;
+  int nx, ny, nz;
+  double grid;             // dda_grid_size_
+  double ray_angle_half;   // ray_angle_half_
+  double min_dist_thr_sq;  // min_dist_thr_sq_
+  float hit_tolerance_f;   // (float)hit_tolerance_  (Vec3::operator*(float))
+};
+
+struct BeamParams
+{
+  float sin_total_ref;
+  float hit_range_sq;
+  uint32_t filter_label_max;
+  int short_only;
+  float beam_likelihood_min;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Likelihood-field model: LidarMeasurementModelLikelihood::measure, src/lidar_measurement_model_likelihood.cpp:105-139
+// ---------------------------------------------------------------------------------------------------------
+// Nearest rescaled map point to q among the 27 cells around it; returns min d2 (FLT_MAX if none).
+template <bool STATS>
+__device__ inline float nearest_d2(const LikGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  // cell of the query; (q - o) * inv is the same float expression the host used to bin the map points
+  const float fx = floorf((qx - g.ox) * g.inv_cell);
+  const float fy = floorf((qy - g.oy) * g.inv_cell);
+  const float fz = floorf((qz - g.oz) * g.inv_cell);
+  float best = 3.0e38f;
+  // written so that NaN coordinates fall through to "not found"
+  if (!(fx >= 1.0f && fy >= 1.0f && fz >= 1.0f && fx <= static_cast<float>(g.nx - 2) &&
+        fy <= static_cast<float>(g.ny - 2) && fz <= static_cast<float>(g.nz - 2)))
+    return best;
+  const int cx = static_cast<int>(fx), cy = static_cast<int>(fy), cz = static_cast<int>(fz);
+  uint32_t rs[9], re[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r)
+  {
+    const int dz = r / 3 - 1, dy = r % 3 - 1;
+    const size_t row = (static_cast<size_t>(cz + dz) * g.ny + (cy + dy)) * g.nx + cx;
+    rs[r] = g.cell_start[row - 1];
+    re[r] = g.cell_start[row + 2];
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r)
+  {
+    for (uint32_t k = rs[r]; k < re[r]; ++k)
+    {
+      const float4 p = g.pts[k];
+      // flann::L2_Simple<float>: ((0 + dx*dx) + dy*dy) + dz*dz
+      const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+      float d2 = dx * dx;
+      d2 = d2 + dy * dy;
+      d2 = d2 + dz * dz;
+      best = d2 < best ? d2 : best;
+      if (STATS)
+        ++n_tested;
+    }
+  }
+  return best;
+}
+
+template <int BLOCK, bool STATS>
+__global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
+                                                           const float4* __restrict__ scan, int n_s, LikGrid g,
+                                                           LikParams prm, float* __restrict__ out_lik,
+                                                           float* __restrict__ out_ratio,
+                                                           double* __restrict__ out_tested)
+{
+  const int p = blockIdx.x;
+  const float* ps = pose7 + 7 * static_cast<size_t>(p);
+  const Vec3f pos = { ps[0], ps[1], ps[2] };
+  const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
+
+  double acc = 0.0;   // sum of float terms, each exactly representable: fp64 sum is exact to ~1e-16
+  unsigned num = 0;   // matched points
+  unsigned tested = 0;
+  for (int i = threadIdx.x; i < n_s; i += BLOCK)
+  {
+    const float4 v = scan[i];
+    // State6DOF::transform, state_6dof.h:219-223
+    const Vec3f t = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+    // PointRepresentation::vectorize: rescale by dist_weight (one rounding per coordinate)
+    float qx = t.x, qy = t.y, qz = t.z;
+    if (prm.has_weight)
+    {
+      qx = t.x * prm.wx;
+      qy = t.y * prm.wy;
+      qz = t.z * prm.wz;
+    }
+    const float d2 = nearest_d2<STATS>(g, qx, qy, qz, tested);
+    if (d2 < prm.r2)  // radiusSearch found a neighbour (strict <)
+    {
+      const float s = sqrtf(d2);
+      const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);  // :128
+      if (!(dist < 0.0f))                                                                           // :129
+      {
+        acc += static_cast<double>(dist * prm.match_weight);  // :132 (float product, then accumulated)
+        ++num;
+      }
+    }
+  }
+  // wavefront __shfl reduction, then across the work-group's waves through LDS
+  __shared__ double s_acc[BLOCK / 64];
+  __shared__ unsigned s_num[BLOCK / 64];
+  __shared__ unsigned s_tested[BLOCK / 64];
+  acc = wave_sum(acc);
+  num = wave_sum(num);
+  if (STATS)
+    tested = wave_sum(tested);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    s_acc[wave] = acc;
+    s_num[wave] = num;
+    if (STATS)
+      s_tested[wave] = tested;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double a = 0.0;
+    unsigned n = 0, tt = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w)
+    {
+      a += s_acc[w];
+      n += s_num[w];
+      if (STATS)
+        tt += s_tested[w];
+    }
+    if (out_lik)
+      out_lik[p] = static_cast<float>(a);
+    if (out_ratio)
+      out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);  // :136
+    if (STATS && out_tested)
+      out_tested[p] = static_cast<double>(tt);
+  }
+}
+
+// n_s == 0: (likelihood 1, quality 0), src/lidar_measurement_model_likelihood.cpp:111-114
+__global__ void fill_kernel(float* a, float va, float* b, float vb, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+  {
+    if (a)
+      a[i] = va;
+    if (b)
+      b[i] = vb;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Beam model: RaycastUsingDDA (include/mcl_3dl/raycasts/raycast_using_dda.h) +
+//             LidarMeasurementModelBeam::getBeamStatus / measure (src/lidar_measurement_model_beam.cpp:124-192)
+// ---------------------------------------------------------------------------------------------------------
+struct RayStats
+{
+  unsigned long long steps, occupied, tested;
+};
+
+// Casts one ray; returns BeamStatus (0 SHORT, 1 HIT, 2 LONG, 3 TOTAL_REFLECTION). *hit = original map index of the
+// collided point (-1 if the ray was exhausted).
+template <bool STATS>
+__device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
+                               unsigned& st_steps, unsigned& st_occ, unsigned& st_tested)
+{
+  *hit = -1;
+  // isPointWithinMap, raycast_using_dda.h:260-270  -> max_movement_ = 0 -> getNextCastResult false -> LONG
+  if ((b.x < g.min_x) || (g.max_x < b.x) || (b.y < g.min_y) || (g.max_y < b.y) || (b.z < g.min_z) || (g.max_z < b.z))
+    return 2;
+  // setRay, :76-103
+  const Vec3f diff = vsub(e_org, b);
+  const float nrm = sqrtf(vdot(diff, diff));
+  const Vec3f dir = { diff.x / nrm, diff.y / nrm, diff.z / nrm };
+  const Vec3f e = vadd(e_org, vscale(dir, g.hit_tolerance_f));
+  // toIndex, :205-210: float difference, double division, truncation toward zero
+  const int bx = static_cast<int>(static_cast<double>(b.x - g.min_x) / g.grid);
+  const int by = static_cast<int>(static_cast<double>(b.y - g.min_y) / g.grid);
+  const int bz = static_cast<int>(static_cast<double>(b.z - g.min_z) / g.grid);
+  const int ex = static_cast<int>(static_cast<double>(e.x - g.min_x) / g.grid);
+  const int ey = static_cast<int>(static_cast<double>(e.y - g.min_y) / g.grid);
+  const int ez = static_cast<int>(static_cast<double>(e.z - g.min_z) / g.grid);
+  const int dix = ex - bx, diy = ey - by, diz = ez - bz;
+  const int max_movement = abs(dix) + abs(diy) + abs(diz);
+  const int sx = dix < 0 ? -1 : 1, sy = diy < 0 ? -1 : 1, sz = diz < 0 ? -1 : 1;
+  const float inf = __builtin_inff();
+  float iex = inf, iey = inf, iez = inf, tdx = inf, tdy = inf, tdz = inf;
+  if (dix != 0)
+  {
+    const double nearest = (dir.x < 0) ? bx * g.grid + g.min_x : (bx + 1) * g.grid + g.min_x;
+    iex = static_cast<float>(fabs((nearest - b.x) / dir.x));
+    tdx = static_cast<float>(fabs(g.grid / dir.x));
+  }
+  if (diy != 0)
+  {
+    const double nearest = (dir.y < 0) ? by * g.grid + g.min_y : (by + 1) * g.grid + g.min_y;
+    iey = static_cast<float>(fabs((nearest - b.y) / dir.y));
+    tdy = static_cast<float>(fabs(g.grid / dir.y));
+  }
+  if (diz != 0)
+  {
+    const double nearest = (dir.z < 0) ? bz * g.grid + g.min_z : (bz + 1) * g.grid + g.min_z;
+    iez = static_cast<float>(fabs((nearest - b.z) / dir.z));
+    tdz = static_cast<float>(fabs(g.grid / dir.z));
+  }
+  float tmx = iex, tmy = iey, tmz = iez;
+  int cx = bx, cy = by, cz = bz;
+  int pos = 0;
+  const long long plane = static_cast<long long>(g.nx) * g.ny;
+  for (;;)
+  {
+    // getNextCastResult, :106-159
+    ++pos;
+    if (pos >= max_movement)
+      break;
+    bool inside;
+    if (tmx < tmy ? (tmx < tmz) : false)
+    {
+      cx += sx;  // incrementIndex(0), :192-203
+      tmx = iex + tdx * static_cast<float>(abs(cx - bx));
+      inside = !(cx < 0 || g.nx <= cx);
+    }
+    else if (tmx < tmy ? false : (tmy < tmz))
+    {
+      cy += sy;
+      tmy = iey + tdy * static_cast<float>(abs(cy - by));
+      inside = !(cy < 0 || g.ny <= cy);
+    }
+    else
+    {
+      cz += sz;
+      tmz = iez + tdz * static_cast<float>(abs(cz - bz));
+      inside = !(cz < 0 || g.nz <= cz);
+    }
+    if (!inside)
+      break;
+    if (STATS)
+      ++st_steps;
+    // hasIntersection, :237-258
+    const long long v = cx + static_cast<long long>(cy) * g.nx + static_cast<long long>(cz) * plane;
+    const uint32_t word = g.bits[v >> 5];
+    if (!((word >> (v & 31)) & 1u))
+      continue;
+    if (STATS)
+      ++st_occ;
+    const uint32_t k0 = g.vox_start[v], k1 = g.vox_start[v + 1];
+    int collided = -1;
+    float4 cp = { 0, 0, 0, 0 };
+    for (uint32_t k = k0; k < k1; ++k)
+    {
+      const float4 t = g.pts[k];
+      if (STATS)
+        ++st_tested;
+      const Vec3f rel = { t.x - b.x, t.y - b.y, t.z - b.z };
+      const double foot = static_cast<double>(fabsf(vdot(rel, dir)));
+      const double a = g.ray_angle_half * foot;
+      const double a2 = a * a;
+      const double thr = a2 < g.min_dist_thr_sq ? g.min_dist_thr_sq : a2;
+      const double dist_sq = static_cast<double>(vdot(rel, rel)) - foot * foot;
+      if (dist_sq < thr)
+      {
+        collided = static_cast<int>(k);
+        cp = t;
+        break;
+      }
+    }
+    if (collided < 0)
+      continue;
+    // getBeamStatus, beam.cpp:164-187
+    if (__float_as_uint(cp.w) > bp.filter_label_max)
+      continue;
+    *hit = static_cast<int>(g.pt_index[collided]);
+    if (1.0f > bp.sin_total_ref)  // DDA always reports sin_angle_ = 1.0 (raycast_using_dda.h:152)
+    {
+      const double ddx = static_cast<double>(e_org.x - cp.x), ddy = static_cast<double>(e_org.y - cp.y),
+                   ddz = static_cast<double>(e_org.z - cp.z);
+      const float distance_from_point_sq = static_cast<float>(ddx * ddx + ddy * ddy + ddz * ddz);
+      return distance_from_point_sq < bp.hit_range_sq ? 1 : 0;
+    }
+    return 3;
+  }
+  return 2;
+}
+
+// One lane per (particle, beam point).  scan_beam.w = origin index (PointXYZIL::label of the scan point).
+template <bool STATS>
+__global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
+                                                   int n_b, const float4* __restrict__ origins, long long n_rays,
+                                                   DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
+                                                   RayStats* __restrict__ stats)
+{
+  const long long ray = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  unsigned st_steps = 0, st_occ = 0, st_tested = 0;
+  if (ray < n_rays)
+  {
+    const long long p = ray / n_b;
+    const int i = static_cast<int>(ray - p * n_b);
+    const float* ps = pose7 + 7 * p;
+    const Vec3f pos = { ps[0], ps[1], ps[2] };
+    const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
+    const Quat rot = qnormalized(raw);
+    const float4 v = scan[i];
+    const Vec3f end = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);  // beam.cpp:139 (transform)
+    const float4 og = origins[__float_as_uint(v.w)];
+    const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
+    int hit;
+    const int status = cast_ray<STATS>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
+    if ((status == 0) || (!bp.short_only && (status == 2)))  // beam.cpp:146
+      atomicAdd(&penalty_count[p], 1u);
+  }
+  if (STATS)
+  {
+    atomicAdd(&stats->steps, static_cast<unsigned long long>(st_steps));
+    atomicAdd(&stats->occupied, static_cast<unsigned long long>(st_occ));
+    atomicAdd(&stats->tested, static_cast<unsigned long long>(st_tested));
+  }
+}
+
+// score_beam = beam_likelihood_^k by k float multiplications (table built on the host the same way), then the
+// clamp of beam.cpp:151-152.
+__global__ void beam_finalize_kernel(const unsigned* __restrict__ penalty_count, const float* __restrict__ pow_table,
+                                     float beam_likelihood_min, float* __restrict__ out_beam, int n_p)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_p)
+  {
+    float s = pow_table[penalty_count[p]];
+    if (s < beam_likelihood_min)
+      s = beam_likelihood_min;
+    out_beam[p] = s;
+  }
+}
+
+// LidarMeasurementModelBeam::getBeamStatus for explicit rays (debug-marker path, src/mcl_3dl.cpp:471-478).
+__global__ void beam_status_kernel(const float* __restrict__ begin_xyz, const float* __restrict__ end_xyz, int n,
+                                   DdaGrid g, BeamParams bp, int* __restrict__ status, int* __restrict__ hit_index)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  unsigned a = 0, b = 0, c = 0;
+  int hit;
+  const int s = cast_ray<false>(g, bp, Vec3f{ begin_xyz[3 * i], begin_xyz[3 * i + 1], begin_xyz[3 * i + 2] },
+                                Vec3f{ end_xyz[3 * i], end_xyz[3 * i + 1], end_xyz[3 * i + 2] }, &hit, a, b, c);
+  status[i] = s;
+  if (hit_index)
+    hit_index[i] = (s == 2) ? -1 : hit;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pf::ParticleFilter::measure, include/mcl_3dl/pf.h:252-279  (+ the lambda's product, src/mcl_3dl.cpp:407-424)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PF_BLOCK = 256;
+
+// w_new = w * (((1 * beam) * lik) * extra); per-block partials {sum w, sum w ln w, max ratio, -min ratio}.
+__global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __restrict__ w, const float* __restrict__ lik,
+                                                              const float* __restrict__ beam,
+                                                              const float* __restrict__ extra,
+                                                              const float* __restrict__ ratio, int n,
+                                                              float* __restrict__ w_new,
+                                                              double* __restrict__ block_partials)
+{
+  double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;  // match_ratio_max = 0, match_ratio_min = 1 (mcl_3dl.cpp:398-399)
+  for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+  {
+    float l = 1.0f;
+    if (beam)
+      l *= beam[i];
+    l *= lik[i];
+    if (extra)
+      l = l * extra[i];
+    const float wn = w[i] * l;  // pf.h:258
+    w_new[i] = wn;
+    s += static_cast<double>(wn);
+    if (wn > 0.0f)
+      t += static_cast<double>(wn) * log(static_cast<double>(wn));
+    if (ratio)
+    {
+      const double r = static_cast<double>(ratio[i]);
+      rmax = r > rmax ? r : rmax;
+      rneg = -r > rneg ? -r : rneg;
+    }
+  }
+  __shared__ double sh[4][PF_BLOCK / 64];
+  s = wave_sum(s);
+  t = wave_sum(t);
+  rmax = wave_max(rmax);
+  rneg = wave_max(rneg);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    sh[0][wave] = s;
+    sh[1][wave] = t;
+    sh[2][wave] = rmax;
+    sh[3][wave] = rneg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double a = 0, b = 0, c = sh[2][0], d = sh[3][0];
+    for (int k = 0; k < PF_BLOCK / 64; ++k)
+    {
+      a += sh[0][k];
+      b += sh[1][k];
+      c = sh[2][k] > c ? sh[2][k] : c;
+      d = sh[3][k] > d ? sh[3][k] : d;
+    }
+    block_partials[4 * blockIdx.x + 0] = a;
+    block_partials[4 * blockIdx.x + 1] = b;
+    block_partials[4 * blockIdx.x + 2] = c;
+    block_partials[4 * blockIdx.x + 3] = d;
+  }
+}
+
+// Fixed-order reduction of the block partials (deterministic run to run).
+__global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict__ block_partials, int n_blocks,
+                                                       double* __restrict__ partial4)
+{
+  double a = 0, b = 0, c = 0.0, d = -1.0;
+  for (int k = threadIdx.x; k < n_blocks; k += 64)
+  {
+    a += block_partials[4 * k + 0];
+    b += block_partials[4 * k + 1];
+    c = block_partials[4 * k + 2] > c ? block_partials[4 * k + 2] : c;
+    d = block_partials[4 * k + 3] > d ? block_partials[4 * k + 3] : d;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_max(c);
+  d = wave_max(d);
+  if (threadIdx.x == 0)
+  {
+    partial4[0] = a;
+    partial4[1] = b;
+    partial4[2] = c;
+    partial4[3] = d;
+  }
+}
+
+// Normalise (pf.h:262-272) or restore (pf.h:274-278); entropy = ln S - T/S == -sum (w/S) ln (w/S).
+__global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ w, const float* __restrict__ w_new,
+                                                            int n, const double* __restrict__ total4,
+                                                            float* __restrict__ stats4)
+{
+  const double S = total4[0];
+  const float sum_f = static_cast<float>(S);
+  const bool alive = sum_f > 0.0f;
+  if (alive)
+  {
+    for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+      w[i] = w_new[i] / sum_f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats4)
+  {
+    stats4[0] = alive ? static_cast<float>(log(S) - total4[1] / S) : __builtin_nanf("");
+    stats4[1] = static_cast<float>(-total4[3]);
+    stats4[2] = static_cast<float>(total4[2]);
+    stats4[3] = alive ? 0.0f : 1.0f;
+  }
+}
+}  // namespace mcl3dl

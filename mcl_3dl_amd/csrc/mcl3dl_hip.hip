@@ -1,0 +1,1064 @@
+// mcl3dl_hip.hip — host side of the C ABI declared in include/mcl3dl_hip.h: context, map compiler
+// (cell-sorted exact-NN grid, DDA occupancy), scan ordering, kernel launches, hipEvent timing.
+// Device code lives in kernels.h.  gfx950 only; there is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "mcl3dl_hip.h"
+
+#pragma clang fp contract(off)
+
+using namespace mcl3dl;
+
+namespace
+{
+struct DevBuf
+{
+  void* p = nullptr;
+  size_t cap = 0;
+  template <typename T>
+  T* as() const
+  {
+    return static_cast<T*>(p);
+  }
+};
+
+struct EventPair
+{
+  hipEvent_t start, stop;
+  int kernel;
+};
+}  // namespace
+
+struct mcl3dl_hip_ctx
+{
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // host copy of the map (kept to rebuild the device structures when parameters change)
+  std::vector<float> map_xyz;
+  std::vector<uint32_t> map_label;
+  uint64_t stamp = 0;
+  bool has_map = false;
+  bool has_weight = false;
+  float weight[3] = { 1.f, 1.f, 1.f };
+
+  // LidarMeasurementModelLikelihoodParameters defaults, include/mcl_3dl/parameters.h:74-76
+  float match_dist_min = 0.2f, match_dist_flat = 0.05f, match_weight = 5.0f;
+  // LidarMeasurementModelBeamParameters defaults, include/mcl_3dl/parameters.h:96-112
+  float map_grid[3] = { 0.1f, 0.1f, 0.1f };
+  float dda_grid_size = 0.2f;
+  float ray_angle_half = static_cast<float>(0.25 * M_PI / 180.0);
+  float hit_range = 0.3f;
+  float beam_likelihood_min = 0.2f;
+  uint32_t beam_num_points = 3;
+  float ang_total_ref = static_cast<float>(M_PI / 6.0);
+  uint32_t filter_label_max = 0xFFFFFFFFu;
+  int short_only = 1;
+  // derived, src/lidar_measurement_model_beam.cpp:65-67
+  float hit_range_sq = 0, beam_likelihood = 0, sin_total_ref = 0;
+
+  bool lik_dirty = true, dda_dirty = true;
+  DevBuf lik_pts, lik_cells;
+  LikGrid lg{};
+  DevBuf dda_bits, dda_start, dda_pts, dda_index;
+  DdaGrid dg{};
+  uint64_t footprint[5] = { 0, 0, 0, 0, 0 };
+
+  // scans of the current update
+  DevBuf scan_lik, scan_beam, origins, pow_table;
+  size_t n_s = 0, n_b = 0, n_o = 0;
+  bool has_scan = false;
+  bool pow_table_dirty = true;
+
+  // work buffers
+  DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
+      tested, ray_begin, ray_end, ray_status, ray_hit;
+
+  // timing
+  bool timing = false;
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> free_events;
+  double kernel_ms[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
+  uint64_t kernel_launches[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
+
+  int fail(int code, const char* fmt, ...)
+  {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+namespace
+{
+#define HIP_TRY(expr)                                                                            \
+  do                                                                                             \
+  {                                                                                              \
+    const hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                        \
+      return ctx->fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define TRY(expr)        \
+  do                     \
+  {                      \
+    const int r_ = (expr); \
+    if (r_ != 0)         \
+      return r_;         \
+  } while (0)
+
+inline float bits_to_float(uint32_t u)
+{
+  float f;
+  memcpy(&f, &u, sizeof(f));
+  return f;
+}
+
+int ensure(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t bytes)
+{
+  if (bytes == 0)
+    bytes = 16;
+  if (b.cap >= bytes)
+    return 0;
+  if (b.p)
+  {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t cap = bytes + bytes / 4;
+  HIP_TRY(hipMalloc(&b.p, cap));
+  b.cap = cap;
+  return 0;
+}
+
+int h2d(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  if (bytes == 0)
+    return 0;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+int d2h(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  if (bytes == 0)
+    return 0;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+// ---- timing -----------------------------------------------------------------------------------------
+int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep)
+{
+  if (!ctx->timing)
+    return 0;
+  hipEvent_t ev[2];
+  for (int i = 0; i < 2; ++i)
+  {
+    if (!ctx->free_events.empty())
+    {
+      ev[i] = ctx->free_events.back();
+      ctx->free_events.pop_back();
+    }
+    else
+    {
+      HIP_TRY(hipEventCreate(&ev[i]));
+    }
+  }
+  ep->start = ev[0];
+  ep->stop = ev[1];
+  ep->kernel = kernel;
+  HIP_TRY(hipEventRecord(ep->start, ctx->stream));
+  return 0;
+}
+
+int timing_end(mcl3dl_hip_ctx* ctx, const EventPair& ep)
+{
+  if (!ctx->timing)
+    return 0;
+  HIP_TRY(hipEventRecord(ep.stop, ctx->stream));
+  ctx->pending.push_back(ep);
+  return 0;
+}
+
+int timing_collect(mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->pending.empty())
+    return 0;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (const EventPair& ep : ctx->pending)
+  {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+    ctx->kernel_ms[ep.kernel] += ms;
+    ctx->kernel_launches[ep.kernel] += 1;
+    ctx->free_events.push_back(ep.start);
+    ctx->free_events.push_back(ep.stop);
+  }
+  ctx->pending.clear();
+  return 0;
+}
+
+// ---- map compiler: exact-NN grid -----------------------------------------------------------------------
+// Replaces ChunkedKdtree::setInputCloud + pcl::KdTreeFLANN::setInputCloud.  The reference's chunking is a memory
+// device (20 m chunks with duplicated margins, chunked_kdtree.h:124-216) whose query result equals the global
+// nearest neighbour within the radius whenever radius <= max_search_radius; the grid gives that result directly.
+int build_lik_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const float cell = ctx->match_dist_min * 1.01f;
+  if (!(cell > 0.f) || !std::isfinite(cell))
+    return ctx->fail(-3, "match_dist_min must be positive and finite");
+  const float inv = 1.0f / cell;
+  std::vector<float> s(3 * n);
+  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a)
+    {
+      // PointRepresentation::vectorize: one float product per coordinate
+      const float v = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
+      if (!std::isfinite(v))
+        return ctx->fail(-3, "map point %zu is not finite", i);
+      s[3 * i + a] = v;
+      if (i == 0 || v < mn[a])
+        mn[a] = v;
+      if (i == 0 || v > mx[a])
+        mx[a] = v;
+    }
+  float o[3];
+  int dim[3];
+  double total = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    o[a] = mn[a] - 2.0f * cell;
+    dim[a] = static_cast<int>(floorf((mx[a] - o[a]) * inv)) + 3;
+    total *= dim[a];
+  }
+  if (total > 3.0e9)
+    return ctx->fail(-4, "likelihood grid would need %.3g cells (map extent too large for the dense index)", total);
+  const size_t ncell = static_cast<size_t>(dim[0]) * dim[1] * dim[2];
+  std::vector<uint32_t> cell_of(n);
+  std::vector<uint32_t> start(ncell + 1, 0);
+  for (size_t i = 0; i < n; ++i)
+  {
+    int c[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      c[a] = static_cast<int>(floorf((s[3 * i + a] - o[a]) * inv));  // same expression as the kernel's
+      c[a] = std::min(std::max(c[a], 0), dim[a] - 1);
+    }
+    cell_of[i] = static_cast<uint32_t>((static_cast<size_t>(c[2]) * dim[1] + c[1]) * dim[0] + c[0]);
+    ++start[cell_of[i] + 1];
+  }
+  for (size_t c = 0; c < ncell; ++c)
+    start[c + 1] += start[c];
+  std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+  std::vector<float4> pts(n);
+  for (size_t i = 0; i < n; ++i)
+  {
+    const uint32_t dst = fill[cell_of[i]]++;
+    pts[dst] = make_float4(s[3 * i], s[3 * i + 1], s[3 * i + 2], bits_to_float(static_cast<uint32_t>(i)));
+  }
+  TRY(ensure(ctx, ctx->lik_pts, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->lik_cells, sizeof(uint32_t) * (ncell + 1)));
+  TRY(h2d(ctx, ctx->lik_pts.p, pts.data(), sizeof(float4) * n));
+  TRY(h2d(ctx, ctx->lik_cells.p, start.data(), sizeof(uint32_t) * (ncell + 1)));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
+  ctx->lg.pts = ctx->lik_pts.as<float4>();
+  ctx->lg.ox = o[0];
+  ctx->lg.oy = o[1];
+  ctx->lg.oz = o[2];
+  ctx->lg.inv_cell = inv;
+  ctx->lg.nx = dim[0];
+  ctx->lg.ny = dim[1];
+  ctx->lg.nz = dim[2];
+  ctx->footprint[0] = sizeof(float4) * n;
+  ctx->footprint[1] = sizeof(uint32_t) * (ncell + 1);
+  ctx->lik_dirty = false;
+  return 0;
+}
+
+// ---- map compiler: DDA occupancy -------------------------------------------------------------------------
+// RaycastUsingDDA::updatePointCloud / setExists, include/mcl_3dl/raycasts/raycast_using_dda.h:162-190,230-235:
+// AABB by getMinMax3D, map_size = (size_t)((max-min)/grid)+1, voxel = trunc((p-min)/grid) (float difference,
+// double division), x-fastest array index; per voxel the points stay in insertion (map) order.
+int build_dda_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const double grid = static_cast<double>(ctx->dda_grid_size);
+  if (!(grid > 0))
+    return ctx->fail(-3, "dda_grid_size must be positive");
+  float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a)
+    {
+      const float v = ctx->map_xyz[3 * i + a];
+      if (v < mn[a])
+        mn[a] = v;
+      if (v > mx[a])
+        mx[a] = v;
+    }
+  int dim[3];
+  double total_d = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    dim[a] = static_cast<int>(static_cast<size_t>((mx[a] - mn[a]) / grid) + 1);
+    total_d *= dim[a];
+  }
+  if (total_d >= 2147483647.0)  // the reference keeps point_total in an int (raycast_using_dda.h:176)
+    return ctx->fail(-4, "DDA grid would need %.3g voxels (>= 2^31)", total_d);
+  const size_t total = static_cast<size_t>(total_d);
+  std::vector<uint32_t> vox(n);
+  std::vector<uint32_t> start(total + 1, 0);
+  std::vector<uint32_t> bits((total + 31) / 32 + 1, 0);
+  for (size_t i = 0; i < n; ++i)
+  {
+    int c[3];
+    for (int a = 0; a < 3; ++a)
+      c[a] = static_cast<int>(static_cast<double>(ctx->map_xyz[3 * i + a] - mn[a]) / grid);
+    const size_t v = static_cast<size_t>(c[0] + c[1] * dim[0] + c[2] * (dim[0] * dim[1]));
+    if (v >= total)
+      return ctx->fail(-3, "map point %zu falls outside its own DDA grid", i);
+    vox[i] = static_cast<uint32_t>(v);
+    ++start[v + 1];
+    bits[v >> 5] |= 1u << (v & 31);
+  }
+  for (size_t v = 0; v < total; ++v)
+    start[v + 1] += start[v];
+  std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+  std::vector<float4> pts(n);
+  std::vector<uint32_t> index(n);
+  for (size_t i = 0; i < n; ++i)  // ascending i: insertion order preserved inside a voxel
+  {
+    const uint32_t dst = fill[vox[i]]++;
+    pts[dst] = make_float4(ctx->map_xyz[3 * i], ctx->map_xyz[3 * i + 1], ctx->map_xyz[3 * i + 2],
+                           bits_to_float(ctx->map_label[i]));
+    index[dst] = static_cast<uint32_t>(i);
+  }
+  TRY(ensure(ctx, ctx->dda_bits, sizeof(uint32_t) * bits.size()));
+  TRY(ensure(ctx, ctx->dda_start, sizeof(uint32_t) * (total + 1)));
+  TRY(ensure(ctx, ctx->dda_pts, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->dda_index, sizeof(uint32_t) * n));
+  TRY(h2d(ctx, ctx->dda_bits.p, bits.data(), sizeof(uint32_t) * bits.size()));
+  TRY(h2d(ctx, ctx->dda_start.p, start.data(), sizeof(uint32_t) * (total + 1)));
+  TRY(h2d(ctx, ctx->dda_pts.p, pts.data(), sizeof(float4) * n));
+  TRY(h2d(ctx, ctx->dda_index.p, index.data(), sizeof(uint32_t) * n));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  DdaGrid& g = ctx->dg;
+  g.bits = ctx->dda_bits.as<uint32_t>();
+  g.vox_start = ctx->dda_start.as<uint32_t>();
+  g.pts = ctx->dda_pts.as<float4>();
+  g.pt_index = ctx->dda_index.as<uint32_t>();
+  g.min_x = mn[0];
+  g.min_y = mn[1];
+  g.min_z = mn[2];
+  g.max_x = mx[0];
+  g.max_y = mx[1];
+  g.max_z = mx[2];
+  g.nx = dim[0];
+  g.ny = dim[1];
+  g.nz = dim[2];
+  g.grid = grid;
+  g.ray_angle_half = static_cast<double>(ctx->ray_angle_half);
+  // RaycastUsingDDA ctor, raycast_using_dda.h:59: map_grid_size_y appears twice (reference quirk, kept)
+  const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];
+  g.min_dist_thr_sq = gx * gx + gy * gy + gy * gy;
+  g.hit_tolerance_f = static_cast<float>(static_cast<double>(ctx->hit_range));
+  ctx->footprint[2] = sizeof(uint32_t) * bits.size();
+  ctx->footprint[3] = sizeof(uint32_t) * (total + 1);
+  ctx->footprint[4] = sizeof(float4) * n + sizeof(uint32_t) * n;
+  ctx->dda_dirty = false;
+  return 0;
+}
+
+int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda)
+{
+  if (!ctx->has_map)
+    return ctx->fail(-5, "no map: call mcl3dl_hip_set_map first");
+  if (need_lik && ctx->lik_dirty)
+    TRY(build_lik_grid(ctx));
+  if (need_dda && ctx->dda_dirty)
+    TRY(build_dda_grid(ctx));
+  return 0;
+}
+
+LikParams lik_params(const mcl3dl_hip_ctx* ctx)
+{
+  LikParams p;
+  p.wx = ctx->weight[0];
+  p.wy = ctx->weight[1];
+  p.wz = ctx->weight[2];
+  p.has_weight = ctx->has_weight ? 1 : 0;
+  p.match_dist_min = ctx->match_dist_min;
+  // pcl::KdTreeFLANN::radiusSearch: (float)(radius * radius) with radius widened to double
+  p.r2 = static_cast<float>(static_cast<double>(ctx->match_dist_min) * static_cast<double>(ctx->match_dist_min));
+  p.match_dist_flat = ctx->match_dist_flat;
+  p.match_weight = ctx->match_weight;
+  return p;
+}
+
+BeamParams beam_params(const mcl3dl_hip_ctx* ctx)
+{
+  BeamParams p;
+  p.sin_total_ref = ctx->sin_total_ref;
+  p.hit_range_sq = ctx->hit_range_sq;
+  p.filter_label_max = ctx->filter_label_max;
+  p.short_only = ctx->short_only;
+  p.beam_likelihood_min = ctx->beam_likelihood_min;
+  return p;
+}
+
+// LidarMeasurementModelBeam::refreshParameters, src/lidar_measurement_model_beam.cpp:65-67 (host libm, like the reference)
+void beam_refresh(mcl3dl_hip_ctx* ctx)
+{
+  ctx->hit_range_sq = static_cast<float>(std::pow(static_cast<double>(ctx->hit_range), 2));
+  ctx->beam_likelihood = static_cast<float>(
+      std::pow(static_cast<double>(ctx->beam_likelihood_min), 1.0 / static_cast<float>(ctx->beam_num_points)));
+  ctx->sin_total_ref = sinf(ctx->ang_total_ref);
+  ctx->pow_table_dirty = true;
+}
+
+// 3-D Morton key of a scan point (robot frame), 0.25 m cells: neighbouring lanes of a wavefront then gather from
+// neighbouring map cells.
+uint64_t morton3(uint32_t x, uint32_t y, uint32_t z)
+{
+  auto spread = [](uint64_t v)
+  {
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+  };
+  return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
+                   bool stats, double* stats6)
+{
+  if (!ctx->has_scan)
+    return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
+  if (n_p == 0)
+    return 0;
+  if (n_p > 0x7fffffffu)
+    return ctx->fail(-3, "too many particles");
+  const bool want_lik = (d_lik || d_ratio || stats);
+  const bool want_beam = (d_beam || stats);
+  TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0));
+  const int np = static_cast<int>(n_p);
+  // ---- likelihood-field model
+  if (want_lik)
+  {
+    if (ctx->n_s == 0)
+    {
+      if (!stats)
+        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_lik, 1.0f, d_ratio, 0.0f,
+                           np);
+    }
+    else
+    {
+      const LikParams lp = lik_params(ctx);
+      const int ns = static_cast<int>(ctx->n_s);
+      EventPair ep{};
+      if (stats)
+      {
+        TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
+        hipLaunchKernelGGL((likelihood_kernel<256, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
+                           ctx->scan_lik.as<float4>(), ns, ctx->lg, lp, nullptr, nullptr, ctx->tested.as<double>());
+      }
+      else
+      {
+        TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
+        if (ns <= 128)
+          hipLaunchKernelGGL((likelihood_kernel<64, false>), dim3(np), dim3(64), 0, ctx->stream, d_pose,
+                             ctx->scan_lik.as<float4>(), ns, ctx->lg, lp, d_lik, d_ratio, nullptr);
+        else
+          hipLaunchKernelGGL((likelihood_kernel<256, false>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
+                             ctx->scan_lik.as<float4>(), ns, ctx->lg, lp, d_lik, d_ratio, nullptr);
+        TRY(timing_end(ctx, ep));
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  // ---- beam model
+  if (want_beam)
+  {
+    if (ctx->n_b == 0)
+    {
+      if (!stats)
+        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
+                           static_cast<float*>(nullptr), 0.0f, np);
+    }
+    else
+    {
+      if (ctx->pow_table_dirty)
+      {
+        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float
+        std::vector<float> table(ctx->n_b + 1);
+        table[0] = 1.0f;
+        for (size_t k = 1; k <= ctx->n_b; ++k)
+          table[k] = table[k - 1] * ctx->beam_likelihood;
+        TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
+        TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->pow_table_dirty = false;
+      }
+      const BeamParams bp = beam_params(ctx);
+      const long long n_rays = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_b);
+      const long long blocks = (n_rays + 255) / 256;
+      if (blocks > 0x7fffffffLL)
+        return ctx->fail(-3, "too many rays for one launch");
+      TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+      EventPair ep{};
+      if (!stats)
+        TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep));
+      HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, ctx->stream));
+      if (stats)
+      {
+        TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
+        HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), ctx->stream));
+        hipLaunchKernelGGL((beam_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_pose,
+                           ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), ctx->ray_stats.as<RayStats>());
+      }
+      else
+      {
+        hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
+                           d_pose, ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(),
+                           n_rays, ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr));
+        hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
+                           ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
+                           np);
+        TRY(timing_end(ctx, ep));
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  if (stats)
+  {
+    std::vector<double> tested(ctx->n_s ? n_p : 0);
+    RayStats rs{ 0, 0, 0 };
+    if (ctx->n_s)
+      TRY(d2h(ctx, tested.data(), ctx->tested.p, sizeof(double) * n_p));
+    if (ctx->n_b)
+      TRY(d2h(ctx, &rs, ctx->ray_stats.p, sizeof(RayStats)));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    stats6[0] = std::accumulate(tested.begin(), tested.end(), 0.0);
+    stats6[1] = static_cast<double>(n_p) * static_cast<double>(ctx->n_s);
+    stats6[2] = static_cast<double>(rs.steps);
+    stats6[3] = static_cast<double>(rs.occupied);
+    stats6[4] = static_cast<double>(rs.tested);
+    stats6[5] = static_cast<double>(n_p) * static_cast<double>(ctx->n_b);
+  }
+  return 0;
+}
+
+int pf_blocks(size_t n)
+{
+  const size_t b = (n + PF_BLOCK - 1) / PF_BLOCK;
+  return static_cast<int>(std::min<size_t>(std::max<size_t>(b, 1), 1024));
+}
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C"
+{
+int mcl3dl_hip_abi_version(void)
+{
+  return MCL3DL_HIP_ABI_VERSION;
+}
+
+int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
+{
+  if (!out)
+    return -1;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return -6;  // no GPU: there is deliberately no CPU fallback
+  if (device_id < 0 || device_id >= count)
+    return -6;
+  mcl3dl_hip_ctx* ctx = new mcl3dl_hip_ctx;
+  ctx->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    delete ctx;
+    return -2;
+  }
+  ctx->stream = ctx->own_stream;
+  beam_refresh(ctx);
+  *out = ctx;
+  return 0;
+}
+
+void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf* bufs[] = { &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
+                     &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
+                     &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
+                     &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
+                     &ctx->ray_begin, &ctx->ray_end, &ctx->ray_status, &ctx->ray_hit };
+  for (DevBuf* b : bufs)
+    if (b->p)
+      (void)hipFree(b->p);
+  for (const EventPair& ep : ctx->pending)
+  {
+    (void)hipEventDestroy(ep.start);
+    (void)hipEventDestroy(ep.stop);
+  }
+  for (hipEvent_t e : ctx->free_events)
+    (void)hipEventDestroy(e);
+  if (ctx->own_stream)
+    (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* mcl3dl_hip_last_error(const mcl3dl_hip_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : "null context";
+}
+
+int mcl3dl_hip_set_stream(mcl3dl_hip_ctx* ctx, void* hip_stream)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return 0;
+}
+
+void* mcl3dl_hip_get_stream(mcl3dl_hip_ctx* ctx)
+{
+  return ctx ? static_cast<void*>(ctx->stream) : nullptr;
+}
+
+int mcl3dl_hip_synchronize(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n_m, uint64_t stamp,
+                       const float* dist_weight)
+{
+  if (!ctx)
+    return -1;
+  if (!xyz || n_m == 0)
+    return ctx->fail(-3, "empty map");
+  if (n_m > 0xfffffff0u)
+    return ctx->fail(-3, "map too large (index must fit 32 bits)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->map_xyz.assign(xyz, xyz + 3 * n_m);
+  if (label)
+    ctx->map_label.assign(label, label + n_m);
+  else
+    ctx->map_label.assign(n_m, 0u);
+  ctx->stamp = stamp;
+  ctx->has_weight = dist_weight != nullptr;
+  for (int a = 0; a < 3; ++a)
+    ctx->weight[a] = dist_weight ? dist_weight[a] : 1.0f;
+  ctx->has_map = true;
+  ctx->lik_dirty = true;
+  ctx->dda_dirty = true;
+  return 0;
+}
+
+int mcl3dl_hip_set_likelihood_params(mcl3dl_hip_ctx* ctx, float match_dist_min, float match_dist_flat,
+                                     float match_weight)
+{
+  if (!ctx)
+    return -1;
+  if (!(match_dist_min > 0.f))
+    return ctx->fail(-3, "match_dist_min must be > 0");
+  if (match_dist_min != ctx->match_dist_min)
+    ctx->lik_dirty = true;  // the cell edge follows the search radius
+  ctx->match_dist_min = match_dist_min;
+  ctx->match_dist_flat = match_dist_flat;
+  ctx->match_weight = match_weight;
+  return 0;
+}
+
+int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_grid_y, float map_grid_z,
+                               float dda_grid_size, float ray_angle_half, float hit_range, float beam_likelihood_min,
+                               uint32_t num_points, float ang_total_ref, uint32_t filter_label_max,
+                               int add_penalty_short_only_mode)
+{
+  if (!ctx)
+    return -1;
+  if (!(dda_grid_size > 0.f))
+    return ctx->fail(-3, "dda_grid_size must be > 0");
+  ctx->map_grid[0] = map_grid_x;
+  ctx->map_grid[1] = map_grid_y;
+  ctx->map_grid[2] = map_grid_z;
+  ctx->dda_grid_size = dda_grid_size;
+  ctx->ray_angle_half = ray_angle_half;
+  ctx->hit_range = hit_range;
+  ctx->beam_likelihood_min = beam_likelihood_min;
+  ctx->beam_num_points = num_points;
+  ctx->ang_total_ref = ang_total_ref;
+  ctx->filter_label_max = filter_label_max;
+  ctx->short_only = add_penalty_short_only_mode ? 1 : 0;
+  ctx->dda_dirty = true;  // refreshParameters re-creates the raycaster (beam.cpp:69-79)
+  beam_refresh(ctx);
+  return 0;
+}
+
+int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                           const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o)
+{
+  if (!ctx)
+    return -1;
+  if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
+    return ctx->fail(-3, "null scan array");
+  if (n_s > 0x7fffffffu || n_b > 0x7fffffffu)
+    return ctx->fail(-3, "scan too large");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // likelihood scan: spatial (Morton) order. The score is a sum, so the order only changes which lanes work together.
+  std::vector<float4> lik(n_s);
+  if (n_s)
+  {
+    float mn[3] = { scan_lik_xyz[0], scan_lik_xyz[1], scan_lik_xyz[2] };
+    for (size_t i = 0; i < n_s; ++i)
+      for (int a = 0; a < 3; ++a)
+        mn[a] = std::min(mn[a], scan_lik_xyz[3 * i + a]);
+    std::vector<std::pair<uint64_t, uint32_t>> keys(n_s);
+    for (size_t i = 0; i < n_s; ++i)
+    {
+      uint32_t c[3];
+      for (int a = 0; a < 3; ++a)
+      {
+        const float f = (scan_lik_xyz[3 * i + a] - mn[a]) * 4.0f;
+        c[a] = (f >= 0.f && f < 2097151.f) ? static_cast<uint32_t>(f) : 0u;
+      }
+      keys[i] = { morton3(c[0], c[1], c[2]), static_cast<uint32_t>(i) };
+    }
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < n_s; ++k)
+    {
+      const uint32_t i = keys[k].second;
+      lik[k] = make_float4(scan_lik_xyz[3 * i], scan_lik_xyz[3 * i + 1], scan_lik_xyz[3 * i + 2], 0.f);
+    }
+  }
+  std::vector<float4> beam(n_b);
+  for (size_t i = 0; i < n_b; ++i)
+  {
+    const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
+    if (og >= n_o)
+      return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, og, n_o);
+    beam[i] = make_float4(scan_beam_xyz[3 * i], scan_beam_xyz[3 * i + 1], scan_beam_xyz[3 * i + 2], bits_to_float(og));
+  }
+  std::vector<float4> org(n_o);
+  for (size_t i = 0; i < n_o; ++i)
+    org[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+  TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
+  TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
+  TRY(ensure(ctx, ctx->origins, sizeof(float4) * n_o));
+  TRY(h2d(ctx, ctx->scan_lik.p, lik.data(), sizeof(float4) * n_s));
+  TRY(h2d(ctx, ctx->scan_beam.p, beam.data(), sizeof(float4) * n_b));
+  TRY(h2d(ctx, ctx->origins.p, org.data(), sizeof(float4) * n_o));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staging vectors die at return
+  if (n_b != ctx->n_b)
+    ctx->pow_table_dirty = true;
+  ctx->n_s = n_s;
+  ctx->n_b = n_b;
+  ctx->n_o = n_o;
+  ctx->has_scan = true;
+  return 0;
+}
+
+int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_match_ratio,
+                              float* d_beam)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_measure(ctx, d_pose, n_p, d_lik, d_match_ratio, d_beam, false, nullptr);
+}
+
+int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, double* stats6)
+{
+  if (!ctx || !stats6)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_measure(ctx, d_pose, n_p, nullptr, nullptr, nullptr, true, stats6);
+}
+
+int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, const float* d_lik, const float* d_beam,
+                                 const float* d_extra, const float* d_match_ratio, size_t n_p, double* d_partial4)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad particle count");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int nb = pf_blocks(n_p);
+  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * nb));
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  hipLaunchKernelGGL(pf_partial_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
+                     d_match_ratio, static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
+  hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb,
+                     d_partial4);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, const double* d_total4,
+                               float* d_stats4)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad particle count");
+  HIP_TRY(hipSetDevice(ctx->device));
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight_inout,
+                     ctx->wnew.as<float>(), static_cast<int>(n_p), d_total4, d_stats4);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- host entry points -------------------------------------------------------------------------------------
+int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
+                             const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
+                             const float* origins, size_t n_o, float* out_lik, float* out_match_ratio, float* out_beam)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0)
+    return 0;
+  if (!pose)
+    return ctx->fail(-3, "null pose array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(mcl3dl_hip_upload_scan(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o));
+  TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
+  TRY(ensure(ctx, ctx->lik, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->ratio, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->beam, sizeof(float) * n_p));
+  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  const bool lik_wanted = out_lik || out_match_ratio;
+  TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? ctx->lik.as<float>() : nullptr,
+                     lik_wanted ? ctx->ratio.as<float>() : nullptr, out_beam ? ctx->beam.as<float>() : nullptr, false,
+                     nullptr));
+  if (out_lik)
+    TRY(d2h(ctx, out_lik, ctx->lik.p, sizeof(float) * n_p));
+  if (out_match_ratio)
+    TRY(d2h(ctx, out_match_ratio, ctx->ratio.p, sizeof(float) * n_p));
+  if (out_beam)
+    TRY(d2h(ctx, out_beam, ctx->beam.p, sizeof(float) * n_p));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float* lik, const float* beam,
+                          const float* extra, const float* match_ratio, size_t n_p, float* entropy,
+                          float* match_ratio_min, float* match_ratio_max, int* restored)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0)
+    return ctx->fail(-3, "no particles");
+  if (!weight_inout || !lik)
+    return ctx->fail(-3, "null weight / likelihood array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t fb = sizeof(float) * n_p;
+  TRY(ensure(ctx, ctx->weightb, fb));
+  TRY(ensure(ctx, ctx->lik, fb));
+  TRY(ensure(ctx, ctx->beam, fb));
+  TRY(ensure(ctx, ctx->extra, fb));
+  TRY(ensure(ctx, ctx->ratio, fb));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
+  TRY(h2d(ctx, ctx->weightb.p, weight_inout, fb));
+  TRY(h2d(ctx, ctx->lik.p, lik, fb));
+  if (beam)
+    TRY(h2d(ctx, ctx->beam.p, beam, fb));
+  if (extra)
+    TRY(h2d(ctx, ctx->extra.p, extra, fb));
+  if (match_ratio)
+    TRY(h2d(ctx, ctx->ratio.p, match_ratio, fb));
+  TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(),
+                                   beam ? ctx->beam.as<float>() : nullptr, extra ? ctx->extra.as<float>() : nullptr,
+                                   match_ratio ? ctx->ratio.as<float>() : nullptr, n_p, ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, ctx->partial4.as<double>(),
+                                 ctx->stats4.as<float>()));
+  float st[4];
+  TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
+  TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (entropy)
+    *entropy = st[0];
+  if (match_ratio_min)
+    *match_ratio_min = st[1];
+  if (match_ratio_max)
+    *match_ratio_max = st[2];
+  if (restored)
+    *restored = st[3] != 0.0f;
+  return 0;
+}
+
+int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout,
+                              size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                              const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                              float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
+                              float* match_ratio_min, float* match_ratio_max, int* restored)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0)
+    return ctx->fail(-3, "no particles");
+  if (!pose || !weight_inout)
+    return ctx->fail(-3, "null pose / weight array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t fb = sizeof(float) * n_p;
+  TRY(mcl3dl_hip_upload_scan(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o));
+  TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
+  TRY(ensure(ctx, ctx->weightb, fb));
+  TRY(ensure(ctx, ctx->lik, fb));
+  TRY(ensure(ctx, ctx->ratio, fb));
+  TRY(ensure(ctx, ctx->beam, fb));
+  TRY(ensure(ctx, ctx->extra, fb));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
+  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  TRY(h2d(ctx, ctx->weightb.p, weight_inout, fb));
+  if (extra)
+    TRY(h2d(ctx, ctx->extra.p, extra, fb));
+  TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, ctx->lik.as<float>(), ctx->ratio.as<float>(),
+                     ctx->beam.as<float>(), false, nullptr));
+  TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
+                                   extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p,
+                                   ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, ctx->partial4.as<double>(),
+                                 ctx->stats4.as<float>()));
+  float st[4];
+  TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
+  TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));
+  if (out_lik)
+    TRY(d2h(ctx, out_lik, ctx->lik.p, fb));
+  if (out_match_ratio)
+    TRY(d2h(ctx, out_match_ratio, ctx->ratio.p, fb));
+  if (out_beam)
+    TRY(d2h(ctx, out_beam, ctx->beam.p, fb));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (entropy)
+    *entropy = st[0];
+  if (match_ratio_min)
+    *match_ratio_min = st[1];
+  if (match_ratio_max)
+    *match_ratio_max = st[2];
+  if (restored)
+    *restored = st[3] != 0.0f;
+  return 0;
+}
+
+int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz, const float* end_xyz, size_t n, int32_t* status,
+                           int32_t* hit_index)
+{
+  if (!ctx)
+    return -1;
+  if (n == 0)
+    return 0;
+  if (!begin_xyz || !end_xyz || !status)
+    return ctx->fail(-3, "null ray array");
+  if (n > 0x7fffffffu)
+    return ctx->fail(-3, "too many rays");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure_structures(ctx, false, true));
+  TRY(ensure(ctx, ctx->ray_begin, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->ray_end, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->ray_status, sizeof(int) * n));
+  TRY(ensure(ctx, ctx->ray_hit, sizeof(int) * n));
+  TRY(h2d(ctx, ctx->ray_begin.p, begin_xyz, sizeof(float) * 3 * n));
+  TRY(h2d(ctx, ctx->ray_end.p, end_xyz, sizeof(float) * 3 * n));
+  const int ni = static_cast<int>(n);
+  hipLaunchKernelGGL(beam_status_kernel, dim3((ni + 63) / 64), dim3(64), 0, ctx->stream, ctx->ray_begin.as<float>(),
+                     ctx->ray_end.as<float>(), ni, ctx->dg, beam_params(ctx), ctx->ray_status.as<int>(),
+                     ctx->ray_hit.as<int>());
+  HIP_TRY(hipGetLastError());
+  TRY(d2h(ctx, status, ctx->ray_status.p, sizeof(int) * n));
+  if (hit_index)
+    TRY(d2h(ctx, hit_index, ctx->ray_hit.p, sizeof(int) * n));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- measurement support ---------------------------------------------------------------------------------------
+int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable)
+{
+  if (!ctx)
+    return -1;
+  TRY(timing_collect(ctx));
+  ctx->timing = enable != 0;
+  return 0;
+}
+
+int mcl3dl_hip_get_kernel_time(mcl3dl_hip_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches)
+{
+  if (!ctx)
+    return -1;
+  if (kernel_id < 0 || kernel_id >= MCL3DL_KERNEL_COUNT)
+    return ctx->fail(-3, "bad kernel id");
+  TRY(timing_collect(ctx));
+  if (total_ms)
+    *total_ms = ctx->kernel_ms[kernel_id];
+  if (launches)
+    *launches = ctx->kernel_launches[kernel_id];
+  return 0;
+}
+
+int mcl3dl_hip_reset_kernel_time(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return -1;
+  TRY(timing_collect(ctx));
+  for (int k = 0; k < MCL3DL_KERNEL_COUNT; ++k)
+  {
+    ctx->kernel_ms[k] = 0;
+    ctx->kernel_launches[k] = 0;
+  }
+  return 0;
+}
+
+int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes5)
+{
+  if (!ctx || !bytes5)
+    return -1;
+  for (int i = 0; i < 5; ++i)
+    bytes5[i] = ctx->footprint[i];
+  return 0;
+}
+}  // extern "C"

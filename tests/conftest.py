@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+
+
+@pytest.fixture(scope="session")
+def oracle_kind():
+    """Prefer the real reference (oracle/_ref) when it has been built; the plain-C port otherwise."""
+    from oracle import pyoracle
+    if pyoracle.available("ref"):
+        return "ref"
+    if pyoracle.available("port"):
+        return "port"
+    pytest.fail("no oracle library built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP engine on cuda:0. Fails loudly (never skips, never falls back) when the extension or GPU is missing."""
+    from mcl_3dl_amd import capi
+    eng = capi.Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,211 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP engine, called through the C ABI, against the CPU oracle
+on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star: "weights within 1e-5 relative of the CPU path"):
+  * likelihood score      rtol 1e-5 vs the reference-order float oracle (the GPU sums the same bit-identical float
+                          terms in fp64, so the only difference is the reference's own float-summation rounding)
+  * match ratio (quality) exact (integer count / N_s)
+  * beam score            exact (integer penalty count -> float product table)
+  * beam status / hit id  exact
+  * normalised weights, entropy  rtol 1e-5
+"""
+import numpy as np
+import pytest
+
+from mcl_3dl_amd.synthetic import make_scene
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def make_oracle(kind, sc, dist_weight, beam_kw=None, lik_kw=None):
+    o = pyoracle.Oracle(kind)
+    o.set_map(sc.map_xyz, sc.map_label, dist_weight=dist_weight)
+    o.set_likelihood_params(pyoracle.LikelihoodParams(**(lik_kw or {})))
+    o.set_beam_params(pyoracle.BeamParams(**(beam_kw or {})))
+    return o
+
+
+def setup_engine(eng, sc, dist_weight, stamp, beam_kw=None, lik_kw=None):
+    eng.set_map(sc.map_xyz, sc.map_label, stamp=stamp, dist_weight=dist_weight)
+    eng.set_likelihood_params(**(lik_kw or {}))
+    kw = dict(beam_kw or {})
+    eng.set_beam_params(**kw)
+
+
+@pytest.fixture(scope="module")
+def scene_c1():
+    return make_scene(n=91, n_p=64, n_s=1000, n_b=96)
+
+
+@pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0), None])
+def test_likelihood_c1(engine, oracle_kind, scene_c1, dist_weight):
+    """BASELINE config C1 (64 particles x 1k points, 50k-pt cube map), unit and default (1,1,5) dist_weight."""
+    sc = scene_c1
+    setup_engine(engine, sc, dist_weight, stamp=11)
+    lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    o = make_oracle(oracle_kind, sc, dist_weight)
+    want_lik, want_q = o.likelihood_measure(sc.poses, sc.scan_lik)
+    assert np.all(want_lik > 0)
+    np.testing.assert_allclose(lik, want_lik, rtol=RTOL)
+    np.testing.assert_array_equal(ratio, want_q)
+
+
+@pytest.mark.parametrize("short_only", [True, False])
+@pytest.mark.parametrize("n_b", [3, 96])
+def test_beam_c1(engine, oracle_kind, scene_c1, short_only, n_b):
+    sc = scene_c1
+    kw = dict(num_points=n_b, add_penalty_short_only_mode=short_only)
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=12, beam_kw=kw)
+    sb, sl = sc.scan_beam[:n_b], sc.scan_beam_label[:n_b]
+    _, _, beam = engine.measure_batch(sc.poses, None, sb, sl, sc.origins)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=kw)
+    want, want_q = o.beam_measure(sc.poses, sb, sl, sc.origins)
+    np.testing.assert_array_equal(beam, want)
+    assert np.all(want_q == 1.0)
+    assert len(np.unique(want)) > 1  # the case must exercise different penalty counts
+
+
+def test_beam_status_random_rays(engine, oracle_kind, scene_c1):
+    """getBeamStatus for explicit rays: status and collided map point identical to the reference."""
+    sc = scene_c1
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=13, beam_kw=dict(num_points=8))
+    rng = np.random.default_rng(7)
+    half = 91 * 0.1 / 2
+    begin = rng.uniform(-half * 1.1, half * 1.1, (4000, 3)).astype(np.float32)
+    end = (begin + rng.normal(0, 2.0, (4000, 3))).astype(np.float32)
+    st, hit = engine.beam_status(begin, end)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=dict(num_points=8))
+    want_st, want_hit = o.beam_status(begin, end)
+    np.testing.assert_array_equal(st, want_st)
+    np.testing.assert_array_equal(hit, want_hit)
+    assert set(np.unique(want_st)) >= {0, 1, 2}
+
+
+def test_beam_label_filter(engine, oracle_kind):
+    """Hits on map points with label > filter_label_max are ignored and the ray continues (beam.cpp:168-169)."""
+    sc = make_scene(n=61, n_p=32, n_s=64, n_b=64, label_wall=2)
+    kw = dict(num_points=64, filter_label_max=1)
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=14, beam_kw=kw)
+    _, _, beam = engine.measure_batch(sc.poses, None, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=kw)
+    want, _ = o.beam_measure(sc.poses, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    np.testing.assert_array_equal(beam, want)
+    kw2 = dict(num_points=64)
+    o2 = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=kw2)
+    unfiltered, _ = o2.beam_measure(sc.poses, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    assert not np.array_equal(unfiltered, want)  # the filter changes the answer in this scene
+
+
+def test_measure_update_c1(engine, oracle_kind, scene_c1):
+    """The whole `pf_->measure(measure_func)` statement (src/mcl_3dl.cpp:398-426): beam x likelihood x odom factor,
+    normalisation, entropy, match-ratio min/max."""
+    sc = scene_c1
+    dw = (1.0, 1.0, 5.0)
+    kw = dict(num_points=96)
+    setup_engine(engine, sc, dw, stamp=15, beam_kw=kw)
+    sigma = 1.0
+    # NormalLikelihood<float>(sigma)(|odom_err|), include/mcl_3dl/nd.h:41-58, computed by the caller
+    a = np.float32(1.0 / np.sqrt(2.0 * np.pi * sigma * sigma))
+    sq2 = np.float32(sigma * sigma * 2.0)
+    x = np.sqrt((sc.odom_err[:, 0] * sc.odom_err[:, 0] + sc.odom_err[:, 1] * sc.odom_err[:, 1])
+                + sc.odom_err[:, 2] * sc.odom_err[:, 2]).astype(np.float32)
+    extra = (a * np.exp((-x * x / sq2).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    w0 = rng.uniform(0.5, 1.5, len(sc.poses)).astype(np.float32)
+    w0 /= w0.sum()
+    got = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+    o = make_oracle(oracle_kind, sc, dw, beam_kw=kw)
+    want = o.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
+                            odom_err=sc.odom_err, odom_sigma=sigma)
+    np.testing.assert_allclose(got["lik"], want["lik"], rtol=RTOL)
+    np.testing.assert_array_equal(got["beam"], want["beam"])
+    np.testing.assert_array_equal(got["quality"], want["quality"])
+    np.testing.assert_allclose(got["weights"], want["weights"], rtol=RTOL)
+    np.testing.assert_allclose(got["entropy"], want["entropy"], rtol=RTOL)
+    assert got["match_ratio_min"] == want["match_ratio_min"]
+    assert got["match_ratio_max"] == want["match_ratio_max"]
+    assert got["restored"] == want["restored"] is False
+    np.testing.assert_allclose(got["weights"].sum(dtype=np.float64), 1.0, rtol=1e-6)
+
+
+def test_empty_scans(engine, oracle_kind, scene_c1):
+    """Null/empty cloud -> (likelihood 1, quality 0) for both models (likelihood.cpp:111-114, beam.cpp:130-133)."""
+    sc = scene_c1
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=16)
+    lik, ratio, beam = engine.measure_batch(sc.poses, np.zeros((0, 3), np.float32))
+    assert np.all(lik == 1.0) and np.all(ratio == 0.0) and np.all(beam == 1.0)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0))
+    wl, wq = o.likelihood_measure(sc.poses, np.zeros((0, 3), np.float32))
+    np.testing.assert_array_equal(lik, wl)
+    np.testing.assert_array_equal(ratio, wq)
+
+
+def test_far_away_particles_restore(engine, oracle_kind, scene_c1):
+    """Particles far outside the map score 0; if every particle scores 0 the weights are restored (pf.h:274-278)."""
+    sc = scene_c1
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=17)
+    poses = sc.poses.copy()
+    poses[:, :3] += 500.0
+    got = engine.measure_update(poses, sc.weights, sc.scan_lik)
+    assert np.all(got["lik"] == 0.0) and np.all(got["quality"] == 0.0)
+    assert got["restored"] is True
+    np.testing.assert_array_equal(got["weights"], sc.weights)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0))
+    want = o.measure_update(poses, sc.weights, sc.scan_lik, np.zeros((0, 3), np.float32), None, sc.origins)
+    assert want["restored"] is True
+    np.testing.assert_array_equal(got["weights"], want["weights"])
+    # mixed: half the particles far away -> their weights become exactly 0, the rest normalise
+    poses2 = sc.poses.copy()
+    poses2[::2, :3] += 500.0
+    got2 = engine.measure_update(poses2, sc.weights, sc.scan_lik)
+    want2 = o.measure_update(poses2, sc.weights, sc.scan_lik, np.zeros((0, 3), np.float32), None, sc.origins)
+    assert np.all(got2["weights"][::2] == 0.0)
+    np.testing.assert_allclose(got2["weights"], want2["weights"], rtol=RTOL)
+    assert got2["match_ratio_min"] == want2["match_ratio_min"] == 0.0
+
+
+def test_unnormalised_quaternions(engine, oracle_kind, scene_c1):
+    """transform() normalises rot_ (state_6dof.h:217) but the beam origin uses the raw rot_ (beam.cpp:145)."""
+    sc = scene_c1
+    kw = dict(num_points=96)
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=18, beam_kw=kw)
+    poses = sc.poses.copy()
+    poses[:, 3:] *= np.linspace(0.7, 1.4, len(poses), dtype=np.float32)[:, None]
+    lik, ratio, beam = engine.measure_batch(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=kw)
+    wl, wq = o.likelihood_measure(poses, sc.scan_lik)
+    wb, _ = o.beam_measure(poses, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    np.testing.assert_allclose(lik, wl, rtol=RTOL)
+    np.testing.assert_array_equal(ratio, wq)
+    np.testing.assert_array_equal(beam, wb)
+
+
+def test_ragged_sizes(engine, oracle_kind, scene_c1):
+    """Scan sizes that are not multiples of the work-group / wavefront size, single particle, single point."""
+    sc = scene_c1
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=19, beam_kw=dict(num_points=5))
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=dict(num_points=5))
+    for n_p, n_s, n_b in [(1, 1, 1), (3, 63, 2), (7, 129, 5), (64, 257, 5), (5, 999, 0)]:
+        lik, ratio, beam = engine.measure_batch(sc.poses[:n_p], sc.scan_lik[:n_s], sc.scan_beam[:n_b],
+                                                sc.scan_beam_label[:n_b], sc.origins)
+        wl, wq = o.likelihood_measure(sc.poses[:n_p], sc.scan_lik[:n_s])
+        wb, _ = o.beam_measure(sc.poses[:n_p], sc.scan_beam[:n_b], sc.scan_beam_label[:n_b], sc.origins)
+        np.testing.assert_allclose(lik, wl, rtol=RTOL)
+        np.testing.assert_array_equal(ratio, wq)
+        np.testing.assert_array_equal(beam, wb)
+
+
+def test_likelihood_params_change(engine, oracle_kind, scene_c1):
+    """refreshParameters(): a different search radius rebuilds the cell index."""
+    sc = scene_c1
+    lk = dict(match_dist_min=0.35, match_dist_flat=0.1, match_weight=2.5)
+    setup_engine(engine, sc, (1.0, 1.0, 2.0), stamp=20, lik_kw=lk)
+    lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 2.0), lik_kw=lk)
+    wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
+    np.testing.assert_allclose(lik, wl, rtol=RTOL)
+    np.testing.assert_array_equal(ratio, wq)
+    engine.set_likelihood_params()  # back to the defaults for later tests
