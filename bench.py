@@ -71,6 +71,7 @@ def main():
     import torch
     import torch.distributed as dist
     from mcl_3dl_amd import capi
+    from mcl_3dl_amd.distributed import allreduce_partials
     from mcl_3dl_amd.synthetic import CONFIGS, make_config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,13 +124,7 @@ def main():
         eng.measure_device(d_pose, n_p, d_lik, d_ratio, d_beam if n_b else None)
         eng.pf_partial_device(d_w, d_lik, d_beam if n_b else None, None, d_ratio, n_p, d_partial)
         if world > 1:
-            d_pack.zero_()
-            d_pack[0:2] = d_partial[0:2]
-            d_pack[2 + 2 * rank:4 + 2 * rank] = d_partial[2:4]
-            dist.all_reduce(d_pack, op=dist.ReduceOp.SUM)
-            d_total[0:2] = d_pack[0:2]
-            d_total[2] = d_pack[2::2].max()
-            d_total[3] = d_pack[3::2].max()
+            allreduce_partials(d_partial, scratch=d_pack, out=d_total)  # the update's single collective (RCCL)
             eng.pf_apply_device(d_w, n_p, d_total, d_stats)
         else:
             eng.pf_apply_device(d_w, n_p, d_partial, d_stats)

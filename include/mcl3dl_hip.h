@@ -116,6 +116,14 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, 
 int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz /*n*3*/, const float* end_xyz /*n*3*/,
                            size_t n, int32_t* status /*n*/, int32_t* hit_index /*n or NULL*/);
 
+/* Replaces: driving one RaycastUsingDDA by hand — setRay + getNextCastResult until the first collision
+ * (include/mcl_3dl/raycast.h:45-77, include/mcl_3dl/raycasts/raycast_using_dda.h:66-159), the way the reference's
+ * waypoint tests do (test/src/test_raycast_dda.cpp:157-183). Uses the caster of mcl3dl_hip_set_beam_params
+ * (hit_range = hit_tolerance). out_xyz receives up to max_out voxel centres (CastResult::pos_); *n_visited may exceed
+ * max_out. Introspection only: not on the per-update path. */
+int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* end3, float* out_xyz /*max_out*3*/,
+                         int max_out, int* n_visited, int* collided, int* hit_index);
+
 /* ---- device entry points (asynchronous on the context's stream) ------------------------------------- */
 /* Upload (and spatially order) the two filtered scans `pc_locals` of one update (src/mcl_3dl.cpp:377-383). */
 int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mcl3dl_hip_pf_measure": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
+    "mcl3dl_hip_dda_trace": (_i, [_p, _p, _p, _p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
     "mcl3dl_hip_measure_device": (_i, [_p, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -194,6 +195,15 @@ class Engine:
         hit = np.zeros(len(b), np.int32)
         self._check(self.lib.mcl3dl_hip_beam_status(self.h, _ptr(b), _ptr(e), len(b), _ptr(st), _ptr(hit)))
         return st, hit
+
+    def dda_trace(self, begin, end, max_out=4096):
+        b = _np_f32(begin)
+        e = _np_f32(end)
+        out = np.zeros((max_out, 3), np.float32)
+        n, col, hit = C.c_int(0), C.c_int(0), C.c_int(-1)
+        self._check(self.lib.mcl3dl_hip_dda_trace(self.h, _ptr(b), _ptr(e), _ptr(out), max_out, C.byref(n),
+                                                  C.byref(col), C.byref(hit)))
+        return out[:min(n.value, max_out)].copy(), bool(col.value), int(hit.value), int(n.value)
 
     # ---- device entry points (torch CUDA tensors or raw device addresses) ---------------------------------------
     def upload_scan(self, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):

@@ -218,9 +218,21 @@ struct RayStats
 
 // Casts one ray; returns BeamStatus (0 SHORT, 1 HIT, 2 LONG, 3 TOTAL_REFLECTION). *hit = original map index of the
 // collided point (-1 if the ray was exhausted).
-template <bool STATS>
+//
+// TRACE = true is the introspection variant behind mcl3dl_hip_dda_trace: the very same walk, but every visited voxel
+// centre (fromIndex, raycast_using_dda.h:219-223) is recorded and the walk stops at the first collision regardless of
+// label, exactly like the reference's waypoint test harness (test/src/test_raycast_dda.cpp:157-183).
+struct RayTrace
+{
+  float* xyz;     // [max * 3]
+  int max;
+  int n;          // voxels visited (may exceed max; only the first max are stored)
+  int collided;   // 1 if the walk ended on a collision
+};
+
+template <bool STATS, bool TRACE = false>
 __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
-                               unsigned& st_steps, unsigned& st_occ, unsigned& st_tested)
+                               unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
 {
   *hit = -1;
   // isPointWithinMap, raycast_using_dda.h:260-270  -> max_movement_ = 0 -> getNextCastResult false -> LONG
@@ -294,6 +306,16 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
       break;
     if (STATS)
       ++st_steps;
+    if (TRACE)
+    {
+      if (tr->n < tr->max)
+      {
+        tr->xyz[3 * tr->n + 0] = static_cast<float>((cx + 0.5) * g.grid + g.min_x);
+        tr->xyz[3 * tr->n + 1] = static_cast<float>((cy + 0.5) * g.grid + g.min_y);
+        tr->xyz[3 * tr->n + 2] = static_cast<float>((cz + 0.5) * g.grid + g.min_z);
+      }
+      ++tr->n;
+    }
     // hasIntersection, :237-258
     const long long v = cx + static_cast<long long>(cy) * g.nx + static_cast<long long>(cz) * plane;
     const uint32_t word = g.bits[v >> 5];
@@ -324,6 +346,12 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
     }
     if (collided < 0)
       continue;
+    if (TRACE)
+    {
+      tr->collided = 1;
+      *hit = static_cast<int>(g.pt_index[collided]);
+      return 0;
+    }
     // getBeamStatus, beam.cpp:164-187
     if (__float_as_uint(cp.w) > bp.filter_label_max)
       continue;
@@ -403,6 +431,21 @@ __global__ void beam_status_kernel(const float* __restrict__ begin_xyz, const fl
   status[i] = s;
   if (hit_index)
     hit_index[i] = (s == 2) ? -1 : hit;
+}
+
+// One ray, one lane: the waypoint introspection used by the known-answer tests.
+__global__ void dda_trace_kernel(Vec3f begin, Vec3f end, DdaGrid g, BeamParams bp, float* __restrict__ out_xyz,
+                                 int max_out, int* __restrict__ out3 /* n, collided, hit index */)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  RayTrace tr = { out_xyz, max_out, 0, 0 };
+  unsigned a = 0, b = 0, c = 0;
+  int hit;
+  cast_ray<false, true>(g, bp, begin, end, &hit, a, b, c, &tr);
+  out3[0] = tr.n;
+  out3[1] = tr.collided;
+  out3[2] = tr.collided ? hit : -1;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1016,6 +1016,39 @@ int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz, const fl
   return 0;
 }
 
+int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* end3, float* out_xyz, int max_out,
+                         int* n_visited, int* collided, int* hit_index)
+{
+  if (!ctx)
+    return -1;
+  if (!begin3 || !end3 || max_out < 0 || (max_out > 0 && !out_xyz))
+    return ctx->fail(-3, "bad trace arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure_structures(ctx, false, true));
+  TRY(ensure(ctx, ctx->ray_begin, sizeof(float) * 3 * static_cast<size_t>(max_out)));
+  TRY(ensure(ctx, ctx->ray_status, sizeof(int) * 3));
+  hipLaunchKernelGGL(dda_trace_kernel, dim3(1), dim3(64), 0, ctx->stream, Vec3f{ begin3[0], begin3[1], begin3[2] },
+                     Vec3f{ end3[0], end3[1], end3[2] }, ctx->dg, beam_params(ctx), ctx->ray_begin.as<float>(), max_out,
+                     ctx->ray_status.as<int>());
+  HIP_TRY(hipGetLastError());
+  int out3[3] = { 0, 0, -1 };
+  TRY(d2h(ctx, out3, ctx->ray_status.p, sizeof(out3)));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int n_copy = std::min(out3[0], max_out);
+  if (n_copy > 0)
+  {
+    TRY(d2h(ctx, out_xyz, ctx->ray_begin.p, sizeof(float) * 3 * static_cast<size_t>(n_copy)));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (n_visited)
+    *n_visited = out3[0];
+  if (collided)
+    *collided = out3[1];
+  if (hit_index)
+    *hit_index = out3[2];
+  return 0;
+}
+
 // ---- measurement support ---------------------------------------------------------------------------------------
 int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable)
 {

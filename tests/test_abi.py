@@ -1,0 +1,60 @@
+"""CPU tests: the C-ABI shared library loads and exports every symbol include/mcl3dl_hip.h declares, the ctypes binding
+covers all of them, and nothing falls back to a CPU path when no GPU is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mcl3dl_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcl3dl_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for must in ("mcl3dl_hip_create", "mcl3dl_hip_set_map", "mcl3dl_hip_measure_batch", "mcl3dl_hip_pf_measure",
+                 "mcl3dl_hip_measure_update", "mcl3dl_hip_beam_status", "mcl3dl_hip_measure_device"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from mcl_3dl_amd import capi
+    assert os.path.exists(capi.LIB_PATH), "libmcl3dl_hip.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), "missing export: " + name
+
+
+def test_binding_covers_every_declared_symbol():
+    from mcl_3dl_amd import capi
+    assert sorted(capi.SIGNATURES) == declared_symbols()
+    lib = capi.load_library()
+    assert lib.mcl3dl_hip_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU, creating an engine must raise — never silently compute on the CPU."""
+    import torch
+    from mcl_3dl_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the failure path is exercised on CPU-only boxes")
+    with pytest.raises(capi.EngineError):
+        capi.Engine(0)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "mcl_3dl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "pyoracle" not in text.replace("never imports anything from oracle/", ""), f
+                assert "libmcl3dl_oracle" not in text and "libmcl3dl_ref" not in text, f

@@ -1,0 +1,100 @@
+"""CPU test of the N > 1 path: two gloo ranks each own a particle shard, compute their partials, run the single
+all-reduce of mcl_3dl_amd.distributed and normalise their shard; the stitched result must equal pf::measure over the
+whole particle set (checked against the oracle's pf_measure, which is the reference's code when oracle/_ref is built).
+The per-shard arithmetic below is the same arithmetic the pf_partial / pf_apply kernels perform."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mcl_3dl_amd.distributed import allreduce_partials, pack_partials, shard_bounds, unpack_totals
+from oracle import pyoracle
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partials(w, lik, ratio):
+    wn = (w * lik).astype(np.float32)
+    pos = wn > 0
+    t = np.sum(wn[pos].astype(np.float64) * np.log(wn[pos].astype(np.float64)))
+    return wn, np.array([wn.sum(dtype=np.float64), t, max(0.0, ratio.max(initial=0.0)),
+                         max(-1.0, (-ratio).max(initial=-1.0))], np.float64)
+
+
+def _worker(rank, world, port, w, lik, ratio, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(len(w), world, rank)
+    wn, part = _partials(w[lo:hi], lik[lo:hi], ratio[lo:hi])
+    total = allreduce_partials(torch.from_numpy(part)).numpy()
+    S = np.float32(total[0])
+    w_out = (wn / S).astype(np.float32) if S > 0 else w[lo:hi]
+    entropy = np.float32(np.log(total[0]) - total[1] / total[0]) if S > 0 else np.float32("nan")
+    np.savez(out_path % rank, w=w_out, entropy=entropy, rmax=total[2], rmin=-total[3], lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    for n in (1, 7, 64, 4096, 262144, 65537):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(n, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    world = 4
+    parts = [torch.tensor([1.0 + r, -0.5 * r, 0.1 * r, -1.0 + 0.2 * r], dtype=torch.float64) for r in range(world)]
+    packed = sum(pack_partials(p, r, world) for r, p in enumerate(parts))
+    total = unpack_totals(packed)
+    assert total[0] == sum(p[0] for p in parts) and total[1] == sum(p[1] for p in parts)
+    assert total[2] == max(p[2] for p in parts) and total[3] == max(p[3] for p in parts)
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_rank_update_matches_single_process(tmp_path, world):
+    rng = np.random.default_rng(42)
+    n = 1001  # not divisible by the world size
+    w = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    w /= w.sum()
+    lik = rng.uniform(0.0, 900.0, n).astype(np.float32)
+    lik[rng.integers(0, n, 50)] = 0.0  # dead particles
+    ratio = rng.uniform(0.1, 0.95, n).astype(np.float32)
+    out_path = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, lik, ratio, out_path), nprocs=world, join=True)
+    parts = [np.load(out_path % r) for r in range(world)]
+    w_got = np.concatenate([p["w"] for p in parts])
+    kind = "ref" if pyoracle.available("ref") else "port"
+    w_want, ent_want, restored = pyoracle.Oracle(kind).pf_measure(w, lik)
+    assert not restored
+    np.testing.assert_allclose(w_got, w_want, rtol=1e-5)
+    for p in parts:  # every rank derived the same global statistics
+        np.testing.assert_allclose(p["entropy"], ent_want, rtol=1e-5)
+        assert np.float32(p["rmax"]) == ratio.max() and np.float32(p["rmin"]) == ratio.min()
+
+
+def test_all_dead_restores_on_every_rank(tmp_path):
+    n = 64
+    w = np.full(n, 1.0 / n, np.float32)
+    lik = np.zeros(n, np.float32)
+    ratio = np.zeros(n, np.float32)
+    out_path = str(tmp_path / "dead%d.npz")
+    mp.spawn(_worker, args=(2, _free_port(), w, lik, ratio, out_path), nprocs=2, join=True)
+    for r in range(2):
+        p = np.load(out_path % r)
+        np.testing.assert_array_equal(p["w"], w[p["lo"]:p["hi"]])
+        assert np.isnan(p["entropy"])
