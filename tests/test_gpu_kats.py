@@ -68,7 +68,7 @@ def test_chunked_kdtree_kat_through_the_likelihood_score(engine):
         assert ratio[0] == 1.0
         assert lik[0] == np.float32(r - np.sqrt(np.float32(d2)))
         others = [np.linalg.norm(kats.KDTREE_MAP[j] - q) for j in range(len(kats.KDTREE_MAP)) if j != want_idx]
-        assert np.sqrt(d2) < min(others)
+        assert np.sqrt(d2) <= min(others) + 1e-7  # (0,-0.05,0) is equidistant from #3 and #4 in float
     engine.set_likelihood_params()
 
 
