@@ -1,0 +1,106 @@
+// mcl_3dl_hip/engine.hpp — C++ host layer over the C ABI (include/mcl3dl_hip.h) shared by the two drop-in LiDAR
+// model classes.  Header-only except for the context singleton in src/engine.cpp.
+//
+//  * Engine            RAII handle on one mcl3dl_hip_ctx; C-ABI errors become std::runtime_error (the reference's
+//                      models only ever throw std::runtime_error, chunked_kdtree.h:224-225).
+//  * BatchDescriptor   what the batch-aware pf::ParticleFilter::measure publishes before running the reference's
+//                      per-particle loop (include/mcl_3dl/pf.h:252-260), so a model's per-particle measure() can
+//                      evaluate ALL particles on the GPU at the first call and answer the rest from the result buffer.
+#ifndef MCL_3DL_HIP_ENGINE_HPP
+#define MCL_3DL_HIP_ENGINE_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <mcl3dl_hip.h>
+
+namespace mcl_3dl
+{
+namespace hip
+{
+class Engine
+{
+public:
+  explicit Engine(int device_id = 0)
+  {
+    const int rc = mcl3dl_hip_create(&ctx_, device_id);
+    if (rc != 0 || !ctx_)
+      throw std::runtime_error("mcl3dl_hip_create failed (" + std::to_string(rc) +
+                               "): no usable gfx950 device; this engine has no CPU fallback");
+  }
+  ~Engine()
+  {
+    mcl3dl_hip_destroy(ctx_);
+  }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  mcl3dl_hip_ctx* get() const
+  {
+    return ctx_;
+  }
+  void check(const int rc) const
+  {
+    if (rc != 0)
+      throw std::runtime_error(std::string("mcl3dl_hip: ") + mcl3dl_hip_last_error(ctx_));
+  }
+
+  // process-wide context used by the drop-in model classes (the node builds one likelihood and one beam model that
+  // share the map: src/mcl_3dl.cpp:1315-1318)
+  static Engine& shared();
+
+  // ---- map bookkeeping shared by both models: upload when the cloud or its stamp changes ------------------------
+  const void* map_cloud = nullptr;
+  std::uint64_t map_stamp = 0;
+  std::size_t map_size = 0;
+  float dist_weight[3] = { 1.f, 1.f, 1.f };
+  bool has_weight = false;
+
+private:
+  mcl3dl_hip_ctx* ctx_ = nullptr;
+};
+
+// Published by pf::ParticleFilter::measure (mcl_3dl/pf.h in this directory tree) for the duration of one update.
+struct BatchDescriptor
+{
+  const void* first_state = nullptr;  // &particles_[0].state_
+  std::size_t stride = 0;             // sizeof(Particle<State6DOF, float>)
+  std::size_t count = 0;
+  std::uint64_t epoch = 0;  // changes every measure() call: invalidates the models' result caches
+};
+
+inline BatchDescriptor& currentBatch()
+{
+  static thread_local BatchDescriptor d;
+  return d;
+}
+
+class BatchScope
+{
+public:
+  BatchScope(const void* first_state, const std::size_t stride, const std::size_t count)
+  {
+    static thread_local std::uint64_t counter = 0;
+    BatchDescriptor& d = currentBatch();
+    saved_ = d;
+    d.first_state = first_state;
+    d.stride = stride;
+    d.count = count;
+    d.epoch = ++counter;
+  }
+  ~BatchScope()
+  {
+    currentBatch() = saved_;
+  }
+
+private:
+  BatchDescriptor saved_;
+};
+}  // namespace hip
+}  // namespace mcl_3dl
+
+#endif  // MCL_3DL_HIP_ENGINE_HPP
