@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--workload", default="C2", help="C1..C5 of BASELINE.json (default C2: 4096 x 16k, 1M-pt map)")
     ap.add_argument("--particles", type=int, default=0, help="override particles per GPU")
     ap.add_argument("--dist-weight-z", type=float, default=1.0)
+    ap.add_argument("--lik-index", type=int, default=1, help="1 = candidate-voxel index (default), 0 = 27-cell scan")
+    ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
+    ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=1024, help="particles in the CPU-baseline sample")
     return ap.parse_args()
@@ -104,6 +107,9 @@ def main():
     t0 = time.time()
     eng.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=dist_weight)
     eng.set_likelihood_params()
+    eng.set_option("lik_index", args.lik_index)
+    eng.set_option("cand_voxel_ratio", args.cand_voxel_ratio)
+    eng.set_option("cand_phase", args.cand_phase)
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
@@ -200,7 +206,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "likelihood_kernel<256>",
+                "kernel": "likelihood_kernel<256,%d>" % args.lik_index,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -217,6 +223,8 @@ def main():
             "kernels_ms_per_step": {"likelihood": lik_avg_ms, "beam": beam_ms / max(beam_n, 1) if n_b else 0.0,
                                     "pf": 2.0 * pf_ms / max(pf_n, 1)},
             "setup_seconds": setup_s,
+            "index": dict(eng.index_stats(), lik_index=args.lik_index, voxel_ratio=args.cand_voxel_ratio,
+                          footprint_bytes=eng.memory_footprint()),
             "result_check": {"entropy": float(stats[0]), "match_ratio_min": float(stats[1]),
                              "match_ratio_max": float(stats[2]), "restored": bool(stats[3])},
         }

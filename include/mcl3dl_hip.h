@@ -151,9 +151,18 @@ int mcl3dl_hip_reset_kernel_time(mcl3dl_hip_ctx* ctx);
  * stats[0] = sum over (particle, point) of K = map points in the 27-cell neighbourhood, [1] = evaluations,
  * [2] = DDA voxel steps, [3] = occupied voxels visited, [4] = map points tested, [5] = rays. */
 int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, double* stats6);
-/* Sizes of the device-resident structures (bytes): [0] likelihood points, [1] likelihood cell index,
- * [2] DDA occupancy bitmap, [3] DDA voxel index, [4] DDA points. */
-int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes5);
+/* Sizes of the device-resident structures (bytes): [0] cell-grid points, [1] cell-grid index, [2] DDA occupancy bitmap,
+ * [3] DDA voxel index, [4] DDA points, [5] candidate-voxel brick table, [6] candidate-voxel run delimiters,
+ * [7] candidate points. Structures that were never needed are 0. */
+int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
+/* Tuning knobs (no reference counterpart; results are identical for every setting):
+ *   "lik_index"         1 (default) = candidate-voxel index, 0 = 27-cell scan of the cell-sorted map
+ *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min (default 0.5)
+ *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5) */
+int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
+/* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,
+ * [3] device build time in ms. */
+int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,8 @@ SIGNATURES = {
     "mcl3dl_hip_reset_kernel_time": (_i, [_p]),
     "mcl3dl_hip_workload_stats": (_i, [_p, _p, _sz, _p]),
     "mcl3dl_hip_memory_footprint": (_i, [_p, _p]),
+    "mcl3dl_hip_set_option": (_i, [_p, C.c_char_p, _d]),
+    "mcl3dl_hip_index_stats": (_i, [_p, _p]),
 }
 
 _lib = None
@@ -240,7 +242,15 @@ class Engine:
         return dict(sum_k=st[0], evals=st[1], dda_steps=st[2], dda_occupied=st[3], dda_tested=st[4], rays=st[5])
 
     def memory_footprint(self):
-        b = np.zeros(5, np.uint64)
+        b = np.zeros(8, np.uint64)
         self._check(self.lib.mcl3dl_hip_memory_footprint(self.h, _ptr(b)))
         return dict(lik_points=int(b[0]), lik_cells=int(b[1]), dda_bits=int(b[2]), dda_voxels=int(b[3]),
-                    dda_points=int(b[4]))
+                    dda_points=int(b[4]), cand_table=int(b[5]), cand_start=int(b[6]), cand_points=int(b[7]))
+
+    def set_option(self, name, value):
+        self._check(self.lib.mcl3dl_hip_set_option(self.h, name.encode(), float(value)))
+
+    def index_stats(self):
+        s = np.zeros(4, np.float64)
+        self._check(self.lib.mcl3dl_hip_index_stats(self.h, _ptr(s)))
+        return dict(bricks=int(s[0]), preliminary=int(s[1]), candidates=int(s[2]), build_ms=float(s[3]))

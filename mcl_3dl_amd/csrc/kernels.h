@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "map_compiler.h"
 
 #pragma clang fp contract(off)
 
@@ -116,10 +117,44 @@ __device__ inline float nearest_d2(const LikGrid& g, float qx, float qy, float q
   return best;
 }
 
-template <int BLOCK, bool STATS>
+// Same query against the candidate-voxel index (map_compiler.h): the voxel of q holds every map point that can be the
+// nearest neighbour within r of a query inside it, so min d2 over that run == min d2 over the whole map.
+template <bool STATS>
+__device__ inline float nearest_d2_cand(const CandGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  const float fx = floorf((qx - g.ox) * g.inv_e);
+  const float fy = floorf((qy - g.oy) * g.inv_e);
+  const float fz = floorf((qz - g.oz) * g.inv_e);
+  float best = 3.0e38f;
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
+        fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
+    return best;
+  const int vx = static_cast<int>(fx), vy = static_cast<int>(fy), vz = static_cast<int>(fz);
+  const int b = g.brick_table[(static_cast<size_t>(vz >> 3) * g.nby + (vy >> 3)) * g.nbx + (vx >> 3)];
+  if (b < 0)
+    return best;
+  const size_t v = static_cast<size_t>(b) * 512 + (((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  const uint32_t s = g.vox_start[v], e = g.vox_start[v + 1];
+  for (uint32_t k = s; k < e; ++k)
+  {
+    const float4 p = g.cand[k];
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    best = d2 < best ? d2 : best;
+    if (STATS)
+      ++n_tested;
+  }
+  return best;
+}
+
+// MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
+// MODE 1: candidate-voxel index
+template <int BLOCK, int MODE, bool STATS>
 __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
                                                            const float4* __restrict__ scan, int n_s, LikGrid g,
-                                                           LikParams prm, float* __restrict__ out_lik,
+                                                           CandGrid cg, LikParams prm, float* __restrict__ out_lik,
                                                            float* __restrict__ out_ratio,
                                                            double* __restrict__ out_tested)
 {
@@ -144,7 +179,7 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
       qy = t.y * prm.wy;
       qz = t.z * prm.wz;
     }
-    const float d2 = nearest_d2<STATS>(g, qx, qy, qz, tested);
+    const float d2 = MODE == 0 ? nearest_d2<STATS>(g, qx, qy, qz, tested) : nearest_d2_cand<STATS>(cg, qx, qy, qz, tested);
     if (d2 < prm.r2)  // radiusSearch found a neighbour (strict <)
     {
       const float s = sqrtf(d2);

@@ -1,0 +1,346 @@
+// map_compiler.h — device-side map compiler for the likelihood-field index ("candidate voxels").
+//
+// What it builds (once per map stamp / search radius, entirely on the GPU):
+//   a sparse two-level voxel grid over the dist_weight-rescaled map — dense table of 8x8x8-voxel bricks, bricks allocated
+//   only within reach of map points — in which every voxel V (edge e = r/2) stores the EXACT candidate set
+//        C(V) = { map points that can be the nearest neighbour, at distance < r, of at least one query inside V }
+//   (conservatively: a superset proven below), as a contiguous run of float4 {x,y,z,index}.
+//   A query then costs: 1 brick-table load + 2 run-delimiter loads + |C(V)| contiguous point loads (|C| ~ 4 on a 0.1 m
+//   sampled wall) instead of 18 delimiter loads + ~25 points of the 27-cell scan — ~6x fewer cache-line accesses, which is
+//   what bounds likelihood_kernel.
+//
+// Exactness argument (V+ = V grown by 1e-3*e on every side to absorb the float rounding of the query's voxel index):
+//   (1) p is the NN of q in V+ at distance < r  =>  dmin(p,V+) <= |q-p| < r.
+//   (2) for any q in V+, |q - NN(q)| <= |q - p'| <= dmax(p',V+) for every p'  =>  dmin(NN(q),V+) <= D(V) := min_p' dmax(p',V+).
+//   (3) if some p' is closer than p by more than a margin m at EVERY q of V+ (the difference of squared distances is
+//       linear in q, so its minimum over the box is attained at a corner and has a closed form) then p is never the NN.
+//   All three tests are evaluated in fp64 with relative slack 1e-5 / absolute margin m = 1e-5*r^2, orders of magnitude above
+//   the ~2e-7 relative error of the kernel's float d^2, so the float-argmin point of the query kernel is never dropped and
+//   min d^2 over C(V) is bit-identical to min d^2 over the whole map (checked by every parity test).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcl3dl
+{
+struct CandGrid
+{
+  const int32_t* brick_table;  // dense [nbx*nby*nbz]: brick id or -1
+  const uint32_t* vox_start;   // [n_bricks*512 + 1] run delimiters into cand
+  const float4* cand;          // rescaled x,y,z ; w = original map index (bits)
+  float ox, oy, oz;            // origin of voxel (0,0,0), rescaled coordinates
+  float inv_e;                 // 1 / voxel edge
+  int nvx, nvy, nvz;           // voxel-grid extent
+  int nbx, nby, nbz;           // brick-grid extent (= ceil(nv / 8))
+};
+
+struct CompileParams
+{
+  float ox, oy, oz, inv_e;
+  double e;       // voxel edge
+  double grow;    // V+ = V grown by this on every side
+  double r2_hi;   // (r*(1+1e-5))^2
+  double margin;  // domination margin m
+  int reach;      // voxels to visit around a point's own voxel
+  int nvx, nvy, nvz, nbx, nby, nbz;
+  int n_points;
+};
+
+__device__ inline int3 voxel_of(const CompileParams& c, const float4 p)
+{
+  // the same float expression the query kernel evaluates
+  return make_int3(static_cast<int>(floorf((p.x - c.ox) * c.inv_e)), static_cast<int>(floorf((p.y - c.oy) * c.inv_e)),
+                   static_cast<int>(floorf((p.z - c.oz) * c.inv_e)));
+}
+
+__device__ inline long long brick_index(const CompileParams& c, int vx, int vy, int vz)
+{
+  return (static_cast<long long>(vz >> 3) * c.nby + (vy >> 3)) * c.nbx + (vx >> 3);
+}
+
+__device__ inline unsigned local_index(int vx, int vy, int vz)
+{
+  return static_cast<unsigned>(((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+}
+
+// squared min / max distance from point p to the grown voxel box (fp64)
+__device__ inline void box_dist2(const CompileParams& c, const float4 p, int vx, int vy, int vz, double& dmin2,
+                                 double& dmax2)
+{
+  const double pc[3] = { static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z) };
+  const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
+  const int v[3] = { vx, vy, vz };
+  dmin2 = 0.0;
+  dmax2 = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    const double lo = o[a] + v[a] * c.e - c.grow, hi = o[a] + (v[a] + 1) * c.e + c.grow;
+    const double below = lo - pc[a], above = pc[a] - hi;
+    const double out = below > 0 ? below : (above > 0 ? above : 0.0);
+    dmin2 += out * out;
+    const double f1 = fabs(pc[a] - lo), f2 = fabs(pc[a] - hi);
+    const double far = f1 > f2 ? f1 : f2;
+    dmax2 += far * far;
+  }
+}
+
+// decode thread -> (point, voxel offset); returns false if outside the grid
+__device__ inline bool visit(const CompileParams& c, const float4* __restrict__ pts, long long t, int& pi, int& vx,
+                             int& vy, int& vz)
+{
+  const int side = 2 * c.reach + 1;
+  const int per = side * side * side;
+  pi = static_cast<int>(t / per);
+  if (pi >= c.n_points)
+    return false;
+  const int o = static_cast<int>(t - static_cast<long long>(pi) * per);
+  const int3 pv = voxel_of(c, pts[pi]);
+  vx = pv.x + (o % side) - c.reach;
+  vy = pv.y + ((o / side) % side) - c.reach;
+  vz = pv.z + (o / (side * side)) - c.reach;
+  return vx >= 0 && vy >= 0 && vz >= 0 && vx < c.nvx && vy < c.nvy && vz < c.nvz;
+}
+
+// K1: mark every brick that holds a voxel within reach of a point
+__global__ void mc_mark_bricks(CompileParams c, const float4* __restrict__ pts, int* __restrict__ brick_flag)
+{
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= c.n_points)
+    return;
+  const int3 v = voxel_of(c, pts[pi]);
+  const int x0 = max(v.x - c.reach, 0) >> 3, x1 = min(v.x + c.reach, c.nvx - 1) >> 3;
+  const int y0 = max(v.y - c.reach, 0) >> 3, y1 = min(v.y + c.reach, c.nvy - 1) >> 3;
+  const int z0 = max(v.z - c.reach, 0) >> 3, z1 = min(v.z + c.reach, c.nvz - 1) >> 3;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x)
+        brick_flag[(static_cast<long long>(z) * c.nby + y) * c.nbx + x] = 1;
+}
+
+// brick_flag (0/1) + its exclusive scan -> brick id or -1
+__global__ void mc_brick_ids(const int* __restrict__ flag, const uint32_t* __restrict__ scanned, int* __restrict__ table,
+                             long long n)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    table[i] = flag[i] ? static_cast<int>(scanned[i]) : -1;
+}
+
+__global__ void mc_fill_u32(uint32_t* a, uint32_t v, long long n)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    a[i] = v;
+}
+
+// K3: D^2(V) = min over points within reach of dmax^2(p, V+), kept as float bits rounded UP (positive floats order like uints)
+__global__ void mc_scatter_dmax(CompileParams c, const float4* __restrict__ pts, const int* __restrict__ table,
+                                uint32_t* __restrict__ d2bits, long long n_threads)
+{
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_threads)
+    return;
+  int pi, vx, vy, vz;
+  if (!visit(c, pts, t, pi, vx, vy, vz))
+    return;
+  double dmin2, dmax2;
+  box_dist2(c, pts[pi], vx, vy, vz, dmin2, dmax2);
+  if (dmin2 > c.r2_hi)
+    return;
+  const int b = table[brick_index(c, vx, vy, vz)];
+  if (b < 0)
+    return;
+  float up = static_cast<float>(dmax2);
+  if (static_cast<double>(up) < dmax2)
+    up = __uint_as_float(__float_as_uint(up) + 1u);
+  atomicMin(&d2bits[static_cast<size_t>(b) * 512 + local_index(vx, vy, vz)], __float_as_uint(up));
+}
+
+__device__ inline bool prelim_test(const CompileParams& c, const float4 p, int vx, int vy, int vz, uint32_t dbits)
+{
+  double dmin2, dmax2;
+  box_dist2(c, p, vx, vy, vz, dmin2, dmax2);
+  const double d2 = static_cast<double>(__uint_as_float(dbits)) * (1.0 + 2e-5) + 1e-12;
+  return dmin2 <= c.r2_hi && dmin2 <= d2;
+}
+
+// K4 / K5: preliminary candidates = points with dmin <= min(r, D) (slack included); count, then fill
+template <bool FILL>
+__global__ void mc_prelim(CompileParams c, const float4* __restrict__ pts, const int* __restrict__ table,
+                          const uint32_t* __restrict__ d2bits, uint32_t* __restrict__ count,
+                          const uint32_t* __restrict__ pstart, uint32_t* __restrict__ prelim, long long n_threads)
+{
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_threads)
+    return;
+  int pi, vx, vy, vz;
+  if (!visit(c, pts, t, pi, vx, vy, vz))
+    return;
+  const int b = table[brick_index(c, vx, vy, vz)];
+  if (b < 0)
+    return;
+  const size_t v = static_cast<size_t>(b) * 512 + local_index(vx, vy, vz);
+  if (!prelim_test(c, pts[pi], vx, vy, vz, d2bits[v]))
+    return;
+  const uint32_t slot = atomicAdd(&count[v], 1u);
+  if (FILL)
+    prelim[pstart[v] + slot] = static_cast<uint32_t>(pi);
+}
+
+// K6 (mc_prune_boxed below): per voxel, drop every candidate that another candidate beats by more than the margin
+// everywhere in V+; the survivors are compacted to the front of the voxel's preliminary run in ascending point order.
+// brick id -> brick coordinate (inverse of the table), so a voxel index decodes to its integer coordinates
+__global__ void mc_brick_coords(const int* __restrict__ table, int nbx, int nby, long long n_table,
+                                int* __restrict__ brick_xyz)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_table)
+    return;
+  const int b = table[i];
+  if (b < 0)
+    return;
+  const long long plane = static_cast<long long>(nbx) * nby;
+  brick_xyz[3 * b + 0] = static_cast<int>(i % nbx);
+  brick_xyz[3 * b + 1] = static_cast<int>((i / nbx) % nby);
+  brick_xyz[3 * b + 2] = static_cast<int>(i / plane);
+}
+
+__global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, const int* __restrict__ brick_xyz,
+                               const uint32_t* __restrict__ pstart, uint32_t* __restrict__ prelim,
+                               uint32_t* __restrict__ kept_count, long long n_vox)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vox)
+    return;
+  const uint32_t s = pstart[v], e = pstart[v + 1];
+  if (s == e)
+  {
+    kept_count[v] = 0;
+    return;
+  }
+  const int b = static_cast<int>(v >> 9);
+  const int l = static_cast<int>(v & 511);
+  const int vc[3] = { brick_xyz[3 * b + 0] * 8 + (l & 7), brick_xyz[3 * b + 1] * 8 + ((l >> 3) & 7),
+                      brick_xyz[3 * b + 2] * 8 + (l >> 6) };
+  const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
+  double ctr[3], half;
+  half = 0.5 * c.e + c.grow;
+  for (int a = 0; a < 3; ++a)
+    ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
+  // pass 1: mark dominated candidates (bit 31 of the stored id)
+  for (uint32_t i = s; i < e; ++i)
+  {
+    const float4 p = pts[prelim[i] & 0x7fffffffu];
+    const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
+    const double pp = px * px + py * py + pz * pz;
+    bool dominated = false;
+    for (uint32_t j = s; j < e && !dominated; ++j)
+    {
+      if (j == i)
+        continue;
+      const float4 q = pts[prelim[j] & 0x7fffffffu];
+      const double qx = q.x - ctr[0], qy = q.y - ctr[1], qz = q.z - ctr[2];
+      // g(x) = |x-p|^2 - |x-q|^2 = 2 x.(q-p) + |p|^2 - |q|^2 ; its minimum over the box [-half, half]^3
+      const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
+      const double gmin = pp - (qx * qx + qy * qy + qz * qz) - half * (fabs(cx) + fabs(cy) + fabs(cz));
+      dominated = gmin > c.margin;
+    }
+    if (dominated)
+      prelim[i] |= 0x80000000u;
+  }
+  // pass 2: compact survivors to the front, ascending point id (selection sort; runs are short)
+  uint32_t n = 0;
+  for (uint32_t i = s; i < e; ++i)
+  {
+    const uint32_t id = prelim[i];
+    if (!(id & 0x80000000u))
+    {
+      prelim[i] = prelim[s + n];
+      prelim[s + n] = id;
+      ++n;
+    }
+  }
+  for (uint32_t i = 0; i + 1 < n; ++i)
+  {
+    uint32_t m = i;
+    for (uint32_t j = i + 1; j < n; ++j)
+    {
+      const uint32_t a = prelim[s + j] & 0x7fffffffu, bb = prelim[s + m] & 0x7fffffffu;
+      if (a < bb)
+        m = j;
+    }
+    const uint32_t tmp = prelim[s + i];
+    prelim[s + i] = prelim[s + m];
+    prelim[s + m] = tmp;
+  }
+  kept_count[v] = n;
+}
+
+// K7: write the final candidate runs
+__global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
+                               const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ vstart,
+                               float4* __restrict__ cand, long long n_vox)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vox)
+    return;
+  const uint32_t s = vstart[v], e = vstart[v + 1], src = pstart[v];
+  for (uint32_t k = 0; k < e - s; ++k)
+    cand[s + k] = pts[prelim[src + k] & 0x7fffffffu];
+}
+
+// ---- exclusive scan of uint32 (3 levels of 1024-element tiles cover 2^30 elements) --------------------------------
+constexpr int SCAN_TILE = 1024;  // 256 threads x 4 elements
+
+__global__ __launch_bounds__(256) void scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                  uint32_t* __restrict__ tile_sums, long long n)
+{
+  __shared__ uint32_t sh[256];
+  const long long base = static_cast<long long>(blockIdx.x) * SCAN_TILE + threadIdx.x * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+  const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1)  // Hillis-Steele inclusive scan of the 256 thread sums
+  {
+    const uint32_t add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = sh[threadIdx.x] - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    if (base + k < n)
+      out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255 && tile_sums)
+    tile_sums[blockIdx.x] = sh[255];
+}
+
+__global__ void scan_add_offsets(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_offsets, long long n)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] += tile_offsets[i / SCAN_TILE];
+}
+
+__global__ void sum_u32_to_u64(const uint32_t* __restrict__ in, long long n, unsigned long long* __restrict__ total)
+{
+  unsigned long long s = 0;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x)
+    s += in[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0)
+    atomicAdd(total, s);
+}
+}  // namespace mcl3dl

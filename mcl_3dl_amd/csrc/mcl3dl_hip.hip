@@ -69,12 +69,19 @@ struct mcl3dl_hip_ctx
   // derived, src/lidar_measurement_model_beam.cpp:65-67
   float hit_range_sq = 0, beam_likelihood = 0, sin_total_ref = 0;
 
-  bool lik_dirty = true, dda_dirty = true;
+  bool lik_dirty = true, dda_dirty = true, cand_dirty = true;
   DevBuf lik_pts, lik_cells;
   LikGrid lg{};
+  // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
+  int lik_index = 1;
+  double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
+  double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
+  DevBuf cand_table, cand_start, cand_pts;
+  CandGrid cg{};
+  double cand_stats[4] = { 0, 0, 0, 0 };  // bricks, voxels with candidates, candidates, build ms
   DevBuf dda_bits, dda_start, dda_pts, dda_index;
   DdaGrid dg{};
-  uint64_t footprint[5] = { 0, 0, 0, 0, 0 };
+  uint64_t footprint[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 
   // scans of the current update
   DevBuf scan_lik, scan_beam, origins, pow_table;
@@ -390,12 +397,224 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
   return 0;
 }
 
-int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda)
+// ---- map compiler: candidate-voxel index (device side in map_compiler.h) ------------------------------------------
+int device_exclusive_scan(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n)  // in place
+{
+  if (n <= 0)
+    return 0;
+  const long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* sums = nullptr;
+  if (tiles > 1)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sums), sizeof(uint32_t) * tiles));
+  hipLaunchKernelGGL(scan_tiles, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, ctx->stream, data, data, sums, n);
+  if (tiles > 1)
+  {
+    const int rc = device_exclusive_scan(ctx, sums, tiles);
+    if (rc == 0)
+      hipLaunchKernelGGL(scan_add_offsets, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                         data, sums, n);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(sums));
+    if (rc != 0)
+      return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+struct TempBuf
+{
+  void* p = nullptr;
+  ~TempBuf()
+  {
+    if (p)
+      (void)hipFree(p);
+  }
+};
+
+int build_cand_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const double r = static_cast<double>(ctx->match_dist_min);
+  const float e_f = static_cast<float>(r * ctx->cand_voxel_ratio);
+  if (!(e_f > 0.f) || !std::isfinite(e_f))
+    return ctx->fail(-3, "bad candidate voxel edge");
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, ctx->stream));
+  // rescaled points in map order (PointRepresentation::vectorize), w = original index
+  std::vector<float4> sp(n);
+  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+  for (size_t i = 0; i < n; ++i)
+  {
+    float v[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      v[a] = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
+      if (!std::isfinite(v[a]))
+        return ctx->fail(-3, "map point %zu is not finite", i);
+      if (i == 0 || v[a] < mn[a])
+        mn[a] = v[a];
+      if (i == 0 || v[a] > mx[a])
+        mx[a] = v[a];
+    }
+    sp[i] = make_float4(v[0], v[1], v[2], bits_to_float(static_cast<uint32_t>(i)));
+  }
+  CompileParams cp{};
+  cp.e = static_cast<double>(e_f);
+  cp.inv_e = 1.0f / e_f;
+  cp.grow = 1e-3 * cp.e;
+  const double r_hi = r * (1.0 + 1e-5);
+  cp.r2_hi = r_hi * r_hi;
+  cp.margin = 1e-5 * r * r;
+  cp.reach = static_cast<int>(std::floor((r_hi + cp.grow) / cp.e)) + 1;
+  cp.n_points = static_cast<int>(n);
+  float o[3];
+  int nv[3], nb[3];
+  double n_table_d = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    // Phase: maps that come out of a voxel filter sit on a lattice; with the origin ON that lattice every voxel face
+    // coincides with a Voronoi face of the map and each voxel keeps 3 candidates per axis instead of the 2 a generic
+    // position needs. Half a voxel of phase puts lattice maps in the generic position; arbitrary maps do not care.
+    o[a] = mn[a] - static_cast<float>((cp.reach + 1 + ctx->cand_phase) * cp.e);
+    nv[a] = static_cast<int>(std::floor((static_cast<double>(mx[a]) - o[a]) / cp.e)) + cp.reach + 2;
+    nb[a] = (nv[a] + 7) / 8;
+    n_table_d *= nb[a];
+  }
+  if (n_table_d > 2.0e9)
+    return ctx->fail(-4, "candidate index would need %.3g bricks in its dense table", n_table_d);
+  cp.ox = o[0];
+  cp.oy = o[1];
+  cp.oz = o[2];
+  cp.nvx = nv[0];
+  cp.nvy = nv[1];
+  cp.nvz = nv[2];
+  cp.nbx = nb[0];
+  cp.nby = nb[1];
+  cp.nbz = nb[2];
+  const long long n_table = static_cast<long long>(n_table_d);
+
+  TempBuf d_pts, d_flag, d_scan, d_d2, d_count, d_pstart, d_prelim, d_bxyz, d_total;
+  HIP_TRY(hipMalloc(&d_pts.p, sizeof(float4) * n));
+  TRY(h2d(ctx, d_pts.p, sp.data(), sizeof(float4) * n));
+  HIP_TRY(hipMalloc(&d_flag.p, sizeof(int) * n_table));
+  HIP_TRY(hipMalloc(&d_scan.p, sizeof(uint32_t) * (n_table + 1)));
+  HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(int) * n_table, ctx->stream));
+  const float4* pts = static_cast<const float4*>(d_pts.p);
+  hipLaunchKernelGGL(mc_mark_bricks, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, cp, pts,
+                     static_cast<int*>(d_flag.p));
+  HIP_TRY(hipMemsetAsync(d_scan.p, 0, sizeof(uint32_t) * (n_table + 1), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_scan.p, d_flag.p, sizeof(int) * n_table, hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_scan.p), n_table + 1));
+  uint32_t n_bricks = 0;
+  TRY(d2h(ctx, &n_bricks, static_cast<uint32_t*>(d_scan.p) + n_table, sizeof(uint32_t)));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (n_bricks == 0 || n_bricks > (1u << 22))
+    return ctx->fail(-4, "candidate index: %u bricks", n_bricks);
+  TRY(ensure(ctx, ctx->cand_table, sizeof(int) * n_table));
+  int* table = ctx->cand_table.as<int>();
+  hipLaunchKernelGGL(mc_brick_ids, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const int*>(d_flag.p), static_cast<const uint32_t*>(d_scan.p), table, n_table);
+  HIP_TRY(hipMalloc(&d_bxyz.p, sizeof(int) * 3 * n_bricks));
+  hipLaunchKernelGGL(mc_brick_coords, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
+                     table, cp.nbx, cp.nby, n_table, static_cast<int*>(d_bxyz.p));
+
+  const long long n_vox = static_cast<long long>(n_bricks) * 512;
+  const int side = 2 * cp.reach + 1;
+  const long long n_threads = static_cast<long long>(n) * side * side * side;
+  const unsigned blocks_t = static_cast<unsigned>((n_threads + 255) / 256);
+  if ((n_threads + 255) / 256 > 0x7fffffffLL)
+    return ctx->fail(-4, "candidate index: too many (point, voxel) pairs");
+  const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
+  HIP_TRY(hipMalloc(&d_d2.p, sizeof(uint32_t) * n_vox));
+  HIP_TRY(hipMalloc(&d_count.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMalloc(&d_pstart.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMalloc(&d_total.p, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(mc_fill_u32, dim3(blocks_v), dim3(256), 0, ctx->stream, static_cast<uint32_t*>(d_d2.p), 0x7f800000u,
+                     n_vox);
+  hipLaunchKernelGGL(mc_scatter_dmax, dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                     static_cast<uint32_t*>(d_d2.p), n_threads);
+  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  hipLaunchKernelGGL((mc_prelim<false>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                     static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
+                     static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n_threads);
+  // total preliminary candidates must fit the 32-bit run delimiters
+  unsigned long long total = 0;
+  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+                     n_vox, static_cast<unsigned long long*>(d_total.p));
+  TRY(d2h(ctx, &total, d_total.p, sizeof(total)));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (total >= 0xfffffff0ULL)
+    return ctx->fail(-4, "candidate index: %llu preliminary candidates exceed 32-bit offsets", total);
+  HIP_TRY(hipMemcpyAsync(d_pstart.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_pstart.p), n_vox + 1));
+  HIP_TRY(hipMalloc(&d_prelim.p, sizeof(uint32_t) * (total ? total : 1)));
+  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  hipLaunchKernelGGL((mc_prelim<true>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                     static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p), n_threads);
+  // prune; d_count becomes the kept count per voxel
+  hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, static_cast<const int*>(d_bxyz.p),
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
+                     static_cast<uint32_t*>(d_count.p), n_vox);
+  unsigned long long kept = 0;
+  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+                     n_vox, static_cast<unsigned long long*>(d_total.p));
+  TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(ensure(ctx, ctx->cand_start, sizeof(uint32_t) * (n_vox + 1)));
+  TRY(ensure(ctx, ctx->cand_pts, sizeof(float4) * (kept ? kept : 1)));
+  HIP_TRY(hipMemsetAsync(static_cast<uint32_t*>(d_count.p) + n_vox, 0, sizeof(uint32_t), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->cand_start.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice,
+                         ctx->stream));
+  TRY(device_exclusive_scan(ctx, ctx->cand_start.as<uint32_t>(), n_vox + 1));
+  hipLaunchKernelGGL(mc_write_final, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
+                     ctx->cand_start.as<uint32_t>(), ctx->cand_pts.as<float4>(), n_vox);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev1, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  CandGrid& g = ctx->cg;
+  g.brick_table = table;
+  g.vox_start = ctx->cand_start.as<uint32_t>();
+  g.cand = ctx->cand_pts.as<float4>();
+  g.ox = cp.ox;
+  g.oy = cp.oy;
+  g.oz = cp.oz;
+  g.inv_e = cp.inv_e;
+  g.nvx = cp.nvx;
+  g.nvy = cp.nvy;
+  g.nvz = cp.nvz;
+  g.nbx = cp.nbx;
+  g.nby = cp.nby;
+  g.nbz = cp.nbz;
+  ctx->footprint[5] = sizeof(int) * n_table;
+  ctx->footprint[6] = sizeof(uint32_t) * (n_vox + 1);
+  ctx->footprint[7] = sizeof(float4) * kept;
+  ctx->cand_stats[0] = n_bricks;
+  ctx->cand_stats[1] = static_cast<double>(total);
+  ctx->cand_stats[2] = static_cast<double>(kept);
+  ctx->cand_stats[3] = ms;
+  ctx->cand_dirty = false;
+  return 0;
+}
+
+int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda, bool need_cells = false)
 {
   if (!ctx->has_map)
     return ctx->fail(-5, "no map: call mcl3dl_hip_set_map first");
-  if (need_lik && ctx->lik_dirty)
+  if (need_lik && (ctx->lik_index == 0 || need_cells) && ctx->lik_dirty)
     TRY(build_lik_grid(ctx));
+  if (need_lik && ctx->lik_index == 1 && !need_cells && ctx->cand_dirty)
+    TRY(build_cand_grid(ctx));
   if (need_dda && ctx->dda_dirty)
     TRY(build_dda_grid(ctx));
   return 0;
@@ -465,7 +684,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     return ctx->fail(-3, "too many particles");
   const bool want_lik = (d_lik || d_ratio || stats);
   const bool want_beam = (d_beam || stats);
-  TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0));
+  TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0, stats));
   const int np = static_cast<int>(n_p);
   // ---- likelihood-field model
   if (want_lik)
@@ -484,18 +703,32 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (stats)
       {
         TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
-        hipLaunchKernelGGL((likelihood_kernel<256, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
-                           ctx->scan_lik.as<float4>(), ns, ctx->lg, lp, nullptr, nullptr, ctx->tested.as<double>());
+        hipLaunchKernelGGL((likelihood_kernel<256, 0, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
+                           ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, lp, nullptr, nullptr,
+                           ctx->tested.as<double>());
       }
       else
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
-        if (ns <= 128)
-          hipLaunchKernelGGL((likelihood_kernel<64, false>), dim3(np), dim3(64), 0, ctx->stream, d_pose,
-                             ctx->scan_lik.as<float4>(), ns, ctx->lg, lp, d_lik, d_ratio, nullptr);
+        const float4* scan = ctx->scan_lik.as<float4>();
+        if (ctx->lik_index == 1)
+        {
+          if (ns <= 128)
+            hipLaunchKernelGGL((likelihood_kernel<64, 1, false>), dim3(np), dim3(64), 0, ctx->stream, d_pose, scan, ns,
+                               ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+          else
+            hipLaunchKernelGGL((likelihood_kernel<256, 1, false>), dim3(np), dim3(256), 0, ctx->stream, d_pose, scan,
+                               ns, ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+        }
         else
-          hipLaunchKernelGGL((likelihood_kernel<256, false>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
-                             ctx->scan_lik.as<float4>(), ns, ctx->lg, lp, d_lik, d_ratio, nullptr);
+        {
+          if (ns <= 128)
+            hipLaunchKernelGGL((likelihood_kernel<64, 0, false>), dim3(np), dim3(64), 0, ctx->stream, d_pose, scan, ns,
+                               ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+          else
+            hipLaunchKernelGGL((likelihood_kernel<256, 0, false>), dim3(np), dim3(256), 0, ctx->stream, d_pose, scan,
+                               ns, ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+        }
         TRY(timing_end(ctx, ep));
       }
     }
@@ -620,7 +853,7 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf* bufs[] = { &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
+  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
                      &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
                      &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
                      &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
@@ -688,6 +921,7 @@ int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* la
     ctx->weight[a] = dist_weight ? dist_weight[a] : 1.0f;
   ctx->has_map = true;
   ctx->lik_dirty = true;
+  ctx->cand_dirty = true;
   ctx->dda_dirty = true;
   return 0;
 }
@@ -700,7 +934,7 @@ int mcl3dl_hip_set_likelihood_params(mcl3dl_hip_ctx* ctx, float match_dist_min, 
   if (!(match_dist_min > 0.f))
     return ctx->fail(-3, "match_dist_min must be > 0");
   if (match_dist_min != ctx->match_dist_min)
-    ctx->lik_dirty = true;  // the cell edge follows the search radius
+    ctx->lik_dirty = ctx->cand_dirty = true;  // cell / voxel edges follow the search radius
   ctx->match_dist_min = match_dist_min;
   ctx->match_dist_flat = match_dist_flat;
   ctx->match_weight = match_weight;
@@ -1086,12 +1320,54 @@ int mcl3dl_hip_reset_kernel_time(mcl3dl_hip_ctx* ctx)
   return 0;
 }
 
-int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes5)
+int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8)
 {
-  if (!ctx || !bytes5)
+  if (!ctx || !bytes8)
     return -1;
-  for (int i = 0; i < 5; ++i)
-    bytes5[i] = ctx->footprint[i];
+  for (int i = 0; i < 8; ++i)
+    bytes8[i] = ctx->footprint[i];
+  return 0;
+}
+
+int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
+{
+  if (!ctx || !name)
+    return -1;
+  const std::string key(name);
+  if (key == "lik_index")
+  {
+    if (value != 0.0 && value != 1.0)
+      return ctx->fail(-3, "lik_index must be 0 (27-cell scan) or 1 (candidate voxels)");
+    ctx->lik_index = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "cand_voxel_ratio")
+  {
+    if (!(value >= 0.125 && value <= 2.0))
+      return ctx->fail(-3, "cand_voxel_ratio must be in [0.125, 2]");
+    if (value != ctx->cand_voxel_ratio)
+      ctx->cand_dirty = true;
+    ctx->cand_voxel_ratio = value;
+    return 0;
+  }
+  if (key == "cand_phase")
+  {
+    if (!(value >= 0.0 && value < 1.0))
+      return ctx->fail(-3, "cand_phase must be in [0, 1)");
+    if (value != ctx->cand_phase)
+      ctx->cand_dirty = true;
+    ctx->cand_phase = value;
+    return 0;
+  }
+  return ctx->fail(-3, "unknown option '%s'", name);
+}
+
+int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4)
+{
+  if (!ctx || !stats4)
+    return -1;
+  for (int i = 0; i < 4; ++i)
+    stats4[i] = ctx->cand_stats[i];
   return 0;
 }
 }  // extern "C"

@@ -209,3 +209,30 @@ def test_likelihood_params_change(engine, oracle_kind, scene_c1):
     np.testing.assert_allclose(lik, wl, rtol=RTOL)
     np.testing.assert_array_equal(ratio, wq)
     engine.set_likelihood_params()  # back to the defaults for later tests
+
+
+@pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
+@pytest.mark.parametrize("ratio", [0.5, 0.25, 1.0])
+def test_candidate_index_equals_cell_scan_bit_for_bit(engine, scene_c1, dist_weight, ratio):
+    """The pruned candidate-voxel index (map_compiler.h) must return exactly the nearest distance the 27-cell scan of
+    the whole neighbourhood returns: identical per-point terms, identical fp64 sums, identical floats."""
+    sc = scene_c1
+    rng = np.random.default_rng(11)
+    # poses spread far wider than the tracking case so queries land at every offset from the surfaces, incl. off-map
+    poses = sc.poses.copy()
+    poses[:, :3] += rng.normal(0, 0.6, (len(poses), 3)).astype(np.float32)
+    setup_engine(engine, sc, dist_weight, stamp=30)
+    try:
+        engine.set_option("lik_index", 0)
+        lik0, ratio0, _ = engine.measure_batch(poses, sc.scan_lik)
+        engine.set_option("lik_index", 1)
+        engine.set_option("cand_voxel_ratio", ratio)
+        lik1, ratio1, _ = engine.measure_batch(poses, sc.scan_lik)
+        st = engine.index_stats()
+        assert 0 < st["candidates"] <= st["preliminary"]
+    finally:
+        engine.set_option("lik_index", 1)
+        engine.set_option("cand_voxel_ratio", 0.5)
+    np.testing.assert_array_equal(lik1, lik0)
+    np.testing.assert_array_equal(ratio1, ratio0)
+    assert np.count_nonzero(lik0) > len(poses) // 2
