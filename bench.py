@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--workload", default="C2", help="C1..C5 of BASELINE.json (default C2: 4096 x 16k, 1M-pt map)")
     ap.add_argument("--particles", type=int, default=0, help="override particles per GPU")
     ap.add_argument("--dist-weight-z", type=float, default=1.0)
-    ap.add_argument("--lik-index", type=int, default=1, help="1 = candidate-voxel index (default), 0 = 27-cell scan")
+    ap.add_argument("--lik-index", type=int, default=2,
+                    help="2 = candidate records (default), 1 = candidate runs, 0 = 27-cell scan")
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")

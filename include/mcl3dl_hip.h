@@ -156,7 +156,8 @@ int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n
  * [7] candidate points. Structures that were never needed are 0. */
 int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
 /* Tuning knobs (no reference counterpart; results are identical for every setting):
- *   "lik_index"         1 (default) = candidate-voxel index, 0 = 27-cell scan of the cell-sorted map
+ *   "lik_index"         2 (default) = candidate-voxel index, one 64-byte record per voxel; 1 = candidate-voxel index,
+ *                       CSR runs; 0 = 27-cell scan of the cell-sorted map
  *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min (default 0.5)
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5) */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);

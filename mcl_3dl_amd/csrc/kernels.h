@@ -149,12 +149,80 @@ __device__ inline float nearest_d2_cand(const CandGrid& g, float qx, float qy, f
   return best;
 }
 
+// MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates (overflow runs for
+// voxels with more than 5).
+__device__ inline float d2_simple(float qx, float qy, float qz, float px, float py, float pz)
+{
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  float d2 = dx * dx;
+  d2 = d2 + dy * dy;
+  d2 = d2 + dz * dz;
+  return d2;
+}
+
+template <bool STATS>
+__device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  const float fx = floorf((qx - g.ox) * g.inv_e);
+  const float fy = floorf((qy - g.oy) * g.inv_e);
+  const float fz = floorf((qz - g.oz) * g.inv_e);
+  float best = 3.0e38f;
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
+        fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
+    return best;
+  const int vx = static_cast<int>(fx), vy = static_cast<int>(fy), vz = static_cast<int>(fz);
+  const int b = g.brick_table[(static_cast<size_t>(vz >> 3) * g.nby + (vy >> 3)) * g.nbx + (vx >> 3)];
+  if (b < 0)
+    return best;
+  const size_t v = static_cast<size_t>(b) * 512 + (((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  const float4* r = g.rec + 4 * v;
+  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  const uint32_t count = __float_as_uint(r0.x);
+  if (count == 0)
+    return best;
+  if (STATS)
+    n_tested += count;
+  if (count <= 5)
+  {
+    float d;
+    d = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
+    best = d;
+    d = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
+    best = (count > 1 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
+    best = (count > 2 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
+    best = (count > 3 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
+    best = (count > 4 && d < best) ? d : best;
+    return best;
+  }
+  float d;
+  d = d2_simple(qx, qy, qz, r0.z, r0.w, r1.x);
+  best = d;
+  d = d2_simple(qx, qy, qz, r1.y, r1.z, r1.w);
+  best = d < best ? d : best;
+  d = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
+  best = d < best ? d : best;
+  d = d2_simple(qx, qy, qz, r2.w, r3.x, r3.y);
+  best = d < best ? d : best;
+  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(__float_as_uint(r0.y));
+  for (uint32_t j = 0; j < count - 4; ++j)
+  {
+    const float* s = o + 16 * (j / 5) + 3 * (j % 5);
+    d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
+    best = d < best ? d : best;
+  }
+  return best;
+}
+
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
 // MODE 1: candidate-voxel index
 template <int BLOCK, int MODE, bool STATS>
 __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
                                                            const float4* __restrict__ scan, int n_s, LikGrid g,
-                                                           CandGrid cg, LikParams prm, float* __restrict__ out_lik,
+                                                           CandGrid cg, RecGrid rg, LikParams prm,
+                                                           float* __restrict__ out_lik,
                                                            float* __restrict__ out_ratio,
                                                            double* __restrict__ out_tested)
 {
@@ -179,7 +247,9 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
       qy = t.y * prm.wy;
       qz = t.z * prm.wz;
     }
-    const float d2 = MODE == 0 ? nearest_d2<STATS>(g, qx, qy, qz, tested) : nearest_d2_cand<STATS>(cg, qx, qy, qz, tested);
+    const float d2 = MODE == 0 ? nearest_d2<STATS>(g, qx, qy, qz, tested) :
+                     MODE == 1 ? nearest_d2_cand<STATS>(cg, qx, qy, qz, tested) :
+                                 nearest_d2_rec<STATS>(rg, qx, qy, qz, tested);
     if (d2 < prm.r2)  // radiusSearch found a neighbour (strict <)
     {
       const float s = sqrtf(d2);

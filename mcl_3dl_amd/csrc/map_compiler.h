@@ -290,6 +290,73 @@ __global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* _
     cand[s + k] = pts[prelim[src + k] & 0x7fffffffu];
 }
 
+// ---- "fat" voxel records (query MODE 2) -------------------------------------------------------------------------
+// One 64-byte record per voxel of every allocated brick, so a query is ONE cache line after the brick table:
+//   count <= 5 : { count, xyz[5] }                       (15 floats of candidates inline)
+//   count  > 5 : { count, ext, xyz[4], pad, pad }        (4 inline, the rest in overflow records ext, ext+1, ...)
+//   overflow   : { xyz[5], pad }                         contiguous, 5 candidates each
+struct RecGrid
+{
+  const int32_t* brick_table;
+  const float4* rec;  // [n_bricks*512][4]
+  const float4* ovf;  // [n_overflow][4]
+  float ox, oy, oz, inv_e;
+  int nvx, nvy, nvz, nbx, nby, nbz;
+};
+
+__global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vox)
+    return;
+  const uint32_t c = kept_count[v];
+  n_ovf[v] = c > 5 ? (c - 4 + 4) / 5 : 0u;
+}
+
+__global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
+                                 const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ kept_count,
+                                 const uint32_t* __restrict__ ovf_start, float* __restrict__ rec,
+                                 float* __restrict__ ovf, long long n_vox)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vox)
+    return;
+  const uint32_t c = kept_count[v], src = pstart[v];
+  float out[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    out[i] = 0.f;
+  out[0] = __uint_as_float(c);
+  const uint32_t inline_n = c <= 5 ? c : 4u;
+  const int base = c <= 5 ? 1 : 2;
+  if (c > 5)
+    out[1] = __uint_as_float(ovf_start[v]);
+  for (uint32_t k = 0; k < inline_n; ++k)
+  {
+    const float4 p = pts[prelim[src + k] & 0x7fffffffu];
+    out[base + 3 * k + 0] = p.x;
+    out[base + 3 * k + 1] = p.y;
+    out[base + 3 * k + 2] = p.z;
+  }
+  float4* dst = reinterpret_cast<float4*>(rec + 16 * v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+  if (c > 5)
+  {
+    float* o = ovf + 16 * static_cast<size_t>(ovf_start[v]);
+    for (uint32_t k = 4; k < c; ++k)
+    {
+      const float4 p = pts[prelim[src + k] & 0x7fffffffu];
+      const uint32_t j = k - 4;
+      float* slot = o + 16 * (j / 5) + 3 * (j % 5);
+      slot[0] = p.x;
+      slot[1] = p.y;
+      slot[2] = p.z;
+    }
+  }
+}
+
 // ---- exclusive scan of uint32 (3 levels of 1024-element tiles cover 2^30 elements) --------------------------------
 constexpr int SCAN_TILE = 1024;  // 256 threads x 4 elements
 

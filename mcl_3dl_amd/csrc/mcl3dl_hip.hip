@@ -73,11 +73,12 @@ struct mcl3dl_hip_ctx
   DevBuf lik_pts, lik_cells;
   LikGrid lg{};
   // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
-  int lik_index = 1;
+  int lik_index = 2;
   double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
-  DevBuf cand_table, cand_start, cand_pts;
+  DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
   CandGrid cg{};
+  RecGrid rg{};
   double cand_stats[4] = { 0, 0, 0, 0 };  // bricks, voxels with candidates, candidates, build ms
   DevBuf dda_bits, dda_start, dda_pts, dda_index;
   DdaGrid dg{};
@@ -566,6 +567,56 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
                      n_vox, static_cast<unsigned long long*>(d_total.p));
   TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->lik_index == 2)
+  {
+    // fat records: overflow slots per voxel -> exclusive scan -> write
+    TempBuf d_ovf;
+    HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
+    HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+    hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox);
+    TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
+    uint32_t n_ovf = 0;
+    TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(ensure(ctx, ctx->cand_rec, 64ull * static_cast<size_t>(n_vox)));
+    TRY(ensure(ctx, ctx->cand_ovf, 64ull * (n_ovf ? n_ovf : 1)));
+    HIP_TRY(hipMemsetAsync(ctx->cand_ovf.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
+    hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
+                       static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
+                       static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p),
+                       ctx->cand_rec.as<float>(), ctx->cand_ovf.as<float>(), n_vox);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms2 = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms2, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    RecGrid& g = ctx->rg;
+    g.brick_table = table;
+    g.rec = ctx->cand_rec.as<float4>();
+    g.ovf = ctx->cand_ovf.as<float4>();
+    g.ox = cp.ox;
+    g.oy = cp.oy;
+    g.oz = cp.oz;
+    g.inv_e = cp.inv_e;
+    g.nvx = cp.nvx;
+    g.nvy = cp.nvy;
+    g.nvz = cp.nvz;
+    g.nbx = cp.nbx;
+    g.nby = cp.nby;
+    g.nbz = cp.nbz;
+    ctx->footprint[5] = sizeof(int) * n_table;
+    ctx->footprint[6] = 64ull * static_cast<size_t>(n_vox);
+    ctx->footprint[7] = 64ull * n_ovf;
+    ctx->cand_stats[0] = n_bricks;
+    ctx->cand_stats[1] = static_cast<double>(total);
+    ctx->cand_stats[2] = static_cast<double>(kept);
+    ctx->cand_stats[3] = ms2;
+    ctx->cand_dirty = false;
+    return 0;
+  }
   TRY(ensure(ctx, ctx->cand_start, sizeof(uint32_t) * (n_vox + 1)));
   TRY(ensure(ctx, ctx->cand_pts, sizeof(float4) * (kept ? kept : 1)));
   HIP_TRY(hipMemsetAsync(static_cast<uint32_t*>(d_count.p) + n_vox, 0, sizeof(uint32_t), ctx->stream));
@@ -613,7 +664,7 @@ int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda, bool ne
     return ctx->fail(-5, "no map: call mcl3dl_hip_set_map first");
   if (need_lik && (ctx->lik_index == 0 || need_cells) && ctx->lik_dirty)
     TRY(build_lik_grid(ctx));
-  if (need_lik && ctx->lik_index == 1 && !need_cells && ctx->cand_dirty)
+  if (need_lik && ctx->lik_index >= 1 && !need_cells && ctx->cand_dirty)
     TRY(build_cand_grid(ctx));
   if (need_dda && ctx->dda_dirty)
     TRY(build_dda_grid(ctx));
@@ -704,31 +755,38 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       {
         TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
         hipLaunchKernelGGL((likelihood_kernel<256, 0, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
-                           ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, lp, nullptr, nullptr,
+                           ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, ctx->rg, lp, nullptr, nullptr,
                            ctx->tested.as<double>());
       }
       else
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
         const float4* scan = ctx->scan_lik.as<float4>();
-        if (ctx->lik_index == 1)
+#define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
+  hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), 0, ctx->stream, d_pose, scan, ns, \
+                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr)
+        if (ctx->lik_index == 2)
         {
           if (ns <= 128)
-            hipLaunchKernelGGL((likelihood_kernel<64, 1, false>), dim3(np), dim3(64), 0, ctx->stream, d_pose, scan, ns,
-                               ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+            LAUNCH_LIK(64, 2);
           else
-            hipLaunchKernelGGL((likelihood_kernel<256, 1, false>), dim3(np), dim3(256), 0, ctx->stream, d_pose, scan,
-                               ns, ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+            LAUNCH_LIK(256, 2);
+        }
+        else if (ctx->lik_index == 1)
+        {
+          if (ns <= 128)
+            LAUNCH_LIK(64, 1);
+          else
+            LAUNCH_LIK(256, 1);
         }
         else
         {
           if (ns <= 128)
-            hipLaunchKernelGGL((likelihood_kernel<64, 0, false>), dim3(np), dim3(64), 0, ctx->stream, d_pose, scan, ns,
-                               ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+            LAUNCH_LIK(64, 0);
           else
-            hipLaunchKernelGGL((likelihood_kernel<256, 0, false>), dim3(np), dim3(256), 0, ctx->stream, d_pose, scan,
-                               ns, ctx->lg, ctx->cg, lp, d_lik, d_ratio, nullptr);
+            LAUNCH_LIK(256, 0);
         }
+#undef LAUNCH_LIK
         TRY(timing_end(ctx, ep));
       }
     }
@@ -853,7 +911,7 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
+  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
                      &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
                      &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
                      &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
@@ -1336,8 +1394,10 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   const std::string key(name);
   if (key == "lik_index")
   {
-    if (value != 0.0 && value != 1.0)
-      return ctx->fail(-3, "lik_index must be 0 (27-cell scan) or 1 (candidate voxels)");
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return ctx->fail(-3, "lik_index must be 0 (27-cell scan), 1 (candidate runs) or 2 (candidate records)");
+    if ((value == 0.0) != (ctx->lik_index == 0) || static_cast<int>(value) != ctx->lik_index)
+      ctx->cand_dirty = true;
     ctx->lik_index = static_cast<int>(value);
     return 0;
   }

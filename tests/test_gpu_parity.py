@@ -212,8 +212,9 @@ def test_likelihood_params_change(engine, oracle_kind, scene_c1):
 
 
 @pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
-@pytest.mark.parametrize("ratio", [0.5, 0.25, 1.0])
-def test_candidate_index_equals_cell_scan_bit_for_bit(engine, scene_c1, dist_weight, ratio):
+@pytest.mark.parametrize("ratio,phase", [(0.5, 0.5), (0.5, 0.0), (0.25, 0.5), (1.0, 0.3)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_candidate_index_equals_cell_scan_bit_for_bit(engine, scene_c1, dist_weight, ratio, phase, mode):
     """The pruned candidate-voxel index (map_compiler.h) must return exactly the nearest distance the 27-cell scan of
     the whole neighbourhood returns: identical per-point terms, identical fp64 sums, identical floats."""
     sc = scene_c1
@@ -225,14 +226,16 @@ def test_candidate_index_equals_cell_scan_bit_for_bit(engine, scene_c1, dist_wei
     try:
         engine.set_option("lik_index", 0)
         lik0, ratio0, _ = engine.measure_batch(poses, sc.scan_lik)
-        engine.set_option("lik_index", 1)
+        engine.set_option("lik_index", mode)
         engine.set_option("cand_voxel_ratio", ratio)
+        engine.set_option("cand_phase", phase)
         lik1, ratio1, _ = engine.measure_batch(poses, sc.scan_lik)
         st = engine.index_stats()
         assert 0 < st["candidates"] <= st["preliminary"]
     finally:
-        engine.set_option("lik_index", 1)
+        engine.set_option("lik_index", 2)
         engine.set_option("cand_voxel_ratio", 0.5)
+        engine.set_option("cand_phase", 0.5)
     np.testing.assert_array_equal(lik1, lik0)
     np.testing.assert_array_equal(ratio1, ratio0)
     assert np.count_nonzero(lik0) > len(poses) // 2
