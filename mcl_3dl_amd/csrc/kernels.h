@@ -50,7 +50,8 @@ struct LikParams
 // DDA occupancy (replaces RaycastUsingDDA::point_exists_ / points_, raycast_using_dda.h:280-281).
 struct DdaGrid
 {
-  const uint32_t* bits;       // occupancy, 1 bit per voxel, x fastest
+  const unsigned long long* bricks;  // occupancy: one 64-bit word per 4x4x4 voxel brick (bit = z<<4 | y<<2 | x), bricks x fastest
+  int bnx, bny, bnz;                 // brick-grid extent = ceil(n / 4)
   const uint32_t* vox_start;  // [total + 1] CSR into pts (voxel order, insertion order inside a voxel)
   const float4* pts;          // x,y,z (unscaled map coordinates), w = label bits
   const uint32_t* pt_index;   // original map index of pts[k]
@@ -381,32 +382,36 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
   float tmx = iex, tmy = iey, tmz = iez;
   int cx = bx, cy = by, cz = bz;
   int pos = 0;
-  const long long plane = static_cast<long long>(g.nx) * g.ny;
+  const int plane = g.nx * g.ny;
+  // The occupancy word of the brick the ray is currently in stays in registers: stepping inside a brick is pure ALU,
+  // a (dependent, high-latency) load happens only when the ray enters a new 4x4x4 brick.
+  int cur_brick = -1;
+  unsigned long long word = 0ull;
   for (;;)
   {
     // getNextCastResult, :106-159
     ++pos;
     if (pos >= max_movement)
       break;
-    bool inside;
-    if (tmx < tmy ? (tmx < tmz) : false)
-    {
-      cx += sx;  // incrementIndex(0), :192-203
-      tmx = iex + tdx * static_cast<float>(abs(cx - bx));
-      inside = !(cx < 0 || g.nx <= cx);
-    }
-    else if (tmx < tmy ? false : (tmy < tmz))
-    {
-      cy += sy;
-      tmy = iey + tdy * static_cast<float>(abs(cy - by));
-      inside = !(cy < 0 || g.ny <= cy);
-    }
-    else
-    {
-      cz += sz;
-      tmz = iez + tdz * static_cast<float>(abs(cz - bz));
-      inside = !(cz < 0 || g.nz <= cz);
-    }
+    // axis choice of :114-147 (strict <, ties fall to the later axis), written branch-free so the 64 rays of a wavefront
+    // do not serialise on three divergent bodies; only the chosen axis changes (incrementIndex, :192-203).
+    const bool x_first = tmx < tmy;
+    const bool ax = x_first && (tmx < tmz);
+    const bool ay = !x_first && (tmy < tmz);
+    const bool az = !(ax || ay);
+    cx += ax ? sx : 0;
+    cy += ay ? sy : 0;
+    cz += az ? sz : 0;
+    const float nx_t = iex + tdx * static_cast<float>(abs(cx - bx));
+    const float ny_t = iey + tdy * static_cast<float>(abs(cy - by));
+    const float nz_t = iez + tdz * static_cast<float>(abs(cz - bz));
+    tmx = ax ? nx_t : tmx;
+    tmy = ay ? ny_t : tmy;
+    tmz = az ? nz_t : tmz;
+    // only the moved index can have left the grid (the others were checked when they moved; begin is inside the map)
+    const bool inside = static_cast<unsigned>(cx) < static_cast<unsigned>(g.nx) &&
+                        static_cast<unsigned>(cy) < static_cast<unsigned>(g.ny) &&
+                        static_cast<unsigned>(cz) < static_cast<unsigned>(g.nz);
     if (!inside)
       break;
     if (STATS)
@@ -422,12 +427,17 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
       ++tr->n;
     }
     // hasIntersection, :237-258
-    const long long v = cx + static_cast<long long>(cy) * g.nx + static_cast<long long>(cz) * plane;
-    const uint32_t word = g.bits[v >> 5];
-    if (!((word >> (v & 31)) & 1u))
+    const int brick = ((cz >> 2) * g.bny + (cy >> 2)) * g.bnx + (cx >> 2);  // < 2^31 / 64 (total voxels < 2^31)
+    if (brick != cur_brick)
+    {
+      cur_brick = brick;
+      word = g.bricks[brick];
+    }
+    if (!((word >> (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1ull))
       continue;
     if (STATS)
       ++st_occ;
+    const int v = cx + cy * g.nx + cz * plane;  // getArrayIndex, :225-228 (int arithmetic there too)
     const uint32_t k0 = g.vox_start[v], k1 = g.vox_start[v + 1];
     int collided = -1;
     float4 cp = { 0, 0, 0, 0 };

@@ -337,7 +337,8 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
   const size_t total = static_cast<size_t>(total_d);
   std::vector<uint32_t> vox(n);
   std::vector<uint32_t> start(total + 1, 0);
-  std::vector<uint32_t> bits((total + 31) / 32 + 1, 0);
+  const int bdim[3] = { (dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4 };
+  std::vector<unsigned long long> bits(static_cast<size_t>(bdim[0]) * bdim[1] * bdim[2], 0ull);
   for (size_t i = 0; i < n; ++i)
   {
     int c[3];
@@ -348,7 +349,8 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
       return ctx->fail(-3, "map point %zu falls outside its own DDA grid", i);
     vox[i] = static_cast<uint32_t>(v);
     ++start[v + 1];
-    bits[v >> 5] |= 1u << (v & 31);
+    const size_t brick = (static_cast<size_t>(c[2] >> 2) * bdim[1] + (c[1] >> 2)) * bdim[0] + (c[0] >> 2);
+    bits[brick] |= 1ull << (((c[2] & 3) << 4) | ((c[1] & 3) << 2) | (c[0] & 3));
   }
   for (size_t v = 0; v < total; ++v)
     start[v + 1] += start[v];
@@ -362,17 +364,20 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
                            bits_to_float(ctx->map_label[i]));
     index[dst] = static_cast<uint32_t>(i);
   }
-  TRY(ensure(ctx, ctx->dda_bits, sizeof(uint32_t) * bits.size()));
+  TRY(ensure(ctx, ctx->dda_bits, sizeof(unsigned long long) * bits.size()));
   TRY(ensure(ctx, ctx->dda_start, sizeof(uint32_t) * (total + 1)));
   TRY(ensure(ctx, ctx->dda_pts, sizeof(float4) * n));
   TRY(ensure(ctx, ctx->dda_index, sizeof(uint32_t) * n));
-  TRY(h2d(ctx, ctx->dda_bits.p, bits.data(), sizeof(uint32_t) * bits.size()));
+  TRY(h2d(ctx, ctx->dda_bits.p, bits.data(), sizeof(unsigned long long) * bits.size()));
   TRY(h2d(ctx, ctx->dda_start.p, start.data(), sizeof(uint32_t) * (total + 1)));
   TRY(h2d(ctx, ctx->dda_pts.p, pts.data(), sizeof(float4) * n));
   TRY(h2d(ctx, ctx->dda_index.p, index.data(), sizeof(uint32_t) * n));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   DdaGrid& g = ctx->dg;
-  g.bits = ctx->dda_bits.as<uint32_t>();
+  g.bricks = ctx->dda_bits.as<unsigned long long>();
+  g.bnx = bdim[0];
+  g.bny = bdim[1];
+  g.bnz = bdim[2];
   g.vox_start = ctx->dda_start.as<uint32_t>();
   g.pts = ctx->dda_pts.as<float4>();
   g.pt_index = ctx->dda_index.as<uint32_t>();
@@ -391,7 +396,7 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
   const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];
   g.min_dist_thr_sq = gx * gx + gy * gy + gy * gy;
   g.hit_tolerance_f = static_cast<float>(static_cast<double>(ctx->hit_range));
-  ctx->footprint[2] = sizeof(uint32_t) * bits.size();
+  ctx->footprint[2] = sizeof(unsigned long long) * bits.size();
   ctx->footprint[3] = sizeof(uint32_t) * (total + 1);
   ctx->footprint[4] = sizeof(float4) * n + sizeof(uint32_t) * n;
   ctx->dda_dirty = false;
@@ -1060,13 +1065,29 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
       lik[k] = make_float4(scan_lik_xyz[3 * i], scan_lik_xyz[3 * i + 1], scan_lik_xyz[3 * i + 2], 0.f);
     }
   }
+  // beam scan: ordered by range from its scan origin. A ray walks ~range/dda_grid voxels and (its end point being a
+  // measured surface) ends near its last voxel, so the 64 rays of a wavefront finish together instead of idling behind the
+  // longest one. The beam score is a count of penalised rays, so the order is free.
   std::vector<float4> beam(n_b);
-  for (size_t i = 0; i < n_b; ++i)
+  if (n_b)
   {
-    const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
-    if (og >= n_o)
-      return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, og, n_o);
-    beam[i] = make_float4(scan_beam_xyz[3 * i], scan_beam_xyz[3 * i + 1], scan_beam_xyz[3 * i + 2], bits_to_float(og));
+    std::vector<std::pair<float, uint32_t>> keys(n_b);
+    for (size_t i = 0; i < n_b; ++i)
+    {
+      const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
+      if (og >= n_o)
+        return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, og, n_o);
+      const float dx = scan_beam_xyz[3 * i] - origins[3 * og], dy = scan_beam_xyz[3 * i + 1] - origins[3 * og + 1],
+                  dz = scan_beam_xyz[3 * i + 2] - origins[3 * og + 2];
+      keys[i] = { dx * dx + dy * dy + dz * dz, static_cast<uint32_t>(i) };
+    }
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < n_b; ++k)
+    {
+      const uint32_t i = keys[k].second;
+      const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
+      beam[k] = make_float4(scan_beam_xyz[3 * i], scan_beam_xyz[3 * i + 1], scan_beam_xyz[3 * i + 2], bits_to_float(og));
+    }
   }
   std::vector<float4> org(n_o);
   for (size_t i = 0; i < n_o; ++i)

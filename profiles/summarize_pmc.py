@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Collapse gpurun_out/prof_<tag>/pmc_*/<tag>_counter_collection.csv into profiles/<tag>_pmc_summary.csv (mean per launch
+per kernel) and copy the --stats kernel summary next to it.   usage: summarize_pmc.py <tag>"""
+import collections
+import csv
+import glob
+import shutil
+import sys
+
+tag = sys.argv[1]
+out = {}
+for f in sorted(glob.glob('gpurun_out/prof_%s/pmc_*/%s_counter_collection.csv' % (tag, tag))):
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0]
+        if 'mcl3dl' not in k:
+            continue
+        a = agg[k][r['Counter_Name']]
+        a[0] += float(r['Counter_Value'])
+        a[1] += 1
+    for k, cs in agg.items():
+        for c, (s, n) in cs.items():
+            out.setdefault(k, {})[c] = (s / n, n)
+w = csv.writer(open('profiles/%s_pmc_summary.csv' % tag, 'w'))
+w.writerow(["kernel", "counter", "mean_per_launch", "launches"])
+for k in sorted(out):
+    for c in sorted(out[k]):
+        w.writerow([k, c, "%.6g" % out[k][c][0], out[k][c][1]])
+shutil.copy('gpurun_out/prof_%s/stats/%s_kernel_stats.csv' % (tag, tag), 'profiles/%s_kernel_stats.csv' % tag)
+for k in out:
+    if len(sys.argv) > 2 and sys.argv[2] in k:
+        print(k, {c: "%.4g" % v[0] for c, v in out[k].items()})
