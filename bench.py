@@ -41,9 +41,32 @@ def parse():
                     help="2 = candidate records (default), 1 = candidate runs, 0 = 27-cell scan")
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
+    ap.add_argument("--lik-tiled", type=int, default=1)
+    ap.add_argument("--lik-group", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=1024, help="particles in the CPU-baseline sample")
     return ap.parse_args()
+
+
+def pmc_traffic(kernel_prefix, workload):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary for this workload
+    (profiles/*_pmc_summary.csv, produced by profiles/run_profiles.sh in separate --pmc passes): FETCH_SIZE and
+    WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes actually fetched (MI355X_MICROARCH.md, HBM
+    section), hence the factor 2."""
+    import csv
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s*_pmc_summary.csv" % workload))):
+        vals = {}
+        for row in csv.DictReader(open(path)):
+            if row["kernel"].startswith(kernel_prefix):
+                vals[row["counter"]] = float(row["mean_per_launch"])
+        if "FETCH_SIZE" in vals:
+            best = (path, vals)
+    if not best:
+        return None, None
+    path, vals = best
+    return (2.0 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024.0, os.path.relpath(path, ROOT)
 
 
 def cpu_baseline(sc, dist_weight, n_particles, beam_points):
@@ -111,6 +134,8 @@ def main():
     eng.set_option("lik_index", args.lik_index)
     eng.set_option("cand_voxel_ratio", args.cand_voxel_ratio)
     eng.set_option("cand_phase", args.cand_phase)
+    eng.set_option("lik_tiled", args.lik_tiled)
+    eng.set_option("lik_group", args.lik_group)
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
@@ -183,6 +208,10 @@ def main():
         lik_avg_ms = lik_ms / max(lik_n, 1)
         achieved = bytes_lik_launch / (lik_avg_ms * 1e-3) / 1e9 if lik_n else 0.0
         stats = d_stats.cpu().numpy()
+        tiled = bool(args.lik_tiled and n_s >= 1024 and n_p >= 64)
+        traffic, traffic_src = pmc_traffic("void mcl3dl::likelihood_tiled_kernel<%d, %d>" % (args.lik_group, args.lik_index)
+                                           if tiled else "void mcl3dl::likelihood_kernel<256, %d, false>" % args.lik_index,
+                                           args.workload)
         out = {
             "metric": "particle*point likelihood evals/sec (filter-update Hz @ 4096 particles x 16k-pt scan in config)",
             "value": value,
@@ -207,12 +236,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "likelihood_kernel<256,%d>" % args.lik_index,
+                "kernel": ("likelihood_tiled_kernel<%d,%d>" % (args.lik_group, args.lik_index)) if args.lik_tiled and n_s >= 1024 and n_p >= 64 else ("likelihood_kernel<256,%d>" % args.lik_index),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_lik_launch,
                 "bytes_per_eval": bytes_lik_launch / max(ws["evals"], 1.0),
                 "k_bar": k_bar,

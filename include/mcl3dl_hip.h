@@ -159,7 +159,10 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "lik_index"         2 (default) = candidate-voxel index, one 64-byte record per voxel; 1 = candidate-voxel index,
  *                       CSR runs; 0 = 27-cell scan of the cell-sorted map
  *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min (default 0.5)
- *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5) */
+ *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
+ *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points; 0 = one
+ *                       work-group per particle always (only the fp64 summation order differs)
+ *   "lik_group"         particles per work-group of the tiled kernel: 16 (default) or 32 */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,
  * [3] device build time in ms. */

@@ -300,6 +300,141 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tile-major variant for large scans: one work-group = one 256-point scan tile x G particles.
+//
+//  * the scan point of each lane stays in registers for all G particles; the G (normalised) poses are staged through
+//    LDS once per work-group and read back as broadcasts;
+//  * blockIdx -> (tile, particle group) is XCD-aware: work-groups are dispatched round-robin over the 8 XCDs
+//    (block b runs on XCD b % 8), so XCD x is given the tiles t == x (mod 8) and walks them one after the other over all
+//    particle groups. A tile is a spatially compact patch (Morton order), so the voxel records it touches under every
+//    particle pose (~1 MB) stay resident in that XCD's 4 MB L2 instead of every work-group sweeping the whole scan;
+//  * per-(particle, lane) float terms go to LDS and are summed in fp64 in a fixed order (deterministic), one partial per
+//    (tile, particle); lik_finalize_kernel adds the tiles in order.
+// Same per-point arithmetic as likelihood_kernel — identical terms — only the (fp64) summation order differs.
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
+                                                               const float4* __restrict__ scan, int n_s, int n_tiles,
+                                                               int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
+                                                               LikParams prm, double* __restrict__ partial_sum,
+                                                               unsigned* __restrict__ partial_cnt)
+{
+  __shared__ float s_pose[G][8];        // px,py,pz, qx,qy,qz,qw (normalised), valid
+  __shared__ float s_term[G][256];
+  __shared__ unsigned s_cnt[G][4];
+  const int xcd = blockIdx.x & 7;
+  const int seq = blockIdx.x >> 3;
+  const int tile = (seq / n_groups) * 8 + xcd;
+  const int group = seq % n_groups;
+  if (tile >= n_tiles)
+    return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < G)
+  {
+    const int p = group * G + t;
+    float v = 0.f;
+    if (p < n_p)
+    {
+      const float* ps = pose7 + 7 * static_cast<size_t>(p);
+      const Quat r = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });
+      s_pose[t][0] = ps[0];
+      s_pose[t][1] = ps[1];
+      s_pose[t][2] = ps[2];
+      s_pose[t][3] = r.x;
+      s_pose[t][4] = r.y;
+      s_pose[t][5] = r.z;
+      s_pose[t][6] = r.w;
+      v = 1.f;
+    }
+    s_pose[t][7] = v;
+  }
+  const int i = tile * 256 + t;
+  const bool have_point = i < n_s;
+  const float4 v = have_point ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int n_valid = min(G, n_p - group * G);
+  for (int k = 0; k < n_valid; ++k)
+  {
+    const Vec3f pos = { s_pose[k][0], s_pose[k][1], s_pose[k][2] };
+    const Quat rot = { s_pose[k][3], s_pose[k][4], s_pose[k][5], s_pose[k][6] };
+    float term = 0.f;
+    bool matched = false;
+    if (have_point)
+    {
+      const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+      float qx = tp.x, qy = tp.y, qz = tp.z;
+      if (prm.has_weight)
+      {
+        qx = tp.x * prm.wx;
+        qy = tp.y * prm.wy;
+        qz = tp.z * prm.wz;
+      }
+      unsigned dummy = 0;
+      const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
+                       MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
+                                   nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
+      if (d2 < prm.r2)
+      {
+        const float s = sqrtf(d2);
+        const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
+        if (!(dist < 0.0f))
+        {
+          term = dist * prm.match_weight;
+          matched = true;
+        }
+      }
+    }
+    s_term[k][t] = term;
+    const unsigned long long m = __ballot(matched);
+    if (lane == 0)
+      s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
+  }
+  __syncthreads();
+  // fixed-order fp64 reduction: 256 / G lanes per particle, each sums a contiguous segment (bank-rotated reads)
+  constexpr int LPP = 256 / G;        // lanes per particle
+  constexpr int SEG = 256 / LPP;      // = G terms per lane
+  const int pk = t / LPP, seg = t % LPP;
+  double acc = 0.0;
+  if (pk < n_valid)
+  {
+#pragma unroll 8
+    for (int j = 0; j < SEG; ++j)
+    {
+      const int jj = (j + t) % SEG;
+      acc += static_cast<double>(s_term[pk][seg * SEG + jj]);
+    }
+  }
+#pragma unroll
+  for (int off = LPP / 2; off > 0; off >>= 1)
+    acc += __shfl_down(acc, off, LPP);
+  if (seg == 0 && pk < n_valid)
+  {
+    const size_t o = static_cast<size_t>(tile) * n_p + (group * G + pk);
+    partial_sum[o] = acc;
+    partial_cnt[o] = s_cnt[pk][0] + s_cnt[pk][1] + s_cnt[pk][2] + s_cnt[pk][3];
+  }
+}
+
+__global__ void lik_finalize_kernel(const double* __restrict__ partial_sum, const unsigned* __restrict__ partial_cnt,
+                                    int n_tiles, int n_p, int n_s, float* __restrict__ out_lik,
+                                    float* __restrict__ out_ratio)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_p)
+    return;
+  double a = 0.0;
+  unsigned n = 0;
+  for (int tl = 0; tl < n_tiles; ++tl)
+  {
+    a += partial_sum[static_cast<size_t>(tl) * n_p + p];
+    n += partial_cnt[static_cast<size_t>(tl) * n_p + p];
+  }
+  if (out_lik)
+    out_lik[p] = static_cast<float>(a);
+  if (out_ratio)
+    out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
+}
+
 // n_s == 0: (likelihood 1, quality 0), src/lidar_measurement_model_likelihood.cpp:111-114
 __global__ void fill_kernel(float* a, float va, float* b, float vb, int n)
 {

@@ -74,6 +74,9 @@ struct mcl3dl_hip_ctx
   LikGrid lg{};
   // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
   int lik_index = 2;
+  int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
+  int lik_group = 16;      // particles per work-group of the tiled kernel (16 or 32)
+  DevBuf lik_partial_sum, lik_partial_cnt;
   double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
@@ -767,6 +770,45 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
         const float4* scan = ctx->scan_lik.as<float4>();
+        const bool tiled = ctx->lik_tiled && ns >= 1024 && np >= 64;
+        if (tiled)
+        {
+          const int G = ctx->lik_group;
+          const int n_tiles = (ns + 255) / 256, n_groups = (np + G - 1) / G;
+          const long long blocks = static_cast<long long>((n_tiles + 7) / 8) * 8 * n_groups;
+          if (blocks > 0x7fffffffLL)
+            return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
+          TRY(ensure(ctx, ctx->lik_partial_sum, sizeof(double) * static_cast<size_t>(n_tiles) * n_p));
+          TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(n_tiles) * n_p));
+#define LAUNCH_TILED(GG, MODE)                                                                                         \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
+                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
+                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>())
+          if (G == 32)
+          {
+            if (ctx->lik_index == 2)
+              LAUNCH_TILED(32, 2);
+            else if (ctx->lik_index == 1)
+              LAUNCH_TILED(32, 1);
+            else
+              LAUNCH_TILED(32, 0);
+          }
+          else
+          {
+            if (ctx->lik_index == 2)
+              LAUNCH_TILED(16, 2);
+            else if (ctx->lik_index == 1)
+              LAUNCH_TILED(16, 1);
+            else
+              LAUNCH_TILED(16, 0);
+          }
+#undef LAUNCH_TILED
+          hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
+                             ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
+                             d_lik, d_ratio);
+        }
+        else
+        {
 #define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
   hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), 0, ctx->stream, d_pose, scan, ns, \
                      ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr)
@@ -792,6 +834,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             LAUNCH_LIK(256, 0);
         }
 #undef LAUNCH_LIK
+        }
         TRY(timing_end(ctx, ep));
       }
     }
@@ -916,7 +959,7 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
+  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
                      &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
                      &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
                      &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
@@ -1429,6 +1472,18 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     if (value != ctx->cand_voxel_ratio)
       ctx->cand_dirty = true;
     ctx->cand_voxel_ratio = value;
+    return 0;
+  }
+  if (key == "lik_tiled")
+  {
+    ctx->lik_tiled = value != 0.0;
+    return 0;
+  }
+  if (key == "lik_group")
+  {
+    if (value != 16.0 && value != 32.0)
+      return ctx->fail(-3, "lik_group must be 16 or 32");
+    ctx->lik_group = static_cast<int>(value);
     return 0;
   }
   if (key == "cand_phase")
