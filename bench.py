@@ -126,7 +126,11 @@ def main():
     n_s, n_b = len(sc.scan_lik), len(sc.scan_beam)
 
     eng = capi.Engine(local_rank)
-    stream = torch.cuda.current_stream(dev)
+    # One explicit (non-null) stream carries everything in order: torch copies, the engine's kernels, the RCCL all-reduce.
+    # (torch's default stream has handle 0, which mcl3dl_hip_set_stream reads as "use the context's own stream".)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     eng.set_stream(stream.cuda_stream)
     t0 = time.time()
     eng.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=dist_weight)
@@ -212,6 +216,13 @@ def main():
         traffic, traffic_src = pmc_traffic("void mcl3dl::likelihood_tiled_kernel<%d, %d>" % (args.lik_group, args.lik_index)
                                            if tiled else "void mcl3dl::likelihood_kernel<256, %d, false>" % args.lik_index,
                                            args.workload)
+        # bytes the shipped index really reads per evaluation, priced against the measured L2 ceiling
+        # (MI355X_MICROARCH.md: ~34.5 TB/s aggregate): mode 2 = brick-table entry + one 64-byte voxel record
+        l2 = None
+        if lik_n and args.lik_index in (0, 2):
+            bpe = 68.0 if args.lik_index == 2 else bytes_lik_launch / max(ws["evals"], 1.0)
+            l2_gbps = ws["evals"] * bpe / (lik_avg_ms * 1e-3) / 1e9
+            l2 = {"bytes_per_eval": bpe, "achieved": l2_gbps, "peak": 34500.0, "unit": "GB/s", "frac": l2_gbps / 34500.0}
         out = {
             "metric": "particle*point likelihood evals/sec (filter-update Hz @ 4096 particles x 16k-pt scan in config)",
             "value": value,
@@ -248,8 +259,10 @@ def main():
                 "k_bar": k_bar,
                 "avg_launch_ms": lik_avg_ms,
                 "launches": lik_n,
-                "note": "map working set is L2/Infinity-Cache resident at this size: achieved can exceed what HBM "
-                        "alone could deliver; see DESIGN.md",
+                # what the shipped index really reads per evaluation (brick-table entry + one 64-byte voxel record;
+                # the 27-cell scan reads the canonical bytes above), priced against the measured L2 ceiling
+                # (MI355X_MICROARCH.md: ~34.5 TB/s aggregate)
+                "l2": l2,
             },
             "kernels_ms_per_step": {"likelihood": lik_avg_ms, "beam": beam_ms / max(beam_n, 1) if n_b else 0.0,
                                     "pf": 2.0 * pf_ms / max(pf_n, 1)},
@@ -259,10 +272,27 @@ def main():
             "result_check": {"entropy": float(stats[0]), "match_ratio_min": float(stats[1]),
                              "match_ratio_max": float(stats[2]), "restored": bool(stats[3])},
         }
+        # self-consistency of the numbers that were timed: normalised weights sum to 1 and reproduce the entropy
+        wf = d_w.cpu().numpy().astype(np.float64)
+        out["result_check"]["weight_sum"] = float(wf.sum())
+        out["result_check"]["entropy_from_weights"] = float(-(wf[wf > 0] * np.log(wf[wf > 0])).sum())
         if n_b:
             beam_avg = beam_ms / max(beam_n, 1)
             out["beam"] = {"rays_per_s": ws["rays"] / (beam_avg * 1e-3), "dda_steps_per_s": ws["dda_steps"] / (beam_avg * 1e-3),
                            "algorithmic_GBps": bytes_beam_launch / (beam_avg * 1e-3) / 1e9, "avg_launch_ms": beam_avg}
+        if world == 1:
+            # the drop-in boundary hands over HOST buffers: time the synchronous host entry point too (scan ordering on
+            # the host, H2D of scan + poses + weights, kernels, D2H of weights) — never part of `value`
+            eng.set_stream(None)
+            eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            t2 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            host_ms = (time.perf_counter() - t2) / reps * 1e3
+            out["host_api"] = {"ms_per_update": host_ms, "evals_per_s": n_p * n_s / (host_ms * 1e-3),
+                               "note": "mcl3dl_hip_measure_update with host buffers (PCIe + host-side scan ordering included)"}
+            eng.set_stream(stream.cuda_stream)
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_lik, cpu_q = cpu_baseline(sc, dist_weight, args.cpu_particles, n_b)
             out["cpu_baseline"] = cb

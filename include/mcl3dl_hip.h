@@ -54,7 +54,8 @@ int mcl3dl_hip_abi_version(void);
 int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id);
 void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx);
 const char* mcl3dl_hip_last_error(const mcl3dl_hip_ctx* ctx);
-/* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own stream. */
+/* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own (non-blocking)
+ * stream. To run on the legacy default stream pass hipStreamLegacy, not NULL. */
 int mcl3dl_hip_set_stream(mcl3dl_hip_ctx* ctx, void* hip_stream);
 void* mcl3dl_hip_get_stream(mcl3dl_hip_ctx* ctx);
 int mcl3dl_hip_synchronize(mcl3dl_hip_ctx* ctx);
