@@ -98,7 +98,6 @@ def main():
     import torch
     import torch.distributed as dist
     from mcl_3dl_amd import capi
-    from mcl_3dl_amd.distributed import allreduce_partials
     from mcl_3dl_amd.synthetic import CONFIGS, make_config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,8 +148,6 @@ def main():
     d_lik = torch.empty(n_p, dtype=torch.float32, device=dev)
     d_ratio = torch.empty(n_p, dtype=torch.float32, device=dev)
     d_beam = torch.empty(n_p, dtype=torch.float32, device=dev)
-    d_partial = torch.zeros(4, dtype=torch.float64, device=dev)
-    d_total = torch.zeros(4, dtype=torch.float64, device=dev)
     d_stats = torch.zeros(4, dtype=torch.float32, device=dev)
     # one all-reduce(SUM) carries the sums and, in per-rank slots, the max/min candidates
     d_pack = torch.zeros(2 + 2 * world, dtype=torch.float64, device=dev)
@@ -158,12 +155,10 @@ def main():
     def step():
         d_w.copy_(d_w0)  # resampling leaves uniform weights before every update (pf.h:203,207)
         eng.measure_device(d_pose, n_p, d_lik, d_ratio, d_beam if n_b else None)
-        eng.pf_partial_device(d_w, d_lik, d_beam if n_b else None, None, d_ratio, n_p, d_partial)
+        eng.pf_partial_device(d_w, d_lik, d_beam if n_b else None, None, d_ratio, n_p, d_pack, rank, world)
         if world > 1:
-            allreduce_partials(d_partial, scratch=d_pack, out=d_total)  # the update's single collective (RCCL)
-            eng.pf_apply_device(d_w, n_p, d_total, d_stats)
-        else:
-            eng.pf_apply_device(d_w, n_p, d_partial, d_stats)
+            dist.all_reduce(d_pack, op=dist.ReduceOp.SUM)  # the update's single collective (RCCL over xGMI), 16+16*N bytes
+        eng.pf_apply_device(d_w, n_p, d_pack, d_stats, world)
 
     # first call builds + uploads the map structures (outside every timed region)
     step()

@@ -132,16 +132,18 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
 /* measure_batch on device-resident poses against the uploaded scans; outputs are device arrays (may be NULL). */
 int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose /*n_p*7*/, size_t n_p, float* d_lik,
                               float* d_match_ratio, float* d_beam);
-/* pf::measure split for particle shards (one context per GPU):
- *   partial: w_new = w*((1*beam)*lik)*extra kept in the context; d_partial4 = { sum w_new, sum w_new*ln(w_new),
- *            max match_ratio, -min match_ratio } (doubles, this shard only)
- *   [all-reduce d_partial4 across shards: sum for [0],[1]; max for [2],[3]]
- *   apply:   weights = w_new / total[0] if total[0] > 0, else untouched; d_stats4 = { entropy, match_ratio_min,
+/* pf::measure split for particle shards (one context per GPU, `world` shards, this one is `rank`):
+ *   partial: w_new = w*((1*beam)*lik)*extra kept in the context; d_packed[2 + 2*world] (doubles) = { sum w_new,
+ *            sum w_new*ln(w_new), then per rank r: max match_ratio, -min match_ratio } with only THIS rank's pair filled
+ *            (the others 0)
+ *   [one all-reduce(SUM) of d_packed across the shards — the update's only collective; nothing to do for world == 1]
+ *   apply:   weights = w_new / packed[0] if packed[0] > 0, else untouched; d_stats4 = { entropy, match_ratio_min,
  *            match_ratio_max, restored } with entropy = ln S - T/S (== -sum p ln p). */
 int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, const float* d_lik, const float* d_beam,
-                                 const float* d_extra, const float* d_match_ratio, size_t n_p, double* d_partial4);
-int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, const double* d_total4,
-                               float* d_stats4);
+                                 const float* d_extra, const float* d_match_ratio, size_t n_p, int rank, int world,
+                                 double* d_packed);
+int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, int world,
+                               const double* d_packed, float* d_stats4);
 
 /* ---- measurement support ------------------------------------------------------------------------------ */
 /* Per-kernel hipEvent timing on the launch stream (off by default). */

@@ -35,8 +35,8 @@ SIGNATURES = {
     "mcl3dl_hip_dda_trace": (_i, [_p, _p, _p, _p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
     "mcl3dl_hip_measure_device": (_i, [_p, _p, _sz, _p, _p, _p]),
-    "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p]),
-    "mcl3dl_hip_pf_apply_device": (_i, [_p, _p, _sz, _p, _p]),
+    "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
+    "mcl3dl_hip_pf_apply_device": (_i, [_p, _p, _sz, _i, _p, _p]),
     "mcl3dl_hip_set_kernel_timing": (_i, [_p, _i]),
     "mcl3dl_hip_get_kernel_time": (_i, [_p, _i, C.POINTER(_d), C.POINTER(_u64)]),
     "mcl3dl_hip_reset_kernel_time": (_i, [_p]),
@@ -217,12 +217,15 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_measure_device(self.h, _ptr(d_pose), n_p, _ptr(d_lik), _ptr(d_ratio),
                                                        _ptr(d_beam)))
 
-    def pf_partial_device(self, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_partial4):
+    def pf_partial_device(self, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_packed, rank=0, world=1):
+        """d_packed: 2 + 2*world float64 on the device, ready for all_reduce(SUM) (see mcl_3dl_amd/distributed.py)."""
         self._check(self.lib.mcl3dl_hip_pf_partial_device(self.h, _ptr(d_weight), _ptr(d_lik), _ptr(d_beam),
-                                                          _ptr(d_extra), _ptr(d_ratio), n_p, _ptr(d_partial4)))
+                                                          _ptr(d_extra), _ptr(d_ratio), n_p, int(rank), int(world),
+                                                          _ptr(d_packed)))
 
-    def pf_apply_device(self, d_weight, n_p, d_total4, d_stats4):
-        self._check(self.lib.mcl3dl_hip_pf_apply_device(self.h, _ptr(d_weight), n_p, _ptr(d_total4), _ptr(d_stats4)))
+    def pf_apply_device(self, d_weight, n_p, d_packed, d_stats4, world=1):
+        self._check(self.lib.mcl3dl_hip_pf_apply_device(self.h, _ptr(d_weight), n_p, int(world), _ptr(d_packed),
+                                                        _ptr(d_stats4)))
 
     # ---- measurement support -----------------------------------------------------------------------------------
     def set_kernel_timing(self, enable):

@@ -763,9 +763,12 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __res
   }
 }
 
-// Fixed-order reduction of the block partials (deterministic run to run).
-__global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict__ block_partials, int n_blocks,
-                                                       double* __restrict__ partial4)
+// Fixed-order reduction of the block partials (deterministic run to run). The result is written in the layout the
+// update's single all-reduce(SUM) needs (mcl_3dl_amd/distributed.py): [0] sum w, [1] sum w ln w, then per rank r the pair
+// [2+2r] max ratio, [3+2r] -min ratio — this rank fills its own pair and zeroes the others, so that after the SUM every
+// rank holds every rank's pair. world == 1 degenerates to the plain 4 doubles.
+__global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict__ block_partials, int n_blocks, int rank,
+                                                       int world, double* __restrict__ packed)
 {
   double a = 0, b = 0, c = 0.0, d = -1.0;
   for (int k = threadIdx.x; k < n_blocks; k += 64)
@@ -781,19 +784,23 @@ __global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict_
   d = wave_max(d);
   if (threadIdx.x == 0)
   {
-    partial4[0] = a;
-    partial4[1] = b;
-    partial4[2] = c;
-    partial4[3] = d;
+    packed[0] = a;
+    packed[1] = b;
+    for (int r = 0; r < world; ++r)
+    {
+      packed[2 + 2 * r] = (r == rank) ? c : 0.0;
+      packed[3 + 2 * r] = (r == rank) ? d : 0.0;
+    }
   }
 }
 
 // Normalise (pf.h:262-272) or restore (pf.h:274-278); entropy = ln S - T/S == -sum (w/S) ln (w/S).
+// `packed` is the (all-reduced) vector described above.
 __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ w, const float* __restrict__ w_new,
-                                                            int n, const double* __restrict__ total4,
+                                                            int n, int world, const double* __restrict__ packed,
                                                             float* __restrict__ stats4)
 {
-  const double S = total4[0];
+  const double S = packed[0];
   const float sum_f = static_cast<float>(S);
   const bool alive = sum_f > 0.0f;
   if (alive)
@@ -803,9 +810,17 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats4)
   {
-    stats4[0] = alive ? static_cast<float>(log(S) - total4[1] / S) : __builtin_nanf("");
-    stats4[1] = static_cast<float>(-total4[3]);
-    stats4[2] = static_cast<float>(total4[2]);
+    // every rank's slot holds a value in [0,1] resp. [-1,0] (0 in both for a rank whose shard saw no ratios is impossible:
+    // an empty shard reports max 0 / -min -1); the maxima over the slots are the global max ratio and -min ratio
+    double rmax = packed[2], rneg = packed[3];
+    for (int r = 1; r < world; ++r)
+    {
+      rmax = packed[2 + 2 * r] > rmax ? packed[2 + 2 * r] : rmax;
+      rneg = packed[3 + 2 * r] > rneg ? packed[3 + 2 * r] : rneg;
+    }
+    stats4[0] = alive ? static_cast<float>(log(S) - packed[1] / S) : __builtin_nanf("");
+    stats4[1] = static_cast<float>(-rneg);
+    stats4[2] = static_cast<float>(rmax);
     stats4[3] = alive ? 0.0f : 1.0f;
   }
 }

@@ -1187,12 +1187,15 @@ int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n
 }
 
 int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, const float* d_lik, const float* d_beam,
-                                 const float* d_extra, const float* d_match_ratio, size_t n_p, double* d_partial4)
+                                 const float* d_extra, const float* d_match_ratio, size_t n_p, int rank, int world,
+                                 double* d_packed)
 {
   if (!ctx)
     return -1;
   if (n_p == 0 || n_p > 0x7fffffffu)
     return ctx->fail(-3, "bad particle count");
+  if (world < 1 || rank < 0 || rank >= world || world > 4096)
+    return ctx->fail(-3, "bad rank/world (%d/%d)", rank, world);
   HIP_TRY(hipSetDevice(ctx->device));
   const int nb = pf_blocks(n_p);
   TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
@@ -1201,25 +1204,27 @@ int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, con
   TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
   hipLaunchKernelGGL(pf_partial_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
                      d_match_ratio, static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
-  hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb,
-                     d_partial4);
+  hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank,
+                     world, d_packed);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, const double* d_total4,
-                               float* d_stats4)
+int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, int world,
+                               const double* d_packed, float* d_stats4)
 {
   if (!ctx)
     return -1;
   if (n_p == 0 || n_p > 0x7fffffffu)
     return ctx->fail(-3, "bad particle count");
+  if (world < 1 || world > 4096)
+    return ctx->fail(-3, "bad world size %d", world);
   HIP_TRY(hipSetDevice(ctx->device));
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
   hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight_inout,
-                     ctx->wnew.as<float>(), static_cast<int>(n_p), d_total4, d_stats4);
+                     ctx->wnew.as<float>(), static_cast<int>(n_p), world, d_packed, d_stats4);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1286,8 +1291,8 @@ int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float*
     TRY(h2d(ctx, ctx->ratio.p, match_ratio, fb));
   TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(),
                                    beam ? ctx->beam.as<float>() : nullptr, extra ? ctx->extra.as<float>() : nullptr,
-                                   match_ratio ? ctx->ratio.as<float>() : nullptr, n_p, ctx->partial4.as<double>()));
-  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, ctx->partial4.as<double>(),
+                                   match_ratio ? ctx->ratio.as<float>() : nullptr, n_p, 0, 1, ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, 1, ctx->partial4.as<double>(),
                                  ctx->stats4.as<float>()));
   float st[4];
   TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
@@ -1334,9 +1339,9 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
   TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, ctx->lik.as<float>(), ctx->ratio.as<float>(),
                      ctx->beam.as<float>(), false, nullptr));
   TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
-                                   extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p,
+                                   extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p, 0, 1,
                                    ctx->partial4.as<double>()));
-  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, ctx->partial4.as<double>(),
+  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, 1, ctx->partial4.as<double>(),
                                  ctx->stats4.as<float>()));
   float st[4];
   TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));

@@ -266,3 +266,52 @@ def test_tiled_kernel_matches_per_particle_kernel(engine, oracle_kind, group, mo
     wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
     np.testing.assert_allclose(lik1, wl, rtol=RTOL)
     np.testing.assert_array_equal(ratio1, wq)
+
+
+def test_sharded_update_protocol_on_one_gpu(engine, oracle_kind, scene_c1):
+    """The multi-GPU protocol (particle shards, packed partials, ONE all-reduce(SUM), apply) with the collective emulated
+    by a tensor add: two shards of unequal size must reproduce the unsharded update and the CPU reference."""
+    import torch
+    from mcl_3dl_amd.distributed import shard_bounds
+    sc = scene_c1
+    dev = torch.device("cuda", 0)
+    kw = dict(num_points=96)
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=50, beam_kw=kw)
+    engine.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    n = len(sc.poses)
+    rng = np.random.default_rng(8)
+    w0 = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    w0 /= w0.sum()
+    world = 3
+    shards = []
+    packed_sum = torch.zeros(2 + 2 * world, dtype=torch.float64, device=dev)
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        m = hi - lo
+        t = dict(pose=torch.from_numpy(sc.poses[lo:hi].copy()).to(dev), w=torch.from_numpy(w0[lo:hi].copy()).to(dev),
+                 lik=torch.empty(m, device=dev), ratio=torch.empty(m, device=dev), beam=torch.empty(m, device=dev),
+                 pack=torch.zeros(2 + 2 * world, dtype=torch.float64, device=dev), stats=torch.zeros(4, device=dev), m=m)
+        engine.measure_device(t["pose"], m, t["lik"], t["ratio"], t["beam"])
+        engine.pf_partial_device(t["w"], t["lik"], t["beam"], None, t["ratio"], m, t["pack"], rank=r, world=world)
+        engine.synchronize()
+        # each rank applies right after the collective in real use; the engine keeps w_new per call, so apply per shard
+        # needs the reduced vector first: emulate by computing all partials, then re-running partial before each apply
+        packed_sum += t["pack"]
+        shards.append(t)
+    got_w = []
+    for r, t in enumerate(shards):
+        engine.pf_partial_device(t["w"], t["lik"], t["beam"], None, t["ratio"], t["m"], t["pack"], rank=r, world=world)
+        engine.pf_apply_device(t["w"], t["m"], packed_sum, t["stats"], world=world)
+        engine.synchronize()
+        got_w.append(t["w"].cpu().numpy())
+    got_w = np.concatenate(got_w)
+    stats = [t["stats"].cpu().numpy() for t in shards]
+    o = make_oracle(oracle_kind, sc, (1.0, 1.0, 1.0), beam_kw=kw)
+    want = o.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    np.testing.assert_allclose(got_w, want["weights"], rtol=RTOL)
+    for s in stats:  # every shard derives the same global statistics
+        np.testing.assert_allclose(s[0], want["entropy"], rtol=RTOL)
+        assert s[1] == np.float32(want["match_ratio_min"]) and s[2] == np.float32(want["match_ratio_max"])
+        assert s[3] == 0.0
+    whole = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+    np.testing.assert_allclose(got_w, whole["weights"], rtol=2e-7)
