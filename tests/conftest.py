@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch first: its HIP runtime and libmcl3dl_hip.so's must be the same instance when device pointers are shared
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - CPU-only environments without torch
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
