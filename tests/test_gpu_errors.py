@@ -1,0 +1,115 @@
+"""GPU tests of the C ABI's error behaviour and odd inputs (no exceptions across the boundary, negative
+codes + mcl3dl_hip_last_error; the reference's own edge cases for empty / invalid data)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mcl_3dl_amd import capi
+from mcl_3dl_amd.synthetic import make_scene
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fresh():
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def test_measure_without_map_is_an_error(fresh):
+    sc = make_scene(n=21, n_p=4, n_s=16)
+    with pytest.raises(capi.EngineError, match="no map"):
+        fresh.measure_batch(sc.poses, sc.scan_lik)
+    # the context stays usable after an error
+    fresh.set_map(sc.map_xyz, sc.map_label)
+    lik, ratio, beam = fresh.measure_batch(sc.poses, sc.scan_lik)
+    assert np.all(np.isfinite(lik))
+
+
+def test_bad_arguments_return_codes(fresh):
+    lib = fresh.lib
+    assert lib.mcl3dl_hip_set_map(fresh.h, None, None, 0, 1, None) != 0
+    assert b"empty map" in lib.mcl3dl_hip_last_error(fresh.h)
+    assert lib.mcl3dl_hip_set_likelihood_params(fresh.h, -1.0, 0.05, 5.0) != 0
+    assert lib.mcl3dl_hip_set_beam_params(fresh.h, 0.1, 0.1, 0.1, 0.0, 0.004, 0.3, 0.2, 3, 0.5, 0xFFFFFFFF, 1) != 0
+    assert lib.mcl3dl_hip_set_option(fresh.h, b"no_such_option", 1.0) != 0
+    assert lib.mcl3dl_hip_set_option(fresh.h, b"lik_index", 7.0) != 0
+    assert lib.mcl3dl_hip_get_kernel_time(fresh.h, 99, None, None) != 0
+    # null context: negative, never a crash
+    assert lib.mcl3dl_hip_synchronize(None) != 0
+    assert lib.mcl3dl_hip_measure_device(None, None, 0, None, None, None) != 0
+    lib.mcl3dl_hip_destroy(None)
+    out = C.c_void_p()
+    assert lib.mcl3dl_hip_create(C.byref(out), 12345) != 0 and not out  # no such device
+
+
+def test_beam_origin_out_of_range(fresh):
+    sc = make_scene(n=21, n_p=4, n_s=16, n_b=8)
+    fresh.set_map(sc.map_xyz, sc.map_label)
+    bad = sc.scan_beam_label.copy()
+    bad[3] = 5
+    with pytest.raises(capi.EngineError, match="origin"):
+        fresh.measure_batch(sc.poses, None, sc.scan_beam, bad, sc.origins)
+
+
+def test_zero_particles_is_a_no_op(fresh):
+    sc = make_scene(n=21, n_p=4, n_s=16)
+    fresh.set_map(sc.map_xyz, sc.map_label)
+    lik, ratio, beam = fresh.measure_batch(np.zeros((0, 7), np.float32), sc.scan_lik)
+    assert len(lik) == 0
+
+
+def test_non_finite_scan_points_do_not_match(fresh, oracle_kind):
+    """NaN / Inf scan coordinates find no neighbour (FLANN returns nothing for them) but still count in the quality
+    denominator (likelihood.cpp:136)."""
+    sc = make_scene(n=41, n_p=8, n_s=64)
+    fresh.set_map(sc.map_xyz, sc.map_label)
+    scan = sc.scan_lik.copy()
+    scan[5] = np.nan
+    scan[9, 1] = np.inf
+    scan[11] = 1e30
+    lik, ratio, _ = fresh.measure_batch(sc.poses, scan)
+    o = pyoracle.Oracle(oracle_kind)
+    o.set_map(sc.map_xyz, sc.map_label)
+    o.set_likelihood_params(pyoracle.LikelihoodParams())
+    wl, wq = o.likelihood_measure(sc.poses, scan)
+    np.testing.assert_allclose(lik, wl, rtol=1e-5)
+    np.testing.assert_array_equal(ratio, wq)
+    assert np.all(np.isfinite(lik))
+
+
+def test_map_replaced_and_stamp_semantics(fresh, oracle_kind):
+    """A new map (new stamp) replaces every device structure; results follow the new map."""
+    a = make_scene(n=41, n_p=8, n_s=64, n_b=8, seed=1)
+    b = make_scene(n=61, n_p=8, n_s=64, n_b=8, seed=2)
+    for stamp, sc in ((1, a), (2, b), (3, a)):
+        fresh.set_map(sc.map_xyz, sc.map_label, stamp=stamp)
+        fresh.set_beam_params(num_points=8)
+        lik, ratio, beam = fresh.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+        o = pyoracle.Oracle(oracle_kind)
+        o.set_map(sc.map_xyz, sc.map_label)
+        o.set_likelihood_params(pyoracle.LikelihoodParams())
+        o.set_beam_params(pyoracle.BeamParams(num_points=8))
+        wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
+        wb, _ = o.beam_measure(sc.poses, sc.scan_beam, sc.scan_beam_label, sc.origins)
+        np.testing.assert_allclose(lik, wl, rtol=1e-5)
+        np.testing.assert_array_equal(ratio, wq)
+        np.testing.assert_array_equal(beam, wb)
+
+
+def test_two_contexts_are_independent():
+    a, b = capi.Engine(0), capi.Engine(0)
+    sa = make_scene(n=41, n_p=8, n_s=64, seed=1)
+    sb = make_scene(n=61, n_p=8, n_s=64, seed=2)
+    a.set_map(sa.map_xyz, sa.map_label)
+    b.set_map(sb.map_xyz, sb.map_label)
+    la1, _, _ = a.measure_batch(sa.poses, sa.scan_lik)
+    lb, _, _ = b.measure_batch(sb.poses, sb.scan_lik)
+    la2, _, _ = a.measure_batch(sa.poses, sa.scan_lik)
+    np.testing.assert_array_equal(la1, la2)
+    assert not np.array_equal(la1, lb)
+    a.close()
+    b.close()
