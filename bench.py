@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
     ap.add_argument("--lik-group", type=int, default=16)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=1024, help="particles in the CPU-baseline sample")
     return ap.parse_args()
@@ -110,8 +112,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = CONFIGS[args.workload]
@@ -156,7 +162,7 @@ def main():
         d_w.copy_(d_w0)  # resampling leaves uniform weights before every update (pf.h:203,207)
         eng.measure_device(d_pose, n_p, d_lik, d_ratio, d_beam if n_b else None)
         eng.pf_partial_device(d_w, d_lik, d_beam if n_b else None, None, d_ratio, n_p, d_pack, rank, world)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(d_pack, op=dist.ReduceOp.SUM)  # the update's single collective (RCCL over xGMI), 16+16*N bytes
         eng.pf_apply_device(d_w, n_p, d_pack, d_stats, world)
 
@@ -180,14 +186,14 @@ def main():
         step()
     eng.set_kernel_timing(True)
     eng.reset_kernel_time()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t1
     lik_ms, lik_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
@@ -196,7 +202,7 @@ def main():
     eng.set_kernel_timing(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -300,7 +306,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
