@@ -145,6 +145,28 @@ int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, con
 int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, int world,
                                const double* d_packed, float* d_stats4);
 
+/* ---- "next" row: the reductions right after the measurement update ---------------------- */
+/* Replaces: pf::ParticleFilter::expectationBiased (include/mcl_3dl/pf.h:294-303, called at src/mcl_3dl.cpp:451) with
+ * ParticleWeightedMeanQuat (include/mcl_3dl/state_6dof.h:316-355), and max() / maxBiased() (pf.h:361-390, :452).
+ * bias NULL = probability_bias_ 1 (= expectation over all particles). out_mean7 = px,py,pz,qx,qy,qz,qw;
+ * out_total = sum of weight*bias; the max indices are those of the FIRST maximum (strict < in the reference).
+ * Per-particle products are the reference's float expressions; sums are fp64 trees (reference: float sequential). */
+int mcl3dl_hip_expectation(mcl3dl_hip_ctx* ctx, const float* pose /*n*7*/, const float* weight /*n*/,
+                           const float* bias /*n or NULL*/, size_t n, float* out_mean7, float* out_total,
+                           int32_t* out_max_index, int32_t* out_max_biased_index);
+/* Replaces: pf::ParticleFilter::covariance (pf.h:304-360, called at src/mcl_3dl.cpp:373,706) with
+ * State6DOF::covElement (state_6dof.h:162-184) about `mean7` (the caller's expectation). subset = the particle indices
+ * the caller's RNG drew for random_sample_ratio < 1 (pf.h:322-336), or NULL = all n particles. out_cov36 row-major. */
+int mcl3dl_hip_covariance(mcl3dl_hip_ctx* ctx, const float* pose /*n*7*/, const float* weight /*n*/, size_t n,
+                          const uint32_t* subset /*n_subset or NULL*/, size_t n_subset, const float* mean7,
+                          float* out_cov36);
+/* The same on device-resident poses / weights (results still returned to the host: they are a dozen scalars). */
+int mcl3dl_hip_expectation_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const float* d_weight, const float* d_bias,
+                                  size_t n, float* out_mean7, float* out_total, int32_t* out_max_index,
+                                  int32_t* out_max_biased_index);
+int mcl3dl_hip_covariance_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const float* d_weight, size_t n_particles,
+                                 const uint32_t* d_subset, size_t n_subset, const float* mean7, float* out_cov36);
+
 /* ---- measurement support ------------------------------------------------------------------------------ */
 /* Per-kernel hipEvent timing on the launch stream (off by default). */
 int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable);

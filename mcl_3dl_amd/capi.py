@@ -33,6 +33,10 @@ SIGNATURES = {
     "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
     "mcl3dl_hip_dda_trace": (_i, [_p, _p, _p, _p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "mcl3dl_hip_expectation": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
+    "mcl3dl_hip_covariance": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
+    "mcl3dl_hip_expectation_device": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
+    "mcl3dl_hip_covariance_device": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
     "mcl3dl_hip_measure_device": (_i, [_p, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
@@ -197,6 +201,27 @@ class Engine:
         hit = np.zeros(len(b), np.int32)
         self._check(self.lib.mcl3dl_hip_beam_status(self.h, _ptr(b), _ptr(e), len(b), _ptr(st), _ptr(hit)))
         return st, hit
+
+    def expectation(self, poses, weights, bias=None):
+        poses = _np_f32(poses, 7)
+        w = _np_f32(weights)
+        b = None if bias is None else _np_f32(bias)
+        mean = np.zeros(7, np.float32)
+        total = C.c_float(0)
+        im, ib = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.mcl3dl_hip_expectation(self.h, _ptr(poses), _ptr(w), _ptr(b), len(poses), _ptr(mean),
+                                                    C.byref(total), C.byref(im), C.byref(ib)))
+        return mean, float(total.value), int(im.value), int(ib.value)
+
+    def covariance(self, poses, weights, mean7, subset=None):
+        poses = _np_f32(poses, 7)
+        w = _np_f32(weights)
+        m = _np_f32(mean7)
+        sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.uint32)
+        cov = np.zeros((6, 6), np.float32)
+        self._check(self.lib.mcl3dl_hip_covariance(self.h, _ptr(poses), _ptr(w), len(poses), _ptr(sub),
+                                                   0 if sub is None else len(sub), _ptr(m), _ptr(cov)))
+        return cov
 
     def dda_trace(self, begin, end, max_out=4096):
         b = _np_f32(begin)

@@ -824,4 +824,208 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
     stats4[3] = alive ? 0.0f : 1.0f;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// "Next" row: the reductions that follow pf::measure in the node (src/mcl_3dl.cpp:451-452,706-709):
+// pf::expectationBiased / max / maxBiased (include/mcl_3dl/pf.h:294-303,361-390) with ParticleWeightedMeanQuat
+// (include/mcl_3dl/state_6dof.h:316-355), and pf::covariance (pf.h:304-360) with State6DOF::covElement (:162-184).
+// Per-particle products are the reference's float expressions; the sums are fp64 trees (reference: float sequential).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MOM_N = 10;  // p_sum, pos[3], front[3], up[3]
+
+struct ArgMax
+{
+  float v;
+  int i;
+};
+__device__ inline ArgMax argmax_better(ArgMax a, ArgMax b)
+{
+  // pf.h:365-372: `if (max_probability < p.probability_)` -> the FIRST maximum wins
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void pf_moments_kernel(const float* __restrict__ pose7,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int n,
+                                                              double* __restrict__ block_mom /*[grid][MOM_N]*/,
+                                                              ArgMax* __restrict__ block_arg /*[grid][2]*/)
+{
+  double m[MOM_N];
+#pragma unroll
+  for (int k = 0; k < MOM_N; ++k)
+    m[k] = 0.0;
+  ArgMax am = { -1.0f, 0x7fffffff }, ab = { -1.0f, 0x7fffffff };
+  bool first = true;
+  for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+  {
+    const float* ps = pose7 + 7 * static_cast<size_t>(i);
+    const float prob = w[i] * (bias ? bias[i] : 1.0f);  // pf.h:300
+    const Quat rot = { ps[3], ps[4], ps[5], ps[6] };
+    const Vec3f front = vscale(qrot(rot, Vec3f{ 1.0f, 0.0f, 0.0f }), prob);  // state_6dof.h:337-338
+    const Vec3f up = vscale(qrot(rot, Vec3f{ 0.0f, 0.0f, 1.0f }), prob);
+    m[0] += static_cast<double>(prob);
+    m[1] += static_cast<double>(ps[0] * prob);  // e_.pos_ += e1.pos_ * prob, :335
+    m[2] += static_cast<double>(ps[1] * prob);
+    m[3] += static_cast<double>(ps[2] * prob);
+    m[4] += static_cast<double>(front.x);
+    m[5] += static_cast<double>(front.y);
+    m[6] += static_cast<double>(front.z);
+    m[7] += static_cast<double>(up.x);
+    m[8] += static_cast<double>(up.y);
+    m[9] += static_cast<double>(up.z);
+    const ArgMax cm = { w[i], i }, cb = { prob, i };
+    am = first ? cm : argmax_better(am, cm);
+    ab = first ? cb : argmax_better(ab, cb);
+    first = false;
+  }
+  __shared__ double sh[MOM_N][PF_BLOCK / 64];
+  __shared__ ArgMax sa[2][PF_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < MOM_N; ++k)
+  {
+    const double s = wave_sum(m[k]);
+    if (lane == 0)
+      sh[k][wave] = s;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    ArgMax o1 = { __shfl_down(am.v, off, 64), __shfl_down(am.i, off, 64) };
+    ArgMax o2 = { __shfl_down(ab.v, off, 64), __shfl_down(ab.i, off, 64) };
+    am = argmax_better(am, o1);
+    ab = argmax_better(ab, o2);
+  }
+  if (lane == 0)
+  {
+    sa[0][wave] = am;
+    sa[1][wave] = ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int k = 0; k < MOM_N; ++k)
+    {
+      double s = 0;
+      for (int q = 0; q < PF_BLOCK / 64; ++q)
+        s += sh[k][q];
+      block_mom[MOM_N * blockIdx.x + k] = s;
+    }
+    ArgMax a = sa[0][0], b = sa[1][0];
+    for (int q = 1; q < PF_BLOCK / 64; ++q)
+    {
+      a = argmax_better(a, sa[0][q]);
+      b = argmax_better(b, sa[1][q]);
+    }
+    block_arg[2 * blockIdx.x + 0] = a;
+    block_arg[2 * blockIdx.x + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(64) void pf_moments_reduce_kernel(const double* __restrict__ block_mom,
+                                                               const ArgMax* __restrict__ block_arg, int n_blocks,
+                                                               double* __restrict__ out_mom /*[MOM_N]*/,
+                                                               int* __restrict__ out_arg /*[2]*/)
+{
+  if (threadIdx.x < MOM_N)
+  {
+    double s = 0;
+    for (int b = 0; b < n_blocks; ++b)  // fixed order
+      s += block_mom[MOM_N * b + threadIdx.x];
+    out_mom[threadIdx.x] = s;
+  }
+  if (threadIdx.x == 32 || threadIdx.x == 33)
+  {
+    const int which = threadIdx.x - 32;
+    ArgMax a = block_arg[which];
+    for (int b = 1; b < n_blocks; ++b)
+      a = argmax_better(a, block_arg[2 * b + which]);
+    out_arg[which] = a.i;
+  }
+}
+
+// Quat::getRPY, include/mcl_3dl/quat.h:188-203 (float storage, double intermediates; device atan2f / asinf)
+__host__ __device__ inline Vec3f quat_get_rpy(Quat q)
+{
+  const float ysq = q.y * q.y;
+  const float t0 = static_cast<float>(-2.0 * (ysq + q.z * q.z) + 1.0);
+  const float t1 = static_cast<float>(+2.0 * (q.x * q.y + q.w * q.z));
+  const double t2d = -2.0 * (q.x * q.z - q.w * q.y);
+  const float t2 = static_cast<float>(t2d > 1.0 ? 1.0 : (t2d < -1.0 ? -1.0 : t2d));
+  const float t3 = static_cast<float>(+2.0 * (q.y * q.z + q.w * q.x));
+  const float t4 = static_cast<float>(-2.0 * (q.x * q.x + ysq) + 1.0);
+  return { atan2f(t3, t4), asinf(t2), atan2f(t1, t0) };
+}
+
+constexpr int COV_N = 22;  // 21 upper-triangular sums + p_sum
+
+// subset == nullptr: particles 0..n-1; else the n indices the caller drew (pf.h:322-336 shuffles them with its own RNG)
+__global__ __launch_bounds__(PF_BLOCK) void pf_covariance_kernel(const float* __restrict__ pose7,
+                                                                 const float* __restrict__ w,
+                                                                 const uint32_t* __restrict__ subset, int n,
+                                                                 float e0, float e1, float e2, Vec3f exp_rpy,
+                                                                 double* __restrict__ block_cov /*[grid][COV_N]*/)
+{
+  double acc[COV_N];
+#pragma unroll
+  for (int k = 0; k < COV_N; ++k)
+    acc[k] = 0.0;
+  for (int t = blockIdx.x * PF_BLOCK + threadIdx.x; t < n; t += gridDim.x * PF_BLOCK)
+  {
+    const size_t i = subset ? subset[t] : static_cast<size_t>(t);
+    const float* ps = pose7 + 7 * i;
+    const float prob = w[i];
+    const Vec3f rpy = quat_get_rpy(Quat{ ps[3], ps[4], ps[5], ps[6] });
+    float d[6] = { ps[0] - e0, ps[1] - e1, ps[2] - e2, rpy.x - exp_rpy.x, rpy.y - exp_rpy.y, rpy.z - exp_rpy.z };
+#pragma unroll
+    for (int a = 3; a < 6; ++a)  // covElement, state_6dof.h:175-179
+    {
+      while (d[a] > M_PI)
+        d[a] = static_cast<float>(d[a] - 2 * M_PI);
+      while (d[a] < -M_PI)
+        d[a] = static_cast<float>(d[a] + 2 * M_PI);
+    }
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int k = j; k < 6; ++k)
+      {
+        float val = 1.0f;
+        val *= d[j];
+        val *= d[k];
+        acc[idx++] += static_cast<double>(val * prob);  // pf.h:347
+      }
+    acc[21] += static_cast<double>(prob);
+  }
+  __shared__ double sh[COV_N][PF_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < COV_N; ++k)
+  {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0)
+      sh[k][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < COV_N)
+  {
+    double s = 0;
+    for (int q = 0; q < PF_BLOCK / 64; ++q)
+      s += sh[threadIdx.x][q];
+    block_cov[COV_N * blockIdx.x + threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void pf_covariance_reduce_kernel(const double* __restrict__ block_cov, int n_blocks,
+                                                                  double* __restrict__ out_cov /*[COV_N]*/)
+{
+  if (threadIdx.x < COV_N)
+  {
+    double s = 0;
+    for (int b = 0; b < n_blocks; ++b)
+      s += block_cov[COV_N * b + threadIdx.x];
+    out_cov[threadIdx.x] = s;
+  }
+}
 }  // namespace mcl3dl

@@ -1060,6 +1060,174 @@ double orc_measure_update(void* h, const float* poses, const float* odom_err_int
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * expectationBiased / max / covariance — pf.h:280-390 with ParticleWeightedMeanQuat (state_6dof.h:316-355)
+ * ---------------------------------------------------------------------------------------------- */
+static V3 v3_cross(V3 a, V3 q) /* vec3.h:145-150 */
+{
+  return v3(a.y * q.z - a.z * q.y, a.z * q.x - a.x * q.z, a.x * q.y - a.y * q.x);
+}
+
+/* Quat(const Vec3& forward, const Vec3& up_raw), quat.h:61-80 */
+static Q4 q_from_front_up(V3 forward, V3 up_raw)
+{
+  const V3 xv = v3_normalized(forward);
+  const V3 yv = v3_normalized(v3_cross(up_raw, xv));
+  const V3 zv = v3_normalized(v3_cross(xv, yv));
+  Q4 q;
+  q.w = (float)(sqrt(fmax(0.0, 1.0 + xv.x + yv.y + zv.z)) / 2.0);
+  q.x = (float)(sqrt(fmax(0.0, 1.0 + xv.x - yv.y - zv.z)) / 2.0);
+  q.y = (float)(sqrt(fmax(0.0, 1.0 - xv.x + yv.y - zv.z)) / 2.0);
+  q.z = (float)(sqrt(fmax(0.0, 1.0 - xv.x - yv.y + zv.z)) / 2.0);
+  if (zv.y - yv.z > 0)
+    q.x = -q.x;
+  if (xv.z - zv.x > 0)
+    q.y = -q.y;
+  if (yv.x - xv.y > 0)
+    q.z = -q.z;
+  return q;
+}
+
+/* Quat::getRPY, quat.h:188-203 */
+static V3 q_get_rpy(Q4 q)
+{
+  const float ysq = q.y * q.y;
+  const float t0 = (float)(-2.0 * (ysq + q.z * q.z) + 1.0);
+  const float t1 = (float)(+2.0 * (q.x * q.y + q.w * q.z));
+  const float t2 = (float)fmax(-1.0, fmin(1.0, -2.0 * (q.x * q.z - q.w * q.y)));
+  const float t3 = (float)(+2.0 * (q.y * q.z + q.w * q.x));
+  const float t4 = (float)(-2.0 * (q.x * q.x + ysq) + 1.0);
+  return v3(atan2f(t3, t4), asinf(t2), atan2f(t1, t0));
+}
+
+typedef struct
+{
+  float p_sum;
+  V3 pos, front, up;
+} WMean; /* ParticleWeightedMeanQuat */
+
+static void wmean_add(WMean* m, const float* pose7, float prob) /* state_6dof.h:330-343 */
+{
+  const Q4 rot = { pose7[3], pose7[4], pose7[5], pose7[6] };
+  m->p_sum += prob;
+  m->pos = v3_add(m->pos, v3_scale(v3(pose7[0], pose7[1], pose7[2]), prob));
+  m->front = v3_add(m->front, v3_scale(q_rot(rot, v3(1.0f, 0.0f, 0.0f)), prob));
+  m->up = v3_add(m->up, v3_scale(q_rot(rot, v3(0.0f, 0.0f, 1.0f)), prob));
+}
+
+static void wmean_get(const WMean* m, float* out7) /* state_6dof.h:345-350 */
+{
+  const Q4 q = q_from_front_up(m->front, m->up);
+  out7[0] = m->pos.x / m->p_sum;
+  out7[1] = m->pos.y / m->p_sum;
+  out7[2] = m->pos.z / m->p_sum;
+  out7[3] = q.x;
+  out7[4] = q.y;
+  out7[5] = q.z;
+  out7[6] = q.w;
+}
+
+void orc_expectation(const float* poses, const float* weights, const float* bias, size_t n, float* out_mean7,
+                     int* out_max_index, int* out_max_biased_index)
+{
+  WMean m;
+  memset(&m, 0, sizeof(m));
+  for (size_t i = 0; i < n; ++i) /* expectationBiased, pf.h:294-303 */
+    wmean_add(&m, &poses[7 * i], weights[i] * (bias ? bias[i] : 1.0f));
+  wmean_get(&m, out_mean7);
+  size_t im = 0, ib = 0; /* max / maxBiased, pf.h:361-390: strict <, so the first maximum wins */
+  float mp = weights[0], mb = weights[0] * (bias ? bias[0] : 1.0f);
+  for (size_t i = 0; i < n; ++i)
+  {
+    if (mp < weights[i])
+    {
+      mp = weights[i];
+      im = i;
+    }
+    const float pb = weights[i] * (bias ? bias[i] : 1.0f);
+    if (mb < pb)
+    {
+      mb = pb;
+      ib = i;
+    }
+  }
+  *out_max_index = (int)im;
+  *out_max_biased_index = (int)ib;
+}
+
+/* State6DOF::covElement, state_6dof.h:162-184 */
+static float cov_element(const float* s7, const float* e7, V3 rpy, V3 exp_rpy, size_t j, size_t k)
+{
+  float val = 1.0f, diff = 0.0f;
+  const size_t idx[2] = { j, k };
+  const float r[3] = { rpy.x, rpy.y, rpy.z }, er[3] = { exp_rpy.x, exp_rpy.y, exp_rpy.z };
+  for (int t = 0; t < 2; ++t)
+  {
+    const size_t i = idx[t];
+    if (i < 3)
+    {
+      diff = s7[i] - e7[i];
+    }
+    else
+    {
+      diff = r[i - 3] - er[i - 3];
+      while (diff > M_PI)
+        diff -= 2 * M_PI;
+      while (diff < -M_PI)
+        diff += 2 * M_PI;
+    }
+    val *= diff;
+  }
+  return val;
+}
+
+void orc_covariance(const float* poses, const float* weights, size_t n, float* out_cov36, float* out_mean7)
+{
+  /* expectation(1.0), pf.h:280-293: stops once the running float sum exceeds pass_ratio */
+  WMean m;
+  memset(&m, 0, sizeof(m));
+  for (size_t i = 0; i < n; ++i)
+  {
+    wmean_add(&m, &poses[7 * i], weights[i]);
+    if (m.p_sum > 1.0f)
+      break;
+  }
+  float e7[7];
+  wmean_get(&m, e7);
+  memcpy(out_mean7, e7, sizeof(e7));
+  /* covariance, pf.h:308-359 */
+  float p_sum = 0;
+  size_t p_num = 0;
+  for (size_t i = 0; i < n; ++i)
+  {
+    p_num++;
+    p_sum += weights[i];
+    if (p_sum > 1.0f)
+      break;
+  }
+  float cov[6][6];
+  memset(cov, 0, sizeof(cov));
+  const Q4 eq = { e7[3], e7[4], e7[5], e7[6] };
+  const V3 exp_rpy = q_get_rpy(eq);
+  p_sum = 0.0f;
+  for (size_t i = 0; i < p_num; ++i)
+  {
+    const float* s = &poses[7 * i];
+    const Q4 sq = { s[3], s[4], s[5], s[6] };
+    const V3 rpy = q_get_rpy(sq);
+    p_sum += weights[i];
+    for (size_t j = 0; j < 6; ++j)
+      for (size_t k = j; k < 6; ++k)
+      {
+        cov[j][k] += cov_element(s, e7, rpy, exp_rpy, j, k) * weights[i];
+        cov[k][j] = cov[j][k];
+      }
+  }
+  for (size_t j = 0; j < 6; ++j)
+    for (size_t k = 0; k < 6; ++k)
+      out_cov36[6 * j + k] = cov[k][j] / p_sum;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Workload statistics for the algorithmic-bytes accounting — oracle-only helpers.
  * ---------------------------------------------------------------------------------------------- */
 void orc_count_neighbourhood(void* h, const float* poses, size_t n_p, const float* scan_xyz, size_t n_s,

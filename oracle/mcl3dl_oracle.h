@@ -53,6 +53,10 @@ double orc_measure_update(void* h, const float* poses, const float* odom_err_int
                           float odom_err_integ_lin_sigma, float* out_lik, float* out_beam, float* out_quality,
                           float* entropy, float* match_ratio_min_out, float* match_ratio_max_out, int* restored_out);
 
+void orc_expectation(const float* poses, const float* weights, const float* bias, size_t n, float* out_mean7,
+                     int* out_max_index, int* out_max_biased_index);
+void orc_covariance(const float* poses, const float* weights, size_t n, float* out_cov36, float* out_mean7);
+
 /* Extra, oracle-only: exact workload statistics used by bench.py / DESIGN.md for the algorithmic-bytes
  * accounting: K = map points in the 3x3x3 cell neighbourhood (cell edge = match_dist_min
  * in the weighted metric) of each transformed scan point, summed over a batch of poses. */

@@ -132,6 +132,8 @@ class Oracle:
         s("beam_status", None, [_p, _p, _p, _sz, _p, _p])
         s("dda_waypoints", _i, [_p, _d, _d, _d, _d, _d, _d, _p, _p, _p, _i, _p, _p, _i])
         s("pf_measure", _i, [_p, _p, _sz, _p])
+        s("expectation", None, [_p, _p, _p, _sz, _p, _p, _p])
+        s("covariance", None, [_p, _p, _sz, _p, _p])
         s("measure_update", _d, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _f,
                                  _p, _p, _p, _p, _p, _p, _p])
 
@@ -242,6 +244,25 @@ class Oracle:
         ent = C.c_float(0)
         restored = self._fn("pf_measure")(_fp(w), _fp(lk), len(w), C.byref(ent))
         return w, float(ent.value), bool(restored)
+
+    def expectation(self, poses, weights, bias=None):
+        """pf::expectationBiased + max + maxBiased (pf.h:294-303,361-390)."""
+        poses = _f32(poses, 7)
+        w = _f32(weights)
+        b = None if bias is None else _f32(bias)
+        mean = np.zeros(7, np.float32)
+        im, ib = C.c_int(0), C.c_int(0)
+        self._fn("expectation")(_fp(poses), _fp(w), _fp(b), len(poses), _fp(mean), C.byref(im), C.byref(ib))
+        return mean, int(im.value), int(ib.value)
+
+    def covariance(self, poses, weights):
+        """pf::covariance(1.0, 1.0) (pf.h:304-360); returns (6x6 covariance, the expectation(1.0) it is centred on)."""
+        poses = _f32(poses, 7)
+        w = _f32(weights)
+        cov = np.zeros((6, 6), np.float32)
+        mean = np.zeros(7, np.float32)
+        self._fn("covariance")(_fp(poses), _fp(w), len(poses), _fp(cov), _fp(mean))
+        return cov, mean
 
     def measure_update(self, poses, weights, scan_lik, scan_beam, scan_beam_label, origins, odom_err=None,
                        odom_sigma=1.0):

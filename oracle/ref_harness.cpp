@@ -511,4 +511,60 @@ double ref_measure_update(void* h, const float* poses, const float* odom_err_int
     *match_ratio_max_out = match_ratio_max;
   return dt;
 }
+
+// pf::ParticleFilter::expectationBiased (include/mcl_3dl/pf.h:294-303) with ParticleWeightedMeanQuat
+// (include/mcl_3dl/state_6dof.h:316-355), plus max() / maxBiased() (pf.h:361-390).  bias == NULL -> probability_bias_ = 1.
+void ref_expectation(const float* poses, const float* weights, const float* bias, size_t n, float* out_mean7,
+                     int* out_max_index, int* out_max_biased_index)
+{
+  using PF = mcl_3dl::pf::ParticleFilter<mcl_3dl::State6DOF, float, mcl_3dl::ParticleWeightedMeanQuat,
+                                         std::default_random_engine>;
+  PF pf(static_cast<int>(n), 12345);
+  size_t i = 0;
+  for (auto it = pf.begin(); it != pf.end(); ++it, ++i)
+  {
+    it->state_ = makeState(poses + 7 * i);
+    it->state_.odom_err_integ_lin_.x_ = static_cast<float>(i);  // tag: which particle max() returned
+    it->probability_ = weights[i];
+    it->probability_bias_ = bias ? bias[i] : 1.0f;
+  }
+  const mcl_3dl::State6DOF e = pf.expectationBiased();
+  out_mean7[0] = e.pos_.x_;
+  out_mean7[1] = e.pos_.y_;
+  out_mean7[2] = e.pos_.z_;
+  out_mean7[3] = e.rot_.x_;
+  out_mean7[4] = e.rot_.y_;
+  out_mean7[5] = e.rot_.z_;
+  out_mean7[6] = e.rot_.w_;
+  *out_max_index = static_cast<int>(pf.max().odom_err_integ_lin_.x_);
+  *out_max_biased_index = static_cast<int>(pf.maxBiased().odom_err_integ_lin_.x_);
+}
+
+// pf::ParticleFilter::covariance(1.0, 1.0) (pf.h:304-360) with State6DOF::covElement (state_6dof.h:162-184); also returns
+// the expectation(1.0) it is centred on (pf.h:280-293, including its "stop once the running sum exceeds pass_ratio" rule).
+void ref_covariance(const float* poses, const float* weights, size_t n, float* out_cov36, float* out_mean7)
+{
+  using PF = mcl_3dl::pf::ParticleFilter<mcl_3dl::State6DOF, float, mcl_3dl::ParticleWeightedMeanQuat,
+                                         std::default_random_engine>;
+  PF pf(static_cast<int>(n), 12345);
+  size_t i = 0;
+  for (auto it = pf.begin(); it != pf.end(); ++it, ++i)
+  {
+    it->state_ = makeState(poses + 7 * i);
+    it->probability_ = weights[i];
+    it->probability_bias_ = 1.0f;
+  }
+  const mcl_3dl::State6DOF e = pf.expectation();
+  out_mean7[0] = e.pos_.x_;
+  out_mean7[1] = e.pos_.y_;
+  out_mean7[2] = e.pos_.z_;
+  out_mean7[3] = e.rot_.x_;
+  out_mean7[4] = e.rot_.y_;
+  out_mean7[5] = e.rot_.z_;
+  out_mean7[6] = e.rot_.w_;
+  std::vector<mcl_3dl::State6DOF> cov = pf.covariance(1.0, 1.0);
+  for (size_t j = 0; j < 6; ++j)
+    for (size_t k = 0; k < 6; ++k)
+      out_cov36[6 * j + k] = cov[j][k];
+}
 }  // extern "C"

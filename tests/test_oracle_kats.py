@@ -199,3 +199,49 @@ def test_beam_wall_fixture_shape(kind):
     assert np.all(st[xs > 2.45] == 0)                     # beam ends well behind the wall -> SHORT
     assert np.all(st[(xs > 1.75) & (xs < 2.25)] == 1)     # ends within hit_range of the wall -> HIT
     assert np.all(st[xs < 1.4] == 2)                      # ends in front of it -> LONG
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_expectation_and_covariance_against_float64(kind):
+    """pf::expectationBiased / max / covariance (pf.h:280-390, state_6dof.h:162-184,316-355) against an independent
+    float64 evaluation of the same definitions."""
+    from mcl_3dl_amd.synthetic import quat_to_matrix
+    sc = make_scene(n=41, n_p=400, n_s=4, seed=77, sigma_rpy=(0.05, 0.05, 0.3))
+    rng = np.random.default_rng(9)
+    w = rng.uniform(0, 1, 400).astype(np.float32)
+    w /= w.sum()
+    bias = rng.uniform(0.1, 1, 400).astype(np.float32)
+    o = pyoracle.Oracle(kind)
+    mean, im, ib = o.expectation(sc.poses, w, bias)
+    wb = w.astype(np.float64) * bias
+    np.testing.assert_allclose(mean[:3], (sc.poses[:, :3] * wb[:, None]).sum(0) / wb.sum(), rtol=1e-5)
+    assert im == int(np.argmax(w)) and ib == int(np.argmax(w * bias))
+    front = sum(wb[i] * quat_to_matrix(sc.poses[i, 3:])[:, 0] for i in range(400))
+    got_front = quat_to_matrix(mean[3:])[:, 0]
+    assert np.dot(front / np.linalg.norm(front), got_front) > 1 - 1e-6
+    cov, e = o.covariance(sc.poses, w)
+    d = sc.poses[:, :3].astype(np.float64) - e[:3]
+    want_pos = (d[:, :, None] * d[:, None, :] * w[:, None, None].astype(np.float64)).sum(0) / w.sum(dtype=np.float64)
+    np.testing.assert_allclose(cov[:3, :3], want_pos, rtol=1e-3, atol=1e-8)
+    np.testing.assert_array_equal(cov, cov.T)
+    assert np.all(np.diag(cov) > 0)
+
+
+@pytest.mark.skipif(len(KINDS) < 2, reason="oracle/_ref not built here")
+def test_port_expectation_covariance_equal_reference():
+    sc = make_scene(n=41, n_p=777, n_s=4, seed=12)
+    rng = np.random.default_rng(2)
+    w = (rng.uniform(0, 1, 777) ** 3).astype(np.float32)
+    w[::13] = 0
+    w /= w.sum()
+    bias = rng.uniform(1e-6, 1, 777).astype(np.float32)
+    a, b = pyoracle.Oracle("ref"), pyoracle.Oracle("port")
+    for bb in (None, bias):
+        ma, ia, ja = a.expectation(sc.poses, w, bb)
+        mb, ib, jb = b.expectation(sc.poses, w, bb)
+        np.testing.assert_array_equal(ma, mb)
+        assert (ia, ja) == (ib, jb)
+    ca, ea = a.covariance(sc.poses, w)
+    cb, eb = b.covariance(sc.poses, w)
+    np.testing.assert_array_equal(ca, cb)
+    np.testing.assert_array_equal(ea, eb)
