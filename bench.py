@@ -281,6 +281,15 @@ def main():
             beam_avg = beam_ms / max(beam_n, 1)
             out["beam"] = {"rays_per_s": ws["rays"] / (beam_avg * 1e-3), "dda_steps_per_s": ws["dda_steps"] / (beam_avg * 1e-3),
                            "algorithmic_GBps": bytes_beam_launch / (beam_avg * 1e-3) / 1e9, "avg_launch_ms": beam_avg}
+        # the reductions that follow the update in the node (expectationBiased + max + covariance) on the
+        # device-resident particles; each call ends with a D2H of a dozen scalars
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for _ in range(10):
+            mean7, _tot, _im, _ib = eng.expectation_device(d_pose, d_w, None, n_p)
+            eng.covariance_device(d_pose, d_w, n_p, mean7)
+        out["post_update_reductions"] = {"ms": (time.perf_counter() - t3) / 10 * 1e3,
+                                         "what": "expectationBiased + max + covariance over this rank's particles"}
         if world == 1:
             # the drop-in boundary hands over HOST buffers: time the synchronous host entry point too (scan ordering on
             # the host, H2D of scan + poses + weights, kernels, D2H of weights) — never part of `value`

@@ -223,6 +223,21 @@ class Engine:
                                                    0 if sub is None else len(sub), _ptr(m), _ptr(cov)))
         return cov
 
+    def expectation_device(self, d_pose, d_weight, d_bias, n):
+        mean = np.zeros(7, np.float32)
+        total = C.c_float(0)
+        im, ib = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.mcl3dl_hip_expectation_device(self.h, _ptr(d_pose), _ptr(d_weight), _ptr(d_bias), n,
+                                                           _ptr(mean), C.byref(total), C.byref(im), C.byref(ib)))
+        return mean, float(total.value), int(im.value), int(ib.value)
+
+    def covariance_device(self, d_pose, d_weight, n, mean7, d_subset=None, n_subset=0):
+        m = _np_f32(mean7)
+        cov = np.zeros((6, 6), np.float32)
+        self._check(self.lib.mcl3dl_hip_covariance_device(self.h, _ptr(d_pose), _ptr(d_weight), n, _ptr(d_subset),
+                                                          n_subset, _ptr(m), _ptr(cov)))
+        return cov
+
     def dda_trace(self, begin, end, max_out=4096):
         b = _np_f32(begin)
         e = _np_f32(end)
