@@ -1,61 +1,30 @@
-// Drop-in replacement for the reference header of the same path
-// (include/mcl_3dl/lidar_measurement_models/lidar_measurement_model_likelihood.h): same class name, same public surface,
-// same LidarMeasurementModelBase parent — measure() is answered by the gfx950 engine through the C ABI.
+// Drop-in for the reference header of the same path: class mcl_3dl::LidarMeasurementModelLikelihood with the reference's
+// public surface, answered by the gfx950 engine through the C ABI (mcl3dl_hip_measure_batch).
 #ifndef MCL_3DL_HIP_LIDAR_MEASUREMENT_MODEL_LIKELIHOOD_H
 #define MCL_3DL_HIP_LIDAR_MEASUREMENT_MODEL_LIKELIHOOD_H
 
-#include <cstdint>
 #include <memory>
 #include <vector>
 
-#include <pcl/point_types.h>
-#include <pcl_ros/point_cloud.h>
-
-#include <mcl_3dl/chunked_kdtree.h>
-#include <mcl_3dl/lidar_measurement_model_base.h>
 #include <mcl_3dl/parameters.h>
 #include <mcl_3dl/pf.h>
-#include <mcl_3dl/point_cloud_random_sampler.h>
-#include <mcl_3dl/vec3.h>
+#include <mcl_3dl_hip/batched_model.hpp>
 
 namespace mcl_3dl
 {
-class LidarMeasurementModelLikelihood : public LidarMeasurementModelBase
+class LidarMeasurementModelLikelihood final : public hip::BatchedLidarModel
 {
-public:
-  explicit LidarMeasurementModelLikelihood(
-      const std::shared_ptr<LidarMeasurementModelLikelihoodParameters>& params);
+  using Params = LidarMeasurementModelLikelihoodParameters;
 
-  inline float getMaxSearchRange() const
-  {
-    return params_->match_dist_min_;
-  }
-  void refreshParameters() final;
-  void setGlobalLocalizationStatus(const size_t num_particles, const size_t current_num_particles);
-  pcl::PointCloud<PointType>::Ptr filter(
-      const pcl::PointCloud<PointType>::ConstPtr& pc,
-      const PointCloudRandomSampler<PointType>& sampler) const;
-  LidarMeasurementResult measure(
-      ChunkedKdtree<PointType>::Ptr& kdtree,
-      const pcl::PointCloud<PointType>::ConstPtr& pc,
-      const std::vector<Vec3>& origins,
-      const State6DOF& s) const;
+public:
+  explicit LidarMeasurementModelLikelihood(const std::shared_ptr<Params>& params);
+  float getMaxSearchRange() const override { return params_->match_dist_min_; }
+  void refreshParameters() override;
+  LidarMeasurementResult measure(ChunkedKdtree<PointType>::Ptr& kdtree, const hip::Cloud::ConstPtr& pc,
+                                 const std::vector<Vec3>& origins, const State6DOF& s) const override;
 
 private:
-  std::shared_ptr<LidarMeasurementModelLikelihoodParameters> params_;
-  size_t num_points_;
-  float clip_far_sq_;
-  float clip_near_sq_;
-
-  // results of the last batched launch, valid for one (pf::measure epoch, scan cloud) pair
-  struct Cache
-  {
-    std::uint64_t epoch = 0;
-    const void* cloud = nullptr;
-    std::vector<float> likelihood;
-    std::vector<float> quality;
-  };
-  mutable Cache cache_;
+  std::shared_ptr<Params> params_;
 };
 }  // namespace mcl_3dl
 

@@ -1,17 +1,14 @@
 // GPU-backed mcl_3dl::LidarMeasurementModelBeam (drop-in for src/lidar_measurement_model_beam.cpp, DDA raycaster).
 #include <algorithm>
 #include <cmath>
-#include <memory>
 #include <stdexcept>
-#include <vector>
 
 #include <mcl_3dl/lidar_measurement_models/lidar_measurement_model_beam.h>
-#include <mcl_3dl_hip/model_common.hpp>
 
 namespace mcl_3dl
 {
-LidarMeasurementModelBeam::LidarMeasurementModelBeam(const std::shared_ptr<LidarMeasurementModelBeamParameters>& params)
-  : params_(params ? params : std::make_shared<LidarMeasurementModelBeamParameters>())
+LidarMeasurementModelBeam::LidarMeasurementModelBeam(const std::shared_ptr<Params>& params)
+  : params_(params ? params : std::make_shared<Params>())
 {
   refreshParameters();
 }
@@ -21,15 +18,13 @@ LidarMeasurementModelBeam::LidarMeasurementModelBeam(const std::shared_ptr<Lidar
 // expressions; only what the public getters expose is kept here.
 void LidarMeasurementModelBeam::refreshParameters()
 {
-  search_range_ = std::max({ params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_ }) * 4;
-  num_points_ = params_->num_points_default_;
-  clip_near_sq_ = params_->clip_near_ * params_->clip_near_;
-  clip_far_sq_ = params_->clip_far_ * params_->clip_far_;
-  sin_total_ref_ = sinf(params_->ang_total_ref_);
   if (!params_->use_raycast_using_dda_)
     throw std::runtime_error("mcl3dl_hip: the GPU beam model implements RaycastUsingDDA only; set "
                              "beam/use_raycast_using_dda to true");
-  cache_ = Cache();
+  search_range_ = std::max({ params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_ }) * 4;
+  sin_total_ref_ = sinf(params_->ang_total_ref_);
+  configureFilter(params_->num_points_default_, params_->num_points_global_, params_->clip_near_, params_->clip_far_,
+                  params_->clip_z_min_, params_->clip_z_max_);
 }
 
 void LidarMeasurementModelBeam::pushParameters() const
@@ -37,41 +32,23 @@ void LidarMeasurementModelBeam::pushParameters() const
   hip::Engine& e = hip::Engine::shared();
   e.check(mcl3dl_hip_set_beam_params(e.get(), params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_,
                                      params_->dda_grid_size_, params_->ray_angle_half_, params_->hit_range_,
-                                     params_->beam_likelihood_min_, static_cast<std::uint32_t>(params_->num_points_default_),
-                                     params_->ang_total_ref_, params_->filter_label_max_,
-                                     params_->add_penalty_short_only_mode_ ? 1 : 0));
-}
-
-void LidarMeasurementModelBeam::setGlobalLocalizationStatus(const size_t num_particles,
-                                                            const size_t current_num_particles)
-{
-  num_points_ = hip::pointsPerParticle(params_->num_points_default_, params_->num_points_global_, num_particles,
-                                       current_num_particles);
-}
-
-// reference: src/lidar_measurement_model_beam.cpp:98-122
-pcl::PointCloud<LidarMeasurementModelBase::PointType>::Ptr LidarMeasurementModelBeam::filter(
-    const pcl::PointCloud<PointType>::ConstPtr& pc, const PointCloudRandomSampler<PointType>& sampler) const
-{
-  const hip::Cloud::Ptr clipped =
-      hip::clipCloud(*pc, clip_near_sq_, clip_far_sq_, params_->clip_z_min_, params_->clip_z_max_);
-  return sampler.sample(clipped, num_points_);
+                                     params_->beam_likelihood_min_,
+                                     static_cast<std::uint32_t>(params_->num_points_default_), params_->ang_total_ref_,
+                                     params_->filter_label_max_, params_->add_penalty_short_only_mode_ ? 1 : 0));
 }
 
 // reference: src/lidar_measurement_model_beam.cpp:124-155
 LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointType>::Ptr& kdtree,
-                                                          const pcl::PointCloud<PointType>::ConstPtr& pc,
+                                                          const hip::Cloud::ConstPtr& pc,
                                                           const std::vector<Vec3>& origins, const State6DOF& s) const
 {
   if (!pc || pc->size() == 0)
-    return LidarMeasurementResult(1, 0);
+    return LidarMeasurementResult(1, 0);  // :130-133
 
   std::vector<float> poses;
-  std::uint64_t epoch = 0;
-  const std::size_t index = hip::gatherPoses(s, poses, &epoch);
-  const bool cached = epoch != 0 && cache_.epoch == epoch && cache_.cloud == pc.get() &&
-                      cache_.likelihood.size() == poses.size() / 7;
-  if (!cached)
+  bool refresh = false;
+  const std::size_t index = lookup(s, pc.get(), poses, &refresh);
+  if (refresh)
   {
     hip::Engine& e = hip::Engine::shared();
     hip::syncMap(e, *kdtree);
@@ -85,22 +62,20 @@ LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointTyp
       org[3 * i + 1] = origins[i].y_;
       org[3 * i + 2] = origins[i].z_;
     }
-    const std::size_t n_p = poses.size() / 7;
-    cache_.likelihood.assign(n_p, 0.f);
-    e.check(mcl3dl_hip_measure_batch(e.get(), poses.data(), n_p, nullptr, 0, scan.data(), label.data(), pc->size(),
-                                     org.data(), origins.size(), nullptr, nullptr, cache_.likelihood.data()));
-    cache_.epoch = epoch;
-    cache_.cloud = pc.get();
+    e.check(mcl3dl_hip_measure_batch(e.get(), poses.data(), poses.size() / 7, nullptr, 0, scan.data(), label.data(),
+                                     pc->size(), org.data(), origins.size(), nullptr, nullptr,
+                                     results_.likelihood.data()));
   }
-  return LidarMeasurementResult(cache_.likelihood[index], 1.0);
+  return LidarMeasurementResult(results_.likelihood[index], 1.0);
 }
 
 // reference: src/lidar_measurement_model_beam.cpp:157-192. result.point_ points into the kd-tree's input cloud like the
 // reference's; result.pos_ is the collided map point's position (the reference reports the voxel centre — only the
 // debug-marker path reads it, and only through point_).
-LidarMeasurementModelBeam::BeamStatus LidarMeasurementModelBeam::getBeamStatus(
-    ChunkedKdtree<PointType>::Ptr& kdtree, const Vec3& lidar_pos, const Vec3& scan_pos,
-    typename mcl_3dl::Raycast<PointType>::CastResult& result) const
+LidarMeasurementModelBeam::BeamStatus LidarMeasurementModelBeam::getBeamStatus(ChunkedKdtree<PointType>::Ptr& kdtree,
+                                                                               const Vec3& lidar_pos,
+                                                                               const Vec3& scan_pos,
+                                                                               CastResult& result) const
 {
   hip::Engine& e = hip::Engine::shared();
   hip::syncMap(e, *kdtree);
@@ -112,7 +87,7 @@ LidarMeasurementModelBeam::BeamStatus LidarMeasurementModelBeam::getBeamStatus(
   if (hit >= 0)
   {
     const PointType* p = &kdtree->getInputCloud()->points[hit];
-    result = typename mcl_3dl::Raycast<PointType>::CastResult(Vec3(p->x, p->y, p->z), true, 1.0, p);
+    result = CastResult(Vec3(p->x, p->y, p->z), true, 1.0, p);
   }
   return static_cast<BeamStatus>(status);
 }

@@ -1,60 +1,36 @@
 // GPU-backed mcl_3dl::LidarMeasurementModelLikelihood (drop-in for src/lidar_measurement_model_likelihood.cpp).
-#include <memory>
-#include <vector>
-
 #include <mcl_3dl/lidar_measurement_models/lidar_measurement_model_likelihood.h>
-#include <mcl_3dl_hip/model_common.hpp>
 
 namespace mcl_3dl
 {
-LidarMeasurementModelLikelihood::LidarMeasurementModelLikelihood(
-    const std::shared_ptr<LidarMeasurementModelLikelihoodParameters>& params)
-  : params_(params ? params : std::make_shared<LidarMeasurementModelLikelihoodParameters>())
+LidarMeasurementModelLikelihood::LidarMeasurementModelLikelihood(const std::shared_ptr<Params>& params)
+  : params_(params ? params : std::make_shared<Params>())
 {
   refreshParameters();
 }
 
-// reference: src/lidar_measurement_model_likelihood.cpp:56-61
+// reference: src/lidar_measurement_model_likelihood.cpp:56-61 — the search radius / flat distance / weight themselves
+// are pushed to the engine at every batched launch, so a parameter object mutated by dynamic_reconfigure is always seen.
 void LidarMeasurementModelLikelihood::refreshParameters()
 {
-  num_points_ = params_->num_points_default_;
-  clip_near_sq_ = params_->clip_near_ * params_->clip_near_;
-  clip_far_sq_ = params_->clip_far_ * params_->clip_far_;
-  cache_ = Cache();
+  configureFilter(params_->num_points_default_, params_->num_points_global_, params_->clip_near_, params_->clip_far_,
+                  params_->clip_z_min_, params_->clip_z_max_);
 }
 
-void LidarMeasurementModelLikelihood::setGlobalLocalizationStatus(const size_t num_particles,
-                                                                  const size_t current_num_particles)
-{
-  num_points_ = hip::pointsPerParticle(params_->num_points_default_, params_->num_points_global_, num_particles,
-                                       current_num_particles);
-}
-
-// reference: src/lidar_measurement_model_likelihood.cpp:79-103 (clip, then sampler.sample(num_points_))
-pcl::PointCloud<LidarMeasurementModelBase::PointType>::Ptr LidarMeasurementModelLikelihood::filter(
-    const pcl::PointCloud<PointType>::ConstPtr& pc, const PointCloudRandomSampler<PointType>& sampler) const
-{
-  const hip::Cloud::Ptr clipped =
-      hip::clipCloud(*pc, clip_near_sq_, clip_far_sq_, params_->clip_z_min_, params_->clip_z_max_);
-  return sampler.sample(clipped, num_points_);
-}
-
-// reference: src/lidar_measurement_model_likelihood.cpp:105-139.  Same inputs, same (likelihood, quality) result; inside
+// reference: src/lidar_measurement_model_likelihood.cpp:105-139. Same inputs, same (likelihood, quality); inside
 // pf::measure the first call evaluates every particle of the batch in one launch.
 LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<PointType>::Ptr& kdtree,
-                                                                const pcl::PointCloud<PointType>::ConstPtr& pc,
+                                                                const hip::Cloud::ConstPtr& pc,
                                                                 const std::vector<Vec3>& /*origins*/,
                                                                 const State6DOF& s) const
 {
   if (!pc || pc->size() == 0)
-    return LidarMeasurementResult(1, 0);
+    return LidarMeasurementResult(1, 0);  // :111-114
 
   std::vector<float> poses;
-  std::uint64_t epoch = 0;
-  const std::size_t index = hip::gatherPoses(s, poses, &epoch);
-  const bool cached = epoch != 0 && cache_.epoch == epoch && cache_.cloud == pc.get() &&
-                      cache_.likelihood.size() == poses.size() / 7;
-  if (!cached)
+  bool refresh = false;
+  const std::size_t index = lookup(s, pc.get(), poses, &refresh);
+  if (refresh)
   {
     hip::Engine& e = hip::Engine::shared();
     hip::syncMap(e, *kdtree);
@@ -62,14 +38,9 @@ LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<Po
                                              params_->match_weight_));
     std::vector<float> scan;
     hip::packCloud(*pc, scan, nullptr);
-    const std::size_t n_p = poses.size() / 7;
-    cache_.likelihood.assign(n_p, 0.f);
-    cache_.quality.assign(n_p, 0.f);
-    e.check(mcl3dl_hip_measure_batch(e.get(), poses.data(), n_p, scan.data(), pc->size(), nullptr, nullptr, 0,
-                                     nullptr, 0, cache_.likelihood.data(), cache_.quality.data(), nullptr));
-    cache_.epoch = epoch;
-    cache_.cloud = pc.get();
+    e.check(mcl3dl_hip_measure_batch(e.get(), poses.data(), poses.size() / 7, scan.data(), pc->size(), nullptr, nullptr,
+                                     0, nullptr, 0, results_.likelihood.data(), results_.quality.data(), nullptr));
   }
-  return LidarMeasurementResult(cache_.likelihood[index], cache_.quality[index]);
+  return LidarMeasurementResult(results_.likelihood[index], results_.quality[index]);
 }
 }  // namespace mcl_3dl
