@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
     ap.add_argument("--lik-group", type=int, default=16)
+    ap.add_argument("--strict-order", type=int, default=0,
+                    help="1 = reference float summation order (bit-identical likelihoods and weights; slower)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,6 +145,7 @@ def main():
     eng.set_option("lik_index", args.lik_index)
     eng.set_option("cand_voxel_ratio", args.cand_voxel_ratio)
     eng.set_option("cand_phase", args.cand_phase)
+    eng.set_option("strict_order", args.strict_order)
     eng.set_option("lik_tiled", args.lik_tiled)
     eng.set_option("lik_group", args.lik_group)
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
@@ -244,7 +247,8 @@ def main():
                 "particles_per_gpu": n_p, "scan_points": n_s, "beam_points": n_b, "map_points": int(len(sc.map_xyz)),
                 "parallelism": "particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world,
                 "update_hz": 1e3 / ms_per_step,
-                "accumulate": "fp64 tree (terms bit-identical to the reference's float terms)",
+                "accumulate": ("float, reference order (bit-identical results)" if args.strict_order else
+                               "fp64 tree (terms bit-identical to the reference's float terms)"),
             },
             "roofline": {
                 "bound": "hbm",

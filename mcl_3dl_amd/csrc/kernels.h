@@ -317,8 +317,12 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
                                                                int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
                                                                LikParams prm, double* __restrict__ partial_sum,
-                                                               unsigned* __restrict__ partial_cnt)
+                                                               unsigned* __restrict__ partial_cnt,
+                                                               const uint32_t* __restrict__ scan_perm,
+                                                               float* __restrict__ strict_terms)
 {
+  // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
+  // [original scan index][particle] so that lik_strict_sum_kernel can add them in the reference's own order.
   __shared__ float s_pose[G][8];        // px,py,pz, qx,qy,qz,qw (normalised), valid
   __shared__ float s_term[G][256];
   __shared__ unsigned s_cnt[G][4];
@@ -385,6 +389,8 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
       }
     }
     s_term[k][t] = term;
+    if (strict_terms && have_point)
+      strict_terms[static_cast<size_t>(scan_perm[i]) * n_p + (group * G + k)] = term;
     const unsigned long long m = __ballot(matched);
     if (lane == 0)
       s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
@@ -433,6 +439,56 @@ __global__ void lik_finalize_kernel(const double* __restrict__ partial_sum, cons
     out_lik[p] = static_cast<float>(a);
   if (out_ratio)
     out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
+}
+
+// "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): one lane per
+// particle walks the scan in ORIGINAL order, float adds, sequentially. Unmatched points hold 0 (x + 0.0f == x), so
+// the result is the reference's float, bit for bit. Loads run DEPTH ahead of the dependent add chain.
+__global__ __launch_bounds__(64) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
+                                                            float* __restrict__ out_lik)
+{
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_p)
+    return;
+  constexpr int DEPTH = 32;
+  float score = 0.0f;
+  int i = 0;
+  for (; i + DEPTH <= n_s; i += DEPTH)
+  {
+    float v[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      v[j] = terms[static_cast<size_t>(i + j) * n_p + p];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      score += v[j];
+  }
+  for (; i < n_s; ++i)
+    score += terms[static_cast<size_t>(i) * n_p + p];
+  out_lik[p] = score;
+}
+
+// "strict_order": pf::measure's `sum += p.probability_` (pf.h:255-260) as a float, sequentially, by one lane; the result
+// replaces the fp64 tree sum in packed[0] so that pf_apply_kernel divides by exactly the reference's float.
+__global__ void pf_strict_sum_kernel(const float* __restrict__ w_new, int n, double* __restrict__ packed)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  float sum = 0.0f;
+  int i = 0;
+  for (; i + 16 <= n; i += 16)
+  {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      v[j] = w_new[i + j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      sum += v[j];
+  }
+  for (; i < n; ++i)
+    sum += w_new[i];
+  packed[0] = static_cast<double>(sum);
 }
 
 // n_s == 0: (likelihood 1, quality 0), src/lidar_measurement_model_likelihood.cpp:111-114

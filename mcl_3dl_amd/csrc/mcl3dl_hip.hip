@@ -77,6 +77,8 @@ struct mcl3dl_hip_ctx
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_group = 16;      // particles per work-group of the tiled kernel (16 or 32)
   DevBuf lik_partial_sum, lik_partial_cnt;
+  int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
+  DevBuf scan_perm, strict_terms;
   double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
@@ -770,7 +772,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
         const float4* scan = ctx->scan_lik.as<float4>();
-        const bool tiled = ctx->lik_tiled && ns >= 1024 && np >= 64;
+        const bool tiled = (ctx->lik_tiled && ns >= 1024 && np >= 64) || ctx->strict_order;
+        float* strict_terms = nullptr;
+        if (ctx->strict_order)
+        {
+          TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * n_p));
+          strict_terms = ctx->strict_terms.as<float>();
+        }
         if (tiled)
         {
           const int G = ctx->lik_group;
@@ -783,7 +791,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
 #define LAUNCH_TILED(GG, MODE)                                                                                         \
   hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
-                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>())
+                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
+                     ctx->scan_perm.as<uint32_t>(), strict_terms)
           if (G == 32)
           {
             if (ctx->lik_index == 2)
@@ -806,6 +815,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
                              d_lik, d_ratio);
+          if (strict_terms && d_lik)
+            hipLaunchKernelGGL(lik_strict_sum_kernel, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, strict_terms, ns, np,
+                               d_lik);
         }
         else
         {
@@ -959,7 +971,7 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->mom_blocks, &ctx->mom_arg, &ctx->mom_out, &ctx->mom_idx,
+  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->scan_perm, &ctx->strict_terms, &ctx->mom_blocks, &ctx->mom_arg, &ctx->mom_out, &ctx->mom_idx,
                      &ctx->subset, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
                      &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
                      &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
@@ -1126,6 +1138,9 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
       const uint32_t i = idx[k];
       lik[k] = make_float4(scan_lik_xyz[3 * i], scan_lik_xyz[3 * i + 1], scan_lik_xyz[3 * i + 2], 0.f);
     }
+    TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
+    TRY(h2d(ctx, ctx->scan_perm.p, idx.data(), sizeof(uint32_t) * n_s));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   // beam scan: ordered by range from its scan origin. A ray walks ~range/dda_grid voxels and (its end point being a
   // measured surface) ends near its last voxel, so the 64 rays of a wavefront finish together instead of idling behind the
@@ -1207,6 +1222,9 @@ int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, con
                      d_match_ratio, static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
   hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank,
                      world, d_packed);
+  if (ctx->strict_order && world == 1)
+    hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->wnew.as<float>(),
+                       static_cast<int>(n_p), d_packed);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1649,6 +1667,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     if (value != ctx->cand_voxel_ratio)
       ctx->cand_dirty = true;
     ctx->cand_voxel_ratio = value;
+    return 0;
+  }
+  if (key == "strict_order")
+  {
+    ctx->strict_order = value != 0.0;
     return 0;
   }
   if (key == "lik_tiled")

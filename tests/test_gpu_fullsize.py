@@ -87,3 +87,22 @@ def test_duplicated_particles_and_update(engine, full, c3):
     assert np.all(beam >= np.float32(0.2)) and np.all(beam <= 1.0)
     assert np.isin(beam, np.maximum(np.cumprod(np.concatenate([[np.float32(1)], np.full(512, b, np.float32)]),
                                                dtype=np.float32), np.float32(0.2))).all()
+
+
+def test_strict_order_slice_is_bit_identical(engine, c3, oracle_kind):
+    """C2-size launch in "strict_order" mode: a 64-particle slice equals the reference bit for bit."""
+    sc = c3
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=901, dist_weight=(1.0, 1.0, 1.0))
+    engine.set_likelihood_params()
+    try:
+        engine.set_option("strict_order", 1)
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    finally:
+        engine.set_option("strict_order", 0)
+    o = pyoracle.Oracle(oracle_kind)
+    o.set_map(sc.map_xyz, sc.map_label, dist_weight=(1.0, 1.0, 1.0))
+    o.set_likelihood_params(pyoracle.LikelihoodParams())
+    idx = np.arange(0, len(sc.poses), len(sc.poses) // 64)[:64]
+    wl, wq = o.likelihood_measure(sc.poses[idx], sc.scan_lik)
+    np.testing.assert_array_equal(lik[idx], wl)
+    np.testing.assert_array_equal(ratio[idx], wq)

@@ -315,3 +315,33 @@ def test_sharded_update_protocol_on_one_gpu(engine, oracle_kind, scene_c1):
         assert s[3] == 0.0
     whole = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
     np.testing.assert_allclose(got_w, whole["weights"], rtol=2e-7)
+
+
+@pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
+def test_strict_order_is_bit_identical_to_the_reference(engine, oracle_kind, dist_weight):
+    """With the "strict_order" option the likelihood terms are added per particle, and the weights over the particles,
+    as floats in the reference's own sequential order: likelihoods, match ratios, beam scores AND normalised weights then
+    equal the reference's bit for bit (the entropy still goes through the device's log)."""
+    sc = make_scene(n=91, n_p=200, n_s=3000, n_b=40, seed=31)
+    kw = dict(num_points=40)
+    setup_engine(engine, sc, dist_weight, stamp=60, beam_kw=kw)
+    sigma = np.float32(0.8)
+    nd_a = np.float32(1.0 / np.sqrt(2.0 * np.pi * float(sigma) * float(sigma)))  # NormalLikelihood(0), nd.h:46,51
+    extra = np.full(len(sc.poses), nd_a, np.float32)
+    rng = np.random.default_rng(4)
+    w0 = rng.uniform(0.5, 1.5, len(sc.poses)).astype(np.float32)
+    w0 /= w0.sum()
+    try:
+        engine.set_option("strict_order", 1)
+        got = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
+                                    extra=extra)
+    finally:
+        engine.set_option("strict_order", 0)
+    o = make_oracle(oracle_kind, sc, dist_weight, beam_kw=kw)
+    want = o.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
+                            odom_err=None, odom_sigma=float(sigma))
+    np.testing.assert_array_equal(got["lik"], want["lik"])
+    np.testing.assert_array_equal(got["quality"], want["quality"])
+    np.testing.assert_array_equal(got["beam"], want["beam"])
+    np.testing.assert_array_equal(got["weights"], want["weights"])
+    np.testing.assert_allclose(got["entropy"], want["entropy"], rtol=1e-6)
