@@ -167,6 +167,28 @@ int mcl3dl_hip_expectation_device(mcl3dl_hip_ctx* ctx, const float* d_pose, cons
 int mcl3dl_hip_covariance_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const float* d_weight, size_t n_particles,
                                  const uint32_t* d_subset, size_t n_subset, const float* mean7, float* out_cov36);
 
+/* ---- "next" row: resampling ------------------------------------------------------------------ */
+/* Replaces: pf::ParticleFilter::resample (include/mcl_3dl/pf.h:187-225, called at src/mcl_3dl.cpp:809) and
+ * resizeParticle (pf.h:399-436, :880-884) on 13-dof states (State6DOF::operator[], state_6dof.h:80-149: pos, rot,
+ * odom_err_integ_lin, odom_err_integ_ang). The caller keeps its random engine, so the sequence is three calls:
+ *   begin : float prefix sums of the weights + the std::sort of the duplicate array (tie groups of weight-0 particles
+ *           are ordered by libstdc++'s introsort exactly as in the reference); returns pstep = accum / n_out
+ *   [resample only: the caller draws initial_p = uniform_real_distribution<float>(0, pstep)(engine_), pf.h:203]
+ *   plan  : mode 0 = resample (pscan = pstep*i + initial_p), 1 = resizeParticle (pscan += pstep; initial_p ignored);
+ *           n_out lower_bound searches on the device; out_source[i] = particle copied into slot i,
+ *           out_duplicate[i] = 1 where the reference adds noise (it == it_prev, pf.h:217-221)
+ *   [the caller draws one State6DOF::generateNoise per duplicated slot, in slot order, pf.h:216]
+ *   apply : gather on the device; duplicated slots get state + noise (State6DOF::operator+, state_6dof.h:248-260)
+ *           and normalize() (:150-153). New weights are 1/n_out (pf.h:207 / 419) — the caller's to set.
+ * any out_* may be NULL. noise13 holds n_noise >= (number of duplicates) 13-float noise states. */
+int mcl3dl_hip_resample_begin(mcl3dl_hip_ctx* ctx, const float* weight /*n*/, size_t n, size_t n_out, float* out_pstep);
+int mcl3dl_hip_resample_plan(mcl3dl_hip_ctx* ctx, int mode, float initial_p, uint32_t* out_source /*n_out*/,
+                             uint8_t* out_duplicate /*n_out*/, size_t* out_n_duplicates);
+int mcl3dl_hip_resample_apply(mcl3dl_hip_ctx* ctx, const float* state13_in /*n*13*/, const float* noise13, size_t n_noise,
+                              float* state13_out /*n_out*13*/);
+int mcl3dl_hip_resample_apply_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13 /*host*/,
+                                     size_t n_noise, float* d_state13_out);
+
 /* ---- measurement support ------------------------------------------------------------------------------ */
 /* Per-kernel hipEvent timing on the launch stream (off by default). */
 int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable);

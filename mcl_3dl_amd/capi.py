@@ -37,6 +37,10 @@ SIGNATURES = {
     "mcl3dl_hip_covariance": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
     "mcl3dl_hip_expectation_device": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_covariance_device": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
+    "mcl3dl_hip_resample_begin": (_i, [_p, _p, _sz, _sz, C.POINTER(_f)]),
+    "mcl3dl_hip_resample_plan": (_i, [_p, _i, _f, _p, _p, C.POINTER(_sz)]),
+    "mcl3dl_hip_resample_apply": (_i, [_p, _p, _p, _sz, _p]),
+    "mcl3dl_hip_resample_apply_device": (_i, [_p, _p, _p, _sz, _p]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
     "mcl3dl_hip_measure_device": (_i, [_p, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
@@ -237,6 +241,30 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_covariance_device(self.h, _ptr(d_pose), _ptr(d_weight), n, _ptr(d_subset),
                                                           n_subset, _ptr(m), _ptr(cov)))
         return cov
+
+    def resample_begin(self, weights, n_out=None):
+        w = _np_f32(weights)
+        pstep = C.c_float(0)
+        self._check(self.lib.mcl3dl_hip_resample_begin(self.h, _ptr(w), len(w), len(w) if n_out is None else n_out,
+                                                       C.byref(pstep)))
+        self._rs_n_out = len(w) if n_out is None else n_out
+        return float(pstep.value)
+
+    def resample_plan(self, mode, initial_p=0.0):
+        src = np.zeros(self._rs_n_out, np.uint32)
+        dup = np.zeros(self._rs_n_out, np.uint8)
+        nd = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_resample_plan(self.h, int(mode), float(initial_p), _ptr(src), _ptr(dup),
+                                                      C.byref(nd)))
+        return src, dup, int(nd.value)
+
+    def resample_apply(self, state13, noise13=None):
+        s = _np_f32(state13, 13)
+        nz = None if noise13 is None or len(noise13) == 0 else _np_f32(noise13, 13)
+        out = np.zeros((self._rs_n_out, 13), np.float32)
+        self._check(self.lib.mcl3dl_hip_resample_apply(self.h, _ptr(s), _ptr(nz), 0 if nz is None else len(nz),
+                                                       _ptr(out)))
+        return out
 
     def dda_trace(self, begin, end, max_out=4096):
         b = _np_f32(begin)

@@ -1084,4 +1084,65 @@ __global__ __launch_bounds__(64) void pf_covariance_reduce_kernel(const double* 
     out_cov[threadIdx.x] = s;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// "Next" row: pf::ParticleFilter::resample / resizeParticle (include/mcl_3dl/pf.h:187-225, 399-436).
+// The serial, order-defining parts (float prefix sums, libstdc++'s std::sort of the tie groups, the it/it_prev walk)
+// stay on the host in mcl3dl_hip.hip; the device does the n_out independent std::lower_bound searches and the
+// gather of the 13-dof states with State6DOF::operator+ / normalize() for the duplicated ones.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void resample_lower_bound_kernel(const float* __restrict__ keys, int n, const float* __restrict__ pscan,
+                                            int n_out, uint32_t* __restrict__ it_out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out)
+    return;
+  const float p = pscan[i];
+  int lo = 0, len = n;  // std::lower_bound with Particle::operator< (pf.h:104-107): first key with !(key < p)
+  while (len > 0)
+  {
+    const int half = len >> 1;
+    if (keys[lo + half] < p)
+    {
+      lo += half + 1;
+      len -= half + 1;
+    }
+    else
+      len = half;
+  }
+  it_out[i] = static_cast<uint32_t>(lo);
+}
+
+// slot i receives the state of particle source[i]; duplicated picks get `state + noise` (State6DOF::operator+,
+// state_6dof.h:248-260: components 0-2 and 7-12 add, rot = noise.rot * state.rot) followed by normalize() (:150-153).
+__global__ void resample_apply_kernel(const float* __restrict__ state_in, const uint32_t* __restrict__ source,
+                                      const uint32_t* __restrict__ noise_slot /* 0xffffffff = not duplicated */,
+                                      const float* __restrict__ noise13, int n_out, float* __restrict__ state_out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out)
+    return;
+  const float* s = state_in + 13 * static_cast<size_t>(source[i]);
+  float* o = state_out + 13 * static_cast<size_t>(i);
+  const uint32_t slot = noise_slot[i];
+  if (slot == 0xffffffffu)
+  {
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+      o[k] = s[k];
+    return;
+  }
+  const float* a = noise13 + 13 * static_cast<size_t>(slot);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    o[k] = s[k] + a[k];
+#pragma unroll
+  for (int k = 7; k < 13; ++k)
+    o[k] = s[k] + a[k];
+  const Quat r = qnormalized(qmul(Quat{ a[3], a[4], a[5], a[6] }, Quat{ s[3], s[4], s[5], s[6] }));
+  o[3] = r.x;
+  o[4] = r.y;
+  o[5] = r.z;
+  o[6] = r.w;
+}
 }  // namespace mcl3dl

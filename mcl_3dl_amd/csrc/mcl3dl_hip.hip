@@ -99,6 +99,15 @@ struct mcl3dl_hip_ctx
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
       tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset;
 
+  // resampling plan
+  std::vector<float> rs_keys;        // accumulated probabilities, in particles_dup_ order after std::sort
+  std::vector<uint32_t> rs_order;    // which particle sits at each position of particles_dup_
+  std::vector<uint32_t> rs_source, rs_slot;
+  size_t rs_n = 0, rs_n_out = 0, rs_n_dup = 0;
+  float rs_pstep = 0.f;
+  bool rs_planned = false;
+  DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out;
+
   // timing
   bool timing = false;
   std::vector<EventPair> pending;
@@ -972,7 +981,8 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->scan_perm, &ctx->strict_terms, &ctx->mom_blocks, &ctx->mom_arg, &ctx->mom_out, &ctx->mom_idx,
-                     &ctx->subset, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
+                     &ctx->subset, &ctx->rs_d_keys, &ctx->rs_d_pscan, &ctx->rs_d_it, &ctx->rs_d_source, &ctx->rs_d_slot,
+                     &ctx->rs_d_noise, &ctx->rs_d_in, &ctx->rs_d_out, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
                      &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
                      &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
                      &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
@@ -1598,6 +1608,162 @@ int mcl3dl_hip_covariance(mcl3dl_hip_ctx* ctx, const float* pose, const float* w
   }
   return mcl3dl_hip_covariance_device(ctx, ctx->pose.as<float>(), ctx->weightb.as<float>(), n,
                                       subset ? ctx->subset.as<uint32_t>() : nullptr, n_subset, mean7, out_cov36);
+}
+
+// ---- "next" row: resample / resizeParticle ---------------------------------------------------------------------------
+int mcl3dl_hip_resample_begin(mcl3dl_hip_ctx* ctx, const float* weight, size_t n, size_t n_out, float* out_pstep)
+{
+  if (!ctx)
+    return -1;
+  if (!weight || n == 0 || n_out == 0 || n > 0x7fffffffu || n_out > 0x7fffffffu)
+    return ctx->fail(-3, "bad arguments to resample_begin");
+  // accum += p.probability_ ; p.accum_probability_ = accum   (pf.h:193-197 / 401-405): float, sequential
+  std::vector<std::pair<float, uint32_t>> dup(n);
+  float accum = 0;
+  bool ties = false;
+  for (size_t i = 0; i < n; ++i)
+  {
+    const float prev = accum;
+    accum += weight[i];
+    ties = ties || (i > 0 && !(prev < accum));
+    dup[i] = { accum, static_cast<uint32_t>(i) };
+  }
+  // std::sort(particles_dup_) (pf.h:200 / 408). Ascending and tie-free input is left as it is by any sort; with ties
+  // (weight-0 particles) libstdc++'s introsort decides who leads each tie group, so the very same std::sort runs here
+  // (the comparison looks at the accumulated probability only, like Particle::operator<, pf.h:104-107).
+  if (ties)
+    std::sort(dup.begin(), dup.end(),
+              [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
+  ctx->rs_keys.resize(n);
+  ctx->rs_order.resize(n);
+  for (size_t i = 0; i < n; ++i)
+  {
+    ctx->rs_keys[i] = dup[i].first;
+    ctx->rs_order[i] = dup[i].second;
+  }
+  ctx->rs_n = n;
+  ctx->rs_n_out = n_out;
+  ctx->rs_pstep = accum / n_out;  // pf.h:202 / 410 (float / size_t)
+  ctx->rs_planned = false;
+  if (out_pstep)
+    *out_pstep = ctx->rs_pstep;
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure(ctx, ctx->rs_d_keys, sizeof(float) * n));
+  TRY(h2d(ctx, ctx->rs_d_keys.p, ctx->rs_keys.data(), sizeof(float) * n));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mcl3dl_hip_resample_plan(mcl3dl_hip_ctx* ctx, int mode, float initial_p, uint32_t* out_source,
+                             uint8_t* out_duplicate, size_t* out_n_duplicates)
+{
+  if (!ctx)
+    return -1;
+  if (ctx->rs_n == 0)
+    return ctx->fail(-5, "resample_plan before resample_begin");
+  if (mode != 0 && mode != 1)
+    return ctx->fail(-3, "mode must be 0 (resample) or 1 (resizeParticle)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = ctx->rs_n, n_out = ctx->rs_n_out;
+  std::vector<float> pscan(n_out);
+  float acc = 0;
+  for (size_t i = 0; i < n_out; ++i)
+  {
+    if (mode == 0)
+      pscan[i] = ctx->rs_pstep * i + initial_p;  // pf.h:209
+    else
+      pscan[i] = (acc += ctx->rs_pstep);  // pf.h:421
+  }
+  TRY(ensure(ctx, ctx->rs_d_pscan, sizeof(float) * n_out));
+  TRY(ensure(ctx, ctx->rs_d_it, sizeof(uint32_t) * n_out));
+  TRY(h2d(ctx, ctx->rs_d_pscan.p, pscan.data(), sizeof(float) * n_out));
+  const int no = static_cast<int>(n_out);
+  hipLaunchKernelGGL(resample_lower_bound_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream,
+                     ctx->rs_d_keys.as<float>(), static_cast<int>(n), ctx->rs_d_pscan.as<float>(), no,
+                     ctx->rs_d_it.as<uint32_t>());
+  HIP_TRY(hipGetLastError());
+  std::vector<uint32_t> it(n_out);
+  TRY(d2h(ctx, it.data(), ctx->rs_d_it.p, sizeof(uint32_t) * n_out));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // the it / it_prev walk of pf.h:204-223 / 414-434 (pscan is non-decreasing, so the search that starts at the previous
+  // `it` lands where the global one does)
+  ctx->rs_source.resize(n_out);
+  ctx->rs_slot.assign(n_out, 0xffffffffu);
+  size_t it_prev = 0, n_dup = 0;
+  size_t cur = 0;
+  for (size_t i = 0; i < n_out; ++i)
+  {
+    cur = std::max<size_t>(cur, it[i]);
+    bool is_dup = false;
+    if (cur == n)
+    {
+      ctx->rs_source[i] = ctx->rs_order[it_prev];
+    }
+    else
+    {
+      is_dup = (mode == 0) && (cur == it_prev);
+      ctx->rs_source[i] = ctx->rs_order[cur];
+      it_prev = cur;
+    }
+    if (is_dup)
+      ctx->rs_slot[i] = static_cast<uint32_t>(n_dup++);
+    if (out_source)
+      out_source[i] = ctx->rs_source[i];
+    if (out_duplicate)
+      out_duplicate[i] = is_dup ? 1 : 0;
+  }
+  ctx->rs_n_dup = n_dup;
+  ctx->rs_planned = true;
+  if (out_n_duplicates)
+    *out_n_duplicates = n_dup;
+  TRY(ensure(ctx, ctx->rs_d_source, sizeof(uint32_t) * n_out));
+  TRY(ensure(ctx, ctx->rs_d_slot, sizeof(uint32_t) * n_out));
+  TRY(h2d(ctx, ctx->rs_d_source.p, ctx->rs_source.data(), sizeof(uint32_t) * n_out));
+  TRY(h2d(ctx, ctx->rs_d_slot.p, ctx->rs_slot.data(), sizeof(uint32_t) * n_out));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mcl3dl_hip_resample_apply_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13,
+                                     size_t n_noise, float* d_state13_out)
+{
+  if (!ctx)
+    return -1;
+  if (!ctx->rs_planned)
+    return ctx->fail(-5, "resample_apply before resample_plan");
+  if (!d_state13_in || !d_state13_out || d_state13_in == d_state13_out)
+    return ctx->fail(-3, "resample_apply needs distinct input and output state arrays");
+  if (n_noise < ctx->rs_n_dup || (ctx->rs_n_dup && !noise13))
+    return ctx->fail(-3, "resample_apply: %zu duplicated particles need noise, %zu given", ctx->rs_n_dup, n_noise);
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure(ctx, ctx->rs_d_noise, sizeof(float) * 13 * ctx->rs_n_dup));
+  TRY(h2d(ctx, ctx->rs_d_noise.p, noise13, sizeof(float) * 13 * ctx->rs_n_dup));
+  const int no = static_cast<int>(ctx->rs_n_out);
+  hipLaunchKernelGGL(resample_apply_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream, d_state13_in,
+                     ctx->rs_d_source.as<uint32_t>(), ctx->rs_d_slot.as<uint32_t>(), ctx->rs_d_noise.as<float>(), no,
+                     d_state13_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // noise13 is the caller's host buffer
+  return 0;
+}
+
+int mcl3dl_hip_resample_apply(mcl3dl_hip_ctx* ctx, const float* state13_in, const float* noise13, size_t n_noise,
+                              float* state13_out)
+{
+  if (!ctx)
+    return -1;
+  if (!ctx->rs_planned)
+    return ctx->fail(-5, "resample_apply before resample_plan");
+  if (!state13_in || !state13_out)
+    return ctx->fail(-3, "null state array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure(ctx, ctx->rs_d_in, sizeof(float) * 13 * ctx->rs_n));
+  TRY(ensure(ctx, ctx->rs_d_out, sizeof(float) * 13 * ctx->rs_n_out));
+  TRY(h2d(ctx, ctx->rs_d_in.p, state13_in, sizeof(float) * 13 * ctx->rs_n));
+  TRY(mcl3dl_hip_resample_apply_device(ctx, ctx->rs_d_in.as<float>(), noise13, n_noise, ctx->rs_d_out.as<float>()));
+  TRY(d2h(ctx, state13_out, ctx->rs_d_out.p, sizeof(float) * 13 * ctx->rs_n_out));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 // ---- measurement support ---------------------------------------------------------------------------------------

@@ -1228,6 +1228,273 @@ void orc_covariance(const float* poses, const float* weights, size_t n, float* o
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * pf::ParticleFilter::resample / resizeParticle — include/mcl_3dl/pf.h:187-225, 399-436
+ *
+ * The reference sorts a copy of the particle array by accumulated probability with std::sort. The accumulated
+ * probabilities are already ascending, but particles of weight 0 TIE with their predecessor, and libstdc++'s
+ * introsort is not stable: which particle of a tie group ends up first (and is therefore the one lower_bound
+ * picks) is decided by its partition swaps. To stay bit-identical, std::sort itself is restated below
+ * (third-party: libstdc++ <bits/stl_algo.h>, GCC 11: __introsort_loop, threshold 16, median-of-3 moved to
+ * first, __unguarded_partition, __final_insertion_sort; the heapsort fallback is never reached for
+ * ascending input and is restated for completeness). Pinned against the real std::sort through oracle/_ref.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct
+{
+  float key;    /* accum_probability_ */
+  uint32_t idx; /* which particle */
+} SortItem;
+
+#define LESS(a, b) ((a).key < (b).key) /* Particle::operator<, pf.h:104-107 */
+
+static void si_swap(SortItem* a, SortItem* b)
+{
+  SortItem t = *a;
+  *a = *b;
+  *b = t;
+}
+
+static void si_move_median_to_first(SortItem* result, SortItem* a, SortItem* b, SortItem* c)
+{
+  if (LESS(*a, *b))
+  {
+    if (LESS(*b, *c))
+      si_swap(result, b);
+    else if (LESS(*a, *c))
+      si_swap(result, c);
+    else
+      si_swap(result, a);
+  }
+  else if (LESS(*a, *c))
+    si_swap(result, a);
+  else if (LESS(*b, *c))
+    si_swap(result, c);
+  else
+    si_swap(result, b);
+}
+
+static SortItem* si_unguarded_partition(SortItem* first, SortItem* last, SortItem* pivot)
+{
+  for (;;)
+  {
+    while (LESS(*first, *pivot))
+      ++first;
+    --last;
+    while (LESS(*pivot, *last))
+      --last;
+    if (!(first < last))
+      return first;
+    si_swap(first, last);
+    ++first;
+  }
+}
+
+static void si_adjust_heap(SortItem* first, long hole, long len, SortItem value)
+{
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2)
+  {
+    child = 2 * (child + 1);
+    if (LESS(first[child], first[child - 1]))
+      child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2)
+  {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  long parent = (hole - 1) / 2; /* __push_heap */
+  while (hole > top && LESS(first[parent], value))
+  {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+
+static void si_heapsort(SortItem* first, SortItem* last) /* __partial_sort(first, last, last) */
+{
+  const long len = last - first;
+  if (len >= 2)
+    for (long parent = (len - 2) / 2;; --parent)
+    {
+      si_adjust_heap(first, parent, len, first[parent]);
+      if (parent == 0)
+        break;
+    }
+  while (last - first > 1)
+  {
+    --last;
+    SortItem value = *last;
+    *last = *first;
+    si_adjust_heap(first, 0, last - first, value);
+  }
+}
+
+static void si_introsort_loop(SortItem* first, SortItem* last, long depth_limit)
+{
+  while (last - first > 16)
+  {
+    if (depth_limit == 0)
+    {
+      si_heapsort(first, last);
+      return;
+    }
+    --depth_limit;
+    SortItem* mid = first + (last - first) / 2;
+    si_move_median_to_first(first, first + 1, mid, last - 1);
+    SortItem* cut = si_unguarded_partition(first + 1, last, first);
+    si_introsort_loop(cut, last, depth_limit);
+    last = cut;
+  }
+}
+
+static void si_unguarded_linear_insert(SortItem* last)
+{
+  SortItem val = *last;
+  SortItem* next = last - 1;
+  while (LESS(val, *next))
+  {
+    *last = *next;
+    last = next;
+    --next;
+  }
+  *last = val;
+}
+
+static void si_insertion_sort(SortItem* first, SortItem* last)
+{
+  if (first == last)
+    return;
+  for (SortItem* i = first + 1; i != last; ++i)
+  {
+    if (LESS(*i, *first))
+    {
+      SortItem val = *i;
+      memmove(first + 1, first, (size_t)(i - first) * sizeof(SortItem));
+      *first = val;
+    }
+    else
+      si_unguarded_linear_insert(i);
+  }
+}
+
+static void si_std_sort(SortItem* first, SortItem* last)
+{
+  if (first == last)
+    return;
+  long n = last - first, lg = 0;
+  while (n > 1)
+  {
+    n >>= 1;
+    ++lg;
+  }
+  si_introsort_loop(first, last, lg * 2);
+  if (last - first > 16)
+  {
+    si_insertion_sort(first, first + 16);
+    for (SortItem* i = first + 16; i != last; ++i)
+      si_unguarded_linear_insert(i);
+  }
+  else
+    si_insertion_sort(first, last);
+}
+
+static size_t si_lower_bound(const SortItem* a, size_t from, size_t n, float pscan)
+{
+  size_t lo = from, len = n - from; /* std::lower_bound */
+  while (len > 0)
+  {
+    const size_t half = len >> 1, mid = lo + half;
+    if (a[mid].key < pscan)
+    {
+      lo = mid + 1;
+      len = len - half - 1;
+    }
+    else
+      len = half;
+  }
+  return lo;
+}
+
+float orc_resample_pstep(const float* weight, size_t n, size_t n_out)
+{
+  float accum = 0;
+  for (size_t i = 0; i < n; ++i)
+    accum += weight[i]; /* pf.h:193-197 / 401-405 */
+  return accum / n_out; /* :202 (n_out == n) / :410 */
+}
+
+/* mode 0: resample (pf.h:191-224), mode 1: resizeParticle (pf.h:399-436).
+ * out_source[i] = index of the particle whose state slot i receives; out_dup[i] = 1 when the reference adds noise. */
+void orc_resample_plan(const float* weight, size_t n, size_t n_out, int mode, float initial_p, uint32_t* out_source,
+                       uint8_t* out_dup)
+{
+  SortItem* dup = (SortItem*)malloc(sizeof(SortItem) * (n ? n : 1));
+  float accum = 0;
+  for (size_t i = 0; i < n; ++i)
+  {
+    accum += weight[i];
+    dup[i].key = accum;
+    dup[i].idx = (uint32_t)i;
+  }
+  si_std_sort(dup, dup + n); /* std::sort(particles_dup_), :200 / :408 */
+  const float pstep = accum / n_out;
+  float pscan = 0;
+  size_t it = 0, it_prev = 0;
+  for (size_t i = 0; i < n_out; ++i)
+  {
+    if (mode == 0)
+      pscan = pstep * i + initial_p; /* :209 */
+    else
+      pscan += pstep; /* :421 */
+    it = si_lower_bound(dup, it, n, pscan);
+    out_dup[i] = 0;
+    if (it == n)
+    {
+      out_source[i] = dup[it_prev].idx; /* :212-216 / :425-429 */
+      continue;
+    }
+    if (mode == 0 && it == it_prev)
+      out_dup[i] = 1; /* :217-221 */
+    out_source[i] = dup[it].idx;
+    it_prev = it;
+  }
+  free(dup);
+}
+
+/* State6DOF::operator+ (state_6dof.h:248-260) then normalize() (:150-153) for duplicated particles; plain copies otherwise. */
+void orc_resample_apply(const float* state13_in, const uint32_t* source, const uint8_t* dupf, const float* noise13,
+                        size_t n_out, float* state13_out)
+{
+  size_t d = 0;
+  for (size_t i = 0; i < n_out; ++i)
+  {
+    const float* s = &state13_in[13 * (size_t)source[i]];
+    float* o = &state13_out[13 * i];
+    if (!dupf[i])
+    {
+      memcpy(o, s, sizeof(float) * 13);
+      continue;
+    }
+    const float* a = &noise13[13 * d++];
+    for (int k = 0; k < 13; ++k)
+      if (k < 3 || k > 6)
+        o[k] = s[k] + a[k];
+    const Q4 ar = { a[3], a[4], a[5], a[6] }, sr = { s[3], s[4], s[5], s[6] };
+    const Q4 r = q_normalized(q_mul(ar, sr)); /* ret.rot_ = a.rot_ * rot_; then rot_.normalize() */
+    o[3] = r.x;
+    o[4] = r.y;
+    o[5] = r.z;
+    o[6] = r.w;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Workload statistics for the algorithmic-bytes accounting — oracle-only helpers.
  * ---------------------------------------------------------------------------------------------- */
 void orc_count_neighbourhood(void* h, const float* poses, size_t n_p, const float* scan_xyz, size_t n_s,

@@ -57,6 +57,12 @@ void orc_expectation(const float* poses, const float* weights, const float* bias
                      int* out_max_index, int* out_max_biased_index);
 void orc_covariance(const float* poses, const float* weights, size_t n, float* out_cov36, float* out_mean7);
 
+float orc_resample_pstep(const float* weight, size_t n, size_t n_out);
+void orc_resample_plan(const float* weight, size_t n, size_t n_out, int mode, float initial_p, uint32_t* out_source,
+                       uint8_t* out_dup);
+void orc_resample_apply(const float* state13_in, const uint32_t* source, const uint8_t* dup, const float* noise13,
+                        size_t n_out, float* state13_out);
+
 /* Extra, oracle-only: exact workload statistics used by bench.py / DESIGN.md for the algorithmic-bytes
  * accounting: K = map points in the 3x3x3 cell neighbourhood (cell edge = match_dist_min
  * in the weighted metric) of each transformed scan point, summed over a batch of poses. */

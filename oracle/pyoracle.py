@@ -134,6 +134,14 @@ class Oracle:
         s("pf_measure", _i, [_p, _p, _sz, _p])
         s("expectation", None, [_p, _p, _p, _sz, _p, _p, _p])
         s("covariance", None, [_p, _p, _sz, _p, _p])
+        if self.kind == "ref":
+            s("resample", None, [_p, _p, _sz, C.c_uint, _p, _p, _p])
+            s("resample_draws", None, [C.c_uint, _f, _p, _sz, _p, _p])
+            s("resize", None, [_p, _p, _sz, _sz, _p, _p])
+        else:
+            s("resample_pstep", _f, [_p, _sz, _sz])
+            s("resample_plan", None, [_p, _sz, _sz, _i, _f, _p, _p])
+            s("resample_apply", None, [_p, _p, _p, _p, _sz, _p])
         s("measure_update", _d, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _f,
                                  _p, _p, _p, _p, _p, _p, _p])
 
@@ -263,6 +271,55 @@ class Oracle:
         mean = np.zeros(7, np.float32)
         self._fn("covariance")(_fp(poses), _fp(w), len(poses), _fp(cov), _fp(mean))
         return cov, mean
+
+    # ---- resampling: the real pf.h code with a seeded engine ("ref") / the deterministic restatement ("port") ------
+    def resample(self, state13, weights, seed, sigma6):
+        assert self.kind == "ref"
+        s = _f32(state13, 13)
+        w = _f32(weights)
+        out = np.zeros_like(s)
+        wout = np.zeros_like(w)
+        self._fn("resample")(_fp(s), _fp(w), len(s), int(seed), _fp(_f32(sigma6)), _fp(out), _fp(wout))
+        return out, wout
+
+    def resample_draws(self, seed, pstep, sigma6, n_dup):
+        assert self.kind == "ref"
+        ip = C.c_float(0)
+        noise = np.zeros((max(n_dup, 1), 13), np.float32)
+        self._fn("resample_draws")(int(seed), float(pstep), _fp(_f32(sigma6)), n_dup, C.byref(ip), _fp(noise))
+        return float(ip.value), noise[:n_dup]
+
+    def resize(self, state13, weights, n_out):
+        assert self.kind == "ref"
+        s = _f32(state13, 13)
+        w = _f32(weights)
+        out = np.zeros((n_out, 13), np.float32)
+        wout = np.zeros(n_out, np.float32)
+        self._fn("resize")(_fp(s), _fp(w), len(s), n_out, _fp(out), _fp(wout))
+        return out, wout
+
+    def resample_pstep(self, weights, n_out):
+        assert self.kind == "port"
+        w = _f32(weights)
+        return float(self._fn("resample_pstep")(_fp(w), len(w), n_out))
+
+    def resample_plan(self, weights, n_out, mode, initial_p):
+        assert self.kind == "port"
+        w = _f32(weights)
+        src = np.zeros(n_out, np.uint32)
+        dup = np.zeros(n_out, np.uint8)
+        self._fn("resample_plan")(_fp(w), len(w), n_out, int(mode), float(initial_p), _fp(src), _fp(dup))
+        return src, dup
+
+    def resample_apply(self, state13, source, dup, noise13):
+        assert self.kind == "port"
+        s = _f32(state13, 13)
+        src = np.ascontiguousarray(source, np.uint32)
+        d = np.ascontiguousarray(dup, np.uint8)
+        nz = _f32(noise13 if len(noise13) else np.zeros((1, 13)), 13)
+        out = np.zeros((len(src), 13), np.float32)
+        self._fn("resample_apply")(_fp(s), _fp(src), _fp(d), _fp(nz), len(src), _fp(out))
+        return out
 
     def measure_update(self, poses, weights, scan_lik, scan_beam, scan_beam_label, origins, odom_err=None,
                        odom_sigma=1.0):

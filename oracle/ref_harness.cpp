@@ -567,4 +567,72 @@ void ref_covariance(const float* poses, const float* weights, size_t n, float* o
     for (size_t k = 0; k < 6; ++k)
       out_cov36[6 * j + k] = cov[j][k];
 }
+
+namespace
+{
+using PF6 = mcl_3dl::pf::ParticleFilter<mcl_3dl::State6DOF, float, mcl_3dl::ParticleWeightedMeanQuat,
+                                        std::default_random_engine>;
+void loadStates13(PF6& pf, const float* state13, const float* weight)
+{
+  size_t i = 0;
+  for (auto it = pf.begin(); it != pf.end(); ++it, ++i)
+  {
+    for (size_t k = 0; k < 13; ++k)
+      it->state_[k] = state13[13 * i + k];
+    it->probability_ = weight[i];
+  }
+}
+void storeStates13(PF6& pf, float* state13, float* weight)
+{
+  size_t i = 0;
+  for (auto it = pf.begin(); it != pf.end(); ++it, ++i)
+  {
+    for (size_t k = 0; k < 13; ++k)
+      state13[13 * i + k] = it->state_[k];
+    if (weight)
+      weight[i] = it->probability_;
+  }
+}
+mcl_3dl::State6DOF sigmaState(const float* sigma6)
+{
+  return mcl_3dl::State6DOF(mcl_3dl::Vec3(sigma6[0], sigma6[1], sigma6[2]), mcl_3dl::Vec3(sigma6[3], sigma6[4], sigma6[5]));
+}
+}  // namespace
+
+// pf::ParticleFilter::resample(sigma) (include/mcl_3dl/pf.h:187-225) with the filter's engine seeded with `seed`, on
+// 13-dof State6DOF vectors (state_6dof.h:80-149: pos, rot, odom_err_integ_lin, odom_err_integ_ang).
+void ref_resample(const float* state13, const float* weight, size_t n, unsigned seed, const float* sigma6,
+                  float* out_state13, float* out_weight)
+{
+  PF6 pf(static_cast<int>(n), seed);
+  loadStates13(pf, state13, weight);
+  pf.resample(sigmaState(sigma6));
+  storeStates13(pf, out_state13, out_weight);
+}
+
+// The random numbers that call consumes, in order, reproduced on an identically seeded engine: initial_p =
+// uniform_real_distribution<float>(0, pstep)(engine) (pf.h:203), then one State6DOF::generateNoise per duplicated
+// particle (pf.h:216, state_6dof.h:226-247, noise_generators/diagonal_noise_generator.h:66-80).
+void ref_resample_draws(unsigned seed, float pstep, const float* sigma6, size_t n_dup, float* out_initial_p,
+                        float* out_noise13)
+{
+  std::default_random_engine engine(seed);
+  *out_initial_p = std::uniform_real_distribution<float>(0.0, pstep)(engine);
+  const mcl_3dl::DiagonalNoiseGenerator<float> gen(mcl_3dl::State6DOF(), sigmaState(sigma6));
+  for (size_t d = 0; d < n_dup; ++d)
+  {
+    mcl_3dl::State6DOF noise = mcl_3dl::State6DOF::generateNoise<mcl_3dl::State6DOF>(engine, gen);
+    for (size_t k = 0; k < 13; ++k)
+      out_noise13[13 * d + k] = noise[k];
+  }
+}
+
+// pf::ParticleFilter::resizeParticle(num) (pf.h:399-436)
+void ref_resize(const float* state13, const float* weight, size_t n, size_t n_out, float* out_state13, float* out_weight)
+{
+  PF6 pf(static_cast<int>(n), 12345);
+  loadStates13(pf, state13, weight);
+  pf.resizeParticle(n_out);
+  storeStates13(pf, out_state13, out_weight);
+}
 }  // extern "C"

@@ -87,5 +87,39 @@ def main():
     print("beam_wall_fixture: ", "".join("s*lt"[s] for s in out["status_m1_h2"]))
 
 
+def resample_goldens():
+    """pf::resample (seed 12345) and pf::resizeParticle through the real pf.h: expected states + the random numbers the
+    resample consumed (so that a path that keeps the caller's RNG outside can be replayed exactly)."""
+    import resample_cases as rc
+    ref = pyoracle.Oracle("ref")
+    port = pyoracle.Oracle("port")
+    out = {}
+    for n, dead in rc.CASES:
+        s, w = rc.make_case(n, dead)
+        want, _ = ref.resample(s, w, rc.SEED, rc.SIGMA6)
+        pstep = port.resample_pstep(w, n)
+        ip, _ = ref.resample_draws(rc.SEED, pstep, rc.SIGMA6, 0)
+        src, dup = port.resample_plan(w, n, 0, ip)
+        _, noise = ref.resample_draws(rc.SEED, pstep, rc.SIGMA6, int(dup.sum()))
+        assert np.array_equal(port.resample_apply(s, src, dup, noise), want)
+        key = "n%d_d%d" % (n, dead)
+        out[key + "_states"] = want
+        out[key + "_initial_p"] = np.float32(ip)
+        out[key + "_noise"] = noise
+        out[key + "_source"] = src
+        out[key + "_dup"] = dup
+        for n_out in rc.resize_targets(n):
+            out[key + "_resize%d" % n_out] = ref.resize(s, w, n_out)[0]
+        print("resample", key, "duplicates", int(dup.sum()), "dead particles picked", int((w[src] == 0).sum()))
+    # the draw behind the upstream KAT test/src/test_pf.cpp:210-289 (engine seed 12345, pstep = sum(probs) / 5)
+    small = np.float32(1.0e-06)
+    for name, probs in (("first", [small, 0.2, 0.2, 0.2, np.float32(0.4) - small]),
+                        ("last", [0.2, 0.2, 0.2, np.float32(0.4) - small, small])):
+        pstep = port.resample_pstep(np.array(probs, np.float32), 5)
+        out["kat_initial_p_" + name] = np.float32(ref.resample_draws(12345, pstep, np.zeros(6, np.float32), 0)[0])
+    np.savez_compressed(os.path.join(HERE, "resample.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    resample_goldens()

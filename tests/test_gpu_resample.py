@@ -1,0 +1,80 @@
+"""GPU tests of the resampling row: mcl3dl_hip_resample_begin / plan / apply against the committed outputs
+of the real pf.h (tests/golden/resample.npz; bit-exact, including who leads the tie groups of weight-0 particles) and,
+where oracle/_ref is present, against the live reference with other seeds."""
+import os
+
+import numpy as np
+import pytest
+
+import resample_cases as rc
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample.npz"))
+
+
+def test_upstream_resample_kats(engine):
+    """test/src/test_pf.cpp:210-289 (ResampleFirstAndLastParticle) and :190-208 (flat likelihood = identity)."""
+    small = np.float32(1.0e-06)
+    states = np.zeros((5, 13), np.float32)
+    states[:, 0] = np.arange(5)
+    states[:, 6] = 1.0
+    for name, probs, expected in (("first", [small, 0.2, 0.2, 0.2, np.float32(0.4) - small], [1, 2, 3, 4, 4]),
+                                  ("last", [0.2, 0.2, 0.2, np.float32(0.4) - small, small], [0, 1, 2, 3, 3])):
+        engine.resample_begin(np.array(probs, np.float32))
+        src, dup, nd = engine.resample_plan(0, float(GOLD["kat_initial_p_" + name]))
+        noise = np.zeros((nd, 13), np.float32)
+        noise[:, 6] = 1.0  # zero sigma: the noise state is the identity
+        out = engine.resample_apply(states, noise)
+        assert out[:, 0].tolist() == [float(v) for v in expected]
+    pstep = engine.resample_begin(np.full(10, 0.1, np.float32))
+    src, dup, nd = engine.resample_plan(0, pstep * 0.5)
+    assert src.tolist() == list(range(10))
+
+
+@pytest.mark.parametrize("n,dead", rc.CASES)
+def test_against_reference_goldens(engine, n, dead):
+    s, w = rc.make_case(n, dead)
+    key = "n%d_d%d" % (n, dead)
+    engine.resample_begin(w)
+    src, dup, nd = engine.resample_plan(0, float(GOLD[key + "_initial_p"]))
+    np.testing.assert_array_equal(src, GOLD[key + "_source"])
+    np.testing.assert_array_equal(dup, GOLD[key + "_dup"])
+    assert nd == len(GOLD[key + "_noise"])
+    np.testing.assert_array_equal(engine.resample_apply(s, GOLD[key + "_noise"]), GOLD[key + "_states"])
+    for n_out in rc.resize_targets(n):
+        engine.resample_begin(w, n_out)
+        s2, d2, nd2 = engine.resample_plan(1)
+        assert nd2 == 0
+        np.testing.assert_array_equal(engine.resample_apply(s), GOLD[key + "_resize%d" % n_out])
+
+
+@pytest.mark.parametrize("n,dead", [(300, 120), (20000, 9000), (262144, 0)])
+def test_against_live_reference(engine, n, dead):
+    if not pyoracle.available("ref"):
+        pytest.skip("oracle/_ref not on this box; the golden test above covers the reference")
+    ref = pyoracle.Oracle("ref")
+    s, w = rc.make_case(n, dead)
+    seed = 777
+    want, _ = ref.resample(s, w, seed, rc.SIGMA6)
+    pstep = engine.resample_begin(w)
+    ip, _ = ref.resample_draws(seed, pstep, rc.SIGMA6, 0)
+    src, dup, nd = engine.resample_plan(0, ip)
+    _, noise = ref.resample_draws(seed, pstep, rc.SIGMA6, nd)
+    np.testing.assert_array_equal(engine.resample_apply(s, noise), want)
+
+
+def test_error_paths(engine):
+    from mcl_3dl_amd import capi
+    e = capi.Engine(0)
+    with pytest.raises(capi.EngineError, match="before resample_begin"):
+        e._rs_n_out = 4
+        e.resample_plan(0, 0.0)
+    e.resample_begin(np.full(4, 0.25, np.float32))
+    with pytest.raises(capi.EngineError, match="before resample_plan"):
+        e.resample_apply(np.zeros((4, 13), np.float32))
+    src, dup, nd = e.resample_plan(0, 0.0)
+    assert nd > 0
+    with pytest.raises(capi.EngineError, match="need noise"):
+        e.resample_apply(np.zeros((4, 13), np.float32), None)
+    e.close()
