@@ -294,6 +294,20 @@ def main():
             eng.covariance_device(d_pose, d_w, n_p, mean7)
         out["post_update_reductions"] = {"ms": (time.perf_counter() - t3) / 10 * 1e3,
                                          "what": "expectationBiased + max + covariance over this rank's particles"}
+        # resampling of this rank's particles with the weights the update just produced: host bookkeeping
+        # (prefix sums, tie sort, it/it_prev walk) + device lower_bound / gather; noise = identity (timing only)
+        w_host = d_w.cpu().numpy()
+        st13 = np.zeros((n_p, 13), np.float32)
+        st13[:, :7] = sc.poses
+        t4 = time.perf_counter()
+        for _ in range(5):
+            pstep = eng.resample_begin(w_host)
+            _src, _dup, n_dup = eng.resample_plan(0, 0.37 * pstep)
+            ident = np.zeros((n_dup, 13), np.float32)
+            ident[:, 6] = 1.0
+            eng.resample_apply(st13, ident)
+        out["resample"] = {"ms": (time.perf_counter() - t4) / 5 * 1e3, "duplicates": int(n_dup),
+                           "what": "mcl3dl_hip_resample_begin + plan + apply, host buffers, %d particles" % n_p}
         if world == 1:
             # the drop-in boundary hands over HOST buffers: time the synchronous host entry point too (scan ordering on
             # the host, H2D of scan + poses + weights, kernels, D2H of weights) — never part of `value`
