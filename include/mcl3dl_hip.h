@@ -117,6 +117,14 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, 
 int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz /*n*3*/, const float* end_xyz /*n*3*/,
                            size_t n, int32_t* status /*n*/, int32_t* hit_index /*n or NULL*/);
 
+/* Replaces: ChunkedKdtree::radiusSearch(p, radius, id, sqdist, 1) (include/mcl_3dl/chunked_kdtree.h:217-237) for n query
+ * points (map frame) and ANY radius — besides the likelihood model the node searches with unmatch_output_dist
+ * (matched / unmatched clouds, src/mcl_3dl.cpp:776-789) and with the global-localisation grid (:1058-1070).
+ * out_index[i] = map index of the nearest point with d2 < (float)(radius*radius) in the dist_weight-rescaled metric, or -1;
+ * out_sqdist[i] = that d2 (flann::L2_Simple float arithmetic), -1 when not found. Ties in d2 -> the lowest index. */
+int mcl3dl_hip_radius_search(mcl3dl_hip_ctx* ctx, const float* query_xyz /*n*3*/, size_t n, float radius,
+                             int32_t* out_index /*n*/, float* out_sqdist /*n or NULL*/);
+
 /* Replaces: driving one RaycastUsingDDA by hand — setRay + getNextCastResult until the first collision
  * (include/mcl_3dl/raycast.h:45-77, include/mcl_3dl/raycasts/raycast_using_dda.h:66-159), the way the reference's
  * waypoint tests do (test/src/test_raycast_dda.cpp:157-183). Uses the caster of mcl3dl_hip_set_beam_params

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mcl3dl_hip_pf_measure": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
+    "mcl3dl_hip_radius_search": (_i, [_p, _p, _sz, _f, _p, _p]),
     "mcl3dl_hip_dda_trace": (_i, [_p, _p, _p, _p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mcl3dl_hip_expectation": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_covariance": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
@@ -265,6 +266,13 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_resample_apply(self.h, _ptr(s), _ptr(nz), 0 if nz is None else len(nz),
                                                        _ptr(out)))
         return out
+
+    def radius_search(self, query_xyz, radius):
+        q = _np_f32(query_xyz, 3)
+        idx = np.zeros(len(q), np.int32)
+        sq = np.zeros(len(q), np.float32)
+        self._check(self.lib.mcl3dl_hip_radius_search(self.h, _ptr(q), len(q), float(radius), _ptr(idx), _ptr(sq)))
+        return idx, sq
 
     def dda_trace(self, begin, end, max_out=4096):
         b = _np_f32(begin)

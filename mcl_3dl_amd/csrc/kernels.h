@@ -150,8 +150,7 @@ __device__ inline float nearest_d2_cand(const CandGrid& g, float qx, float qy, f
   return best;
 }
 
-// MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates (overflow runs for
-// voxels with more than 5).
+// flann::L2_Simple<float>: ((0 + dx*dx) + dy*dy) + dz*dz, float, no contraction
 __device__ inline float d2_simple(float qx, float qy, float qz, float px, float py, float pz)
 {
   const float dx = qx - px, dy = qy - py, dz = qz - pz;
@@ -160,6 +159,64 @@ __device__ inline float d2_simple(float qx, float qy, float qz, float px, float 
   d2 = d2 + dz * dz;
   return d2;
 }
+
+// ChunkedKdtree::radiusSearch(p, radius, id, sqdist, 1) as a stand-alone query (include/mcl_3dl/chunked_kdtree.h:217-237):
+// nearest map point with d2 < (float)(radius*radius) in the rescaled metric, ANY radius (the node also searches with
+// unmatch_output_dist, src/mcl_3dl.cpp:780, and global_localization_grid, :1058-1070). Walks the cell-sorted map over
+// ceil(radius / cell) cells each way: one contiguous run per (y,z) row. Ties in d2 resolve to the lowest map index.
+__global__ void radius_search_kernel(const float* __restrict__ query_xyz, int n, LikGrid g, LikParams prm, float radius,
+                                     float r2, int reach, int* __restrict__ out_index, float* __restrict__ out_sqdist)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  float qx = query_xyz[3 * i], qy = query_xyz[3 * i + 1], qz = query_xyz[3 * i + 2];
+  if (prm.has_weight)
+  {
+    qx = qx * prm.wx;
+    qy = qy * prm.wy;
+    qz = qz * prm.wz;
+  }
+  (void)radius;
+  float best = r2;
+  int best_idx = -1;
+  const float fx = floorf((qx - g.ox) * g.inv_cell), fy = floorf((qy - g.oy) * g.inv_cell),
+              fz = floorf((qz - g.oz) * g.inv_cell);
+  // NaN / far-away queries: comparisons fail -> no neighbour
+  if (fx >= -static_cast<float>(reach) && fy >= -static_cast<float>(reach) && fz >= -static_cast<float>(reach) &&
+      fx <= static_cast<float>(g.nx - 1 + reach) && fy <= static_cast<float>(g.ny - 1 + reach) &&
+      fz <= static_cast<float>(g.nz - 1 + reach))
+  {
+    const int cx = static_cast<int>(fx), cy = static_cast<int>(fy), cz = static_cast<int>(fz);
+    const int x0 = max(cx - reach, 0), x1 = min(cx + reach, g.nx - 1);
+    const int y0 = max(cy - reach, 0), y1 = min(cy + reach, g.ny - 1);
+    const int z0 = max(cz - reach, 0), z1 = min(cz + reach, g.nz - 1);
+    if (x0 <= x1)
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y)
+        {
+          const size_t row = (static_cast<size_t>(z) * g.ny + y) * g.nx;
+          const uint32_t s = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+          for (uint32_t k = s; k < e; ++k)
+          {
+            const float4 p = g.pts[k];
+            const float d2 = d2_simple(qx, qy, qz, p.x, p.y, p.z);
+            const int idx = static_cast<int>(__float_as_uint(p.w));
+            if (d2 < best || (d2 == best && best_idx >= 0 && idx < best_idx))
+            {
+              best = d2;
+              best_idx = idx;
+            }
+          }
+        }
+  }
+  out_index[i] = best_idx;
+  if (out_sqdist)
+    out_sqdist[i] = best_idx >= 0 ? best : -1.0f;
+}
+
+// MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates (overflow runs for
+// voxels with more than 5).
 
 template <bool STATS>
 __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)

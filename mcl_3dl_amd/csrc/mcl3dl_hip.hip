@@ -1457,6 +1457,39 @@ int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* 
   return 0;
 }
 
+// ---- R4 as a stand-alone query: ChunkedKdtree::radiusSearch -------------------------------------------------------------
+int mcl3dl_hip_radius_search(mcl3dl_hip_ctx* ctx, const float* query_xyz, size_t n, float radius, int32_t* out_index,
+                             float* out_sqdist)
+{
+  if (!ctx)
+    return -1;
+  if (n == 0)
+    return 0;
+  if (!query_xyz || !out_index || n > 0x7fffffffu || !(radius > 0.f))
+    return ctx->fail(-3, "bad arguments to radius_search");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure_structures(ctx, true, false, true));  // the cell-sorted map
+  const float cell = 1.0f / ctx->lg.inv_cell;
+  const int reach = static_cast<int>(std::ceil(radius / cell)) + 1;
+  if (reach > 64)
+    return ctx->fail(-3, "radius %.3g is more than 64 cells of the map index", radius);
+  TRY(ensure(ctx, ctx->ray_begin, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->ray_hit, sizeof(int) * n));
+  TRY(ensure(ctx, ctx->ray_end, sizeof(float) * n));
+  TRY(h2d(ctx, ctx->ray_begin.p, query_xyz, sizeof(float) * 3 * n));
+  const LikParams lp = lik_params(ctx);
+  const float r2 = static_cast<float>(static_cast<double>(radius) * static_cast<double>(radius));
+  const int ni = static_cast<int>(n);
+  hipLaunchKernelGGL(radius_search_kernel, dim3((ni + 63) / 64), dim3(64), 0, ctx->stream, ctx->ray_begin.as<float>(), ni,
+                     ctx->lg, lp, radius, r2, reach, ctx->ray_hit.as<int>(), ctx->ray_end.as<float>());
+  HIP_TRY(hipGetLastError());
+  TRY(d2h(ctx, out_index, ctx->ray_hit.p, sizeof(int) * n));
+  if (out_sqdist)
+    TRY(d2h(ctx, out_sqdist, ctx->ray_end.p, sizeof(float) * n));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 // ---- "next" row: expectation / max / covariance ----------------------------------------------------------------------
 // Quat(const Vec3& forward, const Vec3& up_raw), include/mcl_3dl/quat.h:61-80 (host, float with double square roots)
 static Quat quat_from_front_up(Vec3f forward, Vec3f up_raw)

@@ -72,6 +72,35 @@ def test_chunked_kdtree_kat_through_the_likelihood_score(engine):
     engine.set_likelihood_params()
 
 
+def test_chunked_kdtree_kat_indices(engine):
+    """test/src/test_chunked_kdtree.cpp:38-88 directly: the nearest INDEX for each of the six queries."""
+    engine.set_map(kats.KDTREE_MAP, None, stamp=107, dist_weight=None)
+    idx, sq = engine.radius_search(kats.KDTREE_QUERIES, kats.KDTREE_RADIUS)
+    assert idx.tolist() == kats.KDTREE_EXPECTED
+
+
+def test_radius_search_against_oracle(engine, oracle_kind):
+    """ChunkedKdtree::radiusSearch for several radii (likelihood 0.2, unmatch_output_dist 0.5, a large 1.3) and both
+    metrics: found flag, map index and squared distance identical to the oracle."""
+    from mcl_3dl_amd.synthetic import make_scene
+    from oracle import pyoracle
+    sc = make_scene(n=41, n_p=4, n_s=600, seed=9)
+    rng = np.random.default_rng(3)
+    for dw in (None, (1.0, 1.0, 5.0)):
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=108, dist_weight=dw)
+        o = pyoracle.Oracle(oracle_kind, 20.0, 1.5)
+        o.set_map(sc.map_xyz, sc.map_label, dist_weight=dw)
+        q = o.transform(sc.poses[0], sc.scan_lik)
+        q = np.concatenate([q, rng.uniform(-3, 3, (400, 3)).astype(np.float32), [[np.nan, 0, 0], [1e6, 0, 0]]], 0).astype(np.float32)
+        for radius in (0.2, 0.5, 1.3):
+            idx, sq = engine.radius_search(q, radius)
+            found, widx, wsq = o.radius_search(q, radius)
+            np.testing.assert_array_equal(idx >= 0, found == 1)
+            np.testing.assert_array_equal(idx, widx)
+            np.testing.assert_array_equal(sq, wsq)
+            assert (found == 1).sum() > 100 and (found == 0).sum() > 1
+
+
 def test_quat_rotation_table_through_the_transform(engine):
     """test/src/test_quat.cpp:234-273: r * v, observed as the position of the nearest map point found."""
     # a map holding the 6 axis unit points; a scan point v under pose (0, r) must land on the expected one exactly
