@@ -635,54 +635,68 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
   // a (dependent, high-latency) load happens only when the ray enters a new 4x4x4 brick.
   int cur_brick = -1;
   unsigned long long word = 0ull;
+  // Two nested loops instead of one ("while-while" traversal): the inner loop only WALKS — to the next occupied voxel
+  // or to the end of the ray — and the point tests of that voxel run after it. On a wavefront the inner loop ends when
+  // every ray has found its voxel (or run out), so the long, double-precision test body executes once per round for all
+  // 64 rays together instead of once per step for whichever ray happens to sit on an occupied voxel (a ray visits
+  // ~1.0 occupied voxel on its way: measured). The per-ray sequence of operations is unchanged.
   for (;;)
   {
-    // getNextCastResult, :106-159
-    ++pos;
-    if (pos >= max_movement)
-      break;
-    // axis choice of :114-147 (strict <, ties fall to the later axis), written branch-free so the 64 rays of a wavefront
-    // do not serialise on three divergent bodies; only the chosen axis changes (incrementIndex, :192-203).
-    const bool x_first = tmx < tmy;
-    const bool ax = x_first && (tmx < tmz);
-    const bool ay = !x_first && (tmy < tmz);
-    const bool az = !(ax || ay);
-    cx += ax ? sx : 0;
-    cy += ay ? sy : 0;
-    cz += az ? sz : 0;
-    const float nx_t = iex + tdx * static_cast<float>(abs(cx - bx));
-    const float ny_t = iey + tdy * static_cast<float>(abs(cy - by));
-    const float nz_t = iez + tdz * static_cast<float>(abs(cz - bz));
-    tmx = ax ? nx_t : tmx;
-    tmy = ay ? ny_t : tmy;
-    tmz = az ? nz_t : tmz;
-    // only the moved index can have left the grid (the others were checked when they moved; begin is inside the map)
-    const bool inside = static_cast<unsigned>(cx) < static_cast<unsigned>(g.nx) &&
-                        static_cast<unsigned>(cy) < static_cast<unsigned>(g.ny) &&
-                        static_cast<unsigned>(cz) < static_cast<unsigned>(g.nz);
-    if (!inside)
-      break;
-    if (STATS)
-      ++st_steps;
-    if (TRACE)
+    bool found = false;
+    for (;;)
     {
-      if (tr->n < tr->max)
+      // getNextCastResult, :106-159
+      ++pos;
+      if (pos >= max_movement)
+        break;
+      // axis choice of :114-147 (strict <, ties fall to the later axis), written branch-free so the 64 rays of a
+      // wavefront do not serialise on three divergent bodies; only the chosen axis changes (incrementIndex, :192-203).
+      const bool x_first = tmx < tmy;
+      const bool ax = x_first && (tmx < tmz);
+      const bool ay = !x_first && (tmy < tmz);
+      const bool az = !(ax || ay);
+      cx += ax ? sx : 0;
+      cy += ay ? sy : 0;
+      cz += az ? sz : 0;
+      const float nx_t = iex + tdx * static_cast<float>(abs(cx - bx));
+      const float ny_t = iey + tdy * static_cast<float>(abs(cy - by));
+      const float nz_t = iez + tdz * static_cast<float>(abs(cz - bz));
+      tmx = ax ? nx_t : tmx;
+      tmy = ay ? ny_t : tmy;
+      tmz = az ? nz_t : tmz;
+      // only the moved index can have left the grid (the others were checked when they moved; begin is inside the map)
+      const bool inside = static_cast<unsigned>(cx) < static_cast<unsigned>(g.nx) &&
+                          static_cast<unsigned>(cy) < static_cast<unsigned>(g.ny) &&
+                          static_cast<unsigned>(cz) < static_cast<unsigned>(g.nz);
+      if (!inside)
+        break;
+      if (STATS)
+        ++st_steps;
+      if (TRACE)
       {
-        tr->xyz[3 * tr->n + 0] = static_cast<float>((cx + 0.5) * g.grid + g.min_x);
-        tr->xyz[3 * tr->n + 1] = static_cast<float>((cy + 0.5) * g.grid + g.min_y);
-        tr->xyz[3 * tr->n + 2] = static_cast<float>((cz + 0.5) * g.grid + g.min_z);
+        if (tr->n < tr->max)
+        {
+          tr->xyz[3 * tr->n + 0] = static_cast<float>((cx + 0.5) * g.grid + g.min_x);
+          tr->xyz[3 * tr->n + 1] = static_cast<float>((cy + 0.5) * g.grid + g.min_y);
+          tr->xyz[3 * tr->n + 2] = static_cast<float>((cz + 0.5) * g.grid + g.min_z);
+        }
+        ++tr->n;
       }
-      ++tr->n;
+      // hasIntersection, :237-258: occupancy bit first
+      const int brick = ((cz >> 2) * g.bny + (cy >> 2)) * g.bnx + (cx >> 2);  // < 2^31 / 64 (total voxels < 2^31)
+      if (brick != cur_brick)
+      {
+        cur_brick = brick;
+        word = g.bricks[brick];
+      }
+      if ((word >> (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1ull)
+      {
+        found = true;
+        break;
+      }
     }
-    // hasIntersection, :237-258
-    const int brick = ((cz >> 2) * g.bny + (cy >> 2)) * g.bnx + (cx >> 2);  // < 2^31 / 64 (total voxels < 2^31)
-    if (brick != cur_brick)
-    {
-      cur_brick = brick;
-      word = g.bricks[brick];
-    }
-    if (!((word >> (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1ull))
-      continue;
+    if (!found)
+      break;  // ray exhausted (or left the grid): LONG
     if (STATS)
       ++st_occ;
     const int v = cx + cy * g.nx + cz * plane;  // getArrayIndex, :225-228 (int arithmetic there too)
