@@ -802,7 +802,16 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
-          if (G == 32)
+          if (G == 8)
+          {
+            if (ctx->lik_index == 2)
+              LAUNCH_TILED(8, 2);
+            else if (ctx->lik_index == 1)
+              LAUNCH_TILED(8, 1);
+            else
+              LAUNCH_TILED(8, 0);
+          }
+          else if (G == 32)
           {
             if (ctx->lik_index == 2)
               LAUNCH_TILED(32, 2);
@@ -1880,8 +1889,8 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   }
   if (key == "lik_group")
   {
-    if (value != 16.0 && value != 32.0)
-      return ctx->fail(-3, "lik_group must be 16 or 32");
+    if (value != 8.0 && value != 16.0 && value != 32.0)
+      return ctx->fail(-3, "lik_group must be 8, 16 or 32");
     ctx->lik_group = static_cast<int>(value);
     return 0;
   }
