@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
+    ap.add_argument("--lik-small", type=int, default=1)
+    ap.add_argument("--scan-points", type=int, default=0, help="override the number of likelihood scan points")
     ap.add_argument("--lik-group", type=int, default=16)
     ap.add_argument("--strict-order", type=int, default=0,
                     help="1 = reference float summation order (bit-identical likelihoods and weights; slower)")
@@ -125,9 +127,10 @@ def main():
     cfg = CONFIGS[args.workload]
     n_p = args.particles or cfg["n_p"]
     # weak scaling: every rank holds a full-size particle shard drawn with its own seed; map and scan are replicated
-    sc = make_config(args.workload, n_p=n_p, seed=12345)
+    extra_cfg = dict(n_s=args.scan_points) if args.scan_points else {}
+    sc = make_config(args.workload, n_p=n_p, seed=12345, **extra_cfg)
     if rank > 0:
-        shard = make_config(args.workload, n_p=n_p, seed=12345 + rank)
+        shard = make_config(args.workload, n_p=n_p, seed=12345 + rank, **extra_cfg)
         sc.poses = shard.poses
     dist_weight = (1.0, 1.0, args.dist_weight_z)
     n_s, n_b = len(sc.scan_lik), len(sc.scan_beam)
@@ -147,6 +150,7 @@ def main():
     eng.set_option("cand_phase", args.cand_phase)
     eng.set_option("strict_order", args.strict_order)
     eng.set_option("lik_tiled", args.lik_tiled)
+    eng.set_option("lik_small", args.lik_small)
     eng.set_option("lik_group", args.lik_group)
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)

@@ -358,6 +358,67 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Small-scan variant (global localisation: hundreds of thousands of particles x 8..32 points each,
+// src/lidar_measurement_model_likelihood.cpp:63-77): a wavefront is shared by 64 / W particles, W = the scan size rounded
+// up to a power of two; lane = (particle, point). Poses differ between the lanes of a wave, so each lane normalises its
+// own quaternion; the W terms of a particle are reduced with width-W shuffles (fp64, fixed order).
+// ---------------------------------------------------------------------------------------------------------
+template <int W, int MODE>
+__global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __restrict__ pose7, int n_p,
+                                                               const float4* __restrict__ scan, int n_s, LikGrid g,
+                                                               CandGrid cg, RecGrid rg, LikParams prm,
+                                                               float* __restrict__ out_lik, float* __restrict__ out_ratio)
+{
+  const long long gt = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long p = gt / W;
+  const int i = static_cast<int>(gt % W);
+  double acc = 0.0;
+  unsigned num = 0;
+  if (p < n_p && i < n_s)
+  {
+    const float* ps = pose7 + 7 * p;
+    const Vec3f pos = { ps[0], ps[1], ps[2] };
+    const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });
+    const float4 v = scan[i];
+    const Vec3f t = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+    float qx = t.x, qy = t.y, qz = t.z;
+    if (prm.has_weight)
+    {
+      qx = t.x * prm.wx;
+      qy = t.y * prm.wy;
+      qz = t.z * prm.wz;
+    }
+    unsigned dummy = 0;
+    const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
+                     MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
+                                 nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
+    if (d2 < prm.r2)
+    {
+      const float s = sqrtf(d2);
+      const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
+      if (!(dist < 0.0f))
+      {
+        acc = static_cast<double>(dist * prm.match_weight);
+        num = 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = W / 2; off > 0; off >>= 1)
+  {
+    acc += __shfl_down(acc, off, W);
+    num += __shfl_down(num, off, W);
+  }
+  if (i == 0 && p < n_p)
+  {
+    if (out_lik)
+      out_lik[p] = static_cast<float>(acc);
+    if (out_ratio)
+      out_ratio[p] = static_cast<float>(num) / static_cast<float>(n_s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Tile-major variant for large scans: one work-group = one 256-point scan tile x G particles.
 //
 //  * the scan point of each lane stays in registers for all G particles; the G (normalised) poses are staged through

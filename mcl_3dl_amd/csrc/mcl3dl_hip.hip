@@ -74,6 +74,7 @@ struct mcl3dl_hip_ctx
   LikGrid lg{};
   // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
   int lik_index = 2;
+  int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_group = 16;      // particles per work-group of the tiled kernel (16 or 32)
   DevBuf lik_partial_sum, lik_partial_cnt;
@@ -788,7 +789,44 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * n_p));
           strict_terms = ctx->strict_terms.as<float>();
         }
-        if (tiled)
+        const bool small = !tiled && ns <= 32 && np >= 256 && ctx->lik_small;
+        if (small)
+        {
+          int W = 1;
+          while (W < ns)
+            W <<= 1;
+          const long long blocks = (static_cast<long long>(np) * W + 255) / 256;
+          if (blocks > 0x7fffffffLL)
+            return ctx->fail(-3, "too many work-groups for the small-scan likelihood kernel");
+#define LAUNCH_SMALL(WW, MODE)                                                                                         \
+  hipLaunchKernelGGL((likelihood_small_kernel<WW, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
+                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio)
+#define LAUNCH_SMALL_W(MODE)       \
+  switch (W)                       \
+  {                                \
+    case 1: LAUNCH_SMALL(1, MODE); break;   \
+    case 2: LAUNCH_SMALL(2, MODE); break;   \
+    case 4: LAUNCH_SMALL(4, MODE); break;   \
+    case 8: LAUNCH_SMALL(8, MODE); break;   \
+    case 16: LAUNCH_SMALL(16, MODE); break; \
+    default: LAUNCH_SMALL(32, MODE); break; \
+  }
+          if (ctx->lik_index == 2)
+          {
+            LAUNCH_SMALL_W(2)
+          }
+          else if (ctx->lik_index == 1)
+          {
+            LAUNCH_SMALL_W(1)
+          }
+          else
+          {
+            LAUNCH_SMALL_W(0)
+          }
+#undef LAUNCH_SMALL_W
+#undef LAUNCH_SMALL
+        }
+        else if (tiled)
         {
           const int G = ctx->lik_group;
           const int n_tiles = (ns + 255) / 256, n_groups = (np + G - 1) / G;
@@ -1880,6 +1918,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   if (key == "strict_order")
   {
     ctx->strict_order = value != 0.0;
+    return 0;
+  }
+  if (key == "lik_small")
+  {
+    ctx->lik_small = value != 0.0;
     return 0;
   }
   if (key == "lik_tiled")

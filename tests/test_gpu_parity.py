@@ -345,3 +345,28 @@ def test_strict_order_is_bit_identical_to_the_reference(engine, oracle_kind, dis
     np.testing.assert_array_equal(got["beam"], want["beam"])
     np.testing.assert_array_equal(got["weights"], want["weights"])
     np.testing.assert_allclose(got["entropy"], want["entropy"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_s", [1, 3, 8, 13, 32])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_small_scan_kernel(engine, oracle_kind, n_s, mode):
+    """Global-localisation shape: many particles, a handful of points each (likelihood.cpp:63-77: num_points_global = 8).
+    The wavefront-sharing kernel gives the same floats as one work-group per particle, and matches the oracle."""
+    sc = make_scene(n=91, n_p=1000, n_s=n_s, seed=17 + n_s, sigma_xyz=(1.5, 1.5, 0.2), sigma_rpy=(0.05, 0.05, 3.0))
+    dw = (1.0, 1.0, 5.0)
+    setup_engine(engine, sc, dw, stamp=70)
+    try:
+        engine.set_option("lik_index", mode)
+        engine.set_option("lik_small", 0)
+        lik0, ratio0, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        engine.set_option("lik_small", 1)
+        lik1, ratio1, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    finally:
+        engine.set_option("lik_index", 2)
+        engine.set_option("lik_small", 1)
+    np.testing.assert_array_equal(ratio1, ratio0)
+    np.testing.assert_allclose(lik1, lik0, rtol=1.2e-7)
+    o = make_oracle(oracle_kind, sc, dw)
+    wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
+    np.testing.assert_allclose(lik1, wl, rtol=RTOL)
+    np.testing.assert_array_equal(ratio1, wq)
