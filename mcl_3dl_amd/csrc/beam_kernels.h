@@ -1,0 +1,276 @@
+// beam_kernels.h — beam model (R6/R7/R8): the DDA ray walk and its kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "map_structs.h"
+#pragma clang fp contract(off)
+
+namespace mcl3dl
+{
+// ---------------------------------------------------------------------------------------------------------
+// Beam model: RaycastUsingDDA (include/mcl_3dl/raycasts/raycast_using_dda.h) +
+//             LidarMeasurementModelBeam::getBeamStatus / measure (src/lidar_measurement_model_beam.cpp:124-192)
+// ---------------------------------------------------------------------------------------------------------
+struct RayStats
+{
+  unsigned long long steps, occupied, tested;
+};
+
+// Casts one ray; returns BeamStatus (0 SHORT, 1 HIT, 2 LONG, 3 TOTAL_REFLECTION). *hit = original map index of the
+// collided point (-1 if the ray was exhausted).
+//
+// TRACE = true is the introspection variant behind mcl3dl_hip_dda_trace: the very same walk, but every visited voxel
+// centre (fromIndex, raycast_using_dda.h:219-223) is recorded and the walk stops at the first collision regardless of
+// label, exactly like the reference's waypoint test harness (test/src/test_raycast_dda.cpp:157-183).
+struct RayTrace
+{
+  float* xyz;     // [max * 3]
+  int max;
+  int n;          // voxels visited (may exceed max; only the first max are stored)
+  int collided;   // 1 if the walk ended on a collision
+};
+
+template <bool STATS, bool TRACE = false>
+__device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
+                               unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
+{
+  *hit = -1;
+  // isPointWithinMap, raycast_using_dda.h:260-270  -> max_movement_ = 0 -> getNextCastResult false -> LONG
+  if ((b.x < g.min_x) || (g.max_x < b.x) || (b.y < g.min_y) || (g.max_y < b.y) || (b.z < g.min_z) || (g.max_z < b.z))
+    return 2;
+  // setRay, :76-103
+  const Vec3f diff = vsub(e_org, b);
+  const float nrm = sqrtf(vdot(diff, diff));
+  const Vec3f dir = { diff.x / nrm, diff.y / nrm, diff.z / nrm };
+  const Vec3f e = vadd(e_org, vscale(dir, g.hit_tolerance_f));
+  // toIndex, :205-210: float difference, double division, truncation toward zero
+  const int bx = static_cast<int>(static_cast<double>(b.x - g.min_x) / g.grid);
+  const int by = static_cast<int>(static_cast<double>(b.y - g.min_y) / g.grid);
+  const int bz = static_cast<int>(static_cast<double>(b.z - g.min_z) / g.grid);
+  const int ex = static_cast<int>(static_cast<double>(e.x - g.min_x) / g.grid);
+  const int ey = static_cast<int>(static_cast<double>(e.y - g.min_y) / g.grid);
+  const int ez = static_cast<int>(static_cast<double>(e.z - g.min_z) / g.grid);
+  const int dix = ex - bx, diy = ey - by, diz = ez - bz;
+  const int max_movement = abs(dix) + abs(diy) + abs(diz);
+  const int sx = dix < 0 ? -1 : 1, sy = diy < 0 ? -1 : 1, sz = diz < 0 ? -1 : 1;
+  const float inf = __builtin_inff();
+  float iex = inf, iey = inf, iez = inf, tdx = inf, tdy = inf, tdz = inf;
+  if (dix != 0)
+  {
+    const double nearest = (dir.x < 0) ? bx * g.grid + g.min_x : (bx + 1) * g.grid + g.min_x;
+    iex = static_cast<float>(fabs((nearest - b.x) / dir.x));
+    tdx = static_cast<float>(fabs(g.grid / dir.x));
+  }
+  if (diy != 0)
+  {
+    const double nearest = (dir.y < 0) ? by * g.grid + g.min_y : (by + 1) * g.grid + g.min_y;
+    iey = static_cast<float>(fabs((nearest - b.y) / dir.y));
+    tdy = static_cast<float>(fabs(g.grid / dir.y));
+  }
+  if (diz != 0)
+  {
+    const double nearest = (dir.z < 0) ? bz * g.grid + g.min_z : (bz + 1) * g.grid + g.min_z;
+    iez = static_cast<float>(fabs((nearest - b.z) / dir.z));
+    tdz = static_cast<float>(fabs(g.grid / dir.z));
+  }
+  float tmx = iex, tmy = iey, tmz = iez;
+  int cx = bx, cy = by, cz = bz;
+  int pos = 0;
+  const int plane = g.nx * g.ny;
+  // The occupancy word of the brick the ray is currently in stays in registers: stepping inside a brick is pure ALU,
+  // a (dependent, high-latency) load happens only when the ray enters a new 4x4x4 brick.
+  int cur_brick = -1;
+  unsigned long long word = 0ull;
+  // Two nested loops instead of one ("while-while" traversal): the inner loop only WALKS — to the next occupied voxel
+  // or to the end of the ray — and the point tests of that voxel run after it. On a wavefront the inner loop ends when
+  // every ray has found its voxel (or run out), so the long, double-precision test body executes once per round for all
+  // 64 rays together instead of once per step for whichever ray happens to sit on an occupied voxel (a ray visits
+  // ~1.0 occupied voxel on its way: measured). The per-ray sequence of operations is unchanged.
+  for (;;)
+  {
+    bool found = false;
+    for (;;)
+    {
+      // getNextCastResult, :106-159
+      ++pos;
+      if (pos >= max_movement)
+        break;
+      // axis choice of :114-147 (strict <, ties fall to the later axis), written branch-free so the 64 rays of a
+      // wavefront do not serialise on three divergent bodies; only the chosen axis changes (incrementIndex, :192-203).
+      const bool x_first = tmx < tmy;
+      const bool ax = x_first && (tmx < tmz);
+      const bool ay = !x_first && (tmy < tmz);
+      const bool az = !(ax || ay);
+      cx += ax ? sx : 0;
+      cy += ay ? sy : 0;
+      cz += az ? sz : 0;
+      const float nx_t = iex + tdx * static_cast<float>(abs(cx - bx));
+      const float ny_t = iey + tdy * static_cast<float>(abs(cy - by));
+      const float nz_t = iez + tdz * static_cast<float>(abs(cz - bz));
+      tmx = ax ? nx_t : tmx;
+      tmy = ay ? ny_t : tmy;
+      tmz = az ? nz_t : tmz;
+      // only the moved index can have left the grid (the others were checked when they moved; begin is inside the map)
+      const bool inside = static_cast<unsigned>(cx) < static_cast<unsigned>(g.nx) &&
+                          static_cast<unsigned>(cy) < static_cast<unsigned>(g.ny) &&
+                          static_cast<unsigned>(cz) < static_cast<unsigned>(g.nz);
+      if (!inside)
+        break;
+      if (STATS)
+        ++st_steps;
+      if (TRACE)
+      {
+        if (tr->n < tr->max)
+        {
+          tr->xyz[3 * tr->n + 0] = static_cast<float>((cx + 0.5) * g.grid + g.min_x);
+          tr->xyz[3 * tr->n + 1] = static_cast<float>((cy + 0.5) * g.grid + g.min_y);
+          tr->xyz[3 * tr->n + 2] = static_cast<float>((cz + 0.5) * g.grid + g.min_z);
+        }
+        ++tr->n;
+      }
+      // hasIntersection, :237-258: occupancy bit first
+      const int brick = ((cz >> 2) * g.bny + (cy >> 2)) * g.bnx + (cx >> 2);  // < 2^31 / 64 (total voxels < 2^31)
+      if (brick != cur_brick)
+      {
+        cur_brick = brick;
+        word = g.bricks[brick];
+      }
+      if ((word >> (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1ull)
+      {
+        found = true;
+        break;
+      }
+    }
+    if (!found)
+      break;  // ray exhausted (or left the grid): LONG
+    if (STATS)
+      ++st_occ;
+    const int v = cx + cy * g.nx + cz * plane;  // getArrayIndex, :225-228 (int arithmetic there too)
+    const uint32_t k0 = g.vox_start[v], k1 = g.vox_start[v + 1];
+    int collided = -1;
+    float4 cp = { 0, 0, 0, 0 };
+    for (uint32_t k = k0; k < k1; ++k)
+    {
+      const float4 t = g.pts[k];
+      if (STATS)
+        ++st_tested;
+      const Vec3f rel = { t.x - b.x, t.y - b.y, t.z - b.z };
+      const double foot = static_cast<double>(fabsf(vdot(rel, dir)));
+      const double a = g.ray_angle_half * foot;
+      const double a2 = a * a;
+      const double thr = a2 < g.min_dist_thr_sq ? g.min_dist_thr_sq : a2;
+      const double dist_sq = static_cast<double>(vdot(rel, rel)) - foot * foot;
+      if (dist_sq < thr)
+      {
+        collided = static_cast<int>(k);
+        cp = t;
+        break;
+      }
+    }
+    if (collided < 0)
+      continue;
+    if (TRACE)
+    {
+      tr->collided = 1;
+      *hit = static_cast<int>(g.pt_index[collided]);
+      return 0;
+    }
+    // getBeamStatus, beam.cpp:164-187
+    if (__float_as_uint(cp.w) > bp.filter_label_max)
+      continue;
+    *hit = static_cast<int>(g.pt_index[collided]);
+    if (1.0f > bp.sin_total_ref)  // DDA always reports sin_angle_ = 1.0 (raycast_using_dda.h:152)
+    {
+      const double ddx = static_cast<double>(e_org.x - cp.x), ddy = static_cast<double>(e_org.y - cp.y),
+                   ddz = static_cast<double>(e_org.z - cp.z);
+      const float distance_from_point_sq = static_cast<float>(ddx * ddx + ddy * ddy + ddz * ddz);
+      return distance_from_point_sq < bp.hit_range_sq ? 1 : 0;
+    }
+    return 3;
+  }
+  return 2;
+}
+
+// One lane per (particle, beam point).  scan_beam.w = origin index (PointXYZIL::label of the scan point).
+template <bool STATS>
+__global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
+                                                   int n_b, const float4* __restrict__ origins, long long n_rays,
+                                                   DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
+                                                   RayStats* __restrict__ stats)
+{
+  const long long ray = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  unsigned st_steps = 0, st_occ = 0, st_tested = 0;
+  if (ray < n_rays)
+  {
+    const long long p = ray / n_b;
+    const int i = static_cast<int>(ray - p * n_b);
+    const float* ps = pose7 + 7 * p;
+    const Vec3f pos = { ps[0], ps[1], ps[2] };
+    const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
+    const Quat rot = qnormalized(raw);
+    const float4 v = scan[i];
+    const Vec3f end = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);  // beam.cpp:139 (transform)
+    const float4 og = origins[__float_as_uint(v.w)];
+    const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
+    int hit;
+    const int status = cast_ray<STATS>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
+    if ((status == 0) || (!bp.short_only && (status == 2)))  // beam.cpp:146
+      atomicAdd(&penalty_count[p], 1u);
+  }
+  if (STATS)
+  {
+    atomicAdd(&stats->steps, static_cast<unsigned long long>(st_steps));
+    atomicAdd(&stats->occupied, static_cast<unsigned long long>(st_occ));
+    atomicAdd(&stats->tested, static_cast<unsigned long long>(st_tested));
+  }
+}
+
+// score_beam = beam_likelihood_^k by k float multiplications (table built on the host the same way), then the
+// clamp of beam.cpp:151-152.
+__global__ void beam_finalize_kernel(const unsigned* __restrict__ penalty_count, const float* __restrict__ pow_table,
+                                     float beam_likelihood_min, float* __restrict__ out_beam, int n_p)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_p)
+  {
+    float s = pow_table[penalty_count[p]];
+    if (s < beam_likelihood_min)
+      s = beam_likelihood_min;
+    out_beam[p] = s;
+  }
+}
+
+// LidarMeasurementModelBeam::getBeamStatus for explicit rays (debug-marker path, src/mcl_3dl.cpp:471-478).
+__global__ void beam_status_kernel(const float* __restrict__ begin_xyz, const float* __restrict__ end_xyz, int n,
+                                   DdaGrid g, BeamParams bp, int* __restrict__ status, int* __restrict__ hit_index)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  unsigned a = 0, b = 0, c = 0;
+  int hit;
+  const int s = cast_ray<false>(g, bp, Vec3f{ begin_xyz[3 * i], begin_xyz[3 * i + 1], begin_xyz[3 * i + 2] },
+                                Vec3f{ end_xyz[3 * i], end_xyz[3 * i + 1], end_xyz[3 * i + 2] }, &hit, a, b, c);
+  status[i] = s;
+  if (hit_index)
+    hit_index[i] = (s == 2) ? -1 : hit;
+}
+
+// One ray, one lane: the waypoint introspection used by the known-answer tests.
+__global__ void dda_trace_kernel(Vec3f begin, Vec3f end, DdaGrid g, BeamParams bp, float* __restrict__ out_xyz,
+                                 int max_out, int* __restrict__ out3 /* n, collided, hit index */)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  RayTrace tr = { out_xyz, max_out, 0, 0 };
+  unsigned a = 0, b = 0, c = 0;
+  int hit;
+  cast_ray<false, true>(g, bp, begin, end, &hit, a, b, c, &tr);
+  out3[0] = tr.n;
+  out3[1] = tr.collided;
+  out3[2] = tr.collided ? hit : -1;
+}
+
+}  // namespace mcl3dl

@@ -1,0 +1,562 @@
+// likelihood_kernels.h — likelihood-field model (R3/R4/R5): nearest-neighbour queries against the three map indices, the
+// per-particle / small-scan / tile-major kernels, the strict-order sums and the stand-alone radius search.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "map_structs.h"
+#pragma clang fp contract(off)
+
+namespace mcl3dl
+{
+// ---------------------------------------------------------------------------------------------------------
+// Likelihood-field model: LidarMeasurementModelLikelihood::measure, src/lidar_measurement_model_likelihood.cpp:105-139
+// ---------------------------------------------------------------------------------------------------------
+// Nearest rescaled map point to q among the 27 cells around it; returns min d2 (FLT_MAX if none).
+template <bool STATS>
+__device__ inline float nearest_d2(const LikGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  // cell of the query; (q - o) * inv is the same float expression the host used to bin the map points
+  const float fx = floorf((qx - g.ox) * g.inv_cell);
+  const float fy = floorf((qy - g.oy) * g.inv_cell);
+  const float fz = floorf((qz - g.oz) * g.inv_cell);
+  float best = 3.0e38f;
+  // written so that NaN coordinates fall through to "not found"
+  if (!(fx >= 1.0f && fy >= 1.0f && fz >= 1.0f && fx <= static_cast<float>(g.nx - 2) &&
+        fy <= static_cast<float>(g.ny - 2) && fz <= static_cast<float>(g.nz - 2)))
+    return best;
+  const int cx = static_cast<int>(fx), cy = static_cast<int>(fy), cz = static_cast<int>(fz);
+  uint32_t rs[9], re[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r)
+  {
+    const int dz = r / 3 - 1, dy = r % 3 - 1;
+    const size_t row = (static_cast<size_t>(cz + dz) * g.ny + (cy + dy)) * g.nx + cx;
+    rs[r] = g.cell_start[row - 1];
+    re[r] = g.cell_start[row + 2];
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r)
+  {
+    for (uint32_t k = rs[r]; k < re[r]; ++k)
+    {
+      const float4 p = g.pts[k];
+      // flann::L2_Simple<float>: ((0 + dx*dx) + dy*dy) + dz*dz
+      const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+      float d2 = dx * dx;
+      d2 = d2 + dy * dy;
+      d2 = d2 + dz * dz;
+      best = d2 < best ? d2 : best;
+      if (STATS)
+        ++n_tested;
+    }
+  }
+  return best;
+}
+
+// Same query against the candidate-voxel index (map_compiler.h): the voxel of q holds every map point that can be the
+// nearest neighbour within r of a query inside it, so min d2 over that run == min d2 over the whole map.
+template <bool STATS>
+__device__ inline float nearest_d2_cand(const CandGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  const float fx = floorf((qx - g.ox) * g.inv_e);
+  const float fy = floorf((qy - g.oy) * g.inv_e);
+  const float fz = floorf((qz - g.oz) * g.inv_e);
+  float best = 3.0e38f;
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
+        fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
+    return best;
+  const int vx = static_cast<int>(fx), vy = static_cast<int>(fy), vz = static_cast<int>(fz);
+  const int b = g.brick_table[(static_cast<size_t>(vz >> 3) * g.nby + (vy >> 3)) * g.nbx + (vx >> 3)];
+  if (b < 0)
+    return best;
+  const size_t v = static_cast<size_t>(b) * 512 + (((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  const uint32_t s = g.vox_start[v], e = g.vox_start[v + 1];
+  for (uint32_t k = s; k < e; ++k)
+  {
+    const float4 p = g.cand[k];
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    best = d2 < best ? d2 : best;
+    if (STATS)
+      ++n_tested;
+  }
+  return best;
+}
+
+// flann::L2_Simple<float>: ((0 + dx*dx) + dy*dy) + dz*dz, float, no contraction
+__device__ inline float d2_simple(float qx, float qy, float qz, float px, float py, float pz)
+{
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  float d2 = dx * dx;
+  d2 = d2 + dy * dy;
+  d2 = d2 + dz * dz;
+  return d2;
+}
+
+// ChunkedKdtree::radiusSearch(p, radius, id, sqdist, 1) as a stand-alone query (include/mcl_3dl/chunked_kdtree.h:217-237):
+// nearest map point with d2 < (float)(radius*radius) in the rescaled metric, ANY radius (the node also searches with
+// unmatch_output_dist, src/mcl_3dl.cpp:780, and global_localization_grid, :1058-1070). Walks the cell-sorted map over
+// ceil(radius / cell) cells each way: one contiguous run per (y,z) row. Ties in d2 resolve to the lowest map index.
+__global__ void radius_search_kernel(const float* __restrict__ query_xyz, int n, LikGrid g, LikParams prm, float radius,
+                                     float r2, int reach, int* __restrict__ out_index, float* __restrict__ out_sqdist)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  float qx = query_xyz[3 * i], qy = query_xyz[3 * i + 1], qz = query_xyz[3 * i + 2];
+  if (prm.has_weight)
+  {
+    qx = qx * prm.wx;
+    qy = qy * prm.wy;
+    qz = qz * prm.wz;
+  }
+  (void)radius;
+  float best = r2;
+  int best_idx = -1;
+  const float fx = floorf((qx - g.ox) * g.inv_cell), fy = floorf((qy - g.oy) * g.inv_cell),
+              fz = floorf((qz - g.oz) * g.inv_cell);
+  // NaN / far-away queries: comparisons fail -> no neighbour
+  if (fx >= -static_cast<float>(reach) && fy >= -static_cast<float>(reach) && fz >= -static_cast<float>(reach) &&
+      fx <= static_cast<float>(g.nx - 1 + reach) && fy <= static_cast<float>(g.ny - 1 + reach) &&
+      fz <= static_cast<float>(g.nz - 1 + reach))
+  {
+    const int cx = static_cast<int>(fx), cy = static_cast<int>(fy), cz = static_cast<int>(fz);
+    const int x0 = max(cx - reach, 0), x1 = min(cx + reach, g.nx - 1);
+    const int y0 = max(cy - reach, 0), y1 = min(cy + reach, g.ny - 1);
+    const int z0 = max(cz - reach, 0), z1 = min(cz + reach, g.nz - 1);
+    if (x0 <= x1)
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y)
+        {
+          const size_t row = (static_cast<size_t>(z) * g.ny + y) * g.nx;
+          const uint32_t s = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+          for (uint32_t k = s; k < e; ++k)
+          {
+            const float4 p = g.pts[k];
+            const float d2 = d2_simple(qx, qy, qz, p.x, p.y, p.z);
+            const int idx = static_cast<int>(__float_as_uint(p.w));
+            if (d2 < best || (d2 == best && best_idx >= 0 && idx < best_idx))
+            {
+              best = d2;
+              best_idx = idx;
+            }
+          }
+        }
+  }
+  out_index[i] = best_idx;
+  if (out_sqdist)
+    out_sqdist[i] = best_idx >= 0 ? best : -1.0f;
+}
+
+// MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates (overflow runs for
+// voxels with more than 5).
+
+template <bool STATS>
+__device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  const float fx = floorf((qx - g.ox) * g.inv_e);
+  const float fy = floorf((qy - g.oy) * g.inv_e);
+  const float fz = floorf((qz - g.oz) * g.inv_e);
+  float best = 3.0e38f;
+  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
+        fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
+    return best;
+  const int vx = static_cast<int>(fx), vy = static_cast<int>(fy), vz = static_cast<int>(fz);
+  const int b = g.brick_table[(static_cast<size_t>(vz >> 3) * g.nby + (vy >> 3)) * g.nbx + (vx >> 3)];
+  if (b < 0)
+    return best;
+  const size_t v = static_cast<size_t>(b) * 512 + (((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  const float4* r = g.rec + 4 * v;
+  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  const uint32_t count = __float_as_uint(r0.x);
+  if (count == 0)
+    return best;
+  if (STATS)
+    n_tested += count;
+  if (count <= 5)
+  {
+    float d;
+    d = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
+    best = d;
+    d = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
+    best = (count > 1 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
+    best = (count > 2 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
+    best = (count > 3 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
+    best = (count > 4 && d < best) ? d : best;
+    return best;
+  }
+  float d;
+  d = d2_simple(qx, qy, qz, r0.z, r0.w, r1.x);
+  best = d;
+  d = d2_simple(qx, qy, qz, r1.y, r1.z, r1.w);
+  best = d < best ? d : best;
+  d = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
+  best = d < best ? d : best;
+  d = d2_simple(qx, qy, qz, r2.w, r3.x, r3.y);
+  best = d < best ? d : best;
+  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(__float_as_uint(r0.y));
+  for (uint32_t j = 0; j < count - 4; ++j)
+  {
+    const float* s = o + 16 * (j / 5) + 3 * (j % 5);
+    d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
+    best = d < best ? d : best;
+  }
+  return best;
+}
+
+// MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
+// MODE 1: candidate-voxel index
+template <int BLOCK, int MODE, bool STATS>
+__global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
+                                                           const float4* __restrict__ scan, int n_s, LikGrid g,
+                                                           CandGrid cg, RecGrid rg, LikParams prm,
+                                                           float* __restrict__ out_lik,
+                                                           float* __restrict__ out_ratio,
+                                                           double* __restrict__ out_tested)
+{
+  const int p = blockIdx.x;
+  const float* ps = pose7 + 7 * static_cast<size_t>(p);
+  const Vec3f pos = { ps[0], ps[1], ps[2] };
+  const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
+
+  double acc = 0.0;   // sum of float terms, each exactly representable: fp64 sum is exact to ~1e-16
+  unsigned num = 0;   // matched points
+  unsigned tested = 0;
+  for (int i = threadIdx.x; i < n_s; i += BLOCK)
+  {
+    const float4 v = scan[i];
+    // State6DOF::transform, state_6dof.h:219-223
+    const Vec3f t = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+    // PointRepresentation::vectorize: rescale by dist_weight (one rounding per coordinate)
+    float qx = t.x, qy = t.y, qz = t.z;
+    if (prm.has_weight)
+    {
+      qx = t.x * prm.wx;
+      qy = t.y * prm.wy;
+      qz = t.z * prm.wz;
+    }
+    const float d2 = MODE == 0 ? nearest_d2<STATS>(g, qx, qy, qz, tested) :
+                     MODE == 1 ? nearest_d2_cand<STATS>(cg, qx, qy, qz, tested) :
+                                 nearest_d2_rec<STATS>(rg, qx, qy, qz, tested);
+    if (d2 < prm.r2)  // radiusSearch found a neighbour (strict <)
+    {
+      const float s = sqrtf(d2);
+      const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);  // :128
+      if (!(dist < 0.0f))                                                                           // :129
+      {
+        acc += static_cast<double>(dist * prm.match_weight);  // :132 (float product, then accumulated)
+        ++num;
+      }
+    }
+  }
+  // wavefront __shfl reduction, then across the work-group's waves through LDS
+  __shared__ double s_acc[BLOCK / 64];
+  __shared__ unsigned s_num[BLOCK / 64];
+  __shared__ unsigned s_tested[BLOCK / 64];
+  acc = wave_sum(acc);
+  num = wave_sum(num);
+  if (STATS)
+    tested = wave_sum(tested);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    s_acc[wave] = acc;
+    s_num[wave] = num;
+    if (STATS)
+      s_tested[wave] = tested;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double a = 0.0;
+    unsigned n = 0, tt = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w)
+    {
+      a += s_acc[w];
+      n += s_num[w];
+      if (STATS)
+        tt += s_tested[w];
+    }
+    if (out_lik)
+      out_lik[p] = static_cast<float>(a);
+    if (out_ratio)
+      out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);  // :136
+    if (STATS && out_tested)
+      out_tested[p] = static_cast<double>(tt);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Small-scan variant (global localisation: hundreds of thousands of particles x 8..32 points each,
+// src/lidar_measurement_model_likelihood.cpp:63-77): a wavefront is shared by 64 / W particles, W = the scan size rounded
+// up to a power of two; lane = (particle, point). Poses differ between the lanes of a wave, so each lane normalises its
+// own quaternion; the W terms of a particle are reduced with width-W shuffles (fp64, fixed order).
+// ---------------------------------------------------------------------------------------------------------
+template <int W, int MODE>
+__global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __restrict__ pose7, int n_p,
+                                                               const float4* __restrict__ scan, int n_s, LikGrid g,
+                                                               CandGrid cg, RecGrid rg, LikParams prm,
+                                                               float* __restrict__ out_lik, float* __restrict__ out_ratio)
+{
+  const long long gt = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long p = gt / W;
+  const int i = static_cast<int>(gt % W);
+  double acc = 0.0;
+  unsigned num = 0;
+  if (p < n_p && i < n_s)
+  {
+    const float* ps = pose7 + 7 * p;
+    const Vec3f pos = { ps[0], ps[1], ps[2] };
+    const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });
+    const float4 v = scan[i];
+    const Vec3f t = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+    float qx = t.x, qy = t.y, qz = t.z;
+    if (prm.has_weight)
+    {
+      qx = t.x * prm.wx;
+      qy = t.y * prm.wy;
+      qz = t.z * prm.wz;
+    }
+    unsigned dummy = 0;
+    const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
+                     MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
+                                 nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
+    if (d2 < prm.r2)
+    {
+      const float s = sqrtf(d2);
+      const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
+      if (!(dist < 0.0f))
+      {
+        acc = static_cast<double>(dist * prm.match_weight);
+        num = 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = W / 2; off > 0; off >>= 1)
+  {
+    acc += __shfl_down(acc, off, W);
+    num += __shfl_down(num, off, W);
+  }
+  if (i == 0 && p < n_p)
+  {
+    if (out_lik)
+      out_lik[p] = static_cast<float>(acc);
+    if (out_ratio)
+      out_ratio[p] = static_cast<float>(num) / static_cast<float>(n_s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tile-major variant for large scans: one work-group = one 256-point scan tile x G particles.
+//
+//  * the scan point of each lane stays in registers for all G particles; the G (normalised) poses are staged through
+//    LDS once per work-group and read back as broadcasts;
+//  * blockIdx -> (tile, particle group) is XCD-aware: work-groups are dispatched round-robin over the 8 XCDs
+//    (block b runs on XCD b % 8), so XCD x is given the tiles t == x (mod 8) and walks them one after the other over all
+//    particle groups. A tile is a spatially compact patch (Morton order), so the voxel records it touches under every
+//    particle pose (~1 MB) stay resident in that XCD's 4 MB L2 instead of every work-group sweeping the whole scan;
+//  * per-(particle, lane) float terms go to LDS and are summed in fp64 in a fixed order (deterministic), one partial per
+//    (tile, particle); lik_finalize_kernel adds the tiles in order.
+// Same per-point arithmetic as likelihood_kernel — identical terms — only the (fp64) summation order differs.
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
+                                                               const float4* __restrict__ scan, int n_s, int n_tiles,
+                                                               int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
+                                                               LikParams prm, double* __restrict__ partial_sum,
+                                                               unsigned* __restrict__ partial_cnt,
+                                                               const uint32_t* __restrict__ scan_perm,
+                                                               float* __restrict__ strict_terms)
+{
+  // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
+  // [original scan index][particle] so that lik_strict_sum_kernel can add them in the reference's own order.
+  __shared__ float s_pose[G][8];        // px,py,pz, qx,qy,qz,qw (normalised), valid
+  __shared__ float s_term[G][256];
+  __shared__ unsigned s_cnt[G][4];
+  const int xcd = blockIdx.x & 7;
+  const int seq = blockIdx.x >> 3;
+  const int tile = (seq / n_groups) * 8 + xcd;
+  const int group = seq % n_groups;
+  if (tile >= n_tiles)
+    return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < G)
+  {
+    const int p = group * G + t;
+    float v = 0.f;
+    if (p < n_p)
+    {
+      const float* ps = pose7 + 7 * static_cast<size_t>(p);
+      const Quat r = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });
+      s_pose[t][0] = ps[0];
+      s_pose[t][1] = ps[1];
+      s_pose[t][2] = ps[2];
+      s_pose[t][3] = r.x;
+      s_pose[t][4] = r.y;
+      s_pose[t][5] = r.z;
+      s_pose[t][6] = r.w;
+      v = 1.f;
+    }
+    s_pose[t][7] = v;
+  }
+  const int i = tile * 256 + t;
+  const bool have_point = i < n_s;
+  const float4 v = have_point ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int n_valid = min(G, n_p - group * G);
+  for (int k = 0; k < n_valid; ++k)
+  {
+    const Vec3f pos = { s_pose[k][0], s_pose[k][1], s_pose[k][2] };
+    const Quat rot = { s_pose[k][3], s_pose[k][4], s_pose[k][5], s_pose[k][6] };
+    float term = 0.f;
+    bool matched = false;
+    if (have_point)
+    {
+      const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+      float qx = tp.x, qy = tp.y, qz = tp.z;
+      if (prm.has_weight)
+      {
+        qx = tp.x * prm.wx;
+        qy = tp.y * prm.wy;
+        qz = tp.z * prm.wz;
+      }
+      unsigned dummy = 0;
+      const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
+                       MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
+                                   nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
+      if (d2 < prm.r2)
+      {
+        const float s = sqrtf(d2);
+        const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
+        if (!(dist < 0.0f))
+        {
+          term = dist * prm.match_weight;
+          matched = true;
+        }
+      }
+    }
+    s_term[k][t] = term;
+    if (strict_terms && have_point)
+      strict_terms[static_cast<size_t>(scan_perm[i]) * n_p + (group * G + k)] = term;
+    const unsigned long long m = __ballot(matched);
+    if (lane == 0)
+      s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
+  }
+  __syncthreads();
+  // fixed-order fp64 reduction: 256 / G lanes per particle, each sums a contiguous segment (bank-rotated reads)
+  constexpr int LPP = 256 / G;        // lanes per particle
+  constexpr int SEG = 256 / LPP;      // = G terms per lane
+  const int pk = t / LPP, seg = t % LPP;
+  double acc = 0.0;
+  if (pk < n_valid)
+  {
+#pragma unroll 8
+    for (int j = 0; j < SEG; ++j)
+    {
+      const int jj = (j + t) % SEG;
+      acc += static_cast<double>(s_term[pk][seg * SEG + jj]);
+    }
+  }
+#pragma unroll
+  for (int off = LPP / 2; off > 0; off >>= 1)
+    acc += __shfl_down(acc, off, LPP);
+  if (seg == 0 && pk < n_valid)
+  {
+    const size_t o = static_cast<size_t>(tile) * n_p + (group * G + pk);
+    partial_sum[o] = acc;
+    partial_cnt[o] = s_cnt[pk][0] + s_cnt[pk][1] + s_cnt[pk][2] + s_cnt[pk][3];
+  }
+}
+
+__global__ void lik_finalize_kernel(const double* __restrict__ partial_sum, const unsigned* __restrict__ partial_cnt,
+                                    int n_tiles, int n_p, int n_s, float* __restrict__ out_lik,
+                                    float* __restrict__ out_ratio)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_p)
+    return;
+  double a = 0.0;
+  unsigned n = 0;
+  for (int tl = 0; tl < n_tiles; ++tl)
+  {
+    a += partial_sum[static_cast<size_t>(tl) * n_p + p];
+    n += partial_cnt[static_cast<size_t>(tl) * n_p + p];
+  }
+  if (out_lik)
+    out_lik[p] = static_cast<float>(a);
+  if (out_ratio)
+    out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
+}
+
+// "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): one lane per
+// particle walks the scan in ORIGINAL order, float adds, sequentially. Unmatched points hold 0 (x + 0.0f == x), so
+// the result is the reference's float, bit for bit. Loads run DEPTH ahead of the dependent add chain.
+__global__ __launch_bounds__(64) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
+                                                            float* __restrict__ out_lik)
+{
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_p)
+    return;
+  constexpr int DEPTH = 32;
+  float score = 0.0f;
+  int i = 0;
+  for (; i + DEPTH <= n_s; i += DEPTH)
+  {
+    float v[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      v[j] = terms[static_cast<size_t>(i + j) * n_p + p];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      score += v[j];
+  }
+  for (; i < n_s; ++i)
+    score += terms[static_cast<size_t>(i) * n_p + p];
+  out_lik[p] = score;
+}
+
+// "strict_order": pf::measure's `sum += p.probability_` (pf.h:255-260) as a float, sequentially, by one lane; the result
+// replaces the fp64 tree sum in packed[0] so that pf_apply_kernel divides by exactly the reference's float.
+__global__ void pf_strict_sum_kernel(const float* __restrict__ w_new, int n, double* __restrict__ packed)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  float sum = 0.0f;
+  int i = 0;
+  for (; i + 16 <= n; i += 16)
+  {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      v[j] = w_new[i + j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      sum += v[j];
+  }
+  for (; i < n; ++i)
+    sum += w_new[i];
+  packed[0] = static_cast<double>(sum);
+}
+
+// n_s == 0: (likelihood 1, quality 0), src/lidar_measurement_model_likelihood.cpp:111-114
+__global__ void fill_kernel(float* a, float va, float* b, float vb, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+  {
+    if (a)
+      a[i] = va;
+    if (b)
+      b[i] = vb;
+  }
+}
+
+}  // namespace mcl3dl

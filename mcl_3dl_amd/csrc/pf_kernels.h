@@ -1,0 +1,403 @@
+// pf_kernels.h — pf::ParticleFilter::measure (R1/R2) and the "next" rows: expectation / max / covariance, resampling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+#pragma clang fp contract(off)
+
+namespace mcl3dl
+{
+// ---------------------------------------------------------------------------------------------------------
+// pf::ParticleFilter::measure, include/mcl_3dl/pf.h:252-279  (+ the lambda's product, src/mcl_3dl.cpp:407-424)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PF_BLOCK = 256;
+
+// w_new = w * (((1 * beam) * lik) * extra); per-block partials {sum w, sum w ln w, max ratio, -min ratio}.
+__global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __restrict__ w, const float* __restrict__ lik,
+                                                              const float* __restrict__ beam,
+                                                              const float* __restrict__ extra,
+                                                              const float* __restrict__ ratio, int n,
+                                                              float* __restrict__ w_new,
+                                                              double* __restrict__ block_partials)
+{
+  double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;  // match_ratio_max = 0, match_ratio_min = 1 (mcl_3dl.cpp:398-399)
+  for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+  {
+    float l = 1.0f;
+    if (beam)
+      l *= beam[i];
+    l *= lik[i];
+    if (extra)
+      l = l * extra[i];
+    const float wn = w[i] * l;  // pf.h:258
+    w_new[i] = wn;
+    s += static_cast<double>(wn);
+    if (wn > 0.0f)
+      t += static_cast<double>(wn) * log(static_cast<double>(wn));
+    if (ratio)
+    {
+      const double r = static_cast<double>(ratio[i]);
+      rmax = r > rmax ? r : rmax;
+      rneg = -r > rneg ? -r : rneg;
+    }
+  }
+  __shared__ double sh[4][PF_BLOCK / 64];
+  s = wave_sum(s);
+  t = wave_sum(t);
+  rmax = wave_max(rmax);
+  rneg = wave_max(rneg);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    sh[0][wave] = s;
+    sh[1][wave] = t;
+    sh[2][wave] = rmax;
+    sh[3][wave] = rneg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double a = 0, b = 0, c = sh[2][0], d = sh[3][0];
+    for (int k = 0; k < PF_BLOCK / 64; ++k)
+    {
+      a += sh[0][k];
+      b += sh[1][k];
+      c = sh[2][k] > c ? sh[2][k] : c;
+      d = sh[3][k] > d ? sh[3][k] : d;
+    }
+    block_partials[4 * blockIdx.x + 0] = a;
+    block_partials[4 * blockIdx.x + 1] = b;
+    block_partials[4 * blockIdx.x + 2] = c;
+    block_partials[4 * blockIdx.x + 3] = d;
+  }
+}
+
+// Fixed-order reduction of the block partials (deterministic run to run). The result is written in the layout the
+// update's single all-reduce(SUM) needs (mcl_3dl_amd/distributed.py): [0] sum w, [1] sum w ln w, then per rank r the pair
+// [2+2r] max ratio, [3+2r] -min ratio — this rank fills its own pair and zeroes the others, so that after the SUM every
+// rank holds every rank's pair. world == 1 degenerates to the plain 4 doubles.
+__global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict__ block_partials, int n_blocks, int rank,
+                                                       int world, double* __restrict__ packed)
+{
+  double a = 0, b = 0, c = 0.0, d = -1.0;
+  for (int k = threadIdx.x; k < n_blocks; k += 64)
+  {
+    a += block_partials[4 * k + 0];
+    b += block_partials[4 * k + 1];
+    c = block_partials[4 * k + 2] > c ? block_partials[4 * k + 2] : c;
+    d = block_partials[4 * k + 3] > d ? block_partials[4 * k + 3] : d;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_max(c);
+  d = wave_max(d);
+  if (threadIdx.x == 0)
+  {
+    packed[0] = a;
+    packed[1] = b;
+    for (int r = 0; r < world; ++r)
+    {
+      packed[2 + 2 * r] = (r == rank) ? c : 0.0;
+      packed[3 + 2 * r] = (r == rank) ? d : 0.0;
+    }
+  }
+}
+
+// Normalise (pf.h:262-272) or restore (pf.h:274-278); entropy = ln S - T/S == -sum (w/S) ln (w/S).
+// `packed` is the (all-reduced) vector described above.
+__global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ w, const float* __restrict__ w_new,
+                                                            int n, int world, const double* __restrict__ packed,
+                                                            float* __restrict__ stats4)
+{
+  const double S = packed[0];
+  const float sum_f = static_cast<float>(S);
+  const bool alive = sum_f > 0.0f;
+  if (alive)
+  {
+    for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+      w[i] = w_new[i] / sum_f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats4)
+  {
+    // every rank's slot holds a value in [0,1] resp. [-1,0] (0 in both for a rank whose shard saw no ratios is impossible:
+    // an empty shard reports max 0 / -min -1); the maxima over the slots are the global max ratio and -min ratio
+    double rmax = packed[2], rneg = packed[3];
+    for (int r = 1; r < world; ++r)
+    {
+      rmax = packed[2 + 2 * r] > rmax ? packed[2 + 2 * r] : rmax;
+      rneg = packed[3 + 2 * r] > rneg ? packed[3 + 2 * r] : rneg;
+    }
+    stats4[0] = alive ? static_cast<float>(log(S) - packed[1] / S) : __builtin_nanf("");
+    stats4[1] = static_cast<float>(-rneg);
+    stats4[2] = static_cast<float>(rmax);
+    stats4[3] = alive ? 0.0f : 1.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// "Next" row: the reductions that follow pf::measure in the node (src/mcl_3dl.cpp:451-452,706-709):
+// pf::expectationBiased / max / maxBiased (include/mcl_3dl/pf.h:294-303,361-390) with ParticleWeightedMeanQuat
+// (include/mcl_3dl/state_6dof.h:316-355), and pf::covariance (pf.h:304-360) with State6DOF::covElement (:162-184).
+// Per-particle products are the reference's float expressions; the sums are fp64 trees (reference: float sequential).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MOM_N = 10;  // p_sum, pos[3], front[3], up[3]
+
+struct ArgMax
+{
+  float v;
+  int i;
+};
+__device__ inline ArgMax argmax_better(ArgMax a, ArgMax b)
+{
+  // pf.h:365-372: `if (max_probability < p.probability_)` -> the FIRST maximum wins
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void pf_moments_kernel(const float* __restrict__ pose7,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int n,
+                                                              double* __restrict__ block_mom /*[grid][MOM_N]*/,
+                                                              ArgMax* __restrict__ block_arg /*[grid][2]*/)
+{
+  double m[MOM_N];
+#pragma unroll
+  for (int k = 0; k < MOM_N; ++k)
+    m[k] = 0.0;
+  ArgMax am = { -1.0f, 0x7fffffff }, ab = { -1.0f, 0x7fffffff };
+  bool first = true;
+  for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+  {
+    const float* ps = pose7 + 7 * static_cast<size_t>(i);
+    const float prob = w[i] * (bias ? bias[i] : 1.0f);  // pf.h:300
+    const Quat rot = { ps[3], ps[4], ps[5], ps[6] };
+    const Vec3f front = vscale(qrot(rot, Vec3f{ 1.0f, 0.0f, 0.0f }), prob);  // state_6dof.h:337-338
+    const Vec3f up = vscale(qrot(rot, Vec3f{ 0.0f, 0.0f, 1.0f }), prob);
+    m[0] += static_cast<double>(prob);
+    m[1] += static_cast<double>(ps[0] * prob);  // e_.pos_ += e1.pos_ * prob, :335
+    m[2] += static_cast<double>(ps[1] * prob);
+    m[3] += static_cast<double>(ps[2] * prob);
+    m[4] += static_cast<double>(front.x);
+    m[5] += static_cast<double>(front.y);
+    m[6] += static_cast<double>(front.z);
+    m[7] += static_cast<double>(up.x);
+    m[8] += static_cast<double>(up.y);
+    m[9] += static_cast<double>(up.z);
+    const ArgMax cm = { w[i], i }, cb = { prob, i };
+    am = first ? cm : argmax_better(am, cm);
+    ab = first ? cb : argmax_better(ab, cb);
+    first = false;
+  }
+  __shared__ double sh[MOM_N][PF_BLOCK / 64];
+  __shared__ ArgMax sa[2][PF_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < MOM_N; ++k)
+  {
+    const double s = wave_sum(m[k]);
+    if (lane == 0)
+      sh[k][wave] = s;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    ArgMax o1 = { __shfl_down(am.v, off, 64), __shfl_down(am.i, off, 64) };
+    ArgMax o2 = { __shfl_down(ab.v, off, 64), __shfl_down(ab.i, off, 64) };
+    am = argmax_better(am, o1);
+    ab = argmax_better(ab, o2);
+  }
+  if (lane == 0)
+  {
+    sa[0][wave] = am;
+    sa[1][wave] = ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int k = 0; k < MOM_N; ++k)
+    {
+      double s = 0;
+      for (int q = 0; q < PF_BLOCK / 64; ++q)
+        s += sh[k][q];
+      block_mom[MOM_N * blockIdx.x + k] = s;
+    }
+    ArgMax a = sa[0][0], b = sa[1][0];
+    for (int q = 1; q < PF_BLOCK / 64; ++q)
+    {
+      a = argmax_better(a, sa[0][q]);
+      b = argmax_better(b, sa[1][q]);
+    }
+    block_arg[2 * blockIdx.x + 0] = a;
+    block_arg[2 * blockIdx.x + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(64) void pf_moments_reduce_kernel(const double* __restrict__ block_mom,
+                                                               const ArgMax* __restrict__ block_arg, int n_blocks,
+                                                               double* __restrict__ out_mom /*[MOM_N]*/,
+                                                               int* __restrict__ out_arg /*[2]*/)
+{
+  if (threadIdx.x < MOM_N)
+  {
+    double s = 0;
+    for (int b = 0; b < n_blocks; ++b)  // fixed order
+      s += block_mom[MOM_N * b + threadIdx.x];
+    out_mom[threadIdx.x] = s;
+  }
+  if (threadIdx.x == 32 || threadIdx.x == 33)
+  {
+    const int which = threadIdx.x - 32;
+    ArgMax a = block_arg[which];
+    for (int b = 1; b < n_blocks; ++b)
+      a = argmax_better(a, block_arg[2 * b + which]);
+    out_arg[which] = a.i;
+  }
+}
+
+// Quat::getRPY, include/mcl_3dl/quat.h:188-203 (float storage, double intermediates; device atan2f / asinf)
+__host__ __device__ inline Vec3f quat_get_rpy(Quat q)
+{
+  const float ysq = q.y * q.y;
+  const float t0 = static_cast<float>(-2.0 * (ysq + q.z * q.z) + 1.0);
+  const float t1 = static_cast<float>(+2.0 * (q.x * q.y + q.w * q.z));
+  const double t2d = -2.0 * (q.x * q.z - q.w * q.y);
+  const float t2 = static_cast<float>(t2d > 1.0 ? 1.0 : (t2d < -1.0 ? -1.0 : t2d));
+  const float t3 = static_cast<float>(+2.0 * (q.y * q.z + q.w * q.x));
+  const float t4 = static_cast<float>(-2.0 * (q.x * q.x + ysq) + 1.0);
+  return { atan2f(t3, t4), asinf(t2), atan2f(t1, t0) };
+}
+
+constexpr int COV_N = 22;  // 21 upper-triangular sums + p_sum
+
+// subset == nullptr: particles 0..n-1; else the n indices the caller drew (pf.h:322-336 shuffles them with its own RNG)
+__global__ __launch_bounds__(PF_BLOCK) void pf_covariance_kernel(const float* __restrict__ pose7,
+                                                                 const float* __restrict__ w,
+                                                                 const uint32_t* __restrict__ subset, int n,
+                                                                 float e0, float e1, float e2, Vec3f exp_rpy,
+                                                                 double* __restrict__ block_cov /*[grid][COV_N]*/)
+{
+  double acc[COV_N];
+#pragma unroll
+  for (int k = 0; k < COV_N; ++k)
+    acc[k] = 0.0;
+  for (int t = blockIdx.x * PF_BLOCK + threadIdx.x; t < n; t += gridDim.x * PF_BLOCK)
+  {
+    const size_t i = subset ? subset[t] : static_cast<size_t>(t);
+    const float* ps = pose7 + 7 * i;
+    const float prob = w[i];
+    const Vec3f rpy = quat_get_rpy(Quat{ ps[3], ps[4], ps[5], ps[6] });
+    float d[6] = { ps[0] - e0, ps[1] - e1, ps[2] - e2, rpy.x - exp_rpy.x, rpy.y - exp_rpy.y, rpy.z - exp_rpy.z };
+#pragma unroll
+    for (int a = 3; a < 6; ++a)  // covElement, state_6dof.h:175-179
+    {
+      while (d[a] > M_PI)
+        d[a] = static_cast<float>(d[a] - 2 * M_PI);
+      while (d[a] < -M_PI)
+        d[a] = static_cast<float>(d[a] + 2 * M_PI);
+    }
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int k = j; k < 6; ++k)
+      {
+        float val = 1.0f;
+        val *= d[j];
+        val *= d[k];
+        acc[idx++] += static_cast<double>(val * prob);  // pf.h:347
+      }
+    acc[21] += static_cast<double>(prob);
+  }
+  __shared__ double sh[COV_N][PF_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < COV_N; ++k)
+  {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0)
+      sh[k][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < COV_N)
+  {
+    double s = 0;
+    for (int q = 0; q < PF_BLOCK / 64; ++q)
+      s += sh[threadIdx.x][q];
+    block_cov[COV_N * blockIdx.x + threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void pf_covariance_reduce_kernel(const double* __restrict__ block_cov, int n_blocks,
+                                                                  double* __restrict__ out_cov /*[COV_N]*/)
+{
+  if (threadIdx.x < COV_N)
+  {
+    double s = 0;
+    for (int b = 0; b < n_blocks; ++b)
+      s += block_cov[COV_N * b + threadIdx.x];
+    out_cov[threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// "Next" row: pf::ParticleFilter::resample / resizeParticle (include/mcl_3dl/pf.h:187-225, 399-436).
+// The serial, order-defining parts (float prefix sums, libstdc++'s std::sort of the tie groups, the it/it_prev walk)
+// stay on the host in mcl3dl_hip.hip; the device does the n_out independent std::lower_bound searches and the
+// gather of the 13-dof states with State6DOF::operator+ / normalize() for the duplicated ones.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void resample_lower_bound_kernel(const float* __restrict__ keys, int n, const float* __restrict__ pscan,
+                                            int n_out, uint32_t* __restrict__ it_out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out)
+    return;
+  const float p = pscan[i];
+  int lo = 0, len = n;  // std::lower_bound with Particle::operator< (pf.h:104-107): first key with !(key < p)
+  while (len > 0)
+  {
+    const int half = len >> 1;
+    if (keys[lo + half] < p)
+    {
+      lo += half + 1;
+      len -= half + 1;
+    }
+    else
+      len = half;
+  }
+  it_out[i] = static_cast<uint32_t>(lo);
+}
+
+// slot i receives the state of particle source[i]; duplicated picks get `state + noise` (State6DOF::operator+,
+// state_6dof.h:248-260: components 0-2 and 7-12 add, rot = noise.rot * state.rot) followed by normalize() (:150-153).
+__global__ void resample_apply_kernel(const float* __restrict__ state_in, const uint32_t* __restrict__ source,
+                                      const uint32_t* __restrict__ noise_slot /* 0xffffffff = not duplicated */,
+                                      const float* __restrict__ noise13, int n_out, float* __restrict__ state_out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out)
+    return;
+  const float* s = state_in + 13 * static_cast<size_t>(source[i]);
+  float* o = state_out + 13 * static_cast<size_t>(i);
+  const uint32_t slot = noise_slot[i];
+  if (slot == 0xffffffffu)
+  {
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+      o[k] = s[k];
+    return;
+  }
+  const float* a = noise13 + 13 * static_cast<size_t>(slot);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    o[k] = s[k] + a[k];
+#pragma unroll
+  for (int k = 7; k < 13; ++k)
+    o[k] = s[k] + a[k];
+  const Quat r = qnormalized(qmul(Quat{ a[3], a[4], a[5], a[6] }, Quat{ s[3], s[4], s[5], s[6] }));
+  o[3] = r.x;
+  o[4] = r.y;
+  o[5] = r.z;
+  o[6] = r.w;
+}
+}  // namespace mcl3dl
