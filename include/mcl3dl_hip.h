@@ -217,6 +217,8 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
  *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points; 0 = one
  *                       work-group per particle always (only the fp64 summation order differs)
+ *   "overlap_models"    1 (default) = the beam kernels run on a second stream concurrently with the likelihood kernels
+ *                       (forked from / joined into the context's stream with events); 0 = one after the other
  *   "lik_small"         1 (default) = scans of <= 32 points with >= 256 particles (global localisation) share each
  *                       wavefront between 64 / W particles; 0 = always one work-group per particle
  *   "lik_group"         particles per work-group of the tiled kernel: 8, 16 (default) or 32

@@ -44,6 +44,12 @@ struct mcl3dl_hip_ctx
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // The two LiDAR models are independent until pf::measure: the beam kernels run on a second stream, forked from and
+  // joined back into `stream` with events, so their (VALU-heavy, memory-light) waves fill the slots the likelihood
+  // kernel leaves idle while it waits on L2.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int overlap_models = 1;
   std::string err;
 
   // host copy of the map (kept to rebuild the device structures when parameters change)
@@ -189,8 +195,10 @@ int d2h(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
 }
 
 // ---- timing -----------------------------------------------------------------------------------------
-int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep)
+int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep, hipStream_t on = nullptr)
 {
+  if (!on)
+    on = ctx->stream;
   if (!ctx->timing)
     return 0;
   hipEvent_t ev[2];
@@ -209,15 +217,15 @@ int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep)
   ep->start = ev[0];
   ep->stop = ev[1];
   ep->kernel = kernel;
-  HIP_TRY(hipEventRecord(ep->start, ctx->stream));
+  HIP_TRY(hipEventRecord(ep->start, on));
   return 0;
 }
 
-int timing_end(mcl3dl_hip_ctx* ctx, const EventPair& ep)
+int timing_end(mcl3dl_hip_ctx* ctx, const EventPair& ep, hipStream_t on = nullptr)
 {
   if (!ctx->timing)
     return 0;
-  HIP_TRY(hipEventRecord(ep.stop, ctx->stream));
+  HIP_TRY(hipEventRecord(ep.stop, on ? on : ctx->stream));
   ctx->pending.push_back(ep);
   return 0;
 }
@@ -227,6 +235,7 @@ int timing_collect(mcl3dl_hip_ctx* ctx)
   if (ctx->pending.empty())
     return 0;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
   for (const EventPair& ep : ctx->pending)
   {
     float ms = 0.f;
@@ -757,6 +766,73 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   const bool want_beam = (d_beam || stats);
   TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0, stats));
   const int np = static_cast<int>(n_p);
+  bool beam_forked = false;
+  // ---- beam model (enqueued first: on its own stream when both models run, see mcl3dl_hip_ctx::aux_stream)
+  if (want_beam)
+  {
+    if (ctx->n_b == 0)
+    {
+      if (!stats)
+        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
+                           static_cast<float*>(nullptr), 0.0f, np);
+    }
+    else
+    {
+      if (ctx->pow_table_dirty)
+      {
+        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float
+        std::vector<float> table(ctx->n_b + 1);
+        table[0] = 1.0f;
+        for (size_t k = 1; k <= ctx->n_b; ++k)
+          table[k] = table[k - 1] * ctx->beam_likelihood;
+        TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
+        TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->pow_table_dirty = false;
+      }
+      const BeamParams bp = beam_params(ctx);
+      const long long n_rays = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_b);
+      const long long blocks = (n_rays + 255) / 256;
+      if (blocks > 0x7fffffffLL)
+        return ctx->fail(-3, "too many rays for one launch");
+      TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+      const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0;
+      hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
+      if (overlap)
+      {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(bs, ctx->ev_fork, 0));
+      }
+      EventPair ep{};
+      if (!stats)
+        TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep, bs));
+      HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, bs));
+      if (stats)
+      {
+        TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
+        HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), bs));
+        hipLaunchKernelGGL((beam_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
+                           ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), ctx->ray_stats.as<RayStats>());
+      }
+      else
+      {
+        hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
+                           ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr));
+        hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,
+                           ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
+                           np);
+        TRY(timing_end(ctx, ep, bs));
+      }
+      if (overlap)
+      {
+        HIP_TRY(hipEventRecord(ctx->ev_join, bs));
+        beam_forked = true;
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
   // ---- likelihood-field model
   if (want_lik)
   {
@@ -908,60 +984,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     }
     HIP_TRY(hipGetLastError());
   }
-  // ---- beam model
-  if (want_beam)
-  {
-    if (ctx->n_b == 0)
-    {
-      if (!stats)
-        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
-                           static_cast<float*>(nullptr), 0.0f, np);
-    }
-    else
-    {
-      if (ctx->pow_table_dirty)
-      {
-        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float
-        std::vector<float> table(ctx->n_b + 1);
-        table[0] = 1.0f;
-        for (size_t k = 1; k <= ctx->n_b; ++k)
-          table[k] = table[k - 1] * ctx->beam_likelihood;
-        TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
-        TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx->pow_table_dirty = false;
-      }
-      const BeamParams bp = beam_params(ctx);
-      const long long n_rays = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_b);
-      const long long blocks = (n_rays + 255) / 256;
-      if (blocks > 0x7fffffffLL)
-        return ctx->fail(-3, "too many rays for one launch");
-      TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
-      EventPair ep{};
-      if (!stats)
-        TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep));
-      HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, ctx->stream));
-      if (stats)
-      {
-        TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
-        HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), ctx->stream));
-        hipLaunchKernelGGL((beam_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d_pose,
-                           ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
-                           ctx->dg, bp, ctx->penalty.as<unsigned>(), ctx->ray_stats.as<RayStats>());
-      }
-      else
-      {
-        hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
-                           d_pose, ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(),
-                           n_rays, ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr));
-        hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
-                           ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
-                           np);
-        TRY(timing_end(ctx, ep));
-      }
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  if (beam_forked)
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // later work on `stream` sees the beam scores
   if (stats)
   {
     std::vector<double> tested(ctx->n_s ? n_p : 0);
@@ -1016,6 +1040,13 @@ int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
     return -2;
   }
   ctx->stream = ctx->own_stream;
+  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+  {
+    delete ctx;
+    return -2;
+  }
   beam_refresh(ctx);
   *out = ctx;
   return 0;
@@ -1027,6 +1058,8 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream)
+    (void)hipStreamSynchronize(ctx->aux_stream);
   DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->scan_perm, &ctx->strict_terms, &ctx->mom_blocks, &ctx->mom_arg, &ctx->mom_out, &ctx->mom_idx,
                      &ctx->subset, &ctx->rs_d_keys, &ctx->rs_d_pscan, &ctx->rs_d_it, &ctx->rs_d_source, &ctx->rs_d_slot,
                      &ctx->rs_d_noise, &ctx->rs_d_in, &ctx->rs_d_out, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
@@ -1044,6 +1077,12 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
   }
   for (hipEvent_t e : ctx->free_events)
     (void)hipEventDestroy(e);
+  if (ctx->ev_fork)
+    (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join)
+    (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->aux_stream)
+    (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream)
     (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -1918,6 +1957,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   if (key == "strict_order")
   {
     ctx->strict_order = value != 0.0;
+    return 0;
+  }
+  if (key == "overlap_models")
+  {
+    ctx->overlap_models = value != 0.0;
     return 0;
   }
   if (key == "lik_small")
