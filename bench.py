@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
+    ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
     ap.add_argument("--lik-small", type=int, default=1)
     ap.add_argument("--overlap-models", type=int, default=1)
     ap.add_argument("--scan-points", type=int, default=0, help="override the number of likelihood scan points")
@@ -129,6 +130,8 @@ def main():
     n_p = args.particles or cfg["n_p"]
     # weak scaling: every rank holds a full-size particle shard drawn with its own seed; map and scan are replicated
     extra_cfg = dict(n_s=args.scan_points) if args.scan_points else {}
+    if args.beam_points:
+        extra_cfg["n_b"] = args.beam_points  # C3 stress case N_b = 16 384
     sc = make_config(args.workload, n_p=n_p, seed=12345, **extra_cfg)
     if rank > 0:
         shard = make_config(args.workload, n_p=n_p, seed=12345 + rank, **extra_cfg)

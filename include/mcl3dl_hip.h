@@ -196,6 +196,15 @@ int mcl3dl_hip_resample_apply(mcl3dl_hip_ctx* ctx, const float* state13_in /*n*1
                               float* state13_out /*n_out*13*/);
 int mcl3dl_hip_resample_apply_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13 /*host*/,
                                      size_t n_noise, float* d_state13_out);
+/* Device-resident / sharded variants. begin_device takes the weights from device memory (they travel to the host: the
+ * prefix sums are a sequential float recurrence). apply_slice_device fills only the output slots
+ * [out_begin, out_begin + out_count) — a rank's own shard when particles are split over GPUs: every rank plans on the
+ * all-gathered weights, gathers the states, and writes its slice (mcl_3dl_amd/distributed.py:sharded_resample).
+ * d_state13_in holds all n input particles, d_state13_out out_count states, noise13 the noise of ALL duplicated slots. */
+int mcl3dl_hip_resample_begin_device(mcl3dl_hip_ctx* ctx, const float* d_weight /*n*/, size_t n, size_t n_out,
+                                     float* out_pstep);
+int mcl3dl_hip_resample_apply_slice_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13 /*host*/,
+                                           size_t n_noise, size_t out_begin, size_t out_count, float* d_state13_out);
 
 /* ---- measurement support ------------------------------------------------------------------------------ */
 /* Per-kernel hipEvent timing on the launch stream (off by default). */

@@ -42,6 +42,8 @@ SIGNATURES = {
     "mcl3dl_hip_resample_plan": (_i, [_p, _i, _f, _p, _p, C.POINTER(_sz)]),
     "mcl3dl_hip_resample_apply": (_i, [_p, _p, _p, _sz, _p]),
     "mcl3dl_hip_resample_apply_device": (_i, [_p, _p, _p, _sz, _p]),
+    "mcl3dl_hip_resample_begin_device": (_i, [_p, _p, _sz, _sz, C.POINTER(_f)]),
+    "mcl3dl_hip_resample_apply_slice_device": (_i, [_p, _p, _p, _sz, _sz, _sz, _p]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
     "mcl3dl_hip_measure_device": (_i, [_p, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_pf_partial_device": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
@@ -266,6 +268,21 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_resample_apply(self.h, _ptr(s), _ptr(nz), 0 if nz is None else len(nz),
                                                        _ptr(out)))
         return out
+
+    def resample_begin_device(self, d_weight, n, n_out=None):
+        pstep = C.c_float(0)
+        self._rs_n_out = n if n_out is None else n_out
+        self._check(self.lib.mcl3dl_hip_resample_begin_device(self.h, _ptr(d_weight), n, self._rs_n_out,
+                                                              C.byref(pstep)))
+        return float(pstep.value)
+
+    def resample_apply_device(self, d_state13_in, noise13, d_state13_out, out_begin=0, out_count=None):
+        """Gather (+ noise on duplicated slots) into d_state13_out; a slice of the planned slots when out_count is set."""
+        nz = None if noise13 is None or len(noise13) == 0 else _np_f32(noise13, 13)
+        cnt = self._rs_n_out - out_begin if out_count is None else out_count
+        self._check(self.lib.mcl3dl_hip_resample_apply_slice_device(self.h, _ptr(d_state13_in), _ptr(nz),
+                                                                    0 if nz is None else len(nz), out_begin, cnt,
+                                                                    _ptr(d_state13_out)))
 
     def radius_search(self, query_xyz, radius):
         q = _np_f32(query_xyz, 3)

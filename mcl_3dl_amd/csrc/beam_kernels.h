@@ -200,11 +200,22 @@ __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pos
                                                    DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
                                                    RayStats* __restrict__ stats)
 {
-  const long long ray = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long ray0 = static_cast<long long>(blockIdx.x) * 256;
+  const long long ray = ray0 + threadIdx.x;
   unsigned st_steps = 0, st_occ = 0, st_tested = 0;
+  // Penalised rays are counted per particle. Thousands of rays of one particle bumping one global counter serialise in
+  // L2 (same cache line), so a work-group first counts in LDS for the (at most two, when N_b >= 256) particles its 256
+  // rays start with — one ballot + popcount per wavefront — and issues one global atomic per particle at the end.
+  __shared__ unsigned block_count[2];
+  if (threadIdx.x < 2)
+    block_count[threadIdx.x] = 0u;
+  __syncthreads();
+  const long long p0 = ray0 / n_b;
+  bool penalised = false;
+  long long p = p0;
   if (ray < n_rays)
   {
-    const long long p = ray / n_b;
+    p = ray / n_b;
     const int i = static_cast<int>(ray - p * n_b);
     const float* ps = pose7 + 7 * p;
     const Vec3f pos = { ps[0], ps[1], ps[2] };
@@ -216,9 +227,21 @@ __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pos
     const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
     int hit;
     const int status = cast_ray<STATS>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
-    if ((status == 0) || (!bp.short_only && (status == 2)))  // beam.cpp:146
-      atomicAdd(&penalty_count[p], 1u);
+    penalised = (status == 0) || (!bp.short_only && (status == 2));  // beam.cpp:146
   }
+  const int rel = static_cast<int>(p - p0);  // >= 0; small N_b puts many particles in one work-group
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+  {
+    const unsigned long long m = __ballot(penalised && rel == s);
+    if (m != 0ull && (threadIdx.x & 63) == 0)
+      atomicAdd(&block_count[s], static_cast<unsigned>(__popcll(m)));
+  }
+  if (penalised && rel >= 2)
+    atomicAdd(&penalty_count[p], 1u);
+  __syncthreads();
+  if (threadIdx.x < 2 && block_count[threadIdx.x] != 0u)
+    atomicAdd(&penalty_count[p0 + threadIdx.x], block_count[threadIdx.x]);
   if (STATS)
   {
     atomicAdd(&stats->steps, static_cast<unsigned long long>(st_steps));

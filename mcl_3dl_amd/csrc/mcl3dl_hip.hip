@@ -1843,8 +1843,22 @@ int mcl3dl_hip_resample_plan(mcl3dl_hip_ctx* ctx, int mode, float initial_p, uin
   return 0;
 }
 
-int mcl3dl_hip_resample_apply_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13,
-                                     size_t n_noise, float* d_state13_out)
+int mcl3dl_hip_resample_begin_device(mcl3dl_hip_ctx* ctx, const float* d_weight, size_t n, size_t n_out, float* out_pstep)
+{
+  if (!ctx)
+    return -1;
+  if (!d_weight || n == 0 || n > 0x7fffffffu)
+    return ctx->fail(-3, "bad arguments to resample_begin_device");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // the prefix sums are a float recurrence in particle order (pf.h:193-197): 4 bytes per particle come to the host
+  std::vector<float> w(n);
+  TRY(d2h(ctx, w.data(), d_weight, sizeof(float) * n));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return mcl3dl_hip_resample_begin(ctx, w.data(), n, n_out, out_pstep);
+}
+
+int mcl3dl_hip_resample_apply_slice_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13,
+                                           size_t n_noise, size_t out_begin, size_t out_count, float* d_state13_out)
 {
   if (!ctx)
     return -1;
@@ -1852,18 +1866,31 @@ int mcl3dl_hip_resample_apply_device(mcl3dl_hip_ctx* ctx, const float* d_state13
     return ctx->fail(-5, "resample_apply before resample_plan");
   if (!d_state13_in || !d_state13_out || d_state13_in == d_state13_out)
     return ctx->fail(-3, "resample_apply needs distinct input and output state arrays");
+  if (out_begin > ctx->rs_n_out || out_count > ctx->rs_n_out - out_begin)
+    return ctx->fail(-3, "resample_apply: slice [%zu, %zu) is outside the %zu planned slots", out_begin,
+                     out_begin + out_count, ctx->rs_n_out);
   if (n_noise < ctx->rs_n_dup || (ctx->rs_n_dup && !noise13))
     return ctx->fail(-3, "resample_apply: %zu duplicated particles need noise, %zu given", ctx->rs_n_dup, n_noise);
+  if (out_count == 0)
+    return 0;
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(ensure(ctx, ctx->rs_d_noise, sizeof(float) * 13 * ctx->rs_n_dup));
   TRY(h2d(ctx, ctx->rs_d_noise.p, noise13, sizeof(float) * 13 * ctx->rs_n_dup));
-  const int no = static_cast<int>(ctx->rs_n_out);
+  const int no = static_cast<int>(out_count);
   hipLaunchKernelGGL(resample_apply_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream, d_state13_in,
-                     ctx->rs_d_source.as<uint32_t>(), ctx->rs_d_slot.as<uint32_t>(), ctx->rs_d_noise.as<float>(), no,
-                     d_state13_out);
+                     ctx->rs_d_source.as<uint32_t>() + out_begin, ctx->rs_d_slot.as<uint32_t>() + out_begin,
+                     ctx->rs_d_noise.as<float>(), no, d_state13_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));  // noise13 is the caller's host buffer
   return 0;
+}
+
+int mcl3dl_hip_resample_apply_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13,
+                                     size_t n_noise, float* d_state13_out)
+{
+  if (!ctx)
+    return -1;
+  return mcl3dl_hip_resample_apply_slice_device(ctx, d_state13_in, noise13, n_noise, 0, ctx->rs_n_out, d_state13_out);
 }
 
 int mcl3dl_hip_resample_apply(mcl3dl_hip_ctx* ctx, const float* state13_in, const float* noise13, size_t n_noise,

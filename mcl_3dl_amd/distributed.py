@@ -7,6 +7,11 @@ all-reduce(SUM) of 2 + 2*world doubles that carries
     [2 + 2r], [3 + 2r]          rank r's  max match_ratio  and  -min match_ratio  (every other rank contributes 0)
 so max / min fall out of the same SUM (slot r is written by rank r only).  16-80 bytes: latency-bound over xGMI.
 The functions here are backend-agnostic (`nccl` == RCCL on the GPU box, `gloo` in the CPU tests).
+
+Resampling (SURVEY.md §8f-1) is the one step with a real exchange: pf::resample (include/mcl_3dl/pf.h:187-225) walks
+the GLOBAL prefix sums of the weights, so an output slot on one GPU may copy a particle that lives on another.
+`sharded_resample` all-gathers the weights (4 B/particle) and the 13-float states (52 B/particle; 13.6 MB at 262 144
+particles, one collective each), every rank builds the same plan, and each rank fills its own output slice.
 """
 import torch
 import torch.distributed as dist
@@ -52,3 +57,56 @@ def allreduce_partials(partial4, group=None, scratch=None, out=None):
     packed = pack_partials(partial4, rank, world, out=scratch)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return unpack_totals(packed, out=out)
+
+
+def all_gather_shards(local, n_total, group=None):
+    """Concatenate the contiguous shards (shard_bounds) of every rank along dim 0. Shards may differ by one row."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(n_total, world, r) for r in range(world)]
+    rows = max(hi - lo for lo, hi in sizes)
+    if local.shape[0] < rows:
+        pad = torch.zeros((rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    out = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if all(hi - lo == rows for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * rows:r * rows + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+class EngineResampleOps:
+    """The three resampling calls of the C ABI on device tensors (mcl_3dl_amd/capi.py:Engine)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def begin(self, weight_all):
+        return self.engine.resample_begin_device(weight_all, weight_all.shape[0])
+
+    def plan(self, initial_p):
+        return self.engine.resample_plan(0, initial_p)
+
+    def apply_slice(self, state_all, noise13, lo, count):
+        out = torch.empty((count, 13), dtype=torch.float32, device=state_all.device)
+        self.engine.resample_apply_device(state_all, noise13, out, lo, count)
+        return out
+
+
+def sharded_resample(ops, state_local, weight_local, n_total, draw_initial_p, draw_noise, group=None):
+    """pf::resample over particles sharded by shard_bounds. Every rank must pass callbacks that return the SAME draws
+    (the reference's single random engine: seed it identically on every rank, or draw on rank 0 and broadcast):
+    draw_initial_p(pstep) -> float in [0, pstep) (pf.h:203), draw_noise(n_dup) -> (n_dup, 13) noise states in slot order
+    (pf.h:216). Returns (this rank's new states, its new uniform weights 1/n_total (pf.h:207), (source, dup) plan)."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_bounds(n_total, world, rank)
+    weight_all = all_gather_shards(weight_local, n_total, group)
+    state_all = all_gather_shards(state_local, n_total, group)
+    pstep = ops.begin(weight_all)
+    source, dup, n_dup = ops.plan(draw_initial_p(pstep))
+    noise = draw_noise(n_dup)
+    new_state = ops.apply_slice(state_all, noise, lo, hi - lo)
+    new_weight = torch.full((hi - lo,), 1.0 / n_total, dtype=torch.float32, device=weight_local.device)
+    return new_state, new_weight, (source, dup)

@@ -98,3 +98,62 @@ def test_all_dead_restores_on_every_rank(tmp_path):
         p = np.load(out_path % r)
         np.testing.assert_array_equal(p["w"], w[p["lo"]:p["hi"]])
         assert np.isnan(p["entropy"])
+
+
+# ---- sharded resampling (multi-GPU clause) ---------------------------------------------------------
+class _OracleResampleOps:
+    """CPU stand-in with the interface of mcl_3dl_amd.distributed.EngineResampleOps, backed by the plain-C oracle."""
+
+    def __init__(self):
+        self.o = pyoracle.Oracle("port")
+
+    def begin(self, weight_all):
+        self.w = weight_all.numpy().copy()
+        return self.o.resample_pstep(self.w, len(self.w))
+
+    def plan(self, initial_p):
+        self.src, self.dup = self.o.resample_plan(self.w, len(self.w), 0, initial_p)
+        return self.src, self.dup, int(self.dup.sum())
+
+    def apply_slice(self, state_all, noise13, lo, count):
+        slot = np.cumsum(self.dup) - 1  # noise is indexed by the GLOBAL duplicate slot
+        nz = np.zeros((len(self.src), 13), np.float32)
+        nz[self.dup > 0] = noise13[slot[self.dup > 0]]
+        # the oracle consumes noise in order of the duplicates it meets: hand it the slice's own
+        sl = slice(lo, lo + count)
+        return torch.from_numpy(self.o.resample_apply(state_all.numpy(), self.src[sl], self.dup[sl],
+                                                      nz[sl][self.dup[sl] > 0]))
+
+
+def _resample_worker(rank, world, port, s, w, initial_frac, noise_all, out_path):
+    from mcl_3dl_amd.distributed import sharded_resample
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(len(w), world, rank)
+    new_s, new_w, (src, dup) = sharded_resample(
+        _OracleResampleOps(), torch.from_numpy(s[lo:hi].copy()), torch.from_numpy(w[lo:hi].copy()), len(w),
+        lambda pstep: np.float32(pstep) * np.float32(initial_frac), lambda n_dup: noise_all[:n_dup])
+    np.savez(out_path % rank, s=new_s.numpy(), w=new_w.numpy(), src=src, dup=dup)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,dead", [(1001, 0), (512, 100)])
+def test_two_rank_resample_matches_single_process(tmp_path, n, dead):
+    import resample_cases as rc
+    s, w = rc.make_case(n, dead)
+    rng = np.random.default_rng(7)
+    noise_all = rng.normal(0, 0.05, (n, 13)).astype(np.float32)
+    frac = 0.37
+    o = pyoracle.Oracle("port")
+    pstep = o.resample_pstep(w, n)
+    src, dup = o.resample_plan(w, n, 0, np.float32(pstep) * np.float32(frac))
+    want = o.resample_apply(s, src, dup, noise_all[:int(dup.sum())])
+    out_path = str(tmp_path / "rs%d.npz")
+    mp.spawn(_resample_worker, args=(2, _free_port(), s, w, frac, noise_all, out_path), nprocs=2, join=True)
+    parts = [np.load(out_path % r) for r in range(2)]
+    np.testing.assert_array_equal(parts[0]["src"], src)
+    np.testing.assert_array_equal(parts[1]["dup"], dup)
+    np.testing.assert_array_equal(np.concatenate([p["s"] for p in parts]), want)
+    assert all(np.all(p["w"] == np.float32(1.0 / n)) for p in parts)

@@ -78,3 +78,30 @@ def test_error_paths(engine):
     with pytest.raises(capi.EngineError, match="need noise"):
         e.resample_apply(np.zeros((4, 13), np.float32), None)
     e.close()
+
+
+@pytest.mark.parametrize("n,dead", [(1000, 300), (2048, 900), (5, 0)])
+def test_device_resident_and_sliced_apply(engine, n, dead):
+    """Weights and states stay in device memory; the output is produced in two slices, as two GPUs would
+    (mcl_3dl_amd/distributed.py:sharded_resample), and must equal the reference's single pass bit for bit."""
+    import torch
+    from mcl_3dl_amd.distributed import EngineResampleOps, shard_bounds, sharded_resample
+    key = "n%d_d%d" % (n, dead)
+    dev = torch.device("cuda:0")
+    s, w = rc.make_case(n, dead)
+    d_w, d_s = torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev)
+    ops = EngineResampleOps(engine)
+    # world size 1 through the distributed entry point
+    new_s, new_w, (src, dup) = sharded_resample(ops, d_s, d_w, n, lambda pstep: float(GOLD[key + "_initial_p"]),
+                                                lambda nd: GOLD[key + "_noise"][:nd])
+    np.testing.assert_array_equal(new_s.cpu().numpy(), GOLD[key + "_states"])
+    assert torch.all(new_w == np.float32(1.0 / n))
+    # two output slices from the same plan
+    parts = []
+    for r in range(2):
+        lo, hi = shard_bounds(n, 2, r)
+        parts.append(ops.apply_slice(d_s, GOLD[key + "_noise"], lo, hi - lo).cpu().numpy())
+    np.testing.assert_array_equal(np.concatenate(parts), GOLD[key + "_states"])
+    from mcl_3dl_amd import capi
+    with pytest.raises(capi.EngineError, match="outside"):
+        ops.apply_slice(d_s, GOLD[key + "_noise"], n - 1, 5)
