@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
                                                                float* __restrict__ strict_terms)
 {
   // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
-  // [original scan index][particle] so that lik_strict_sum_kernel can add them in the reference's own order.
+  // [particle group][original scan index][G] so that lik_strict_sum_kernel can add them in the reference's own order.
   __shared__ float s_pose[G][8];        // px,py,pz, qx,qy,qz,qw (normalised), valid
   __shared__ float s_term[G][256];
   __shared__ unsigned s_cnt[G][4];
@@ -444,13 +444,26 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
       }
     }
     s_term[k][t] = term;
-    if (strict_terms && have_point)
-      strict_terms[static_cast<size_t>(scan_perm[i]) * n_p + (group * G + k)] = term;
     const unsigned long long m = __ballot(matched);
     if (lane == 0)
       s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
   }
   __syncthreads();
+  if (strict_terms)
+  {
+    // rows of G floats, [group][original scan index][G]: G / 4 lanes write one row as float4s (one 16..128-byte run)
+    constexpr int Q = G / 4;
+    float4* rows = reinterpret_cast<float4*>(strict_terms) + static_cast<size_t>(group) * n_s * Q;
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+    {
+      const int e = t + 256 * j, pt = e / Q, k4 = (e % Q) * 4;
+      const int src = tile * 256 + pt;
+      if (src < n_s)
+        rows[static_cast<size_t>(scan_perm[src]) * Q + (e % Q)] =
+            make_float4(s_term[k4][pt], s_term[k4 + 1][pt], s_term[k4 + 2][pt], s_term[k4 + 3][pt]);
+    }
+  }
   // fixed-order fp64 reduction: 256 / G lanes per particle, each sums a contiguous segment (bank-rotated reads)
   constexpr int LPP = 256 / G;        // lanes per particle
   constexpr int SEG = 256 / LPP;      // = G terms per lane
@@ -496,31 +509,75 @@ __global__ void lik_finalize_kernel(const double* __restrict__ partial_sum, cons
     out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
 }
 
-// "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): one lane per
-// particle walks the scan in ORIGINAL order, float adds, sequentially. Unmatched points hold 0 (x + 0.0f == x), so
-// the result is the reference's float, bit for bit. Loads run DEPTH ahead of the dependent add chain.
-__global__ __launch_bounds__(64) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
-                                                            float* __restrict__ out_lik)
+// "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): float adds,
+// sequentially, in ORIGINAL scan order. Unmatched points hold 0 (x + 0.0f == x), so the result is the reference's
+// float, bit for bit. One work-group per particle group streams its [n_s][G] term rows: all 256 lanes fetch the next
+// 256 rows (registers -> LDS, double-buffered) while lanes 0..G-1 of wavefront 0, one per particle, run the dependent
+// add chain over the 256 rows already in LDS — the chain (n_s adds) is the critical path, the loads hide behind it.
+template <int G>
+__global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
+                                                             float* __restrict__ out_lik)
 {
-  const int p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= n_p)
-    return;
-  constexpr int DEPTH = 32;
-  float score = 0.0f;
-  int i = 0;
-  for (; i + DEPTH <= n_s; i += DEPTH)
+  constexpr int Q = G / 4;  // float4s per row
+  __shared__ float4 buf[2][256 * Q];
+  const int group = blockIdx.x, t = threadIdx.x;
+  const float4* rows = reinterpret_cast<const float4*>(terms) + static_cast<size_t>(group) * n_s * Q;
+  const int total = n_s * Q;  // float4s of this group
+  const int n_chunks = (n_s + 255) / 256;
+  float4 reg[Q];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < Q; ++j)
   {
-    float v[DEPTH];
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j)
-      v[j] = terms[static_cast<size_t>(i + j) * n_p + p];
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j)
-      score += v[j];
+    const int e = t + 256 * j;
+    reg[j] = e < total ? rows[e] : z4;
   }
-  for (; i < n_s; ++i)
-    score += terms[static_cast<size_t>(i) * n_p + p];
-  out_lik[p] = score;
+#pragma unroll
+  for (int j = 0; j < Q; ++j)
+    buf[0][t + 256 * j] = reg[j];
+  __syncthreads();
+  float score = 0.0f;
+  for (int c = 0; c < n_chunks; ++c)
+  {
+    const int nxt = (c + 1) * 256 * Q;
+    if (c + 1 < n_chunks)
+    {
+#pragma unroll
+      for (int j = 0; j < Q; ++j)
+      {
+        const int e = nxt + t + 256 * j;
+        reg[j] = e < total ? rows[e] : z4;
+      }
+    }
+    if (t < G)
+    {
+      const float* cur = reinterpret_cast<const float*>(buf[c & 1]);
+      const int n_rows = min(256, n_s - c * 256);
+      int r = 0;
+      for (; r + 16 <= n_rows; r += 16)
+      {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          v[j] = cur[(r + j) * G + t];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          score += v[j];
+      }
+      for (; r < n_rows; ++r)
+        score += cur[r * G + t];
+    }
+    if (c + 1 < n_chunks)
+    {
+#pragma unroll
+      for (int j = 0; j < Q; ++j)
+        buf[(c + 1) & 1][t + 256 * j] = reg[j];
+    }
+    __syncthreads();
+  }
+  const int p = group * G + t;
+  if (t < G && p < n_p)
+    out_lik[p] = score;
 }
 
 // "strict_order": pf::measure's `sum += p.probability_` (pf.h:255-260) as a float, sequentially, by one lane; the result

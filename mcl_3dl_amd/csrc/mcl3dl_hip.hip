@@ -862,7 +862,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         float* strict_terms = nullptr;
         if (ctx->strict_order)
         {
-          TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * n_p));
+          const size_t G = static_cast<size_t>(ctx->lik_group);  // rows of G floats per particle group
+          TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));
           strict_terms = ctx->strict_terms.as<float>();
         }
         const bool small = !tiled && ns <= 32 && np >= 256 && ctx->lik_small;
@@ -948,8 +949,17 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
                              d_lik, d_ratio);
           if (strict_terms && d_lik)
-            hipLaunchKernelGGL(lik_strict_sum_kernel, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, strict_terms, ns, np,
-                               d_lik);
+          {
+            if (G == 8)
+              hipLaunchKernelGGL(lik_strict_sum_kernel<8>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns, np,
+                                 d_lik);
+            else if (G == 32)
+              hipLaunchKernelGGL(lik_strict_sum_kernel<32>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns,
+                                 np, d_lik);
+            else
+              hipLaunchKernelGGL(lik_strict_sum_kernel<16>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns,
+                                 np, d_lik);
+          }
         }
         else
         {
