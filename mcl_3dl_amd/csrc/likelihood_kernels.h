@@ -489,19 +489,37 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
   }
 }
 
-__global__ void lik_finalize_kernel(const double* __restrict__ partial_sum, const unsigned* __restrict__ partial_cnt,
-                                    int n_tiles, int n_p, int n_s, float* __restrict__ out_lik,
-                                    float* __restrict__ out_ratio)
+// Sums the per-tile partials of each particle: 32 particles per work-group, 8 lanes per particle each walk every 8th tile
+// (independent loads, 1/8 of the dependent chain), then lane-slice 0 adds the 8 sub-sums in fixed order (deterministic).
+__global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restrict__ partial_sum,
+                                                           const unsigned* __restrict__ partial_cnt, int n_tiles, int n_p,
+                                                           int n_s, float* __restrict__ out_lik,
+                                                           float* __restrict__ out_ratio)
 {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_p)
-    return;
+  __shared__ double s_a[8][32];
+  __shared__ unsigned s_n[8][32];
+  const int pl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int p = blockIdx.x * 32 + pl;
   double a = 0.0;
   unsigned n = 0;
-  for (int tl = 0; tl < n_tiles; ++tl)
+  if (p < n_p)
   {
-    a += partial_sum[static_cast<size_t>(tl) * n_p + p];
-    n += partial_cnt[static_cast<size_t>(tl) * n_p + p];
+    for (int tl = slice; tl < n_tiles; tl += 8)
+    {
+      a += partial_sum[static_cast<size_t>(tl) * n_p + p];
+      n += partial_cnt[static_cast<size_t>(tl) * n_p + p];
+    }
+  }
+  s_a[slice][pl] = a;
+  s_n[slice][pl] = n;
+  __syncthreads();
+  if (slice != 0 || p >= n_p)
+    return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+  {
+    a += s_a[k][pl];
+    n += s_n[k][pl];
   }
   if (out_lik)
     out_lik[p] = static_cast<float>(a);
@@ -511,67 +529,80 @@ __global__ void lik_finalize_kernel(const double* __restrict__ partial_sum, cons
 
 // "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): float adds,
 // sequentially, in ORIGINAL scan order. Unmatched points hold 0 (x + 0.0f == x), so the result is the reference's
-// float, bit for bit. One work-group per particle group streams its [n_s][G] term rows: all 256 lanes fetch the next
-// 256 rows (registers -> LDS, double-buffered) while lanes 0..G-1 of wavefront 0, one per particle, run the dependent
-// add chain over the 256 rows already in LDS — the chain (n_s adds) is the critical path, the loads hide behind it.
+// float, bit for bit. One work-group per particle group streams its [n_s][G] term rows. Wavefronts 1-3 are loaders:
+// they fetch the next ROWS rows and store them TRANSPOSED ([particle][row]) into the other LDS buffer; wavefront 0 is the
+// adder: lanes 0..G-1, one per particle, read four consecutive rows per ds_read_b128 and run the dependent add chain.
+// The chain (n_s adds per particle) is the critical path; the loads hide behind it.
 template <int G>
 __global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
                                                              float* __restrict__ out_lik)
 {
-  constexpr int Q = G / 4;  // float4s per row
-  __shared__ float4 buf[2][256 * Q];
+  constexpr int Q = G / 4;               // float4s per row
+  constexpr int ROWS = 65536 / (4 * G);  // rows per chunk (64 KB of terms)
+  constexpr int LD = ROWS + 4;           // padded row length of the transposed buffer (keeps 16-byte alignment)
+  constexpr int LOADERS = 192;
+  constexpr int PER = (ROWS * Q + LOADERS - 1) / LOADERS;
+  __shared__ __attribute__((aligned(16))) float buf[2][G * LD];
   const int group = blockIdx.x, t = threadIdx.x;
   const float4* rows = reinterpret_cast<const float4*>(terms) + static_cast<size_t>(group) * n_s * Q;
-  const int total = n_s * Q;  // float4s of this group
-  const int n_chunks = (n_s + 255) / 256;
-  float4 reg[Q];
+  const int n_chunks = (n_s + ROWS - 1) / ROWS;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int j = 0; j < Q; ++j)
+  const auto stage = [&](int c)
   {
-    const int e = t + 256 * j;
-    reg[j] = e < total ? rows[e] : z4;
-  }
+    // loaders only: chunk c -> buf[c & 1], transposed; rows past n_s are zero-filled up to the next multiple of 4
+    const int lt = t - 64;
+    const int first = c * ROWS, n_rows = min(ROWS, n_s - first);
+    const int padded = (n_rows + 3) & ~3;
+    float* dst = buf[c & 1];
+    float4 reg[PER];
 #pragma unroll
-  for (int j = 0; j < Q; ++j)
-    buf[0][t + 256 * j] = reg[j];
+    for (int j = 0; j < PER; ++j)
+    {
+      const int e = lt + LOADERS * j, r = e / Q;
+      reg[j] = r < n_rows ? rows[static_cast<size_t>(first) * Q + e] : z4;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+    {
+      const int e = lt + LOADERS * j, r = e / Q, k4 = (e % Q) * 4;
+      if (r < padded)
+      {
+        dst[(k4 + 0) * LD + r] = reg[j].x;
+        dst[(k4 + 1) * LD + r] = reg[j].y;
+        dst[(k4 + 2) * LD + r] = reg[j].z;
+        dst[(k4 + 3) * LD + r] = reg[j].w;
+      }
+    }
+  };
+  if (t >= 64 && n_chunks > 0)
+    stage(0);
   __syncthreads();
   float score = 0.0f;
   for (int c = 0; c < n_chunks; ++c)
   {
-    const int nxt = (c + 1) * 256 * Q;
-    if (c + 1 < n_chunks)
+    if (t >= 64)
     {
-#pragma unroll
-      for (int j = 0; j < Q; ++j)
-      {
-        const int e = nxt + t + 256 * j;
-        reg[j] = e < total ? rows[e] : z4;
-      }
+      if (c + 1 < n_chunks)
+        stage(c + 1);
     }
-    if (t < G)
+    else if (t < G)
     {
-      const float* cur = reinterpret_cast<const float*>(buf[c & 1]);
-      const int n_rows = min(256, n_s - c * 256);
+      const float4* cur = reinterpret_cast<const float4*>(buf[c & 1] + t * LD);
+      const int n4 = (min(ROWS, n_s - c * ROWS) + 3) >> 2;  // zero padding: x + 0.0f == x
       int r = 0;
-      for (; r + 16 <= n_rows; r += 16)
+      for (; r + 4 <= n4; r += 4)
       {
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          v[j] = cur[(r + j) * G + t];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          score += v[j];
+        const float4 a = cur[r], b = cur[r + 1], d = cur[r + 2], e = cur[r + 3];
+        score += a.x; score += a.y; score += a.z; score += a.w;
+        score += b.x; score += b.y; score += b.z; score += b.w;
+        score += d.x; score += d.y; score += d.z; score += d.w;
+        score += e.x; score += e.y; score += e.z; score += e.w;
       }
-      for (; r < n_rows; ++r)
-        score += cur[r * G + t];
-    }
-    if (c + 1 < n_chunks)
-    {
-#pragma unroll
-      for (int j = 0; j < Q; ++j)
-        buf[(c + 1) & 1][t + 256 * j] = reg[j];
+      for (; r < n4; ++r)
+      {
+        const float4 a = cur[r];
+        score += a.x; score += a.y; score += a.z; score += a.w;
+      }
     }
     __syncthreads();
   }
@@ -582,25 +613,40 @@ __global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __rest
 
 // "strict_order": pf::measure's `sum += p.probability_` (pf.h:255-260) as a float, sequentially, by one lane; the result
 // replaces the fp64 tree sum in packed[0] so that pf_apply_kernel divides by exactly the reference's float.
-__global__ void pf_strict_sum_kernel(const float* __restrict__ w_new, int n, double* __restrict__ packed)
+__global__ __launch_bounds__(256) void pf_strict_sum_kernel(const float* __restrict__ w_new, int n,
+                                                            double* __restrict__ packed)
 {
-  if (blockIdx.x != 0 || threadIdx.x != 0)
+  // one work-group: 256 lanes stage 4096 weights at a time in LDS (coalesced), lane 0 runs the dependent add chain
+  __shared__ float buf[4096];
+  if (blockIdx.x != 0)
     return;
   float sum = 0.0f;
-  int i = 0;
-  for (; i + 16 <= n; i += 16)
+  for (int base = 0; base < n; base += 4096)
   {
-    float v[16];
+    const int m = min(4096, n - base);
+    for (int j = threadIdx.x; j < m; j += 256)
+      buf[j] = w_new[base + j];
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int i = 0;
+      for (; i + 16 <= m; i += 16)
+      {
+        float v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      v[j] = w_new[i + j];
+        for (int j = 0; j < 16; ++j)
+          v[j] = buf[i + j];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      sum += v[j];
+        for (int j = 0; j < 16; ++j)
+          sum += v[j];
+      }
+      for (; i < m; ++i)
+        sum += buf[i];
+    }
+    __syncthreads();
   }
-  for (; i < n; ++i)
-    sum += w_new[i];
-  packed[0] = static_cast<double>(sum);
+  if (threadIdx.x == 0)
+    packed[0] = static_cast<double>(sum);
 }
 
 // n_s == 0: (likelihood 1, quality 0), src/lidar_measurement_model_likelihood.cpp:111-114

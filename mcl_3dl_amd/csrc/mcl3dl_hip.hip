@@ -945,7 +945,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
               LAUNCH_TILED(16, 0);
           }
 #undef LAUNCH_TILED
-          hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream,
+          hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
                              d_lik, d_ratio);
           if (strict_terms && d_lik)
@@ -1329,7 +1329,7 @@ int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, con
   hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank,
                      world, d_packed);
   if (ctx->strict_order && world == 1)
-    hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->wnew.as<float>(),
+    hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->wnew.as<float>(),
                        static_cast<int>(n_p), d_packed);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
