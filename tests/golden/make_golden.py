@@ -120,6 +120,16 @@ def resample_goldens():
     np.savez_compressed(os.path.join(HERE, "resample.npz"), **out)
 
 
+def surface_golden():
+    """Output of tests/cpp/surface_check.cpp built against the reference's own classes (oracle/Makefile, target `ref`):
+    getMaxSearchRange / setGlobalLocalizationStatus / filter / refreshParameters / getSinTotalRef / getFilterLabelMax."""
+    import subprocess
+    exe = os.path.join(HERE, "..", "..", "oracle", "_ref", "surface_ref.bin")
+    subprocess.run([exe, os.path.join(HERE, "surface_ref.dat")], check=True)
+    print("surface", os.path.getsize(os.path.join(HERE, "surface_ref.dat")), "bytes")
+
+
 if __name__ == "__main__":
     main()
     resample_goldens()
+    surface_golden()

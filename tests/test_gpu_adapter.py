@@ -58,3 +58,23 @@ def test_node_call_site_through_drop_in_classes(tmp_path, oracle_kind, dist_weig
     assert tail[3] == lik[0] and tail[4] == quality[0]
     st, _ = o.beam_status(sc.poses[:1, :3], sc.poses[:1, :3] + np.array([[3.0, 0.5, -0.2]], np.float32))
     assert int(tail[5]) == int(st[0])
+
+
+def test_rest_of_the_plugin_surface(tmp_path):
+    """getMaxSearchRange, refreshParameters, setGlobalLocalizationStatus, filter, getSinTotalRef, getFilterLabelMax of the
+    drop-in classes against the reference's own classes: tests/cpp/surface_check.cpp is built against both, the two
+    record streams must be byte-identical."""
+    exe = os.path.join(ROOT, "tests", "cpp", "surface_gpu.bin")
+    assert os.path.exists(exe), "tests/cpp/surface_gpu.bin missing: run __graft_entry__.build() where /root/reference exists"
+    got_path = str(tmp_path / "surface_gpu.out")
+    proc = subprocess.run([exe, got_path], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    got = open(got_path, "rb").read()
+    golden = open(os.path.join(ROOT, "tests", "golden", "surface_ref.dat"), "rb").read()
+    assert len(golden) > 10000
+    assert got == golden
+    live = os.path.join(ROOT, "oracle", "_ref", "surface_ref.bin")
+    if os.path.exists(live):  # the reference's classes, run on this box
+        ref_path = str(tmp_path / "surface_ref.out")
+        subprocess.run([live, ref_path], check=True, timeout=300)
+        assert open(ref_path, "rb").read() == got
