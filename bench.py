@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
     ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
+    ap.add_argument("--map-jitter", type=float, default=0.0,
+                    help="displace every map point uniformly by +-this (m): voxel-filter centroids instead of a lattice")
     ap.add_argument("--lik-small", type=int, default=1)
     ap.add_argument("--overlap-models", type=int, default=1)
     ap.add_argument("--scan-points", type=int, default=0, help="override the number of likelihood scan points")
@@ -130,6 +132,8 @@ def main():
     n_p = args.particles or cfg["n_p"]
     # weak scaling: every rank holds a full-size particle shard drawn with its own seed; map and scan are replicated
     extra_cfg = dict(n_s=args.scan_points) if args.scan_points else {}
+    if args.map_jitter:
+        extra_cfg["map_jitter"] = args.map_jitter
     if args.beam_points:
         extra_cfg["n_b"] = args.beam_points  # C3 stress case N_b = 16 384
     sc = make_config(args.workload, n_p=n_p, seed=12345, **extra_cfg)

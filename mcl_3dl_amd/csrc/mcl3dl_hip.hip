@@ -115,6 +115,27 @@ struct mcl3dl_hip_ctx
   bool rs_planned = false;
   DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out;
 
+  // Pinned staging for the host-buffer entry points: small copies go through page-locked memory so that
+  // hipMemcpyAsync really is asynchronous (a pageable copy costs a driver-side staging round trip each); results are
+  // handed to the caller's arrays when the stream is synchronised (sync_stream).
+  struct StageChunk
+  {
+    char* p;
+    size_t cap;
+  };
+  struct StagedResult
+  {
+    void* user;
+    const void* staged;
+    size_t bytes;
+  };
+  std::vector<StageChunk> stage;
+  size_t stage_cur = 0, stage_off = 0;
+  std::vector<StagedResult> stage_out;
+  // host-side scan staging (kept in the context so that it outlives the asynchronous copies)
+  std::vector<float4> h_scan_lik, h_scan_beam, h_origins;
+  std::vector<uint32_t> h_scan_perm;
+
   // timing
   bool timing = false;
   std::vector<EventPair> pending;
@@ -130,6 +151,7 @@ struct mcl3dl_hip_ctx
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     err = buf;
+    stage_out.clear();  // results of a failed call are not delivered (their destinations may be gone)
     return code;
   }
 };
@@ -178,19 +200,83 @@ int ensure(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t bytes)
   return 0;
 }
 
+constexpr size_t STAGE_MAX_COPY = 4u << 20;  // larger copies go straight from / to the caller's (pageable) memory
+
+// bump allocation in page-locked chunks; everything is released for reuse by sync_stream. nullptr = allocation failed
+// (the caller then falls back to a direct copy).
+void* stage_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
+{
+  bytes = (bytes + 255) & ~static_cast<size_t>(255);
+  while (ctx->stage_cur < ctx->stage.size())
+  {
+    mcl3dl_hip_ctx::StageChunk& ch = ctx->stage[ctx->stage_cur];
+    if (ctx->stage_off + bytes <= ch.cap)
+    {
+      void* p = ch.p + ctx->stage_off;
+      ctx->stage_off += bytes;
+      return p;
+    }
+    ++ctx->stage_cur;
+    ctx->stage_off = 0;
+  }
+  const size_t last = ctx->stage.empty() ? (512u << 10) : ctx->stage.back().cap;
+  const size_t cap = std::max(bytes, 2 * last);
+  void* p = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  ctx->stage.push_back({ static_cast<char*>(p), cap });
+  ctx->stage_cur = ctx->stage.size() - 1;
+  ctx->stage_off = bytes;
+  return p;
+}
+
 int h2d(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
   if (bytes == 0)
     return 0;
+  if (bytes <= STAGE_MAX_COPY)
+  {
+    if (void* p = stage_alloc(ctx, bytes))
+    {
+      memcpy(p, src, bytes);
+      HIP_TRY(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return 0;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
 
+// The data is in `dst` only after sync_stream().
 int d2h(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
   if (bytes == 0)
     return 0;
+  if (bytes <= STAGE_MAX_COPY)
+  {
+    if (void* p = stage_alloc(ctx, bytes))
+    {
+      HIP_TRY(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->stage_out.push_back({ dst, p, bytes });
+      return 0;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+// hipStreamSynchronize + hand the staged results to the caller's arrays + recycle the staging memory.
+int sync_stream(mcl3dl_hip_ctx* ctx)
+{
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (const mcl3dl_hip_ctx::StagedResult& r : ctx->stage_out)
+    memcpy(r.user, r.staged, r.bytes);
+  ctx->stage_out.clear();
+  ctx->stage_cur = 0;
+  ctx->stage_off = 0;
   return 0;
 }
 
@@ -234,7 +320,7 @@ int timing_collect(mcl3dl_hip_ctx* ctx)
 {
   if (ctx->pending.empty())
     return 0;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
   for (const EventPair& ep : ctx->pending)
   {
@@ -313,7 +399,7 @@ int build_lik_grid(mcl3dl_hip_ctx* ctx)
   TRY(ensure(ctx, ctx->lik_cells, sizeof(uint32_t) * (ncell + 1)));
   TRY(h2d(ctx, ctx->lik_pts.p, pts.data(), sizeof(float4) * n));
   TRY(h2d(ctx, ctx->lik_cells.p, start.data(), sizeof(uint32_t) * (ncell + 1)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
   ctx->lg.pts = ctx->lik_pts.as<float4>();
   ctx->lg.ox = o[0];
@@ -396,7 +482,7 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
   TRY(h2d(ctx, ctx->dda_start.p, start.data(), sizeof(uint32_t) * (total + 1)));
   TRY(h2d(ctx, ctx->dda_pts.p, pts.data(), sizeof(float4) * n));
   TRY(h2d(ctx, ctx->dda_index.p, index.data(), sizeof(uint32_t) * n));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   DdaGrid& g = ctx->dg;
   g.bricks = ctx->dda_bits.as<unsigned long long>();
   g.bnx = bdim[0];
@@ -443,7 +529,7 @@ int device_exclusive_scan(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n)  // 
     if (rc == 0)
       hipLaunchKernelGGL(scan_add_offsets, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream,
                          data, sums, n);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(sync_stream(ctx));
     HIP_TRY(hipFree(sums));
     if (rc != 0)
       return rc;
@@ -540,7 +626,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_scan.p), n_table + 1));
   uint32_t n_bricks = 0;
   TRY(d2h(ctx, &n_bricks, static_cast<uint32_t*>(d_scan.p) + n_table, sizeof(uint32_t)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   if (n_bricks == 0 || n_bricks > (1u << 22))
     return ctx->fail(-4, "candidate index: %u bricks", n_bricks);
   TRY(ensure(ctx, ctx->cand_table, sizeof(int) * n_table));
@@ -576,7 +662,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
                      n_vox, static_cast<unsigned long long*>(d_total.p));
   TRY(d2h(ctx, &total, d_total.p, sizeof(total)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   if (total >= 0xfffffff0ULL)
     return ctx->fail(-4, "candidate index: %llu preliminary candidates exceed 32-bit offsets", total);
   HIP_TRY(hipMemcpyAsync(d_pstart.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice, ctx->stream));
@@ -595,7 +681,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
                      n_vox, static_cast<unsigned long long*>(d_total.p));
   TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   if (ctx->lik_index == 2)
   {
     // fat records: overflow slots per voxel -> exclusive scan -> write
@@ -607,7 +693,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
     uint32_t n_ovf = 0;
     TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(sync_stream(ctx));
     TRY(ensure(ctx, ctx->cand_rec, 64ull * static_cast<size_t>(n_vox)));
     TRY(ensure(ctx, ctx->cand_ovf, 64ull * (n_ovf ? n_ovf : 1)));
     HIP_TRY(hipMemsetAsync(ctx->cand_ovf.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
@@ -617,7 +703,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
                        ctx->cand_rec.as<float>(), ctx->cand_ovf.as<float>(), n_vox);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(sync_stream(ctx));
     float ms2 = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms2, ev0, ev1));
     (void)hipEventDestroy(ev0);
@@ -657,7 +743,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
                      ctx->cand_start.as<uint32_t>(), ctx->cand_pts.as<float4>(), n_vox);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   (void)hipEventDestroy(ev0);
@@ -787,7 +873,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           table[k] = table[k - 1] * ctx->beam_likelihood;
         TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
         TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        TRY(sync_stream(ctx));
         ctx->pow_table_dirty = false;
       }
       const BeamParams bp = beam_params(ctx);
@@ -1004,7 +1090,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       TRY(d2h(ctx, tested.data(), ctx->tested.p, sizeof(double) * n_p));
     if (ctx->n_b)
       TRY(d2h(ctx, &rs, ctx->ray_stats.p, sizeof(RayStats)));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(sync_stream(ctx));
     stats6[0] = std::accumulate(tested.begin(), tested.end(), 0.0);
     stats6[1] = static_cast<double>(n_p) * static_cast<double>(ctx->n_s);
     stats6[2] = static_cast<double>(rs.steps);
@@ -1087,6 +1173,8 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
   }
   for (hipEvent_t e : ctx->free_events)
     (void)hipEventDestroy(e);
+  for (const mcl3dl_hip_ctx::StageChunk& ch : ctx->stage)
+    (void)hipHostFree(ch.p);
   if (ctx->ev_fork)
     (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join)
@@ -1107,7 +1195,7 @@ int mcl3dl_hip_set_stream(mcl3dl_hip_ctx* ctx, void* hip_stream)
 {
   if (!ctx)
     return -1;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return 0;
 }
@@ -1121,7 +1209,7 @@ int mcl3dl_hip_synchronize(mcl3dl_hip_ctx* ctx)
 {
   if (!ctx)
     return -1;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 
@@ -1191,8 +1279,11 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
   return 0;
 }
 
-int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
-                           const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o)
+// sync_at_end = false: the caller synchronises the stream itself before it returns (the staging vectors live in the
+// context, so nothing here dies earlier).
+static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                            const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                            bool sync_at_end)
 {
   if (!ctx)
     return -1;
@@ -1202,7 +1293,8 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
     return ctx->fail(-3, "scan too large");
   HIP_TRY(hipSetDevice(ctx->device));
   // likelihood scan: spatial (Morton) order. The score is a sum, so the order only changes which lanes work together.
-  std::vector<float4> lik(n_s);
+  std::vector<float4>& lik = ctx->h_scan_lik;
+  lik.resize(n_s);
   if (n_s)
   {
     float mn[3] = { scan_lik_xyz[0], scan_lik_xyz[1], scan_lik_xyz[2] };
@@ -1210,7 +1302,9 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
       for (int a = 0; a < 3; ++a)
         mn[a] = std::min(mn[a], scan_lik_xyz[3 * i + a]);
     // 30-bit Morton key (10 bits per axis, 0.25 m cells) + 3-pass LSD radix sort: ~0.1 ms for 16 k points on one core
-    std::vector<uint32_t> key(n_s), idx(n_s), key2(n_s), idx2(n_s);
+    std::vector<uint32_t>& idx = ctx->h_scan_perm;
+    std::vector<uint32_t> key(n_s), key2(n_s), idx2(n_s);
+    idx.resize(n_s);
     for (size_t i = 0; i < n_s; ++i)
     {
       uint32_t c[3];
@@ -1246,12 +1340,12 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
     }
     TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
     TRY(h2d(ctx, ctx->scan_perm.p, idx.data(), sizeof(uint32_t) * n_s));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   // beam scan: ordered by range from its scan origin. A ray walks ~range/dda_grid voxels and (its end point being a
   // measured surface) ends near its last voxel, so the 64 rays of a wavefront finish together instead of idling behind the
   // longest one. The beam score is a count of penalised rays, so the order is free.
-  std::vector<float4> beam(n_b);
+  std::vector<float4>& beam = ctx->h_scan_beam;
+  beam.resize(n_b);
   if (n_b)
   {
     std::vector<std::pair<float, uint32_t>> keys(n_b);
@@ -1272,7 +1366,8 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
       beam[k] = make_float4(scan_beam_xyz[3 * i], scan_beam_xyz[3 * i + 1], scan_beam_xyz[3 * i + 2], bits_to_float(og));
     }
   }
-  std::vector<float4> org(n_o);
+  std::vector<float4>& org = ctx->h_origins;
+  org.resize(n_o);
   for (size_t i = 0; i < n_o; ++i)
     org[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
   TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
@@ -1281,7 +1376,8 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
   TRY(h2d(ctx, ctx->scan_lik.p, lik.data(), sizeof(float4) * n_s));
   TRY(h2d(ctx, ctx->scan_beam.p, beam.data(), sizeof(float4) * n_b));
   TRY(h2d(ctx, ctx->origins.p, org.data(), sizeof(float4) * n_o));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staging vectors die at return
+  if (sync_at_end)
+    TRY(sync_stream(ctx));
   if (n_b != ctx->n_b)
     ctx->pow_table_dirty = true;
   ctx->n_s = n_s;
@@ -1289,6 +1385,12 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
   ctx->n_o = n_o;
   ctx->has_scan = true;
   return 0;
+}
+
+int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                           const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o)
+{
+  return upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, true);
 }
 
 int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_match_ratio,
@@ -1367,7 +1469,7 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p,
   if (!pose)
     return ctx->fail(-3, "null pose array");
   HIP_TRY(hipSetDevice(ctx->device));
-  TRY(mcl3dl_hip_upload_scan(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o));
+  TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
   TRY(ensure(ctx, ctx->lik, sizeof(float) * n_p));
   TRY(ensure(ctx, ctx->ratio, sizeof(float) * n_p));
@@ -1383,7 +1485,7 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p,
     TRY(d2h(ctx, out_match_ratio, ctx->ratio.p, sizeof(float) * n_p));
   if (out_beam)
     TRY(d2h(ctx, out_beam, ctx->beam.p, sizeof(float) * n_p));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 
@@ -1422,7 +1524,7 @@ int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float*
   float st[4];
   TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
   TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   if (entropy)
     *entropy = st[0];
   if (match_ratio_min)
@@ -1448,7 +1550,7 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
     return ctx->fail(-3, "null pose / weight array");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t fb = sizeof(float) * n_p;
-  TRY(mcl3dl_hip_upload_scan(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o));
+  TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
   TRY(ensure(ctx, ctx->weightb, fb));
   TRY(ensure(ctx, ctx->lik, fb));
@@ -1477,7 +1579,7 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
     TRY(d2h(ctx, out_match_ratio, ctx->ratio.p, fb));
   if (out_beam)
     TRY(d2h(ctx, out_beam, ctx->beam.p, fb));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   if (entropy)
     *entropy = st[0];
   if (match_ratio_min)
@@ -1516,7 +1618,7 @@ int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz, const fl
   TRY(d2h(ctx, status, ctx->ray_status.p, sizeof(int) * n));
   if (hit_index)
     TRY(d2h(ctx, hit_index, ctx->ray_hit.p, sizeof(int) * n));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 
@@ -1537,12 +1639,12 @@ int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* 
   HIP_TRY(hipGetLastError());
   int out3[3] = { 0, 0, -1 };
   TRY(d2h(ctx, out3, ctx->ray_status.p, sizeof(out3)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   const int n_copy = std::min(out3[0], max_out);
   if (n_copy > 0)
   {
     TRY(d2h(ctx, out_xyz, ctx->ray_begin.p, sizeof(float) * 3 * static_cast<size_t>(n_copy)));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TRY(sync_stream(ctx));
   }
   if (n_visited)
     *n_visited = out3[0];
@@ -1582,7 +1684,7 @@ int mcl3dl_hip_radius_search(mcl3dl_hip_ctx* ctx, const float* query_xyz, size_t
   TRY(d2h(ctx, out_index, ctx->ray_hit.p, sizeof(int) * n));
   if (out_sqdist)
     TRY(d2h(ctx, out_sqdist, ctx->ray_end.p, sizeof(float) * n));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 
@@ -1637,7 +1739,7 @@ int mcl3dl_hip_expectation_device(mcl3dl_hip_ctx* ctx, const float* d_pose, cons
   int arg[2];
   TRY(d2h(ctx, m, ctx->mom_out.p, sizeof(m)));
   TRY(d2h(ctx, arg, ctx->mom_idx.p, sizeof(arg)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   // ParticleWeightedMeanQuat::getMean, state_6dof.h:345-350
   const float p_sum = static_cast<float>(m[0]);
   const Quat q = quat_from_front_up(Vec3f{ static_cast<float>(m[4]), static_cast<float>(m[5]), static_cast<float>(m[6]) },
@@ -1681,7 +1783,7 @@ int mcl3dl_hip_covariance_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const
   HIP_TRY(hipGetLastError());
   double s[COV_N];
   TRY(d2h(ctx, s, ctx->mom_out.p, sizeof(s)));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   const float p_sum = static_cast<float>(s[21]);
   int idx = 0;
   for (int j = 0; j < 6; ++j)
@@ -1779,7 +1881,7 @@ int mcl3dl_hip_resample_begin(mcl3dl_hip_ctx* ctx, const float* weight, size_t n
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(ensure(ctx, ctx->rs_d_keys, sizeof(float) * n));
   TRY(h2d(ctx, ctx->rs_d_keys.p, ctx->rs_keys.data(), sizeof(float) * n));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 
@@ -1813,7 +1915,7 @@ int mcl3dl_hip_resample_plan(mcl3dl_hip_ctx* ctx, int mode, float initial_p, uin
   HIP_TRY(hipGetLastError());
   std::vector<uint32_t> it(n_out);
   TRY(d2h(ctx, it.data(), ctx->rs_d_it.p, sizeof(uint32_t) * n_out));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   // the it / it_prev walk of pf.h:204-223 / 414-434 (pscan is non-decreasing, so the search that starts at the previous
   // `it` lands where the global one does)
   ctx->rs_source.resize(n_out);
@@ -1849,7 +1951,7 @@ int mcl3dl_hip_resample_plan(mcl3dl_hip_ctx* ctx, int mode, float initial_p, uin
   TRY(ensure(ctx, ctx->rs_d_slot, sizeof(uint32_t) * n_out));
   TRY(h2d(ctx, ctx->rs_d_source.p, ctx->rs_source.data(), sizeof(uint32_t) * n_out));
   TRY(h2d(ctx, ctx->rs_d_slot.p, ctx->rs_slot.data(), sizeof(uint32_t) * n_out));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 
@@ -1863,7 +1965,7 @@ int mcl3dl_hip_resample_begin_device(mcl3dl_hip_ctx* ctx, const float* d_weight,
   // the prefix sums are a float recurrence in particle order (pf.h:193-197): 4 bytes per particle come to the host
   std::vector<float> w(n);
   TRY(d2h(ctx, w.data(), d_weight, sizeof(float) * n));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return mcl3dl_hip_resample_begin(ctx, w.data(), n, n_out, out_pstep);
 }
 
@@ -1891,7 +1993,7 @@ int mcl3dl_hip_resample_apply_slice_device(mcl3dl_hip_ctx* ctx, const float* d_s
                      ctx->rs_d_source.as<uint32_t>() + out_begin, ctx->rs_d_slot.as<uint32_t>() + out_begin,
                      ctx->rs_d_noise.as<float>(), no, d_state13_out);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));  // noise13 is the caller's host buffer
+  TRY(sync_stream(ctx));  // noise13 is the caller's host buffer
   return 0;
 }
 
@@ -1918,7 +2020,7 @@ int mcl3dl_hip_resample_apply(mcl3dl_hip_ctx* ctx, const float* state13_in, cons
   TRY(h2d(ctx, ctx->rs_d_in.p, state13_in, sizeof(float) * 13 * ctx->rs_n));
   TRY(mcl3dl_hip_resample_apply_device(ctx, ctx->rs_d_in.as<float>(), noise13, n_noise, ctx->rs_d_out.as<float>()));
   TRY(d2h(ctx, state13_out, ctx->rs_d_out.p, sizeof(float) * 13 * ctx->rs_n_out));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  TRY(sync_stream(ctx));
   return 0;
 }
 

@@ -106,9 +106,14 @@ def _visible(map_xyz, pos, rot_m, clip_near, clip_far, z_min, z_max, need, rng):
 
 def make_scene(n=91, n_p=64, n_s=1000, n_b=0, seed=12345, spacing=0.1, label_wall=None,
                sigma_xyz=(0.2, 0.2, 0.05), sigma_rpy=(0.02, 0.02, 0.1), scan_noise=0.01,
-               lik_clip=(0.5, 10.0, -2.0, 2.0), beam_clip=(0.5, 4.0, -2.0, 2.0), global_lattice=False):
+               lik_clip=(0.5, 10.0, -2.0, 2.0), beam_clip=(0.5, 4.0, -2.0, 2.0), global_lattice=False, map_jitter=0.0):
     rng = np.random.default_rng(seed)
     map_xyz = cube_map(n, spacing)
+    if map_jitter:
+        # a voxel-filtered real map: one CENTROID per occupied voxel, i.e. lattice points displaced inside their voxel
+        # (the BASELINE maps are exact lattices; this is the stress case for the candidate-voxel index)
+        jit = np.random.default_rng(seed + 777).uniform(-map_jitter, map_jitter, map_xyz.shape)
+        map_xyz = (map_xyz + jit).astype(np.float32)
     map_label = np.zeros(len(map_xyz), np.uint32)
     if label_wall is not None:
         # give one wall (x = -half) a semantic label, after test/src/test_beam_label.cpp:69-85
