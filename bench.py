@@ -47,6 +47,11 @@ def parse():
                     help="displace every map point uniformly by +-this (m): voxel-filter centroids instead of a lattice")
     ap.add_argument("--lik-small", type=int, default=1)
     ap.add_argument("--overlap-models", type=int, default=1)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="wall time of untimed updates before the W warm-up steps (GPU clock ramp), 0 = none")
+    ap.add_argument("--timing-mask", type=int, default=1,
+                    help="kernel groups timed with hipEvents INSIDE the timed region (bit 0 likelihood = the roofline "
+                         "kernel, 1 beam, 2 pf); the others are timed in a second pass of the same steps")
     ap.add_argument("--scan-points", type=int, default=0, help="override the number of likelihood scan points")
     ap.add_argument("--lik-group", type=int, default=16)
     ap.add_argument("--strict-order", type=int, default=0,
@@ -103,6 +108,15 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
     return out, lik, q
 
 
+def _flush_c_stdio():
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def main():
     args = parse()
     import torch
@@ -127,6 +141,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        # RCCL writes a version banner through C stdio when its communicator comes up; push it out NOW so that rank 0's
+        # JSON line is the last thing on stdout
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize(dev)
+        _flush_c_stdio()
 
     cfg = CONFIGS[args.workload]
     n_p = args.particles or cfg["n_p"]
@@ -198,8 +218,25 @@ def main():
         # B_beam per ray = 16 + S*1 + O*8 + T*16
         bytes_beam_launch = ws["rays"] * 16.0 + ws["dda_steps"] + ws["dda_occupied"] * 8.0 + ws["dda_tested"] * 16.0
 
+    # Clock ramp: a GPU coming out of idle needs tens of milliseconds of load before it holds its sustained clocks, far
+    # more than W steps of a sub-millisecond update. Run the update for --prewarm-ms of wall time first (set-up, like the
+    # map upload above; not part of W or K), then the W warm-up steps the contract asks for.
+    if args.prewarm_ms > 0:
+        torch.cuda.synchronize(dev)
+        t_pre = time.perf_counter()
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize(dev)
+        per_step_ms = (time.perf_counter() - t_pre) * 1e3 / 8
+        n_pre = torch.tensor([min(int(args.prewarm_ms / max(per_step_ms, 1e-3)), 100000)], dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(n_pre, op=dist.ReduceOp.MAX)  # every rank must run the same number of collectives
+        for _ in range(int(n_pre.item())):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
+    eng.set_option("timing_mask", args.timing_mask)
     eng.set_kernel_timing(True)
     eng.reset_kernel_time()
     if use_dist:
@@ -213,22 +250,26 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t1
     lik_ms, lik_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
+    # Second pass of the same K steps, outside `elapsed`, every kernel group timed and the two models one after the other:
+    # the beam / pf durations (each timed group costs two event records per launch, so only the roofline kernel is
+    # timed inside the timed region), and the likelihood duration too when it ran concurrently with the beam kernels
+    # above (overlapping event intervals say nothing about either kernel).
+    overlapped = bool(n_b and n_s and args.overlap_models)
+    eng.set_option("timing_mask", 7)
+    eng.set_option("overlap_models", 0)
+    eng.reset_kernel_time()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    lik2_ms, lik2_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
     beam_ms, beam_n = eng.kernel_time(capi.KERNEL_BEAM)
     pf_ms, pf_n = eng.kernel_time(capi.KERNEL_PF)
-    kernel_timing_pass = "timed region"
-    if n_b and n_s and args.overlap_models:
-        # the two models' kernels ran concurrently above, so their event durations overlap each other: take the
-        # per-kernel durations from a second pass of the same K steps with the overlap off (not part of `elapsed`)
-        eng.set_option("overlap_models", 0)
-        eng.reset_kernel_time()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        lik_ms, lik_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
-        beam_ms, beam_n = eng.kernel_time(capi.KERNEL_BEAM)
-        pf_ms, pf_n = eng.kernel_time(capi.KERNEL_PF)
-        eng.set_option("overlap_models", 1)
-        kernel_timing_pass = "separate pass of the same steps with overlap_models=0"
+    eng.set_option("overlap_models", args.overlap_models)
+    if overlapped or not (args.timing_mask & 1):
+        lik_ms, lik_n = lik2_ms, lik2_n
+        kernel_timing_pass = "second pass of the same steps (overlap_models=0, all kernel groups timed)"
+    else:
+        kernel_timing_pass = "likelihood: hipEvents inside the timed region; beam, pf: second pass of the same steps"
     eng.set_kernel_timing(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -349,6 +390,24 @@ def main():
             out["host_api"] = {"ms_per_update": host_ms, "evals_per_s": n_p * n_s / (host_ms * 1e-3),
                                "note": "mcl3dl_hip_measure_update with host buffers (PCIe + host-side scan ordering included)"}
             eng.set_stream(stream.cuda_stream)
+            # the fused device-resident call (measure + pf::measure in one C call) replaying its captured hipGraph, next
+            # to the same call enqueuing kernel by kernel: what launch overhead is worth at this size. Not `value`.
+            fused = {}
+            for use_graph in (0, 1):
+                eng.set_option("use_graph", use_graph)
+                for _ in range(3):
+                    d_w.copy_(d_w0)
+                    eng.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam if n_b else None)
+                torch.cuda.synchronize(dev)
+                t5 = time.perf_counter()
+                for _ in range(args.steps):
+                    d_w.copy_(d_w0)
+                    eng.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam if n_b else None)
+                torch.cuda.synchronize(dev)
+                fused["graph" if use_graph else "eager"] = (time.perf_counter() - t5) / args.steps * 1e3
+            out["fused_update"] = {"ms_per_update_graph": fused["graph"], "ms_per_update_eager": fused["eager"],
+                                   "graph": eng.graph_stats(),
+                                   "what": "mcl3dl_hip_update_device, device-resident, hipGraph replay vs plain launches"}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_lik, cpu_q = cpu_baseline(sc, dist_weight, args.cpu_particles, n_b)
             out["cpu_baseline"] = cb
@@ -360,9 +419,13 @@ def main():
             out["result_check"]["match_ratio_equal"] = bool(np.array_equal(gq, cpu_q))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(line, flush=True)  # the one JSON line, last on stdout
 
 
 if __name__ == "__main__":

@@ -206,6 +206,22 @@ int mcl3dl_hip_resample_begin_device(mcl3dl_hip_ctx* ctx, const float* d_weight 
 int mcl3dl_hip_resample_apply_slice_device(mcl3dl_hip_ctx* ctx, const float* d_state13_in, const float* noise13 /*host*/,
                                            size_t n_noise, size_t out_begin, size_t out_count, float* d_state13_out);
 
+/* One device-resident update in one call (single GPU): measure_device + pf_partial_device + pf_apply_device, i.e. the
+ * statement pf_->measure(measure_func) of src/mcl_3dl.cpp:398-426 on device arrays. d_extra, d_lik, d_match_ratio,
+ * d_beam may be NULL (no odometry factor / results kept internally); d_stats4 as in pf_apply_device.
+ * Small updates are launch-bound, so the enqueued sequence is captured into a hipGraph the second time the same
+ * With option "use_graph" = 1 the enqueued sequence is captured into a hipGraph the second time the same argument set
+ * arrives and replayed from then on. Anything that changes what would be enqueued (parameters, options, map, stream,
+ * scan sizes, a reallocated buffer, other pointers) starts over; a new scan of the same size does not. Results are
+ * identical to the three separate calls. The option is OFF by default: on ROCm 7.2 / MI355X replaying the 6-10 node
+ * graph measured slower than launching the kernels directly (C1: 26.5 vs 23.2 us per update, C3: 0.517 vs 0.482 ms,
+ * DESIGN.md section 6). */
+int mcl3dl_hip_update_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight_inout,
+                             const float* d_extra, float* d_lik, float* d_match_ratio, float* d_beam, float* d_stats4);
+int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* replays);
+/* Why the last capture attempt fell back to kernel-by-kernel launches ("" if none did). */
+const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx);
+
 /* ---- measurement support ------------------------------------------------------------------------------ */
 /* Per-kernel hipEvent timing on the launch stream (off by default). */
 int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable);
@@ -226,6 +242,8 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
  *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points; 0 = one
  *                       work-group per particle always (only the fp64 summation order differs)
+ *   "use_graph"         1 = mcl3dl_hip_update_device replays a captured hipGraph; 0 (default) = enqueue kernel by kernel
+ *   "timing_mask"       bit k set (default: all) = kernel group k is timed while kernel timing is on
  *   "overlap_models"    1 (default) = the beam kernels run on a second stream concurrently with the likelihood kernels
  *                       (forked from / joined into the context's stream with events); 0 = one after the other
  *   "lik_small"         1 (default) = scans of <= 32 points with >= 256 particles (global localisation) share each

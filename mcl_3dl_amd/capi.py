@@ -42,6 +42,9 @@ SIGNATURES = {
     "mcl3dl_hip_resample_plan": (_i, [_p, _i, _f, _p, _p, C.POINTER(_sz)]),
     "mcl3dl_hip_resample_apply": (_i, [_p, _p, _p, _sz, _p]),
     "mcl3dl_hip_resample_apply_device": (_i, [_p, _p, _p, _sz, _p]),
+    "mcl3dl_hip_update_device": (_i, [_p, _p, _sz, _p, _p, _p, _p, _p, _p]),
+    "mcl3dl_hip_graph_note": (C.c_char_p, [_p]),
+    "mcl3dl_hip_graph_stats": (_i, [_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mcl3dl_hip_resample_begin_device": (_i, [_p, _p, _sz, _sz, C.POINTER(_f)]),
     "mcl3dl_hip_resample_apply_slice_device": (_i, [_p, _p, _p, _sz, _sz, _sz, _p]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
@@ -309,6 +312,17 @@ class Engine:
     def measure_device(self, d_pose, n_p, d_lik, d_ratio, d_beam):
         self._check(self.lib.mcl3dl_hip_measure_device(self.h, _ptr(d_pose), n_p, _ptr(d_lik), _ptr(d_ratio),
                                                        _ptr(d_beam)))
+
+    def update_device(self, d_pose, n_p, d_weight, d_stats4, d_extra=None, d_lik=None, d_ratio=None, d_beam=None):
+        """measure_device + pf_partial_device + pf_apply_device in one call (hipGraph replay from the third call on)."""
+        self._check(self.lib.mcl3dl_hip_update_device(self.h, _ptr(d_pose), n_p, _ptr(d_weight), _ptr(d_extra),
+                                                      _ptr(d_lik), _ptr(d_ratio), _ptr(d_beam), _ptr(d_stats4)))
+
+    def graph_stats(self):
+        cap, rep = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.mcl3dl_hip_graph_stats(self.h, C.byref(cap), C.byref(rep)))
+        return dict(captures=int(cap.value), replays=int(rep.value),
+                    note=self.lib.mcl3dl_hip_graph_note(self.h).decode())
 
     def pf_partial_device(self, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_packed, rank=0, world=1):
         """d_packed: 2 + 2*world float64 on the device, ready for all_reduce(SUM) (see mcl_3dl_amd/distributed.py)."""

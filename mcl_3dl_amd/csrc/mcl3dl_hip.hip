@@ -115,6 +115,29 @@ struct mcl3dl_hip_ctx
   bool rs_planned = false;
   DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out;
 
+  // mcl3dl_hip_update_device: the launch sequence of one device-resident update, captured into a hipGraph the second
+  // time the same arguments arrive and replayed afterwards (small updates are launch-bound: 8-10 launches of a few
+  // microseconds each). `generation` counts everything that can change what gets enqueued — parameters, options, map,
+  // stream, scan sizes, any device buffer that had to be reallocated.
+  uint64_t generation = 0;
+  int use_graph = 0;
+  struct UpdateKey
+  {
+    const void* p[8];
+    size_t n_p;
+    uint64_t generation;
+    bool operator==(const UpdateKey& o) const
+    {
+      return memcmp(p, o.p, sizeof(p)) == 0 && n_p == o.n_p && generation == o.generation;
+    }
+  };
+  UpdateKey graph_key{}, seen_key{}, failed_key{};
+  bool have_seen = false, have_failed = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  uint64_t graph_replays = 0, graph_captures = 0;
+  std::string graph_note;  // why the last capture attempt fell back to plain launches (diagnostics)
+
   // Pinned staging for the host-buffer entry points: small copies go through page-locked memory so that
   // hipMemcpyAsync really is asynchronous (a pageable copy costs a driver-side staging round trip each); results are
   // handed to the caller's arrays when the stream is synchronised (sync_stream).
@@ -138,6 +161,7 @@ struct mcl3dl_hip_ctx
 
   // timing
   bool timing = false;
+  unsigned timing_mask = 0xffffffffu;  // bit k = time kernel group k (MCL3DL_KERNEL_*); each timed group costs two event records
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
   double kernel_ms[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
@@ -197,6 +221,7 @@ int ensure(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t bytes)
   const size_t cap = bytes + bytes / 4;
   HIP_TRY(hipMalloc(&b.p, cap));
   b.cap = cap;
+  ++ctx->generation;  // a captured update graph holds the old address
   return 0;
 }
 
@@ -285,7 +310,8 @@ int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep, hipStream_t on 
 {
   if (!on)
     on = ctx->stream;
-  if (!ctx->timing)
+  ep->start = nullptr;
+  if (!ctx->timing || !(ctx->timing_mask & (1u << kernel)))
     return 0;
   hipEvent_t ev[2];
   for (int i = 0; i < 2; ++i)
@@ -309,7 +335,7 @@ int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep, hipStream_t on 
 
 int timing_end(mcl3dl_hip_ctx* ctx, const EventPair& ep, hipStream_t on = nullptr)
 {
-  if (!ctx->timing)
+  if (!ctx->timing || !ep.start)
     return 0;
   HIP_TRY(hipEventRecord(ep.stop, on ? on : ctx->stream));
   ctx->pending.push_back(ep);
@@ -1173,6 +1199,10 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
   }
   for (hipEvent_t e : ctx->free_events)
     (void)hipEventDestroy(e);
+  if (ctx->graph_exec)
+    (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph)
+    (void)hipGraphDestroy(ctx->graph);
   for (const mcl3dl_hip_ctx::StageChunk& ch : ctx->stage)
     (void)hipHostFree(ch.p);
   if (ctx->ev_fork)
@@ -1195,6 +1225,7 @@ int mcl3dl_hip_set_stream(mcl3dl_hip_ctx* ctx, void* hip_stream)
 {
   if (!ctx)
     return -1;
+  ++ctx->generation;
   TRY(sync_stream(ctx));
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return 0;
@@ -1218,6 +1249,7 @@ int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* la
 {
   if (!ctx)
     return -1;
+  ++ctx->generation;
   if (!xyz || n_m == 0)
     return ctx->fail(-3, "empty map");
   if (n_m > 0xfffffff0u)
@@ -1244,6 +1276,7 @@ int mcl3dl_hip_set_likelihood_params(mcl3dl_hip_ctx* ctx, float match_dist_min, 
 {
   if (!ctx)
     return -1;
+  ++ctx->generation;
   if (!(match_dist_min > 0.f))
     return ctx->fail(-3, "match_dist_min must be > 0");
   if (match_dist_min != ctx->match_dist_min)
@@ -1261,6 +1294,7 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
 {
   if (!ctx)
     return -1;
+  ++ctx->generation;
   if (!(dda_grid_size > 0.f))
     return ctx->fail(-3, "dda_grid_size must be > 0");
   ctx->map_grid[0] = map_grid_x;
@@ -1380,6 +1414,8 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
     TRY(sync_stream(ctx));
   if (n_b != ctx->n_b)
     ctx->pow_table_dirty = true;
+  if (n_s != ctx->n_s || n_b != ctx->n_b || n_o != ctx->n_o || !ctx->has_scan)
+    ++ctx->generation;
   ctx->n_s = n_s;
   ctx->n_b = n_b;
   ctx->n_o = n_o;
@@ -1458,6 +1494,143 @@ int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_
 }
 
 // ---- host entry points -------------------------------------------------------------------------------------
+namespace
+{
+int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
+                   float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
+{
+  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
+  TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4));
+  return 0;
+}
+
+void drop_graph(mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->graph_exec)
+    (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph)
+    (void)hipGraphDestroy(ctx->graph);
+  ctx->graph_exec = nullptr;
+  ctx->graph = nullptr;
+}
+}  // namespace
+
+int mcl3dl_hip_update_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight_inout,
+                             const float* d_extra, float* d_lik, float* d_match_ratio, float* d_beam, float* d_stats4)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad particle count");
+  if (!d_pose || !d_weight_inout || !d_stats4)
+    return ctx->fail(-3, "null pose / weight / stats array");
+  if (!ctx->has_scan)
+    return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t fb = sizeof(float) * n_p;
+  if (!d_lik)
+  {
+    TRY(ensure(ctx, ctx->lik, fb));
+    d_lik = ctx->lik.as<float>();
+  }
+  if (!d_match_ratio)
+  {
+    TRY(ensure(ctx, ctx->ratio, fb));
+    d_match_ratio = ctx->ratio.as<float>();
+  }
+  if (!d_beam)
+  {
+    TRY(ensure(ctx, ctx->beam, fb));
+    d_beam = ctx->beam.as<float>();
+  }
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  mcl3dl_hip_ctx::UpdateKey key{};
+  key.p[0] = d_pose;
+  key.p[1] = d_weight_inout;
+  key.p[2] = d_extra;
+  key.p[3] = d_lik;
+  key.p[4] = d_match_ratio;
+  key.p[5] = d_beam;
+  key.p[6] = d_stats4;
+  key.p[7] = ctx->stream;
+  key.n_p = n_p;
+  key.generation = ctx->generation;
+  const bool graphs = ctx->use_graph && !ctx->timing;
+  if (graphs && ctx->graph_exec && ctx->graph_key == key)
+  {
+    HIP_TRY(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    ++ctx->graph_replays;
+    return 0;
+  }
+  // First sighting of these arguments: run eagerly (this is also what builds the map structures and sizes every work
+  // buffer). Second sighting: nothing is left to build or allocate, so the same calls can be captured.
+  // (the structure checks mirror ensure_structures / launch_measure: whatever this update needs must already exist)
+  const bool need_lik = ctx->n_s > 0, need_dda = ctx->n_b > 0;
+  const bool built = ctx->has_map && !(need_lik && ctx->lik_index == 0 && ctx->lik_dirty) &&
+                     !(need_lik && ctx->lik_index >= 1 && ctx->cand_dirty) &&
+                     !(need_dda && (ctx->dda_dirty || ctx->pow_table_dirty));
+  const bool capture = graphs && built && ctx->have_seen && ctx->seen_key == key &&
+                       !(ctx->have_failed && ctx->failed_key == key);
+  if (!capture)
+  {
+    TRY(enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4));
+    // enqueue_update may itself have moved the generation on (first-use allocations): remember the state it left
+    key.generation = ctx->generation;
+    ctx->seen_key = key;
+    ctx->have_seen = true;
+    return 0;
+  }
+  drop_graph(ctx);
+  HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
+  hipGraph_t g = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(ctx->stream, &g);
+  bool ok = rc == 0 && e_end == hipSuccess && g != nullptr && ctx->generation == key.generation;
+  if (ok)
+  {
+    ctx->graph = g;
+    ok = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+  }
+  else if (g)
+    (void)hipGraphDestroy(g);
+  if (!ok)
+  {
+    // not capturable in this state (e.g. a buffer had to grow): forget it and run the plain sequence
+    const hipError_t e_last = hipGetLastError();
+    char why[256];
+    snprintf(why, sizeof(why), "update graph not captured: rc=%d end=%s last=%s graph=%p generation %llu -> %llu", rc,
+             hipGetErrorString(e_end), hipGetErrorString(e_last), static_cast<void*>(g),
+             static_cast<unsigned long long>(key.generation), static_cast<unsigned long long>(ctx->generation));
+    ctx->graph_note = why;
+    drop_graph(ctx);
+    ctx->failed_key = key;
+    ctx->have_failed = true;
+    return enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
+  }
+  ctx->graph_key = key;
+  ++ctx->graph_captures;
+  HIP_TRY(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+  ++ctx->graph_replays;
+  return 0;
+}
+
+const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx)
+{
+  return ctx ? ctx->graph_note.c_str() : "";
+}
+
+int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* replays)
+{
+  if (!ctx)
+    return -1;
+  if (captures)
+    *captures = ctx->graph_captures;
+  if (replays)
+    *replays = ctx->graph_replays;
+  return 0;
+}
+
 int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
                              const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
                              const float* origins, size_t n_o, float* out_lik, float* out_match_ratio, float* out_beam)
@@ -2029,6 +2202,7 @@ int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable)
 {
   if (!ctx)
     return -1;
+  ++ctx->generation;
   TRY(timing_collect(ctx));
   ctx->timing = enable != 0;
   return 0;
@@ -2074,6 +2248,7 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
 {
   if (!ctx || !name)
     return -1;
+  ++ctx->generation;
   const std::string key(name);
   if (key == "lik_index")
   {
@@ -2096,6 +2271,16 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   if (key == "strict_order")
   {
     ctx->strict_order = value != 0.0;
+    return 0;
+  }
+  if (key == "timing_mask")
+  {
+    ctx->timing_mask = static_cast<unsigned>(value);
+    return 0;
+  }
+  if (key == "use_graph")
+  {
+    ctx->use_graph = value != 0.0;
     return 0;
   }
   if (key == "overlap_models")
