@@ -158,19 +158,30 @@ __global__ void radius_search_kernel(const float* __restrict__ query_xyz, int n,
 template <bool STATS>
 __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)
 {
-  const float fx = floorf((qx - g.ox) * g.inv_e);
-  const float fy = floorf((qy - g.oy) * g.inv_e);
-  const float fz = floorf((qz - g.oz) * g.inv_e);
+  // voxel of the query: floor to int in one conversion, range check as unsigned compares (a non-finite coordinate
+  // saturates to a voxel outside the grid, or for NaN lands in voxel 0 and yields a NaN distance: no match either way)
+  const int vx = __float2int_rd((qx - g.ox) * g.inv_e);
+  const int vy = __float2int_rd((qy - g.oy) * g.inv_e);
+  const int vz = __float2int_rd((qz - g.oz) * g.inv_e);
   float best = 3.0e38f;
-  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
-        fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
+  if (!(static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
+        static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz)))
     return best;
-  const int vx = static_cast<int>(fx), vy = static_cast<int>(fy), vz = static_cast<int>(fz);
-  const int b = g.brick_table[(static_cast<size_t>(vz >> 3) * g.nby + (vy >> 3)) * g.nbx + (vx >> 3)];
+  // 32-bit index arithmetic (the dense brick table has < 2^31 entries, there are <= 2^22 bricks: build_cand_grid) with
+  // 24-bit multiplies — full rate, where a 32-bit integer multiply is a quarter-rate instruction. row_stride = nbx,
+  // slab_stride = nbx * nby; build_cand_grid sets mul24_ok only when every factor is below 2^24.
+  uint32_t ti;
+  if (g.mul24_ok)
+    ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
+         __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
+  else
+    ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
+             static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
+  const int b = g.brick_table[ti];
   if (b < 0)
     return best;
-  const size_t v = static_cast<size_t>(b) * 512 + (((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
-  const float4* r = g.rec + 4 * v;
+  const uint32_t v = (static_cast<uint32_t>(b) << 9) | static_cast<uint32_t>(((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  const float4* r = g.rec + 4 * static_cast<size_t>(v);
   const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
   const uint32_t count = __float_as_uint(r0.x);
   if (count == 0)
@@ -421,13 +432,8 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
     if (have_point)
     {
       const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
-      float qx = tp.x, qy = tp.y, qz = tp.z;
-      if (prm.has_weight)
-      {
-        qx = tp.x * prm.wx;
-        qy = tp.y * prm.wy;
-        qz = tp.z * prm.wz;
-      }
+      // rescale by dist_weight; without one the weights are 1.0f and x * 1.0f == x bit for bit, so no select is needed
+      const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
       unsigned dummy = 0;
       const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
                        MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :

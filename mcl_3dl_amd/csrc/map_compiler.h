@@ -302,6 +302,7 @@ struct RecGrid
   const float4* ovf;  // [n_overflow][4]
   float ox, oy, oz, inv_e;
   int nvx, nvy, nvz, nbx, nby, nbz;
+  int mul24_ok;  // nbx * nby and every brick coordinate < 2^24: the table index can use 24-bit multiplies
 };
 
 __global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox)

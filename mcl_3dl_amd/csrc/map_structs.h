@@ -40,6 +40,7 @@ struct DdaGrid
 {
   const unsigned long long* bricks;  // occupancy: one 64-bit word per 4x4x4 voxel brick (bit = z<<4 | y<<2 | x), bricks x fastest
   int bnx, bny, bnz;                 // brick-grid extent = ceil(n / 4)
+  int mul24_ok;                      // bnx < 2^24 and bny * bnz < 2^24: the brick index can use 24-bit multiplies
   const uint32_t* vox_start;  // [total + 1] CSR into pts (voxel order, insertion order inside a voxel)
   const float4* pts;          // x,y,z (unscaled map coordinates), w = label bits
   const uint32_t* pt_index;   // original map index of pts[k]

@@ -514,6 +514,7 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
   g.bnx = bdim[0];
   g.bny = bdim[1];
   g.bnz = bdim[2];
+  g.mul24_ok = (bdim[0] < (1 << 24) && static_cast<long long>(bdim[1]) * bdim[2] < (1ll << 24)) ? 1 : 0;
   g.vox_start = ctx->dda_start.as<uint32_t>();
   g.pts = ctx->dda_pts.as<float4>();
   g.pt_index = ctx->dda_index.as<uint32_t>();
@@ -748,6 +749,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     g.nbx = cp.nbx;
     g.nby = cp.nby;
     g.nbz = cp.nbz;
+    g.mul24_ok = (static_cast<long long>(cp.nbx) * cp.nby < (1ll << 24) && cp.nbz < (1 << 24)) ? 1 : 0;
     ctx->footprint[5] = sizeof(int) * n_table;
     ctx->footprint[6] = 64ull * static_cast<size_t>(n_vox);
     ctx->footprint[7] = 64ull * n_ovf;
