@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=int, default=1024, help="particles in the CPU-baseline sample")
+    ap.add_argument("--cpu-particles", type=int, default=0,
+                    help="particles in the CPU-baseline sample (0 = as many as ~12 s of one core buys, at most all)")
     return ap.parse_args()
 
 
@@ -93,6 +94,9 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
     o.set_map(sc.map_xyz, sc.map_label, dist_weight=dist_weight)
     o.set_likelihood_params(pyoracle.LikelihoodParams())
     o.set_beam_params(pyoracle.BeamParams(num_points=max(beam_points, 1)))
+    if n_particles <= 0:
+        # ~12 s of single-thread work at the ~4.4e6 evals/s this path runs at on one core
+        n_particles = max(64, int(12.0 * 4.4e6 / max(len(sc.scan_lik), 1)))
     n = min(n_particles, len(sc.poses))
     lik, q, sec = o.likelihood_measure(sc.poses[:n], sc.scan_lik, threads=1, return_time=True)
     evals = n * len(sc.scan_lik)
