@@ -381,6 +381,19 @@ def main():
             eng.resample_apply(st13, ident)
         out["resample"] = {"ms": (time.perf_counter() - t4) / 5 * 1e3, "duplicates": int(n_dup),
                            "what": "mcl3dl_hip_resample_begin + plan + apply, host buffers, %d particles" % n_p}
+        # the same with weights and 13-float states resident on the device (what a multi-GPU host runs per rank after
+        # the all-gather, mcl_3dl_amd/distributed.py:sharded_resample)
+        d_st_in = torch.from_numpy(st13).to(dev)
+        d_st_out = torch.empty_like(d_st_in)
+        torch.cuda.synchronize(dev)
+        t6 = time.perf_counter()
+        for _ in range(5):
+            pstep = eng.resample_begin_device(d_w, n_p)
+            _src, _dup, n_dup = eng.resample_plan(0, 0.37 * pstep)
+            ident = np.zeros((n_dup, 13), np.float32)
+            ident[:, 6] = 1.0
+            eng.resample_apply_device(d_st_in, ident, d_st_out)
+        out["resample"]["ms_device_resident"] = (time.perf_counter() - t6) / 5 * 1e3
         if world == 1:
             # the drop-in boundary hands over HOST buffers: time the synchronous host entry point too (scan ordering on
             # the host, H2D of scan + poses + weights, kernels, D2H of weights) — never part of `value`
