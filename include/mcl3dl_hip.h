@@ -2,7 +2,7 @@
  *
  * This is the drop-in boundary: plain C, plain pointers and sizes, no C++/torch types.
  * Each entry point names the reference interface it replaces (paths relative to the at-wat/mcl_3dl
- * v0.7.0 tree).  The C++ adapter classes in mcl_3dl_amd/include/mcl_3dl_hip/ (same class names as the
+ * v0.7.0 tree).  The C++ adapter classes in mcl_3dl_amd/cpp/include/ (same class names as the
  * reference's plugins) and the ctypes binding mcl_3dl_amd/capi.py both sit on top of exactly these symbols.
  *
  * Conventions
