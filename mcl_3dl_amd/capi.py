@@ -256,10 +256,14 @@ class Engine:
         self._rs_n_out = len(w) if n_out is None else n_out
         return float(pstep.value)
 
-    def resample_plan(self, mode, initial_p=0.0):
+    def resample_plan(self, mode, initial_p=0.0, want_plan=True):
+        """want_plan=False leaves source / duplicate flags on the device (returns (None, None, n_duplicates))."""
+        nd = C.c_size_t(0)
+        if not want_plan:
+            self._check(self.lib.mcl3dl_hip_resample_plan(self.h, int(mode), float(initial_p), None, None, C.byref(nd)))
+            return None, None, int(nd.value)
         src = np.zeros(self._rs_n_out, np.uint32)
         dup = np.zeros(self._rs_n_out, np.uint8)
-        nd = C.c_size_t(0)
         self._check(self.lib.mcl3dl_hip_resample_plan(self.h, int(mode), float(initial_p), _ptr(src), _ptr(dup),
                                                       C.byref(nd)))
         return src, dup, int(nd.value)

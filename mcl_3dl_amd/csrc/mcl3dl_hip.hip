@@ -113,7 +113,9 @@ struct mcl3dl_hip_ctx
   size_t rs_n = 0, rs_n_out = 0, rs_n_dup = 0;
   float rs_pstep = 0.f;
   bool rs_planned = false;
-  DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out;
+  DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out, rs_d_order, rs_d_flag,
+      rs_d_ws, rs_d_dup8;
+  bool rs_sorted = false;  // std::sort had ties to order: rs_order is not the identity
 
   // mcl3dl_hip_update_device: the launch sequence of one device-resident update, captured into a hipGraph the second
   // time the same arguments arrive and replayed afterwards (small updates are launch-bound: 8-10 launches of a few
@@ -560,6 +562,25 @@ int device_exclusive_scan(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n)  // 
     HIP_TRY(hipFree(sums));
     if (rc != 0)
       return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The same scan without allocation or synchronisation: `ws` holds the per-tile sums of every level
+// (>= n / 1023 + 4 entries).
+int device_exclusive_scan_ws(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n, uint32_t* ws)
+{
+  if (n <= 0)
+    return 0;
+  const long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* sums = tiles > 1 ? ws : nullptr;
+  hipLaunchKernelGGL(scan_tiles, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, ctx->stream, data, data, sums, n);
+  if (tiles > 1)
+  {
+    TRY(device_exclusive_scan_ws(ctx, sums, tiles, ws + tiles));
+    hipLaunchKernelGGL(scan_add_offsets, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, data,
+                       sums, n);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -2023,8 +2044,9 @@ int mcl3dl_hip_resample_begin(mcl3dl_hip_ctx* ctx, const float* weight, size_t n
     return -1;
   if (!weight || n == 0 || n_out == 0 || n > 0x7fffffffu || n_out > 0x7fffffffu)
     return ctx->fail(-3, "bad arguments to resample_begin");
-  // accum += p.probability_ ; p.accum_probability_ = accum   (pf.h:193-197 / 401-405): float, sequential
-  std::vector<std::pair<float, uint32_t>> dup(n);
+  // accum += p.probability_ ; p.accum_probability_ = accum   (pf.h:193-197 / 401-405): a float recurrence in particle
+  // order, so it runs on the host (one add per particle)
+  ctx->rs_keys.resize(n);
   float accum = 0;
   bool ties = false;
   for (size_t i = 0; i < n; ++i)
@@ -2032,20 +2054,25 @@ int mcl3dl_hip_resample_begin(mcl3dl_hip_ctx* ctx, const float* weight, size_t n
     const float prev = accum;
     accum += weight[i];
     ties = ties || (i > 0 && !(prev < accum));
-    dup[i] = { accum, static_cast<uint32_t>(i) };
+    ctx->rs_keys[i] = accum;
   }
   // std::sort(particles_dup_) (pf.h:200 / 408). Ascending and tie-free input is left as it is by any sort; with ties
   // (weight-0 particles) libstdc++'s introsort decides who leads each tie group, so the very same std::sort runs here
   // (the comparison looks at the accumulated probability only, like Particle::operator<, pf.h:104-107).
+  ctx->rs_sorted = ties;
   if (ties)
+  {
+    std::vector<std::pair<float, uint32_t>> dup(n);
+    for (size_t i = 0; i < n; ++i)
+      dup[i] = { ctx->rs_keys[i], static_cast<uint32_t>(i) };
     std::sort(dup.begin(), dup.end(),
               [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
-  ctx->rs_keys.resize(n);
-  ctx->rs_order.resize(n);
-  for (size_t i = 0; i < n; ++i)
-  {
-    ctx->rs_keys[i] = dup[i].first;
-    ctx->rs_order[i] = dup[i].second;
+    ctx->rs_order.resize(n);
+    for (size_t i = 0; i < n; ++i)
+    {
+      ctx->rs_keys[i] = dup[i].first;
+      ctx->rs_order[i] = dup[i].second;
+    }
   }
   ctx->rs_n = n;
   ctx->rs_n_out = n_out;
@@ -2056,6 +2083,11 @@ int mcl3dl_hip_resample_begin(mcl3dl_hip_ctx* ctx, const float* weight, size_t n
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(ensure(ctx, ctx->rs_d_keys, sizeof(float) * n));
   TRY(h2d(ctx, ctx->rs_d_keys.p, ctx->rs_keys.data(), sizeof(float) * n));
+  if (ties)
+  {
+    TRY(ensure(ctx, ctx->rs_d_order, sizeof(uint32_t) * n));
+    TRY(h2d(ctx, ctx->rs_d_order.p, ctx->rs_order.data(), sizeof(uint32_t) * n));
+  }
   TRY(sync_stream(ctx));
   return 0;
 }
@@ -2071,62 +2103,60 @@ int mcl3dl_hip_resample_plan(mcl3dl_hip_ctx* ctx, int mode, float initial_p, uin
     return ctx->fail(-3, "mode must be 0 (resample) or 1 (resizeParticle)");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t n = ctx->rs_n, n_out = ctx->rs_n_out;
-  std::vector<float> pscan(n_out);
-  float acc = 0;
-  for (size_t i = 0; i < n_out; ++i)
+  const int ni = static_cast<int>(n), no = static_cast<int>(n_out);
+  TRY(ensure(ctx, ctx->rs_d_it, sizeof(uint32_t) * (n_out + 1)));  // [n_out] = the last search result below n
+  TRY(ensure(ctx, ctx->rs_d_flag, sizeof(uint32_t) * (n_out + 1)));
+  TRY(ensure(ctx, ctx->rs_d_ws, sizeof(uint32_t) * (n_out / 1023 + 8)));
+  TRY(ensure(ctx, ctx->rs_d_source, sizeof(uint32_t) * n_out));
+  TRY(ensure(ctx, ctx->rs_d_slot, sizeof(uint32_t) * n_out));
+  uint32_t* d_it = ctx->rs_d_it.as<uint32_t>();
+  uint32_t* d_flag = ctx->rs_d_flag.as<uint32_t>();
+  HIP_TRY(hipMemsetAsync(d_it + n_out, 0, sizeof(uint32_t), ctx->stream));
+  const float* d_pscan = nullptr;
+  if (mode == 1)
   {
-    if (mode == 0)
-      pscan[i] = ctx->rs_pstep * i + initial_p;  // pf.h:209
-    else
-      pscan[i] = (acc += ctx->rs_pstep);  // pf.h:421
+    // pscan += pstep (pf.h:421): another float recurrence, host side
+    std::vector<float> pscan(n_out);
+    float acc = 0;
+    for (size_t i = 0; i < n_out; ++i)
+      pscan[i] = (acc += ctx->rs_pstep);
+    TRY(ensure(ctx, ctx->rs_d_pscan, sizeof(float) * n_out));
+    TRY(h2d(ctx, ctx->rs_d_pscan.p, pscan.data(), sizeof(float) * n_out));
+    TRY(sync_stream(ctx));  // pscan dies at the end of this block
+    d_pscan = ctx->rs_d_pscan.as<float>();
   }
-  TRY(ensure(ctx, ctx->rs_d_pscan, sizeof(float) * n_out));
-  TRY(ensure(ctx, ctx->rs_d_it, sizeof(uint32_t) * n_out));
-  TRY(h2d(ctx, ctx->rs_d_pscan.p, pscan.data(), sizeof(float) * n_out));
-  const int no = static_cast<int>(n_out);
+  // n_out lower_bound searches (pscan = pstep * i + initial_p computed in the kernel for mode 0, pf.h:209); pscan never
+  // decreases, so the search the reference starts at the previous `it` lands where the global one does and the
+  // it / it_prev walk of pf.h:204-223 / 414-434 becomes a neighbour comparison + an exclusive scan.
   hipLaunchKernelGGL(resample_lower_bound_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream,
-                     ctx->rs_d_keys.as<float>(), static_cast<int>(n), ctx->rs_d_pscan.as<float>(), no,
-                     ctx->rs_d_it.as<uint32_t>());
-  HIP_TRY(hipGetLastError());
-  std::vector<uint32_t> it(n_out);
-  TRY(d2h(ctx, it.data(), ctx->rs_d_it.p, sizeof(uint32_t) * n_out));
-  TRY(sync_stream(ctx));
-  // the it / it_prev walk of pf.h:204-223 / 414-434 (pscan is non-decreasing, so the search that starts at the previous
-  // `it` lands where the global one does)
-  ctx->rs_source.resize(n_out);
-  ctx->rs_slot.assign(n_out, 0xffffffffu);
-  size_t it_prev = 0, n_dup = 0;
-  size_t cur = 0;
-  for (size_t i = 0; i < n_out; ++i)
+                     ctx->rs_d_keys.as<float>(), ni, d_pscan, ctx->rs_pstep, initial_p, no, d_it, d_it + n_out);
+  hipLaunchKernelGGL(resample_walk_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream, d_it, ni,
+                     ctx->rs_sorted ? ctx->rs_d_order.as<uint32_t>() : static_cast<const uint32_t*>(nullptr), mode, no,
+                     ctx->rs_d_source.as<uint32_t>(), d_flag);
+  HIP_TRY(hipMemcpyAsync(ctx->rs_d_slot.p, d_flag, sizeof(uint32_t) * n_out, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(d_flag + n_out, 0, sizeof(uint32_t), ctx->stream));
+  TRY(device_exclusive_scan_ws(ctx, d_flag, static_cast<long long>(n_out) + 1, ctx->rs_d_ws.as<uint32_t>()));
+  if (out_duplicate)
   {
-    cur = std::max<size_t>(cur, it[i]);
-    bool is_dup = false;
-    if (cur == n)
-    {
-      ctx->rs_source[i] = ctx->rs_order[it_prev];
-    }
-    else
-    {
-      is_dup = (mode == 0) && (cur == it_prev);
-      ctx->rs_source[i] = ctx->rs_order[cur];
-      it_prev = cur;
-    }
-    if (is_dup)
-      ctx->rs_slot[i] = static_cast<uint32_t>(n_dup++);
-    if (out_source)
-      out_source[i] = ctx->rs_source[i];
-    if (out_duplicate)
-      out_duplicate[i] = is_dup ? 1 : 0;
+    TRY(ensure(ctx, ctx->rs_d_dup8, n_out));
+    hipLaunchKernelGGL(resample_slot_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream, d_flag, no,
+                       ctx->rs_d_slot.as<uint32_t>(), ctx->rs_d_dup8.as<uint8_t>());
   }
+  else
+    hipLaunchKernelGGL(resample_slot_kernel, dim3((no + 255) / 256), dim3(256), 0, ctx->stream, d_flag, no,
+                       ctx->rs_d_slot.as<uint32_t>(), static_cast<uint8_t*>(nullptr));
+  HIP_TRY(hipGetLastError());
+  uint32_t n_dup = 0;
+  TRY(d2h(ctx, &n_dup, d_flag + n_out, sizeof(uint32_t)));
+  if (out_source)
+    TRY(d2h(ctx, out_source, ctx->rs_d_source.p, sizeof(uint32_t) * n_out));
+  if (out_duplicate)
+    TRY(d2h(ctx, out_duplicate, ctx->rs_d_dup8.p, n_out));
+  TRY(sync_stream(ctx));
   ctx->rs_n_dup = n_dup;
   ctx->rs_planned = true;
   if (out_n_duplicates)
     *out_n_duplicates = n_dup;
-  TRY(ensure(ctx, ctx->rs_d_source, sizeof(uint32_t) * n_out));
-  TRY(ensure(ctx, ctx->rs_d_slot, sizeof(uint32_t) * n_out));
-  TRY(h2d(ctx, ctx->rs_d_source.p, ctx->rs_source.data(), sizeof(uint32_t) * n_out));
-  TRY(h2d(ctx, ctx->rs_d_slot.p, ctx->rs_slot.data(), sizeof(uint32_t) * n_out));
-  TRY(sync_stream(ctx));
   return 0;
 }
 

@@ -347,12 +347,15 @@ __global__ __launch_bounds__(64) void pf_covariance_reduce_kernel(const double* 
 // gather of the 13-dof states with State6DOF::operator+ / normalize() for the duplicated ones.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void resample_lower_bound_kernel(const float* __restrict__ keys, int n, const float* __restrict__ pscan,
-                                            int n_out, uint32_t* __restrict__ it_out)
+                                            float pstep, float initial_p, int n_out, uint32_t* __restrict__ it_out,
+                                            uint32_t* __restrict__ last_valid)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out)
     return;
-  const float p = pscan[i];
+  // resample: pscan = pstep * i + initial_p with i a size_t converted to float (pf.h:209); resizeParticle: the host's
+  // running sum
+  const float p = pscan ? pscan[i] : pstep * static_cast<float>(static_cast<unsigned long long>(i)) + initial_p;
   int lo = 0, len = n;  // std::lower_bound with Particle::operator< (pf.h:104-107): first key with !(key < p)
   while (len > 0)
   {
@@ -366,6 +369,45 @@ __global__ void resample_lower_bound_kernel(const float* __restrict__ keys, int 
       len = half;
   }
   it_out[i] = static_cast<uint32_t>(lo);
+  if (lo < n)
+    atomicMax(last_valid, static_cast<uint32_t>(lo));  // = it_prev once the scan position runs past the last key
+}
+
+// The it / it_prev walk of pf.h:204-223 (resample) and :414-434 (resizeParticle) for non-decreasing search results:
+// slot i copies particles_dup_[it[i]]; it is a duplicate (gets noise) when it[i] equals the previous slot's result
+// (it_prev starts at begin(), so slot 0 is a duplicate when it lands on element 0); once it[i] == n every remaining slot
+// copies the last element found before the end and nothing else changes (`continue`, :212-216).
+__global__ void resample_walk_kernel(const uint32_t* __restrict__ it, int n, const uint32_t* __restrict__ order /*or null*/,
+                                     int mode, int n_out, uint32_t* __restrict__ source, uint32_t* __restrict__ dup_flag)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out)
+    return;
+  const uint32_t cur = it[i];
+  uint32_t pick, dup = 0u;
+  if (cur >= static_cast<uint32_t>(n))
+    pick = it[n_out];  // last search result below n (0 = begin() if there was none)
+  else
+  {
+    pick = cur;
+    const uint32_t prev = i ? it[i - 1] : 0u;
+    dup = (mode == 0 && cur == prev) ? 1u : 0u;
+  }
+  source[i] = order ? order[pick] : pick;
+  dup_flag[i] = dup;
+}
+
+// noise slot of every duplicated output slot = its rank among the duplicates (exclusive scan of the flags)
+__global__ void resample_slot_kernel(const uint32_t* __restrict__ scanned, int n_out, uint32_t* __restrict__ slot_inout,
+                                     uint8_t* __restrict__ dup8)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out)
+    return;
+  const uint32_t flag = slot_inout[i];  // the un-scanned flag was parked here
+  slot_inout[i] = flag ? scanned[i] : 0xffffffffu;
+  if (dup8)
+    dup8[i] = static_cast<uint8_t>(flag);
 }
 
 // slot i receives the state of particle source[i]; duplicated picks get `state + noise` (State6DOF::operator+,
