@@ -100,7 +100,7 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
     n = min(n_particles, len(sc.poses))
     lik, q, sec = o.likelihood_measure(sc.poses[:n], sc.scan_lik, threads=1, return_time=True)
     evals = n * len(sc.scan_lik)
-    out = {"value": evals / sec, "unit": "particle*point evals/s", "cores": 1,
+    out = {"value": evals / sec, "unit": "particle\u00b7point evals/s", "cores": 1,
            "kind": "reference" if kind == "ref" else "port",
            "sample": "%d of the workload's particles x %d points, likelihood model, 1 thread, %.1f s"
                      % (n, len(sc.scan_lik), sec),
@@ -300,9 +300,9 @@ def main():
             l2_gbps = ws["evals"] * bpe / (lik_avg_ms * 1e-3) / 1e9
             l2 = {"bytes_per_eval": bpe, "achieved": l2_gbps, "peak": 34500.0, "unit": "GB/s", "frac": l2_gbps / 34500.0}
         out = {
-            "metric": "particle*point likelihood evals/sec (filter-update Hz @ 4096 particles x 16k-pt scan in config)",
+            "metric": "particle\u00b7point evals/sec; filter-update Hz @ 4096 particles \u00d7 16k-pt scan",  # BASELINE.json
             "value": value,
-            "unit": "particle*point evals/s",
+            "unit": "particle\u00b7point evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
