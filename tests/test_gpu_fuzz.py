@@ -14,6 +14,8 @@ other combination the plugin surface accepts (parameters.h:64-132).
 dist_weight components stay >= 1: below 1 the reference's ChunkedKdtree can miss a neighbour that sits across a chunk
 border (its overlap margin is max_search_radius in RAW coordinates, chunked_kdtree.h:139-201, while the search radius
 is in weighted ones), the engine returns the global nearest neighbour; DESIGN.md §4 lists this as a declared deviation."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,6 +23,10 @@ from oracle import pyoracle
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
+# the default suite runs seeds 0..95 (~7 s); MCL3DL_FUZZ_FIRST / MCL3DL_FUZZ_LAST widen the sweep (seeds 96..599 were run
+# once for round 1: 504 further configurations, all green)
+FUZZ_FIRST = int(os.environ.get("MCL3DL_FUZZ_FIRST", "0"))
+FUZZ_LAST = int(os.environ.get("MCL3DL_FUZZ_LAST", "96"))
 
 
 def draw_map(rng):
@@ -111,7 +117,7 @@ def setup_engine(eng, c, stamp):
     eng.set_beam_params(**kw)
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(FUZZ_FIRST, FUZZ_LAST))
 def test_random_configuration(engine, oracle_kind, seed):
     c = draw_case(seed)
     try:
