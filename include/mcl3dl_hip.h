@@ -175,6 +175,23 @@ int mcl3dl_hip_expectation_device(mcl3dl_hip_ctx* ctx, const float* d_pose, cons
 int mcl3dl_hip_covariance_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const float* d_weight, size_t n_particles,
                                  const uint32_t* d_subset, size_t n_subset, const float* mean7, float* out_cov36);
 
+/* The same reductions over particle shards (multi-GPU hosts, mcl_3dl_amd/distributed.py:sharded_expectation /
+ * sharded_covariance). *_partial_device leaves one record per shard in DEVICE memory:
+ *   moments    16 doubles {sum w, sum w*pos[3], sum w*front[3], sum w*up[3], max w, its index in the shard,
+ *              max w*bias, its index, 0, 0}      -> all-gather, then mcl3dl_hip_moments_finish (host arithmetic of
+ *              ParticleWeightedMeanQuat::getMean, state_6dof.h:345-350; index_offset[r] = first particle of shard r)
+ *   covariance 22 doubles {21 upper-triangular sums, sum w} -> all-reduce(SUM), then mcl3dl_hip_covariance_finish.
+ * The *_finish functions are pure host functions (no context). */
+int mcl3dl_hip_moments_partial_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const float* d_weight,
+                                      const float* d_bias /*or NULL*/, size_t n, double* d_out16);
+int mcl3dl_hip_moments_finish(const double* parts16 /*world*16, rank order*/, int world,
+                              const uint64_t* index_offset /*world or NULL*/, float* out_mean7, float* out_total,
+                              int64_t* out_max_index, int64_t* out_max_biased_index);
+int mcl3dl_hip_covariance_partial_device(mcl3dl_hip_ctx* ctx, const float* d_pose, const float* d_weight,
+                                         size_t n_particles, const uint32_t* d_subset /*or NULL*/, size_t n_subset,
+                                         const float* mean7 /*host*/, double* d_out22);
+int mcl3dl_hip_covariance_finish(const double* sums22, float* out_cov36);
+
 /* ---- "next" row: resampling ------------------------------------------------------------------ */
 /* Replaces: pf::ParticleFilter::resample (include/mcl_3dl/pf.h:187-225, called at src/mcl_3dl.cpp:809) and
  * resizeParticle (pf.h:399-436, :880-884) on 13-dof states (State6DOF::operator[], state_6dof.h:80-149: pos, rot,

@@ -42,6 +42,10 @@ SIGNATURES = {
     "mcl3dl_hip_resample_plan": (_i, [_p, _i, _f, _p, _p, C.POINTER(_sz)]),
     "mcl3dl_hip_resample_apply": (_i, [_p, _p, _p, _sz, _p]),
     "mcl3dl_hip_resample_apply_device": (_i, [_p, _p, _p, _sz, _p]),
+    "mcl3dl_hip_moments_partial_device": (_i, [_p, _p, _p, _p, _sz, _p]),
+    "mcl3dl_hip_moments_finish": (_i, [_p, _i, _p, _p, C.POINTER(_f), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mcl3dl_hip_covariance_partial_device": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
+    "mcl3dl_hip_covariance_finish": (_i, [_p, _p]),
     "mcl3dl_hip_update_device": (_i, [_p, _p, _sz, _p, _p, _p, _p, _p, _p]),
     "mcl3dl_hip_graph_note": (C.c_char_p, [_p]),
     "mcl3dl_hip_graph_stats": (_i, [_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -246,6 +250,33 @@ class Engine:
         cov = np.zeros((6, 6), np.float32)
         self._check(self.lib.mcl3dl_hip_covariance_device(self.h, _ptr(d_pose), _ptr(d_weight), n, _ptr(d_subset),
                                                           n_subset, _ptr(m), _ptr(cov)))
+        return cov
+
+    def moments_partial_device(self, d_pose, d_weight, d_bias, n, d_out16):
+        self._check(self.lib.mcl3dl_hip_moments_partial_device(self.h, _ptr(d_pose), _ptr(d_weight), _ptr(d_bias), n,
+                                                               _ptr(d_out16)))
+
+    def moments_finish(self, parts16, index_offset=None):
+        parts = np.ascontiguousarray(parts16, np.float64).reshape(-1, 16)
+        off = None if index_offset is None else np.ascontiguousarray(index_offset, np.uint64)
+        mean = np.zeros(7, np.float32)
+        total, im, ib = C.c_float(0), C.c_int64(0), C.c_int64(0)
+        rc = self.lib.mcl3dl_hip_moments_finish(_ptr(parts), len(parts), _ptr(off), _ptr(mean), C.byref(total),
+                                                C.byref(im), C.byref(ib))
+        if rc != 0:
+            raise EngineError("moments_finish: bad arguments")
+        return mean, float(total.value), int(im.value), int(ib.value)
+
+    def covariance_partial_device(self, d_pose, d_weight, n, mean7, d_out22, d_subset=None, n_subset=0):
+        m = _np_f32(mean7)
+        self._check(self.lib.mcl3dl_hip_covariance_partial_device(self.h, _ptr(d_pose), _ptr(d_weight), n,
+                                                                  _ptr(d_subset), n_subset, _ptr(m), _ptr(d_out22)))
+
+    def covariance_finish(self, sums22):
+        s = np.ascontiguousarray(sums22, np.float64)
+        cov = np.zeros((6, 6), np.float32)
+        if self.lib.mcl3dl_hip_covariance_finish(_ptr(s), _ptr(cov)) != 0:
+            raise EngineError("covariance_finish: bad arguments")
         return cov
 
     def resample_begin(self, weights, n_out=None):

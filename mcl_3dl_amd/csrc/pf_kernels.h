@@ -236,7 +236,8 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_moments_kernel(const float* __res
 __global__ __launch_bounds__(64) void pf_moments_reduce_kernel(const double* __restrict__ block_mom,
                                                                const ArgMax* __restrict__ block_arg, int n_blocks,
                                                                double* __restrict__ out_mom /*[MOM_N]*/,
-                                                               int* __restrict__ out_arg /*[2]*/)
+                                                               int* __restrict__ out_arg /*[2]*/,
+                                                               double* __restrict__ out16 /*or null: shard record*/)
 {
   if (threadIdx.x < MOM_N)
   {
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(64) void pf_moments_reduce_kernel(const double* __r
     for (int b = 0; b < n_blocks; ++b)  // fixed order
       s += block_mom[MOM_N * b + threadIdx.x];
     out_mom[threadIdx.x] = s;
+    if (out16)
+      out16[threadIdx.x] = s;
   }
   if (threadIdx.x == 32 || threadIdx.x == 33)
   {
@@ -252,6 +255,13 @@ __global__ __launch_bounds__(64) void pf_moments_reduce_kernel(const double* __r
     for (int b = 1; b < n_blocks; ++b)
       a = argmax_better(a, block_arg[2 * b + which]);
     out_arg[which] = a.i;
+    if (out16)
+    {
+      // {10: max weight, 11: its index in this shard, 12: max biased weight, 13: its index, 14-15: 0}
+      out16[MOM_N + 2 * which] = static_cast<double>(a.v);
+      out16[MOM_N + 2 * which + 1] = static_cast<double>(a.i);
+      out16[14 + which] = 0.0;
+    }
   }
 }
 

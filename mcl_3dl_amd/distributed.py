@@ -110,3 +110,29 @@ def sharded_resample(ops, state_local, weight_local, n_total, draw_initial_p, dr
     new_state = ops.apply_slice(state_all, noise, lo, hi - lo)
     new_weight = torch.full((hi - lo,), 1.0 / n_total, dtype=torch.float32, device=weight_local.device)
     return new_state, new_weight, (source, dup)
+
+
+def sharded_expectation(engine, d_pose, d_weight, d_bias, n_local, n_total, group=None):
+    """pf::expectationBiased + max + maxBiased (include/mcl_3dl/pf.h:294-303, 361-390) over particle shards: one
+    16-double record per rank, all-gathered (128 B per rank), combined on the host in rank order.
+    Returns (mean7, total weight, global index of the max-weight particle, of the max biased-weight particle)."""
+    rec = torch.zeros(16, dtype=torch.float64, device=d_pose.device)
+    engine.moments_partial_device(d_pose, d_weight, d_bias, n_local, rec)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        allrec = torch.empty(16 * world, dtype=torch.float64, device=rec.device)
+        dist.all_gather_into_tensor(allrec, rec, group=group)
+    else:
+        world, allrec = 1, rec
+    offsets = [shard_bounds(n_total, world, r)[0] for r in range(world)]
+    return engine.moments_finish(allrec.cpu().numpy(), offsets)
+
+
+def sharded_covariance(engine, d_pose, d_weight, n_local, mean7, group=None):
+    """pf::covariance (pf.h:304-360, pass ratio 1, all particles) over particle shards: 22 sums per rank, one
+    all-reduce(SUM) of 176 bytes, host division."""
+    rec = torch.zeros(22, dtype=torch.float64, device=d_pose.device)
+    engine.covariance_partial_device(d_pose, d_weight, n_local, mean7, rec)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
+    return engine.covariance_finish(rec.cpu().numpy())

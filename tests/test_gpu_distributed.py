@@ -26,7 +26,8 @@ def _worker(rank, world, port, sc_args, w0, noise_all, out_path):
     import torch  # before the engine library: it initialises the HIP runtime
     import torch.distributed as dist
     from mcl_3dl_amd import capi
-    from mcl_3dl_amd.distributed import EngineResampleOps, allreduce_partials, shard_bounds, sharded_resample
+    from mcl_3dl_amd.distributed import (EngineResampleOps, allreduce_partials, shard_bounds, sharded_covariance,
+                                         sharded_expectation, sharded_resample)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,6 +56,9 @@ def _worker(rank, world, port, sc_args, w0, noise_all, out_path):
     d_pack.copy_(host_pack)
     eng.pf_apply_device(d_w, m, d_pack, d_stats, world)
     torch.cuda.synchronize()
+    # the reductions that follow the update in the node (expectationBiased / max / covariance), over the shards
+    mean7, total, imax, ibias = sharded_expectation(eng, d_pose, d_w, None, m, n)
+    cov = sharded_covariance(eng, d_pose, d_w, m, mean7)
     # resampling over the shards (states = pose + 6 zero odometry-error terms)
     st = np.zeros((m, 13), np.float32)
     st[:, :7] = sc.poses[lo:hi]
@@ -63,7 +67,8 @@ def _worker(rank, world, port, sc_args, w0, noise_all, out_path):
                                                 lambda n_dup: noise_all[:n_dup])
     torch.cuda.synchronize()
     np.savez(out_path % rank, w=d_w.cpu().numpy(), stats=d_stats.cpu().numpy(), lik=d_lik.cpu().numpy(),
-             beam=d_beam.cpu().numpy(), new_s=new_s.cpu().numpy(), src=src, dup=dup)
+             beam=d_beam.cpu().numpy(), new_s=new_s.cpu().numpy(), src=src, dup=dup, mean7=mean7, total=total,
+             imax=imax, ibias=ibias, cov=cov)
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
@@ -96,6 +101,18 @@ def test_two_processes_shard_one_update_and_resample(engine, tmp_path):
             np.testing.assert_allclose(p["stats"][0], whole["entropy"], rtol=1e-6)
             assert p["stats"][1] == np.float32(whole["match_ratio_min"]) and p["stats"][2] == np.float32(whole["match_ratio_max"])
         np.testing.assert_array_equal(parts[0]["stats"], parts[1]["stats"])
+        # reductions: every rank holds the same mean / covariance / arg-max, equal to the single-context ones
+        mean_w, total_w, imax_w, ibias_w = engine.expectation(sc.poses, w_sharded)
+        cov_w = engine.covariance(sc.poses, w_sharded, mean_w)
+        for p in parts:
+            np.testing.assert_allclose(p["mean7"][:3], mean_w[:3], rtol=2e-6)
+            dot = abs(float(np.dot(p["mean7"][3:], mean_w[3:])))
+            assert 2.0 * np.arccos(min(1.0, dot)) < 5e-4  # same rotation (tests/test_gpu_moments.py explains the metric)
+            np.testing.assert_allclose(p["total"], total_w, rtol=1e-6)
+            assert int(p["imax"]) == imax_w and int(p["ibias"]) == ibias_w
+            np.testing.assert_allclose(p["cov"], cov_w, rtol=2e-3, atol=1e-9)
+        np.testing.assert_array_equal(parts[0]["mean7"], parts[1]["mean7"])
+        np.testing.assert_array_equal(parts[0]["cov"], parts[1]["cov"])
         # resampling: the plan of the sharded run equals the plan on the stitched weights, and so do the states
         st = np.zeros((n, 13), np.float32)
         st[:, :7] = sc.poses
