@@ -112,6 +112,13 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
     return out, lik, q
 
 
+def _identity_noise(n):
+    """n noise states that leave a particle where it is (zero offsets, identity quaternion)."""
+    a = np.zeros((n, 13), np.float32)
+    a[:, 6] = 1.0
+    return a
+
+
 def _flush_c_stdio():
     import ctypes
     sys.stdout.flush()
@@ -420,6 +427,21 @@ def main():
                     eng.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam if n_b else None)
                 torch.cuda.synchronize(dev)
                 fused["graph" if use_graph else "eager"] = (time.perf_counter() - t5) / args.steps * 1e3
+            # one whole filter iteration with everything resident on the device: measurement update -> expectation + max
+            # (the node publishes the pose from it) -> resampling of the 13-float states; noise = identity
+            eng.set_option("use_graph", 0)
+            torch.cuda.synchronize(dev)
+            t7 = time.perf_counter()
+            for _ in range(args.steps):
+                d_w.copy_(d_w0)
+                eng.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam if n_b else None)
+                eng.expectation_device(d_pose, d_w, None, n_p)
+                pstep = eng.resample_begin_device(d_w, n_p)
+                _s, _d, nd = eng.resample_plan(0, 0.37 * pstep, want_plan=False)
+                eng.resample_apply_device(d_st_in, _identity_noise(nd), d_st_out)
+            torch.cuda.synchronize(dev)
+            out["filter_iteration"] = {"ms": (time.perf_counter() - t7) / args.steps * 1e3,
+                                       "what": "update + expectationBiased/max + resample, device-resident, one GPU"}
             out["fused_update"] = {"ms_per_update_graph": fused["graph"], "ms_per_update_eager": fused["eager"],
                                    "graph": eng.graph_stats(),
                                    "what": "mcl3dl_hip_update_device, device-resident, hipGraph replay vs plain launches"}
