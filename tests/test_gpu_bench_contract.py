@@ -1,0 +1,50 @@
+"""bench.py's output contract, on the GPU box: the LAST stdout line is one JSON object with the driver's keys plus the
+`roofline` and `cpu_baseline` objects; the torch.distributed (RCCL) path runs with one rank; figures are sane."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def run_bench(*extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C1", "--steps", "3",
+                           "--warmup", "1", "--prewarm-ms", "20", *extra], capture_output=True, text=True, timeout=600,
+                          cwd=ROOT, env=env)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    return json.loads(lines[-1])  # must be the last line
+
+
+def test_single_gpu_line():
+    d = run_bench("--cpu-particles", "16")
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e8 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0
+    # the run checks itself against the CPU path
+    assert d["result_check"]["max_rel_err_vs_cpu"] < 1e-5 and d["result_check"]["match_ratio_equal"] is True
+
+
+def test_distributed_path_with_one_rank():
+    d = run_bench("--force-dist", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["cpu_baseline"] is None
+    assert "1 all-reduce/update" in d["config"]["parallelism"]
+    assert d["value"] > 1e8
