@@ -1,0 +1,724 @@
+// api_core.inl — included inside the extern "C" block of mcl3dl_hip.hip: lifecycle, map / parameters, scan upload,
+// the device-resident and host-buffer forms of the measurement update, ray and nearest-neighbour queries.
+int mcl3dl_hip_abi_version(void)
+{
+  return MCL3DL_HIP_ABI_VERSION;
+}
+
+int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
+{
+  if (!out)
+    return -1;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return -6;  // no GPU: there is deliberately no CPU fallback
+  if (device_id < 0 || device_id >= count)
+    return -6;
+  mcl3dl_hip_ctx* ctx = new mcl3dl_hip_ctx;
+  ctx->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    delete ctx;
+    return -2;
+  }
+  ctx->stream = ctx->own_stream;
+  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+  {
+    delete ctx;
+    return -2;
+  }
+  beam_refresh(ctx);
+  *out = ctx;
+  return 0;
+}
+
+void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux_stream)
+    (void)hipStreamSynchronize(ctx->aux_stream);
+  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->scan_perm, &ctx->strict_terms, &ctx->mom_blocks, &ctx->mom_arg, &ctx->mom_out, &ctx->mom_idx,
+                     &ctx->subset, &ctx->rs_d_keys, &ctx->rs_d_pscan, &ctx->rs_d_it, &ctx->rs_d_source, &ctx->rs_d_slot,
+                     &ctx->rs_d_noise, &ctx->rs_d_in, &ctx->rs_d_out, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
+                     &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
+                     &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
+                     &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
+                     &ctx->ray_begin, &ctx->ray_end, &ctx->ray_status, &ctx->ray_hit };
+  for (DevBuf* b : bufs)
+    if (b->p)
+      (void)hipFree(b->p);
+  for (const EventPair& ep : ctx->pending)
+  {
+    (void)hipEventDestroy(ep.start);
+    (void)hipEventDestroy(ep.stop);
+  }
+  for (hipEvent_t e : ctx->free_events)
+    (void)hipEventDestroy(e);
+  if (ctx->graph_exec)
+    (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph)
+    (void)hipGraphDestroy(ctx->graph);
+  for (const mcl3dl_hip_ctx::StageChunk& ch : ctx->stage)
+    (void)hipHostFree(ch.p);
+  if (ctx->ev_fork)
+    (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join)
+    (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->aux_stream)
+    (void)hipStreamDestroy(ctx->aux_stream);
+  if (ctx->own_stream)
+    (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* mcl3dl_hip_last_error(const mcl3dl_hip_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : "null context";
+}
+
+int mcl3dl_hip_set_stream(mcl3dl_hip_ctx* ctx, void* hip_stream)
+{
+  if (!ctx)
+    return -1;
+  ++ctx->generation;
+  TRY(sync_stream(ctx));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return 0;
+}
+
+void* mcl3dl_hip_get_stream(mcl3dl_hip_ctx* ctx)
+{
+  return ctx ? static_cast<void*>(ctx->stream) : nullptr;
+}
+
+int mcl3dl_hip_synchronize(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return -1;
+  TRY(sync_stream(ctx));
+  return 0;
+}
+
+int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n_m, uint64_t stamp,
+                       const float* dist_weight)
+{
+  if (!ctx)
+    return -1;
+  ++ctx->generation;
+  if (!xyz || n_m == 0)
+    return ctx->fail(-3, "empty map");
+  if (n_m > 0xfffffff0u)
+    return ctx->fail(-3, "map too large (index must fit 32 bits)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->map_xyz.assign(xyz, xyz + 3 * n_m);
+  if (label)
+    ctx->map_label.assign(label, label + n_m);
+  else
+    ctx->map_label.assign(n_m, 0u);
+  ctx->stamp = stamp;
+  ctx->has_weight = dist_weight != nullptr;
+  for (int a = 0; a < 3; ++a)
+    ctx->weight[a] = dist_weight ? dist_weight[a] : 1.0f;
+  ctx->has_map = true;
+  ctx->lik_dirty = true;
+  ctx->cand_dirty = true;
+  ctx->dda_dirty = true;
+  return 0;
+}
+
+int mcl3dl_hip_set_likelihood_params(mcl3dl_hip_ctx* ctx, float match_dist_min, float match_dist_flat,
+                                     float match_weight)
+{
+  if (!ctx)
+    return -1;
+  ++ctx->generation;
+  if (!(match_dist_min > 0.f))
+    return ctx->fail(-3, "match_dist_min must be > 0");
+  if (match_dist_min != ctx->match_dist_min)
+    ctx->lik_dirty = ctx->cand_dirty = true;  // cell / voxel edges follow the search radius
+  ctx->match_dist_min = match_dist_min;
+  ctx->match_dist_flat = match_dist_flat;
+  ctx->match_weight = match_weight;
+  return 0;
+}
+
+int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_grid_y, float map_grid_z,
+                               float dda_grid_size, float ray_angle_half, float hit_range, float beam_likelihood_min,
+                               uint32_t num_points, float ang_total_ref, uint32_t filter_label_max,
+                               int add_penalty_short_only_mode)
+{
+  if (!ctx)
+    return -1;
+  ++ctx->generation;
+  if (!(dda_grid_size > 0.f))
+    return ctx->fail(-3, "dda_grid_size must be > 0");
+  ctx->map_grid[0] = map_grid_x;
+  ctx->map_grid[1] = map_grid_y;
+  ctx->map_grid[2] = map_grid_z;
+  ctx->dda_grid_size = dda_grid_size;
+  ctx->ray_angle_half = ray_angle_half;
+  ctx->hit_range = hit_range;
+  ctx->beam_likelihood_min = beam_likelihood_min;
+  ctx->beam_num_points = num_points;
+  ctx->ang_total_ref = ang_total_ref;
+  ctx->filter_label_max = filter_label_max;
+  ctx->short_only = add_penalty_short_only_mode ? 1 : 0;
+  ctx->dda_dirty = true;  // refreshParameters re-creates the raycaster (beam.cpp:69-79)
+  beam_refresh(ctx);
+  return 0;
+}
+
+// sync_at_end = false: the caller synchronises the stream itself before it returns (the staging vectors live in the
+// context, so nothing here dies earlier).
+static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                            const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                            bool sync_at_end)
+{
+  if (!ctx)
+    return -1;
+  if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
+    return ctx->fail(-3, "null scan array");
+  if (n_s > 0x7fffffffu || n_b > 0x7fffffffu)
+    return ctx->fail(-3, "scan too large");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // likelihood scan: spatial (Morton) order. The score is a sum, so the order only changes which lanes work together.
+  std::vector<float4>& lik = ctx->h_scan_lik;
+  lik.resize(n_s);
+  if (n_s)
+  {
+    float mn[3] = { scan_lik_xyz[0], scan_lik_xyz[1], scan_lik_xyz[2] };
+    for (size_t i = 0; i < n_s; ++i)
+      for (int a = 0; a < 3; ++a)
+        mn[a] = std::min(mn[a], scan_lik_xyz[3 * i + a]);
+    // 30-bit Morton key (10 bits per axis, 0.25 m cells) + 3-pass LSD radix sort: ~0.1 ms for 16 k points on one core
+    std::vector<uint32_t>& idx = ctx->h_scan_perm;
+    std::vector<uint32_t> key(n_s), key2(n_s), idx2(n_s);
+    idx.resize(n_s);
+    for (size_t i = 0; i < n_s; ++i)
+    {
+      uint32_t c[3];
+      for (int a = 0; a < 3; ++a)
+      {
+        const float f = (scan_lik_xyz[3 * i + a] - mn[a]) * 4.0f;
+        c[a] = (f >= 0.f) ? (f < 1023.f ? static_cast<uint32_t>(f) : 1023u) : 0u;
+      }
+      key[i] = static_cast<uint32_t>(morton3(c[0], c[1], c[2]));
+      idx[i] = static_cast<uint32_t>(i);
+    }
+    for (int pass = 0; pass < 3; ++pass)
+    {
+      uint32_t hist[1025] = { 0 };
+      const int shift = 10 * pass;
+      for (size_t i = 0; i < n_s; ++i)
+        ++hist[((key[i] >> shift) & 1023u) + 1];
+      for (int b = 0; b < 1024; ++b)
+        hist[b + 1] += hist[b];
+      for (size_t i = 0; i < n_s; ++i)
+      {
+        const uint32_t dst = hist[(key[i] >> shift) & 1023u]++;
+        key2[dst] = key[i];
+        idx2[dst] = idx[i];
+      }
+      key.swap(key2);
+      idx.swap(idx2);
+    }
+    for (size_t k = 0; k < n_s; ++k)
+    {
+      const uint32_t i = idx[k];
+      lik[k] = make_float4(scan_lik_xyz[3 * i], scan_lik_xyz[3 * i + 1], scan_lik_xyz[3 * i + 2], 0.f);
+    }
+    TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
+    TRY(h2d(ctx, ctx->scan_perm.p, idx.data(), sizeof(uint32_t) * n_s));
+  }
+  // beam scan: ordered by range from its scan origin. A ray walks ~range/dda_grid voxels and (its end point being a
+  // measured surface) ends near its last voxel, so the 64 rays of a wavefront finish together instead of idling behind the
+  // longest one. The beam score is a count of penalised rays, so the order is free.
+  std::vector<float4>& beam = ctx->h_scan_beam;
+  beam.resize(n_b);
+  if (n_b)
+  {
+    std::vector<std::pair<float, uint32_t>> keys(n_b);
+    for (size_t i = 0; i < n_b; ++i)
+    {
+      const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
+      if (og >= n_o)
+        return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, og, n_o);
+      const float dx = scan_beam_xyz[3 * i] - origins[3 * og], dy = scan_beam_xyz[3 * i + 1] - origins[3 * og + 1],
+                  dz = scan_beam_xyz[3 * i + 2] - origins[3 * og + 2];
+      keys[i] = { dx * dx + dy * dy + dz * dz, static_cast<uint32_t>(i) };
+    }
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < n_b; ++k)
+    {
+      const uint32_t i = keys[k].second;
+      const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
+      beam[k] = make_float4(scan_beam_xyz[3 * i], scan_beam_xyz[3 * i + 1], scan_beam_xyz[3 * i + 2], bits_to_float(og));
+    }
+  }
+  std::vector<float4>& org = ctx->h_origins;
+  org.resize(n_o);
+  for (size_t i = 0; i < n_o; ++i)
+    org[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+  TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
+  TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
+  TRY(ensure(ctx, ctx->origins, sizeof(float4) * n_o));
+  TRY(h2d(ctx, ctx->scan_lik.p, lik.data(), sizeof(float4) * n_s));
+  TRY(h2d(ctx, ctx->scan_beam.p, beam.data(), sizeof(float4) * n_b));
+  TRY(h2d(ctx, ctx->origins.p, org.data(), sizeof(float4) * n_o));
+  if (sync_at_end)
+    TRY(sync_stream(ctx));
+  if (n_b != ctx->n_b)
+    ctx->pow_table_dirty = true;
+  if (n_s != ctx->n_s || n_b != ctx->n_b || n_o != ctx->n_o || !ctx->has_scan)
+    ++ctx->generation;
+  ctx->n_s = n_s;
+  ctx->n_b = n_b;
+  ctx->n_o = n_o;
+  ctx->has_scan = true;
+  return 0;
+}
+
+int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                           const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o)
+{
+  return upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, true);
+}
+
+int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_match_ratio,
+                              float* d_beam)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_measure(ctx, d_pose, n_p, d_lik, d_match_ratio, d_beam, false, nullptr);
+}
+
+int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, double* stats6)
+{
+  if (!ctx || !stats6)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_measure(ctx, d_pose, n_p, nullptr, nullptr, nullptr, true, stats6);
+}
+
+int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, const float* d_lik, const float* d_beam,
+                                 const float* d_extra, const float* d_match_ratio, size_t n_p, int rank, int world,
+                                 double* d_packed)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad particle count");
+  if (world < 1 || rank < 0 || rank >= world || world > 4096)
+    return ctx->fail(-3, "bad rank/world (%d/%d)", rank, world);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int nb = pf_blocks(n_p);
+  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * nb));
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  hipLaunchKernelGGL(pf_partial_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
+                     d_match_ratio, static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
+  hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank,
+                     world, d_packed);
+  if (ctx->strict_order && world == 1)
+    hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->wnew.as<float>(),
+                       static_cast<int>(n_p), d_packed);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_t n_p, int world,
+                               const double* d_packed, float* d_stats4)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad particle count");
+  if (world < 1 || world > 4096)
+    return ctx->fail(-3, "bad world size %d", world);
+  HIP_TRY(hipSetDevice(ctx->device));
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight_inout,
+                     ctx->wnew.as<float>(), static_cast<int>(n_p), world, d_packed, d_stats4);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- host entry points -------------------------------------------------------------------------------------
+namespace
+{
+int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
+                   float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
+{
+  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
+  TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4));
+  return 0;
+}
+
+void drop_graph(mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->graph_exec)
+    (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph)
+    (void)hipGraphDestroy(ctx->graph);
+  ctx->graph_exec = nullptr;
+  ctx->graph = nullptr;
+}
+}  // namespace
+
+int mcl3dl_hip_update_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight_inout,
+                             const float* d_extra, float* d_lik, float* d_match_ratio, float* d_beam, float* d_stats4)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad particle count");
+  if (!d_pose || !d_weight_inout || !d_stats4)
+    return ctx->fail(-3, "null pose / weight / stats array");
+  if (!ctx->has_scan)
+    return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t fb = sizeof(float) * n_p;
+  if (!d_lik)
+  {
+    TRY(ensure(ctx, ctx->lik, fb));
+    d_lik = ctx->lik.as<float>();
+  }
+  if (!d_match_ratio)
+  {
+    TRY(ensure(ctx, ctx->ratio, fb));
+    d_match_ratio = ctx->ratio.as<float>();
+  }
+  if (!d_beam)
+  {
+    TRY(ensure(ctx, ctx->beam, fb));
+    d_beam = ctx->beam.as<float>();
+  }
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  mcl3dl_hip_ctx::UpdateKey key{};
+  key.p[0] = d_pose;
+  key.p[1] = d_weight_inout;
+  key.p[2] = d_extra;
+  key.p[3] = d_lik;
+  key.p[4] = d_match_ratio;
+  key.p[5] = d_beam;
+  key.p[6] = d_stats4;
+  key.p[7] = ctx->stream;
+  key.n_p = n_p;
+  key.generation = ctx->generation;
+  const bool graphs = ctx->use_graph && !ctx->timing;
+  if (graphs && ctx->graph_exec && ctx->graph_key == key)
+  {
+    HIP_TRY(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    ++ctx->graph_replays;
+    return 0;
+  }
+  // First sighting of these arguments: run eagerly (this is also what builds the map structures and sizes every work
+  // buffer). Second sighting: nothing is left to build or allocate, so the same calls can be captured.
+  // (the structure checks mirror ensure_structures / launch_measure: whatever this update needs must already exist)
+  const bool need_lik = ctx->n_s > 0, need_dda = ctx->n_b > 0;
+  const bool built = ctx->has_map && !(need_lik && ctx->lik_index == 0 && ctx->lik_dirty) &&
+                     !(need_lik && ctx->lik_index >= 1 && ctx->cand_dirty) &&
+                     !(need_dda && (ctx->dda_dirty || ctx->pow_table_dirty));
+  const bool capture = graphs && built && ctx->have_seen && ctx->seen_key == key &&
+                       !(ctx->have_failed && ctx->failed_key == key);
+  if (!capture)
+  {
+    TRY(enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4));
+    // enqueue_update may itself have moved the generation on (first-use allocations): remember the state it left
+    key.generation = ctx->generation;
+    ctx->seen_key = key;
+    ctx->have_seen = true;
+    return 0;
+  }
+  drop_graph(ctx);
+  HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
+  hipGraph_t g = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(ctx->stream, &g);
+  bool ok = rc == 0 && e_end == hipSuccess && g != nullptr && ctx->generation == key.generation;
+  if (ok)
+  {
+    ctx->graph = g;
+    ok = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+  }
+  else if (g)
+    (void)hipGraphDestroy(g);
+  if (!ok)
+  {
+    // not capturable in this state (e.g. a buffer had to grow): forget it and run the plain sequence
+    const hipError_t e_last = hipGetLastError();
+    char why[256];
+    snprintf(why, sizeof(why), "update graph not captured: rc=%d end=%s last=%s graph=%p generation %llu -> %llu", rc,
+             hipGetErrorString(e_end), hipGetErrorString(e_last), static_cast<void*>(g),
+             static_cast<unsigned long long>(key.generation), static_cast<unsigned long long>(ctx->generation));
+    ctx->graph_note = why;
+    drop_graph(ctx);
+    ctx->failed_key = key;
+    ctx->have_failed = true;
+    return enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
+  }
+  ctx->graph_key = key;
+  ++ctx->graph_captures;
+  HIP_TRY(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+  ++ctx->graph_replays;
+  return 0;
+}
+
+const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx)
+{
+  return ctx ? ctx->graph_note.c_str() : "";
+}
+
+int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* replays)
+{
+  if (!ctx)
+    return -1;
+  if (captures)
+    *captures = ctx->graph_captures;
+  if (replays)
+    *replays = ctx->graph_replays;
+  return 0;
+}
+
+int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
+                             const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
+                             const float* origins, size_t n_o, float* out_lik, float* out_match_ratio, float* out_beam)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0)
+    return 0;
+  if (!pose)
+    return ctx->fail(-3, "null pose array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
+  TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
+  TRY(ensure(ctx, ctx->lik, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->ratio, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->beam, sizeof(float) * n_p));
+  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  const bool lik_wanted = out_lik || out_match_ratio;
+  TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? ctx->lik.as<float>() : nullptr,
+                     lik_wanted ? ctx->ratio.as<float>() : nullptr, out_beam ? ctx->beam.as<float>() : nullptr, false,
+                     nullptr));
+  if (out_lik)
+    TRY(d2h(ctx, out_lik, ctx->lik.p, sizeof(float) * n_p));
+  if (out_match_ratio)
+    TRY(d2h(ctx, out_match_ratio, ctx->ratio.p, sizeof(float) * n_p));
+  if (out_beam)
+    TRY(d2h(ctx, out_beam, ctx->beam.p, sizeof(float) * n_p));
+  TRY(sync_stream(ctx));
+  return 0;
+}
+
+int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float* lik, const float* beam,
+                          const float* extra, const float* match_ratio, size_t n_p, float* entropy,
+                          float* match_ratio_min, float* match_ratio_max, int* restored)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0)
+    return ctx->fail(-3, "no particles");
+  if (!weight_inout || !lik)
+    return ctx->fail(-3, "null weight / likelihood array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t fb = sizeof(float) * n_p;
+  TRY(ensure(ctx, ctx->weightb, fb));
+  TRY(ensure(ctx, ctx->lik, fb));
+  TRY(ensure(ctx, ctx->beam, fb));
+  TRY(ensure(ctx, ctx->extra, fb));
+  TRY(ensure(ctx, ctx->ratio, fb));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
+  TRY(h2d(ctx, ctx->weightb.p, weight_inout, fb));
+  TRY(h2d(ctx, ctx->lik.p, lik, fb));
+  if (beam)
+    TRY(h2d(ctx, ctx->beam.p, beam, fb));
+  if (extra)
+    TRY(h2d(ctx, ctx->extra.p, extra, fb));
+  if (match_ratio)
+    TRY(h2d(ctx, ctx->ratio.p, match_ratio, fb));
+  TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(),
+                                   beam ? ctx->beam.as<float>() : nullptr, extra ? ctx->extra.as<float>() : nullptr,
+                                   match_ratio ? ctx->ratio.as<float>() : nullptr, n_p, 0, 1, ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, 1, ctx->partial4.as<double>(),
+                                 ctx->stats4.as<float>()));
+  float st[4];
+  TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
+  TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));
+  TRY(sync_stream(ctx));
+  if (entropy)
+    *entropy = st[0];
+  if (match_ratio_min)
+    *match_ratio_min = st[1];
+  if (match_ratio_max)
+    *match_ratio_max = st[2];
+  if (restored)
+    *restored = st[3] != 0.0f;
+  return 0;
+}
+
+int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout,
+                              size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                              const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                              float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
+                              float* match_ratio_min, float* match_ratio_max, int* restored)
+{
+  if (!ctx)
+    return -1;
+  if (n_p == 0)
+    return ctx->fail(-3, "no particles");
+  if (!pose || !weight_inout)
+    return ctx->fail(-3, "null pose / weight array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t fb = sizeof(float) * n_p;
+  TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
+  TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
+  TRY(ensure(ctx, ctx->weightb, fb));
+  TRY(ensure(ctx, ctx->lik, fb));
+  TRY(ensure(ctx, ctx->ratio, fb));
+  TRY(ensure(ctx, ctx->beam, fb));
+  TRY(ensure(ctx, ctx->extra, fb));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
+  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  TRY(h2d(ctx, ctx->weightb.p, weight_inout, fb));
+  if (extra)
+    TRY(h2d(ctx, ctx->extra.p, extra, fb));
+  TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, ctx->lik.as<float>(), ctx->ratio.as<float>(),
+                     ctx->beam.as<float>(), false, nullptr));
+  TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
+                                   extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p, 0, 1,
+                                   ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, 1, ctx->partial4.as<double>(),
+                                 ctx->stats4.as<float>()));
+  float st[4];
+  TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
+  TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));
+  if (out_lik)
+    TRY(d2h(ctx, out_lik, ctx->lik.p, fb));
+  if (out_match_ratio)
+    TRY(d2h(ctx, out_match_ratio, ctx->ratio.p, fb));
+  if (out_beam)
+    TRY(d2h(ctx, out_beam, ctx->beam.p, fb));
+  TRY(sync_stream(ctx));
+  if (entropy)
+    *entropy = st[0];
+  if (match_ratio_min)
+    *match_ratio_min = st[1];
+  if (match_ratio_max)
+    *match_ratio_max = st[2];
+  if (restored)
+    *restored = st[3] != 0.0f;
+  return 0;
+}
+
+int mcl3dl_hip_beam_status(mcl3dl_hip_ctx* ctx, const float* begin_xyz, const float* end_xyz, size_t n, int32_t* status,
+                           int32_t* hit_index)
+{
+  if (!ctx)
+    return -1;
+  if (n == 0)
+    return 0;
+  if (!begin_xyz || !end_xyz || !status)
+    return ctx->fail(-3, "null ray array");
+  if (n > 0x7fffffffu)
+    return ctx->fail(-3, "too many rays");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure_structures(ctx, false, true));
+  TRY(ensure(ctx, ctx->ray_begin, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->ray_end, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->ray_status, sizeof(int) * n));
+  TRY(ensure(ctx, ctx->ray_hit, sizeof(int) * n));
+  TRY(h2d(ctx, ctx->ray_begin.p, begin_xyz, sizeof(float) * 3 * n));
+  TRY(h2d(ctx, ctx->ray_end.p, end_xyz, sizeof(float) * 3 * n));
+  const int ni = static_cast<int>(n);
+  hipLaunchKernelGGL(beam_status_kernel, dim3((ni + 63) / 64), dim3(64), 0, ctx->stream, ctx->ray_begin.as<float>(),
+                     ctx->ray_end.as<float>(), ni, ctx->dg, beam_params(ctx), ctx->ray_status.as<int>(),
+                     ctx->ray_hit.as<int>());
+  HIP_TRY(hipGetLastError());
+  TRY(d2h(ctx, status, ctx->ray_status.p, sizeof(int) * n));
+  if (hit_index)
+    TRY(d2h(ctx, hit_index, ctx->ray_hit.p, sizeof(int) * n));
+  TRY(sync_stream(ctx));
+  return 0;
+}
+
+int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* end3, float* out_xyz, int max_out,
+                         int* n_visited, int* collided, int* hit_index)
+{
+  if (!ctx)
+    return -1;
+  if (!begin3 || !end3 || max_out < 0 || (max_out > 0 && !out_xyz))
+    return ctx->fail(-3, "bad trace arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure_structures(ctx, false, true));
+  TRY(ensure(ctx, ctx->ray_begin, sizeof(float) * 3 * static_cast<size_t>(max_out)));
+  TRY(ensure(ctx, ctx->ray_status, sizeof(int) * 3));
+  hipLaunchKernelGGL(dda_trace_kernel, dim3(1), dim3(64), 0, ctx->stream, Vec3f{ begin3[0], begin3[1], begin3[2] },
+                     Vec3f{ end3[0], end3[1], end3[2] }, ctx->dg, beam_params(ctx), ctx->ray_begin.as<float>(), max_out,
+                     ctx->ray_status.as<int>());
+  HIP_TRY(hipGetLastError());
+  int out3[3] = { 0, 0, -1 };
+  TRY(d2h(ctx, out3, ctx->ray_status.p, sizeof(out3)));
+  TRY(sync_stream(ctx));
+  const int n_copy = std::min(out3[0], max_out);
+  if (n_copy > 0)
+  {
+    TRY(d2h(ctx, out_xyz, ctx->ray_begin.p, sizeof(float) * 3 * static_cast<size_t>(n_copy)));
+    TRY(sync_stream(ctx));
+  }
+  if (n_visited)
+    *n_visited = out3[0];
+  if (collided)
+    *collided = out3[1];
+  if (hit_index)
+    *hit_index = out3[2];
+  return 0;
+}
+
+// ---- R4 as a stand-alone query: ChunkedKdtree::radiusSearch -------------------------------------------------------------
+int mcl3dl_hip_radius_search(mcl3dl_hip_ctx* ctx, const float* query_xyz, size_t n, float radius, int32_t* out_index,
+                             float* out_sqdist)
+{
+  if (!ctx)
+    return -1;
+  if (n == 0)
+    return 0;
+  if (!query_xyz || !out_index || n > 0x7fffffffu || !(radius > 0.f))
+    return ctx->fail(-3, "bad arguments to radius_search");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure_structures(ctx, true, false, true));  // the cell-sorted map
+  const float cell = 1.0f / ctx->lg.inv_cell;
+  const int reach = static_cast<int>(std::ceil(radius / cell)) + 1;
+  if (reach > 64)
+    return ctx->fail(-3, "radius %.3g is more than 64 cells of the map index", radius);
+  TRY(ensure(ctx, ctx->ray_begin, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->ray_hit, sizeof(int) * n));
+  TRY(ensure(ctx, ctx->ray_end, sizeof(float) * n));
+  TRY(h2d(ctx, ctx->ray_begin.p, query_xyz, sizeof(float) * 3 * n));
+  const LikParams lp = lik_params(ctx);
+  const float r2 = static_cast<float>(static_cast<double>(radius) * static_cast<double>(radius));
+  const int ni = static_cast<int>(n);
+  hipLaunchKernelGGL(radius_search_kernel, dim3((ni + 63) / 64), dim3(64), 0, ctx->stream, ctx->ray_begin.as<float>(), ni,
+                     ctx->lg, lp, radius, r2, reach, ctx->ray_hit.as<int>(), ctx->ray_end.as<float>());
+  HIP_TRY(hipGetLastError());
+  TRY(d2h(ctx, out_index, ctx->ray_hit.p, sizeof(int) * n));
+  if (out_sqdist)
+    TRY(d2h(ctx, out_sqdist, ctx->ray_end.p, sizeof(float) * n));
+  TRY(sync_stream(ctx));
+  return 0;
+}
+

@@ -1,0 +1,129 @@
+// api_support.inl — included inside the extern "C" block of mcl3dl_hip.hip: kernel timing, footprint, options.
+// ---- measurement support ---------------------------------------------------------------------------------------
+int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable)
+{
+  if (!ctx)
+    return -1;
+  ++ctx->generation;
+  TRY(timing_collect(ctx));
+  ctx->timing = enable != 0;
+  return 0;
+}
+
+int mcl3dl_hip_get_kernel_time(mcl3dl_hip_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches)
+{
+  if (!ctx)
+    return -1;
+  if (kernel_id < 0 || kernel_id >= MCL3DL_KERNEL_COUNT)
+    return ctx->fail(-3, "bad kernel id");
+  TRY(timing_collect(ctx));
+  if (total_ms)
+    *total_ms = ctx->kernel_ms[kernel_id];
+  if (launches)
+    *launches = ctx->kernel_launches[kernel_id];
+  return 0;
+}
+
+int mcl3dl_hip_reset_kernel_time(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return -1;
+  TRY(timing_collect(ctx));
+  for (int k = 0; k < MCL3DL_KERNEL_COUNT; ++k)
+  {
+    ctx->kernel_ms[k] = 0;
+    ctx->kernel_launches[k] = 0;
+  }
+  return 0;
+}
+
+int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8)
+{
+  if (!ctx || !bytes8)
+    return -1;
+  for (int i = 0; i < 8; ++i)
+    bytes8[i] = ctx->footprint[i];
+  return 0;
+}
+
+int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
+{
+  if (!ctx || !name)
+    return -1;
+  ++ctx->generation;
+  const std::string key(name);
+  if (key == "lik_index")
+  {
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return ctx->fail(-3, "lik_index must be 0 (27-cell scan), 1 (candidate runs) or 2 (candidate records)");
+    if ((value == 0.0) != (ctx->lik_index == 0) || static_cast<int>(value) != ctx->lik_index)
+      ctx->cand_dirty = true;
+    ctx->lik_index = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "cand_voxel_ratio")
+  {
+    if (!(value >= 0.125 && value <= 2.0))
+      return ctx->fail(-3, "cand_voxel_ratio must be in [0.125, 2]");
+    if (value != ctx->cand_voxel_ratio)
+      ctx->cand_dirty = true;
+    ctx->cand_voxel_ratio = value;
+    return 0;
+  }
+  if (key == "strict_order")
+  {
+    ctx->strict_order = value != 0.0;
+    return 0;
+  }
+  if (key == "timing_mask")
+  {
+    ctx->timing_mask = static_cast<unsigned>(value);
+    return 0;
+  }
+  if (key == "use_graph")
+  {
+    ctx->use_graph = value != 0.0;
+    return 0;
+  }
+  if (key == "overlap_models")
+  {
+    ctx->overlap_models = value != 0.0;
+    return 0;
+  }
+  if (key == "lik_small")
+  {
+    ctx->lik_small = value != 0.0;
+    return 0;
+  }
+  if (key == "lik_tiled")
+  {
+    ctx->lik_tiled = value != 0.0;
+    return 0;
+  }
+  if (key == "lik_group")
+  {
+    if (value != 8.0 && value != 16.0 && value != 32.0)
+      return ctx->fail(-3, "lik_group must be 8, 16 or 32");
+    ctx->lik_group = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "cand_phase")
+  {
+    if (!(value >= 0.0 && value < 1.0))
+      return ctx->fail(-3, "cand_phase must be in [0, 1)");
+    if (value != ctx->cand_phase)
+      ctx->cand_dirty = true;
+    ctx->cand_phase = value;
+    return 0;
+  }
+  return ctx->fail(-3, "unknown option '%s'", name);
+}
+
+int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4)
+{
+  if (!ctx || !stats4)
+    return -1;
+  for (int i = 0; i < 4; ++i)
+    stats4[i] = ctx->cand_stats[i];
+  return 0;
+}

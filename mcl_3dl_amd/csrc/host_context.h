@@ -1,0 +1,349 @@
+// host_context.h — part of the single translation unit mcl3dl_hip.hip (included there, nowhere else): the context
+// object behind mcl3dl_hip_ctx, error macros, device-buffer / staging helpers, hipEvent kernel timing.
+#pragma once
+
+namespace
+{
+struct DevBuf
+{
+  void* p = nullptr;
+  size_t cap = 0;
+  template <typename T>
+  T* as() const
+  {
+    return static_cast<T*>(p);
+  }
+};
+
+struct EventPair
+{
+  hipEvent_t start, stop;
+  int kernel;
+};
+}  // namespace
+
+struct mcl3dl_hip_ctx
+{
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // The two LiDAR models are independent until pf::measure: the beam kernels run on a second stream, forked from and
+  // joined back into `stream` with events, so their (VALU-heavy, memory-light) waves fill the slots the likelihood
+  // kernel leaves idle while it waits on L2.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int overlap_models = 1;
+  std::string err;
+
+  // host copy of the map (kept to rebuild the device structures when parameters change)
+  std::vector<float> map_xyz;
+  std::vector<uint32_t> map_label;
+  uint64_t stamp = 0;
+  bool has_map = false;
+  bool has_weight = false;
+  float weight[3] = { 1.f, 1.f, 1.f };
+
+  // LidarMeasurementModelLikelihoodParameters defaults, include/mcl_3dl/parameters.h:74-76
+  float match_dist_min = 0.2f, match_dist_flat = 0.05f, match_weight = 5.0f;
+  // LidarMeasurementModelBeamParameters defaults, include/mcl_3dl/parameters.h:96-112
+  float map_grid[3] = { 0.1f, 0.1f, 0.1f };
+  float dda_grid_size = 0.2f;
+  float ray_angle_half = static_cast<float>(0.25 * M_PI / 180.0);
+  float hit_range = 0.3f;
+  float beam_likelihood_min = 0.2f;
+  uint32_t beam_num_points = 3;
+  float ang_total_ref = static_cast<float>(M_PI / 6.0);
+  uint32_t filter_label_max = 0xFFFFFFFFu;
+  int short_only = 1;
+  // derived, src/lidar_measurement_model_beam.cpp:65-67
+  float hit_range_sq = 0, beam_likelihood = 0, sin_total_ref = 0;
+
+  bool lik_dirty = true, dda_dirty = true, cand_dirty = true;
+  DevBuf lik_pts, lik_cells;
+  LikGrid lg{};
+  // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
+  int lik_index = 2;
+  int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
+  int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
+  int lik_group = 16;      // particles per work-group of the tiled kernel (16 or 32)
+  DevBuf lik_partial_sum, lik_partial_cnt;
+  int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
+  DevBuf scan_perm, strict_terms;
+  double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
+  double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
+  DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
+  CandGrid cg{};
+  RecGrid rg{};
+  double cand_stats[4] = { 0, 0, 0, 0 };  // bricks, voxels with candidates, candidates, build ms
+  DevBuf dda_bits, dda_start, dda_pts, dda_index;
+  DdaGrid dg{};
+  uint64_t footprint[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+
+  // scans of the current update
+  DevBuf scan_lik, scan_beam, origins, pow_table;
+  size_t n_s = 0, n_b = 0, n_o = 0;
+  bool has_scan = false;
+  bool pow_table_dirty = true;
+
+  // work buffers
+  DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
+      tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset;
+
+  // resampling plan
+  std::vector<float> rs_keys;        // accumulated probabilities, in particles_dup_ order after std::sort
+  std::vector<uint32_t> rs_order;    // which particle sits at each position of particles_dup_
+  std::vector<uint32_t> rs_source, rs_slot;
+  size_t rs_n = 0, rs_n_out = 0, rs_n_dup = 0;
+  float rs_pstep = 0.f;
+  bool rs_planned = false;
+  DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out, rs_d_order, rs_d_flag,
+      rs_d_ws, rs_d_dup8;
+  bool rs_sorted = false;  // std::sort had ties to order: rs_order is not the identity
+
+  // mcl3dl_hip_update_device: the launch sequence of one device-resident update, captured into a hipGraph the second
+  // time the same arguments arrive and replayed afterwards (small updates are launch-bound: 8-10 launches of a few
+  // microseconds each). `generation` counts everything that can change what gets enqueued — parameters, options, map,
+  // stream, scan sizes, any device buffer that had to be reallocated.
+  uint64_t generation = 0;
+  int use_graph = 0;
+  struct UpdateKey
+  {
+    const void* p[8];
+    size_t n_p;
+    uint64_t generation;
+    bool operator==(const UpdateKey& o) const
+    {
+      return memcmp(p, o.p, sizeof(p)) == 0 && n_p == o.n_p && generation == o.generation;
+    }
+  };
+  UpdateKey graph_key{}, seen_key{}, failed_key{};
+  bool have_seen = false, have_failed = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  uint64_t graph_replays = 0, graph_captures = 0;
+  std::string graph_note;  // why the last capture attempt fell back to plain launches (diagnostics)
+
+  // Pinned staging for the host-buffer entry points: small copies go through page-locked memory so that
+  // hipMemcpyAsync really is asynchronous (a pageable copy costs a driver-side staging round trip each); results are
+  // handed to the caller's arrays when the stream is synchronised (sync_stream).
+  struct StageChunk
+  {
+    char* p;
+    size_t cap;
+  };
+  struct StagedResult
+  {
+    void* user;
+    const void* staged;
+    size_t bytes;
+  };
+  std::vector<StageChunk> stage;
+  size_t stage_cur = 0, stage_off = 0;
+  std::vector<StagedResult> stage_out;
+  // host-side scan staging (kept in the context so that it outlives the asynchronous copies)
+  std::vector<float4> h_scan_lik, h_scan_beam, h_origins;
+  std::vector<uint32_t> h_scan_perm;
+
+  // timing
+  bool timing = false;
+  unsigned timing_mask = 0xffffffffu;  // bit k = time kernel group k (MCL3DL_KERNEL_*); each timed group costs two event records
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> free_events;
+  double kernel_ms[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
+  uint64_t kernel_launches[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
+
+  int fail(int code, const char* fmt, ...)
+  {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+    stage_out.clear();  // results of a failed call are not delivered (their destinations may be gone)
+    return code;
+  }
+};
+
+namespace
+{
+#define HIP_TRY(expr)                                                                            \
+  do                                                                                             \
+  {                                                                                              \
+    const hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                        \
+      return ctx->fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define TRY(expr)        \
+  do                     \
+  {                      \
+    const int r_ = (expr); \
+    if (r_ != 0)         \
+      return r_;         \
+  } while (0)
+
+inline float bits_to_float(uint32_t u)
+{
+  float f;
+  memcpy(&f, &u, sizeof(f));
+  return f;
+}
+
+int ensure(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t bytes)
+{
+  if (bytes == 0)
+    bytes = 16;
+  if (b.cap >= bytes)
+    return 0;
+  if (b.p)
+  {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t cap = bytes + bytes / 4;
+  HIP_TRY(hipMalloc(&b.p, cap));
+  b.cap = cap;
+  ++ctx->generation;  // a captured update graph holds the old address
+  return 0;
+}
+
+constexpr size_t STAGE_MAX_COPY = 4u << 20;  // larger copies go straight from / to the caller's (pageable) memory
+
+// bump allocation in page-locked chunks; everything is released for reuse by sync_stream. nullptr = allocation failed
+// (the caller then falls back to a direct copy).
+void* stage_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
+{
+  bytes = (bytes + 255) & ~static_cast<size_t>(255);
+  while (ctx->stage_cur < ctx->stage.size())
+  {
+    mcl3dl_hip_ctx::StageChunk& ch = ctx->stage[ctx->stage_cur];
+    if (ctx->stage_off + bytes <= ch.cap)
+    {
+      void* p = ch.p + ctx->stage_off;
+      ctx->stage_off += bytes;
+      return p;
+    }
+    ++ctx->stage_cur;
+    ctx->stage_off = 0;
+  }
+  const size_t last = ctx->stage.empty() ? (512u << 10) : ctx->stage.back().cap;
+  const size_t cap = std::max(bytes, 2 * last);
+  void* p = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  ctx->stage.push_back({ static_cast<char*>(p), cap });
+  ctx->stage_cur = ctx->stage.size() - 1;
+  ctx->stage_off = bytes;
+  return p;
+}
+
+int h2d(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  if (bytes == 0)
+    return 0;
+  if (bytes <= STAGE_MAX_COPY)
+  {
+    if (void* p = stage_alloc(ctx, bytes))
+    {
+      memcpy(p, src, bytes);
+      HIP_TRY(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return 0;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// The data is in `dst` only after sync_stream().
+int d2h(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  if (bytes == 0)
+    return 0;
+  if (bytes <= STAGE_MAX_COPY)
+  {
+    if (void* p = stage_alloc(ctx, bytes))
+    {
+      HIP_TRY(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->stage_out.push_back({ dst, p, bytes });
+      return 0;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+// hipStreamSynchronize + hand the staged results to the caller's arrays + recycle the staging memory.
+int sync_stream(mcl3dl_hip_ctx* ctx)
+{
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (const mcl3dl_hip_ctx::StagedResult& r : ctx->stage_out)
+    memcpy(r.user, r.staged, r.bytes);
+  ctx->stage_out.clear();
+  ctx->stage_cur = 0;
+  ctx->stage_off = 0;
+  return 0;
+}
+
+// ---- timing -----------------------------------------------------------------------------------------
+int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep, hipStream_t on = nullptr)
+{
+  if (!on)
+    on = ctx->stream;
+  ep->start = nullptr;
+  if (!ctx->timing || !(ctx->timing_mask & (1u << kernel)))
+    return 0;
+  hipEvent_t ev[2];
+  for (int i = 0; i < 2; ++i)
+  {
+    if (!ctx->free_events.empty())
+    {
+      ev[i] = ctx->free_events.back();
+      ctx->free_events.pop_back();
+    }
+    else
+    {
+      HIP_TRY(hipEventCreate(&ev[i]));
+    }
+  }
+  ep->start = ev[0];
+  ep->stop = ev[1];
+  ep->kernel = kernel;
+  HIP_TRY(hipEventRecord(ep->start, on));
+  return 0;
+}
+
+int timing_end(mcl3dl_hip_ctx* ctx, const EventPair& ep, hipStream_t on = nullptr)
+{
+  if (!ctx->timing || !ep.start)
+    return 0;
+  HIP_TRY(hipEventRecord(ep.stop, on ? on : ctx->stream));
+  ctx->pending.push_back(ep);
+  return 0;
+}
+
+int timing_collect(mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->pending.empty())
+    return 0;
+  TRY(sync_stream(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+  for (const EventPair& ep : ctx->pending)
+  {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+    ctx->kernel_ms[ep.kernel] += ms;
+    ctx->kernel_launches[ep.kernel] += 1;
+    ctx->free_events.push_back(ep.start);
+    ctx->free_events.push_back(ep.stop);
+  }
+  ctx->pending.clear();
+  return 0;
+}
+
+}  // namespace

@@ -1,0 +1,467 @@
+// host_map_compilers.h — part of the single translation unit mcl3dl_hip.hip: host drivers of the three map structures
+// (cell-sorted exact-NN grid, DDA occupancy bricks + voxel index, candidate-voxel records; device side in
+// map_compiler.h) and the device prefix scans they share.
+#pragma once
+
+namespace
+{
+// ---- map compiler: exact-NN grid -----------------------------------------------------------------------
+// Replaces ChunkedKdtree::setInputCloud + pcl::KdTreeFLANN::setInputCloud.  The reference's chunking is a memory
+// device (20 m chunks with duplicated margins, chunked_kdtree.h:124-216) whose query result equals the global
+// nearest neighbour within the radius whenever radius <= max_search_radius; the grid gives that result directly.
+int build_lik_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const float cell = ctx->match_dist_min * 1.01f;
+  if (!(cell > 0.f) || !std::isfinite(cell))
+    return ctx->fail(-3, "match_dist_min must be positive and finite");
+  const float inv = 1.0f / cell;
+  std::vector<float> s(3 * n);
+  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a)
+    {
+      // PointRepresentation::vectorize: one float product per coordinate
+      const float v = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
+      if (!std::isfinite(v))
+        return ctx->fail(-3, "map point %zu is not finite", i);
+      s[3 * i + a] = v;
+      if (i == 0 || v < mn[a])
+        mn[a] = v;
+      if (i == 0 || v > mx[a])
+        mx[a] = v;
+    }
+  float o[3];
+  int dim[3];
+  double total = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    o[a] = mn[a] - 2.0f * cell;
+    dim[a] = static_cast<int>(floorf((mx[a] - o[a]) * inv)) + 3;
+    total *= dim[a];
+  }
+  if (total > 3.0e9)
+    return ctx->fail(-4, "likelihood grid would need %.3g cells (map extent too large for the dense index)", total);
+  const size_t ncell = static_cast<size_t>(dim[0]) * dim[1] * dim[2];
+  std::vector<uint32_t> cell_of(n);
+  std::vector<uint32_t> start(ncell + 1, 0);
+  for (size_t i = 0; i < n; ++i)
+  {
+    int c[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      c[a] = static_cast<int>(floorf((s[3 * i + a] - o[a]) * inv));  // same expression as the kernel's
+      c[a] = std::min(std::max(c[a], 0), dim[a] - 1);
+    }
+    cell_of[i] = static_cast<uint32_t>((static_cast<size_t>(c[2]) * dim[1] + c[1]) * dim[0] + c[0]);
+    ++start[cell_of[i] + 1];
+  }
+  for (size_t c = 0; c < ncell; ++c)
+    start[c + 1] += start[c];
+  std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+  std::vector<float4> pts(n);
+  for (size_t i = 0; i < n; ++i)
+  {
+    const uint32_t dst = fill[cell_of[i]]++;
+    pts[dst] = make_float4(s[3 * i], s[3 * i + 1], s[3 * i + 2], bits_to_float(static_cast<uint32_t>(i)));
+  }
+  TRY(ensure(ctx, ctx->lik_pts, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->lik_cells, sizeof(uint32_t) * (ncell + 1)));
+  TRY(h2d(ctx, ctx->lik_pts.p, pts.data(), sizeof(float4) * n));
+  TRY(h2d(ctx, ctx->lik_cells.p, start.data(), sizeof(uint32_t) * (ncell + 1)));
+  TRY(sync_stream(ctx));
+  ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
+  ctx->lg.pts = ctx->lik_pts.as<float4>();
+  ctx->lg.ox = o[0];
+  ctx->lg.oy = o[1];
+  ctx->lg.oz = o[2];
+  ctx->lg.inv_cell = inv;
+  ctx->lg.nx = dim[0];
+  ctx->lg.ny = dim[1];
+  ctx->lg.nz = dim[2];
+  ctx->footprint[0] = sizeof(float4) * n;
+  ctx->footprint[1] = sizeof(uint32_t) * (ncell + 1);
+  ctx->lik_dirty = false;
+  return 0;
+}
+
+// ---- map compiler: DDA occupancy -------------------------------------------------------------------------
+// RaycastUsingDDA::updatePointCloud / setExists, include/mcl_3dl/raycasts/raycast_using_dda.h:162-190,230-235:
+// AABB by getMinMax3D, map_size = (size_t)((max-min)/grid)+1, voxel = trunc((p-min)/grid) (float difference,
+// double division), x-fastest array index; per voxel the points stay in insertion (map) order.
+int build_dda_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const double grid = static_cast<double>(ctx->dda_grid_size);
+  if (!(grid > 0))
+    return ctx->fail(-3, "dda_grid_size must be positive");
+  float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a)
+    {
+      const float v = ctx->map_xyz[3 * i + a];
+      if (v < mn[a])
+        mn[a] = v;
+      if (v > mx[a])
+        mx[a] = v;
+    }
+  int dim[3];
+  double total_d = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    dim[a] = static_cast<int>(static_cast<size_t>((mx[a] - mn[a]) / grid) + 1);
+    total_d *= dim[a];
+  }
+  if (total_d >= 2147483647.0)  // the reference keeps point_total in an int (raycast_using_dda.h:176)
+    return ctx->fail(-4, "DDA grid would need %.3g voxels (>= 2^31)", total_d);
+  const size_t total = static_cast<size_t>(total_d);
+  std::vector<uint32_t> vox(n);
+  std::vector<uint32_t> start(total + 1, 0);
+  const int bdim[3] = { (dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4 };
+  std::vector<unsigned long long> bits(static_cast<size_t>(bdim[0]) * bdim[1] * bdim[2], 0ull);
+  for (size_t i = 0; i < n; ++i)
+  {
+    int c[3];
+    for (int a = 0; a < 3; ++a)
+      c[a] = static_cast<int>(static_cast<double>(ctx->map_xyz[3 * i + a] - mn[a]) / grid);
+    const size_t v = static_cast<size_t>(c[0] + c[1] * dim[0] + c[2] * (dim[0] * dim[1]));
+    if (v >= total)
+      return ctx->fail(-3, "map point %zu falls outside its own DDA grid", i);
+    vox[i] = static_cast<uint32_t>(v);
+    ++start[v + 1];
+    const size_t brick = (static_cast<size_t>(c[2] >> 2) * bdim[1] + (c[1] >> 2)) * bdim[0] + (c[0] >> 2);
+    bits[brick] |= 1ull << (((c[2] & 3) << 4) | ((c[1] & 3) << 2) | (c[0] & 3));
+  }
+  for (size_t v = 0; v < total; ++v)
+    start[v + 1] += start[v];
+  std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+  std::vector<float4> pts(n);
+  std::vector<uint32_t> index(n);
+  for (size_t i = 0; i < n; ++i)  // ascending i: insertion order preserved inside a voxel
+  {
+    const uint32_t dst = fill[vox[i]]++;
+    pts[dst] = make_float4(ctx->map_xyz[3 * i], ctx->map_xyz[3 * i + 1], ctx->map_xyz[3 * i + 2],
+                           bits_to_float(ctx->map_label[i]));
+    index[dst] = static_cast<uint32_t>(i);
+  }
+  TRY(ensure(ctx, ctx->dda_bits, sizeof(unsigned long long) * bits.size()));
+  TRY(ensure(ctx, ctx->dda_start, sizeof(uint32_t) * (total + 1)));
+  TRY(ensure(ctx, ctx->dda_pts, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->dda_index, sizeof(uint32_t) * n));
+  TRY(h2d(ctx, ctx->dda_bits.p, bits.data(), sizeof(unsigned long long) * bits.size()));
+  TRY(h2d(ctx, ctx->dda_start.p, start.data(), sizeof(uint32_t) * (total + 1)));
+  TRY(h2d(ctx, ctx->dda_pts.p, pts.data(), sizeof(float4) * n));
+  TRY(h2d(ctx, ctx->dda_index.p, index.data(), sizeof(uint32_t) * n));
+  TRY(sync_stream(ctx));
+  DdaGrid& g = ctx->dg;
+  g.bricks = ctx->dda_bits.as<unsigned long long>();
+  g.bnx = bdim[0];
+  g.bny = bdim[1];
+  g.bnz = bdim[2];
+  g.mul24_ok = (bdim[0] < (1 << 24) && static_cast<long long>(bdim[1]) * bdim[2] < (1ll << 24)) ? 1 : 0;
+  g.vox_start = ctx->dda_start.as<uint32_t>();
+  g.pts = ctx->dda_pts.as<float4>();
+  g.pt_index = ctx->dda_index.as<uint32_t>();
+  g.min_x = mn[0];
+  g.min_y = mn[1];
+  g.min_z = mn[2];
+  g.max_x = mx[0];
+  g.max_y = mx[1];
+  g.max_z = mx[2];
+  g.nx = dim[0];
+  g.ny = dim[1];
+  g.nz = dim[2];
+  g.grid = grid;
+  g.ray_angle_half = static_cast<double>(ctx->ray_angle_half);
+  // RaycastUsingDDA ctor, raycast_using_dda.h:59: map_grid_size_y appears twice (reference quirk, kept)
+  const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];
+  g.min_dist_thr_sq = gx * gx + gy * gy + gy * gy;
+  g.hit_tolerance_f = static_cast<float>(static_cast<double>(ctx->hit_range));
+  ctx->footprint[2] = sizeof(unsigned long long) * bits.size();
+  ctx->footprint[3] = sizeof(uint32_t) * (total + 1);
+  ctx->footprint[4] = sizeof(float4) * n + sizeof(uint32_t) * n;
+  ctx->dda_dirty = false;
+  return 0;
+}
+
+// ---- map compiler: candidate-voxel index (device side in map_compiler.h) ------------------------------------------
+int device_exclusive_scan(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n)  // in place
+{
+  if (n <= 0)
+    return 0;
+  const long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* sums = nullptr;
+  if (tiles > 1)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sums), sizeof(uint32_t) * tiles));
+  hipLaunchKernelGGL(scan_tiles, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, ctx->stream, data, data, sums, n);
+  if (tiles > 1)
+  {
+    const int rc = device_exclusive_scan(ctx, sums, tiles);
+    if (rc == 0)
+      hipLaunchKernelGGL(scan_add_offsets, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                         data, sums, n);
+    TRY(sync_stream(ctx));
+    HIP_TRY(hipFree(sums));
+    if (rc != 0)
+      return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The same scan without allocation or synchronisation: `ws` holds the per-tile sums of every level
+// (>= n / 1023 + 4 entries).
+int device_exclusive_scan_ws(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n, uint32_t* ws)
+{
+  if (n <= 0)
+    return 0;
+  const long long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* sums = tiles > 1 ? ws : nullptr;
+  hipLaunchKernelGGL(scan_tiles, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, ctx->stream, data, data, sums, n);
+  if (tiles > 1)
+  {
+    TRY(device_exclusive_scan_ws(ctx, sums, tiles, ws + tiles));
+    hipLaunchKernelGGL(scan_add_offsets, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, data,
+                       sums, n);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+struct TempBuf
+{
+  void* p = nullptr;
+  ~TempBuf()
+  {
+    if (p)
+      (void)hipFree(p);
+  }
+};
+
+int build_cand_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const double r = static_cast<double>(ctx->match_dist_min);
+  const float e_f = static_cast<float>(r * ctx->cand_voxel_ratio);
+  if (!(e_f > 0.f) || !std::isfinite(e_f))
+    return ctx->fail(-3, "bad candidate voxel edge");
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, ctx->stream));
+  // rescaled points in map order (PointRepresentation::vectorize), w = original index
+  std::vector<float4> sp(n);
+  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+  for (size_t i = 0; i < n; ++i)
+  {
+    float v[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      v[a] = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
+      if (!std::isfinite(v[a]))
+        return ctx->fail(-3, "map point %zu is not finite", i);
+      if (i == 0 || v[a] < mn[a])
+        mn[a] = v[a];
+      if (i == 0 || v[a] > mx[a])
+        mx[a] = v[a];
+    }
+    sp[i] = make_float4(v[0], v[1], v[2], bits_to_float(static_cast<uint32_t>(i)));
+  }
+  CompileParams cp{};
+  cp.e = static_cast<double>(e_f);
+  cp.inv_e = 1.0f / e_f;
+  cp.grow = 1e-3 * cp.e;
+  const double r_hi = r * (1.0 + 1e-5);
+  cp.r2_hi = r_hi * r_hi;
+  cp.margin = 1e-5 * r * r;
+  cp.reach = static_cast<int>(std::floor((r_hi + cp.grow) / cp.e)) + 1;
+  cp.n_points = static_cast<int>(n);
+  float o[3];
+  int nv[3], nb[3];
+  double n_table_d = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    // Phase: maps that come out of a voxel filter sit on a lattice; with the origin ON that lattice every voxel face
+    // coincides with a Voronoi face of the map and each voxel keeps 3 candidates per axis instead of the 2 a generic
+    // position needs. Half a voxel of phase puts lattice maps in the generic position; arbitrary maps do not care.
+    o[a] = mn[a] - static_cast<float>((cp.reach + 1 + ctx->cand_phase) * cp.e);
+    nv[a] = static_cast<int>(std::floor((static_cast<double>(mx[a]) - o[a]) / cp.e)) + cp.reach + 2;
+    nb[a] = (nv[a] + 7) / 8;
+    n_table_d *= nb[a];
+  }
+  if (n_table_d > 2.0e9)
+    return ctx->fail(-4, "candidate index would need %.3g bricks in its dense table", n_table_d);
+  cp.ox = o[0];
+  cp.oy = o[1];
+  cp.oz = o[2];
+  cp.nvx = nv[0];
+  cp.nvy = nv[1];
+  cp.nvz = nv[2];
+  cp.nbx = nb[0];
+  cp.nby = nb[1];
+  cp.nbz = nb[2];
+  const long long n_table = static_cast<long long>(n_table_d);
+
+  TempBuf d_pts, d_flag, d_scan, d_d2, d_count, d_pstart, d_prelim, d_bxyz, d_total;
+  HIP_TRY(hipMalloc(&d_pts.p, sizeof(float4) * n));
+  TRY(h2d(ctx, d_pts.p, sp.data(), sizeof(float4) * n));
+  HIP_TRY(hipMalloc(&d_flag.p, sizeof(int) * n_table));
+  HIP_TRY(hipMalloc(&d_scan.p, sizeof(uint32_t) * (n_table + 1)));
+  HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(int) * n_table, ctx->stream));
+  const float4* pts = static_cast<const float4*>(d_pts.p);
+  hipLaunchKernelGGL(mc_mark_bricks, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, cp, pts,
+                     static_cast<int*>(d_flag.p));
+  HIP_TRY(hipMemsetAsync(d_scan.p, 0, sizeof(uint32_t) * (n_table + 1), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_scan.p, d_flag.p, sizeof(int) * n_table, hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_scan.p), n_table + 1));
+  uint32_t n_bricks = 0;
+  TRY(d2h(ctx, &n_bricks, static_cast<uint32_t*>(d_scan.p) + n_table, sizeof(uint32_t)));
+  TRY(sync_stream(ctx));
+  if (n_bricks == 0 || n_bricks > (1u << 22))
+    return ctx->fail(-4, "candidate index: %u bricks", n_bricks);
+  TRY(ensure(ctx, ctx->cand_table, sizeof(int) * n_table));
+  int* table = ctx->cand_table.as<int>();
+  hipLaunchKernelGGL(mc_brick_ids, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const int*>(d_flag.p), static_cast<const uint32_t*>(d_scan.p), table, n_table);
+  HIP_TRY(hipMalloc(&d_bxyz.p, sizeof(int) * 3 * n_bricks));
+  hipLaunchKernelGGL(mc_brick_coords, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
+                     table, cp.nbx, cp.nby, n_table, static_cast<int*>(d_bxyz.p));
+
+  const long long n_vox = static_cast<long long>(n_bricks) * 512;
+  const int side = 2 * cp.reach + 1;
+  const long long n_threads = static_cast<long long>(n) * side * side * side;
+  const unsigned blocks_t = static_cast<unsigned>((n_threads + 255) / 256);
+  if ((n_threads + 255) / 256 > 0x7fffffffLL)
+    return ctx->fail(-4, "candidate index: too many (point, voxel) pairs");
+  const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
+  HIP_TRY(hipMalloc(&d_d2.p, sizeof(uint32_t) * n_vox));
+  HIP_TRY(hipMalloc(&d_count.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMalloc(&d_pstart.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMalloc(&d_total.p, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(mc_fill_u32, dim3(blocks_v), dim3(256), 0, ctx->stream, static_cast<uint32_t*>(d_d2.p), 0x7f800000u,
+                     n_vox);
+  hipLaunchKernelGGL(mc_scatter_dmax, dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                     static_cast<uint32_t*>(d_d2.p), n_threads);
+  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  hipLaunchKernelGGL((mc_prelim<false>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                     static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
+                     static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n_threads);
+  // total preliminary candidates must fit the 32-bit run delimiters
+  unsigned long long total = 0;
+  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+                     n_vox, static_cast<unsigned long long*>(d_total.p));
+  TRY(d2h(ctx, &total, d_total.p, sizeof(total)));
+  TRY(sync_stream(ctx));
+  if (total >= 0xfffffff0ULL)
+    return ctx->fail(-4, "candidate index: %llu preliminary candidates exceed 32-bit offsets", total);
+  HIP_TRY(hipMemcpyAsync(d_pstart.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_pstart.p), n_vox + 1));
+  HIP_TRY(hipMalloc(&d_prelim.p, sizeof(uint32_t) * (total ? total : 1)));
+  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  hipLaunchKernelGGL((mc_prelim<true>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                     static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p), n_threads);
+  // prune; d_count becomes the kept count per voxel
+  hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, static_cast<const int*>(d_bxyz.p),
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
+                     static_cast<uint32_t*>(d_count.p), n_vox);
+  unsigned long long kept = 0;
+  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+                     n_vox, static_cast<unsigned long long*>(d_total.p));
+  TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
+  TRY(sync_stream(ctx));
+  if (ctx->lik_index == 2)
+  {
+    // fat records: overflow slots per voxel -> exclusive scan -> write
+    TempBuf d_ovf;
+    HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
+    HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+    hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox);
+    TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
+    uint32_t n_ovf = 0;
+    TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
+    TRY(sync_stream(ctx));
+    TRY(ensure(ctx, ctx->cand_rec, 64ull * static_cast<size_t>(n_vox)));
+    TRY(ensure(ctx, ctx->cand_ovf, 64ull * (n_ovf ? n_ovf : 1)));
+    HIP_TRY(hipMemsetAsync(ctx->cand_ovf.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
+    hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
+                       static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
+                       static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p),
+                       ctx->cand_rec.as<float>(), ctx->cand_ovf.as<float>(), n_vox);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, ctx->stream));
+    TRY(sync_stream(ctx));
+    float ms2 = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms2, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    RecGrid& g = ctx->rg;
+    g.brick_table = table;
+    g.rec = ctx->cand_rec.as<float4>();
+    g.ovf = ctx->cand_ovf.as<float4>();
+    g.ox = cp.ox;
+    g.oy = cp.oy;
+    g.oz = cp.oz;
+    g.inv_e = cp.inv_e;
+    g.nvx = cp.nvx;
+    g.nvy = cp.nvy;
+    g.nvz = cp.nvz;
+    g.nbx = cp.nbx;
+    g.nby = cp.nby;
+    g.nbz = cp.nbz;
+    g.mul24_ok = (static_cast<long long>(cp.nbx) * cp.nby < (1ll << 24) && cp.nbz < (1 << 24)) ? 1 : 0;
+    ctx->footprint[5] = sizeof(int) * n_table;
+    ctx->footprint[6] = 64ull * static_cast<size_t>(n_vox);
+    ctx->footprint[7] = 64ull * n_ovf;
+    ctx->cand_stats[0] = n_bricks;
+    ctx->cand_stats[1] = static_cast<double>(total);
+    ctx->cand_stats[2] = static_cast<double>(kept);
+    ctx->cand_stats[3] = ms2;
+    ctx->cand_dirty = false;
+    return 0;
+  }
+  TRY(ensure(ctx, ctx->cand_start, sizeof(uint32_t) * (n_vox + 1)));
+  TRY(ensure(ctx, ctx->cand_pts, sizeof(float4) * (kept ? kept : 1)));
+  HIP_TRY(hipMemsetAsync(static_cast<uint32_t*>(d_count.p) + n_vox, 0, sizeof(uint32_t), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->cand_start.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice,
+                         ctx->stream));
+  TRY(device_exclusive_scan(ctx, ctx->cand_start.as<uint32_t>(), n_vox + 1));
+  hipLaunchKernelGGL(mc_write_final, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
+                     ctx->cand_start.as<uint32_t>(), ctx->cand_pts.as<float4>(), n_vox);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev1, ctx->stream));
+  TRY(sync_stream(ctx));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  CandGrid& g = ctx->cg;
+  g.brick_table = table;
+  g.vox_start = ctx->cand_start.as<uint32_t>();
+  g.cand = ctx->cand_pts.as<float4>();
+  g.ox = cp.ox;
+  g.oy = cp.oy;
+  g.oz = cp.oz;
+  g.inv_e = cp.inv_e;
+  g.nvx = cp.nvx;
+  g.nvy = cp.nvy;
+  g.nvz = cp.nvz;
+  g.nbx = cp.nbx;
+  g.nby = cp.nby;
+  g.nbz = cp.nbz;
+  ctx->footprint[5] = sizeof(int) * n_table;
+  ctx->footprint[6] = sizeof(uint32_t) * (n_vox + 1);
+  ctx->footprint[7] = sizeof(float4) * kept;
+  ctx->cand_stats[0] = n_bricks;
+  ctx->cand_stats[1] = static_cast<double>(total);
+  ctx->cand_stats[2] = static_cast<double>(kept);
+  ctx->cand_stats[3] = ms;
+  ctx->cand_dirty = false;
+  return 0;
+}
+
+}  // namespace

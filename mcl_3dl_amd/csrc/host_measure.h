@@ -1,0 +1,340 @@
+// host_measure.h — part of the single translation unit mcl3dl_hip.hip: parameter structs for the kernels and
+// launch_measure, the one place that enqueues the likelihood and beam kernels of an update.
+#pragma once
+
+namespace
+{
+int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda, bool need_cells = false)
+{
+  if (!ctx->has_map)
+    return ctx->fail(-5, "no map: call mcl3dl_hip_set_map first");
+  if (need_lik && (ctx->lik_index == 0 || need_cells) && ctx->lik_dirty)
+    TRY(build_lik_grid(ctx));
+  if (need_lik && ctx->lik_index >= 1 && !need_cells && ctx->cand_dirty)
+    TRY(build_cand_grid(ctx));
+  if (need_dda && ctx->dda_dirty)
+    TRY(build_dda_grid(ctx));
+  return 0;
+}
+
+LikParams lik_params(const mcl3dl_hip_ctx* ctx)
+{
+  LikParams p;
+  p.wx = ctx->weight[0];
+  p.wy = ctx->weight[1];
+  p.wz = ctx->weight[2];
+  p.has_weight = ctx->has_weight ? 1 : 0;
+  p.match_dist_min = ctx->match_dist_min;
+  // pcl::KdTreeFLANN::radiusSearch: (float)(radius * radius) with radius widened to double
+  p.r2 = static_cast<float>(static_cast<double>(ctx->match_dist_min) * static_cast<double>(ctx->match_dist_min));
+  p.match_dist_flat = ctx->match_dist_flat;
+  p.match_weight = ctx->match_weight;
+  return p;
+}
+
+BeamParams beam_params(const mcl3dl_hip_ctx* ctx)
+{
+  BeamParams p;
+  p.sin_total_ref = ctx->sin_total_ref;
+  p.hit_range_sq = ctx->hit_range_sq;
+  p.filter_label_max = ctx->filter_label_max;
+  p.short_only = ctx->short_only;
+  p.beam_likelihood_min = ctx->beam_likelihood_min;
+  return p;
+}
+
+// LidarMeasurementModelBeam::refreshParameters, src/lidar_measurement_model_beam.cpp:65-67 (host libm, like the reference)
+void beam_refresh(mcl3dl_hip_ctx* ctx)
+{
+  ctx->hit_range_sq = static_cast<float>(std::pow(static_cast<double>(ctx->hit_range), 2));
+  ctx->beam_likelihood = static_cast<float>(
+      std::pow(static_cast<double>(ctx->beam_likelihood_min), 1.0 / static_cast<float>(ctx->beam_num_points)));
+  ctx->sin_total_ref = sinf(ctx->ang_total_ref);
+  ctx->pow_table_dirty = true;
+}
+
+// 3-D Morton key of a scan point (robot frame), 0.25 m cells: neighbouring lanes of a wavefront then gather from
+// neighbouring map cells.
+uint64_t morton3(uint32_t x, uint32_t y, uint32_t z)
+{
+  auto spread = [](uint64_t v)
+  {
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+  };
+  return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
+                   bool stats, double* stats6)
+{
+  if (!ctx->has_scan)
+    return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
+  if (n_p == 0)
+    return 0;
+  if (n_p > 0x7fffffffu)
+    return ctx->fail(-3, "too many particles");
+  const bool want_lik = (d_lik || d_ratio || stats);
+  const bool want_beam = (d_beam || stats);
+  TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0, stats));
+  const int np = static_cast<int>(n_p);
+  bool beam_forked = false;
+  // ---- beam model (enqueued first: on its own stream when both models run, see mcl3dl_hip_ctx::aux_stream)
+  if (want_beam)
+  {
+    if (ctx->n_b == 0)
+    {
+      if (!stats)
+        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
+                           static_cast<float*>(nullptr), 0.0f, np);
+    }
+    else
+    {
+      if (ctx->pow_table_dirty)
+      {
+        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float
+        std::vector<float> table(ctx->n_b + 1);
+        table[0] = 1.0f;
+        for (size_t k = 1; k <= ctx->n_b; ++k)
+          table[k] = table[k - 1] * ctx->beam_likelihood;
+        TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
+        TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
+        TRY(sync_stream(ctx));
+        ctx->pow_table_dirty = false;
+      }
+      const BeamParams bp = beam_params(ctx);
+      const long long n_rays = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_b);
+      const long long blocks = (n_rays + 255) / 256;
+      if (blocks > 0x7fffffffLL)
+        return ctx->fail(-3, "too many rays for one launch");
+      TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+      const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0;
+      hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
+      if (overlap)
+      {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(bs, ctx->ev_fork, 0));
+      }
+      EventPair ep{};
+      if (!stats)
+        TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep, bs));
+      HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, bs));
+      if (stats)
+      {
+        TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
+        HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), bs));
+        hipLaunchKernelGGL((beam_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
+                           ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), ctx->ray_stats.as<RayStats>());
+      }
+      else
+      {
+        hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
+                           ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr));
+        hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,
+                           ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
+                           np);
+        TRY(timing_end(ctx, ep, bs));
+      }
+      if (overlap)
+      {
+        HIP_TRY(hipEventRecord(ctx->ev_join, bs));
+        beam_forked = true;
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  // ---- likelihood-field model
+  if (want_lik)
+  {
+    if (ctx->n_s == 0)
+    {
+      if (!stats)
+        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_lik, 1.0f, d_ratio, 0.0f,
+                           np);
+    }
+    else
+    {
+      const LikParams lp = lik_params(ctx);
+      const int ns = static_cast<int>(ctx->n_s);
+      EventPair ep{};
+      if (stats)
+      {
+        TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
+        hipLaunchKernelGGL((likelihood_kernel<256, 0, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
+                           ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, ctx->rg, lp, nullptr, nullptr,
+                           ctx->tested.as<double>());
+      }
+      else
+      {
+        TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
+        const float4* scan = ctx->scan_lik.as<float4>();
+        const bool tiled = (ctx->lik_tiled && ns >= 1024 && np >= 64) || ctx->strict_order;
+        float* strict_terms = nullptr;
+        if (ctx->strict_order)
+        {
+          const size_t G = static_cast<size_t>(ctx->lik_group);  // rows of G floats per particle group
+          TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));
+          strict_terms = ctx->strict_terms.as<float>();
+        }
+        const bool small = !tiled && ns <= 32 && np >= 256 && ctx->lik_small;
+        if (small)
+        {
+          int W = 1;
+          while (W < ns)
+            W <<= 1;
+          const long long blocks = (static_cast<long long>(np) * W + 255) / 256;
+          if (blocks > 0x7fffffffLL)
+            return ctx->fail(-3, "too many work-groups for the small-scan likelihood kernel");
+#define LAUNCH_SMALL(WW, MODE)                                                                                         \
+  hipLaunchKernelGGL((likelihood_small_kernel<WW, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
+                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio)
+#define LAUNCH_SMALL_W(MODE)       \
+  switch (W)                       \
+  {                                \
+    case 1: LAUNCH_SMALL(1, MODE); break;   \
+    case 2: LAUNCH_SMALL(2, MODE); break;   \
+    case 4: LAUNCH_SMALL(4, MODE); break;   \
+    case 8: LAUNCH_SMALL(8, MODE); break;   \
+    case 16: LAUNCH_SMALL(16, MODE); break; \
+    default: LAUNCH_SMALL(32, MODE); break; \
+  }
+          if (ctx->lik_index == 2)
+          {
+            LAUNCH_SMALL_W(2)
+          }
+          else if (ctx->lik_index == 1)
+          {
+            LAUNCH_SMALL_W(1)
+          }
+          else
+          {
+            LAUNCH_SMALL_W(0)
+          }
+#undef LAUNCH_SMALL_W
+#undef LAUNCH_SMALL
+        }
+        else if (tiled)
+        {
+          const int G = ctx->lik_group;
+          const int n_tiles = (ns + 255) / 256, n_groups = (np + G - 1) / G;
+          const long long blocks = static_cast<long long>((n_tiles + 7) / 8) * 8 * n_groups;
+          if (blocks > 0x7fffffffLL)
+            return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
+          TRY(ensure(ctx, ctx->lik_partial_sum, sizeof(double) * static_cast<size_t>(n_tiles) * n_p));
+          TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(n_tiles) * n_p));
+#define LAUNCH_TILED(GG, MODE)                                                                                         \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
+                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
+                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
+                     ctx->scan_perm.as<uint32_t>(), strict_terms)
+          if (G == 8)
+          {
+            if (ctx->lik_index == 2)
+              LAUNCH_TILED(8, 2);
+            else if (ctx->lik_index == 1)
+              LAUNCH_TILED(8, 1);
+            else
+              LAUNCH_TILED(8, 0);
+          }
+          else if (G == 32)
+          {
+            if (ctx->lik_index == 2)
+              LAUNCH_TILED(32, 2);
+            else if (ctx->lik_index == 1)
+              LAUNCH_TILED(32, 1);
+            else
+              LAUNCH_TILED(32, 0);
+          }
+          else
+          {
+            if (ctx->lik_index == 2)
+              LAUNCH_TILED(16, 2);
+            else if (ctx->lik_index == 1)
+              LAUNCH_TILED(16, 1);
+            else
+              LAUNCH_TILED(16, 0);
+          }
+#undef LAUNCH_TILED
+          hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
+                             ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
+                             d_lik, d_ratio);
+          if (strict_terms && d_lik)
+          {
+            if (G == 8)
+              hipLaunchKernelGGL(lik_strict_sum_kernel<8>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns, np,
+                                 d_lik);
+            else if (G == 32)
+              hipLaunchKernelGGL(lik_strict_sum_kernel<32>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns,
+                                 np, d_lik);
+            else
+              hipLaunchKernelGGL(lik_strict_sum_kernel<16>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns,
+                                 np, d_lik);
+          }
+        }
+        else
+        {
+#define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
+  hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), 0, ctx->stream, d_pose, scan, ns, \
+                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr)
+        if (ctx->lik_index == 2)
+        {
+          if (ns <= 128)
+            LAUNCH_LIK(64, 2);
+          else
+            LAUNCH_LIK(256, 2);
+        }
+        else if (ctx->lik_index == 1)
+        {
+          if (ns <= 128)
+            LAUNCH_LIK(64, 1);
+          else
+            LAUNCH_LIK(256, 1);
+        }
+        else
+        {
+          if (ns <= 128)
+            LAUNCH_LIK(64, 0);
+          else
+            LAUNCH_LIK(256, 0);
+        }
+#undef LAUNCH_LIK
+        }
+        TRY(timing_end(ctx, ep));
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  if (beam_forked)
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // later work on `stream` sees the beam scores
+  if (stats)
+  {
+    std::vector<double> tested(ctx->n_s ? n_p : 0);
+    RayStats rs{ 0, 0, 0 };
+    if (ctx->n_s)
+      TRY(d2h(ctx, tested.data(), ctx->tested.p, sizeof(double) * n_p));
+    if (ctx->n_b)
+      TRY(d2h(ctx, &rs, ctx->ray_stats.p, sizeof(RayStats)));
+    TRY(sync_stream(ctx));
+    stats6[0] = std::accumulate(tested.begin(), tested.end(), 0.0);
+    stats6[1] = static_cast<double>(n_p) * static_cast<double>(ctx->n_s);
+    stats6[2] = static_cast<double>(rs.steps);
+    stats6[3] = static_cast<double>(rs.occupied);
+    stats6[4] = static_cast<double>(rs.tested);
+    stats6[5] = static_cast<double>(n_p) * static_cast<double>(ctx->n_b);
+  }
+  return 0;
+}
+
+int pf_blocks(size_t n)
+{
+  const size_t b = (n + PF_BLOCK - 1) / PF_BLOCK;
+  return static_cast<int>(std::min<size_t>(std::max<size_t>(b, 1), 1024));
+}
+}  // namespace
