@@ -43,16 +43,6 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->aux_stream)
     (void)hipStreamSynchronize(ctx->aux_stream);
-  DevBuf* bufs[] = { &ctx->cand_table, &ctx->cand_start, &ctx->cand_pts, &ctx->cand_rec, &ctx->cand_ovf, &ctx->lik_partial_sum, &ctx->lik_partial_cnt, &ctx->scan_perm, &ctx->strict_terms, &ctx->mom_blocks, &ctx->mom_arg, &ctx->mom_out, &ctx->mom_idx,
-                     &ctx->subset, &ctx->rs_d_keys, &ctx->rs_d_pscan, &ctx->rs_d_it, &ctx->rs_d_source, &ctx->rs_d_slot,
-                     &ctx->rs_d_noise, &ctx->rs_d_in, &ctx->rs_d_out, &ctx->lik_pts, &ctx->lik_cells, &ctx->dda_bits, &ctx->dda_start, &ctx->dda_pts, &ctx->dda_index,
-                     &ctx->scan_lik, &ctx->scan_beam, &ctx->origins, &ctx->pow_table, &ctx->pose, &ctx->lik,
-                     &ctx->ratio, &ctx->beam, &ctx->weightb, &ctx->wnew, &ctx->extra, &ctx->penalty,
-                     &ctx->block_partials, &ctx->partial4, &ctx->stats4, &ctx->ray_stats, &ctx->tested,
-                     &ctx->ray_begin, &ctx->ray_end, &ctx->ray_status, &ctx->ray_hit };
-  for (DevBuf* b : bufs)
-    if (b->p)
-      (void)hipFree(b->p);
   for (const EventPair& ep : ctx->pending)
   {
     (void)hipEventDestroy(ep.start);

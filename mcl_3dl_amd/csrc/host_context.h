@@ -4,10 +4,20 @@
 
 namespace
 {
+// A device allocation owned by the context (grown by ensure(), released with the context: mcl3dl_hip_destroy selects the
+// device before it deletes the context object).
 struct DevBuf
 {
   void* p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf()
+  {
+    if (p)
+      (void)hipFree(p);
+  }
   template <typename T>
   T* as() const
   {
