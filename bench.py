@@ -53,7 +53,7 @@ def parse():
                     help="kernel groups timed with hipEvents INSIDE the timed region (bit 0 likelihood = the roofline "
                          "kernel, 1 beam, 2 pf); the others are timed in a second pass of the same steps")
     ap.add_argument("--scan-points", type=int, default=0, help="override the number of likelihood scan points")
-    ap.add_argument("--lik-group", type=int, default=16)
+    ap.add_argument("--lik-group", type=int, default=0, help="0 = the library's choice (16 / 8 / 4 by launch size)")
     ap.add_argument("--strict-order", type=int, default=0,
                     help="1 = reference float summation order (bit-identical likelihoods and weights; slower)")
     ap.add_argument("--force-dist", action="store_true",
@@ -110,6 +110,17 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
         _, _, sec_mt = o.likelihood_measure(sc.poses[:n], sc.scan_lik, threads=threads, return_time=True)
         out["all_cores"] = {"value": evals / sec_mt, "cores": threads}
     return out, lik, q
+
+
+def _tiled_group(n_s, n_p, forced):
+    """The tiled kernel's particles-per-work-group as the library picks it (host_measure.h)."""
+    if forced:
+        return forced
+    n_tiles = (n_s + 255) // 256
+    for g in (16, 8, 4):
+        if n_tiles * ((n_p + g - 1) // g) >= 2048:
+            return g
+    return 4
 
 
 def _identity_noise(n):
@@ -295,8 +306,9 @@ def main():
         lik_avg_ms = lik_ms / max(lik_n, 1)
         achieved = bytes_lik_launch / (lik_avg_ms * 1e-3) / 1e9 if lik_n else 0.0
         stats = d_stats.cpu().numpy()
-        tiled = bool(args.lik_tiled and n_s >= 1024 and n_p >= 64)
-        traffic, traffic_src = pmc_traffic("void mcl3dl::likelihood_tiled_kernel<%d, %d>" % (args.lik_group, args.lik_index)
+        tiled = bool(args.lik_tiled and n_s >= 1024 and n_p >= 4)
+        group = _tiled_group(n_s, n_p, args.lik_group)
+        traffic, traffic_src = pmc_traffic("void mcl3dl::likelihood_tiled_kernel<%d, %d>" % (group, args.lik_index)
                                            if tiled else "void mcl3dl::likelihood_kernel<256, %d, false>" % args.lik_index,
                                            args.workload)
         # bytes the shipped index really reads per evaluation, priced against the measured L2 ceiling
@@ -331,7 +343,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("likelihood_tiled_kernel<%d,%d>" % (args.lik_group, args.lik_index)) if args.lik_tiled and n_s >= 1024 and n_p >= 64 else ("likelihood_kernel<256,%d>" % args.lik_index),
+                "kernel": (("likelihood_tiled_kernel<%d,%d>" % (group, args.lik_index)) if tiled else
+                           ("likelihood_small_kernel<%d>" % args.lik_index) if (n_s <= 32 and n_p >= 256 and args.lik_small) else
+                           ("likelihood_kernel<%d,%d>" % (64 if n_s <= 128 else 256, args.lik_index))),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

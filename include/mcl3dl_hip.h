@@ -257,7 +257,7 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       CSR runs; 0 = 27-cell scan of the cell-sorted map
  *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min (default 0.5)
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
- *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points; 0 = one
+ *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points and >= 4 particles; 0 = one
  *                       work-group per particle always (only the fp64 summation order differs)
  *   "use_graph"         1 = mcl3dl_hip_update_device replays a captured hipGraph; 0 (default) = enqueue kernel by kernel
  *   "timing_mask"       bit k set (default: all) = kernel group k is timed while kernel timing is on
@@ -265,7 +265,8 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       (forked from / joined into the context's stream with events); 0 = one after the other
  *   "lik_small"         1 (default) = scans of <= 32 points with >= 256 particles (global localisation) share each
  *                       wavefront between 64 / W particles; 0 = always one work-group per particle
- *   "lik_group"         particles per work-group of the tiled kernel: 8, 16 (default) or 32
+ *   "lik_group"         particles per work-group of the tiled kernel: 0 (default) = the largest of 16 / 8 / 4 that
+ *                       still yields >= 2048 work-groups, or 4, 8, 16, 32 to force one
  *   "strict_order"      0 (default) = fp64 tree sums; 1 = add the likelihood terms per particle and the weights over the
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit

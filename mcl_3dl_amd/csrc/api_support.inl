@@ -102,8 +102,8 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   }
   if (key == "lik_group")
   {
-    if (value != 8.0 && value != 16.0 && value != 32.0)
-      return ctx->fail(-3, "lik_group must be 8, 16 or 32");
+    if (value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0 && value != 32.0)
+      return ctx->fail(-3, "lik_group must be 0 (chosen per launch), 4, 8, 16 or 32");
     ctx->lik_group = static_cast<int>(value);
     return 0;
   }

@@ -75,7 +75,7 @@ struct mcl3dl_hip_ctx
   int lik_index = 2;
   int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
-  int lik_group = 16;      // particles per work-group of the tiled kernel (16 or 32)
+  int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
   DevBuf lik_partial_sum, lik_partial_cnt;
   int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
   DevBuf scan_perm, strict_terms;

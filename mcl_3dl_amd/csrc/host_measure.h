@@ -175,11 +175,25 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
         const float4* scan = ctx->scan_lik.as<float4>();
-        const bool tiled = (ctx->lik_tiled && ns >= 1024 && np >= 64) || ctx->strict_order;
+        const bool tiled = (ctx->lik_tiled && ns >= 1024 && np >= 4) || ctx->strict_order;
+        // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
+        // work-group slots something to do (few particles x a long scan would otherwise leave most of the GPU idle)
+        int group_size = ctx->lik_group;
+        if (group_size == 0)
+        {
+          const long long n_tiles_ll = (ns + 255) / 256;
+          group_size = 4;
+          for (int gg = 16; gg >= 4; gg >>= 1)
+            if (n_tiles_ll * ((np + gg - 1) / gg) >= 2048)
+            {
+              group_size = gg;
+              break;
+            }
+        }
         float* strict_terms = nullptr;
         if (ctx->strict_order)
         {
-          const size_t G = static_cast<size_t>(ctx->lik_group);  // rows of G floats per particle group
+          const size_t G = static_cast<size_t>(group_size);  // rows of G floats per particle group
           TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));
           strict_terms = ctx->strict_terms.as<float>();
         }
@@ -222,7 +236,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         }
         else if (tiled)
         {
-          const int G = ctx->lik_group;
+          const int G = group_size;
           const int n_tiles = (ns + 255) / 256, n_groups = (np + G - 1) / G;
           const long long blocks = static_cast<long long>((n_tiles + 7) / 8) * 8 * n_groups;
           if (blocks > 0x7fffffffLL)
@@ -234,48 +248,56 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
-          if (G == 8)
+#define LAUNCH_TILED_G(GG)      \
+  do                            \
+  {                             \
+    if (ctx->lik_index == 2)    \
+      LAUNCH_TILED(GG, 2);      \
+    else if (ctx->lik_index == 1) \
+      LAUNCH_TILED(GG, 1);      \
+    else                        \
+      LAUNCH_TILED(GG, 0);      \
+  } while (0)
+          switch (G)
           {
-            if (ctx->lik_index == 2)
-              LAUNCH_TILED(8, 2);
-            else if (ctx->lik_index == 1)
-              LAUNCH_TILED(8, 1);
-            else
-              LAUNCH_TILED(8, 0);
+            case 4:
+              LAUNCH_TILED_G(4);
+              break;
+            case 8:
+              LAUNCH_TILED_G(8);
+              break;
+            case 32:
+              LAUNCH_TILED_G(32);
+              break;
+            default:
+              LAUNCH_TILED_G(16);
+              break;
           }
-          else if (G == 32)
-          {
-            if (ctx->lik_index == 2)
-              LAUNCH_TILED(32, 2);
-            else if (ctx->lik_index == 1)
-              LAUNCH_TILED(32, 1);
-            else
-              LAUNCH_TILED(32, 0);
-          }
-          else
-          {
-            if (ctx->lik_index == 2)
-              LAUNCH_TILED(16, 2);
-            else if (ctx->lik_index == 1)
-              LAUNCH_TILED(16, 1);
-            else
-              LAUNCH_TILED(16, 0);
-          }
+#undef LAUNCH_TILED_G
 #undef LAUNCH_TILED
           hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
                              d_lik, d_ratio);
           if (strict_terms && d_lik)
           {
-            if (G == 8)
-              hipLaunchKernelGGL(lik_strict_sum_kernel<8>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns, np,
-                                 d_lik);
-            else if (G == 32)
-              hipLaunchKernelGGL(lik_strict_sum_kernel<32>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns,
-                                 np, d_lik);
-            else
-              hipLaunchKernelGGL(lik_strict_sum_kernel<16>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns,
-                                 np, d_lik);
+#define LAUNCH_STRICT(GG)                                                                                             \
+  hipLaunchKernelGGL(lik_strict_sum_kernel<GG>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns, np, d_lik)
+            switch (G)
+            {
+              case 4:
+                LAUNCH_STRICT(4);
+                break;
+              case 8:
+                LAUNCH_STRICT(8);
+                break;
+              case 32:
+                LAUNCH_STRICT(32);
+                break;
+              default:
+                LAUNCH_STRICT(16);
+                break;
+            }
+#undef LAUNCH_STRICT
           }
         }
         else

@@ -241,7 +241,7 @@ def test_candidate_index_equals_cell_scan_bit_for_bit(engine, scene_c1, dist_wei
     assert np.count_nonzero(lik0) > len(poses) // 2
 
 
-@pytest.mark.parametrize("group", [16, 32])
+@pytest.mark.parametrize("group", [0, 4, 8, 16, 32])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_tiled_kernel_matches_per_particle_kernel(engine, oracle_kind, group, mode):
     """The tile-major XCD-aware kernel evaluates the same bit-identical terms as the per-particle kernel; only the
@@ -259,7 +259,7 @@ def test_tiled_kernel_matches_per_particle_kernel(engine, oracle_kind, group, mo
     finally:
         engine.set_option("lik_index", 2)
         engine.set_option("lik_tiled", 1)
-        engine.set_option("lik_group", 16)
+        engine.set_option("lik_group", 0)
     np.testing.assert_array_equal(ratio1, ratio0)
     np.testing.assert_allclose(lik1, lik0, rtol=1.2e-7)
     o = make_oracle(oracle_kind, sc, dw)
