@@ -27,6 +27,10 @@ RTOL = 1e-5
 # once for round 1: 504 further configurations, all green)
 FUZZ_FIRST = int(os.environ.get("MCL3DL_FUZZ_FIRST", "0"))
 FUZZ_LAST = int(os.environ.get("MCL3DL_FUZZ_LAST", "96"))
+# MCL3DL_FUZZ_OFFSET=x,y,z moves every scene (map and particles) that far from the origin: large world coordinates,
+# where float32 positions are coarse (1e5 m: 8 mm steps) — parity must hold there too (seeds 0..95 run once with
+# 1e5,-2e5,50: green)
+FUZZ_OFFSET = np.array([float(v) for v in os.environ.get("MCL3DL_FUZZ_OFFSET", "0,0,0").split(",")], np.float64)
 
 
 def draw_map(rng):
@@ -92,6 +96,9 @@ def draw_case(seed):
     if n_p > 4:
         poses[-1, :3] += 10 * ext  # a particle far outside the map: likelihood 0, rays never enter the grid
         poses[-2, :3] = m.min(0) - 0.01  # and one just outside the map's bounding box
+    if np.any(FUZZ_OFFSET != 0):
+        m = (m.astype(np.float64) + FUZZ_OFFSET).astype(np.float32)
+        poses[:, :3] = (poses[:, :3].astype(np.float64) + FUZZ_OFFSET).astype(np.float32)
     return dict(map=m, label=label, dist_weight=dist_weight, lik_kw=lik_kw, beam_kw=beam_kw,
                 scan_lik=scan_lik.astype(np.float32), scan_beam=scan_beam.astype(np.float32),
                 scan_beam_label=scan_beam_label, origins=origins.astype(np.float32), poses=poses, ext=ext, rng=rng)
