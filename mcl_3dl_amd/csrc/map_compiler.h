@@ -228,15 +228,46 @@ __global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, 
   half = 0.5 * c.e + c.grow;
   for (int a = 0; a < 3; ++a)
     ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
-  // pass 1: mark dominated candidates (bit 31 of the stored id)
+  // pass 1: mark dominated candidates (bit 31 of the stored id). Every pair is compared while the list is short (the
+  // normal case: ~10 entries); a long list (huge match_dist_min relative to the map spacing) is compared against its
+  // PRUNE_K entries nearest to the voxel centre only — the likely dominators — which keeps the work linear in the list
+  // length. Pruning less is always safe: the result is a superset of the exact candidate set either way.
+  constexpr int PRUNE_K = 32;
+  const uint32_t k_all = e - s;
+  uint32_t near_idx[PRUNE_K];
+  double near_pp[PRUNE_K];
+  uint32_t n_near = 0;
+  if (k_all > PRUNE_K)
+  {
+    for (uint32_t i = s; i < e; ++i)
+    {
+      const float4 p = pts[prelim[i] & 0x7fffffffu];
+      const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
+      const double pp = px * px + py * py + pz * pz;
+      if (n_near < PRUNE_K || pp < near_pp[n_near - 1])
+      {
+        uint32_t pos = n_near < PRUNE_K ? n_near++ : PRUNE_K - 1;
+        while (pos > 0 && near_pp[pos - 1] > pp)
+        {
+          near_pp[pos] = near_pp[pos - 1];
+          near_idx[pos] = near_idx[pos - 1];
+          --pos;
+        }
+        near_pp[pos] = pp;
+        near_idx[pos] = i;
+      }
+    }
+  }
+  const uint32_t n_rivals = k_all > PRUNE_K ? n_near : k_all;
   for (uint32_t i = s; i < e; ++i)
   {
     const float4 p = pts[prelim[i] & 0x7fffffffu];
     const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
     const double pp = px * px + py * py + pz * pz;
     bool dominated = false;
-    for (uint32_t j = s; j < e && !dominated; ++j)
+    for (uint32_t jj = 0; jj < n_rivals && !dominated; ++jj)
     {
+      const uint32_t j = k_all > PRUNE_K ? near_idx[jj] : s + jj;
       if (j == i)
         continue;
       const float4 q = pts[prelim[j] & 0x7fffffffu];
