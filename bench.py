@@ -243,6 +243,7 @@ def main():
     # Clock ramp: a GPU coming out of idle needs tens of milliseconds of load before it holds its sustained clocks, far
     # more than W steps of a sub-millisecond update. Run the update for --prewarm-ms of wall time first (set-up, like the
     # map upload above; not part of W or K), then the W warm-up steps the contract asks for.
+    prewarm = {"ms": 0.0, "batches": 0}
     if args.prewarm_ms > 0:
         torch.cuda.synchronize(dev)
         t_pre = time.perf_counter()
@@ -250,12 +251,33 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         per_step_ms = (time.perf_counter() - t_pre) * 1e3 / 8
-        n_pre = torch.tensor([min(int(args.prewarm_ms / max(per_step_ms, 1e-3)), 100000)], dtype=torch.int64, device=dev)
+        # batches of ~prewarm_ms / 4; at least 4 of them, then until two consecutive batches agree within 1 % (the clock
+        # has settled) or 5 x prewarm_ms have gone by. Every rank runs the same number of batches (the decision is
+        # all-reduced), so the collectives inside step() stay matched.
+        n_batch = torch.tensor([max(1, min(int(args.prewarm_ms / 4 / max(per_step_ms, 1e-3)), 25000))], dtype=torch.int64,
+                               device=dev)
         if use_dist:
-            dist.all_reduce(n_pre, op=dist.ReduceOp.MAX)  # every rank must run the same number of collectives
-        for _ in range(int(n_pre.item())):
-            step()
-        torch.cuda.synchronize(dev)
+            dist.all_reduce(n_batch, op=dist.ReduceOp.MAX)
+        n_batch = int(n_batch.item())
+        prev, stable = None, 0
+        t_all = time.perf_counter()
+        while True:
+            tb = time.perf_counter()
+            for _ in range(n_batch):
+                step()
+            torch.cuda.synchronize(dev)
+            cur = (time.perf_counter() - tb) / n_batch
+            prewarm["batches"] += 1
+            stable = stable + 1 if (prev is not None and abs(cur - prev) <= 0.01 * prev) else 0
+            prev = cur
+            elapsed_ms = (time.perf_counter() - t_all) * 1e3
+            more = torch.tensor([1 if (prewarm["batches"] < 4 or (stable < 2 and elapsed_ms < 5 * args.prewarm_ms)) else 0],
+                                dtype=torch.int64, device=dev)
+            if use_dist:
+                dist.all_reduce(more, op=dist.ReduceOp.MAX)
+            if int(more.item()) == 0:
+                break
+        prewarm["ms"] = (time.perf_counter() - t_pre) * 1e3
     for _ in range(args.warmup):
         step()
     eng.set_option("timing_mask", args.timing_mask)
@@ -362,6 +384,7 @@ def main():
                 # (MI355X_MICROARCH.md: ~34.5 TB/s aggregate)
                 "l2": l2,
             },
+            "prewarm": prewarm,
             "kernel_timing_pass": kernel_timing_pass,
             "kernels_ms_per_step": {"likelihood": lik_avg_ms, "beam": beam_ms / max(beam_n, 1) if n_b else 0.0,
                                     "pf": 2.0 * pf_ms / max(pf_n, 1)},
