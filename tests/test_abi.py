@@ -58,3 +58,28 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "pyoracle" not in text.replace("never imports anything from oracle/", ""), f
                 assert "libmcl3dl_oracle" not in text and "libmcl3dl_ref" not in text, f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (-pedantic) and a C program must link against the library
+    and get the documented failure from mcl3dl_hip_create on a box without a GPU (or success with one)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "mcl3dl_hip.h")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    src = tmp_path / "probe.c"
+    src.write_text('#include "mcl3dl_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { mcl3dl_hip_ctx* c = NULL; int rc = mcl3dl_hip_create(&c, 0);\n'
+                   '  printf("%d %d\\n", mcl3dl_hip_abi_version(), rc); if (rc == 0) mcl3dl_hip_destroy(c); return 0; }\n')
+    exe = str(tmp_path / "probe")
+    libdir = os.path.join(root, "mcl_3dl_amd")
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), "-o", exe, str(src), "-L", libdir, "-lmcl3dl_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    abi, rc = (int(x) for x in out.stdout.split())
+    assert abi == 1 and rc <= 0
