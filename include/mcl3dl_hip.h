@@ -85,7 +85,11 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
  * (src/lidar_measurement_model_beam.cpp:124-155) made by the measure lambda (src/mcl_3dl.cpp:409-415).
  * n_s == 0 -> out_lik = 1, out_match_ratio = 0; n_b == 0 -> out_beam = 1 (the (1,0) of an empty cloud).
  * scan_beam_origin[i] = PointXYZIL::label of beam point i = index into origins. Any out_* may be NULL. */
-int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, size_t n_p,
+/* Upload the particle poses once per update; measure_batch calls with pose == NULL and the same n_p then use them. The
+ * node asks each model separately (src/mcl_3dl.cpp:409-415): with this the drop-in classes send the poses once per
+ * pf::measure, not once per model. Any host-buffer call that is given a pose array replaces the uploaded set. */
+int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, size_t n_p);
+int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7 or NULL*/, size_t n_p,
                              const float* scan_lik_xyz /*n_s*3*/, size_t n_s, const float* scan_beam_xyz /*n_b*3*/,
                              const uint32_t* scan_beam_origin /*n_b*/, size_t n_b, const float* origins /*n_o*3*/,
                              size_t n_o, float* out_lik /*n_p*/, float* out_match_ratio /*n_p*/,

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mcl3dl_hip_set_map": (_i, [_p, _p, _p, _sz, _u64, _p]),
     "mcl3dl_hip_set_likelihood_params": (_i, [_p, _f, _f, _f]),
     "mcl3dl_hip_set_beam_params": (_i, [_p, _f, _f, _f, _f, _f, _f, _f, _u32, _f, _u32, _i]),
+    "mcl3dl_hip_upload_poses": (_i, [_p, _p, _sz]),
     "mcl3dl_hip_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_pf_measure": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
@@ -138,6 +139,10 @@ class Engine:
     def set_stream(self, stream_handle):
         self._check(self.lib.mcl3dl_hip_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
 
+    def get_stream(self):
+        """The hipStream_t the engine enqueues on, as an integer handle."""
+        return int(self.lib.mcl3dl_hip_get_stream(self.h) or 0)
+
     def synchronize(self):
         self._check(self.lib.mcl3dl_hip_synchronize(self.h))
 
@@ -168,10 +173,19 @@ class Engine:
         og = _np_f32(origins if origins is not None else np.zeros((1, 3)), 3)
         return sl, sb, so, og
 
-    def measure_batch(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
+    def upload_poses(self, poses):
         poses = _np_f32(poses, 7)
+        self._check(self.lib.mcl3dl_hip_upload_poses(self.h, _ptr(poses), len(poses)))
+        self._n_uploaded = len(poses)
+
+    def measure_batch(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
+        """poses=None: the set sent by upload_poses()."""
         sl, sb, so, og = self._scans(scan_lik, scan_beam, scan_beam_origin, origins)
-        n_p = len(poses)
+        if poses is None:
+            n_p = self._n_uploaded
+        else:
+            poses = _np_f32(poses, 7)
+            n_p = len(poses)
         lik = np.zeros(n_p, np.float32)
         ratio = np.zeros(n_p, np.float32)
         beam = np.zeros(n_p, np.float32)

@@ -57,21 +57,52 @@ protected:
     const void* cloud = nullptr;
     std::vector<float> likelihood, quality;
   };
-  // Returns the index of `s` in the batch; fills `poses` (7 floats per particle) when the cache must be refreshed.
-  std::size_t lookup(const State6DOF& s, const void* cloud, std::vector<float>& poses, bool* refresh) const
+  // Where `s` sits in the published batch and whether this model's cached results answer it. The cache is tested FIRST:
+  // inside pf::measure this runs once per particle, so nothing here may cost more than a few comparisons (packing the
+  // poses of the whole batch happens in refreshPoses(), once per epoch).
+  struct Slot
   {
+    std::size_t index = 0, count = 1;
     std::uint64_t epoch = 0;
-    const std::size_t index = gatherPoses(s, poses, &epoch);
-    *refresh = !(epoch != 0 && results_.epoch == epoch && results_.cloud == cloud &&
-                 results_.likelihood.size() == poses.size() / 7);
-    if (*refresh)
+    bool refresh = true;
+  };
+  Slot lookup(const State6DOF& s, const void* cloud) const
+  {
+    Slot slot;
+    const BatchDescriptor& b = currentBatch();
+    const char* first = static_cast<const char*>(b.first_state);
+    const char* self = reinterpret_cast<const char*>(&s);
+    if (b.count > 0 && self >= first && self < first + b.count * b.stride && (self - first) % b.stride == 0)
     {
-      results_.epoch = epoch;
-      results_.cloud = cloud;
-      results_.likelihood.assign(poses.size() / 7, 0.f);
-      results_.quality.assign(poses.size() / 7, 0.f);
+      slot.index = static_cast<std::size_t>(self - first) / b.stride;
+      slot.count = b.count;
+      slot.epoch = b.epoch;
     }
-    return index;
+    slot.refresh = !(slot.epoch != 0 && results_.epoch == slot.epoch && results_.cloud == cloud &&
+                     results_.likelihood.size() == slot.count);
+    if (slot.refresh)
+    {
+      results_.epoch = slot.epoch;
+      results_.cloud = cloud;
+      results_.likelihood.assign(slot.count, 0.f);
+      results_.quality.assign(slot.count, 0.f);
+    }
+    return slot;
+  }
+
+  // Makes sure the engine holds the poses of this epoch: packed and uploaded by whichever model asks first (the node
+  // calls "beam" before "likelihood", src/mcl_3dl.cpp:409), reused by the other. Outside pf::measure (epoch 0) the single
+  // state is sent every time.
+  static void refreshPoses(Engine& e, const State6DOF& s, const Slot& slot)
+  {
+    if (slot.epoch != 0 && e.pose_epoch == slot.epoch && e.pose_count == slot.count)
+      return;
+    std::vector<float>& poses = e.pose_scratch;
+    std::uint64_t epoch = 0;
+    gatherPoses(s, poses, &epoch);
+    e.check(mcl3dl_hip_upload_poses(e.get(), poses.data(), poses.size() / 7));
+    e.pose_epoch = epoch;
+    e.pose_count = poses.size() / 7;
   }
 
   std::size_t points_default_ = 0, points_global_ = 0, points_now_ = 0;

@@ -59,6 +59,10 @@ public:
   std::size_t map_size = 0;
   float dist_weight[3] = { 1.f, 1.f, 1.f };
   bool has_weight = false;
+  // ---- poses of the current pf::measure epoch, uploaded once and shared by both models ---------------------------
+  std::uint64_t pose_epoch = 0;
+  std::size_t pose_count = 0;
+  std::vector<float> pose_scratch;
 
 private:
   mcl3dl_hip_ctx* ctx_ = nullptr;

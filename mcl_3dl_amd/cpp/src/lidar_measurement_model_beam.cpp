@@ -45,14 +45,13 @@ LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointTyp
   if (!pc || pc->size() == 0)
     return LidarMeasurementResult(1, 0);  // :130-133
 
-  std::vector<float> poses;
-  bool refresh = false;
-  const std::size_t index = lookup(s, pc.get(), poses, &refresh);
-  if (refresh)
+  const Slot slot = lookup(s, pc.get());
+  if (slot.refresh)
   {
     hip::Engine& e = hip::Engine::shared();
     hip::syncMap(e, *kdtree);
     pushParameters();
+    refreshPoses(e, s, slot);
     std::vector<float> scan, org(3 * origins.size());
     std::vector<std::uint32_t> label;
     hip::packCloud(*pc, scan, &label);
@@ -62,10 +61,10 @@ LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointTyp
       org[3 * i + 1] = origins[i].y_;
       org[3 * i + 2] = origins[i].z_;
     }
-    e.check(mcl3dl_hip_measure_batch(e.get(), poses.data(), poses.size() / 7, nullptr, 0, scan.data(), label.data(),
-                                     pc->size(), org.data(), origins.size(), nullptr, nullptr,
-                                     results_.likelihood.data()));
+    e.check(mcl3dl_hip_measure_batch(e.get(), nullptr, slot.count, nullptr, 0, scan.data(), label.data(), pc->size(),
+                                     org.data(), origins.size(), nullptr, nullptr, results_.likelihood.data()));
   }
+  const std::size_t index = slot.index;
   return LidarMeasurementResult(results_.likelihood[index], 1.0);
 }
 

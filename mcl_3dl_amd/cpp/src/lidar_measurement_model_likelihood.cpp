@@ -27,20 +27,20 @@ LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<Po
   if (!pc || pc->size() == 0)
     return LidarMeasurementResult(1, 0);  // :111-114
 
-  std::vector<float> poses;
-  bool refresh = false;
-  const std::size_t index = lookup(s, pc.get(), poses, &refresh);
-  if (refresh)
+  const Slot slot = lookup(s, pc.get());
+  if (slot.refresh)
   {
     hip::Engine& e = hip::Engine::shared();
     hip::syncMap(e, *kdtree);
     e.check(mcl3dl_hip_set_likelihood_params(e.get(), params_->match_dist_min_, params_->match_dist_flat_,
                                              params_->match_weight_));
+    refreshPoses(e, s, slot);
     std::vector<float> scan;
     hip::packCloud(*pc, scan, nullptr);
-    e.check(mcl3dl_hip_measure_batch(e.get(), poses.data(), poses.size() / 7, scan.data(), pc->size(), nullptr, nullptr,
-                                     0, nullptr, 0, results_.likelihood.data(), results_.quality.data(), nullptr));
+    e.check(mcl3dl_hip_measure_batch(e.get(), nullptr, slot.count, scan.data(), pc->size(), nullptr, nullptr, 0, nullptr,
+                                     0, results_.likelihood.data(), results_.quality.data(), nullptr));
   }
+  const std::size_t index = slot.index;
   return LidarMeasurementResult(results_.likelihood[index], results_.quality[index]);
 }
 }  // namespace mcl_3dl

@@ -145,9 +145,22 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
 {
   if (!ctx)
     return -1;
-  ++ctx->generation;
   if (!(dda_grid_size > 0.f))
     return ctx->fail(-3, "dda_grid_size must be > 0");
+  // The adapter pushes its parameter block before every batched launch and every getBeamStatus call: only a value that
+  // really changed may invalidate anything. The raycaster is re-created (reference: refreshParameters, beam.cpp:69-79)
+  // only when one of ITS constructor arguments moved; the reference caches the voxel map by stamp the same way
+  // (raycast_using_dda.h:164-171).
+  const bool dda_changed = map_grid_x != ctx->map_grid[0] || map_grid_y != ctx->map_grid[1] ||
+                           map_grid_z != ctx->map_grid[2] || dda_grid_size != ctx->dda_grid_size ||
+                           ray_angle_half != ctx->ray_angle_half || hit_range != ctx->hit_range;
+  const bool derived_changed = hit_range != ctx->hit_range || beam_likelihood_min != ctx->beam_likelihood_min ||
+                               num_points != ctx->beam_num_points || ang_total_ref != ctx->ang_total_ref;
+  const bool other_changed = filter_label_max != ctx->filter_label_max ||
+                             (add_penalty_short_only_mode ? 1 : 0) != ctx->short_only;
+  if (!dda_changed && !derived_changed && !other_changed)
+    return 0;
+  ++ctx->generation;
   ctx->map_grid[0] = map_grid_x;
   ctx->map_grid[1] = map_grid_y;
   ctx->map_grid[2] = map_grid_z;
@@ -159,8 +172,10 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
   ctx->ang_total_ref = ang_total_ref;
   ctx->filter_label_max = filter_label_max;
   ctx->short_only = add_penalty_short_only_mode ? 1 : 0;
-  ctx->dda_dirty = true;  // refreshParameters re-creates the raycaster (beam.cpp:69-79)
-  beam_refresh(ctx);
+  if (dda_changed)
+    ctx->dda_dirty = true;
+  if (derived_changed)
+    beam_refresh(ctx);
   return 0;
 }
 
@@ -263,8 +278,8 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
   TRY(h2d(ctx, ctx->origins.p, org.data(), sizeof(float4) * n_o));
   if (sync_at_end)
     TRY(sync_stream(ctx));
-  if (n_b != ctx->n_b)
-    ctx->pow_table_dirty = true;
+  if (n_b > ctx->pow_table_len)
+    ctx->pow_table_dirty = true;  // table[k] = beam_likelihood^k is a prefix property: a shorter scan reuses it
   if (n_s != ctx->n_s || n_b != ctx->n_b || n_o != ctx->n_o || !ctx->has_scan)
     ++ctx->generation;
   ctx->n_s = n_s;
@@ -482,6 +497,21 @@ int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* re
   return 0;
 }
 
+int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
+{
+  if (!ctx)
+    return -1;
+  if (!pose || n_p == 0 || n_p > 0x7fffffffu)
+    return ctx->fail(-3, "bad pose array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->n_pose_uploaded = 0;
+  TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
+  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  TRY(sync_stream(ctx));  // the staging copy is done with the caller's array
+  ctx->n_pose_uploaded = n_p;
+  return 0;
+}
+
 int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
                              const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
                              const float* origins, size_t n_o, float* out_lik, float* out_match_ratio, float* out_beam)
@@ -490,15 +520,21 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p,
     return -1;
   if (n_p == 0)
     return 0;
-  if (!pose)
-    return ctx->fail(-3, "null pose array");
+  if (!pose && ctx->n_pose_uploaded != n_p)
+    return ctx->fail(-3, "null pose array (and mcl3dl_hip_upload_poses holds %zu poses, not %zu)", ctx->n_pose_uploaded,
+                     n_p);
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
-  TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
   TRY(ensure(ctx, ctx->lik, sizeof(float) * n_p));
   TRY(ensure(ctx, ctx->ratio, sizeof(float) * n_p));
   TRY(ensure(ctx, ctx->beam, sizeof(float) * n_p));
-  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  if (pose)
+  {
+    ctx->n_pose_uploaded = 0;
+    TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
+    TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+    ctx->n_pose_uploaded = n_p;
+  }
   const bool lik_wanted = out_lik || out_match_ratio;
   TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? ctx->lik.as<float>() : nullptr,
                      lik_wanted ? ctx->ratio.as<float>() : nullptr, out_beam ? ctx->beam.as<float>() : nullptr, false,
@@ -583,7 +619,9 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
   TRY(ensure(ctx, ctx->extra, fb));
   TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
   TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
+  ctx->n_pose_uploaded = 0;
   TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
+  ctx->n_pose_uploaded = n_p;
   TRY(h2d(ctx, ctx->weightb.p, weight_inout, fb));
   if (extra)
     TRY(h2d(ctx, ctx->extra.p, extra, fb));

@@ -107,6 +107,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_group = static_cast<int>(value);
     return 0;
   }
+  if (key == "lik_ilp")
+  {
+    if (!(value >= 0.0 && value <= 3.0))
+      return ctx->fail(-3, "lik_ilp must be 0..3");
+    ctx->lik_ilp = static_cast<int>(value);
+    return 0;
+  }
   if (key == "cand_phase")
   {
     if (!(value >= 0.0 && value < 1.0))

@@ -76,6 +76,7 @@ struct mcl3dl_hip_ctx
   int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
+  int lik_ilp = 0;         // tiled kernel, evaluations in flight per lane: 0 = one, 1..8 = the variants of host_measure.h
   DevBuf lik_partial_sum, lik_partial_cnt;
   int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
   DevBuf scan_perm, strict_terms;
@@ -94,8 +95,10 @@ struct mcl3dl_hip_ctx
   size_t n_s = 0, n_b = 0, n_o = 0;
   bool has_scan = false;
   bool pow_table_dirty = true;
+  size_t pow_table_len = 0;  // penalty counts 0..pow_table_len the device table covers
 
   // work buffers
+  size_t n_pose_uploaded = 0;  // poses `pose` holds from mcl3dl_hip_upload_poses / the last host-buffer call
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
       tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset;
 

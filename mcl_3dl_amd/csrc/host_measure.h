@@ -70,6 +70,67 @@ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z)
   return spread(x) | (spread(y) << 1) | (spread(z) << 2);
 }
 
+// Which likelihood kernel an update of np particles x ns points runs, with every size check and every buffer the launch
+// needs done HERE — before launch_measure forks the beam kernels onto the second stream, so that no error path can
+// return with un-joined work in flight.
+struct LikPlan
+{
+  bool tiled = false, small = false;
+  int group_size = 16, W = 1, n_tiles = 0, n_groups = 0;
+  long long blocks = 0;
+  float* strict_terms = nullptr;
+};
+
+int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
+{
+  const int np = static_cast<int>(n_p);
+  pl->tiled = (ctx->lik_tiled && ns >= 1024 && np >= 4) || ctx->strict_order;
+  // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
+  // work-group slots something to do (few particles x a long scan would otherwise leave most of the GPU idle)
+  int group_size = ctx->lik_group;
+  if (group_size == 0)
+  {
+    const long long n_tiles_ll = (ns + 255) / 256;
+    group_size = 4;
+    for (int gg = 16; gg >= 4; gg >>= 1)
+      if (n_tiles_ll * ((np + gg - 1) / gg) >= 2048)
+      {
+        group_size = gg;
+        break;
+      }
+  }
+  pl->group_size = group_size;
+  pl->small = !pl->tiled && ns <= 32 && np >= 256 && ctx->lik_small;
+  if (pl->small)
+  {
+    int W = 1;
+    while (W < ns)
+      W <<= 1;
+    pl->W = W;
+    pl->blocks = (static_cast<long long>(np) * W + 255) / 256;
+    if (pl->blocks > 0x7fffffffLL)
+      return ctx->fail(-3, "too many work-groups for the small-scan likelihood kernel");
+  }
+  else if (pl->tiled)
+  {
+    const size_t G = static_cast<size_t>(group_size);
+    pl->n_tiles = (ns + 255) / 256;
+    pl->n_groups = (np + group_size - 1) / group_size;
+    pl->blocks = static_cast<long long>((pl->n_tiles + 7) / 8) * 8 * pl->n_groups;
+    if (pl->blocks > 0x7fffffffLL)
+      return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
+    TRY(ensure(ctx, ctx->lik_partial_sum, sizeof(double) * static_cast<size_t>(pl->n_tiles) * n_p));
+    TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(pl->n_tiles) * n_p));
+    if (ctx->strict_order)
+    {
+      // rows of G floats per particle group
+      TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));
+      pl->strict_terms = ctx->strict_terms.as<float>();
+    }
+  }
+  return 0;
+}
+
 int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
                    bool stats, double* stats6)
 {
@@ -84,6 +145,23 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0, stats));
   const int np = static_cast<int>(n_p);
   bool beam_forked = false;
+  // any return between the fork and the join below (a failing HIP call) first waits for the second stream, so the caller
+  // never gets control back with beam kernels still writing its buffers
+  struct ForkGuard
+  {
+    mcl3dl_hip_ctx* c;
+    bool armed = false;
+    ~ForkGuard()
+    {
+      if (armed)
+        (void)hipStreamSynchronize(c->aux_stream);
+    }
+  } fork_guard{ ctx };
+  LikPlan plan;
+  if (want_lik && !stats && ctx->n_s > 0)
+    TRY(plan_lik(ctx, n_p, static_cast<int>(ctx->n_s), &plan));
+  if (stats && ctx->n_s > 0)
+    TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
   // ---- beam model (enqueued first: on its own stream when both models run, see mcl3dl_hip_ctx::aux_stream)
   if (want_beam)
   {
@@ -95,17 +173,21 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     }
     else
     {
-      if (ctx->pow_table_dirty)
+      if (ctx->pow_table_dirty || ctx->n_b > ctx->pow_table_len)
       {
-        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float
-        std::vector<float> table(ctx->n_b + 1);
+        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float. Built for at least 1024 counts so that
+        // alternating scan sizes (the adapter launches the two models separately) do not rebuild it every update.
+        const size_t len = std::max<size_t>(ctx->n_b, 1024);
+        std::vector<float> table(len + 1);
         table[0] = 1.0f;
-        for (size_t k = 1; k <= ctx->n_b; ++k)
+        for (size_t k = 1; k <= len; ++k)
           table[k] = table[k - 1] * ctx->beam_likelihood;
         TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
         TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
         TRY(sync_stream(ctx));
         ctx->pow_table_dirty = false;
+        ctx->pow_table_len = len;
+        ++ctx->generation;
       }
       const BeamParams bp = beam_params(ctx);
       const long long n_rays = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_b);
@@ -113,12 +195,15 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (blocks > 0x7fffffffLL)
         return ctx->fail(-3, "too many rays for one launch");
       TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+      if (stats)
+        TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
       const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0;
       hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
       if (overlap)
       {
         HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(bs, ctx->ev_fork, 0));
+        fork_guard.armed = true;
       }
       EventPair ep{};
       if (!stats)
@@ -126,7 +211,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, bs));
       if (stats)
       {
-        TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
         HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), bs));
         hipLaunchKernelGGL((beam_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
                            ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
@@ -166,7 +250,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       EventPair ep{};
       if (stats)
       {
-        TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
         hipLaunchKernelGGL((likelihood_kernel<256, 0, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
                            ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, ctx->rg, lp, nullptr, nullptr,
                            ctx->tested.as<double>());
@@ -175,37 +258,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
         const float4* scan = ctx->scan_lik.as<float4>();
-        const bool tiled = (ctx->lik_tiled && ns >= 1024 && np >= 4) || ctx->strict_order;
-        // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
-        // work-group slots something to do (few particles x a long scan would otherwise leave most of the GPU idle)
-        int group_size = ctx->lik_group;
-        if (group_size == 0)
-        {
-          const long long n_tiles_ll = (ns + 255) / 256;
-          group_size = 4;
-          for (int gg = 16; gg >= 4; gg >>= 1)
-            if (n_tiles_ll * ((np + gg - 1) / gg) >= 2048)
-            {
-              group_size = gg;
-              break;
-            }
-        }
-        float* strict_terms = nullptr;
-        if (ctx->strict_order)
-        {
-          const size_t G = static_cast<size_t>(group_size);  // rows of G floats per particle group
-          TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));
-          strict_terms = ctx->strict_terms.as<float>();
-        }
-        const bool small = !tiled && ns <= 32 && np >= 256 && ctx->lik_small;
+        const bool tiled = plan.tiled, small = plan.small;
+        const int group_size = plan.group_size;
+        float* strict_terms = plan.strict_terms;
         if (small)
         {
-          int W = 1;
-          while (W < ns)
-            W <<= 1;
-          const long long blocks = (static_cast<long long>(np) * W + 255) / 256;
-          if (blocks > 0x7fffffffLL)
-            return ctx->fail(-3, "too many work-groups for the small-scan likelihood kernel");
+          const int W = plan.W;
+          const long long blocks = plan.blocks;
 #define LAUNCH_SMALL(WW, MODE)                                                                                         \
   hipLaunchKernelGGL((likelihood_small_kernel<WW, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
                      ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio)
@@ -237,14 +296,20 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         else if (tiled)
         {
           const int G = group_size;
-          const int n_tiles = (ns + 255) / 256, n_groups = (np + G - 1) / G;
-          const long long blocks = static_cast<long long>((n_tiles + 7) / 8) * 8 * n_groups;
-          if (blocks > 0x7fffffffLL)
-            return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
-          TRY(ensure(ctx, ctx->lik_partial_sum, sizeof(double) * static_cast<size_t>(n_tiles) * n_p));
-          TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(n_tiles) * n_p));
+          const int n_tiles = plan.n_tiles, n_groups = plan.n_groups;
+          const long long blocks = plan.blocks;
 #define LAUNCH_TILED(GG, MODE)                                                                                         \
   hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
+                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
+                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
+                     ctx->scan_perm.as<uint32_t>(), strict_terms)
+#define LAUNCH_TILED_W(GG, MODE, WW)                                                                                   \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, 1, WW>), dim3(static_cast<unsigned>(blocks)), dim3(256), \
+                     0, ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,           \
+                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
+                     ctx->scan_perm.as<uint32_t>(), strict_terms)
+#define LAUNCH_TILED_ILP(GG, UU, WW)                                                                               \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, 2, UU, WW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,  \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
@@ -252,7 +317,15 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   do                            \
   {                             \
     if (ctx->lik_index == 2)    \
-      LAUNCH_TILED(GG, 2);      \
+    {                           \
+      switch (ctx->lik_ilp)     \
+      {                         \
+        case 1: LAUNCH_TILED_ILP(GG, 2, 8); break;  \
+        case 2: LAUNCH_TILED_ILP(GG, 4, 5); break;  \
+        case 3: LAUNCH_TILED_ILP(GG, 4, 4); break;  \
+        default: LAUNCH_TILED(GG, 2); break; \
+      }                         \
+    }                           \
     else if (ctx->lik_index == 1) \
       LAUNCH_TILED(GG, 1);      \
     else                        \
@@ -267,13 +340,20 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
               LAUNCH_TILED_G(8);
               break;
             case 32:
-              LAUNCH_TILED_G(32);
+              if (ctx->lik_index == 2)
+                LAUNCH_TILED_ILP(32, 1, 4);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
+              else if (ctx->lik_index == 1)
+                LAUNCH_TILED_W(32, 1, 4);
+              else
+                LAUNCH_TILED_W(32, 0, 4);
               break;
             default:
               LAUNCH_TILED_G(16);
               break;
           }
 #undef LAUNCH_TILED_G
+#undef LAUNCH_TILED_ILP
+#undef LAUNCH_TILED_W
 #undef LAUNCH_TILED
           hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
@@ -334,7 +414,10 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     HIP_TRY(hipGetLastError());
   }
   if (beam_forked)
+  {
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // later work on `stream` sees the beam scores
+    fork_guard.armed = false;
+  }
   if (stats)
   {
     std::vector<double> tested(ctx->n_s ? n_p : 0);

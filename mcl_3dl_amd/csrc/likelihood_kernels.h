@@ -222,6 +222,64 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
   return best;
 }
 
+// nearest_d2_rec split into its three dependent steps so that a caller can keep several evaluations in flight per lane
+// (likelihood_tiled_kernel, U > 1): all brick-table loads are issued first, then all record loads, then the arithmetic.
+// Same arithmetic, same results as nearest_d2_rec.
+// step 1: voxel of the query -> brick-table index and the voxel's slot inside its brick; false = outside the grid
+__device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz, uint32_t& ti, uint32_t& sub)
+{
+  const int vx = __float2int_rd((qx - g.ox) * g.inv_e);
+  const int vy = __float2int_rd((qy - g.oy) * g.inv_e);
+  const int vz = __float2int_rd((qz - g.oz) * g.inv_e);
+  if (g.mul24_ok)
+    ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
+         __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
+  else
+    ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
+             static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
+  sub = static_cast<uint32_t>(((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  return static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
+         static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
+}
+
+// step 3: min d2 over the candidates of a loaded record (count > 0)
+__device__ inline float rec_min_d2(const RecGrid& g, float qx, float qy, float qz, const float4 r0, const float4 r1,
+                                   const float4 r2, const float4 r3)
+{
+  const uint32_t count = __float_as_uint(r0.x);
+  float best, d;
+  if (count <= 5)
+  {
+    d = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
+    best = d;
+    d = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
+    best = (count > 1 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
+    best = (count > 2 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
+    best = (count > 3 && d < best) ? d : best;
+    d = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
+    best = (count > 4 && d < best) ? d : best;
+    return best;
+  }
+  d = d2_simple(qx, qy, qz, r0.z, r0.w, r1.x);
+  best = d;
+  d = d2_simple(qx, qy, qz, r1.y, r1.z, r1.w);
+  best = d < best ? d : best;
+  d = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
+  best = d < best ? d : best;
+  d = d2_simple(qx, qy, qz, r2.w, r3.x, r3.y);
+  best = d < best ? d : best;
+  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(__float_as_uint(r0.y));
+  for (uint32_t j = 0; j < count - 4; ++j)
+  {
+    const float* s = o + 16 * (j / 5) + 3 * (j % 5);
+    d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
+    best = d < best ? d : best;
+  }
+  return best;
+}
+
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
 // MODE 1: candidate-voxel index
 template <int BLOCK, int MODE, bool STATS>
@@ -378,8 +436,15 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
 //  * per-(particle, lane) float terms go to LDS and are summed in fp64 in a fixed order (deterministic), one partial per
 //    (tile, particle); lik_finalize_kernel adds the tiles in order.
 // Same per-point arithmetic as likelihood_kernel — identical terms — only the (fp64) summation order differs.
-template <int G, int MODE>
-__global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
+//
+// U > 1 (MODE 2 only): U particles per loop iteration with the dependent steps batched — U transforms, then U
+// brick-table loads, then U record loads (4 x 16 bytes each), then the arithmetic — so that every lane has U independent
+// L2 round trips in flight instead of one (the U = 1 loop is a single dependent chain transform -> table -> record ->
+// sqrt per particle, and 8 wavefronts per SIMD do not cover it: DESIGN.md section 6). The loads are issued unconditionally —
+// lanes with nothing to look up read brick-table entry 0 / record 0 and discard it — so the U chains stay in one basic
+// block. MINW = wavefronts per SIMD the register allocation must leave room for (8 -> 64 VGPRs, 5 -> 96, 4 -> 128).
+template <int G, int MODE, int U = 1, int MINW = 8>
+__global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
                                                                int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
                                                                LikParams prm, double* __restrict__ partial_sum,
@@ -423,6 +488,76 @@ __global__ __launch_bounds__(256) void likelihood_tiled_kernel(const float* __re
   const float4 v = have_point ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const int n_valid = min(G, n_p - group * G);
+  if constexpr (U > 1 && MODE == 2)
+  {
+    static_assert(G % U == 0, "the particle group must be a multiple of the unroll");
+    for (int k = 0; k < n_valid; k += U)
+    {
+      float qx[U], qy[U], qz[U];
+      uint32_t ti[U], sub[U];
+      bool in[U];
+      // step 1: U transforms + voxel addresses (a tail iteration re-evaluates the last valid particle; its results are
+      // not stored)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        const int kk = min(k + u, n_valid - 1);
+        const Vec3f pos = { s_pose[kk][0], s_pose[kk][1], s_pose[kk][2] };
+        const Quat rot = { s_pose[kk][3], s_pose[kk][4], s_pose[kk][5], s_pose[kk][6] };
+        const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+        qx[u] = tp.x * prm.wx;
+        qy[u] = tp.y * prm.wy;
+        qz[u] = tp.z * prm.wz;
+        in[u] = rec_locate(rg, qx[u], qy[u], qz[u], ti[u], sub[u]) && have_point;
+      }
+      // step 2: U brick-table loads (lanes outside the grid read entry 0 and discard it)
+      int b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        b[u] = rg.brick_table[in[u] ? ti[u] : 0u];
+      // step 3: U record loads (lanes without a brick read record 0 and discard it)
+      float4 r[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        in[u] = in[u] && b[u] >= 0;
+        const float4* rp = rg.rec + 4 * static_cast<size_t>(in[u] ? ((static_cast<uint32_t>(b[u]) << 9) | sub[u]) : 0u);
+        r[u][0] = rp[0];
+        r[u][1] = rp[1];
+        r[u][2] = rp[2];
+        r[u][3] = rp[3];
+      }
+      // step 4: arithmetic
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        float term = 0.f;
+        bool matched = false;
+        if (in[u] && __float_as_uint(r[u][0].x) != 0u)
+        {
+          const float d2 = rec_min_d2(rg, qx[u], qy[u], qz[u], r[u][0], r[u][1], r[u][2], r[u][3]);
+          if (d2 < prm.r2)
+          {
+            const float s = sqrtf(d2);
+            const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
+            if (!(dist < 0.0f))
+            {
+              term = dist * prm.match_weight;
+              matched = true;
+            }
+          }
+        }
+        if (k + u < n_valid)
+        {
+          s_term[k + u][t] = term;
+          const unsigned long long m = __ballot(matched);
+          if (lane == 0)
+            s_cnt[k + u][wave] = static_cast<unsigned>(__popcll(m));
+        }
+      }
+    }
+  }
+  else
   for (int k = 0; k < n_valid; ++k)
   {
     const Vec3f pos = { s_pose[k][0], s_pose[k][1], s_pose[k][2] };

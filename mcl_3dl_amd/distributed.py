@@ -12,9 +12,28 @@ Resampling (SURVEY.md §8f-1) is the one step with a real exchange: pf::resample
 the GLOBAL prefix sums of the weights, so an output slot on one GPU may copy a particle that lives on another.
 `sharded_resample` all-gathers the weights (4 B/particle) and the 13-float states (52 B/particle; 13.6 MB at 262 144
 particles, one collective each), every rank builds the same plan, and each rank fills its own output slice.
+
+Stream contract.  The engine enqueues its kernels on its own context stream (`Engine.set_stream`; by default a private
+non-blocking stream), torch enqueues its fills and collectives on torch's current stream.  Every helper below that mixes
+the two calls `_fence(engine, tensor)` around the engine call: a no-op when the engine has been bound to torch's current
+stream (`engine.set_stream(torch.cuda.current_stream().cuda_stream)` — what bench.py does, and the fast path), otherwise a
+full synchronisation of both streams, so that a collective can never read a record the engine has not written yet and a
+zero-fill can never land after the engine's write.
 """
 import torch
 import torch.distributed as dist
+
+
+def _fence(engine, tensor):
+    """Order torch's current stream and the engine's stream against each other (see the module docstring)."""
+    get = getattr(engine, "get_stream", None)
+    if get is None or not tensor.is_cuda:
+        return  # CPU tensors / test doubles: nothing is asynchronous
+    cur = torch.cuda.current_stream(tensor.device)
+    if get() == cur.cuda_stream and cur.cuda_stream != 0:
+        return
+    cur.synchronize()
+    engine.synchronize()
 
 
 def shard_bounds(n, world, rank):
@@ -83,6 +102,7 @@ class EngineResampleOps:
         self.engine = engine
 
     def begin(self, weight_all):
+        _fence(self.engine, weight_all)  # the all-gather that produced weight_all ran on torch's stream
         return self.engine.resample_begin_device(weight_all, weight_all.shape[0])
 
     def plan(self, initial_p):
@@ -90,7 +110,9 @@ class EngineResampleOps:
 
     def apply_slice(self, state_all, noise13, lo, count):
         out = torch.empty((count, 13), dtype=torch.float32, device=state_all.device)
+        _fence(self.engine, state_all)
         self.engine.resample_apply_device(state_all, noise13, out, lo, count)
+        _fence(self.engine, out)
         return out
 
 
@@ -117,7 +139,9 @@ def sharded_expectation(engine, d_pose, d_weight, d_bias, n_local, n_total, grou
     16-double record per rank, all-gathered (128 B per rank), combined on the host in rank order.
     Returns (mean7, total weight, global index of the max-weight particle, of the max biased-weight particle)."""
     rec = torch.zeros(16, dtype=torch.float64, device=d_pose.device)
+    _fence(engine, rec)
     engine.moments_partial_device(d_pose, d_weight, d_bias, n_local, rec)
+    _fence(engine, rec)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         allrec = torch.empty(16 * world, dtype=torch.float64, device=rec.device)
@@ -132,7 +156,9 @@ def sharded_covariance(engine, d_pose, d_weight, n_local, mean7, group=None):
     """pf::covariance (pf.h:304-360, pass ratio 1, all particles) over particle shards: 22 sums per rank, one
     all-reduce(SUM) of 176 bytes, host division."""
     rec = torch.zeros(22, dtype=torch.float64, device=d_pose.device)
+    _fence(engine, rec)
     engine.covariance_partial_device(d_pose, d_weight, n_local, mean7, rec)
+    _fence(engine, rec)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
     return engine.covariance_finish(rec.cpu().numpy())
