@@ -9,15 +9,35 @@ A step = one pass of the hot path over one batch of synthetic input: likelihood-
 N_p particles x N_s scan points (+ beam kernel when the workload has beam points), pf::measure
 (weight multiply, {sum w, sum w ln w, ratio min/max} reduction, one all-reduce when N > 1, normalise +
 entropy).  Inputs (map structures, ordered scan, poses, prior weights) are resident in HBM before the
-timed region starts.  Particles shard across ranks ("weak": every GPU gets the configuration's full
-particle count); map and scan are replicated.
+timed region starts (the task contract's definition of `value`); the SURVEY.md §8d form of the same update —
+host buffers in, host buffers out: scan upload + pose H2D + kernels + weight D2H — is timed next to it and
+reported as `update_8d`, and the node's own call site through the drop-in C++ classes as `route_a`.
+
+Particles shard across ranks; map and scan are replicated.  `--scaling weak` (default): every rank holds the
+workload's full particle count.  `--scaling strong`: the workload's particles are split over the ranks.  With
+N > 1 both are measured (the one not asked for under `other_scaling`).
 
 Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` and `cpu_baseline`.
+
+`roofline` (dominant kernel = the likelihood kernel): every fraction is <= 1 and tied to a resource —
+  hbm         HBM-side bytes per launch from the committed PMC pass (FETCH_SIZE x 2 + WRITE_SIZE, profiles/) / live
+              kernel time / 8 TB/s.  Small by construction: the index is built so that the working set of a scan tile
+              stays in one XCD's L2.
+  l2          L1->L2 read requests per launch (TCP_TCC_READ_REQ, PMC) x 128-byte lines / live kernel time / 34.5 TB/s
+  valu_issue  VALU wave-instructions per launch (SQ_INSTS_VALU, PMC) x measured cycles per instruction
+              (profiles/valu_microbench.hip) / (SIMDs x kernel cycles)
+`bound` names the largest; `achieved / peak / frac` repeat that entry.  The canonical algorithmic bytes of SURVEY.md
+§8d (27-cell structure, 16 + 27*4 + 16*K per evaluation) are kept as `algorithmic_bytes_per_launch`, NOT divided by
+the HBM peak: the shipped index never reads them (it reads 68 B per evaluation, from L2).
 """
 import argparse
 import json
 import os
+import re
+import struct
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,7 +46,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+L2_PEAK_GBPS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
+L2_LINE_BYTES = 128.0    # gfx950 L1 <-> L2 request granularity
+N_SIMD = 256 * 4
+CLOCK_HZ = 2.4e9         # sustained shader clock after the pre-warm (GRBM_GUI_ACTIVE / kernel time, profiles/)
+ILP_VARIANTS = {0: (1, 8), 1: (2, 8), 2: (4, 5), 3: (4, 4)}  # lik_ilp -> (U, MINW) template arguments
 
 
 def parse():
@@ -35,16 +60,26 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", help="C1..C5 of BASELINE.json (default C2: 4096 x 16k, 1M-pt map)")
-    ap.add_argument("--particles", type=int, default=0, help="override particles per GPU")
+    ap.add_argument("--particles", type=int, default=0, help="override the workload's particle count")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the driver's contract): every rank holds the workload's full particle count; "
+                         "strong: the workload's particles are split over the ranks (BASELINE config 4 is a fixed "
+                         "262 144-particle problem sharded over 8 GPUs). With N > 1 the other mode is measured too")
     ap.add_argument("--dist-weight-z", type=float, default=1.0)
     ap.add_argument("--lik-index", type=int, default=2,
                     help="2 = candidate records (default), 1 = candidate runs, 0 = 27-cell scan")
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
+    ap.add_argument("--lik-ilp", type=int, default=-1,
+                    help="tiled kernel: evaluations in flight per lane (-1 = the library's default, 0 = one, 1 = two, "
+                         "2 / 3 = four at 5 / 4 wavefronts per SIMD)")
     ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
     ap.add_argument("--map-jitter", type=float, default=0.0,
                     help="displace every map point uniformly by +-this (m): voxel-filter centroids instead of a lattice")
+    ap.add_argument("--jitter-check", type=float, default=0.045,
+                    help="also time the likelihood kernel on the same map with every point displaced by +-this "
+                         "(extra key `map_jitter`; 0 = skip; C2/C3 only)")
     ap.add_argument("--lik-small", type=int, default=1)
     ap.add_argument("--overlap-models", type=int, default=1)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
@@ -59,30 +94,42 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys (post-update reductions, resampling, fused update, route A, jitter check)")
+    ap.add_argument("--route-a-reps", type=int, default=5,
+                    help="timed repetitions of the node's call site through the drop-in C++ classes "
+                         "(tests/cpp/adapter_demo.bin), 0 = skip")
     ap.add_argument("--cpu-particles", type=int, default=0,
                     help="particles in the CPU-baseline sample (0 = as many as ~12 s of one core buys, at most all)")
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_prefix, workload):
-    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary for this workload
-    (profiles/*_pmc_summary.csv, produced by profiles/run_profiles.sh in separate --pmc passes): FETCH_SIZE and
-    WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes actually fetched (MI355X_MICROARCH.md, HBM
-    section), hence the factor 2."""
+def pmc_counters(kernel_prefix, workload):
+    """Mean per launch of every counter the newest committed PMC summary for this workload holds for the kernel
+    (profiles/*_pmc_summary.csv, separate --pmc passes: profiles/run_profiles.sh). Returns (dict, path) or (None, None)."""
     import csv
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s*_pmc_summary.csv" % workload))):
-        vals = {}
+    vals, src = {}, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s*pmc*summary.csv" % workload))):
         for row in csv.DictReader(open(path)):
             if row["kernel"].startswith(kernel_prefix):
-                vals[row["counter"]] = float(row["mean_per_launch"])
-        if "FETCH_SIZE" in vals:
-            best = (path, vals)
-    if not best:
+                vals[row["counter"]] = float(row["mean_per_launch"])  # a later (newer) file wins, counter by counter
+                src = path
+    if not vals:
         return None, None
-    path, vals = best
-    return (2.0 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024.0, os.path.relpath(path, ROOT)
+    return vals, os.path.relpath(src, ROOT)
+
+
+def valu_cycles_per_instruction():
+    """Cycles one wave64 f32 VALU instruction occupies a SIMD at full occupancy, from the committed run of
+    profiles/valu_microbench.hip (row: v_mul_f32, 8 independent chains, 8 wavefronts per SIMD, column cyc@2.4GHz)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_microbench.txt")), reverse=True):
+        for line in open(path):
+            m = re.match(r"v_mul_f32 x8 independent\s+8\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", line)
+            if m:
+                return float(m.group(4)), os.path.relpath(path, ROOT)
+    return 2.0, "MI355X_MICROARCH.md (v_fma_f32 wave64: 2 cycles on a SIMD-32); no micro-benchmark run committed yet"
 
 
 def cpu_baseline(sc, dist_weight, n_particles, beam_points):
@@ -100,7 +147,7 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
     n = min(n_particles, len(sc.poses))
     lik, q, sec = o.likelihood_measure(sc.poses[:n], sc.scan_lik, threads=1, return_time=True)
     evals = n * len(sc.scan_lik)
-    out = {"value": evals / sec, "unit": "particle\u00b7point evals/s", "cores": 1,
+    out = {"value": evals / sec, "unit": "particle·point evals/s", "cores": 1,
            "kind": "reference" if kind == "ref" else "port",
            "sample": "%d of the workload's particles x %d points, likelihood model, 1 thread, %.1f s"
                      % (n, len(sc.scan_lik), sec),
@@ -113,7 +160,7 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
 
 
 def _tiled_group(n_s, n_p, forced):
-    """The tiled kernel's particles-per-work-group as the library picks it (host_measure.h)."""
+    """The tiled kernel's particles-per-work-group as the library picks it (host_measure.h:plan_lik)."""
     if forced:
         return forced
     n_tiles = (n_s + 255) // 256
@@ -139,11 +186,43 @@ def _flush_c_stdio():
         pass
 
 
+def route_a(sc, dist_weight, n_b, reps):
+    """The node's call site (src/mcl_3dl.cpp:377-426) through the drop-in C++ classes over the C ABI: per-particle
+    measure() virtuals answered from one batched launch per model, weights normalised by the reference's pf.h on the
+    CPU. tests/cpp/adapter_demo.bin is built where the reference headers exist and travels as a file."""
+    exe = os.path.join(ROOT, "tests", "cpp", "adapter_demo.bin")
+    if not os.path.exists(exe) or reps <= 0:
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        scene, result = os.path.join(tmp, "scene.bin"), os.path.join(tmp, "result.bin")
+        with open(scene, "wb") as f:
+            f.write(struct.pack("<8Q", len(sc.map_xyz), len(sc.poses), len(sc.scan_lik), len(sc.scan_beam),
+                                len(sc.origins), max(n_b, 1), 1, 0xFFFFFFFF))
+            f.write(struct.pack("<5f", dist_weight[0], dist_weight[1], dist_weight[2], 1.0, 1.0))
+            for a, dt in ((sc.map_xyz, np.float32), (sc.map_label, np.uint32), (sc.poses, np.float32),
+                          (sc.odom_err, np.float32), (sc.weights, np.float32), (sc.scan_lik, np.float32),
+                          (sc.scan_beam, np.float32), (sc.scan_beam_label, np.uint32), (sc.origins, np.float32)):
+                f.write(np.ascontiguousarray(a, dtype=dt).tobytes())
+        try:
+            proc = subprocess.run([exe, scene, result, str(reps)], capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            return {"error": "adapter_demo timed out"}
+        m = re.search(r"route_a_ms_per_update (\S+)", proc.stdout)
+        if proc.returncode != 0 or not m:
+            return {"error": (proc.stdout + proc.stderr)[-300:]}
+        ms = float(m.group(1))
+        return {"ms_per_update": ms, "evals_per_s": len(sc.poses) * len(sc.scan_lik) / (ms * 1e-3), "reps": reps,
+                "what": "pf_->measure(measure_func) through the drop-in LidarMeasurementModel{Likelihood,Beam} classes "
+                        "(per-particle virtuals, host pose/cloud packing, one measure_batch per model, poses uploaded "
+                        "once per update, weights normalised by the reference's pf.h on the CPU)"}
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
     from mcl_3dl_amd import capi
+    from mcl_3dl_amd.distributed import shard_bounds
     from mcl_3dl_amd.synthetic import CONFIGS, make_config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,17 +250,13 @@ def main():
         _flush_c_stdio()
 
     cfg = CONFIGS[args.workload]
-    n_p = args.particles or cfg["n_p"]
-    # weak scaling: every rank holds a full-size particle shard drawn with its own seed; map and scan are replicated
+    n_cfg = args.particles or cfg["n_p"]
     extra_cfg = dict(n_s=args.scan_points) if args.scan_points else {}
     if args.map_jitter:
         extra_cfg["map_jitter"] = args.map_jitter
     if args.beam_points:
         extra_cfg["n_b"] = args.beam_points  # C3 stress case N_b = 16 384
-    sc = make_config(args.workload, n_p=n_p, seed=12345, **extra_cfg)
-    if rank > 0:
-        shard = make_config(args.workload, n_p=n_p, seed=12345 + rank, **extra_cfg)
-        sc.poses = shard.poses
+    sc = make_config(args.workload, n_p=n_cfg, seed=12345, **extra_cfg)
     dist_weight = (1.0, 1.0, args.dist_weight_z)
     n_s, n_b = len(sc.scan_lik), len(sc.scan_beam)
 
@@ -203,34 +278,72 @@ def main():
     eng.set_option("lik_small", args.lik_small)
     eng.set_option("overlap_models", args.overlap_models)
     eng.set_option("lik_group", args.lik_group)
+    if args.lik_ilp >= 0:
+        eng.set_option("lik_ilp", args.lik_ilp)
+    lik_ilp = int(eng.get_option("lik_ilp"))
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
-    d_pose = torch.from_numpy(sc.poses).to(dev).contiguous()
-    d_w0 = torch.from_numpy(sc.weights).to(dev).contiguous()
-    d_w = d_w0.clone()
-    d_lik = torch.empty(n_p, dtype=torch.float32, device=dev)
-    d_ratio = torch.empty(n_p, dtype=torch.float32, device=dev)
-    d_beam = torch.empty(n_p, dtype=torch.float32, device=dev)
-    d_stats = torch.zeros(4, dtype=torch.float32, device=dev)
-    # one all-reduce(SUM) carries the sums and, in per-rank slots, the max/min candidates
-    d_pack = torch.zeros(2 + 2 * world, dtype=torch.float64, device=dev)
+    class Shard:
+        """This rank's particles for one scaling mode, resident on the device."""
 
-    def step():
-        d_w.copy_(d_w0)  # resampling leaves uniform weights before every update (pf.h:203,207)
-        eng.measure_device(d_pose, n_p, d_lik, d_ratio, d_beam if n_b else None)
-        eng.pf_partial_device(d_w, d_lik, d_beam if n_b else None, None, d_ratio, n_p, d_pack, rank, world)
+        def __init__(self, mode):
+            self.mode = mode
+            if mode == "weak":
+                # every rank holds a full-size particle set drawn with its own seed
+                poses = sc.poses if rank == 0 else make_config(args.workload, n_p=n_cfg, seed=12345 + rank, **extra_cfg).poses
+                self.n_total = n_cfg * world
+            else:
+                lo, hi = shard_bounds(n_cfg, world, rank)
+                poses = sc.poses[lo:hi]
+                self.n_total = n_cfg
+            self.n = len(poses)
+            self.host_poses = poses
+            self.d_pose = torch.from_numpy(np.ascontiguousarray(poses)).to(dev).contiguous()
+            self.d_w0 = torch.full((self.n,), 1.0 / self.n_total, dtype=torch.float32, device=dev)
+            self.d_w = self.d_w0.clone()
+            self.d_lik = torch.empty(self.n, dtype=torch.float32, device=dev)
+            self.d_ratio = torch.empty(self.n, dtype=torch.float32, device=dev)
+            self.d_beam = torch.empty(self.n, dtype=torch.float32, device=dev)
+            self.d_stats = torch.zeros(4, dtype=torch.float32, device=dev)
+            # one all-reduce(SUM) carries the sums and, in per-rank slots, the max/min candidates
+            self.d_pack = torch.zeros(2 + 2 * world, dtype=torch.float64, device=dev)
+
+    def step(sh):
+        sh.d_w.copy_(sh.d_w0)  # resampling leaves uniform weights before every update (pf.h:203,207)
+        eng.measure_device(sh.d_pose, sh.n, sh.d_lik, sh.d_ratio, sh.d_beam if n_b else None)
+        eng.pf_partial_device(sh.d_w, sh.d_lik, sh.d_beam if n_b else None, None, sh.d_ratio, sh.n, sh.d_pack, rank, world)
         if use_dist:
-            dist.all_reduce(d_pack, op=dist.ReduceOp.SUM)  # the update's single collective (RCCL over xGMI), 16+16*N bytes
-        eng.pf_apply_device(d_w, n_p, d_pack, d_stats, world)
+            dist.all_reduce(sh.d_pack, op=dist.ReduceOp.SUM)  # the update's single collective (RCCL over xGMI), 16+16*N bytes
+        eng.pf_apply_device(sh.d_w, sh.n, sh.d_pack, sh.d_stats, world)
+
+    def timed(sh, steps):
+        """K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step(sh)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t1
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    main_sh = Shard(args.scaling)
+    n_p = main_sh.n
 
     # first call builds + uploads the map structures (outside every timed region)
-    step()
+    step(main_sh)
     torch.cuda.synchronize(dev)
     setup_s = time.time() - t0
 
     # exact workload counts for the algorithmic-bytes accounting (counting kernels, not timed)
-    ws = eng.workload_stats(d_pose, n_p)
+    ws = eng.workload_stats(main_sh.d_pose, n_p)
     k_bar = ws["sum_k"] / max(ws["evals"], 1.0)
     # SURVEY.md §8d: B_lik = 16 (scan point) + 27*4 (cell-range entries) + 16*K (candidate points) per evaluation,
     # + 28 B pose + 8 B result per particle
@@ -248,7 +361,7 @@ def main():
         torch.cuda.synchronize(dev)
         t_pre = time.perf_counter()
         for _ in range(8):
-            step()
+            step(main_sh)
         torch.cuda.synchronize(dev)
         per_step_ms = (time.perf_counter() - t_pre) * 1e3 / 8
         # batches of ~prewarm_ms / 4; at least 4 of them, then until two consecutive batches agree within 1 % (the clock
@@ -264,7 +377,7 @@ def main():
         while True:
             tb = time.perf_counter()
             for _ in range(n_batch):
-                step()
+                step(main_sh)
             torch.cuda.synchronize(dev)
             cur = (time.perf_counter() - tb) / n_batch
             prewarm["batches"] += 1
@@ -279,20 +392,11 @@ def main():
                 break
         prewarm["ms"] = (time.perf_counter() - t_pre) * 1e3
     for _ in range(args.warmup):
-        step()
+        step(main_sh)
     eng.set_option("timing_mask", args.timing_mask)
     eng.set_kernel_timing(True)
     eng.reset_kernel_time()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t1
+    elapsed = timed(main_sh, args.steps)
     lik_ms, lik_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
     # Second pass of the same K steps, outside `elapsed`, every kernel group timed and the two models one after the other:
     # the beam / pf durations (each timed group costs two event records per launch, so only the roofline kernel is
@@ -302,8 +406,21 @@ def main():
     eng.set_option("timing_mask", 7)
     eng.set_option("overlap_models", 0)
     eng.reset_kernel_time()
+    coll_ms = 0.0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(args.steps):
-        step()
+        sh = main_sh
+        sh.d_w.copy_(sh.d_w0)
+        eng.measure_device(sh.d_pose, sh.n, sh.d_lik, sh.d_ratio, sh.d_beam if n_b else None)
+        eng.pf_partial_device(sh.d_w, sh.d_lik, sh.d_beam if n_b else None, None, sh.d_ratio, sh.n, sh.d_pack, rank, world)
+        if use_dist:
+            ev0.record(stream)
+            dist.all_reduce(sh.d_pack, op=dist.ReduceOp.SUM)
+            ev1.record(stream)
+        eng.pf_apply_device(sh.d_w, sh.n, sh.d_pack, sh.d_stats, world)
+        if use_dist:
+            torch.cuda.synchronize(dev)
+            coll_ms += ev0.elapsed_time(ev1)
     torch.cuda.synchronize(dev)
     lik2_ms, lik2_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
     beam_ms, beam_n = eng.kernel_time(capi.KERNEL_BEAM)
@@ -316,139 +433,182 @@ def main():
         kernel_timing_pass = "likelihood: hipEvents inside the timed region; beam, pf: second pass of the same steps"
     eng.set_kernel_timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # the other scaling mode, same K steps, same bracketing (only when there is more than one rank to tell them apart)
+    other = None
+    if world > 1:
+        other_sh = Shard("strong" if args.scaling == "weak" else "weak")
+        for _ in range(max(args.warmup, 3)):
+            step(other_sh)
+        other_el = timed(other_sh, args.steps)
+        other = {"scaling": other_sh.mode, "particles_total": other_sh.n_total, "particles_per_gpu": other_sh.n,
+                 "ms_per_step": other_el / args.steps * 1e3,
+                 "value": float(other_sh.n_total) * n_s * args.steps / other_el}
 
     if rank == 0:
-        evals_per_step = float(world) * n_p * n_s
+        n_total = main_sh.n_total
+        evals_per_step = float(n_total) * n_s
         ms_per_step = elapsed / args.steps * 1e3
         value = evals_per_step * args.steps / elapsed
         lik_avg_ms = lik_ms / max(lik_n, 1)
-        achieved = bytes_lik_launch / (lik_avg_ms * 1e-3) / 1e9 if lik_n else 0.0
-        stats = d_stats.cpu().numpy()
-        tiled = bool(args.lik_tiled and n_s >= 1024 and n_p >= 4)
+        stats = main_sh.d_stats.cpu().numpy()
+        tiled = bool(args.lik_tiled and n_s >= 1024 and n_p >= 4) or bool(args.strict_order)
         group = _tiled_group(n_s, n_p, args.lik_group)
-        traffic, traffic_src = pmc_traffic("void mcl3dl::likelihood_tiled_kernel<%d, %d>" % (group, args.lik_index)
-                                           if tiled else "void mcl3dl::likelihood_kernel<256, %d, false>" % args.lik_index,
-                                           args.workload)
-        # bytes the shipped index really reads per evaluation, priced against the measured L2 ceiling
-        # (MI355X_MICROARCH.md: ~34.5 TB/s aggregate): mode 2 = brick-table entry + one 64-byte voxel record
-        l2 = None
-        if lik_n and args.lik_index in (0, 2):
-            bpe = 68.0 if args.lik_index == 2 else bytes_lik_launch / max(ws["evals"], 1.0)
-            l2_gbps = ws["evals"] * bpe / (lik_avg_ms * 1e-3) / 1e9
-            l2 = {"bytes_per_eval": bpe, "achieved": l2_gbps, "peak": 34500.0, "unit": "GB/s", "frac": l2_gbps / 34500.0}
+        small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
+        if tiled:
+            u, w = ILP_VARIANTS[lik_ilp] if (args.lik_index == 2 and group != 32) else (1, 4 if group == 32 else 8)
+            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %d>" % (group, args.lik_index, u, w)
+        elif small:
+            kernel_name = "likelihood_small_kernel<"
+        else:
+            kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 256, args.lik_index)
+        pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, args.workload)
+        cpi, cpi_src = valu_cycles_per_instruction()
+        kernel_s = lik_avg_ms * 1e-3
+        res = {}  # resource -> {"achieved", "peak", "unit", "frac"}
+        traffic = None
+        if pmc and lik_n:
+            if "FETCH_SIZE" in pmc:
+                # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes fetched
+                # (MI355X_MICROARCH.md, HBM section), hence the factor 2
+                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
+                gbps = traffic / kernel_s / 1e9
+                res["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                              "note": "cache-resident by construction: tile-major, XCD-aware launch keeps a scan "
+                                      "tile's voxel records in one XCD's L2"}
+            if "TCP_TCC_READ_REQ_sum" in pmc:
+                gbps = pmc["TCP_TCC_READ_REQ_sum"] * L2_LINE_BYTES / kernel_s / 1e9
+                res["l2"] = {"achieved": gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": gbps / L2_PEAK_GBPS,
+                             "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": L2_LINE_BYTES}
+            if "SQ_INSTS_VALU" in pmc:
+                busy = pmc["SQ_INSTS_VALU"] * cpi
+                avail = N_SIMD * kernel_s * CLOCK_HZ
+                res["valu_issue"] = {"achieved": busy / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
+                                     "unit": "G SIMD-cycles/s", "frac": busy / avail,
+                                     "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
+                                     "cycles_per_instruction": cpi, "cycles_per_instruction_source": cpi_src}
+        if res:
+            bound = max(res, key=lambda k: res[k]["frac"])
+            top = res[bound]
+        else:
+            bound, top = "hbm", {"achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None}
+        roofline = {
+            "bound": bound,
+            "kernel": kernel_name,
+            "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+            "traffic": traffic,
+            "counters_source": pmc_src,
+            "avg_launch_ms": lik_avg_ms, "launches": lik_n,
+            "resources": res,
+            # the canonical structure of SURVEY.md §8d, for the record; NOT priced against the HBM peak (the shipped index
+            # reads 68 B per evaluation — brick-table entry + one 64-byte voxel record — and reads them from L2)
+            "algorithmic_bytes_per_launch": bytes_lik_launch,
+            "algorithmic_bytes_per_eval": bytes_lik_launch / max(ws["evals"], 1.0),
+            "algorithmic_rate_GBps": bytes_lik_launch / kernel_s / 1e9 if lik_n else None,
+            "k_bar": k_bar,
+            "index_bytes_per_eval": 68.0 if args.lik_index == 2 else None,
+        }
         out = {
-            "metric": "particle\u00b7point evals/sec; filter-update Hz @ 4096 particles \u00d7 16k-pt scan",  # BASELINE.json
+            "metric": "particle·point evals/sec; filter-update Hz @ 4096 particles × 16k-pt scan",  # BASELINE.json
             "value": value,
-            "unit": "particle\u00b7point evals/s",
+            "unit": "particle·point evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d particles/GPU x %d-pt scan, %d-pt cube map, likelihood model%s, dist_weight=(1,1,%g)"
-                            % (args.workload, n_p, n_s, len(sc.map_xyz), " + beam (DDA) %d rays/particle" % n_b if n_b else "",
-                               args.dist_weight_z),
-                "particles_per_gpu": n_p, "scan_points": n_s, "beam_points": n_b, "map_points": int(len(sc.map_xyz)),
+                "workload": "%s: %d particles%s x %d-pt scan, %d-pt cube map, likelihood model%s, dist_weight=(1,1,%g)"
+                            % (args.workload, n_cfg, "/GPU" if args.scaling == "weak" else " in total", n_s, len(sc.map_xyz),
+                               " + beam (DDA) %d rays/particle" % n_b if n_b else "", args.dist_weight_z),
+                "particles_total": n_total, "particles_per_gpu": n_p, "scan_points": n_s, "beam_points": n_b,
+                "map_points": int(len(sc.map_xyz)),
                 "parallelism": "particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world,
                 "update_hz": 1e3 / ms_per_step,
                 "accumulate": ("float, reference order (bit-identical results)" if args.strict_order else
                                "fp64 tree (terms bit-identical to the reference's float terms)"),
+                "lik_ilp": lik_ilp,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": (("likelihood_tiled_kernel<%d,%d>" % (group, args.lik_index)) if tiled else
-                           ("likelihood_small_kernel<%d>" % args.lik_index) if (n_s <= 32 and n_p >= 256 and args.lik_small) else
-                           ("likelihood_kernel<%d,%d>" % (64 if n_s <= 128 else 256, args.lik_index))),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_lik_launch,
-                "bytes_per_eval": bytes_lik_launch / max(ws["evals"], 1.0),
-                "k_bar": k_bar,
-                "avg_launch_ms": lik_avg_ms,
-                "launches": lik_n,
-                # what the shipped index really reads per evaluation (brick-table entry + one 64-byte voxel record;
-                # the 27-cell scan reads the canonical bytes above), priced against the measured L2 ceiling
-                # (MI355X_MICROARCH.md: ~34.5 TB/s aggregate)
-                "l2": l2,
-            },
+            "value_definition": "device-resident update (map structures, ordered scan, poses, prior weights in HBM before "
+                                "the timed region); the host-buffer form of SURVEY.md section 8d is `update_8d`",
+            "roofline": roofline,
             "prewarm": prewarm,
             "kernel_timing_pass": kernel_timing_pass,
             "kernels_ms_per_step": {"likelihood": lik_avg_ms, "beam": beam_ms / max(beam_n, 1) if n_b else 0.0,
-                                    "pf": 2.0 * pf_ms / max(pf_n, 1)},
+                                    "pf": 2.0 * pf_ms / max(pf_n, 1),
+                                    "collective": coll_ms / args.steps if use_dist else 0.0},
             "setup_seconds": setup_s,
             "index": dict(eng.index_stats(), lik_index=args.lik_index, voxel_ratio=args.cand_voxel_ratio,
                           footprint_bytes=eng.memory_footprint()),
             "result_check": {"entropy": float(stats[0]), "match_ratio_min": float(stats[1]),
                              "match_ratio_max": float(stats[2]), "restored": bool(stats[3])},
         }
+        if other:
+            out["other_scaling"] = other
         # self-consistency of the numbers that were timed: normalised weights sum to 1 and reproduce the entropy
-        wf = d_w.cpu().numpy().astype(np.float64)
-        out["result_check"]["weight_sum"] = float(wf.sum())
-        out["result_check"]["entropy_from_weights"] = float(-(wf[wf > 0] * np.log(wf[wf > 0])).sum())
+        # (one rank's share of the sum when particles are sharded)
+        wf = main_sh.d_w.cpu().numpy().astype(np.float64)
+        out["result_check"]["weight_sum_this_rank"] = float(wf.sum())
+        if world == 1:
+            out["result_check"]["entropy_from_weights"] = float(-(wf[wf > 0] * np.log(wf[wf > 0])).sum())
         if n_b:
             beam_avg = beam_ms / max(beam_n, 1)
             out["beam"] = {"rays_per_s": ws["rays"] / (beam_avg * 1e-3), "dda_steps_per_s": ws["dda_steps"] / (beam_avg * 1e-3),
                            "algorithmic_GBps": bytes_beam_launch / (beam_avg * 1e-3) / 1e9, "avg_launch_ms": beam_avg}
-        # the reductions that follow the update in the node (expectationBiased + max + covariance) on the
-        # device-resident particles; each call ends with a D2H of a dozen scalars
-        torch.cuda.synchronize(dev)
-        t3 = time.perf_counter()
-        for _ in range(10):
-            mean7, _tot, _im, _ib = eng.expectation_device(d_pose, d_w, None, n_p)
-            eng.covariance_device(d_pose, d_w, n_p, mean7)
-        out["post_update_reductions"] = {"ms": (time.perf_counter() - t3) / 10 * 1e3,
-                                         "what": "expectationBiased + max + covariance over this rank's particles"}
-        # resampling of this rank's particles with the weights the update just produced: host bookkeeping
-        # (prefix sums, tie sort, it/it_prev walk) + device lower_bound / gather; noise = identity (timing only)
-        w_host = d_w.cpu().numpy()
-        st13 = np.zeros((n_p, 13), np.float32)
-        st13[:, :7] = sc.poses
-        t4 = time.perf_counter()
-        for _ in range(5):
-            pstep = eng.resample_begin(w_host)
-            _src, _dup, n_dup = eng.resample_plan(0, 0.37 * pstep)
-            ident = np.zeros((n_dup, 13), np.float32)
-            ident[:, 6] = 1.0
-            eng.resample_apply(st13, ident)
-        out["resample"] = {"ms": (time.perf_counter() - t4) / 5 * 1e3, "duplicates": int(n_dup),
-                           "what": "mcl3dl_hip_resample_begin + plan + apply, host buffers, %d particles" % n_p}
-        # the same with weights and 13-float states resident on the device (what a multi-GPU host runs per rank after
-        # the all-gather, mcl_3dl_amd/distributed.py:sharded_resample)
-        d_st_in = torch.from_numpy(st13).to(dev)
-        d_st_out = torch.empty_like(d_st_in)
-        torch.cuda.synchronize(dev)
-        t6 = time.perf_counter()
-        for _ in range(5):
-            pstep = eng.resample_begin_device(d_w, n_p)
-            _src, _dup, n_dup2 = eng.resample_plan(0, 0.37 * pstep, want_plan=False)
-            eng.resample_apply_device(d_st_in, ident[:n_dup2], d_st_out)
-        out["resample"]["ms_device_resident"] = (time.perf_counter() - t6) / 5 * 1e3
+        d_pose, d_w, d_w0, d_lik, d_ratio, d_beam, d_stats = (main_sh.d_pose, main_sh.d_w, main_sh.d_w0, main_sh.d_lik,
+                                                              main_sh.d_ratio, main_sh.d_beam, main_sh.d_stats)
         if world == 1:
-            # the drop-in boundary hands over HOST buffers: time the synchronous host entry point too (scan ordering on
-            # the host, H2D of scan + poses + weights, kernels, D2H of weights) — never part of `value`
+            # SURVEY.md section 8d's definition of one update: host buffers in, host buffers out (scan ordering + upload,
+            # pose and prior-weight H2D, kernels, reduction, weight D2H) through the synchronous host entry point
             eng.set_stream(None)
             eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
             t2 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
+            for _ in range(args.steps):
                 eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
-            host_ms = (time.perf_counter() - t2) / reps * 1e3
-            out["host_api"] = {"ms_per_update": host_ms, "evals_per_s": n_p * n_s / (host_ms * 1e-3),
-                               "note": "mcl3dl_hip_measure_update with host buffers (PCIe + host-side scan ordering included)"}
+            host_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            out["update_8d"] = {"ms_per_update": host_ms, "value": n_p * n_s / (host_ms * 1e-3),
+                                "unit": "particle·point evals/s", "update_hz": 1e3 / host_ms, "steps": args.steps,
+                                "what": "mcl3dl_hip_measure_update on host buffers: scan upload + pose/weight H2D + kernels "
+                                        "+ weight/likelihood D2H, PCIe included (SURVEY.md section 8d's timed region)"}
             eng.set_stream(stream.cuda_stream)
+        if not args.no_extras:
+            # the reductions that follow the update in the node (expectationBiased + max + covariance) on the
+            # device-resident particles; each call ends with a D2H of a dozen scalars
+            torch.cuda.synchronize(dev)
+            t3 = time.perf_counter()
+            for _ in range(10):
+                mean7, _tot, _im, _ib = eng.expectation_device(d_pose, d_w, None, n_p)
+                eng.covariance_device(d_pose, d_w, n_p, mean7)
+            out["post_update_reductions"] = {"ms": (time.perf_counter() - t3) / 10 * 1e3,
+                                             "what": "expectationBiased + max + covariance over this rank's particles"}
+            # resampling of this rank's particles with the weights the update just produced: host bookkeeping
+            # (prefix sums, tie sort, it/it_prev walk) + device lower_bound / gather; noise = identity (timing only)
+            w_host = d_w.cpu().numpy()
+            st13 = np.zeros((n_p, 13), np.float32)
+            st13[:, :7] = main_sh.host_poses
+            t4 = time.perf_counter()
+            for _ in range(5):
+                pstep = eng.resample_begin(w_host)
+                _src, _dup, n_dup = eng.resample_plan(0, 0.37 * pstep)
+                ident = _identity_noise(n_dup)
+                eng.resample_apply(st13, ident)
+            out["resample"] = {"ms": (time.perf_counter() - t4) / 5 * 1e3, "duplicates": int(n_dup),
+                               "what": "mcl3dl_hip_resample_begin + plan + apply, host buffers, %d particles" % n_p}
+            # the same with weights and 13-float states resident on the device (what a multi-GPU host runs per rank after
+            # the all-gather, mcl_3dl_amd/distributed.py:sharded_resample)
+            d_st_in = torch.from_numpy(st13).to(dev)
+            d_st_out = torch.empty_like(d_st_in)
+            torch.cuda.synchronize(dev)
+            t6 = time.perf_counter()
+            for _ in range(5):
+                pstep = eng.resample_begin_device(d_w, n_p)
+                _src, _dup, n_dup2 = eng.resample_plan(0, 0.37 * pstep, want_plan=False)
+                eng.resample_apply_device(d_st_in, ident[:n_dup2], d_st_out)
+            out["resample"]["ms_device_resident"] = (time.perf_counter() - t6) / 5 * 1e3
+        if world == 1 and not args.no_extras:
             # the fused device-resident call (measure + pf::measure in one C call) replaying its captured hipGraph, next
             # to the same call enqueuing kernel by kernel: what launch overhead is worth at this size. Not `value`.
             fused = {}
@@ -491,8 +651,32 @@ def main():
             gq = d_ratio[:n].cpu().numpy()
             out["result_check"]["max_rel_err_vs_cpu"] = float(np.max(np.abs(gl - cpu_lik) / np.maximum(np.abs(cpu_lik), 1e-30)))
             out["result_check"]["match_ratio_equal"] = bool(np.array_equal(gq, cpu_q))
+            out["result_check"]["tolerance"] = ("default mode: fp64 sum of the reference's float terms vs the reference's "
+                                                "sequential float sum, gate 1e-5 (north_star); strict_order=1 is bit-identical")
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            ra = route_a(sc, dist_weight, n_b, args.route_a_reps if args.workload in ("C1", "C2", "C3") else 0)
+            if ra:
+                out["route_a"] = ra
+        if world == 1 and not args.no_extras and args.jitter_check > 0 and args.workload in ("C2", "C3") and not args.map_jitter:
+            # standing robustness figure: the same workload on a map whose points are voxel-filter centroids, not a lattice
+            scj = make_config(args.workload, n_p=n_cfg, seed=12345, map_jitter=args.jitter_check, **extra_cfg)
+            eng.set_map(scj.map_xyz, scj.map_label, stamp=2, dist_weight=dist_weight)
+            eng.upload_scan(scj.scan_lik, scj.scan_beam, scj.scan_beam_label, scj.origins)
+            dj = torch.from_numpy(scj.poses).to(dev).contiguous()
+            for _ in range(5):
+                eng.measure_device(dj, n_p, d_lik, d_ratio, None)
+            eng.set_option("timing_mask", 1)
+            eng.set_kernel_timing(True)
+            eng.reset_kernel_time()
+            for _ in range(args.steps):
+                eng.measure_device(dj, n_p, d_lik, d_ratio, None)
+            jm, jn = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
+            eng.set_kernel_timing(False)
+            out["map_jitter"] = {"jitter_m": args.jitter_check, "likelihood_ms": jm / max(jn, 1),
+                                 "vs_lattice": (jm / max(jn, 1)) / lik_avg_ms if lik_avg_ms else None,
+                                 "index": eng.index_stats()}
         line = json.dumps(out)
     if use_dist:
         dist.barrier()

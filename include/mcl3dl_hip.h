@@ -274,8 +274,11 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "strict_order"      0 (default) = fp64 tree sums; 1 = add the likelihood terms per particle and the weights over the
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
- *                       (single GPU; costs an n_s x n_p float buffer and two serial passes) */
+ *                       (single GPU; costs an n_s x n_p float buffer and two serial passes)
+ *   "lik_ilp"           tiled kernel, evaluations in flight per lane: 0 = one (a single dependent chain per particle),
+ *                       1 = two, 2 / 3 = four with the register budget of 5 / 4 wavefronts per SIMD */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
+int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,
  * [3] device build time in ms. */
 int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mcl3dl_hip_workload_stats": (_i, [_p, _p, _sz, _p]),
     "mcl3dl_hip_memory_footprint": (_i, [_p, _p]),
     "mcl3dl_hip_set_option": (_i, [_p, C.c_char_p, _d]),
+    "mcl3dl_hip_get_option": (_i, [_p, C.c_char_p, C.POINTER(_d)]),
     "mcl3dl_hip_index_stats": (_i, [_p, _p]),
 }
 
@@ -408,6 +409,11 @@ class Engine:
 
     def set_option(self, name, value):
         self._check(self.lib.mcl3dl_hip_set_option(self.h, name.encode(), float(value)))
+
+    def get_option(self, name):
+        v = C.c_double(0)
+        self._check(self.lib.mcl3dl_hip_get_option(self.h, name.encode(), C.byref(v)))
+        return float(v.value)
 
     def index_stats(self):
         s = np.zeros(4, np.float64)

@@ -126,6 +126,27 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   return ctx->fail(-3, "unknown option '%s'", name);
 }
 
+int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
+{
+  if (!ctx || !name || !value)
+    return -1;
+  const std::string key(name);
+  if (key == "lik_index") *value = ctx->lik_index;
+  else if (key == "cand_voxel_ratio") *value = ctx->cand_voxel_ratio;
+  else if (key == "cand_phase") *value = ctx->cand_phase;
+  else if (key == "strict_order") *value = ctx->strict_order;
+  else if (key == "timing_mask") *value = ctx->timing_mask;
+  else if (key == "use_graph") *value = ctx->use_graph;
+  else if (key == "overlap_models") *value = ctx->overlap_models;
+  else if (key == "lik_small") *value = ctx->lik_small;
+  else if (key == "lik_tiled") *value = ctx->lik_tiled;
+  else if (key == "lik_group") *value = ctx->lik_group;
+  else if (key == "lik_ilp") *value = ctx->lik_ilp;
+  else
+    return ctx->fail(-3, "unknown option '%s'", name);
+  return 0;
+}
+
 int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4)
 {
   if (!ctx || !stats4)

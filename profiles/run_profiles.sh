@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-BENCH="python bench.py --steps 5 --warmup 1 --prewarm-ms 60 --no-cpu-baseline $*"
+BENCH="python bench.py --steps 5 --warmup 1 --prewarm-ms 60 --no-cpu-baseline --no-extras $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 for SET in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "GRBM_GUI_ACTIVE"; do

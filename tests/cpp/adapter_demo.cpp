@@ -4,7 +4,9 @@
 // It proves that code written against the reference's plugin surface runs unmodified on the GPU engine:
 //   scene file in -> LidarMeasurementModel{Likelihood,Beam} + pf::ParticleFilter::measure -> result file out.
 // tests/test_gpu_adapter.py compares the result file with the CPU oracle.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -71,11 +73,12 @@ static Cloud::Ptr makeCloud(const std::vector<float>& xyz, const std::vector<uin
 
 int main(int argc, char** argv)
 {
-  if (argc != 3)
+  if (argc != 3 && argc != 4)
   {
-    fprintf(stderr, "usage: adapter_demo scene.bin result.bin\n");
+    fprintf(stderr, "usage: adapter_demo scene.bin result.bin [timed repetitions]\n");
     return 2;
   }
+  const int reps = argc == 4 ? atoi(argv[3]) : 0;
   FILE* f = fopen(argv[1], "rb");
   if (!f)
     return 2;
@@ -171,6 +174,39 @@ int main(int argc, char** argv)
     return likelihood * (nd_a * expf(-x * x / nd_sq2));
   };
   pf_->measure(measure_func);
+
+  // Optional timing of this very statement (bench.py "route_a"): the node-visible latency of one measurement update
+  // through the per-particle virtuals. Weights are reset before every repetition (resampling leaves them uniform).
+  if (reps > 0)
+  {
+    std::vector<float> posterior(n_p);
+    {
+      size_t i = 0;
+      for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
+        posterior[i] = it->probability_;
+    }
+    double total_ms = 0;
+    for (int r = 0; r < reps + 1; ++r)
+    {
+      size_t i = 0;
+      for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
+        it->probability_ = weights[i];
+      idx = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      pf_->measure(measure_func);
+      const auto t1 = std::chrono::steady_clock::now();
+      if (r > 0)  // the first repetition is a warm-up
+        total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    }
+    printf("route_a_ms_per_update %.6f\n", total_ms / reps);
+    size_t i = 0;
+    for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
+      if (it->probability_ != posterior[i])
+      {
+        fprintf(stderr, "repetition changed the posterior of particle %zu\n", i);
+        return 3;
+      }
+  }
 
   // a call outside pf::measure (the debug-marker path, src/mcl_3dl.cpp:471-478): batch of one
   auto beam = std::dynamic_pointer_cast<mcl_3dl::LidarMeasurementModelBeam>(lidar_measurements_["beam"]);
