@@ -24,8 +24,9 @@ Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` a
               kernel time / 8 TB/s.  Small by construction: the index is built so that the working set of a scan tile
               stays in one XCD's L2.
   l2          L1->L2 read requests per launch (TCP_TCC_READ_REQ, PMC) x 128-byte lines / live kernel time / 34.5 TB/s
-  valu_issue  VALU wave-instructions per launch (SQ_INSTS_VALU, PMC) x measured cycles per instruction
-              (profiles/valu_microbench.hip) / (SIMDs x kernel cycles)
+  valu_issue  VALU wave-instructions per launch by class (SQ_INSTS_VALU, _ADD/_MUL/_FMA_F32, _TRANS_F32: PMC) x the
+              measured cycles per instruction of each class (profiles/valu_microbench.hip: f32 add/mul/fma ~2.4,
+              transcendental ~8, everything else ~4.3) / (SIMDs x kernel cycles)
 `bound` names the largest; `achieved / peak / frac` repeat that entry.  The canonical algorithmic bytes of SURVEY.md
 §8d (27-cell structure, 16 + 27*4 + 16*K per evaluation) are kept as `algorithmic_bytes_per_launch`, NOT divided by
 the HBM peak: the shipped index never reads them (it reads 68 B per evaluation, from L2).
@@ -51,7 +52,11 @@ L2_PEAK_GBPS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 L2_LINE_BYTES = 128.0    # gfx950 L1 <-> L2 request granularity
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9         # sustained shader clock after the pre-warm (GRBM_GUI_ACTIVE / kernel time, profiles/)
-ILP_VARIANTS = {0: (1, 8), 1: (2, 8), 2: (4, 5), 3: (4, 4)}  # lik_ilp -> (U, MINW) template arguments
+ILP_VARIANTS = {0: (1, 8), 1: (2, 8)}  # lik_ilp -> (U, MINW) template arguments
+# cycles one wave64 VALU instruction occupies a SIMD, by class (profiles/r02*_valu_microbench.txt; fallback values = the
+# round-2 measurement): f32 add / sub / mul / fma issue at the full rate, transcendentals at a quarter of the half rate,
+# everything else (integer, compares, selects, moves, conversions, min / max, packed pairs, every f64 op) at half rate
+VALU_COST_FALLBACK = {"full": 2.4, "half": 4.3, "trans": 8.2}
 
 
 def parse():
@@ -72,8 +77,9 @@ def parse():
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
     ap.add_argument("--lik-ilp", type=int, default=-1,
-                    help="tiled kernel: evaluations in flight per lane (-1 = the library's default, 0 = one, 1 = two, "
-                         "2 / 3 = four at 5 / 4 wavefronts per SIMD)")
+                    help="tiled kernel: evaluations in flight per lane (-1 = the library's default, 0 = one, 1 = two)")
+    ap.add_argument("--lik-trim", type=int, default=-1,
+                    help="tiled kernel: VALU-trimmed evaluation, same results (-1 = the library's default)")
     ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
     ap.add_argument("--map-jitter", type=float, default=0.0,
                     help="displace every map point uniformly by +-this (m): voxel-filter centroids instead of a lattice")
@@ -120,16 +126,25 @@ def pmc_counters(kernel_prefix, workload):
     return vals, os.path.relpath(src, ROOT)
 
 
-def valu_cycles_per_instruction():
-    """Cycles one wave64 f32 VALU instruction occupies a SIMD at full occupancy, from the committed run of
-    profiles/valu_microbench.hip (row: v_mul_f32, 8 independent chains, 8 wavefronts per SIMD, column cyc@2.4GHz)."""
+def valu_costs():
+    """Cycles one wave64 VALU instruction occupies a SIMD, by class, from the newest committed run of
+    profiles/valu_microbench.hip (two wavefronts per SIMD — enough to saturate the pipe — column cyc@2.4GHz):
+    full = mean of v_mul_f32 / v_add_f32, half = mean of v_max_f32 / v_cndmask-class rows, trans = v_sqrt_f32."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_microbench.txt")), reverse=True):
+        rows = {}
         for line in open(path):
-            m = re.match(r"v_mul_f32 x8 independent\s+8\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", line)
-            if m:
-                return float(m.group(4)), os.path.relpath(path, ROOT)
-    return 2.0, "MI355X_MICROARCH.md (v_fma_f32 wave64: 2 cycles on a SIMD-32); no micro-benchmark run committed yet"
+            m = re.match(r"(v_\S+).*?\s+(\d)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s*$", line)
+            if m and "independent" in line and m.group(2) == "2":
+                rows[m.group(1)] = float(m.group(6))
+        full = [rows[k] for k in ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_fma_f32") if k in rows]
+        half = [rows[k] for k in ("v_max_f32", "v_min_f32", "v_cndmask_b32", "v_mov_b32", "v_and_b32", "v_cvt_flr_i32_f32",
+                                  "v_mul_u32_u24", "v_add_u32", "v_cmp_lt_f32") if k in rows]
+        trans = [rows[k] for k in ("v_sqrt_f32", "v_rcp_f32") if k in rows]
+        if full and half and trans:
+            return ({"full": sum(full) / len(full), "half": sum(half) / len(half), "trans": sum(trans) / len(trans)},
+                    os.path.relpath(path, ROOT))
+    return dict(VALU_COST_FALLBACK), "bench.py VALU_COST_FALLBACK (no micro-benchmark run committed)"
 
 
 def cpu_baseline(sc, dist_weight, n_particles, beam_points):
@@ -280,7 +295,10 @@ def main():
     eng.set_option("lik_group", args.lik_group)
     if args.lik_ilp >= 0:
         eng.set_option("lik_ilp", args.lik_ilp)
+    if args.lik_trim >= 0:
+        eng.set_option("lik_trim", args.lik_trim)
     lik_ilp = int(eng.get_option("lik_ilp"))
+    lik_trim = int(eng.get_option("lik_trim"))
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
@@ -456,13 +474,15 @@ def main():
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:
             u, w = ILP_VARIANTS[lik_ilp] if (args.lik_index == 2 and group != 32) else (1, 4 if group == 32 else 8)
-            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %d>" % (group, args.lik_index, u, w)
+            trim = bool(lik_trim and args.lik_index == 2 and group != 32)
+            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %d, %s>" % (group, args.lik_index, u, w,
+                                                                           "true" if trim else "false")
         elif small:
             kernel_name = "likelihood_small_kernel<"
         else:
             kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 256, args.lik_index)
         pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, args.workload)
-        cpi, cpi_src = valu_cycles_per_instruction()
+        cost, cost_src = valu_costs()
         kernel_s = lik_avg_ms * 1e-3
         res = {}  # resource -> {"achieved", "peak", "unit", "frac"}
         traffic = None
@@ -480,12 +500,24 @@ def main():
                 res["l2"] = {"achieved": gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": gbps / L2_PEAK_GBPS,
                              "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": L2_LINE_BYTES}
             if "SQ_INSTS_VALU" in pmc:
-                busy = pmc["SQ_INSTS_VALU"] * cpi
+                # instruction mix from the per-class counters (separate PMC pass); what they do not cover is priced at the
+                # half rate — integer ops, compares, selects, moves, conversions
+                n_all = pmc["SQ_INSTS_VALU"]
+                n_full = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                                                        "SQ_INSTS_VALU_FMA_F32"))
+                n_trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                have_mix = "SQ_INSTS_VALU_ADD_F32" in pmc
+                if not have_mix:
+                    n_full = 0.0  # no class counters: every instruction priced at the half rate (upper bound)
+                n_half = max(n_all - n_full - n_trans, 0.0)
+                busy = n_full * cost["full"] + n_half * cost["half"] + n_trans * cost["trans"]
                 avail = N_SIMD * kernel_s * CLOCK_HZ
                 res["valu_issue"] = {"achieved": busy / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
-                                     "unit": "G SIMD-cycles/s", "frac": busy / avail,
-                                     "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
-                                     "cycles_per_instruction": cpi, "cycles_per_instruction_source": cpi_src}
+                                     "unit": "G SIMD-cycles/s", "frac": min(busy / avail, 1.0), "frac_raw": busy / avail,
+                                     "wave_instructions_per_launch": n_all,
+                                     "full_rate_f32": n_full, "transcendental": n_trans, "half_rate_rest": n_half,
+                                     "cycles_per_instruction": cost, "cycles_per_instruction_source": cost_src,
+                                     "mix_from_counters": have_mix}
         if res:
             bound = max(res, key=lambda k: res[k]["frac"])
             top = res[bound]
@@ -530,7 +562,7 @@ def main():
                 "update_hz": 1e3 / ms_per_step,
                 "accumulate": ("float, reference order (bit-identical results)" if args.strict_order else
                                "fp64 tree (terms bit-identical to the reference's float terms)"),
-                "lik_ilp": lik_ilp,
+                "lik_ilp": lik_ilp, "lik_trim": lik_trim,
             },
             "value_definition": "device-resident update (map structures, ordered scan, poses, prior weights in HBM before "
                                 "the timed region); the host-buffer form of SURVEY.md section 8d is `update_8d`",

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCL3DL_HIP_ABI_VERSION 1
+#define MCL3DL_HIP_ABI_VERSION 2
 
 typedef struct mcl3dl_hip_ctx mcl3dl_hip_ctx;
 
@@ -243,6 +243,55 @@ int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* re
 /* Why the last capture attempt fell back to kernel-by-kernel launches ("" if none did). */
 const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx);
 
+/* ---- device groups: N GPUs behind one handle, one host process ----------------------------------
+ * The reference node is ONE C++ process (src/mcl_3dl.cpp:1466); a group lets that process use every GPU of the node with
+ * src/mcl_3dl.cpp untouched: the drop-in model classes call the group_* forms of the entry points above.
+ * A group owns one context per listed device and one worker thread per device. Particles are split into contiguous
+ * shards (mcl3dl_hip_group_shard: sizes differ by at most one), map / parameters / scan are replicated on every device,
+ * and one update needs exactly ONE collective — the all-reduce(sum) of the 2 + 2N doubles described at
+ * mcl3dl_hip_pf_partial_device:
+ *   "collective" 0 (default): ncclAllReduce on each device's stream (RCCL over xGMI; librccl is dlopen'ed the first time
+ *                a group of more than one device runs an update — MCL3DL_HIP_RCCL_LIB overrides the library name)
+ *   "collective" 1 (or environment MCL3DL_HIP_COLLECTIVE=host): the N records are brought to the host, summed in rank
+ *                order and sent back — for several contexts on ONE GPU (RCCL needs one GPU per rank) and as a fallback.
+ * With one device every group_* call is the plain call on its context (bit-identical results, no thread, no RCCL);
+ * option "direct_single" = 0 sends a one-device group through the sharded path as well (tests: RCCL with one rank).
+ * A group is not thread-safe (one caller at a time), like a context. */
+typedef struct mcl3dl_hip_group mcl3dl_hip_group;
+int mcl3dl_hip_group_create(mcl3dl_hip_group** out, const int* device_ids, int n_devices /* 1..64 */);
+void mcl3dl_hip_group_destroy(mcl3dl_hip_group* g);
+const char* mcl3dl_hip_group_last_error(const mcl3dl_hip_group* g);
+int mcl3dl_hip_group_size(const mcl3dl_hip_group* g);
+/* The context of one rank (options, introspection, per-device queries such as mcl3dl_hip_beam_status). */
+mcl3dl_hip_ctx* mcl3dl_hip_group_context(mcl3dl_hip_group* g, int rank);
+/* Shard bookkeeping (pure host function): particles [*begin, *begin + *count) belong to `rank`. */
+int mcl3dl_hip_group_shard(size_t n_p, int n_devices, int rank, size_t* begin, size_t* count);
+/* Broadcast forms of mcl3dl_hip_set_map / _set_likelihood_params / _set_beam_params / _set_option
+ * ("collective" is the group's own option, everything else goes to every context). */
+int mcl3dl_hip_group_set_map(mcl3dl_hip_group* g, const float* xyz, const uint32_t* label, size_t n_m, uint64_t stamp,
+                             const float* dist_weight);
+int mcl3dl_hip_group_set_likelihood_params(mcl3dl_hip_group* g, float match_dist_min, float match_dist_flat,
+                                           float match_weight);
+int mcl3dl_hip_group_set_beam_params(mcl3dl_hip_group* g, float map_grid_x, float map_grid_y, float map_grid_z,
+                                     float dda_grid_size, float ray_angle_half, float hit_range,
+                                     float beam_likelihood_min, uint32_t num_points, float ang_total_ref,
+                                     uint32_t filter_label_max, int add_penalty_short_only_mode);
+int mcl3dl_hip_group_set_option(mcl3dl_hip_group* g, const char* name, double value);
+/* Sharded forms of mcl3dl_hip_upload_poses / _measure_batch / _measure_update: same arguments, same results; host arrays
+ * are scattered to / gathered from the shards. measure_batch needs no collective; measure_update runs the one all-reduce. */
+int mcl3dl_hip_group_upload_poses(mcl3dl_hip_group* g, const float* pose /*n_p*7*/, size_t n_p);
+int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose /*n_p*7 or NULL*/, size_t n_p,
+                                   const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                                   const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                                   float* out_lik, float* out_match_ratio, float* out_beam);
+int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, const float* extra, float* weight_inout,
+                                    size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                                    const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                                    float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
+                                    float* match_ratio_min, float* match_ratio_max, int* restored);
+/* How many updates went through each kind of collective so far. */
+int mcl3dl_hip_group_collective_stats(const mcl3dl_hip_group* g, uint64_t* rccl_all_reduces, uint64_t* host_combines);
+
 /* ---- measurement support ------------------------------------------------------------------------------ */
 /* Per-kernel hipEvent timing on the launch stream (off by default). */
 int mcl3dl_hip_set_kernel_timing(mcl3dl_hip_ctx* ctx, int enable);
@@ -254,7 +303,8 @@ int mcl3dl_hip_reset_kernel_time(mcl3dl_hip_ctx* ctx);
 int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, double* stats6);
 /* Sizes of the device-resident structures (bytes): [0] cell-grid points, [1] cell-grid index, [2] DDA occupancy bitmap,
  * [3] DDA voxel index, [4] DDA points, [5] candidate-voxel brick table, [6] candidate-voxel run delimiters,
- * [7] candidate points. Structures that were never needed are 0. */
+ * [7] candidate points (with lik_index 2: [6] = the 64-byte voxel records, [7] = their overflow records). Structures that
+ * were never needed are 0. */
 int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
 /* Tuning knobs (no reference counterpart; results are identical for every setting):
  *   "lik_index"         2 (default) = candidate-voxel index, one 64-byte record per voxel; 1 = candidate-voxel index,
@@ -275,8 +325,11 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
  *                       (single GPU; costs an n_s x n_p float buffer and two serial passes)
- *   "lik_ilp"           tiled kernel, evaluations in flight per lane: 0 = one (a single dependent chain per particle),
- *                       1 = two, 2 / 3 = four with the register budget of 5 / 4 wavefronts per SIMD */
+ *   "lik_ilp"           tiled kernel: 1 = two evaluations in flight per lane (their brick-table and record loads are
+ *                       issued back to back), 0 = one
+ *   "lik_trim"          tiled kernel: 1 = VALU-trimmed evaluation (likelihood_kernels.h: zero-operand products of the
+ *                       quaternion product dropped, single-instruction floor, count-free minimum over sentinel-padded
+ *                       records, sqrt without the sub-2^-96 input scaling); results identical to 0 */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
 int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,

@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcl3dl_hip.so")
+# MCL3DL_HIP_LIB: another build of the same library (A/B measurements: mcl_3dl_amd/variants/); it must exist — a missing
+# file is an error, never a reason to fall back to anything
+LIB_PATH = os.environ.get("MCL3DL_HIP_LIB") or os.path.join(_HERE, "libmcl3dl_hip.so")
 
 KERNEL_LIKELIHOOD, KERNEL_BEAM, KERNEL_PF = 0, 1, 2
 BEAM_STATUS = {0: "SHORT", 1: "HIT", 2: "LONG", 3: "TOTAL_REFLECTION"}
@@ -62,6 +64,21 @@ SIGNATURES = {
     "mcl3dl_hip_workload_stats": (_i, [_p, _p, _sz, _p]),
     "mcl3dl_hip_memory_footprint": (_i, [_p, _p]),
     "mcl3dl_hip_set_option": (_i, [_p, C.c_char_p, _d]),
+    "mcl3dl_hip_group_create": (_i, [C.POINTER(_p), C.POINTER(_i), _i]),
+    "mcl3dl_hip_group_destroy": (None, [_p]),
+    "mcl3dl_hip_group_last_error": (C.c_char_p, [_p]),
+    "mcl3dl_hip_group_size": (_i, [_p]),
+    "mcl3dl_hip_group_context": (_p, [_p, _i]),
+    "mcl3dl_hip_group_shard": (_i, [_sz, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mcl3dl_hip_group_set_map": (_i, [_p, _p, _p, _sz, _u64, _p]),
+    "mcl3dl_hip_group_set_likelihood_params": (_i, [_p, _f, _f, _f]),
+    "mcl3dl_hip_group_set_beam_params": (_i, [_p, _f, _f, _f, _f, _f, _f, _f, _u32, _f, _u32, _i]),
+    "mcl3dl_hip_group_set_option": (_i, [_p, C.c_char_p, _d]),
+    "mcl3dl_hip_group_upload_poses": (_i, [_p, _p, _sz]),
+    "mcl3dl_hip_group_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
+    "mcl3dl_hip_group_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p,
+                                            _p]),
+    "mcl3dl_hip_group_collective_stats": (_i, [_p, C.POINTER(_u64), C.POINTER(_u64)]),
     "mcl3dl_hip_get_option": (_i, [_p, C.c_char_p, C.POINTER(_d)]),
     "mcl3dl_hip_index_stats": (_i, [_p, _p]),
 }
@@ -106,6 +123,102 @@ def _ptr(a):
     if isinstance(a, int):
         return C.c_void_p(a)
     return C.c_void_p(a.data_ptr())  # torch tensor (device memory)
+
+
+def group_shard(n_p, n_devices, rank):
+    """[begin, begin + count) of `rank` — the library's own shard rule (no GPU needed)."""
+    lib = load_library()
+    b, c = C.c_size_t(0), C.c_size_t(0)
+    if lib.mcl3dl_hip_group_shard(n_p, n_devices, rank, C.byref(b), C.byref(c)) != 0:
+        raise EngineError("group_shard: bad arguments")
+    return int(b.value), int(c.value)
+
+
+class Group:
+    """N GPUs behind one handle in ONE process (include/mcl3dl_hip.h, "device groups"): host arrays in, host arrays out."""
+
+    def __init__(self, device_ids=(0,), collective=None):
+        self.lib = load_library()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        rc = self.lib.mcl3dl_hip_group_create(C.byref(h), ids, len(device_ids))
+        if rc != 0 or not h:
+            raise EngineError("mcl3dl_hip_group_create(%s) failed with %d (no CPU fallback exists)" % (list(device_ids), rc))
+        self.h = h
+        self.n = len(device_ids)
+        if collective is not None:
+            self.set_option("collective", {"rccl": 0, "host": 1}[collective])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mcl3dl_hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError("mcl3dl_hip group error %d: %s" % (rc, self.lib.mcl3dl_hip_group_last_error(self.h).decode()))
+
+    def set_map(self, xyz, label=None, stamp=1, dist_weight=(1.0, 1.0, 1.0)):
+        xyz = _np_f32(xyz, 3)
+        lab = None if label is None else np.ascontiguousarray(label, dtype=np.uint32)
+        dw = None if dist_weight is None else _np_f32(dist_weight)
+        self._check(self.lib.mcl3dl_hip_group_set_map(self.h, _ptr(xyz), _ptr(lab), len(xyz), int(stamp), _ptr(dw)))
+
+    def set_likelihood_params(self, match_dist_min=0.2, match_dist_flat=0.05, match_weight=5.0):
+        self._check(self.lib.mcl3dl_hip_group_set_likelihood_params(self.h, match_dist_min, match_dist_flat, match_weight))
+
+    def set_beam_params(self, map_grid=(0.1, 0.1, 0.1), dda_grid_size=0.2, ray_angle_half=0.25 * np.pi / 180.0,
+                        hit_range=0.3, beam_likelihood_min=0.2, num_points=3, ang_total_ref=np.pi / 6.0,
+                        filter_label_max=0xFFFFFFFF, add_penalty_short_only_mode=True):
+        self._check(self.lib.mcl3dl_hip_group_set_beam_params(
+            self.h, map_grid[0], map_grid[1], map_grid[2], dda_grid_size, ray_angle_half, hit_range,
+            beam_likelihood_min, int(num_points), ang_total_ref, int(filter_label_max),
+            int(bool(add_penalty_short_only_mode))))
+
+    def set_option(self, name, value):
+        self._check(self.lib.mcl3dl_hip_group_set_option(self.h, name.encode(), float(value)))
+
+    def upload_poses(self, poses):
+        poses = _np_f32(poses, 7)
+        self._check(self.lib.mcl3dl_hip_group_upload_poses(self.h, _ptr(poses), len(poses)))
+        self._n_uploaded = len(poses)
+
+    def measure_batch(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
+        sl, sb, so, og = Engine._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        if poses is None:
+            n_p = self._n_uploaded
+        else:
+            poses = _np_f32(poses, 7)
+            n_p = len(poses)
+        lik, ratio, beam = (np.zeros(n_p, np.float32) for _ in range(3))
+        self._check(self.lib.mcl3dl_hip_group_measure_batch(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
+                                                            len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam)))
+        return lik, ratio, beam
+
+    def measure_update(self, poses, weights, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None, extra=None):
+        poses = _np_f32(poses, 7)
+        n_p = len(poses)
+        w = _np_f32(weights).copy()
+        ex = None if extra is None else _np_f32(extra)
+        sl, sb, so, og = Engine._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        lik, ratio, beam = (np.zeros(n_p, np.float32) for _ in range(3))
+        ent, rmin, rmax, rest = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        self._check(self.lib.mcl3dl_hip_group_measure_update(
+            self.h, _ptr(poses), _ptr(ex), _ptr(w), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so), len(sb), _ptr(og),
+            len(og), _ptr(lik), _ptr(ratio), _ptr(beam), C.byref(ent), C.byref(rmin), C.byref(rmax), C.byref(rest)))
+        return dict(weights=w, lik=lik, quality=ratio, beam=beam, entropy=float(ent.value),
+                    match_ratio_min=float(rmin.value), match_ratio_max=float(rmax.value), restored=bool(rest.value))
+
+    def collective_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.mcl3dl_hip_group_collective_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(rccl=int(a.value), host=int(b.value))
 
 
 class Engine:

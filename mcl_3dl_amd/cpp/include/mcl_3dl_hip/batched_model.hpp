@@ -100,7 +100,7 @@ protected:
     std::vector<float>& poses = e.pose_scratch;
     std::uint64_t epoch = 0;
     gatherPoses(s, poses, &epoch);
-    e.check(mcl3dl_hip_upload_poses(e.get(), poses.data(), poses.size() / 7));
+    e.check(mcl3dl_hip_group_upload_poses(e.group(), poses.data(), poses.size() / 7));
     e.pose_epoch = epoch;
     e.pose_count = poses.size() / 7;
   }

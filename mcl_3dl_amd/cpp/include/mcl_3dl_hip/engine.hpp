@@ -1,8 +1,8 @@
 // mcl_3dl_hip/engine.hpp — C++ host layer over the C ABI (include/mcl3dl_hip.h) shared by the two drop-in LiDAR
 // model classes.  Header-only except for the context singleton in src/engine.cpp.
 //
-//  * Engine            RAII handle on one mcl3dl_hip_ctx; C-ABI errors become std::runtime_error (the reference's
-//                      models only ever throw std::runtime_error, chunked_kdtree.h:224-225).
+//  * Engine            RAII handle on one mcl3dl_hip_group (1..N GPUs, particles sharded over them inside the library);
+//                      C-ABI errors become std::runtime_error.
 //  * BatchDescriptor   what the batch-aware pf::ParticleFilter::measure publishes before running the reference's
 //                      per-particle loop (include/mcl_3dl/pf.h:252-260), so a model's per-particle measure() can
 //                      evaluate ALL particles on the GPU at the first call and answer the rest from the result buffer.
@@ -25,28 +25,45 @@ namespace hip
 class Engine
 {
 public:
-  explicit Engine(int device_id = 0)
+  // One device group (include/mcl3dl_hip.h "device groups"): `devices` lists the GPUs the particles are sharded over.
+  explicit Engine(const std::vector<int>& devices = { 0 })
   {
-    const int rc = mcl3dl_hip_create(&ctx_, device_id);
-    if (rc != 0 || !ctx_)
-      throw std::runtime_error("mcl3dl_hip_create failed (" + std::to_string(rc) +
+    const int rc = mcl3dl_hip_group_create(&group_, devices.data(), static_cast<int>(devices.size()));
+    if (rc != 0 || !group_)
+      throw std::runtime_error("mcl3dl_hip_group_create failed (" + std::to_string(rc) +
                                "): no usable gfx950 device; this engine has no CPU fallback");
   }
   ~Engine()
   {
-    mcl3dl_hip_destroy(ctx_);
+    mcl3dl_hip_group_destroy(group_);
   }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
 
+  mcl3dl_hip_group* group() const
+  {
+    return group_;
+  }
+  // the first device's context: single-ray queries (getBeamStatus) run there
   mcl3dl_hip_ctx* get() const
   {
-    return ctx_;
+    return mcl3dl_hip_group_context(group_, 0);
   }
+  int size() const
+  {
+    return mcl3dl_hip_group_size(group_);
+  }
+  // C-ABI errors become std::runtime_error (the reference's models only ever throw std::runtime_error,
+  // chunked_kdtree.h:224-225)
   void check(const int rc) const
   {
     if (rc != 0)
-      throw std::runtime_error(std::string("mcl3dl_hip: ") + mcl3dl_hip_last_error(ctx_));
+      throw std::runtime_error(std::string("mcl3dl_hip: ") + mcl3dl_hip_group_last_error(group_));
+  }
+  void checkContext(const int rc) const
+  {
+    if (rc != 0)
+      throw std::runtime_error(std::string("mcl3dl_hip: ") + mcl3dl_hip_last_error(get()));
   }
 
   // process-wide context used by the drop-in model classes (the node builds one likelihood and one beam model that
@@ -65,7 +82,7 @@ public:
   std::vector<float> pose_scratch;
 
 private:
-  mcl3dl_hip_ctx* ctx_ = nullptr;
+  mcl3dl_hip_group* group_ = nullptr;
 };
 
 // Published by pf::ParticleFilter::measure (mcl_3dl/pf.h in this directory tree) for the duration of one update.

@@ -62,8 +62,8 @@ inline void syncMap(Engine& e, const ChunkedKdtree<PointType>& kdtree)
     xyz[3 * i + 2] = map->points[i].z;
     label[i] = map->points[i].label;
   }
-  e.check(mcl3dl_hip_set_map(e.get(), xyz.data(), label.data(), label.size(), map->header.stamp,
-                             has_w ? w : nullptr));
+  e.check(mcl3dl_hip_group_set_map(e.group(), xyz.data(), label.data(), label.size(), map->header.stamp,
+                                   has_w ? w : nullptr));
   e.map_cloud = map.get();
   e.map_stamp = map->header.stamp;
   e.map_size = map->points.size();

@@ -1,5 +1,9 @@
-// The process-wide engine shared by the drop-in LiDAR models (one map, one GPU; MCL3DL_HIP_DEVICE selects the device).
+// The process-wide engine shared by the drop-in LiDAR models: one map, one device group.
+//   MCL3DL_HIP_DEVICES=0,1,2,3   GPUs the particles are sharded over (default: MCL3DL_HIP_DEVICE, or device 0)
+//   MCL3DL_HIP_COLLECTIVE=host   combine the per-device sums on the host instead of an RCCL all-reduce
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 #include <mcl_3dl_hip/engine.hpp>
 
@@ -11,8 +15,28 @@ Engine& Engine::shared()
 {
   static Engine engine([]
                        {
-                         const char* env = std::getenv("MCL3DL_HIP_DEVICE");
-                         return env ? std::atoi(env) : 0;
+                         std::vector<int> devices;
+                         if (const char* list = std::getenv("MCL3DL_HIP_DEVICES"))
+                         {
+                           const std::string s(list);
+                           std::size_t pos = 0;
+                           while (pos < s.size())
+                           {
+                             const std::size_t comma = s.find(',', pos);
+                             const std::string item = s.substr(pos, comma == std::string::npos ? comma : comma - pos);
+                             if (!item.empty())
+                               devices.push_back(std::atoi(item.c_str()));
+                             if (comma == std::string::npos)
+                               break;
+                             pos = comma + 1;
+                           }
+                         }
+                         if (devices.empty())
+                         {
+                           const char* one = std::getenv("MCL3DL_HIP_DEVICE");
+                           devices.push_back(one ? std::atoi(one) : 0);
+                         }
+                         return devices;
                        }());
   return engine;
 }

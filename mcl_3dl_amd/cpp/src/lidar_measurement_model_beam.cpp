@@ -30,7 +30,7 @@ void LidarMeasurementModelBeam::refreshParameters()
 void LidarMeasurementModelBeam::pushParameters() const
 {
   hip::Engine& e = hip::Engine::shared();
-  e.check(mcl3dl_hip_set_beam_params(e.get(), params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_,
+  e.check(mcl3dl_hip_group_set_beam_params(e.group(), params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_,
                                      params_->dda_grid_size_, params_->ray_angle_half_, params_->hit_range_,
                                      params_->beam_likelihood_min_,
                                      static_cast<std::uint32_t>(params_->num_points_default_), params_->ang_total_ref_,
@@ -61,7 +61,7 @@ LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointTyp
       org[3 * i + 1] = origins[i].y_;
       org[3 * i + 2] = origins[i].z_;
     }
-    e.check(mcl3dl_hip_measure_batch(e.get(), nullptr, slot.count, nullptr, 0, scan.data(), label.data(), pc->size(),
+    e.check(mcl3dl_hip_group_measure_batch(e.group(), nullptr, slot.count, nullptr, 0, scan.data(), label.data(), pc->size(),
                                      org.data(), origins.size(), nullptr, nullptr, results_.likelihood.data()));
   }
   const std::size_t index = slot.index;
@@ -82,7 +82,7 @@ LidarMeasurementModelBeam::BeamStatus LidarMeasurementModelBeam::getBeamStatus(C
   const float b[3] = { lidar_pos.x_, lidar_pos.y_, lidar_pos.z_ };
   const float en[3] = { scan_pos.x_, scan_pos.y_, scan_pos.z_ };
   std::int32_t status = 2, hit = -1;
-  e.check(mcl3dl_hip_beam_status(e.get(), b, en, 1, &status, &hit));
+  e.checkContext(mcl3dl_hip_beam_status(e.get(), b, en, 1, &status, &hit));
   if (hit >= 0)
   {
     const PointType* p = &kdtree->getInputCloud()->points[hit];

@@ -32,12 +32,12 @@ LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<Po
   {
     hip::Engine& e = hip::Engine::shared();
     hip::syncMap(e, *kdtree);
-    e.check(mcl3dl_hip_set_likelihood_params(e.get(), params_->match_dist_min_, params_->match_dist_flat_,
+    e.check(mcl3dl_hip_group_set_likelihood_params(e.group(), params_->match_dist_min_, params_->match_dist_flat_,
                                              params_->match_weight_));
     refreshPoses(e, s, slot);
     std::vector<float> scan;
     hip::packCloud(*pc, scan, nullptr);
-    e.check(mcl3dl_hip_measure_batch(e.get(), nullptr, slot.count, scan.data(), pc->size(), nullptr, nullptr, 0, nullptr,
+    e.check(mcl3dl_hip_group_measure_batch(e.group(), nullptr, slot.count, scan.data(), pc->size(), nullptr, nullptr, 0, nullptr,
                                      0, results_.likelihood.data(), results_.quality.data(), nullptr));
   }
   const std::size_t index = slot.index;

@@ -179,22 +179,25 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
   return 0;
 }
 
-// sync_at_end = false: the caller synchronises the stream itself before it returns (the staging vectors live in the
-// context, so nothing here dies earlier).
-static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
-                            const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
-                            bool sync_at_end)
+// Host-side ordering of one update's scans (no device work): shared by the single-context upload and by a device group,
+// which orders once and pushes the same arrays to every GPU. Returns 0, or -3 with `err` filled.
+static int order_scan(std::string& err, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                      const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o, OrderedScan& o)
 {
-  if (!ctx)
-    return -1;
   if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
-    return ctx->fail(-3, "null scan array");
+  {
+    err = "null scan array";
+    return -3;
+  }
   if (n_s > 0x7fffffffu || n_b > 0x7fffffffu)
-    return ctx->fail(-3, "scan too large");
-  HIP_TRY(hipSetDevice(ctx->device));
+  {
+    err = "scan too large";
+    return -3;
+  }
   // likelihood scan: spatial (Morton) order. The score is a sum, so the order only changes which lanes work together.
-  std::vector<float4>& lik = ctx->h_scan_lik;
+  std::vector<float4>& lik = o.lik;
   lik.resize(n_s);
+  o.perm.resize(n_s);
   if (n_s)
   {
     float mn[3] = { scan_lik_xyz[0], scan_lik_xyz[1], scan_lik_xyz[2] };
@@ -202,9 +205,11 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
       for (int a = 0; a < 3; ++a)
         mn[a] = std::min(mn[a], scan_lik_xyz[3 * i + a]);
     // 30-bit Morton key (10 bits per axis, 0.25 m cells) + 3-pass LSD radix sort: ~0.1 ms for 16 k points on one core
-    std::vector<uint32_t>& idx = ctx->h_scan_perm;
-    std::vector<uint32_t> key(n_s), key2(n_s), idx2(n_s);
-    idx.resize(n_s);
+    std::vector<uint32_t>& idx = o.perm;
+    std::vector<uint32_t>&key = o.key, &key2 = o.key2, &idx2 = o.idx2;
+    key.resize(n_s);
+    key2.resize(n_s);
+    idx2.resize(n_s);
     for (size_t i = 0; i < n_s; ++i)
     {
       uint32_t c[3];
@@ -238,22 +243,26 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
       const uint32_t i = idx[k];
       lik[k] = make_float4(scan_lik_xyz[3 * i], scan_lik_xyz[3 * i + 1], scan_lik_xyz[3 * i + 2], 0.f);
     }
-    TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
-    TRY(h2d(ctx, ctx->scan_perm.p, idx.data(), sizeof(uint32_t) * n_s));
   }
   // beam scan: ordered by range from its scan origin. A ray walks ~range/dda_grid voxels and (its end point being a
   // measured surface) ends near its last voxel, so the 64 rays of a wavefront finish together instead of idling behind the
   // longest one. The beam score is a count of penalised rays, so the order is free.
-  std::vector<float4>& beam = ctx->h_scan_beam;
+  std::vector<float4>& beam = o.beam;
   beam.resize(n_b);
   if (n_b)
   {
-    std::vector<std::pair<float, uint32_t>> keys(n_b);
+    std::vector<std::pair<float, uint32_t>>& keys = o.beam_keys;
+    keys.resize(n_b);
     for (size_t i = 0; i < n_b; ++i)
     {
       const uint32_t og = scan_beam_origin ? scan_beam_origin[i] : 0u;
       if (og >= n_o)
-        return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, og, n_o);
+      {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "beam point %zu names origin %u but only %zu origins were given", i, og, n_o);
+        err = buf;
+        return -3;
+      }
       const float dx = scan_beam_xyz[3 * i] - origins[3 * og], dy = scan_beam_xyz[3 * i + 1] - origins[3 * og + 1],
                   dz = scan_beam_xyz[3 * i + 2] - origins[3 * og + 2];
       keys[i] = { dx * dx + dy * dy + dz * dz, static_cast<uint32_t>(i) };
@@ -266,16 +275,27 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
       beam[k] = make_float4(scan_beam_xyz[3 * i], scan_beam_xyz[3 * i + 1], scan_beam_xyz[3 * i + 2], bits_to_float(og));
     }
   }
-  std::vector<float4>& org = ctx->h_origins;
+  std::vector<float4>& org = o.origins;
   org.resize(n_o);
   for (size_t i = 0; i < n_o; ++i)
     org[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+  return 0;
+}
+
+// Ordered scans -> this context's device buffers. `o` must stay alive until the stream has been synchronised (copies above
+// the staging limit read it directly). sync_at_end = false: the caller synchronises the stream itself before it returns.
+static int push_scan(mcl3dl_hip_ctx* ctx, const OrderedScan& o, bool sync_at_end)
+{
+  const size_t n_s = o.lik.size(), n_b = o.beam.size(), n_o = o.origins.size();
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
   TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
   TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
   TRY(ensure(ctx, ctx->origins, sizeof(float4) * n_o));
-  TRY(h2d(ctx, ctx->scan_lik.p, lik.data(), sizeof(float4) * n_s));
-  TRY(h2d(ctx, ctx->scan_beam.p, beam.data(), sizeof(float4) * n_b));
-  TRY(h2d(ctx, ctx->origins.p, org.data(), sizeof(float4) * n_o));
+  TRY(h2d(ctx, ctx->scan_perm.p, o.perm.data(), sizeof(uint32_t) * n_s));
+  TRY(h2d(ctx, ctx->scan_lik.p, o.lik.data(), sizeof(float4) * n_s));
+  TRY(h2d(ctx, ctx->scan_beam.p, o.beam.data(), sizeof(float4) * n_b));
+  TRY(h2d(ctx, ctx->origins.p, o.origins.data(), sizeof(float4) * n_o));
   if (sync_at_end)
     TRY(sync_stream(ctx));
   if (n_b > ctx->pow_table_len)
@@ -287,6 +307,18 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
   ctx->n_o = n_o;
   ctx->has_scan = true;
   return 0;
+}
+
+static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                            const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                            bool sync_at_end)
+{
+  if (!ctx)
+    return -1;
+  std::string err;
+  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, ctx->h_scan) != 0)
+    return ctx->fail(-3, "%s", err.c_str());
+  return push_scan(ctx, ctx->h_scan, sync_at_end);
 }
 
 int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,

@@ -1,0 +1,428 @@
+// api_group.inl — included inside the extern "C" block of mcl3dl_hip.hip: the device group (host_group.h) behind the C ABI.
+namespace
+{
+int group_comms(mcl3dl_hip_group* g)
+{
+  if (g->collective == 1 || !g->comms.empty())
+    return 0;
+  if (!g->devices_distinct)
+    return g->fail(-3, "a device id is listed more than once: RCCL needs one GPU per rank — set option \"collective\" to 1 "
+                       "(host combine) for several contexts on one GPU");
+  const std::string why = g->rccl.load();
+  if (!why.empty())
+    return g->fail(-7, "%s; set option \"collective\" to 1 (host combine) or MCL3DL_HIP_RCCL_LIB", why.c_str());
+  g->comms.assign(g->n(), nullptr);
+  const ncclResult_t rc = g->rccl.CommInitAll(g->comms.data(), g->n(), g->devices.data());
+  if (rc != ncclSuccess)
+  {
+    g->comms.clear();
+    return g->fail(-7, "ncclCommInitAll over %d devices failed: %s", g->n(), g->rccl.GetErrorString(rc));
+  }
+  return 0;
+}
+
+// the shard's share of the 2 + 2N-double record when it holds no particle: sums 0, max ratio 0, -min ratio -1
+int pack_empty(mcl3dl_hip_ctx* ctx, int rank, int world, double* d_packed)
+{
+  hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<const double*>(nullptr), 0, rank, world,
+                     d_packed);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int mcl3dl_hip_group_create(mcl3dl_hip_group** out, const int* device_ids, int n_devices)
+{
+  if (!out)
+    return -1;
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64)
+    return -3;
+  mcl3dl_hip_group* g = new mcl3dl_hip_group;
+  for (int r = 0; r < n_devices; ++r)
+  {
+    mcl3dl_hip_ctx* c = nullptr;
+    const int rc = mcl3dl_hip_create(&c, device_ids[r]);
+    if (rc != 0)
+    {
+      for (mcl3dl_hip_ctx* p : g->ctx)
+        mcl3dl_hip_destroy(p);
+      delete g;
+      return rc;
+    }
+    for (int q = 0; q < r; ++q)
+      if (device_ids[q] == device_ids[r])
+        g->devices_distinct = false;
+    g->ctx.push_back(c);
+    g->devices.push_back(device_ids[r]);
+  }
+  const char* env = getenv("MCL3DL_HIP_COLLECTIVE");
+  if (env && std::string(env) == "host")
+    g->collective = 1;
+  g->host_packed.resize(n_devices);
+  if (n_devices > 1)
+    g->pool.start(n_devices);
+  *out = g;
+  return 0;
+}
+
+void mcl3dl_hip_group_destroy(mcl3dl_hip_group* g)
+{
+  if (!g)
+    return;
+  g->pool.stop();
+  for (mcl3dl_hip_ctx* c : g->ctx)
+  {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+  }
+  for (ncclComm_t c : g->comms)
+    if (c)
+      (void)g->rccl.CommDestroy(c);
+  for (mcl3dl_hip_ctx* c : g->ctx)
+    mcl3dl_hip_destroy(c);
+  delete g;
+}
+
+const char* mcl3dl_hip_group_last_error(const mcl3dl_hip_group* g)
+{
+  return g ? g->err.c_str() : "null group";
+}
+
+int mcl3dl_hip_group_size(const mcl3dl_hip_group* g)
+{
+  return g ? g->n() : 0;
+}
+
+mcl3dl_hip_ctx* mcl3dl_hip_group_context(mcl3dl_hip_group* g, int rank)
+{
+  return (g && rank >= 0 && rank < g->n()) ? g->ctx[rank] : nullptr;
+}
+
+int mcl3dl_hip_group_shard(size_t n_p, int n_devices, int rank, size_t* begin, size_t* count)
+{
+  if (n_devices < 1 || rank < 0 || rank >= n_devices || !begin || !count)
+    return -3;
+  size_t lo, hi;
+  shard_bounds(n_p, n_devices, rank, &lo, &hi);
+  *begin = lo;
+  *count = hi - lo;
+  return 0;
+}
+
+int mcl3dl_hip_group_set_map(mcl3dl_hip_group* g, const float* xyz, const uint32_t* label, size_t n_m, uint64_t stamp,
+                             const float* dist_weight)
+{
+  if (!g)
+    return -1;
+  int bad = 0;
+  const int rc = g->pool.run_all([&](int r) { return mcl3dl_hip_set_map(g->ctx[r], xyz, label, n_m, stamp, dist_weight); },
+                                 &bad);
+  return rc ? g->fail_rank(rc, bad) : 0;
+}
+
+int mcl3dl_hip_group_set_likelihood_params(mcl3dl_hip_group* g, float match_dist_min, float match_dist_flat,
+                                           float match_weight)
+{
+  if (!g)
+    return -1;
+  for (int r = 0; r < g->n(); ++r)
+  {
+    const int rc = mcl3dl_hip_set_likelihood_params(g->ctx[r], match_dist_min, match_dist_flat, match_weight);
+    if (rc)
+      return g->fail_rank(rc, r);
+  }
+  return 0;
+}
+
+int mcl3dl_hip_group_set_beam_params(mcl3dl_hip_group* g, float map_grid_x, float map_grid_y, float map_grid_z,
+                                     float dda_grid_size, float ray_angle_half, float hit_range,
+                                     float beam_likelihood_min, uint32_t num_points, float ang_total_ref,
+                                     uint32_t filter_label_max, int add_penalty_short_only_mode)
+{
+  if (!g)
+    return -1;
+  for (int r = 0; r < g->n(); ++r)
+  {
+    const int rc = mcl3dl_hip_set_beam_params(g->ctx[r], map_grid_x, map_grid_y, map_grid_z, dda_grid_size, ray_angle_half,
+                                              hit_range, beam_likelihood_min, num_points, ang_total_ref, filter_label_max,
+                                              add_penalty_short_only_mode);
+    if (rc)
+      return g->fail_rank(rc, r);
+  }
+  return 0;
+}
+
+int mcl3dl_hip_group_set_option(mcl3dl_hip_group* g, const char* name, double value)
+{
+  if (!g || !name)
+    return -1;
+  if (std::string(name) == "collective")
+  {
+    if (value != 0.0 && value != 1.0)
+      return g->fail(-3, "collective must be 0 (RCCL all-reduce) or 1 (host combine)");
+    g->collective = static_cast<int>(value);
+    return 0;
+  }
+  if (std::string(name) == "direct_single")
+  {
+    g->direct_single = value != 0.0;
+    return 0;
+  }
+  for (int r = 0; r < g->n(); ++r)
+  {
+    const int rc = mcl3dl_hip_set_option(g->ctx[r], name, value);
+    if (rc)
+      return g->fail_rank(rc, r);
+  }
+  return 0;
+}
+
+int mcl3dl_hip_group_collective_stats(const mcl3dl_hip_group* g, uint64_t* rccl_all_reduces, uint64_t* host_combines)
+{
+  if (!g)
+    return -1;
+  if (rccl_all_reduces)
+    *rccl_all_reduces = g->collectives_rccl;
+  if (host_combines)
+    *host_combines = g->collectives_host;
+  return 0;
+}
+
+int mcl3dl_hip_group_upload_poses(mcl3dl_hip_group* g, const float* pose, size_t n_p)
+{
+  if (!g)
+    return -1;
+  if (!pose || n_p == 0 || n_p > 0x7fffffffu)
+    return g->fail(-3, "bad pose array");
+  g->n_pose_uploaded = 0;
+  int bad = 0;
+  const int N = g->n();
+  const int rc = g->pool.run_all(
+      [&](int r) -> int
+      {
+        mcl3dl_hip_ctx* ctx = g->ctx[r];
+        size_t lo, hi;
+        shard_bounds(n_p, N, r, &lo, &hi);
+        ctx->n_pose_uploaded = 0;
+        if (hi == lo)
+          return 0;
+        return mcl3dl_hip_upload_poses(ctx, pose + 7 * lo, hi - lo);
+      },
+      &bad);
+  if (rc)
+    return g->fail_rank(rc, bad);
+  g->n_pose_uploaded = n_p;
+  return 0;
+}
+
+int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_t n_p, const float* scan_lik_xyz,
+                                   size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
+                                   const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
+                                   float* out_beam)
+{
+  if (!g)
+    return -1;
+  if (n_p == 0)
+    return 0;
+  if (!pose && g->n_pose_uploaded != n_p)
+    return g->fail(-3, "null pose array (and mcl3dl_hip_group_upload_poses holds %zu poses, not %zu)", g->n_pose_uploaded,
+                   n_p);
+  if (g->n() == 1 && g->direct_single)
+  {
+    const int rc = mcl3dl_hip_measure_batch(g->ctx[0], pose, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b,
+                                            origins, n_o, out_lik, out_match_ratio, out_beam);
+    return rc ? g->fail_rank(rc, 0) : 0;
+  }
+  std::string err;
+  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
+    return g->fail(-3, "%s", err.c_str());
+  if (pose)
+    g->n_pose_uploaded = 0;
+  int bad = 0;
+  const int N = g->n();
+  const int rc = g->pool.run_all(
+      [&](int r) -> int
+      {
+        mcl3dl_hip_ctx* ctx = g->ctx[r];
+        size_t lo, hi;
+        shard_bounds(n_p, N, r, &lo, &hi);
+        const size_t n = hi - lo;
+        TRY(push_scan(ctx, g->scan, false));
+        if (n == 0)
+          return sync_stream(ctx);
+        if (pose)
+        {
+          ctx->n_pose_uploaded = 0;
+          TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
+          TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
+          ctx->n_pose_uploaded = n;
+        }
+        else if (ctx->n_pose_uploaded != n)
+          return ctx->fail(-3, "uploaded pose shard holds %zu poses, not %zu", ctx->n_pose_uploaded, n);
+        TRY(ensure(ctx, ctx->lik, sizeof(float) * n));
+        TRY(ensure(ctx, ctx->ratio, sizeof(float) * n));
+        TRY(ensure(ctx, ctx->beam, sizeof(float) * n));
+        const bool lik_wanted = out_lik || out_match_ratio;
+        TRY(launch_measure(ctx, ctx->pose.as<float>(), n, lik_wanted ? ctx->lik.as<float>() : nullptr,
+                           lik_wanted ? ctx->ratio.as<float>() : nullptr, out_beam ? ctx->beam.as<float>() : nullptr,
+                           false, nullptr));
+        if (out_lik)
+          TRY(d2h(ctx, out_lik + lo, ctx->lik.p, sizeof(float) * n));
+        if (out_match_ratio)
+          TRY(d2h(ctx, out_match_ratio + lo, ctx->ratio.p, sizeof(float) * n));
+        if (out_beam)
+          TRY(d2h(ctx, out_beam + lo, ctx->beam.p, sizeof(float) * n));
+        return sync_stream(ctx);
+      },
+      &bad);
+  if (rc)
+    return g->fail_rank(rc, bad);
+  if (pose)
+    g->n_pose_uploaded = n_p;
+  return 0;
+}
+
+int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, const float* extra, float* weight_inout,
+                                    size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                                    const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                                    float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
+                                    float* match_ratio_min, float* match_ratio_max, int* restored)
+{
+  if (!g)
+    return -1;
+  if (n_p == 0)
+    return g->fail(-3, "no particles");
+  if (!pose || !weight_inout)
+    return g->fail(-3, "null pose / weight array");
+  if (g->n() == 1 && g->direct_single)
+  {
+    const int rc = mcl3dl_hip_measure_update(g->ctx[0], pose, extra, weight_inout, n_p, scan_lik_xyz, n_s, scan_beam_xyz,
+                                             scan_beam_origin, n_b, origins, n_o, out_lik, out_match_ratio, out_beam,
+                                             entropy, match_ratio_min, match_ratio_max, restored);
+    return rc ? g->fail_rank(rc, 0) : 0;
+  }
+  TRY(group_comms(g));
+  std::string err;
+  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
+    return g->fail(-3, "%s", err.c_str());
+  const int N = g->n();
+  const size_t n_pack = 2 + 2 * static_cast<size_t>(N);
+  const bool host_combine = g->collective == 1;
+  std::vector<float> stats(4 * static_cast<size_t>(N), 0.f);
+  g->n_pose_uploaded = 0;
+
+  // phase A: upload the shard, measure, partial sums, (RCCL) all-reduce, and — with RCCL — straight on to phase B
+  const auto phase_b = [&](mcl3dl_hip_ctx* ctx, int r, size_t lo, size_t n) -> int
+  {
+    const size_t fb = sizeof(float) * n;
+    TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
+    if (n)
+    {
+      TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n, N, ctx->packed.as<double>(), ctx->stats4.as<float>()));
+      TRY(d2h(ctx, weight_inout + lo, ctx->weightb.p, fb));
+      TRY(d2h(ctx, &stats[4 * r], ctx->stats4.p, sizeof(float) * 4));
+      if (out_lik)
+        TRY(d2h(ctx, out_lik + lo, ctx->lik.p, fb));
+      if (out_match_ratio)
+        TRY(d2h(ctx, out_match_ratio + lo, ctx->ratio.p, fb));
+      if (out_beam)
+        TRY(d2h(ctx, out_beam + lo, ctx->beam.p, fb));
+    }
+    return sync_stream(ctx);
+  };
+  int bad = 0;
+  int rc = g->pool.run_all(
+      [&](int r) -> int
+      {
+        mcl3dl_hip_ctx* ctx = g->ctx[r];
+        size_t lo, hi;
+        shard_bounds(n_p, N, r, &lo, &hi);
+        const size_t n = hi - lo, fb = sizeof(float) * n;
+        TRY(push_scan(ctx, g->scan, false));
+        TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
+        ctx->n_pose_uploaded = 0;
+        if (n)
+        {
+          TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
+          TRY(ensure(ctx, ctx->weightb, fb));
+          TRY(ensure(ctx, ctx->lik, fb));
+          TRY(ensure(ctx, ctx->ratio, fb));
+          TRY(ensure(ctx, ctx->beam, fb));
+          TRY(ensure(ctx, ctx->extra, fb));
+          TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
+          ctx->n_pose_uploaded = n;
+          TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
+          if (extra)
+            TRY(h2d(ctx, ctx->extra.p, extra + lo, fb));
+          TRY(launch_measure(ctx, ctx->pose.as<float>(), n, ctx->lik.as<float>(), ctx->ratio.as<float>(),
+                             ctx->beam.as<float>(), false, nullptr));
+          TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
+                                           extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n, r, N,
+                                           ctx->packed.as<double>()));
+        }
+        else
+          TRY(pack_empty(ctx, r, N, ctx->packed.as<double>()));
+        if (host_combine)
+        {
+          g->host_packed[r].resize(n_pack);
+          TRY(d2h(ctx, g->host_packed[r].data(), ctx->packed.p, sizeof(double) * n_pack));
+          return sync_stream(ctx);
+        }
+        // the update's single collective: 16 + 16 N bytes over xGMI, on this device's stream
+        const ncclResult_t nrc = g->rccl.AllReduce(ctx->packed.p, ctx->packed.p, n_pack, ncclDouble, ncclSum, g->comms[r],
+                                                   ctx->stream);
+        if (nrc != ncclSuccess)
+          return ctx->fail(-7, "ncclAllReduce failed: %s", g->rccl.GetErrorString(nrc));
+        return phase_b(ctx, r, lo, n);
+      },
+      &bad);
+  if (rc)
+    return g->fail_rank(rc, bad);
+  if (host_combine)
+  {
+    // sum the N records in rank order (deterministic) and hand the total back to every device
+    std::vector<double> total(n_pack, 0.0);
+    for (int r = 0; r < N; ++r)
+      for (size_t i = 0; i < n_pack; ++i)
+        total[i] += g->host_packed[r][i];
+    rc = g->pool.run_all(
+        [&](int r) -> int
+        {
+          mcl3dl_hip_ctx* ctx = g->ctx[r];
+          size_t lo, hi;
+          shard_bounds(n_p, N, r, &lo, &hi);
+          HIP_TRY(hipSetDevice(ctx->device));
+          TRY(h2d(ctx, ctx->packed.p, total.data(), sizeof(double) * n_pack));
+          return phase_b(ctx, r, lo, hi - lo);
+        },
+        &bad);
+    if (rc)
+      return g->fail_rank(rc, bad);
+    ++g->collectives_host;
+  }
+  else
+    ++g->collectives_rccl;
+  g->n_pose_uploaded = n_p;
+  // every rank computed the same four scalars from the same all-reduced record: take the first non-empty shard's
+  int src = 0;
+  for (int r = 0; r < N; ++r)
+  {
+    size_t lo, hi;
+    shard_bounds(n_p, N, r, &lo, &hi);
+    if (hi > lo)
+    {
+      src = r;
+      break;
+    }
+  }
+  if (entropy)
+    *entropy = stats[4 * src + 0];
+  if (match_ratio_min)
+    *match_ratio_min = stats[4 * src + 1];
+  if (match_ratio_max)
+    *match_ratio_max = stats[4 * src + 2];
+  if (restored)
+    *restored = stats[4 * src + 3] != 0.0f;
+  return 0;
+}

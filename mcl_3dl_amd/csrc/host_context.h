@@ -25,6 +25,17 @@ struct DevBuf
   }
 };
 
+// One update's scans after the host-side ordering (api_core.inl:order_scan): Morton-ordered likelihood points + the
+// permutation back to the caller's order, range-ordered beam points {x, y, z, origin id}, origins. The scratch vectors
+// are kept so that a steady stream of scans allocates nothing.
+struct OrderedScan
+{
+  std::vector<float4> lik, beam, origins;
+  std::vector<uint32_t> perm;
+  std::vector<uint32_t> key, key2, idx2;
+  std::vector<std::pair<float, uint32_t>> beam_keys;
+};
+
 struct EventPair
 {
   hipEvent_t start, stop;
@@ -76,7 +87,8 @@ struct mcl3dl_hip_ctx
   int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
-  int lik_ilp = 0;         // tiled kernel, evaluations in flight per lane: 0 = one, 1..8 = the variants of host_measure.h
+  int lik_ilp = 0;         // tiled kernel: 1 = two evaluations in flight per lane (batched loads), 0 = one
+  int lik_trim = 0;        // tiled kernel: 1 = VALU-trimmed evaluation (likelihood_kernels.h, same results)
   DevBuf lik_partial_sum, lik_partial_cnt;
   int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
   DevBuf scan_perm, strict_terms;
@@ -100,7 +112,8 @@ struct mcl3dl_hip_ctx
   // work buffers
   size_t n_pose_uploaded = 0;  // poses `pose` holds from mcl3dl_hip_upload_poses / the last host-buffer call
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
-      tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset;
+      tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset,
+      packed;  // 2 + 2N doubles: this rank's record of a device group's all-reduce (host_group.h)
 
   // resampling plan
   std::vector<float> rs_keys;        // accumulated probabilities, in particles_dup_ order after std::sort
@@ -154,8 +167,7 @@ struct mcl3dl_hip_ctx
   size_t stage_cur = 0, stage_off = 0;
   std::vector<StagedResult> stage_out;
   // host-side scan staging (kept in the context so that it outlives the asynchronous copies)
-  std::vector<float4> h_scan_lik, h_scan_beam, h_origins;
-  std::vector<uint32_t> h_scan_perm;
+  OrderedScan h_scan;
 
   // timing
   bool timing = false;

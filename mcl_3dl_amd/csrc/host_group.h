@@ -1,0 +1,189 @@
+// host_group.h — part of the single translation unit mcl3dl_hip.hip: a device group = N contexts (one per GPU) owned by ONE
+// host process, the in-process form of SURVEY.md §8e behind the C ABI (the reference node is one C++ process,
+// src/mcl_3dl.cpp:1466).  Contiguous particle shards, map + scan replicated, one worker thread per device so that the
+// launches of the N GPUs are enqueued concurrently, and ONE collective per update: ncclAllReduce(sum) of 2 + 2N doubles
+// over RCCL (librccl is dlopen'ed the first time a group with more than one device needs it — a single-GPU user never
+// loads it), or a host-side combine of the same record (collective = "host": used when device ids repeat — several
+// contexts on one GPU, which RCCL refuses — and as a fallback when librccl is not installed).
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enum values only: every RCCL call goes through the dlopen'ed pointers below
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace
+{
+struct RcclApi
+{
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+
+  // "" on success, otherwise why RCCL is not usable
+  std::string load()
+  {
+    if (lib)
+      return "";
+    const char* env = getenv("MCL3DL_HIP_RCCL_LIB");
+    const char* names[] = { env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    // a copy that is already in the process (e.g. the one torch brought) is preferred over loading a second one
+    for (const char* n : names)
+      if (n && !lib)
+        lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names)
+      if (n && !lib)
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!lib)
+      return std::string("librccl not found (") + dlerror() + ")";
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !AllReduce || !GetErrorString)
+    {
+      lib = nullptr;
+      return "librccl lacks ncclCommInitAll / ncclAllReduce";
+    }
+    return "";
+  }
+};
+
+// One worker thread per device; run_all() hands every worker the same closure (argument = rank) and waits for all.
+class WorkerPool
+{
+public:
+  void start(int n)
+  {
+    rc_.assign(n, 0);
+    for (int r = 0; r < n; ++r)
+      threads_.emplace_back([this, r] { loop(r); });
+  }
+  void stop()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_task_.notify_all();
+    for (std::thread& t : threads_)
+      t.join();
+    threads_.clear();
+  }
+  // returns the first non-zero return code (by rank), 0 if every rank succeeded
+  int run_all(const std::function<int(int)>& f, int* failed_rank)
+  {
+    if (threads_.empty())
+    {
+      const int rc = f(0);
+      if (rc != 0 && failed_rank)
+        *failed_rank = 0;
+      return rc;
+    }
+    std::unique_lock<std::mutex> lk(m_);
+    task_ = &f;
+    pending_ = static_cast<int>(threads_.size());
+    ++gen_;
+    cv_task_.notify_all();
+    cv_done_.wait(lk, [this] { return pending_ == 0; });
+    task_ = nullptr;
+    for (size_t r = 0; r < rc_.size(); ++r)
+      if (rc_[r] != 0)
+      {
+        if (failed_rank)
+          *failed_rank = static_cast<int>(r);
+        return rc_[r];
+      }
+    return 0;
+  }
+
+private:
+  void loop(int r)
+  {
+    uint64_t seen = 0;
+    for (;;)
+    {
+      const std::function<int(int)>* f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_task_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_)
+          return;
+        seen = gen_;
+        f = task_;
+      }
+      const int rc = (*f)(r);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        rc_[r] = rc;
+        if (--pending_ == 0)
+          cv_done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_task_, cv_done_;
+  const std::function<int(int)>* task_ = nullptr;
+  uint64_t gen_ = 0;
+  int pending_ = 0;
+  bool stop_ = false;
+  std::vector<int> rc_;
+};
+}  // namespace
+
+struct mcl3dl_hip_group
+{
+  std::vector<mcl3dl_hip_ctx*> ctx;
+  std::vector<int> devices;
+  std::string err;
+  int collective = 0;  // 0 = RCCL all-reduce, 1 = host combine
+  int direct_single = 1;  // 1 = a group of one device calls its context directly; 0 = it takes the sharded path too
+  bool devices_distinct = true;
+  WorkerPool pool;
+  OrderedScan scan;  // ordered once per update, pushed to every device
+  // RCCL (created on first use by a group of more than one device)
+  RcclApi rccl;
+  std::vector<ncclComm_t> comms;
+  uint64_t collectives_rccl = 0, collectives_host = 0;
+  // per-rank scratch of the host combine
+  std::vector<std::vector<double>> host_packed;
+  // poses kept on the devices by group_upload_poses
+  size_t n_pose_uploaded = 0;
+
+  int n() const
+  {
+    return static_cast<int>(ctx.size());
+  }
+  int fail(int code, const char* fmt, ...)
+  {
+    char buf[640];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  int fail_rank(int rc, int r)
+  {
+    return fail(rc, "device %d (rank %d): %s", devices[r], r, ctx[r]->err.c_str());
+  }
+};
+
+namespace
+{
+// contiguous shard [lo, hi) of rank r when n particles are split over `world` ranks (sizes differ by at most one):
+// the same rule as mcl_3dl_amd/distributed.py:shard_bounds
+inline void shard_bounds(size_t n, int world, int r, size_t* lo, size_t* hi)
+{
+  const size_t base = n / world, rem = n % world;
+  *lo = r * base + std::min<size_t>(r, rem);
+  *hi = *lo + base + (static_cast<size_t>(r) < rem ? 1 : 0);
+}
+}  // namespace

@@ -308,8 +308,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                      0, ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,           \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
-#define LAUNCH_TILED_ILP(GG, UU, WW)                                                                               \
-  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, 2, UU, WW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,  \
+#define LAUNCH_TILED_ILP(GG, UU, WW, TT)                                                                               \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, 2, UU, WW, TT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,  \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
@@ -318,12 +318,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   {                             \
     if (ctx->lik_index == 2)    \
     {                           \
-      switch (ctx->lik_ilp)     \
+      switch (2 * (ctx->lik_ilp ? 1 : 0) + ((ctx->lik_trim && ctx->match_dist_min > 1e-5f) ? 1 : 0)) \
       {                         \
-        case 1: LAUNCH_TILED_ILP(GG, 2, 8); break;  \
-        case 2: LAUNCH_TILED_ILP(GG, 4, 5); break;  \
-        case 3: LAUNCH_TILED_ILP(GG, 4, 4); break;  \
-        default: LAUNCH_TILED(GG, 2); break; \
+        case 1: LAUNCH_TILED_ILP(GG, 1, 8, true); break;  \
+        case 2: LAUNCH_TILED_ILP(GG, 2, 8, false); break; \
+        case 3: LAUNCH_TILED_ILP(GG, 2, 8, true); break;  \
+        default: LAUNCH_TILED_ILP(GG, 1, 8, false); break; \
       }                         \
     }                           \
     else if (ctx->lik_index == 1) \
@@ -341,7 +341,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
               break;
             case 32:
               if (ctx->lik_index == 2)
-                LAUNCH_TILED_ILP(32, 1, 4);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
+                LAUNCH_TILED_ILP(32, 1, 4, false);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
               else if (ctx->lik_index == 1)
                 LAUNCH_TILED_W(32, 1, 4);
               else

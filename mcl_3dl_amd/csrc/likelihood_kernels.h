@@ -280,6 +280,90 @@ __device__ inline float rec_min_d2(const RecGrid& g, float qx, float qy, float q
   return best;
 }
 
+// ---- VALU-trimmed forms (the tiled kernel is bound by VALU issue, not by memory: profiles/r02a_valu_microbench.txt
+// prices a wave64 v_mul/v_add_f32 at ~2.3 cycles on a SIMD and almost everything else — v_max, v_cndmask, v_cvt, integer
+// multiplies, packed f32 pairs, every f64 op — at ~4.3). Same results, fewer and cheaper instructions.
+
+// Quat::operator*(Vec3) (quat.h:139-143) = (q (x) (v,0)) (x) conj(q) with the reference's term order, minus the four
+// products with the vector's zero w component. Dropping them changes nothing observable: for finite q the product is
+// +-0 and x + (+-0) == x exactly (no rounding); where the dropped term could flip the SIGN of an exact zero, that sign
+// never reaches a result (zeros only meet products, sums with non-zeros, and squares from here on); for a non-finite q
+// both forms end in "no neighbour found". Written with scalar temporaries: one v_mul / v_add per line.
+__device__ inline Vec3f qrot_trim(const Quat q, const Vec3f v)
+{
+  // p = q (x) (v, 0)
+  const float px = (q.w * v.x + q.y * v.z) - q.z * v.y;
+  const float py = (q.w * v.y + q.z * v.x) - q.x * v.z;
+  const float pz = (q.w * v.z + q.x * v.y) - q.y * v.x;
+  const float pw = (-(q.x * v.x) - q.y * v.y) - q.z * v.z;
+  // t = p (x) conj(q), conj(q) = (-q.x, -q.y, -q.z, q.w); x * (-y) == -(x * y) bit for bit
+  Vec3f t;
+  t.x = ((pw * -q.x + px * q.w) + py * -q.z) - pz * -q.y;
+  t.y = ((pw * -q.y + py * q.w) + pz * -q.x) - px * -q.z;
+  t.z = ((pw * -q.z + pz * q.w) + px * -q.y) - py * -q.x;
+  return t;
+}
+
+// floor to int in ONE instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for
+// __float2int_rd). Same value for every input: saturating, NaN -> 0.
+__device__ inline int floor_to_int(float x)
+{
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// rec_locate with the single-instruction floor and the brick-local index built from shift-or pairs
+__device__ inline bool rec_locate_trim(const RecGrid& g, float qx, float qy, float qz, uint32_t& ti, uint32_t& sub)
+{
+  const int vx = floor_to_int((qx - g.ox) * g.inv_e);
+  const int vy = floor_to_int((qy - g.oy) * g.inv_e);
+  const int vz = floor_to_int((qz - g.oz) * g.inv_e);
+  if (g.mul24_ok)
+    ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
+         __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
+  else
+    ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
+             static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
+  sub = ((((static_cast<uint32_t>(vz) & 7u) << 3) | (static_cast<uint32_t>(vy) & 7u)) << 3) | (static_cast<uint32_t>(vx) & 7u);
+  return static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
+         static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
+}
+
+// rec_min_d2 for count <= 5 without the count-dependent selects: mc_write_records fills the unused candidate slots with
+// REC_SENTINEL coordinates, whose d2 (~1e36) never wins a minimum and never passes d2 < r2.
+__device__ inline float rec_min_d2_trim(const RecGrid& g, float qx, float qy, float qz, const float4 r0, const float4 r1,
+                                        const float4 r2, const float4 r3)
+{
+  const uint32_t count = __float_as_uint(r0.x);
+  if (count <= 5)
+  {
+    const float d0 = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
+    const float d1 = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
+    const float d2 = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
+    const float d3 = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
+    const float d4 = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
+    return fminf(fminf(fminf(d0, d1), fminf(d2, d3)), d4);
+  }
+  return rec_min_d2(g, qx, qy, qz, r0, r1, r2, r3);
+}
+
+// sqrtf for 0 <= x < r2, correctly rounded wherever its value can reach the result: v_sqrt_f32 (1 ulp) followed by the two
+// fused-residual checks of the compiler's own sqrtf expansion (s - 1 ulp and s + 1 ulp against x), WITHOUT that
+// expansion's input scaling for x < 2^-96 and without its inf/zero pass-through (5 + 2 instructions of 16). Below 2^-96
+// the root is < 3.6e-15: whatever it is rounded to — or flushed to zero — `match_dist_min - max(root, flat)` is the same
+// float as long as match_dist_min > 1.2e-7 m (launch_measure uses this form only then); x = 0 gives 0 (the int(s) -+ 1
+// neighbours are NaN / the smallest denormal, both rejected by the comparisons).
+__device__ inline float sqrt_in_radius(float x)
+{
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float vp = __builtin_fmaf(-s_dn, s, x), vs = __builtin_fmaf(-s_up, s, x);
+  s = (vp <= 0.0f) ? s_dn : s;
+  s = (vs > 0.0f) ? s_up : s;
+  return s;
+}
+
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
 // MODE 1: candidate-voxel index
 template <int BLOCK, int MODE, bool STATS>
@@ -443,7 +527,7 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
 // sqrt per particle, and 8 wavefronts per SIMD do not cover it: DESIGN.md section 6). The loads are issued unconditionally —
 // lanes with nothing to look up read brick-table entry 0 / record 0 and discard it — so the U chains stay in one basic
 // block. MINW = wavefronts per SIMD the register allocation must leave room for (8 -> 64 VGPRs, 5 -> 96, 4 -> 128).
-template <int G, int MODE, int U = 1, int MINW = 8>
+template <int G, int MODE, int U = 1, int MINW = 8, bool TRIM = false>
 __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
                                                                int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
@@ -504,11 +588,12 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
         const int kk = min(k + u, n_valid - 1);
         const Vec3f pos = { s_pose[kk][0], s_pose[kk][1], s_pose[kk][2] };
         const Quat rot = { s_pose[kk][3], s_pose[kk][4], s_pose[kk][5], s_pose[kk][6] };
-        const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+        const Vec3f tp = vadd(TRIM ? qrot_trim(rot, Vec3f{ v.x, v.y, v.z }) : qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
         qx[u] = tp.x * prm.wx;
         qy[u] = tp.y * prm.wy;
         qz[u] = tp.z * prm.wz;
-        in[u] = rec_locate(rg, qx[u], qy[u], qz[u], ti[u], sub[u]) && have_point;
+        in[u] = (TRIM ? rec_locate_trim(rg, qx[u], qy[u], qz[u], ti[u], sub[u]) :
+                        rec_locate(rg, qx[u], qy[u], qz[u], ti[u], sub[u])) && have_point;
       }
       // step 2: U brick-table loads (lanes outside the grid read entry 0 and discard it)
       int b[U];
@@ -535,10 +620,11 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
         bool matched = false;
         if (in[u] && __float_as_uint(r[u][0].x) != 0u)
         {
-          const float d2 = rec_min_d2(rg, qx[u], qy[u], qz[u], r[u][0], r[u][1], r[u][2], r[u][3]);
+          const float d2 = TRIM ? rec_min_d2_trim(rg, qx[u], qy[u], qz[u], r[u][0], r[u][1], r[u][2], r[u][3]) :
+                                  rec_min_d2(rg, qx[u], qy[u], qz[u], r[u][0], r[u][1], r[u][2], r[u][3]);
           if (d2 < prm.r2)
           {
-            const float s = sqrtf(d2);
+            const float s = TRIM ? sqrt_in_radius(d2) : sqrtf(d2);
             const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
             if (!(dist < 0.0f))
             {
@@ -566,16 +652,41 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
     bool matched = false;
     if (have_point)
     {
-      const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+      const Vec3f tp = vadd(TRIM ? qrot_trim(rot, Vec3f{ v.x, v.y, v.z }) : qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
       // rescale by dist_weight; without one the weights are 1.0f and x * 1.0f == x bit for bit, so no select is needed
-      const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
+      // (TRIM: a wave-uniform branch skips the three multiplies then)
+      float qx = tp.x, qy = tp.y, qz = tp.z;
+      if (!TRIM || prm.has_weight)
+      {
+        qx = tp.x * prm.wx;
+        qy = tp.y * prm.wy;
+        qz = tp.z * prm.wz;
+      }
       unsigned dummy = 0;
-      const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
-                       MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
-                                   nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
+      float d2;
+      if constexpr (TRIM && MODE == 2)
+      {
+        d2 = 3.0e38f;
+        uint32_t ti, sub;
+        if (rec_locate_trim(rg, qx, qy, qz, ti, sub))
+        {
+          const int b = rg.brick_table[ti];
+          if (b >= 0)
+          {
+            const float4* r = rg.rec + 4 * static_cast<size_t>((static_cast<uint32_t>(b) << 9) | sub);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            if (__float_as_uint(r0.x) != 0u)
+              d2 = rec_min_d2_trim(rg, qx, qy, qz, r0, r1, r2, r3);
+          }
+        }
+      }
+      else
+        d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
+             MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
+                         nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
       if (d2 < prm.r2)
       {
-        const float s = sqrtf(d2);
+        const float s = TRIM ? sqrt_in_radius(d2) : sqrtf(d2);
         const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
         if (!(dist < 0.0f))
         {

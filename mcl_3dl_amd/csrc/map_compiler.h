@@ -326,6 +326,8 @@ __global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* _
 //   count <= 5 : { count, xyz[5] }                       (15 floats of candidates inline)
 //   count  > 5 : { count, ext, xyz[4], pad, pad }        (4 inline, the rest in overflow records ext, ext+1, ...)
 //   overflow   : { xyz[5], pad }                         contiguous, 5 candidates each
+constexpr float REC_SENTINEL = 1.0e18f;
+
 struct RecGrid
 {
   const int32_t* brick_table;
@@ -354,10 +356,12 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
   if (v >= n_vox)
     return;
   const uint32_t c = kept_count[v], src = pstart[v];
+  // unused candidate slots hold REC_SENTINEL: a point so far away that its d2 (~3e36, finite) never wins a minimum and
+  // never passes the radius test, so a query may take the minimum over all five slots without looking at the count
   float out[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    out[i] = 0.f;
+    out[i] = REC_SENTINEL;
   out[0] = __uint_as_float(c);
   const uint32_t inline_n = c <= 5 ? c : 4u;
   const int base = c <= 5 ? 1 : 2;

@@ -22,6 +22,7 @@ using namespace mcl3dl;
 #include "host_context.h"
 #include "host_map_compilers.h"
 #include "host_measure.h"
+#include "host_group.h"
 
 // =================================================================================================================
 // C ABI
@@ -32,4 +33,5 @@ extern "C"
 #include "api_reductions.inl"
 #include "api_resample.inl"
 #include "api_support.inl"
+#include "api_group.inl"
 }  // extern "C"

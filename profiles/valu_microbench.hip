@@ -173,6 +173,49 @@ UKERNEL(sqrt_f32, "v_sqrt_f32")
 UKERNEL(rcp_f32, "v_rcp_f32")
 UKERNEL(cvt_flr_i32_f32, "v_cvt_flr_i32_f32")
 
+
+// other VOP2 / VOP3 forms the likelihood kernel is made of
+KERNEL32(sub_f32, "v_sub_f32")
+KERNEL32(min_f32, "v_min_f32")
+KERNEL32(and_b32, "v_and_b32")
+KERNEL32(or_b32, "v_or_b32")
+KERNEL32(lshlrev_b32, "v_lshlrev_b32")
+KERNEL32(ashrrev_i32, "v_ashrrev_i32")
+KERNEL32(add_u32, "v_add_u32")
+
+#define XOP8(A, B)                                                                                                   \
+  asm volatile(A "%0" B "\n" A "%1" B "\n" A "%2" B "\n" A "%3" B "\n" A "%4" B "\n" A "%5" B "\n" A "%6" B "\n" A "%7" B \
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                      \
+               : "v"(b)                                                                                               \
+               : "vcc")
+#define XKERNEL(NAME, A, B)                                                                    \
+  __global__ __launch_bounds__(256) void NAME##_indep(float* out, long long* cyc)              \
+  {                                                                                            \
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,   \
+          a6 = a0 + 6, a7 = a0 + 7, b = 1.0000001f;                                            \
+    const long long t0 = __builtin_readcyclecounter();                                         \
+    for (int i = 0; i < ITER; ++i)                                                             \
+    {                                                                                          \
+      XOP8(A, B); XOP8(A, B); XOP8(A, B); XOP8(A, B);                                          \
+      XOP8(A, B); XOP8(A, B); XOP8(A, B); XOP8(A, B);                                          \
+    }                                                                                          \
+    const long long t1 = __builtin_readcyclecounter();                                         \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
+    if ((threadIdx.x & 63) == 0)                                                               \
+      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+  }
+// A "%d" B : the text before / after the destination register
+XKERNEL(fma_f32, "v_fma_f32 ", ", %8, %8, %8")              // d = b*b + b  (no dependence on d: pure issue rate)
+XKERNEL(fma_f32_acc, "v_fmac_f32 ", ", %8, %8")             // d += b*b
+XKERNEL(mov_b32, "v_mov_b32 ", ", %8")
+XKERNEL(cndmask_b32, "v_cndmask_b32 ", ", %8, %8, vcc")
+XKERNEL(cmp_lt_f32, "v_cmp_lt_f32 vcc, ", ", %8")           // reads the register, writes vcc
+XKERNEL(lshl_or_b32, "v_lshl_or_b32 ", ", %8, 3, %8")
+XKERNEL(add3_u32, "v_add3_u32 ", ", %8, %8, %8")
+XKERNEL(mul_f32_sgpr, "v_mul_f32 ", ", s4, %8")             // one SGPR source
+XKERNEL(cvt_i32_f32, "v_cvt_i32_f32 ", ", %8")
+XKERNEL(floor_f32, "v_floor_f32 ", ", %8")
+
 typedef void (*kern_t)(float*, long long*);
 struct Entry
 {
@@ -200,11 +243,20 @@ int main()
     { "v_add_f64 dependent", add_f64_dep, per },          { "v_mul_f64 x8 independent", mul_f64_indep, per },
     { "v_sqrt_f32 x8 independent", sqrt_f32_indep, per }, { "v_rcp_f32 x8 independent", rcp_f32_indep, per },
     { "v_cvt_flr_i32_f32 x8 independent", cvt_flr_i32_f32_indep, per },
+    { "v_sub_f32 x8 independent", sub_f32_indep, per },     { "v_min_f32 x8 independent", min_f32_indep, per },
+    { "v_fma_f32 x8 independent", fma_f32_indep, per },     { "v_fmac_f32 x8 independent", fma_f32_acc_indep, per },
+    { "v_mul_f32 (sgpr src) x8 independent", mul_f32_sgpr_indep, per },
+    { "v_mov_b32 x8 independent", mov_b32_indep, per },     { "v_cndmask_b32 x8 independent", cndmask_b32_indep, per },
+    { "v_cmp_lt_f32 x8 independent", cmp_lt_f32_indep, per }, { "v_and_b32 x8 independent", and_b32_indep, per },
+    { "v_or_b32 x8 independent", or_b32_indep, per },       { "v_lshlrev_b32 x8 independent", lshlrev_b32_indep, per },
+    { "v_ashrrev_i32 x8 independent", ashrrev_i32_indep, per }, { "v_add_u32 x8 independent", add_u32_indep, per },
+    { "v_lshl_or_b32 x8 independent", lshl_or_b32_indep, per }, { "v_add3_u32 x8 independent", add3_u32_indep, per },
+    { "v_cvt_i32_f32 x8 independent", cvt_i32_f32_indep, per }, { "v_floor_f32 x8 independent", floor_f32_indep, per },
   };
   printf("device: %s, %d CUs, clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
   printf("%-36s %5s %14s %12s %12s %14s\n", "instruction", "W", "tick/instr/SIMD", "kernel ms", "ticks/ns", "cyc@2.4GHz");
   for (const Entry& e : entries)
-    for (int W : { 1, 2, 4, 8 })
+    for (int W : { 1, 2, 8 })
     {
       const int blocks = cus * W;
       hipEvent_t a, b;

@@ -157,3 +157,21 @@ def test_two_rank_resample_matches_single_process(tmp_path, n, dead):
     np.testing.assert_array_equal(parts[1]["dup"], dup)
     np.testing.assert_array_equal(np.concatenate([p["s"] for p in parts]), want)
     assert all(np.all(p["w"] == np.float32(1.0 / n)) for p in parts)
+
+
+def test_group_shard_bookkeeping_matches_the_python_rule():
+    """mcl3dl_hip_group_shard (the C side's contiguous shards, host_group.h) == distributed.shard_bounds for every
+    (particles, devices) pair, including fewer particles than devices; the shards tile [0, n) exactly."""
+    from mcl_3dl_amd import capi
+    from mcl_3dl_amd.distributed import shard_bounds
+    for n in (0, 1, 2, 7, 64, 100, 4096, 262144, 262145):
+        for world in (1, 2, 3, 4, 8, 64):
+            end = 0
+            for r in range(world):
+                lo, cnt = capi.group_shard(n, world, r)
+                assert (lo, lo + cnt) == shard_bounds(n, world, r)
+                assert lo == end
+                end = lo + cnt
+            assert end == n
+    with pytest.raises(capi.EngineError):
+        capi.group_shard(10, 4, 4)

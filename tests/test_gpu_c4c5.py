@@ -130,7 +130,8 @@ def test_c5_likelihood_and_beam_slice(c5_launch, c5, c5_oracle, engine):
     lik, ratio, beam = c5_launch
     sc = c5
     fp = engine.memory_footprint()
-    assert fp["cand_points"] > (4 << 30) and fp["dda_voxels"] > (1 << 30)  # the >4 GB / >1 GB structures really are in play
+    # with lik_index = 2 footprint slot 6 ("cand_start") holds the 64-byte voxel records: > 4 GB, and the DDA voxel index > 1 GB
+    assert fp["cand_start"] > (4 << 30) and fp["dda_voxels"] > (1 << 30)
     wl, wq = c5_oracle.likelihood_measure(sc.poses[C5_SLICE], sc.scan_lik)
     wb, _ = c5_oracle.beam_measure(sc.poses[C5_SLICE], sc.scan_beam, sc.scan_beam_label, sc.origins)
     np.testing.assert_array_equal(ratio[C5_SLICE], wq)

@@ -268,35 +268,74 @@ def test_tiled_kernel_matches_per_particle_kernel(engine, oracle_kind, group, mo
     np.testing.assert_array_equal(ratio1, wq)
 
 
-@pytest.mark.parametrize("ilp", [1, 2, 3])
+@pytest.mark.parametrize("variant", [(1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("group", [4, 8, 16])
 @pytest.mark.parametrize("n_p", [100, 37])
-def test_tiled_kernel_several_evaluations_in_flight(engine, ilp, group, n_p):
-    """lik_ilp > 0: U particles per loop iteration with batched loads — the SAME terms summed in the SAME order, so the
-    results equal the one-evaluation-at-a-time kernel bit for bit (also with strict_order, also when the last particle
-    group is ragged: 37 = 2 x 16 + 5, 100 = 6 x 16 + 4). Includes particles outside the map (lanes that discard their
-    loads) through the wide pose noise."""
+def test_tiled_kernel_variants_are_bit_identical(engine, variant, group, n_p):
+    """lik_ilp (two evaluations in flight per lane) and lik_trim (VALU-trimmed evaluation): the SAME terms summed in the
+    SAME order as the plain tiled kernel, so the results are equal bit for bit (also with strict_order, also when the
+    last particle group is ragged: 37 = 2 x 16 + 5, 100 = 6 x 16 + 4). The wide pose noise sends particles outside the
+    map (lanes that discard their loads)."""
+    ilp, trim = variant
     sc = make_scene(n=91, n_p=n_p, n_s=1500, seed=6, sigma_xyz=(1.5, 1.5, 0.4), sigma_rpy=(0.05, 0.05, 1.0))
     sc.poses[::7, 0] += 30.0  # far outside the grid
-    dw = (1.0, 1.0, 3.0)
-    setup_engine(engine, sc, dw, stamp=41)
     res = {}
-    default_ilp = engine.get_option("lik_ilp")
+    d_ilp, d_trim = engine.get_option("lik_ilp"), engine.get_option("lik_trim")
     try:
         engine.set_option("lik_group", group)
-        for strict in (0, 1):
-            engine.set_option("strict_order", strict)
-            for v in (0, ilp):
-                engine.set_option("lik_ilp", v)
-                res[(strict, v)] = engine.measure_batch(sc.poses, sc.scan_lik)
+        for dw in ((1.0, 1.0, 3.0), None):
+            setup_engine(engine, sc, dw, stamp=41)
+            for strict in (0, 1):
+                engine.set_option("strict_order", strict)
+                for v in ((0, 0), (ilp, trim)):
+                    engine.set_option("lik_ilp", v[0])
+                    engine.set_option("lik_trim", v[1])
+                    res[(dw, strict, v)] = engine.measure_batch(sc.poses, sc.scan_lik)
     finally:
-        engine.set_option("lik_ilp", default_ilp)
+        engine.set_option("lik_ilp", d_ilp)
+        engine.set_option("lik_trim", d_trim)
         engine.set_option("lik_group", 0)
         engine.set_option("strict_order", 0)
-    for strict in (0, 1):
-        np.testing.assert_array_equal(res[(strict, ilp)][0], res[(strict, 0)][0])
-        np.testing.assert_array_equal(res[(strict, ilp)][1], res[(strict, 0)][1])
-    assert np.count_nonzero(res[(0, 0)][0]) > n_p // 3
+    for dw in ((1.0, 1.0, 3.0), None):
+        for strict in (0, 1):
+            np.testing.assert_array_equal(res[(dw, strict, (ilp, trim))][0], res[(dw, strict, (0, 0))][0])
+            np.testing.assert_array_equal(res[(dw, strict, (ilp, trim))][1], res[(dw, strict, (0, 0))][1])
+    assert np.count_nonzero(res[(None, 0, (0, 0))][0]) > n_p // 3
+
+
+@pytest.mark.parametrize("flat", [0.05, 0.0, 1e-21])
+def test_trimmed_sqrt_at_tiny_and_zero_distances(engine, oracle_kind, flat):
+    """lik_trim replaces sqrtf by v_sqrt_f32 + the two residual checks, without the compiler's input scaling below 2^-96:
+    distances of exactly zero, denormal and sub-2^-96 squared distances must still give the reference's float."""
+    rng = np.random.default_rng(11)
+    cloud = rng.uniform(-1.0, 1.0, (4000, 3)).astype(np.float32)
+    special = np.array([[0, 0, 0], [0.5, 0.25, -0.125]], np.float32)
+    map_xyz = np.concatenate([special, cloud[np.abs(cloud).max(1) > 0.3]], 0)
+    tiny = np.array([[0, 0, 0], [1e-20, 0, 0], [3e-23, 0, 0], [0, 1e-15, 0], [2e-16, 1e-16, 0], [0.5, 0.25, -0.125],
+                     [0.5, 0.25 + 1.5e-8, -0.125], [1e-7, 0, 0], [0.01, 0.01, 0.01]], np.float32)
+    scan = np.concatenate([np.repeat(tiny, 120, 0), rng.uniform(-1, 1, (1200, 3)).astype(np.float32)], 0)  # >= 1024 points: tiled
+    poses = np.zeros((8, 7), np.float32)
+    poses[:, 6] = 1.0
+    poses[1:, :3] = rng.normal(0, 1e-3, (7, 3)).astype(np.float32)
+    d_trim = engine.get_option("lik_trim")
+    try:
+        engine.set_map(map_xyz, None, stamp=43, dist_weight=None)
+        engine.set_likelihood_params(match_dist_min=0.2, match_dist_flat=flat, match_weight=5.0)
+        out = {}
+        for trim in (0, 1):
+            engine.set_option("lik_trim", trim)
+            out[trim] = engine.measure_batch(poses, scan)
+    finally:
+        engine.set_option("lik_trim", d_trim)
+        engine.set_likelihood_params()
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    np.testing.assert_array_equal(out[1][1], out[0][1])
+    o = pyoracle.Oracle(oracle_kind)
+    o.set_map(map_xyz, None, dist_weight=None)
+    o.set_likelihood_params(pyoracle.LikelihoodParams(match_dist_min=0.2, match_dist_flat=flat, match_weight=5.0))
+    wl, wq = o.likelihood_measure(poses, scan)
+    np.testing.assert_allclose(out[1][0], wl, rtol=RTOL)
+    np.testing.assert_array_equal(out[1][1], wq)
 
 
 def test_sharded_update_protocol_on_one_gpu(engine, oracle_kind, scene_c1):
