@@ -52,7 +52,6 @@ L2_PEAK_GBPS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 L2_LINE_BYTES = 128.0    # gfx950 L1 <-> L2 request granularity
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9         # sustained shader clock after the pre-warm (GRBM_GUI_ACTIVE / kernel time, profiles/)
-ILP_VARIANTS = {0: (1, 8), 1: (2, 8)}  # lik_ilp -> (U, MINW) template arguments
 # cycles one wave64 VALU instruction occupies a SIMD, by class (profiles/r02*_valu_microbench.txt; fallback values = the
 # round-2 measurement): f32 add / sub / mul / fma issue at the full rate, transcendentals at a quarter of the half rate,
 # everything else (integer, compares, selects, moves, conversions, min / max, packed pairs, every f64 op) at half rate
@@ -76,10 +75,9 @@ def parse():
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
-    ap.add_argument("--lik-ilp", type=int, default=-1,
-                    help="tiled kernel: evaluations in flight per lane (-1 = the library's default, 0 = one, 1 = two)")
-    ap.add_argument("--lik-trim", type=int, default=-1,
-                    help="tiled kernel: VALU-trimmed evaluation, same results (-1 = the library's default)")
+    ap.add_argument("--lik-coop", type=int, default=-1,
+                    help="quad-cooperative record fetch (-1 = the library's default, 1 = on, 0 = every lane fetches its "
+                         "own record)")
     ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
     ap.add_argument("--map-jitter", type=float, default=0.0,
                     help="displace every map point uniformly by +-this (m): voxel-filter centroids instead of a lattice")
@@ -293,12 +291,9 @@ def main():
     eng.set_option("lik_small", args.lik_small)
     eng.set_option("overlap_models", args.overlap_models)
     eng.set_option("lik_group", args.lik_group)
-    if args.lik_ilp >= 0:
-        eng.set_option("lik_ilp", args.lik_ilp)
-    if args.lik_trim >= 0:
-        eng.set_option("lik_trim", args.lik_trim)
-    lik_ilp = int(eng.get_option("lik_ilp"))
-    lik_trim = int(eng.get_option("lik_trim"))
+    if args.lik_coop >= 0:
+        eng.set_option("lik_coop", args.lik_coop)
+    lik_coop = int(eng.get_option("lik_coop"))
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
@@ -473,10 +468,9 @@ def main():
         group = _tiled_group(n_s, n_p, args.lik_group)
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:
-            u, w = ILP_VARIANTS[lik_ilp] if (args.lik_index == 2 and group != 32) else (1, 4 if group == 32 else 8)
-            trim = bool(lik_trim and args.lik_index == 2 and group != 32)
-            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %d, %s>" % (group, args.lik_index, u, w,
-                                                                           "true" if trim else "false")
+            coop = bool(lik_coop and args.lik_index == 2)
+            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %s>" % (group, args.lik_index, 4 if group == 32 else 8,
+                                                                       "true" if coop else "false")
         elif small:
             kernel_name = "likelihood_small_kernel<"
         else:
@@ -538,6 +532,10 @@ def main():
             "algorithmic_rate_GBps": bytes_lik_launch / kernel_s / 1e9 if lik_n else None,
             "k_bar": k_bar,
             "index_bytes_per_eval": 68.0 if args.lik_index == 2 else None,
+            # L1 (TCP) cache-line accesses per cycle and CU: the resource that bound the kernel before the cooperative
+            # fetch — kept as an observation, the counter has no documented peak
+            "l1_accesses_per_cycle_per_cu": (pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (kernel_s * CLOCK_HZ)
+                                             if pmc and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc and lik_n else None),
         }
         out = {
             "metric": "particle·point evals/sec; filter-update Hz @ 4096 particles × 16k-pt scan",  # BASELINE.json
@@ -562,7 +560,7 @@ def main():
                 "update_hz": 1e3 / ms_per_step,
                 "accumulate": ("float, reference order (bit-identical results)" if args.strict_order else
                                "fp64 tree (terms bit-identical to the reference's float terms)"),
-                "lik_ilp": lik_ilp, "lik_trim": lik_trim,
+                "lik_coop": lik_coop,
             },
             "value_definition": "device-resident update (map structures, ordered scan, poses, prior weights in HBM before "
                                 "the timed region); the host-buffer form of SURVEY.md section 8d is `update_8d`",

@@ -243,6 +243,73 @@ int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* re
 /* Why the last capture attempt fell back to kernel-by-kernel launches ("" if none did). */
 const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx);
 
+/* ---- "next" row: scan preparation on the GPU ------------------------------------------------------
+ * Replaces, for one measurement update: the pcl::VoxelGrid down-sampling of the accumulated cloud
+ * (src/mcl_3dl.cpp:363-367), both models' clip filter (src/lidar_measurement_model_likelihood.cpp:79-103,
+ * src/lidar_measurement_model_beam.cpp:98-122) and the sampler's gather
+ * (include/mcl_3dl/point_cloud_random_samplers/point_cloud_uniform_sampler.h:56-74) — the random engine stays with the
+ * caller, like resampling:
+ *   begin  : cloud (robot frame; label = index of the accumulated cloud, src/mcl_3dl.cpp:295-298) -> VoxelGrid(leaf3;
+ *            a component <= 0 or NULL skips it) -> pc_local_full; clipped copies for the likelihood and the beam model
+ *            (clip = {clip_near, clip_far, clip_z_min, clip_z_max}; NULL = that model is not used). Returns the three
+ *            sizes; the clouds stay on the device.
+ *   [the caller draws n_s resp. n_b indices with std::uniform_int_distribution<size_t>(0, size - 1), sampler.h:66-71]
+ *   finish : gathers the drawn points, orders them (the ordering mcl3dl_hip_upload_scan does on the host, same keys, same
+ *            stable order) and installs them as the scans of the next mcl3dl_hip_measure_device / _update_device — no
+ *            host round trip of the points. Results are bit-identical to uploading the same sampled clouds.
+ * VoxelGrid follows pcl::VoxelGrid<PointXYZIL> as the node configures it (setLeafSize only): leaf index
+ * int(floor(p * inv_leaf) - float(min_b)) . divb_mul, one centroid per occupied leaf in ascending leaf order, label = the
+ * most frequent one (smallest on a tie); xyz are summed as floats in INPUT order (PCL's own std::sort leaves the order
+ * inside a leaf unspecified; PCL is not vendored by the reference: parity at this boundary is against the restatement
+ * in oracle/). Non-finite points are dropped by the filter. Intensity is not carried.
+ * download: which = 0 pc_local_full, 1 / 2 clipped likelihood / beam cloud, 3 / 4 sampled clouds in the caller's index
+ * order (xyz NULL: only *n). */
+int mcl3dl_hip_scan_begin(mcl3dl_hip_ctx* ctx, const float* xyz /*n*3*/, const uint32_t* label /*n or NULL*/, size_t n,
+                          const float* leaf3, const float* clip_lik4, const float* clip_beam4, size_t* n_full,
+                          size_t* n_lik_clipped, size_t* n_beam_clipped);
+/* The same from the wire format (mcl_3dl::fromROSMsg, include/mcl_3dl/point_conversion.h:64-92): little-endian
+ * sensor_msgs/PointCloud2 data with FLOAT32 x / y / z at the given byte offsets and an optional UINT32 "label" field
+ * (off_label < 0: none). label_override = 0 stamps every point with accumulated-cloud index 0 (what accumCloud does for
+ * the first / only cloud), 0xffffffff keeps the message's labels. */
+int mcl3dl_hip_scan_begin_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
+                                      int off_x, int off_y, int off_z, int off_label, uint32_t label_override,
+                                      const float* leaf3, const float* clip_lik4, const float* clip_beam4, size_t* n_full,
+                                      size_t* n_lik_clipped, size_t* n_beam_clipped);
+int mcl3dl_hip_scan_finish(mcl3dl_hip_ctx* ctx, const uint32_t* idx_lik /*n_s*/, size_t n_s,
+                           const uint32_t* idx_beam /*n_b*/, size_t n_b, const float* origins /*n_o*3*/, size_t n_o);
+int mcl3dl_hip_scan_download(mcl3dl_hip_ctx* ctx, int which, float* xyz, uint32_t* label, size_t capacity, size_t* n);
+
+/* ---- "next" row: map from the wire format, map updates, matched / unmatched output --------------
+ * set_map_*: replaces cbMapcloud + loadMapCloud (src/mcl_3dl.cpp:128-139, 1140-1158): decode, VoxelGrid(map_downsample),
+ * then as mcl3dl_hip_set_map. *n_map = points kept.
+ * map_update*: replaces cbMapcloudUpdate + cbMapUpdateTimer (src/mcl_3dl.cpp:141-153, 1355-1369): pc_map2 = pc_map +
+ * VoxelGrid(update, update_downsample); a later update REPLACES the earlier one (n = 0 removes it). The candidate-voxel
+ * index is not rebuilt: only the bricks within reach of a removed or an added point are compiled again (from the points
+ * that can reach them) and installed over their old records — results identical to a fresh index of the merged map.
+ * stats5 (may be NULL) = {bricks re-compiled, bricks added, points that took part, device milliseconds, overflow
+ * records appended}; all zero when the update fell back to a full rebuild on next use (nothing built yet, a point outside
+ * the grid the index was laid out for, lik_index != 2).
+ * map_download: the map as the engine holds it (base, then update). */
+int mcl3dl_hip_set_map_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step, int off_x,
+                                   int off_y, int off_z, int off_label, const float* leaf3, uint64_t stamp,
+                                   const float* dist_weight, size_t* n_map);
+int mcl3dl_hip_set_map_downsampled(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n,
+                                   const float* leaf3, uint64_t stamp, const float* dist_weight, size_t* n_map);
+int mcl3dl_hip_map_update(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, const float* leaf3,
+                          uint64_t stamp, size_t* n_map, double* stats5);
+int mcl3dl_hip_map_update_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
+                                      int off_x, int off_y, int off_z, int off_label, const float* leaf3, uint64_t stamp,
+                                      size_t* n_map, double* stats5);
+int mcl3dl_hip_map_download(mcl3dl_hip_ctx* ctx, float* xyz, uint32_t* label, size_t capacity, size_t* n);
+/* Replaces the matched / unmatched classification of src/mcl_3dl.cpp:761-805 as ONE device pass: every point of
+ * pc_local_full (xyz NULL: the cloud mcl3dl_hip_scan_begin left on the device; otherwise n explicit robot-frame points)
+ * is transformed by the pose (State6DOF::transform), searched with radiusSearch(p, unmatch_dist, ., ., 1); no neighbour ->
+ * unmatched; sqdist < match_dist^2 (compared in double, :778-786) -> matched. Outputs are the transformed points in input
+ * order (NULL: counts only). */
+int mcl3dl_hip_match_split(mcl3dl_hip_ctx* ctx, const float* pose7, const float* xyz, size_t n, float unmatch_dist,
+                           double match_dist, float* out_matched_xyz, size_t cap_matched, size_t* n_matched,
+                           float* out_unmatched_xyz, size_t cap_unmatched, size_t* n_unmatched);
+
 /* ---- device groups: N GPUs behind one handle, one host process ----------------------------------
  * The reference node is ONE C++ process (src/mcl_3dl.cpp:1466); a group lets that process use every GPU of the node with
  * src/mcl_3dl.cpp untouched: the drop-in model classes call the group_* forms of the entry points above.
@@ -325,11 +392,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
  *                       (single GPU; costs an n_s x n_p float buffer and two serial passes)
- *   "lik_ilp"           tiled kernel: 1 = two evaluations in flight per lane (their brick-table and record loads are
- *                       issued back to back), 0 = one
- *   "lik_trim"          tiled kernel: 1 = VALU-trimmed evaluation (likelihood_kernels.h: zero-operand products of the
- *                       quaternion product dropped, single-instruction floor, count-free minimum over sentinel-padded
- *                       records, sqrt without the sub-2^-96 input scaling); results identical to 0 */
+ *   "lik_coop"          tiled kernel: 1 (default) = the four lanes of a quad fetch each 64-byte voxel record together
+ *                       (16 cache-line accesses per load instruction instead of 64) and split its candidates between
+ *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
 int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,

@@ -64,6 +64,17 @@ SIGNATURES = {
     "mcl3dl_hip_workload_stats": (_i, [_p, _p, _sz, _p]),
     "mcl3dl_hip_memory_footprint": (_i, [_p, _p]),
     "mcl3dl_hip_set_option": (_i, [_p, C.c_char_p, _d]),
+    "mcl3dl_hip_scan_begin": (_i, [_p, _p, _p, _sz, _p, _p, _p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    "mcl3dl_hip_scan_begin_pointcloud2": (_i, [_p, _p, _sz, _u32, _i, _i, _i, _i, _u32, _p, _p, _p, C.POINTER(_sz),
+                                              C.POINTER(_sz), C.POINTER(_sz)]),
+    "mcl3dl_hip_scan_finish": (_i, [_p, _p, _sz, _p, _sz, _p, _sz]),
+    "mcl3dl_hip_scan_download": (_i, [_p, _i, _p, _p, _sz, C.POINTER(_sz)]),
+    "mcl3dl_hip_set_map_pointcloud2": (_i, [_p, _p, _sz, _u32, _i, _i, _i, _i, _p, _u64, _p, C.POINTER(_sz)]),
+    "mcl3dl_hip_set_map_downsampled": (_i, [_p, _p, _p, _sz, _p, _u64, _p, C.POINTER(_sz)]),
+    "mcl3dl_hip_map_update": (_i, [_p, _p, _p, _sz, _p, _u64, C.POINTER(_sz), _p]),
+    "mcl3dl_hip_map_update_pointcloud2": (_i, [_p, _p, _sz, _u32, _i, _i, _i, _i, _p, _u64, C.POINTER(_sz), _p]),
+    "mcl3dl_hip_map_download": (_i, [_p, _p, _p, _sz, C.POINTER(_sz)]),
+    "mcl3dl_hip_match_split": (_i, [_p, _p, _p, _sz, _f, _d, _p, _sz, C.POINTER(_sz), _p, _sz, C.POINTER(_sz)]),
     "mcl3dl_hip_group_create": (_i, [C.POINTER(_p), C.POINTER(_i), _i]),
     "mcl3dl_hip_group_destroy": (None, [_p]),
     "mcl3dl_hip_group_last_error": (C.c_char_p, [_p]),
@@ -465,6 +476,107 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_dda_trace(self.h, _ptr(b), _ptr(e), _ptr(out), max_out, C.byref(n),
                                                   C.byref(col), C.byref(hit)))
         return out[:min(n.value, max_out)].copy(), bool(col.value), int(hit.value), int(n.value)
+
+    # ---- scan preparation / map path on the device ----------------------------------------
+    @staticmethod
+    def _f3(a):
+        return None if a is None else _np_f32(a)
+
+    def scan_begin(self, xyz, label=None, leaf=None, clip_lik=(0.5, 10.0, -2.0, 2.0), clip_beam=(0.5, 4.0, -2.0, 2.0)):
+        """VoxelGrid + both clip filters on the device; returns (n_full, n_lik_clipped, n_beam_clipped)."""
+        pts = _np_f32(xyz, 3)
+        lab = None if label is None else np.ascontiguousarray(label, dtype=np.uint32)
+        lf, cl, cb = self._f3(leaf), self._f3(clip_lik), self._f3(clip_beam)
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_scan_begin(self.h, _ptr(pts), _ptr(lab), len(pts), _ptr(lf), _ptr(cl), _ptr(cb),
+                                                   C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def scan_begin_pointcloud2(self, data, n_points, point_step, off_x, off_y, off_z, off_label=-1, label_override=0,
+                               leaf=None, clip_lik=(0.5, 10.0, -2.0, 2.0), clip_beam=(0.5, 4.0, -2.0, 2.0)):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        lf, cl, cb = self._f3(leaf), self._f3(clip_lik), self._f3(clip_beam)
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_scan_begin_pointcloud2(self.h, _ptr(buf), n_points, point_step, off_x, off_y, off_z,
+                                                               off_label, label_override, _ptr(lf), _ptr(cl), _ptr(cb),
+                                                               C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def scan_finish(self, idx_lik, idx_beam=None, origins=None):
+        il = np.ascontiguousarray(idx_lik if idx_lik is not None else [], dtype=np.uint32)
+        ib = np.ascontiguousarray(idx_beam if idx_beam is not None else [], dtype=np.uint32)
+        og = _np_f32(origins if origins is not None else np.zeros((1, 3)), 3)
+        self._check(self.lib.mcl3dl_hip_scan_finish(self.h, _ptr(il), len(il), _ptr(ib), len(ib), _ptr(og), len(og)))
+
+    def scan_download(self, which):
+        n = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_scan_download(self.h, which, None, None, 0, C.byref(n)))
+        xyz = np.zeros((n.value, 3), np.float32)
+        lab = np.zeros(n.value, np.uint32)
+        if n.value:
+            self._check(self.lib.mcl3dl_hip_scan_download(self.h, which, _ptr(xyz), _ptr(lab), n.value, C.byref(n)))
+        return xyz, lab
+
+    def set_map_downsampled(self, xyz, label=None, leaf=(0.1, 0.1, 0.1), stamp=1, dist_weight=(1.0, 1.0, 1.0)):
+        pts = _np_f32(xyz, 3)
+        lab = None if label is None else np.ascontiguousarray(label, dtype=np.uint32)
+        n = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_set_map_downsampled(self.h, _ptr(pts), _ptr(lab), len(pts), _ptr(self._f3(leaf)),
+                                                            int(stamp), _ptr(self._f3(dist_weight)), C.byref(n)))
+        return int(n.value)
+
+    def set_map_pointcloud2(self, data, n_points, point_step, off_x, off_y, off_z, off_label=-1, leaf=(0.1, 0.1, 0.1),
+                            stamp=1, dist_weight=(1.0, 1.0, 1.0)):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_set_map_pointcloud2(self.h, _ptr(buf), n_points, point_step, off_x, off_y, off_z,
+                                                            off_label, _ptr(self._f3(leaf)), int(stamp),
+                                                            _ptr(self._f3(dist_weight)), C.byref(n)))
+        return int(n.value)
+
+    def map_update(self, xyz, label=None, leaf=(0.2, 0.2, 0.2), stamp=2):
+        """pc_map2 = pc_map + VoxelGrid(update); returns (n_map, stats dict)."""
+        pts = _np_f32(xyz if xyz is not None else np.zeros((0, 3)), 3)
+        lab = None if label is None else np.ascontiguousarray(label, dtype=np.uint32)
+        n = C.c_size_t(0)
+        st = np.zeros(5, np.float64)
+        self._check(self.lib.mcl3dl_hip_map_update(self.h, _ptr(pts), _ptr(lab), len(pts), _ptr(self._f3(leaf)), int(stamp),
+                                                   C.byref(n), _ptr(st)))
+        return int(n.value), dict(bricks_recompiled=int(st[0]), bricks_added=int(st[1]), points_involved=int(st[2]),
+                                  device_ms=float(st[3]), overflow_appended=int(st[4]))
+
+    def map_update_pointcloud2(self, data, n_points, point_step, off_x, off_y, off_z, off_label=-1, leaf=(0.2, 0.2, 0.2),
+                               stamp=2):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        n = C.c_size_t(0)
+        st = np.zeros(5, np.float64)
+        self._check(self.lib.mcl3dl_hip_map_update_pointcloud2(self.h, _ptr(buf), n_points, point_step, off_x, off_y, off_z,
+                                                               off_label, _ptr(self._f3(leaf)), int(stamp), C.byref(n),
+                                                               _ptr(st)))
+        return int(n.value), dict(bricks_recompiled=int(st[0]), bricks_added=int(st[1]), points_involved=int(st[2]),
+                                  device_ms=float(st[3]), overflow_appended=int(st[4]))
+
+    def map_download(self):
+        n = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_map_download(self.h, None, None, 0, C.byref(n)))
+        xyz = np.zeros((n.value, 3), np.float32)
+        lab = np.zeros(n.value, np.uint32)
+        self._check(self.lib.mcl3dl_hip_map_download(self.h, _ptr(xyz), _ptr(lab), n.value, C.byref(n)))
+        return xyz, lab
+
+    def match_split(self, pose7, xyz=None, unmatch_dist=0.5, match_dist=0.1):
+        """Transformed points classified as (matched, unmatched); xyz=None uses the cloud scan_begin left on the device."""
+        pose = _np_f32(pose7)
+        pts = None if xyz is None else _np_f32(xyz, 3)
+        n = 0 if pts is None else len(pts)
+        nm, nu = C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_match_split(self.h, _ptr(pose), _ptr(pts), n, unmatch_dist, match_dist, None, 0,
+                                                    C.byref(nm), None, 0, C.byref(nu)))
+        m = np.zeros((nm.value, 3), np.float32)
+        u = np.zeros((nu.value, 3), np.float32)
+        self._check(self.lib.mcl3dl_hip_match_split(self.h, _ptr(pose), _ptr(pts), n, unmatch_dist, match_dist, _ptr(m),
+                                                    len(m), C.byref(nm), _ptr(u), len(u), C.byref(nu)))
+        return m, u
 
     # ---- device entry points (torch CUDA tensors or raw device addresses) ---------------------------------------
     def upload_scan(self, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):

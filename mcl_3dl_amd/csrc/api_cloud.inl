@@ -1,0 +1,587 @@
+// api_cloud.inl — included inside the extern "C" block of mcl3dl_hip.hip: SURVEY.md §8f-2 (scan preparation on the GPU)
+// and §8f-4 (map from the wire format, map updates, matched / unmatched output). Device code: cloud_kernels.h.
+namespace
+{
+unsigned blocks_for(long long n)
+{
+  return static_cast<unsigned>((std::max<long long>(n, 1) + 255) / 256);
+}
+
+// stable ascending sort of (key, value) pairs on the context's stream; results in keys_out / vals_out
+int sort_pairs(mcl3dl_hip_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+               long long n, int end_bit)
+{
+  if (n <= 0)
+    return 0;
+  if (n > 0x7fffffffLL)
+    return ctx->fail(-3, "too many points to sort");
+  size_t bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, static_cast<int>(n), 0,
+                                             end_bit, ctx->stream));
+  TRY(ensure(ctx, ctx->sort_tmp, bytes));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, bytes, keys_in, keys_out, vals_in, vals_out,
+                                             static_cast<int>(n), 0, end_bit, ctx->stream));
+  return 0;
+}
+
+// min / max of the finite points of a device cloud -> ctx->cl_minmax (6 floats, device) and, on request, the host
+int cloud_minmax(mcl3dl_hip_ctx* ctx, const float4* pts, long long n, float* host6, unsigned long long* host_cnt)
+{
+  const int nb = static_cast<int>(std::min<long long>((n + 255) / 256, 512));
+  TRY(ensure(ctx, ctx->cl_blocks, sizeof(float) * 6 * std::max(nb, 1) + sizeof(unsigned) * std::max(nb, 1)));
+  TRY(ensure(ctx, ctx->cl_minmax, sizeof(float) * 6 + sizeof(unsigned long long)));
+  float* bo = ctx->cl_blocks.as<float>();
+  unsigned* bc = reinterpret_cast<unsigned*>(bo + 6 * std::max(nb, 1));
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ctx->cl_minmax.as<float>() + 6);
+  hipLaunchKernelGGL(cloud_minmax_kernel, dim3(std::max(nb, 1)), dim3(256), 0, ctx->stream, pts, n, bo, bc);
+  hipLaunchKernelGGL(cloud_minmax_final, dim3(1), dim3(64), 0, ctx->stream, bo, bc, std::max(nb, 1),
+                     ctx->cl_minmax.as<float>(), cnt);
+  HIP_TRY(hipGetLastError());
+  if (host6 || host_cnt)
+  {
+    float h[8];
+    TRY(d2h(ctx, h, ctx->cl_minmax.p, sizeof(float) * 6 + sizeof(unsigned long long)));
+    TRY(sync_stream(ctx));
+    if (host6)
+      memcpy(host6, h, sizeof(float) * 6);
+    if (host_cnt)
+      memcpy(host_cnt, h + 6, sizeof(unsigned long long));
+  }
+  return 0;
+}
+
+// pcl::VoxelGrid<PointXYZIL> with only setLeafSize set (the node's three call sites): `in` (n points, device) ->
+// `out` (one centroid per occupied leaf, in ascending leaf-index order). A leaf component <= 0 skips the filter.
+int voxel_grid(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf[3], DevBuf& out, size_t* n_out)
+{
+  *n_out = 0;
+  TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
+  if (n == 0)
+    return 0;
+  if (!leaf || !(leaf[0] > 0.f && leaf[1] > 0.f && leaf[2] > 0.f))
+  {
+    HIP_TRY(hipMemcpyAsync(out.p, in, sizeof(float4) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    *n_out = n;
+    return 0;
+  }
+  float mm[6];
+  unsigned long long n_finite = 0;
+  TRY(cloud_minmax(ctx, in, static_cast<long long>(n), mm, &n_finite));
+  if (n_finite == 0)
+    return 0;
+  VoxelGridParams vp{};
+  long long d[3];
+  int max_b[3];
+  for (int a = 0; a < 3; ++a)
+  {
+    vp.inv_leaf[a] = 1.0f / leaf[a];  // Eigen::Array4f::Ones() / leaf_size_.array()
+    // voxel_grid.hpp: static_cast<std::int64_t>((max_p - min_p) * inverse_leaf_size) + 1
+    d[a] = static_cast<long long>((mm[3 + a] - mm[a]) * vp.inv_leaf[a]) + 1;
+    vp.min_b[a] = static_cast<int>(std::floor(mm[a] * vp.inv_leaf[a]));
+    max_b[a] = static_cast<int>(std::floor(mm[3 + a] * vp.inv_leaf[a]));
+  }
+  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max()))
+  {
+    // "Leaf size is too small for the input dataset. Integer indices would overflow": PCL hands the input back
+    HIP_TRY(hipMemcpyAsync(out.p, in, sizeof(float4) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    *n_out = n;
+    return 0;
+  }
+  const int div0 = max_b[0] - vp.min_b[0] + 1, div1 = max_b[1] - vp.min_b[1] + 1;
+  vp.mul[0] = 1;
+  vp.mul[1] = div0;
+  vp.mul[2] = div0 * div1;
+  const long long nn = static_cast<long long>(n);
+  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_scan, sizeof(uint32_t) * (n + 2)));
+  TRY(ensure(ctx, ctx->cl_scan_ws, sizeof(uint32_t) * (n / 1023 + 16)));
+  hipLaunchKernelGGL(vg_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, in, nn, vp,
+                     ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>());
+  TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
+                 ctx->cl_val[1].as<uint32_t>(), nn, 32));
+  const long long nf = static_cast<long long>(n_finite);  // the non-finite points carry key 0xffffffff: sorted last
+  hipLaunchKernelGGL(vg_heads_kernel, dim3(blocks_for(nf + 1)), dim3(256), 0, ctx->stream, ctx->cl_key[1].as<uint32_t>(),
+                     nf, ctx->cl_scan.as<uint32_t>());
+  TRY(device_exclusive_scan_ws(ctx, ctx->cl_scan.as<uint32_t>(), nf + 1, ctx->cl_scan_ws.as<uint32_t>()));
+  uint32_t n_leaves = 0;
+  TRY(d2h(ctx, &n_leaves, ctx->cl_scan.as<uint32_t>() + nf, sizeof(uint32_t)));
+  TRY(sync_stream(ctx));
+  TRY(ensure(ctx, ctx->cl_start, sizeof(uint32_t) * (static_cast<size_t>(n_leaves) + 1)));
+  hipLaunchKernelGGL(vg_starts_kernel, dim3(blocks_for(nf + 1)), dim3(256), 0, ctx->stream, ctx->cl_key[1].as<uint32_t>(),
+                     ctx->cl_scan.as<uint32_t>(), nf, n_leaves, ctx->cl_start.as<uint32_t>());
+  hipLaunchKernelGGL(vg_centroid_kernel, dim3(blocks_for(n_leaves)), dim3(256), 0, ctx->stream, in,
+                     ctx->cl_val[1].as<uint32_t>(), ctx->cl_start.as<uint32_t>(), n_leaves, out.as<float4>());
+  HIP_TRY(hipGetLastError());
+  *n_out = n_leaves;
+  return 0;
+}
+
+// clip predicate + order-preserving compaction: in (n) -> out, *n_out kept. One stream synchronisation (the count).
+int clip_compact(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float clip4[4], DevBuf& out, size_t* n_out)
+{
+  *n_out = 0;
+  TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
+  if (n == 0)
+    return 0;
+  const long long nn = static_cast<long long>(n);
+  TRY(ensure(ctx, ctx->cl_scan, sizeof(uint32_t) * (n + 2)));
+  TRY(ensure(ctx, ctx->cl_scan_ws, sizeof(uint32_t) * (n / 1023 + 16)));
+  // clip_near_sq_ = clip_near * clip_near etc. in float, like refreshParameters (likelihood.cpp:58-59, beam.cpp:60-61)
+  const float near_sq = clip4[0] * clip4[0], far_sq = clip4[1] * clip4[1];
+  hipLaunchKernelGGL(clip_flag_kernel, dim3(blocks_for(nn + 1)), dim3(256), 0, ctx->stream, in, nn, near_sq, far_sq, clip4[2],
+                     clip4[3], ctx->cl_scan.as<uint32_t>());
+  TRY(device_exclusive_scan_ws(ctx, ctx->cl_scan.as<uint32_t>(), nn + 1, ctx->cl_scan_ws.as<uint32_t>()));
+  hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, in, ctx->cl_scan.as<uint32_t>(), nn,
+                     out.as<float4>());
+  uint32_t kept = 0;
+  TRY(d2h(ctx, &kept, ctx->cl_scan.as<uint32_t>() + nn, sizeof(uint32_t)));
+  TRY(sync_stream(ctx));
+  *n_out = kept;
+  return 0;
+}
+
+// host xyz (+ label) -> device float4 cloud
+int upload_cloud(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, DevBuf& out)
+{
+  TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
+  if (n == 0)
+    return 0;
+  TRY(ensure(ctx, ctx->cl_in_xyz, sizeof(float) * 3 * n));
+  TRY(h2d(ctx, ctx->cl_in_xyz.p, xyz, sizeof(float) * 3 * n));
+  const uint32_t* d_label = nullptr;
+  if (label)
+  {
+    TRY(ensure(ctx, ctx->cl_in_label, sizeof(uint32_t) * n));
+    TRY(h2d(ctx, ctx->cl_in_label.p, label, sizeof(uint32_t) * n));
+    d_label = ctx->cl_in_label.as<uint32_t>();
+  }
+  hipLaunchKernelGGL(cloud_pack_kernel, dim3(blocks_for(static_cast<long long>(n))), dim3(256), 0, ctx->stream,
+                     ctx->cl_in_xyz.as<float>(), d_label, static_cast<long long>(n), out.as<float4>());
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// PointCloud2 bytes -> device float4 cloud (mcl_3dl::fromROSMsg, point_conversion.h:64-92: x, y, z are required; a
+// "label" field is used when present; "intensity" is not on the measurement path)
+int decode_cloud(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step, int off_x, int off_y,
+                 int off_z, int off_label, DevBuf& out)
+{
+  if (off_x < 0 || off_y < 0 || off_z < 0)
+    return ctx->fail(-3, "Given PointCloud2 doesn't have x, y, z fields");
+  if (n_points == 0)
+    return ctx->fail(-3, "Given PointCloud2 is empty");
+  const int offs[4] = { off_x, off_y, off_z, off_label };
+  for (int k = 0; k < 4; ++k)
+    if (offs[k] >= 0 && static_cast<uint32_t>(offs[k]) + 4 > point_step)
+      return ctx->fail(-3, "field offset %d does not fit point_step %u", offs[k], point_step);
+  if (!data)
+    return ctx->fail(-3, "null PointCloud2 data");
+  const size_t bytes = n_points * static_cast<size_t>(point_step);
+  TRY(ensure(ctx, ctx->cl_in_xyz, bytes));
+  TRY(ensure(ctx, out, sizeof(float4) * n_points));
+  TRY(h2d(ctx, ctx->cl_in_xyz.p, data, bytes));
+  hipLaunchKernelGGL(cloud_decode_kernel, dim3(blocks_for(static_cast<long long>(n_points))), dim3(256), 0, ctx->stream,
+                     ctx->cl_in_xyz.as<uint8_t>(), static_cast<long long>(n_points), point_step, off_x, off_y, off_z,
+                     off_label, out.as<float4>());
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int download_cloud(mcl3dl_hip_ctx* ctx, const float4* src, size_t n, float* xyz, uint32_t* label)
+{
+  if (n == 0)
+    return 0;
+  TRY(ensure(ctx, ctx->cl_in_xyz, sizeof(float) * 3 * n));
+  TRY(ensure(ctx, ctx->cl_in_label, sizeof(uint32_t) * n));
+  hipLaunchKernelGGL(cloud_unpack_kernel, dim3(blocks_for(static_cast<long long>(n))), dim3(256), 0, ctx->stream, src,
+                     static_cast<long long>(n), ctx->cl_in_xyz.as<float>(), label ? ctx->cl_in_label.as<uint32_t>() : nullptr);
+  HIP_TRY(hipGetLastError());
+  TRY(d2h(ctx, xyz, ctx->cl_in_xyz.p, sizeof(float) * 3 * n));
+  if (label)
+    TRY(d2h(ctx, label, ctx->cl_in_label.p, sizeof(uint32_t) * n));
+  TRY(sync_stream(ctx));
+  return 0;
+}
+
+int scan_begin_common(mcl3dl_hip_ctx* ctx, size_t n, const float* leaf3, const float* clip_lik4, const float* clip_beam4,
+                      size_t* n_full, size_t* n_lik, size_t* n_beam)
+{
+  // ctx->sp_raw holds the accumulated cloud
+  ctx->sp_ready = false;
+  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n, leaf3, ctx->sp_full, &ctx->sp_n_full));
+  if (clip_lik4)
+    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_lik4, ctx->sp_clip[0], &ctx->sp_n_clip[0]));
+  else
+    ctx->sp_n_clip[0] = 0;
+  if (clip_beam4)
+    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_beam4, ctx->sp_clip[1], &ctx->sp_n_clip[1]));
+  else
+    ctx->sp_n_clip[1] = 0;
+  TRY(sync_stream(ctx));
+  ctx->sp_ready = true;
+  if (n_full)
+    *n_full = ctx->sp_n_full;
+  if (n_lik)
+    *n_lik = ctx->sp_n_clip[0];
+  if (n_beam)
+    *n_beam = ctx->sp_n_clip[1];
+  return 0;
+}
+}  // namespace
+
+int mcl3dl_hip_scan_begin(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, const float* leaf3,
+                          const float* clip_lik4, const float* clip_beam4, size_t* n_full, size_t* n_lik_clipped,
+                          size_t* n_beam_clipped)
+{
+  if (!ctx)
+    return -1;
+  if (n && !xyz)
+    return ctx->fail(-3, "null cloud");
+  if (n > 0x7fffffffu)
+    return ctx->fail(-3, "cloud too large");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(upload_cloud(ctx, xyz, label, n, ctx->sp_raw));
+  return scan_begin_common(ctx, n, leaf3, clip_lik4, clip_beam4, n_full, n_lik_clipped, n_beam_clipped);
+}
+
+int mcl3dl_hip_scan_begin_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
+                                      int off_x, int off_y, int off_z, int off_label, uint32_t label_override,
+                                      const float* leaf3, const float* clip_lik4, const float* clip_beam4, size_t* n_full,
+                                      size_t* n_lik_clipped, size_t* n_beam_clipped)
+{
+  if (!ctx)
+    return -1;
+  if (n_points > 0x7fffffffu)
+    return ctx->fail(-3, "cloud too large");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // accumCloud overwrites every label with the index of the accumulated cloud (src/mcl_3dl.cpp:295-298): with one message
+  // per update that index is label_override; pass 0xffffffff to keep the message's own labels
+  (void)label_override;
+  TRY(decode_cloud(ctx, data, n_points, point_step, off_x, off_y, off_z, label_override == 0xffffffffu ? off_label : -1,
+                   ctx->sp_raw));
+  if (label_override != 0xffffffffu && label_override != 0u)
+    return ctx->fail(-3, "label_override must be 0 (single accumulated cloud) or 0xffffffff (keep the message's labels)");
+  return scan_begin_common(ctx, n_points, leaf3, clip_lik4, clip_beam4, n_full, n_lik_clipped, n_beam_clipped);
+}
+
+int mcl3dl_hip_scan_finish(mcl3dl_hip_ctx* ctx, const uint32_t* idx_lik, size_t n_s, const uint32_t* idx_beam, size_t n_b,
+                           const float* origins, size_t n_o)
+{
+  if (!ctx)
+    return -1;
+  if (!ctx->sp_ready)
+    return ctx->fail(-5, "no prepared scan: call mcl3dl_hip_scan_begin first");
+  if ((n_s && !idx_lik) || (n_b && (!idx_beam || !origins || n_o == 0)))
+    return ctx->fail(-3, "null index / origin array");
+  if (n_s > 0x7fffffffu || n_b > 0x7fffffffu)
+    return ctx->fail(-3, "scan too large");
+  // the sampler draws from a non-empty cloud only (point_cloud_uniform_sampler.h:63-64 returns an empty cloud otherwise)
+  if ((n_s && ctx->sp_n_clip[0] == 0) || (n_b && ctx->sp_n_clip[1] == 0))
+    return ctx->fail(-3, "indices given for an empty clipped cloud");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(ensure(ctx, ctx->cl_err, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(ctx->cl_err.p, 0, sizeof(int), ctx->stream));
+  const size_t n_max = std::max<size_t>(std::max(n_s, n_b), 1);
+  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n_max + 1)));
+  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n_max + 1)));
+  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n_max + 1)));
+  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n_max + 1)));
+  TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
+  TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
+  TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
+  TRY(ensure(ctx, ctx->origins, sizeof(float4) * n_o));
+  // ---- likelihood scan: gather the drawn points, Morton-order them (same keys and stable order as the host path)
+  TRY(ensure(ctx, ctx->sp_samp[0], sizeof(float4) * std::max<size_t>(n_s, 1)));
+  if (n_s)
+  {
+    const long long ns = static_cast<long long>(n_s);
+    TRY(ensure(ctx, ctx->cl_idx, sizeof(uint32_t) * n_s));
+    TRY(h2d(ctx, ctx->cl_idx.p, idx_lik, sizeof(uint32_t) * n_s));
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream, ctx->sp_clip[0].as<float4>(),
+                       static_cast<long long>(ctx->sp_n_clip[0]), ctx->cl_idx.as<uint32_t>(), ns,
+                       ctx->sp_samp[0].as<float4>(), ctx->cl_err.as<int>());
+    TRY(cloud_minmax(ctx, ctx->sp_samp[0].as<float4>(), ns, nullptr, nullptr));
+    hipLaunchKernelGGL(order_morton_key_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream,
+                       ctx->sp_samp[0].as<float4>(), ns, ctx->cl_minmax.as<float>(), ctx->cl_key[0].as<uint32_t>(),
+                       ctx->cl_val[0].as<uint32_t>());
+    TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
+                   ctx->cl_val[1].as<uint32_t>(), ns, 30));
+    hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream, ctx->sp_samp[0].as<float4>(),
+                       ctx->cl_val[1].as<uint32_t>(), ns, 1, ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>());
+  }
+  // ---- beam scan: gather, order by range from the scan origin
+  TRY(ensure(ctx, ctx->sp_samp[1], sizeof(float4) * std::max<size_t>(n_b, 1)));
+  if (n_o)
+  {
+    ctx->h_scan.origins.resize(n_o);
+    for (size_t i = 0; i < n_o; ++i)
+      ctx->h_scan.origins[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+    TRY(h2d(ctx, ctx->origins.p, ctx->h_scan.origins.data(), sizeof(float4) * n_o));
+  }
+  if (n_b)
+  {
+    const long long nb = static_cast<long long>(n_b);
+    TRY(ensure(ctx, ctx->cl_idx, sizeof(uint32_t) * n_b));
+    TRY(h2d(ctx, ctx->cl_idx.p, idx_beam, sizeof(uint32_t) * n_b));
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, ctx->sp_clip[1].as<float4>(),
+                       static_cast<long long>(ctx->sp_n_clip[1]), ctx->cl_idx.as<uint32_t>(), nb,
+                       ctx->sp_samp[1].as<float4>(), ctx->cl_err.as<int>());
+    hipLaunchKernelGGL(order_range_key_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream,
+                       ctx->sp_samp[1].as<float4>(), nb, ctx->origins.as<float4>(), static_cast<uint32_t>(n_o),
+                       ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->cl_err.as<int>());
+    TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
+                   ctx->cl_val[1].as<uint32_t>(), nb, 32));
+    hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, ctx->sp_samp[1].as<float4>(),
+                       ctx->cl_val[1].as<uint32_t>(), nb, 0, ctx->scan_beam.as<float4>(), static_cast<uint32_t*>(nullptr));
+  }
+  HIP_TRY(hipGetLastError());
+  int err = 0;
+  TRY(d2h(ctx, &err, ctx->cl_err.p, sizeof(int)));
+  TRY(sync_stream(ctx));
+  if (err == 1)
+    return ctx->fail(-3, "a sample index is outside the clipped cloud");
+  if (err == 2)
+    return ctx->fail(-3, "a beam point names an origin that was not given");
+  ctx->sp_n_samp[0] = n_s;
+  ctx->sp_n_samp[1] = n_b;
+  if (n_b > ctx->pow_table_len)
+    ctx->pow_table_dirty = true;
+  if (n_s != ctx->n_s || n_b != ctx->n_b || n_o != ctx->n_o || !ctx->has_scan)
+    ++ctx->generation;
+  ctx->n_s = n_s;
+  ctx->n_b = n_b;
+  ctx->n_o = n_o;
+  ctx->has_scan = true;
+  return 0;
+}
+
+int mcl3dl_hip_scan_download(mcl3dl_hip_ctx* ctx, int which, float* xyz, uint32_t* label, size_t capacity, size_t* n)
+{
+  if (!ctx)
+    return -1;
+  if (!ctx->sp_ready)
+    return ctx->fail(-5, "no prepared scan");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const float4* src = nullptr;
+  size_t cnt = 0;
+  switch (which)
+  {
+    case 0: src = ctx->sp_full.as<float4>(); cnt = ctx->sp_n_full; break;
+    case 1: src = ctx->sp_clip[0].as<float4>(); cnt = ctx->sp_n_clip[0]; break;
+    case 2: src = ctx->sp_clip[1].as<float4>(); cnt = ctx->sp_n_clip[1]; break;
+    case 3: src = ctx->sp_samp[0].as<float4>(); cnt = ctx->sp_n_samp[0]; break;
+    case 4: src = ctx->sp_samp[1].as<float4>(); cnt = ctx->sp_n_samp[1]; break;
+    default: return ctx->fail(-3, "which must be 0..4");
+  }
+  if (n)
+    *n = cnt;
+  if (!xyz)
+    return 0;
+  if (capacity < cnt)
+    return ctx->fail(-3, "capacity %zu < %zu points", capacity, cnt);
+  return download_cloud(ctx, src, cnt, xyz, label);
+}
+
+// ---- §8f-4: the map from the wire format, map updates, matched / unmatched output ------------------------------------
+namespace
+{
+// device cloud (n points) -> the context's host copy of the map, appended behind `keep` existing points
+int map_from_device(mcl3dl_hip_ctx* ctx, const float4* src, size_t n, size_t keep)
+{
+  std::vector<float> xyz(3 * n);
+  std::vector<uint32_t> lab(n);
+  TRY(download_cloud(ctx, src, n, xyz.data(), lab.data()));
+  ctx->map_xyz.resize(3 * keep);
+  ctx->map_label.resize(keep);
+  ctx->map_xyz.insert(ctx->map_xyz.end(), xyz.begin(), xyz.end());
+  ctx->map_label.insert(ctx->map_label.end(), lab.begin(), lab.end());
+  return 0;
+}
+
+int install_base_map(mcl3dl_hip_ctx* ctx, size_t n_in, const float* leaf3, uint64_t stamp, const float* dist_weight,
+                     size_t* n_map)
+{
+  size_t n_out = 0;
+  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n_in, leaf3, ctx->sp_full, &n_out));
+  if (n_out == 0)
+    return ctx->fail(-3, "empty map");
+  if (n_out > 0xfffffff0u)
+    return ctx->fail(-3, "map too large (index must fit 32 bits)");
+  TRY(map_from_device(ctx, ctx->sp_full.as<float4>(), n_out, 0));
+  ++ctx->generation;
+  ctx->stamp = stamp;
+  ctx->has_weight = dist_weight != nullptr;
+  for (int a = 0; a < 3; ++a)
+    ctx->weight[a] = dist_weight ? dist_weight[a] : 1.0f;
+  ctx->has_map = true;
+  ctx->lik_dirty = ctx->cand_dirty = ctx->dda_dirty = true;
+  ctx->n_base = n_out;
+  ctx->sp_ready = false;  // sp_full was borrowed
+  if (n_map)
+    *n_map = n_out;
+  return 0;
+}
+
+int install_map_update(mcl3dl_hip_ctx* ctx, size_t n_in, const float* leaf3, uint64_t stamp, size_t* n_map, double* stats5)
+{
+  if (!ctx->has_map)
+    return ctx->fail(-5, "no map: call mcl3dl_hip_set_map first");
+  const size_t n_base = ctx->n_base ? ctx->n_base : ctx->map_xyz.size() / 3;
+  // the update that is being replaced, rescaled like the index holds it
+  std::vector<float4> old_update;
+  const size_t n_old_total = ctx->map_xyz.size() / 3;
+  TRY(rescaled_points(ctx, n_base, n_old_total - n_base, old_update, nullptr, nullptr));
+  size_t n_out = 0;
+  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n_in, leaf3, ctx->sp_full, &n_out));
+  ctx->sp_ready = false;
+  if (n_base + n_out > 0xfffffff0u)
+    return ctx->fail(-3, "map too large (index must fit 32 bits)");
+  TRY(map_from_device(ctx, ctx->sp_full.as<float4>(), n_out, n_base));  // pc_map2 = pc_map + pc_update
+  ++ctx->generation;
+  ctx->n_base = n_base;
+  ctx->stamp = stamp;
+  ctx->lik_dirty = ctx->dda_dirty = true;  // cell grid and DDA grid are rebuilt on next use (they are linear-time builds)
+  TRY(update_cand_grid(ctx, n_base, old_update, stats5));
+  if (n_map)
+    *n_map = n_base + n_out;
+  return 0;
+}
+}  // namespace
+
+int mcl3dl_hip_set_map_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step, int off_x,
+                                   int off_y, int off_z, int off_label, const float* leaf3, uint64_t stamp,
+                                   const float* dist_weight, size_t* n_map)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(decode_cloud(ctx, data, n_points, point_step, off_x, off_y, off_z, off_label, ctx->sp_raw));
+  return install_base_map(ctx, n_points, leaf3, stamp, dist_weight, n_map);
+}
+
+int mcl3dl_hip_set_map_downsampled(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n,
+                                   const float* leaf3, uint64_t stamp, const float* dist_weight, size_t* n_map)
+{
+  if (!ctx)
+    return -1;
+  if (!xyz || n == 0)
+    return ctx->fail(-3, "empty map");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(upload_cloud(ctx, xyz, label, n, ctx->sp_raw));
+  return install_base_map(ctx, n, leaf3, stamp, dist_weight, n_map);
+}
+
+int mcl3dl_hip_map_update(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, const float* leaf3,
+                          uint64_t stamp, size_t* n_map, double* stats5)
+{
+  if (!ctx)
+    return -1;
+  if (n && !xyz)
+    return ctx->fail(-3, "null cloud");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(upload_cloud(ctx, xyz, label, n, ctx->sp_raw));
+  return install_map_update(ctx, n, leaf3, stamp, n_map, stats5);
+}
+
+int mcl3dl_hip_map_update_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
+                                      int off_x, int off_y, int off_z, int off_label, const float* leaf3, uint64_t stamp,
+                                      size_t* n_map, double* stats5)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(decode_cloud(ctx, data, n_points, point_step, off_x, off_y, off_z, off_label, ctx->sp_raw));
+  return install_map_update(ctx, n_points, leaf3, stamp, n_map, stats5);
+}
+
+int mcl3dl_hip_map_download(mcl3dl_hip_ctx* ctx, float* xyz, uint32_t* label, size_t capacity, size_t* n)
+{
+  if (!ctx)
+    return -1;
+  const size_t cnt = ctx->map_xyz.size() / 3;
+  if (n)
+    *n = cnt;
+  if (!xyz)
+    return 0;
+  if (capacity < cnt)
+    return ctx->fail(-3, "capacity %zu < %zu points", capacity, cnt);
+  memcpy(xyz, ctx->map_xyz.data(), sizeof(float) * 3 * cnt);
+  if (label)
+    memcpy(label, ctx->map_label.data(), sizeof(uint32_t) * cnt);
+  return 0;
+}
+
+int mcl3dl_hip_match_split(mcl3dl_hip_ctx* ctx, const float* pose7, const float* xyz, size_t n, float unmatch_dist,
+                           double match_dist, float* out_matched_xyz, size_t cap_matched, size_t* n_matched,
+                           float* out_unmatched_xyz, size_t cap_unmatched, size_t* n_unmatched)
+{
+  if (!ctx)
+    return -1;
+  if (!pose7 || !(unmatch_dist > 0.f))
+    return ctx->fail(-3, "bad arguments to match_split");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const float4* src = nullptr;
+  if (xyz)
+  {
+    TRY(upload_cloud(ctx, xyz, nullptr, n, ctx->sp_raw));
+    src = ctx->sp_raw.as<float4>();
+  }
+  else
+  {
+    if (!ctx->sp_ready)
+      return ctx->fail(-5, "no prepared scan: pass points or call mcl3dl_hip_scan_begin first");
+    src = ctx->sp_full.as<float4>();  // pc_local_full, src/mcl_3dl.cpp:771-772
+    n = ctx->sp_n_full;
+  }
+  if (n_matched)
+    *n_matched = 0;
+  if (n_unmatched)
+    *n_unmatched = 0;
+  if (n == 0)
+    return 0;
+  TRY(ensure_structures(ctx, true, false, true));  // the cell-sorted map
+  const float cell = 1.0f / ctx->lg.inv_cell;
+  const int reach = static_cast<int>(std::ceil(unmatch_dist / cell)) + 1;
+  if (reach > 64)
+    return ctx->fail(-3, "radius %.3g is more than 64 cells of the map index", unmatch_dist);
+  const long long nn = static_cast<long long>(n);
+  TRY(ensure(ctx, ctx->ms_xyz, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->ms_out, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->ms_flag[0], sizeof(uint32_t) * (n + 2)));
+  TRY(ensure(ctx, ctx->ms_flag[1], sizeof(uint32_t) * (n + 2)));
+  TRY(ensure(ctx, ctx->cl_scan_ws, sizeof(uint32_t) * (n / 1023 + 16)));
+  const Quat rot = qnormalized(Quat{ pose7[3], pose7[4], pose7[5], pose7[6] });  // state_6dof.h:217
+  const float r2 = static_cast<float>(static_cast<double>(unmatch_dist) * static_cast<double>(unmatch_dist));
+  const double match_sq = match_dist * match_dist;  // src/mcl_3dl.cpp:778
+  hipLaunchKernelGGL(match_split_kernel, dim3(blocks_for(nn + 1)), dim3(256), 0, ctx->stream, src, nn,
+                     Vec3f{ pose7[0], pose7[1], pose7[2] }, rot, ctx->lg, lik_params(ctx), r2, reach, match_sq,
+                     ctx->ms_xyz.as<float4>(), ctx->ms_flag[0].as<uint32_t>(), ctx->ms_flag[1].as<uint32_t>());
+  size_t counts[2] = { 0, 0 };
+  float* outs[2] = { out_matched_xyz, out_unmatched_xyz };
+  const size_t caps[2] = { cap_matched, cap_unmatched };
+  for (int k = 0; k < 2; ++k)
+  {
+    uint32_t* flag = ctx->ms_flag[k].as<uint32_t>();
+    TRY(device_exclusive_scan_ws(ctx, flag, nn + 1, ctx->cl_scan_ws.as<uint32_t>()));
+    uint32_t cnt = 0;
+    TRY(d2h(ctx, &cnt, flag + nn, sizeof(uint32_t)));
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->ms_xyz.as<float4>(), flag, nn,
+                       ctx->ms_out.as<float4>());
+    TRY(sync_stream(ctx));
+    counts[k] = cnt;
+    if (outs[k])
+    {
+      if (caps[k] < cnt)
+        return ctx->fail(-3, "output capacity %zu < %u points", caps[k], cnt);
+      TRY(download_cloud(ctx, ctx->ms_out.as<float4>(), cnt, outs[k], nullptr));
+    }
+  }
+  if (n_matched)
+    *n_matched = counts[0];
+  if (n_unmatched)
+    *n_unmatched = counts[1];
+  return 0;
+}

@@ -116,6 +116,7 @@ int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* la
   for (int a = 0; a < 3; ++a)
     ctx->weight[a] = dist_weight ? dist_weight[a] : 1.0f;
   ctx->has_map = true;
+  ctx->n_base = n_m;
   ctx->lik_dirty = true;
   ctx->cand_dirty = true;
   ctx->dda_dirty = true;

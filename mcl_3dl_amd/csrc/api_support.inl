@@ -107,16 +107,9 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_group = static_cast<int>(value);
     return 0;
   }
-  if (key == "lik_ilp")
+  if (key == "lik_coop")
   {
-    if (value != 0.0 && value != 1.0)
-      return ctx->fail(-3, "lik_ilp must be 0 or 1");
-    ctx->lik_ilp = static_cast<int>(value);
-    return 0;
-  }
-  if (key == "lik_trim")
-  {
-    ctx->lik_trim = value != 0.0;
+    ctx->lik_coop = value != 0.0;
     return 0;
   }
   if (key == "cand_phase")
@@ -146,8 +139,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_small") *value = ctx->lik_small;
   else if (key == "lik_tiled") *value = ctx->lik_tiled;
   else if (key == "lik_group") *value = ctx->lik_group;
-  else if (key == "lik_ilp") *value = ctx->lik_ilp;
-  else if (key == "lik_trim") *value = ctx->lik_trim;
+  else if (key == "lik_coop") *value = ctx->lik_coop;
   else
     return ctx->fail(-3, "unknown option '%s'", name);
   return 0;

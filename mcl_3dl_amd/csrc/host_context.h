@@ -87,14 +87,19 @@ struct mcl3dl_hip_ctx
   int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
-  int lik_ilp = 0;         // tiled kernel: 1 = two evaluations in flight per lane (batched loads), 0 = one
-  int lik_trim = 0;        // tiled kernel: 1 = VALU-trimmed evaluation (likelihood_kernels.h, same results)
+  int lik_coop = 1;        // tiled kernel: 1 = quad-cooperative record fetch + VALU-trimmed evaluation (same results)
   DevBuf lik_partial_sum, lik_partial_cnt;
   int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
   DevBuf scan_perm, strict_terms;
   double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
+  // kept for map updates (host_map_compilers.h:update_cand_grid): geometry, sizes, every rescaled map point
+  DevBuf cand_all_pts;
+  CompileParams cand_cp{};
+  long long cand_n_table = 0;
+  uint32_t cand_n_bricks = 0, cand_n_ovf = 0, cand_ovf_leaked = 0;
+  size_t cand_n_points = 0;
   CandGrid cg{};
   RecGrid rg{};
   double cand_stats[4] = { 0, 0, 0, 0 };  // bricks, voxels with candidates, candidates, build ms
@@ -114,6 +119,15 @@ struct mcl3dl_hip_ctx
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
       tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset,
       packed;  // 2 + 2N doubles: this rank's record of a device group's all-reduce (host_group.h)
+
+  // point-cloud preparation on the device (api_cloud.inl, cloud_kernels.h)
+  DevBuf sort_tmp, cl_blocks, cl_minmax, cl_key[2], cl_val[2], cl_scan, cl_scan_ws, cl_start, cl_in_xyz, cl_in_label, cl_idx,
+      cl_err;
+  DevBuf sp_raw, sp_full, sp_clip[2], sp_samp[2];   // accumulated cloud, voxel-filtered, clipped (lik / beam), sampled
+  size_t sp_n_full = 0, sp_n_clip[2] = { 0, 0 }, sp_n_samp[2] = { 0, 0 };
+  bool sp_ready = false;
+  size_t n_base = 0;  // points of the base map; anything behind them in map_xyz is the current map update
+  DevBuf ms_xyz, ms_out, ms_flag[2];
 
   // resampling plan
   std::vector<float> rs_keys;        // accumulated probabilities, in particles_dup_ order after std::sort

@@ -238,35 +238,13 @@ struct TempBuf
   }
 };
 
-int build_cand_grid(mcl3dl_hip_ctx* ctx)
+// Geometry of the candidate-voxel grid for a point set with the given bounds (rescaled coordinates).
+int cand_geometry(mcl3dl_hip_ctx* ctx, const float mn[3], const float mx[3], CompileParams* out, long long* n_table_out)
 {
-  const size_t n = ctx->map_xyz.size() / 3;
   const double r = static_cast<double>(ctx->match_dist_min);
   const float e_f = static_cast<float>(r * ctx->cand_voxel_ratio);
   if (!(e_f > 0.f) || !std::isfinite(e_f))
     return ctx->fail(-3, "bad candidate voxel edge");
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  HIP_TRY(hipEventRecord(ev0, ctx->stream));
-  // rescaled points in map order (PointRepresentation::vectorize), w = original index
-  std::vector<float4> sp(n);
-  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
-  for (size_t i = 0; i < n; ++i)
-  {
-    float v[3];
-    for (int a = 0; a < 3; ++a)
-    {
-      v[a] = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
-      if (!std::isfinite(v[a]))
-        return ctx->fail(-3, "map point %zu is not finite", i);
-      if (i == 0 || v[a] < mn[a])
-        mn[a] = v[a];
-      if (i == 0 || v[a] > mx[a])
-        mx[a] = v[a];
-    }
-    sp[i] = make_float4(v[0], v[1], v[2], bits_to_float(static_cast<uint32_t>(i)));
-  }
   CompileParams cp{};
   cp.e = static_cast<double>(e_f);
   cp.inv_e = 1.0f / e_f;
@@ -275,7 +253,6 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   cp.r2_hi = r_hi * r_hi;
   cp.margin = 1e-5 * r * r;
   cp.reach = static_cast<int>(std::floor((r_hi + cp.grow) / cp.e)) + 1;
-  cp.n_points = static_cast<int>(n);
   float o[3];
   int nv[3], nb[3];
   double n_table_d = 1;
@@ -300,15 +277,149 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   cp.nbx = nb[0];
   cp.nby = nb[1];
   cp.nbz = nb[2];
-  const long long n_table = static_cast<long long>(n_table_d);
+  *out = cp;
+  *n_table_out = static_cast<long long>(n_table_d);
+  return 0;
+}
 
-  TempBuf d_pts, d_flag, d_scan, d_d2, d_count, d_pstart, d_prelim, d_bxyz, d_total;
-  HIP_TRY(hipMalloc(&d_pts.p, sizeof(float4) * n));
-  TRY(h2d(ctx, d_pts.p, sp.data(), sizeof(float4) * n));
+// Rescaled map points (PointRepresentation::vectorize) in map order, w = original index; bounds on request.
+int rescaled_points(mcl3dl_hip_ctx* ctx, size_t first, size_t count, std::vector<float4>& sp, float mn[3], float mx[3])
+{
+  sp.resize(count);
+  for (size_t k = 0; k < count; ++k)
+  {
+    const size_t i = first + k;
+    float v[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      v[a] = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
+      if (!std::isfinite(v[a]))
+        return ctx->fail(-3, "map point %zu is not finite", i);
+      if (mn && (k == 0 || v[a] < mn[a]))
+        mn[a] = v[a];
+      if (mx && (k == 0 || v[a] > mx[a]))
+        mx[a] = v[a];
+    }
+    sp[k] = make_float4(v[0], v[1], v[2], bits_to_float(static_cast<uint32_t>(i)));
+  }
+  return 0;
+}
+
+// The compiler proper: for the bricks `table` names (ids 0 .. n_bricks - 1, every other entry -1; bxyz = their brick
+// coordinates) and the points `pts` (cp.n_points of them, device), the candidate set of every voxel: D^2 scatter ->
+// preliminary lists -> domination prune -> 64-byte records into rec_out[n_bricks * 512 * 16 floats] (device) with their
+// overflow records in a fresh allocation (ovf_out, *n_ovf of them). Used for the whole map (build_cand_grid) and for the
+// bricks a map update touches (update_cand_grid).
+struct CompileOutput
+{
+  unsigned long long total = 0, kept = 0;
+  uint32_t n_ovf = 0;
+  // CSR form (lik_index 1): kept counts per voxel stay in d_count, runs in d_pstart / d_prelim
+  TempBuf d_count, d_pstart, d_prelim, d_ovf_data;
+};
+
+int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* pts, const int* table, const int* bxyz,
+                   uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out)
+{
+  const size_t n = static_cast<size_t>(cp.n_points);
+  const long long n_vox = static_cast<long long>(n_bricks) * 512;
+  const int side = 2 * cp.reach + 1;
+  const long long n_threads = static_cast<long long>(n) * side * side * side;
+  const unsigned blocks_t = static_cast<unsigned>((n_threads + 255) / 256);
+  if ((n_threads + 255) / 256 > 0x7fffffffLL)
+    return ctx->fail(-4, "candidate index: too many (point, voxel) pairs");
+  const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
+  TempBuf d_d2, d_total;
+  TempBuf &d_count = out->d_count, &d_pstart = out->d_pstart, &d_prelim = out->d_prelim;
+  HIP_TRY(hipMalloc(&d_d2.p, sizeof(uint32_t) * n_vox));
+  HIP_TRY(hipMalloc(&d_count.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMalloc(&d_pstart.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMalloc(&d_total.p, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(mc_fill_u32, dim3(blocks_v), dim3(256), 0, ctx->stream, static_cast<uint32_t*>(d_d2.p), 0x7f800000u,
+                     n_vox);
+  if (n)
+    hipLaunchKernelGGL(mc_scatter_dmax, dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                       static_cast<uint32_t*>(d_d2.p), n_threads);
+  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  if (n)
+    hipLaunchKernelGGL((mc_prelim<false>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                       static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
+                       static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n_threads);
+  // total preliminary candidates must fit the 32-bit run delimiters
+  unsigned long long total = 0;
+  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+                     n_vox, static_cast<unsigned long long*>(d_total.p));
+  TRY(d2h(ctx, &total, d_total.p, sizeof(total)));
+  TRY(sync_stream(ctx));
+  if (total >= 0xfffffff0ULL)
+    return ctx->fail(-4, "candidate index: %llu preliminary candidates exceed 32-bit offsets", total);
+  HIP_TRY(hipMemcpyAsync(d_pstart.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_pstart.p), n_vox + 1));
+  HIP_TRY(hipMalloc(&d_prelim.p, sizeof(uint32_t) * (total ? total : 1)));
+  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  if (n)
+    hipLaunchKernelGGL((mc_prelim<true>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
+                       static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
+                       static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p), n_threads);
+  // prune; d_count becomes the kept count per voxel
+  hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, bxyz,
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
+                     static_cast<uint32_t*>(d_count.p), n_vox);
+  unsigned long long kept = 0;
+  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+                     n_vox, static_cast<unsigned long long*>(d_total.p));
+  TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
+  TRY(sync_stream(ctx));
+  out->total = total;
+  out->kept = kept;
+  if (!records)
+    return 0;
+  // fat records: overflow slots per voxel -> exclusive scan -> write
+  TempBuf d_ovf;
+  HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
+  HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
+                     static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox);
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
+  uint32_t n_ovf = 0;
+  TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
+  TRY(sync_stream(ctx));
+  HIP_TRY(hipMalloc(&out->d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1)));
+  HIP_TRY(hipMemsetAsync(out->d_ovf_data.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
+  hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
+                     static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
+                     static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p), rec_out,
+                     static_cast<float*>(out->d_ovf_data.p), n_vox);
+  HIP_TRY(hipGetLastError());
+  out->n_ovf = n_ovf;
+  return 0;
+}
+
+int build_cand_grid(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, ctx->stream));
+  std::vector<float4> sp;
+  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+  TRY(rescaled_points(ctx, 0, n, sp, mn, mx));
+  CompileParams cp{};
+  long long n_table = 0;
+  TRY(cand_geometry(ctx, mn, mx, &cp, &n_table));
+  cp.n_points = static_cast<int>(n);
+
+  // the rescaled points stay on the device: a map update (update_cand_grid) re-compiles single bricks from them
+  TempBuf d_flag, d_scan, d_bxyz;
+  TRY(ensure(ctx, ctx->cand_all_pts, sizeof(float4) * n));
+  TRY(h2d(ctx, ctx->cand_all_pts.p, sp.data(), sizeof(float4) * n));
   HIP_TRY(hipMalloc(&d_flag.p, sizeof(int) * n_table));
   HIP_TRY(hipMalloc(&d_scan.p, sizeof(uint32_t) * (n_table + 1)));
   HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(int) * n_table, ctx->stream));
-  const float4* pts = static_cast<const float4*>(d_pts.p);
+  const float4* pts = ctx->cand_all_pts.as<float4>();
   hipLaunchKernelGGL(mc_mark_bricks, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, cp, pts,
                      static_cast<int*>(d_flag.p));
   HIP_TRY(hipMemsetAsync(d_scan.p, 0, sizeof(uint32_t) * (n_table + 1), ctx->stream));
@@ -326,72 +437,26 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   HIP_TRY(hipMalloc(&d_bxyz.p, sizeof(int) * 3 * n_bricks));
   hipLaunchKernelGGL(mc_brick_coords, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
                      table, cp.nbx, cp.nby, n_table, static_cast<int*>(d_bxyz.p));
-
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
-  const int side = 2 * cp.reach + 1;
-  const long long n_threads = static_cast<long long>(n) * side * side * side;
-  const unsigned blocks_t = static_cast<unsigned>((n_threads + 255) / 256);
-  if ((n_threads + 255) / 256 > 0x7fffffffLL)
-    return ctx->fail(-4, "candidate index: too many (point, voxel) pairs");
-  const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
-  HIP_TRY(hipMalloc(&d_d2.p, sizeof(uint32_t) * n_vox));
-  HIP_TRY(hipMalloc(&d_count.p, sizeof(uint32_t) * (n_vox + 1)));
-  HIP_TRY(hipMalloc(&d_pstart.p, sizeof(uint32_t) * (n_vox + 1)));
-  HIP_TRY(hipMalloc(&d_total.p, sizeof(unsigned long long)));
-  hipLaunchKernelGGL(mc_fill_u32, dim3(blocks_v), dim3(256), 0, ctx->stream, static_cast<uint32_t*>(d_d2.p), 0x7f800000u,
-                     n_vox);
-  hipLaunchKernelGGL(mc_scatter_dmax, dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
-                     static_cast<uint32_t*>(d_d2.p), n_threads);
-  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
-  hipLaunchKernelGGL((mc_prelim<false>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
-                     static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
-                     static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n_threads);
-  // total preliminary candidates must fit the 32-bit run delimiters
-  unsigned long long total = 0;
-  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
-                     n_vox, static_cast<unsigned long long*>(d_total.p));
-  TRY(d2h(ctx, &total, d_total.p, sizeof(total)));
-  TRY(sync_stream(ctx));
-  if (total >= 0xfffffff0ULL)
-    return ctx->fail(-4, "candidate index: %llu preliminary candidates exceed 32-bit offsets", total);
-  HIP_TRY(hipMemcpyAsync(d_pstart.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice, ctx->stream));
-  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_pstart.p), n_vox + 1));
-  HIP_TRY(hipMalloc(&d_prelim.p, sizeof(uint32_t) * (total ? total : 1)));
-  HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
-  hipLaunchKernelGGL((mc_prelim<true>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
-                     static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
-                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p), n_threads);
-  // prune; d_count becomes the kept count per voxel
-  hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, static_cast<const int*>(d_bxyz.p),
-                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
-                     static_cast<uint32_t*>(d_count.p), n_vox);
-  unsigned long long kept = 0;
-  HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
-                     n_vox, static_cast<unsigned long long*>(d_total.p));
-  TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
-  TRY(sync_stream(ctx));
-  if (ctx->lik_index == 2)
-  {
-    // fat records: overflow slots per voxel -> exclusive scan -> write
-    TempBuf d_ovf;
-    HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
-    HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
-    hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox);
-    TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
-    uint32_t n_ovf = 0;
-    TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
-    TRY(sync_stream(ctx));
+  const bool records = ctx->lik_index == 2;
+  if (records)
     TRY(ensure(ctx, ctx->cand_rec, 64ull * static_cast<size_t>(n_vox)));
+  CompileOutput co;
+  TRY(compile_bricks(ctx, cp, pts, table, static_cast<const int*>(d_bxyz.p), n_bricks, records,
+                     records ? ctx->cand_rec.as<float>() : nullptr, &co));
+  const unsigned long long total = co.total, kept = co.kept;
+  ctx->cand_cp = cp;
+  ctx->cand_n_table = n_table;
+  ctx->cand_n_bricks = n_bricks;
+  ctx->cand_n_points = n;
+  if (records)
+  {
+    const uint32_t n_ovf = co.n_ovf;
     TRY(ensure(ctx, ctx->cand_ovf, 64ull * (n_ovf ? n_ovf : 1)));
-    HIP_TRY(hipMemsetAsync(ctx->cand_ovf.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
-    hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
-                       static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
-                       static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p),
-                       ctx->cand_rec.as<float>(), ctx->cand_ovf.as<float>(), n_vox);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->cand_ovf.p, co.d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1), hipMemcpyDeviceToDevice,
+                           ctx->stream));
+    ctx->cand_n_ovf = n_ovf;
+    ctx->cand_ovf_leaked = 0;
     HIP_TRY(hipEventRecord(ev1, ctx->stream));
     TRY(sync_stream(ctx));
     float ms2 = 0.f;
@@ -423,6 +488,8 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     ctx->cand_dirty = false;
     return 0;
   }
+  TempBuf &d_count = co.d_count, &d_pstart = co.d_pstart, &d_prelim = co.d_prelim;
+  const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
   TRY(ensure(ctx, ctx->cand_start, sizeof(uint32_t) * (n_vox + 1)));
   TRY(ensure(ctx, ctx->cand_pts, sizeof(float4) * (kept ? kept : 1)));
   HIP_TRY(hipMemsetAsync(static_cast<uint32_t*>(d_count.p) + n_vox, 0, sizeof(uint32_t), ctx->stream));
@@ -461,6 +528,187 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   ctx->cand_stats[2] = static_cast<double>(kept);
   ctx->cand_stats[3] = ms;
   ctx->cand_dirty = false;
+  return 0;
+}
+
+// grow a context buffer KEEPING its content (ensure() drops it)
+int ensure_keep(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t keep_bytes, size_t bytes)
+{
+  if (b.cap >= bytes)
+    return 0;
+  void* old = b.p;
+  const size_t cap = bytes + bytes / 2;
+  void* fresh = nullptr;
+  HIP_TRY(hipMalloc(&fresh, cap));
+  if (old && keep_bytes)
+    HIP_TRY(hipMemcpyAsync(fresh, old, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(sync_stream(ctx));
+  if (old)
+    HIP_TRY(hipFree(old));
+  b.p = fresh;
+  b.cap = cap;
+  ++ctx->generation;
+  return 0;
+}
+
+// The map changed from (base + old update) to (base + new update) — mapcloud_update, src/mcl_3dl.cpp:141-153,1355-1362:
+// pc_map2 = pc_map + pc_update. Only voxels within reach of a removed or an added point can change their candidate set,
+// so only the bricks holding such voxels are compiled again, from the points that can reach them, and installed over
+// their old records (new bricks are appended). A brick's new records equal what a whole-map compile would write for it:
+// same candidate sets, same ascending map order. Falls back to a full rebuild (cand_dirty) when nothing is built yet,
+// when a point falls outside the grid the index was laid out for, or when the index is not in record form.
+// ctx->map_xyz already holds base + new update; old_update = the rescaled points that were removed (host).
+int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float4>& old_update, double* stats5)
+{
+  const size_t n_total = ctx->map_xyz.size() / 3;
+  if (stats5)
+    for (int i = 0; i < 5; ++i)
+      stats5[i] = 0;
+  if (ctx->cand_dirty || ctx->lik_index != 2 || ctx->cand_n_points != n_base + old_update.size())
+  {
+    ctx->cand_dirty = true;
+    return 0;
+  }
+  CompileParams cp = ctx->cand_cp;
+  const long long n_table = ctx->cand_n_table;
+  std::vector<float4> fresh;
+  TRY(rescaled_points(ctx, n_base, n_total - n_base, fresh, nullptr, nullptr));
+  // every added point, with its reach, must lie inside the grid the index was laid out for
+  for (const float4& p : fresh)
+  {
+    const int v[3] = { static_cast<int>(floorf((p.x - cp.ox) * cp.inv_e)), static_cast<int>(floorf((p.y - cp.oy) * cp.inv_e)),
+                       static_cast<int>(floorf((p.z - cp.oz) * cp.inv_e)) };
+    const int nv[3] = { cp.nvx, cp.nvy, cp.nvz };
+    for (int a = 0; a < 3; ++a)
+      if (v[a] - cp.reach - 1 < 0 || v[a] + cp.reach + 1 >= nv[a])
+      {
+        ctx->cand_dirty = true;
+        return 0;
+      }
+  }
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, ctx->stream));
+  // 1. dirty bricks: within reach of a removed or an added point
+  TempBuf d_dirty, d_old, d_newflag, d_dirtyrank, d_sub_table, d_sub_main, d_sub_bxyz, d_relflag, d_rel, d_subrec;
+  HIP_TRY(hipMalloc(&d_dirty.p, sizeof(int) * n_table));
+  HIP_TRY(hipMemsetAsync(d_dirty.p, 0, sizeof(int) * n_table, ctx->stream));
+  if (!old_update.empty())
+  {
+    HIP_TRY(hipMalloc(&d_old.p, sizeof(float4) * old_update.size()));
+    TRY(h2d(ctx, d_old.p, old_update.data(), sizeof(float4) * old_update.size()));
+    CompileParams c2 = cp;
+    c2.n_points = static_cast<int>(old_update.size());
+    hipLaunchKernelGGL(mc_mark_bricks, dim3(static_cast<unsigned>((old_update.size() + 255) / 256)), dim3(256), 0,
+                       ctx->stream, c2, static_cast<const float4*>(d_old.p), static_cast<int*>(d_dirty.p));
+  }
+  TRY(ensure_keep(ctx, ctx->cand_all_pts, sizeof(float4) * n_base, sizeof(float4) * n_total));
+  if (!fresh.empty())
+  {
+    float4* dst = ctx->cand_all_pts.as<float4>() + n_base;
+    TRY(h2d(ctx, dst, fresh.data(), sizeof(float4) * fresh.size()));
+    CompileParams c2 = cp;
+    c2.n_points = static_cast<int>(fresh.size());
+    hipLaunchKernelGGL(mc_mark_bricks, dim3(static_cast<unsigned>((fresh.size() + 255) / 256)), dim3(256), 0, ctx->stream,
+                       c2, static_cast<const float4*>(dst), static_cast<int*>(d_dirty.p));
+  }
+  // 2. ids: new bricks are appended; dense sub ids for the dirty ones
+  const unsigned blocks_tab = static_cast<unsigned>((n_table + 1 + 255) / 256);
+  HIP_TRY(hipMalloc(&d_newflag.p, sizeof(uint32_t) * (n_table + 1)));
+  HIP_TRY(hipMalloc(&d_dirtyrank.p, sizeof(uint32_t) * (n_table + 1)));
+  hipLaunchKernelGGL(mc_new_brick_flags, dim3(blocks_tab), dim3(256), 0, ctx->stream, static_cast<const int*>(d_dirty.p),
+                     ctx->cand_table.as<int>(), static_cast<uint32_t*>(d_newflag.p), n_table);
+  HIP_TRY(hipMemsetAsync(d_dirtyrank.p, 0, sizeof(uint32_t) * (n_table + 1), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_dirtyrank.p, d_dirty.p, sizeof(int) * n_table, hipMemcpyDeviceToDevice, ctx->stream));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_newflag.p), n_table + 1));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_dirtyrank.p), n_table + 1));
+  uint32_t n_new = 0, n_dirty = 0;
+  TRY(d2h(ctx, &n_new, static_cast<uint32_t*>(d_newflag.p) + n_table, sizeof(uint32_t)));
+  TRY(d2h(ctx, &n_dirty, static_cast<uint32_t*>(d_dirtyrank.p) + n_table, sizeof(uint32_t)));
+  TRY(sync_stream(ctx));
+  const uint32_t n_bricks_old = ctx->cand_n_bricks;
+  if (n_dirty == 0)
+  {
+    ctx->cand_n_points = n_total;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return 0;
+  }
+  if (static_cast<unsigned long long>(n_bricks_old) + n_new > (1u << 22) ||
+      ctx->cand_ovf_leaked > std::max<uint32_t>(4096u, ctx->cand_n_ovf / 2))
+  {
+    ctx->cand_dirty = true;  // too many bricks, or too many orphaned overflow records: start over
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return 0;
+  }
+  const uint32_t n_bricks = n_bricks_old + n_new;
+  TRY(ensure_keep(ctx, ctx->cand_rec, 64ull * 512 * n_bricks_old, 64ull * 512 * n_bricks));
+  HIP_TRY(hipMalloc(&d_sub_table.p, sizeof(int) * n_table));
+  HIP_TRY(hipMalloc(&d_sub_main.p, sizeof(int) * n_dirty));
+  HIP_TRY(hipMalloc(&d_sub_bxyz.p, sizeof(int) * 3 * n_dirty));
+  hipLaunchKernelGGL(mc_dirty_tables, dim3(blocks_tab), dim3(256), 0, ctx->stream, static_cast<const int*>(d_dirty.p),
+                     static_cast<const uint32_t*>(d_newflag.p), static_cast<const uint32_t*>(d_dirtyrank.p), n_bricks_old,
+                     cp.nbx, cp.nby, n_table, ctx->cand_table.as<int>(), static_cast<int*>(d_sub_table.p),
+                     static_cast<int*>(d_sub_main.p), static_cast<int*>(d_sub_bxyz.p));
+  // 3. the points that can reach a dirty brick, in map order
+  cp.n_points = static_cast<int>(n_total);
+  HIP_TRY(hipMalloc(&d_relflag.p, sizeof(uint32_t) * (n_total + 1)));
+  hipLaunchKernelGGL(mc_relevant_points, dim3(static_cast<unsigned>((n_total + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     cp, ctx->cand_all_pts.as<float4>(), static_cast<const int*>(d_dirty.p),
+                     static_cast<uint32_t*>(d_relflag.p));
+  TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_relflag.p), static_cast<long long>(n_total) + 1));
+  uint32_t n_rel = 0;
+  TRY(d2h(ctx, &n_rel, static_cast<uint32_t*>(d_relflag.p) + n_total, sizeof(uint32_t)));
+  TRY(sync_stream(ctx));
+  HIP_TRY(hipMalloc(&d_rel.p, sizeof(float4) * (n_rel ? n_rel : 1)));
+  hipLaunchKernelGGL(mc_compact_points, dim3(static_cast<unsigned>((n_total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->cand_all_pts.as<float4>(), static_cast<const uint32_t*>(d_relflag.p), static_cast<int>(n_total),
+                     static_cast<float4*>(d_rel.p));
+  // 4. compile the dirty bricks and install them
+  const long long n_sub_vox = static_cast<long long>(n_dirty) * 512;
+  HIP_TRY(hipMalloc(&d_subrec.p, 64ull * static_cast<size_t>(n_sub_vox)));
+  cp.n_points = static_cast<int>(n_rel);
+  CompileOutput co;
+  TRY(compile_bricks(ctx, cp, static_cast<const float4*>(d_rel.p), static_cast<const int*>(d_sub_table.p),
+                     static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co));
+  const uint32_t ovf_base = ctx->cand_n_ovf;
+  if (co.n_ovf)
+  {
+    TRY(ensure_keep(ctx, ctx->cand_ovf, 64ull * ovf_base, 64ull * (static_cast<size_t>(ovf_base) + co.n_ovf)));
+    HIP_TRY(hipMemcpyAsync(ctx->cand_ovf.as<char>() + 64ull * ovf_base, co.d_ovf_data.p, 64ull * co.n_ovf,
+                           hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  hipLaunchKernelGGL(mc_install_records, dim3(static_cast<unsigned>((n_sub_vox + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_sub_vox,
+                     ctx->cand_rec.as<float4>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev1, ctx->stream));
+  TRY(sync_stream(ctx));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  ctx->cand_n_bricks = n_bricks;
+  ctx->cand_n_ovf = ovf_base + co.n_ovf;
+  ctx->cand_ovf_leaked += co.n_ovf;  // upper bound of what the replaced bricks orphaned: they had about as many
+  ctx->cand_n_points = n_total;
+  ctx->rg.brick_table = ctx->cand_table.as<int>();
+  ctx->rg.rec = ctx->cand_rec.as<float4>();
+  ctx->rg.ovf = ctx->cand_ovf.as<float4>();
+  ctx->footprint[6] = 64ull * 512 * n_bricks;
+  ctx->footprint[7] = 64ull * ctx->cand_n_ovf;
+  ctx->cand_stats[0] = n_bricks;
+  ++ctx->generation;
+  if (stats5)
+  {
+    stats5[0] = n_dirty;
+    stats5[1] = n_new;
+    stats5[2] = n_rel;
+    stats5[3] = ms;
+    stats5[4] = co.n_ovf;
+  }
   return 0;
 }
 

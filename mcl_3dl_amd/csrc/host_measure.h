@@ -252,13 +252,15 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       {
         hipLaunchKernelGGL((likelihood_kernel<256, 0, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
                            ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, ctx->rg, lp, nullptr, nullptr,
-                           ctx->tested.as<double>());
+                           ctx->tested.as<double>(), 0);
       }
       else
       {
         TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
         const float4* scan = ctx->scan_lik.as<float4>();
         const bool tiled = plan.tiled, small = plan.small;
+        // the cooperative form's sqrt needs match_dist_min > 1.2e-7 m (likelihood_kernels.h:sqrt_in_radius)
+        const int coop_arg = (ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f) ? 1 : 0;
         const int group_size = plan.group_size;
         float* strict_terms = plan.strict_terms;
         if (small)
@@ -267,7 +269,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const long long blocks = plan.blocks;
 #define LAUNCH_SMALL(WW, MODE)                                                                                         \
   hipLaunchKernelGGL((likelihood_small_kernel<WW, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
-                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio)
+                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, coop_arg)
 #define LAUNCH_SMALL_W(MODE)       \
   switch (W)                       \
   {                                \
@@ -298,62 +300,40 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const int G = group_size;
           const int n_tiles = plan.n_tiles, n_groups = plan.n_groups;
           const long long blocks = plan.blocks;
-#define LAUNCH_TILED(GG, MODE)                                                                                         \
-  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
+#define LAUNCH_TILED(GG, MODE, WW, CC)                                                                                 \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,   \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
-#define LAUNCH_TILED_W(GG, MODE, WW)                                                                                   \
-  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, 1, WW>), dim3(static_cast<unsigned>(blocks)), dim3(256), \
-                     0, ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,           \
-                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
-                     ctx->scan_perm.as<uint32_t>(), strict_terms)
-#define LAUNCH_TILED_ILP(GG, UU, WW, TT)                                                                               \
-  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, 2, UU, WW, TT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,  \
-                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
-                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
-                     ctx->scan_perm.as<uint32_t>(), strict_terms)
-#define LAUNCH_TILED_G(GG)      \
-  do                            \
-  {                             \
-    if (ctx->lik_index == 2)    \
-    {                           \
-      switch (2 * (ctx->lik_ilp ? 1 : 0) + ((ctx->lik_trim && ctx->match_dist_min > 1e-5f) ? 1 : 0)) \
-      {                         \
-        case 1: LAUNCH_TILED_ILP(GG, 1, 8, true); break;  \
-        case 2: LAUNCH_TILED_ILP(GG, 2, 8, false); break; \
-        case 3: LAUNCH_TILED_ILP(GG, 2, 8, true); break;  \
-        default: LAUNCH_TILED_ILP(GG, 1, 8, false); break; \
-      }                         \
-    }                           \
-    else if (ctx->lik_index == 1) \
-      LAUNCH_TILED(GG, 1);      \
-    else                        \
-      LAUNCH_TILED(GG, 0);      \
+          const bool coop = coop_arg != 0;
+#define LAUNCH_TILED_G(GG, WW)         \
+  do                                   \
+  {                                    \
+    if (coop)                          \
+      LAUNCH_TILED(GG, 2, WW, true);   \
+    else if (ctx->lik_index == 2)      \
+      LAUNCH_TILED(GG, 2, WW, false);  \
+    else if (ctx->lik_index == 1)      \
+      LAUNCH_TILED(GG, 1, WW, false);  \
+    else                               \
+      LAUNCH_TILED(GG, 0, WW, false);  \
   } while (0)
           switch (G)
           {
             case 4:
-              LAUNCH_TILED_G(4);
+              LAUNCH_TILED_G(4, 8);
               break;
             case 8:
-              LAUNCH_TILED_G(8);
+              LAUNCH_TILED_G(8, 8);
               break;
             case 32:
-              if (ctx->lik_index == 2)
-                LAUNCH_TILED_ILP(32, 1, 4, false);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
-              else if (ctx->lik_index == 1)
-                LAUNCH_TILED_W(32, 1, 4);
-              else
-                LAUNCH_TILED_W(32, 0, 4);
+              LAUNCH_TILED_G(32, 4);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
               break;
             default:
-              LAUNCH_TILED_G(16);
+              LAUNCH_TILED_G(16, 8);
               break;
           }
 #undef LAUNCH_TILED_G
-#undef LAUNCH_TILED_ILP
-#undef LAUNCH_TILED_W
 #undef LAUNCH_TILED
           hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
@@ -384,7 +364,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         {
 #define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
   hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), 0, ctx->stream, d_pose, scan, ns, \
-                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr)
+                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg)
         if (ctx->lik_index == 2)
         {
           if (ns <= 128)

@@ -5,7 +5,9 @@
 //   beam_kernels.h        beam model: one lane per ray, DDA walk through 4x4x4 occupancy bricks, point tests, penalty count
 //   pf_kernels.h          pf::measure (weights, deterministic fp64 reductions, normalisation, entropy) and the "next" rows
 //                         (expectation / max / covariance, resampling)
-//   map_compiler.h        device-side compiler of the candidate-voxel index
+//   map_compiler.h        device-side compiler of the candidate-voxel index (whole map, or the bricks a map update touches)
+//   cloud_kernels.h       scan / map preparation: PointCloud2 decode, VoxelGrid, clip + compaction, sampling gather, scan
+//                         ordering, matched / unmatched output
 //
 // These are gather / traversal kernels (bound by L2/HBM reads and the texture-addresser, not by MFMA):
 // there is no dense contraction anywhere on this path, so no matrix-core code.
@@ -14,3 +16,4 @@
 #include "likelihood_kernels.h"
 #include "beam_kernels.h"
 #include "pf_kernels.h"
+#include "cloud_kernels.h"

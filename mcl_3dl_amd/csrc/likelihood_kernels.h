@@ -152,137 +152,93 @@ __global__ void radius_search_kernel(const float* __restrict__ query_xyz, int n,
     out_sqdist[i] = best_idx >= 0 ? best : -1.0f;
 }
 
-// MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates (overflow runs for
-// voxels with more than 5).
+// MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates. Record layout
+// (map_compiler.h:mc_write_records), four 16-byte parts:
+//     part j = { candidate j: x, y, z ; w }      w of part 0 = candidate count, w of part 1 = first overflow record
+// candidates 0..3 inline (unused slots hold REC_SENTINEL coordinates: their d2 never wins a minimum and never passes the
+// radius test), candidates 4.. in overflow records {xyz[5], pad}. One part per lane of a quad is what the tiled kernel's
+// cooperative fetch reads (below).
 
-template <bool STATS>
-__device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+// floor to int in ONE instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for
+// __float2int_rd). Same value for every input: saturating, NaN -> 0.
+__device__ inline int floor_to_int(float x)
 {
-  // voxel of the query: floor to int in one conversion, range check as unsigned compares (a non-finite coordinate
-  // saturates to a voxel outside the grid, or for NaN lands in voxel 0 and yields a NaN distance: no match either way)
-  const int vx = __float2int_rd((qx - g.ox) * g.inv_e);
-  const int vy = __float2int_rd((qy - g.oy) * g.inv_e);
-  const int vz = __float2int_rd((qz - g.oz) * g.inv_e);
-  float best = 3.0e38f;
-  if (!(static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
-        static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz)))
-    return best;
-  // 32-bit index arithmetic (the dense brick table has < 2^31 entries, there are <= 2^22 bricks: build_cand_grid) with
-  // 24-bit multiplies — full rate, where a 32-bit integer multiply is a quarter-rate instruction. row_stride = nbx,
-  // slab_stride = nbx * nby; build_cand_grid sets mul24_ok only when every factor is below 2^24.
-  uint32_t ti;
-  if (g.mul24_ok)
-    ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
-         __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
-  else
-    ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
-             static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
-  const int b = g.brick_table[ti];
-  if (b < 0)
-    return best;
-  const uint32_t v = (static_cast<uint32_t>(b) << 9) | static_cast<uint32_t>(((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
-  const float4* r = g.rec + 4 * static_cast<size_t>(v);
-  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-  const uint32_t count = __float_as_uint(r0.x);
-  if (count == 0)
-    return best;
-  if (STATS)
-    n_tested += count;
-  if (count <= 5)
-  {
-    float d;
-    d = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
-    best = d;
-    d = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
-    best = (count > 1 && d < best) ? d : best;
-    d = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
-    best = (count > 2 && d < best) ? d : best;
-    d = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
-    best = (count > 3 && d < best) ? d : best;
-    d = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
-    best = (count > 4 && d < best) ? d : best;
-    return best;
-  }
-  float d;
-  d = d2_simple(qx, qy, qz, r0.z, r0.w, r1.x);
-  best = d;
-  d = d2_simple(qx, qy, qz, r1.y, r1.z, r1.w);
-  best = d < best ? d : best;
-  d = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
-  best = d < best ? d : best;
-  d = d2_simple(qx, qy, qz, r2.w, r3.x, r3.y);
-  best = d < best ? d : best;
-  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(__float_as_uint(r0.y));
-  for (uint32_t j = 0; j < count - 4; ++j)
-  {
-    const float* s = o + 16 * (j / 5) + 3 * (j % 5);
-    d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
-    best = d < best ? d : best;
-  }
-  return best;
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
-// nearest_d2_rec split into its three dependent steps so that a caller can keep several evaluations in flight per lane
-// (likelihood_tiled_kernel, U > 1): all brick-table loads are issued first, then all record loads, then the arithmetic.
-// Same arithmetic, same results as nearest_d2_rec.
-// step 1: voxel of the query -> brick-table index and the voxel's slot inside its brick; false = outside the grid
+// step 1 of a lookup: voxel of the query -> brick-table index and the voxel's slot inside its brick; false = outside
+// the grid (a non-finite coordinate saturates to a voxel outside the grid, or for NaN lands in voxel 0 and yields NaN
+// distances: no match either way). 32-bit index arithmetic (the dense brick table has < 2^31 entries, there are <= 2^22
+// bricks: build_cand_grid) with 24-bit multiplies where build_cand_grid found every factor below 2^24.
 __device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz, uint32_t& ti, uint32_t& sub)
 {
-  const int vx = __float2int_rd((qx - g.ox) * g.inv_e);
-  const int vy = __float2int_rd((qy - g.oy) * g.inv_e);
-  const int vz = __float2int_rd((qz - g.oz) * g.inv_e);
+  const int vx = floor_to_int((qx - g.ox) * g.inv_e);
+  const int vy = floor_to_int((qy - g.oy) * g.inv_e);
+  const int vz = floor_to_int((qz - g.oz) * g.inv_e);
   if (g.mul24_ok)
     ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
          __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
   else
     ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
              static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
-  sub = static_cast<uint32_t>(((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
+  sub = ((((static_cast<uint32_t>(vz) & 7u) << 3) | (static_cast<uint32_t>(vy) & 7u)) << 3) | (static_cast<uint32_t>(vx) & 7u);
   return static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
          static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
 }
 
-// step 3: min d2 over the candidates of a loaded record (count > 0)
-__device__ inline float rec_min_d2(const RecGrid& g, float qx, float qy, float qz, const float4 r0, const float4 r1,
-                                   const float4 r2, const float4 r3)
+// min d2 over the candidates a voxel's overflow records hold (candidates 4 .. count - 1)
+__device__ inline float rec_overflow_min(const RecGrid& g, float qx, float qy, float qz, uint32_t count, uint32_t ext,
+                                         float best)
 {
-  const uint32_t count = __float_as_uint(r0.x);
-  float best, d;
-  if (count <= 5)
-  {
-    d = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
-    best = d;
-    d = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
-    best = (count > 1 && d < best) ? d : best;
-    d = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
-    best = (count > 2 && d < best) ? d : best;
-    d = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
-    best = (count > 3 && d < best) ? d : best;
-    d = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
-    best = (count > 4 && d < best) ? d : best;
-    return best;
-  }
-  d = d2_simple(qx, qy, qz, r0.z, r0.w, r1.x);
-  best = d;
-  d = d2_simple(qx, qy, qz, r1.y, r1.z, r1.w);
-  best = d < best ? d : best;
-  d = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
-  best = d < best ? d : best;
-  d = d2_simple(qx, qy, qz, r2.w, r3.x, r3.y);
-  best = d < best ? d : best;
-  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(__float_as_uint(r0.y));
+  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(ext);
   for (uint32_t j = 0; j < count - 4; ++j)
   {
     const float* s = o + 16 * (j / 5) + 3 * (j % 5);
-    d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
+    const float d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
     best = d < best ? d : best;
   }
   return best;
 }
 
-// ---- VALU-trimmed forms (the tiled kernel is bound by VALU issue, not by memory: profiles/r02a_valu_microbench.txt
-// prices a wave64 v_mul/v_add_f32 at ~2.3 cycles on a SIMD and almost everything else — v_max, v_cndmask, v_cvt, integer
-// multiplies, packed f32 pairs, every f64 op — at ~4.3). Same results, fewer and cheaper instructions.
+// step 3 of a lookup: min d2 over the candidates of a loaded record
+__device__ inline float rec_min_d2(const RecGrid& g, float qx, float qy, float qz, const float4 r0, const float4 r1,
+                                   const float4 r2, const float4 r3)
+{
+  const float d0 = d2_simple(qx, qy, qz, r0.x, r0.y, r0.z);
+  const float d1 = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
+  const float d2 = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
+  const float d3 = d2_simple(qx, qy, qz, r3.x, r3.y, r3.z);
+  float best = fminf(fminf(d0, d1), fminf(d2, d3));
+  const uint32_t count = __float_as_uint(r0.w);
+  if (count > 4)
+    best = rec_overflow_min(g, qx, qy, qz, count, __float_as_uint(r1.w), best);
+  return best;
+}
+
+template <bool STATS>
+__device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)
+{
+  float best = 3.0e38f;
+  uint32_t ti, sub;
+  if (!rec_locate(g, qx, qy, qz, ti, sub))
+    return best;
+  const int b = g.brick_table[ti];
+  if (b < 0)
+    return best;
+  const float4* r = g.rec + 4 * static_cast<size_t>((static_cast<uint32_t>(b) << 9) | sub);
+  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  const uint32_t count = __float_as_uint(r0.w);
+  if (count == 0)
+    return best;
+  if (STATS)
+    n_tested += count;
+  return rec_min_d2(g, qx, qy, qz, r0, r1, r2, r3);
+}
+
+// ---- VALU-trimmed forms (profiles/r02b_valu_microbench.txt prices a wave64 v_mul/v_add_f32 at ~2.4 cycles on a SIMD and
+// almost everything else — v_max, v_cndmask, v_cvt, integer multiplies, packed f32 pairs, every f64 op — at ~4.3).
 
 // Quat::operator*(Vec3) (quat.h:139-143) = (q (x) (v,0)) (x) conj(q) with the reference's term order, minus the four
 // products with the vector's zero w component. Dropping them changes nothing observable: for finite q the product is
@@ -304,48 +260,65 @@ __device__ inline Vec3f qrot_trim(const Quat q, const Vec3f v)
   return t;
 }
 
-// floor to int in ONE instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for
-// __float2int_rd). Same value for every input: saturating, NaN -> 0.
-__device__ inline int floor_to_int(float x)
+// ---- quad-cooperative record fetch --------------------------------------------------------------------------------
+// What binds the tiled kernel is the L1's access rate (profiles/r02b_C2_pmc_summary.csv: ~1.1 cache-line accesses per
+// cycle and CU, flat against -15 % VALU instructions and against twice the loads in flight per lane): a wave64 16-byte
+// load whose lanes all name different records is 64 accesses, and each lane needs four of them per record. Here the four
+// lanes of a quad fetch a record together — lane j reads part j of the records of lanes 0..3 of its quad, so one load
+// instruction covers 16 whole records in 16 accesses instead of 64 — and compute together: lane j owns candidate j of
+// each of the quad's four evaluations (the query travels by DPP), then a 4 x 4 transpose-min over the quad hands every
+// lane the minimum for its own query. Same candidates, same d2 expression, and a minimum does not care about order:
+// results identical to rec_min_d2.
+template <int CTRL>
+__device__ inline float quad_f(float v)
 {
-  int r;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-
-// rec_locate with the single-instruction floor and the brick-local index built from shift-or pairs
-__device__ inline bool rec_locate_trim(const RecGrid& g, float qx, float qy, float qz, uint32_t& ti, uint32_t& sub)
+template <int CTRL>
+__device__ inline uint32_t quad_u(uint32_t v)
 {
-  const int vx = floor_to_int((qx - g.ox) * g.inv_e);
-  const int vy = floor_to_int((qy - g.oy) * g.inv_e);
-  const int vz = floor_to_int((qz - g.oz) * g.inv_e);
-  if (g.mul24_ok)
-    ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
-         __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
-  else
-    ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
-             static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
-  sub = ((((static_cast<uint32_t>(vz) & 7u) << 3) | (static_cast<uint32_t>(vy) & 7u)) << 3) | (static_cast<uint32_t>(vx) & 7u);
-  return static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
-         static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, true));
 }
+constexpr int QUAD_BCAST0 = 0x00, QUAD_BCAST1 = 0x55, QUAD_BCAST2 = 0xAA, QUAD_BCAST3 = 0xFF;  // quad_perm:[e,e,e,e]
+constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;                                              // [1,0,3,2], [2,3,0,1]
 
-// rec_min_d2 for count <= 5 without the count-dependent selects: mc_write_records fills the unused candidate slots with
-// REC_SENTINEL coordinates, whose d2 (~1e36) never wins a minimum and never passes d2 < r2.
-__device__ inline float rec_min_d2_trim(const RecGrid& g, float qx, float qy, float qz, const float4 r0, const float4 r1,
-                                        const float4 r2, const float4 r3)
+// Every lane of the wavefront must be active here (DPP reads 0 from an inactive lane). vrec = the lane's own record
+// index (0 for a lane without one: it reads record 0 and ignores the answer); returns min d2 for the lane's own query.
+__device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, float qz, uint32_t vrec, bool valid, int lane)
 {
-  const uint32_t count = __float_as_uint(r0.x);
-  if (count <= 5)
+  const int j = lane & 3;
+  const float4* part = g.rec + j;
+  const float4 R0 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST0>(vrec))];
+  const float4 R1 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST1>(vrec))];
+  const float4 R2 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST2>(vrec))];
+  const float4 R3 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST3>(vrec))];
+  // candidate j of evaluation e against the query of lane e
+  const float d0 = d2_simple(quad_f<QUAD_BCAST0>(qx), quad_f<QUAD_BCAST0>(qy), quad_f<QUAD_BCAST0>(qz), R0.x, R0.y, R0.z);
+  const float d1 = d2_simple(quad_f<QUAD_BCAST1>(qx), quad_f<QUAD_BCAST1>(qy), quad_f<QUAD_BCAST1>(qz), R1.x, R1.y, R1.z);
+  const float d2 = d2_simple(quad_f<QUAD_BCAST2>(qx), quad_f<QUAD_BCAST2>(qy), quad_f<QUAD_BCAST2>(qz), R2.x, R2.y, R2.z);
+  const float d3 = d2_simple(quad_f<QUAD_BCAST3>(qx), quad_f<QUAD_BCAST3>(qy), quad_f<QUAD_BCAST3>(qz), R3.x, R3.y, R3.z);
+  // 4 x 4 transpose-min: after the xor-1 step a lane holds min over {j, j^1} for evaluation (j & 1) resp. 2 + (j & 1);
+  // after the xor-2 step min over the whole quad for evaluation j
+  const bool odd = (j & 1) != 0, high = (j & 2) != 0;
+  const float m01 = fminf(odd ? d1 : d0, quad_f<QUAD_XOR1>(odd ? d0 : d1));
+  const float m23 = fminf(odd ? d3 : d2, quad_f<QUAD_XOR1>(odd ? d2 : d3));
+  float best = fminf(high ? m23 : m01, quad_f<QUAD_XOR2>(high ? m01 : m23));
+  // overflow (more than 4 candidates): rare. The counts of the quad's four records sit in lane 0 (part 0's w).
+  const uint32_t c0 = __float_as_uint(R0.w), c1 = __float_as_uint(R1.w), c2 = __float_as_uint(R2.w), c3 = __float_as_uint(R3.w);
+  const uint32_t cmax = max(max(c0, c1), max(c2, c3));
+  if (__ballot(j == 0 && cmax > 4u) != 0ull)
   {
-    const float d0 = d2_simple(qx, qy, qz, r0.y, r0.z, r0.w);
-    const float d1 = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
-    const float d2 = d2_simple(qx, qy, qz, r1.w, r2.x, r2.y);
-    const float d3 = d2_simple(qx, qy, qz, r2.z, r2.w, r3.x);
-    const float d4 = d2_simple(qx, qy, qz, r3.y, r3.z, r3.w);
-    return fminf(fminf(fminf(d0, d1), fminf(d2, d3)), d4);
+    // count of MY record = part 0's w of record j, held by lane 0 of the quad; first overflow record = part 1's w, lane 1
+    const uint32_t n0 = quad_u<QUAD_BCAST0>(c0), n1 = quad_u<QUAD_BCAST0>(c1), n2 = quad_u<QUAD_BCAST0>(c2),
+                   n3 = quad_u<QUAD_BCAST0>(c3);
+    const uint32_t e0 = quad_u<QUAD_BCAST1>(c0), e1 = quad_u<QUAD_BCAST1>(c1), e2 = quad_u<QUAD_BCAST1>(c2),
+                   e3 = quad_u<QUAD_BCAST1>(c3);
+    const uint32_t count = j == 0 ? n0 : j == 1 ? n1 : j == 2 ? n2 : n3;
+    const uint32_t ext = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
+    if (valid && count > 4u)
+      best = rec_overflow_min(g, qx, qy, qz, count, ext, best);
   }
-  return rec_min_d2(g, qx, qy, qz, r0, r1, r2, r3);
+  return best;
 }
 
 // sqrtf for 0 <= x < r2, correctly rounded wherever its value can reach the result: v_sqrt_f32 (1 ulp) followed by the two
@@ -364,6 +337,44 @@ __device__ inline float sqrt_in_radius(float x)
   return s;
 }
 
+// One evaluation on the cooperative path, for kernels in which EVERY lane of the wavefront reaches this point (a lane
+// without work passes have_point = false): transform, locate, cooperative fetch, distance, term. Returns the float term
+// (0 when there is no match) and sets `matched`.
+__device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const Vec3f pos, const Quat rot, const float4 v,
+                                  bool have_point, int lane, bool& matched)
+{
+  const Vec3f tp = vadd(qrot_trim(rot, Vec3f{ v.x, v.y, v.z }), pos);
+  float qx = tp.x, qy = tp.y, qz = tp.z;
+  if (prm.has_weight)  // wave-uniform; x * 1.0f == x, so skipping the multiplies changes nothing
+  {
+    qx = tp.x * prm.wx;
+    qy = tp.y * prm.wy;
+    qz = tp.z * prm.wz;
+  }
+  uint32_t ti, sub;
+  const bool inside = rec_locate(rg, qx, qy, qz, ti, sub) && have_point;
+  const int b = rg.brick_table[inside ? ti : 0u];
+  const bool valid = inside && b >= 0;
+  float term = 0.f;
+  matched = false;
+  if (__ballot(valid) != 0ull)  // wave-uniform: a wavefront with nothing to look up skips the record loads
+  {
+    const uint32_t vrec = valid ? ((static_cast<uint32_t>(b) << 9) | sub) : 0u;
+    const float d2 = rec_min_d2_quad(rg, qx, qy, qz, vrec, valid, lane);
+    if (valid && d2 < prm.r2)
+    {
+      const float s = sqrt_in_radius(d2);
+      const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
+      if (!(dist < 0.0f))
+      {
+        term = dist * prm.match_weight;
+        matched = true;
+      }
+    }
+  }
+  return term;
+}
+
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
 // MODE 1: candidate-voxel index
 template <int BLOCK, int MODE, bool STATS>
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
                                                            CandGrid cg, RecGrid rg, LikParams prm,
                                                            float* __restrict__ out_lik,
                                                            float* __restrict__ out_ratio,
-                                                           double* __restrict__ out_tested)
+                                                           double* __restrict__ out_tested, int coop)
 {
   const int p = blockIdx.x;
   const float* ps = pose7 + 7 * static_cast<size_t>(p);
@@ -382,6 +393,22 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
   double acc = 0.0;   // sum of float terms, each exactly representable: fp64 sum is exact to ~1e-16
   unsigned num = 0;   // matched points
   unsigned tested = 0;
+  if (MODE == 2 && !STATS && coop)
+  {
+    // cooperative record fetch (rec_min_d2_quad): consecutive lanes hold consecutive (Morton-ordered) scan points; every
+    // lane stays in the loop until the whole work-group is done
+    for (int base = 0; base < n_s; base += BLOCK)
+    {
+      const int i = base + static_cast<int>(threadIdx.x);
+      const bool have = i < n_s;
+      const float4 v = have ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bool matched;
+      const float term = eval_coop(rg, prm, pos, rot, v, have, static_cast<int>(threadIdx.x & 63), matched);
+      acc += static_cast<double>(term);
+      num += matched ? 1u : 0u;
+    }
+  }
+  else
   for (int i = threadIdx.x; i < n_s; i += BLOCK)
   {
     const float4 v = scan[i];
@@ -457,14 +484,28 @@ template <int W, int MODE>
 __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, LikGrid g,
                                                                CandGrid cg, RecGrid rg, LikParams prm,
-                                                               float* __restrict__ out_lik, float* __restrict__ out_ratio)
+                                                               float* __restrict__ out_lik, float* __restrict__ out_ratio,
+                                                               int coop)
 {
   const long long gt = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   const long long p = gt / W;
   const int i = static_cast<int>(gt % W);
   double acc = 0.0;
   unsigned num = 0;
-  if (p < n_p && i < n_s)
+  if (MODE == 2 && coop)
+  {
+    // all 64 lanes go through the cooperative fetch; a lane past the last particle / point carries have = false
+    const bool have = p < n_p && i < n_s;
+    const float* ps = pose7 + 7 * (p < n_p ? p : 0);
+    const Vec3f pos = { ps[0], ps[1], ps[2] };
+    const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });
+    const float4 v = scan[i < n_s ? i : 0];
+    bool matched;
+    const float term = eval_coop(rg, prm, pos, rot, v, have, static_cast<int>(threadIdx.x & 63), matched);
+    acc = static_cast<double>(term);
+    num = matched ? 1u : 0u;
+  }
+  else if (p < n_p && i < n_s)
   {
     const float* ps = pose7 + 7 * p;
     const Vec3f pos = { ps[0], ps[1], ps[2] };
@@ -521,13 +562,10 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
 //    (tile, particle); lik_finalize_kernel adds the tiles in order.
 // Same per-point arithmetic as likelihood_kernel — identical terms — only the (fp64) summation order differs.
 //
-// U > 1 (MODE 2 only): U particles per loop iteration with the dependent steps batched — U transforms, then U
-// brick-table loads, then U record loads (4 x 16 bytes each), then the arithmetic — so that every lane has U independent
-// L2 round trips in flight instead of one (the U = 1 loop is a single dependent chain transform -> table -> record ->
-// sqrt per particle, and 8 wavefronts per SIMD do not cover it: DESIGN.md section 6). The loads are issued unconditionally —
-// lanes with nothing to look up read brick-table entry 0 / record 0 and discard it — so the U chains stay in one basic
-// block. MINW = wavefronts per SIMD the register allocation must leave room for (8 -> 64 VGPRs, 5 -> 96, 4 -> 128).
-template <int G, int MODE, int U = 1, int MINW = 8, bool TRIM = false>
+// COOP (MODE 2 only): the quad-cooperative record fetch of rec_min_d2_quad plus the VALU-trimmed transform / sqrt. Same
+// terms, bit for bit. MINW = wavefronts per SIMD the register allocation must leave room for (G = 32 holds 33 KB of LDS:
+// 4 at most).
+template <int G, int MODE, int MINW = 8, bool COOP = false>
 __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
                                                                int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
@@ -572,75 +610,20 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   const float4 v = have_point ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const int n_valid = min(G, n_p - group * G);
-  if constexpr (U > 1 && MODE == 2)
+  if constexpr (COOP && MODE == 2)
   {
-    static_assert(G % U == 0, "the particle group must be a multiple of the unroll");
-    for (int k = 0; k < n_valid; k += U)
+    // every lane stays active through the cooperative fetch (DPP reads 0 from an inactive lane): a lane without a scan
+    // point, outside the grid or without a brick simply carries valid = false
+    for (int k = 0; k < n_valid; ++k)
     {
-      float qx[U], qy[U], qz[U];
-      uint32_t ti[U], sub[U];
-      bool in[U];
-      // step 1: U transforms + voxel addresses (a tail iteration re-evaluates the last valid particle; its results are
-      // not stored)
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        const int kk = min(k + u, n_valid - 1);
-        const Vec3f pos = { s_pose[kk][0], s_pose[kk][1], s_pose[kk][2] };
-        const Quat rot = { s_pose[kk][3], s_pose[kk][4], s_pose[kk][5], s_pose[kk][6] };
-        const Vec3f tp = vadd(TRIM ? qrot_trim(rot, Vec3f{ v.x, v.y, v.z }) : qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
-        qx[u] = tp.x * prm.wx;
-        qy[u] = tp.y * prm.wy;
-        qz[u] = tp.z * prm.wz;
-        in[u] = (TRIM ? rec_locate_trim(rg, qx[u], qy[u], qz[u], ti[u], sub[u]) :
-                        rec_locate(rg, qx[u], qy[u], qz[u], ti[u], sub[u])) && have_point;
-      }
-      // step 2: U brick-table loads (lanes outside the grid read entry 0 and discard it)
-      int b[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        b[u] = rg.brick_table[in[u] ? ti[u] : 0u];
-      // step 3: U record loads (lanes without a brick read record 0 and discard it)
-      float4 r[U][4];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        in[u] = in[u] && b[u] >= 0;
-        const float4* rp = rg.rec + 4 * static_cast<size_t>(in[u] ? ((static_cast<uint32_t>(b[u]) << 9) | sub[u]) : 0u);
-        r[u][0] = rp[0];
-        r[u][1] = rp[1];
-        r[u][2] = rp[2];
-        r[u][3] = rp[3];
-      }
-      // step 4: arithmetic
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        float term = 0.f;
-        bool matched = false;
-        if (in[u] && __float_as_uint(r[u][0].x) != 0u)
-        {
-          const float d2 = TRIM ? rec_min_d2_trim(rg, qx[u], qy[u], qz[u], r[u][0], r[u][1], r[u][2], r[u][3]) :
-                                  rec_min_d2(rg, qx[u], qy[u], qz[u], r[u][0], r[u][1], r[u][2], r[u][3]);
-          if (d2 < prm.r2)
-          {
-            const float s = TRIM ? sqrt_in_radius(d2) : sqrtf(d2);
-            const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
-            if (!(dist < 0.0f))
-            {
-              term = dist * prm.match_weight;
-              matched = true;
-            }
-          }
-        }
-        if (k + u < n_valid)
-        {
-          s_term[k + u][t] = term;
-          const unsigned long long m = __ballot(matched);
-          if (lane == 0)
-            s_cnt[k + u][wave] = static_cast<unsigned>(__popcll(m));
-        }
-      }
+      const Vec3f pos = { s_pose[k][0], s_pose[k][1], s_pose[k][2] };
+      const Quat rot = { s_pose[k][3], s_pose[k][4], s_pose[k][5], s_pose[k][6] };
+      bool matched;
+      const float term = eval_coop(rg, prm, pos, rot, v, have_point, lane, matched);
+      s_term[k][t] = term;
+      const unsigned long long m = __ballot(matched);
+      if (lane == 0)
+        s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
     }
   }
   else
@@ -652,41 +635,16 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
     bool matched = false;
     if (have_point)
     {
-      const Vec3f tp = vadd(TRIM ? qrot_trim(rot, Vec3f{ v.x, v.y, v.z }) : qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
+      const Vec3f tp = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);
       // rescale by dist_weight; without one the weights are 1.0f and x * 1.0f == x bit for bit, so no select is needed
-      // (TRIM: a wave-uniform branch skips the three multiplies then)
-      float qx = tp.x, qy = tp.y, qz = tp.z;
-      if (!TRIM || prm.has_weight)
-      {
-        qx = tp.x * prm.wx;
-        qy = tp.y * prm.wy;
-        qz = tp.z * prm.wz;
-      }
+      const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
       unsigned dummy = 0;
-      float d2;
-      if constexpr (TRIM && MODE == 2)
-      {
-        d2 = 3.0e38f;
-        uint32_t ti, sub;
-        if (rec_locate_trim(rg, qx, qy, qz, ti, sub))
-        {
-          const int b = rg.brick_table[ti];
-          if (b >= 0)
-          {
-            const float4* r = rg.rec + 4 * static_cast<size_t>((static_cast<uint32_t>(b) << 9) | sub);
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-            if (__float_as_uint(r0.x) != 0u)
-              d2 = rec_min_d2_trim(rg, qx, qy, qz, r0, r1, r2, r3);
-          }
-        }
-      }
-      else
-        d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
-             MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
-                         nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
+      const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
+                       MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
+                                   nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
       if (d2 < prm.r2)
       {
-        const float s = TRIM ? sqrt_in_radius(d2) : sqrtf(d2);
+        const float s = sqrtf(d2);
         const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
         if (!(dist < 0.0f))
         {

@@ -322,10 +322,11 @@ __global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* _
 }
 
 // ---- "fat" voxel records (query MODE 2) -------------------------------------------------------------------------
-// One 64-byte record per voxel of every allocated brick, so a query is ONE cache line after the brick table:
-//   count <= 5 : { count, xyz[5] }                       (15 floats of candidates inline)
-//   count  > 5 : { count, ext, xyz[4], pad, pad }        (4 inline, the rest in overflow records ext, ext+1, ...)
-//   overflow   : { xyz[5], pad }                         contiguous, 5 candidates each
+// One 64-byte record per voxel of every allocated brick, so a query is ONE cache line after the brick table. Four 16-byte
+// parts, one per lane of a quad in the tiled kernel's cooperative fetch:
+//   part j   : { candidate j: x, y, z ; w }   w of part 0 = candidate count, w of part 1 = first overflow record (count > 4)
+//   overflow : { xyz[5], pad }                 contiguous, candidates 4, 5, ... five per record
+// Unused candidate slots hold REC_SENTINEL coordinates.
 constexpr float REC_SENTINEL = 1.0e18f;
 
 struct RecGrid
@@ -344,7 +345,7 @@ __global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint3
   if (v >= n_vox)
     return;
   const uint32_t c = kept_count[v];
-  n_ovf[v] = c > 5 ? (c - 4 + 4) / 5 : 0u;
+  n_ovf[v] = c > 4 ? (c - 4 + 4) / 5 : 0u;
 }
 
 __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
@@ -357,28 +358,28 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
     return;
   const uint32_t c = kept_count[v], src = pstart[v];
   // unused candidate slots hold REC_SENTINEL: a point so far away that its d2 (~3e36, finite) never wins a minimum and
-  // never passes the radius test, so a query may take the minimum over all five slots without looking at the count
+  // never passes the radius test, so a query may take the minimum over all four inline slots without looking at the count
   float out[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     out[i] = REC_SENTINEL;
-  out[0] = __uint_as_float(c);
-  const uint32_t inline_n = c <= 5 ? c : 4u;
-  const int base = c <= 5 ? 1 : 2;
-  if (c > 5)
-    out[1] = __uint_as_float(ovf_start[v]);
+  const uint32_t inline_n = c < 4 ? c : 4u;
   for (uint32_t k = 0; k < inline_n; ++k)
   {
     const float4 p = pts[prelim[src + k] & 0x7fffffffu];
-    out[base + 3 * k + 0] = p.x;
-    out[base + 3 * k + 1] = p.y;
-    out[base + 3 * k + 2] = p.z;
+    out[4 * k + 0] = p.x;
+    out[4 * k + 1] = p.y;
+    out[4 * k + 2] = p.z;
   }
+  out[3] = __uint_as_float(c);
+  out[7] = __uint_as_float(c > 4 ? ovf_start[v] : 0u);
+  out[11] = 0.f;
+  out[15] = 0.f;
   float4* dst = reinterpret_cast<float4*>(rec + 16 * v);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
-  if (c > 5)
+  if (c > 4)
   {
     float* o = ovf + 16 * static_cast<size_t>(ovf_start[v]);
     for (uint32_t k = 4; k < c; ++k)
@@ -391,6 +392,103 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
       slot[2] = p.z;
     }
   }
+}
+
+// ---- map updates: re-compile only the bricks a changed set of points can reach (host_map_compilers.h:update_cand_grid) ----
+// new_flag[i] = 1 for a dirty brick that has no id yet
+__global__ void mc_new_brick_flags(const int* __restrict__ dirty, const int* __restrict__ table, uint32_t* __restrict__ new_flag,
+                                   long long n_table)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i > n_table)
+    return;
+  new_flag[i] = (i < n_table && dirty[i] && table[i] < 0) ? 1u : 0u;
+}
+
+// assigns the new ids (appended behind the existing bricks) and builds the sub-problem's view: sub_table = dense ids of
+// the dirty bricks only, sub_main[sub id] = id in the main record array, sub_bxyz = brick coordinates
+__global__ void mc_dirty_tables(const int* __restrict__ dirty, const uint32_t* __restrict__ new_rank,
+                                const uint32_t* __restrict__ dirty_rank, uint32_t n_bricks_old, int nbx, int nby,
+                                long long n_table, int* __restrict__ table, int* __restrict__ sub_table,
+                                int* __restrict__ sub_main, int* __restrict__ sub_bxyz)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_table)
+    return;
+  if (!dirty[i])
+  {
+    sub_table[i] = -1;
+    return;
+  }
+  int id = table[i];
+  if (id < 0)
+  {
+    id = static_cast<int>(n_bricks_old + new_rank[i]);
+    table[i] = id;
+  }
+  const int sub = static_cast<int>(dirty_rank[i]);
+  sub_table[i] = sub;
+  sub_main[sub] = id;
+  const long long plane = static_cast<long long>(nbx) * nby;
+  sub_bxyz[3 * sub + 0] = static_cast<int>(i % nbx);
+  sub_bxyz[3 * sub + 1] = static_cast<int>((i / nbx) % nby);
+  sub_bxyz[3 * sub + 2] = static_cast<int>(i / plane);
+}
+
+// flag[i] = 1 if point i can reach a voxel of a dirty brick (its reach box touches one); flag[n] = 0 (scan slot)
+__global__ void mc_relevant_points(CompileParams c, const float4* __restrict__ pts, const int* __restrict__ dirty,
+                                   uint32_t* __restrict__ flag)
+{
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi > c.n_points)
+    return;
+  if (pi == c.n_points)
+  {
+    flag[pi] = 0;
+    return;
+  }
+  const int3 v = voxel_of(c, pts[pi]);
+  const int x0 = max(v.x - c.reach, 0) >> 3, x1 = min(v.x + c.reach, c.nvx - 1) >> 3;
+  const int y0 = max(v.y - c.reach, 0) >> 3, y1 = min(v.y + c.reach, c.nvy - 1) >> 3;
+  const int z0 = max(v.z - c.reach, 0) >> 3, z1 = min(v.z + c.reach, c.nvz - 1) >> 3;
+  uint32_t f = 0;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x)
+        f |= dirty[(static_cast<long long>(z) * c.nby + y) * c.nbx + x] ? 1u : 0u;
+  flag[pi] = f;
+}
+
+// out[pos[i]] = pts[i] for flagged points (pos = exclusive scan of the flags): order kept, so candidate lists come out in
+// the same ascending map order a whole-map compile produces
+__global__ void mc_compact_points(const float4* __restrict__ pts, const uint32_t* __restrict__ pos, int n,
+                                  float4* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  if (pos[i + 1] != pos[i])
+    out[pos[i]] = pts[i];
+}
+
+// copies the freshly compiled records of the dirty bricks into the main array; overflow references are rebased onto the
+// main overflow array, where the new overflow records were appended at ovf_base
+__global__ void mc_install_records(const float4* __restrict__ sub_rec, const int* __restrict__ sub_main, uint32_t ovf_base,
+                                   long long n_sub_vox, float4* __restrict__ rec)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_sub_vox)
+    return;
+  const int sub = static_cast<int>(v >> 9);
+  const size_t dst = (static_cast<size_t>(sub_main[sub]) << 9) | static_cast<size_t>(v & 511);
+  const float4 r0 = sub_rec[4 * v];
+  float4 r1 = sub_rec[4 * v + 1];
+  if (__float_as_uint(r0.w) > 4u)
+    r1.w = __uint_as_float(__float_as_uint(r1.w) + ovf_base);
+  rec[4 * dst + 0] = r0;
+  rec[4 * dst + 1] = r1;
+  rec[4 * dst + 2] = sub_rec[4 * v + 2];
+  rec[4 * dst + 3] = sub_rec[4 * v + 3];
 }
 
 // ---- exclusive scan of uint32 (3 levels of 1024-element tiles cover 2^30 elements) --------------------------------

@@ -8,9 +8,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <string>
 #include <vector>
+
+#include <hipcub/hipcub.hpp>
 
 #include "kernels.h"
 #include "mcl3dl_hip.h"
@@ -33,5 +36,6 @@ extern "C"
 #include "api_reductions.inl"
 #include "api_resample.inl"
 #include "api_support.inl"
+#include "api_cloud.inl"
 #include "api_group.inl"
 }  // extern "C"

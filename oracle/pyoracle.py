@@ -138,6 +138,11 @@ class Oracle:
             s("resample", None, [_p, _p, _sz, C.c_uint, _p, _p, _p])
             s("resample_draws", None, [C.c_uint, _f, _p, _sz, _p, _p])
             s("resize", None, [_p, _p, _sz, _sz, _p, _p])
+            s("voxel_grid", _sz, [_p, _p, _sz, _p, _p, _p, _sz])
+            s("clip", _sz, [_p, _i, _p, _p, _sz, _p, _p, _sz, C.POINTER(_sz)])
+            s("filter_uniform", _sz, [_p, _i, _p, _p, _sz, C.c_uint, _p, _p, _sz])
+            s("uniform_indices", None, [C.c_uint, _sz, _sz, _p])
+            s("match_split", None, [_p, _p, _p, _sz, _d, _d, _p, _p])
         else:
             s("resample_pstep", _f, [_p, _sz, _sz])
             s("resample_plan", None, [_p, _sz, _sz, _i, _f, _p, _p])
@@ -155,6 +160,50 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    # ---- SURVEY.md 8f-2 / 8f-4 (reference-backed oracle only) ---------------------------------------------------------
+    def voxel_grid(self, xyz, label, leaf):
+        """pcl::VoxelGrid as the node configures it (restated shim, oracle/shims/pcl/filters/voxel_grid.h)."""
+        xyz = _f32(xyz, 3)
+        lab = _u32a(label, len(xyz))
+        lf = _f32(leaf)
+        ox = np.zeros((len(xyz), 3), np.float32)
+        ol = np.zeros(len(xyz), np.uint32)
+        n = self._fn("voxel_grid")(_fp(xyz), _fp(lab), len(xyz), _fp(lf), _fp(ox), _fp(ol), len(xyz))
+        return ox[:n].copy(), ol[:n].copy()
+
+    def clip(self, model, xyz, label=None):
+        """The clip step of the reference's filter() (model 0 = likelihood, 1 = beam) and the num_points_ it would draw."""
+        xyz = _f32(xyz, 3)
+        lab = _u32a(label, len(xyz))
+        ox = np.zeros((len(xyz), 3), np.float32)
+        ol = np.zeros(len(xyz), np.uint32)
+        num = C.c_size_t(0)
+        n = self._fn("clip")(self.h, model, _fp(xyz), _fp(lab), len(xyz), _fp(ox), _fp(ol), len(xyz), C.byref(num))
+        return ox[:n].copy(), ol[:n].copy(), int(num.value)
+
+    def filter_uniform(self, model, xyz, label, seed, capacity):
+        """The reference's filter() with the reference's PointCloudUniformSampler (engine seeded with `seed`)."""
+        xyz = _f32(xyz, 3)
+        lab = _u32a(label, len(xyz))
+        ox = np.zeros((capacity, 3), np.float32)
+        ol = np.zeros(capacity, np.uint32)
+        n = self._fn("filter_uniform")(self.h, model, _fp(xyz), _fp(lab), len(xyz), seed, _fp(ox), _fp(ol), capacity)
+        assert n <= capacity
+        return ox[:n].copy(), ol[:n].copy()
+
+    def uniform_indices(self, seed, n_clipped, num):
+        out = np.zeros(num, np.uint32)
+        self._fn("uniform_indices")(seed, n_clipped, num, _fp(out))
+        return out
+
+    def match_split(self, pose7, xyz, unmatch_dist, match_dist):
+        pose7 = _f32(pose7)
+        xyz = _f32(xyz, 3)
+        cls = np.zeros(len(xyz), np.uint8)
+        out = np.zeros((len(xyz), 3), np.float32)
+        self._fn("match_split")(self.h, _fp(pose7), _fp(xyz), len(xyz), unmatch_dist, match_dist, _fp(cls), _fp(out))
+        return cls, out
 
     def max_threads(self):
         return int(self._fn("max_threads")())

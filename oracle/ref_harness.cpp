@@ -25,11 +25,21 @@
 #include <mcl_3dl/lidar_measurement_models/lidar_measurement_model_beam.h>
 #include <mcl_3dl/lidar_measurement_models/lidar_measurement_model_likelihood.h>
 #include <mcl_3dl/pf.h>
+#include <mcl_3dl/point_cloud_random_sampler.h>
 #include <mcl_3dl/point_types.h>
 #include <mcl_3dl/quat.h>
 #include <mcl_3dl/raycasts/raycast_using_dda.h>
 #include <mcl_3dl/state_6dof.h>
 #include <mcl_3dl/vec3.h>
+
+#include <pcl/filters/voxel_grid.h>  // oracle/shims: restated (PCL is not vendored by the reference)
+
+// The reference's sampler seeds its private engine from std::random_device; the tests need the very same class with a
+// known seed, so the header is read with its private section open (every header it includes is already included above).
+#include <random>
+#define private public
+#include <mcl_3dl/point_cloud_random_samplers/point_cloud_uniform_sampler.h>
+#undef private
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -634,5 +644,117 @@ void ref_resize(const float* state13, const float* weight, size_t n, size_t n_ou
   loadStates13(pf, state13, weight);
   pf.resizeParticle(n_out);
   storeStates13(pf, out_state13, out_weight);
+}
+// ---- the steps either side of the measurement update ------------------------------------------
+namespace
+{
+size_t storeCloud(const Cloud& pc, float* out_xyz, uint32_t* out_label, size_t cap)
+{
+  const size_t n = pc.points.size();
+  if (out_xyz && n <= cap)
+    for (size_t i = 0; i < n; ++i)
+    {
+      out_xyz[3 * i + 0] = pc.points[i].x;
+      out_xyz[3 * i + 1] = pc.points[i].y;
+      out_xyz[3 * i + 2] = pc.points[i].z;
+      if (out_label)
+        out_label[i] = pc.points[i].label;
+    }
+  return n;
+}
+
+// hands the clipped cloud through unchanged: filter()'s clip step alone
+class PassThroughSampler : public mcl_3dl::PointCloudRandomSampler<PointType>
+{
+public:
+  mutable size_t asked = 0;
+  Cloud::Ptr sample(const Cloud::ConstPtr& pc, const size_t num) const final
+  {
+    asked = num;
+    return Cloud::Ptr(new Cloud(*pc));
+  }
+};
+
+mcl_3dl::LidarMeasurementModelBase* modelOf(Ref* r, int model)
+{
+  if (model == 0)
+    return r->lik.get();
+  return r->beam[0].get();
+}
+}  // namespace
+
+// pcl::VoxelGrid as the node uses it (src/mcl_3dl.cpp:147-151, 363-367, 1155-1158) — the restated shim, see its header
+size_t ref_voxel_grid(const float* xyz, const uint32_t* label, size_t n, const float* leaf3, float* out_xyz,
+                      uint32_t* out_label, size_t cap)
+{
+  Cloud::Ptr in = makeCloud(xyz, label, n);
+  Cloud out;
+  pcl::VoxelGrid<PointType> ds;
+  ds.setInputCloud(in);
+  ds.setLeafSize(leaf3[0], leaf3[1], leaf3[2]);
+  ds.filter(out);
+  return storeCloud(out, out_xyz, out_label, cap);
+}
+
+// the clip step of the reference's own filter() (likelihood.cpp:79-103 / beam.cpp:98-122) and the num_points_ it asks
+// the sampler for
+size_t ref_clip(void* h, int model, const float* xyz, const uint32_t* label, size_t n, float* out_xyz, uint32_t* out_label,
+                size_t cap, size_t* num_points)
+{
+  Ref* r = static_cast<Ref*>(h);
+  PassThroughSampler sampler;
+  const Cloud::Ptr out = modelOf(r, model)->filter(makeCloud(xyz, label, n), sampler);
+  if (num_points)
+    *num_points = sampler.asked;
+  return storeCloud(*out, out_xyz, out_label, cap);
+}
+
+// the reference's filter() with the reference's PointCloudUniformSampler, its engine re-seeded with `seed`
+size_t ref_filter_uniform(void* h, int model, const float* xyz, const uint32_t* label, size_t n, unsigned seed,
+                          float* out_xyz, uint32_t* out_label, size_t cap)
+{
+  Ref* r = static_cast<Ref*>(h);
+  mcl_3dl::PointCloudUniformSampler<PointType> sampler;
+  sampler.engine_.reset(new std::default_random_engine(seed));
+  const Cloud::Ptr out = modelOf(r, model)->filter(makeCloud(xyz, label, n), sampler);
+  return storeCloud(*out, out_xyz, out_label, cap);
+}
+
+// the indices that sampler draws from a clipped cloud of n_clipped points (point_cloud_uniform_sampler.h:66-71): what a
+// caller of mcl3dl_hip_scan_finish does with its own engine
+void ref_uniform_indices(unsigned seed, size_t n_clipped, size_t num, uint32_t* out)
+{
+  std::default_random_engine engine(seed);
+  if (n_clipped == 0)
+    return;
+  std::uniform_int_distribution<size_t> ud(0, n_clipped - 1);
+  for (size_t i = 0; i < num; ++i)
+    out[i] = static_cast<uint32_t>(ud(engine));
+}
+
+// src/mcl_3dl.cpp:771-789 restated on the reference's own kd-tree and State6DOF::transform:
+// cls[i] = 2 unmatched (radiusSearch(p, unmatch_output_dist) finds nothing), 1 matched (sqdist < match_output_dist^2), 0 neither
+void ref_match_split(void* h, const float* pose7, const float* xyz, size_t n, double unmatch_dist, double match_dist,
+                     uint8_t* cls, float* out_xyz)
+{
+  Ref* r = static_cast<Ref*>(h);
+  Cloud::Ptr pc_local = makeCloud(xyz, nullptr, n);
+  const mcl_3dl::State6DOF e = makeState(pose7);
+  e.transform(*pc_local);
+  std::vector<int> id(1);
+  std::vector<float> sqdist(1);
+  const double match_dist_sq = match_dist * match_dist;
+  for (size_t i = 0; i < n; ++i)
+  {
+    const PointType& p = pc_local->points[i];
+    cls[i] = 0;
+    if (!r->kdtree->radiusSearch(p, unmatch_dist, id, sqdist, 1))
+      cls[i] = 2;
+    else if (sqdist[0] < match_dist_sq)
+      cls[i] = 1;
+    out_xyz[3 * i + 0] = p.x;
+    out_xyz[3 * i + 1] = p.y;
+    out_xyz[3 * i + 2] = p.z;
+  }
 }
 }  // extern "C"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-2 GPU session 1 (run through gpurun from the repo root): the whole -m gpu suite, the VALU micro-benchmark, the
+"""[historical: option lik_ilp no longer exists] Round-2 GPU session 1 (run through gpurun from the repo root): the whole -m gpu suite, the VALU micro-benchmark, the
 tiled-kernel variant sweep (option lik_ilp) at C2 / C3 / C5, and rocprofv3 stats + PMC passes for the baseline and the
 best variant.  Everything lands in gpurun_out/r02a/; every child runs under a timeout."""
 import json

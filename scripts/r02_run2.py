@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-2 GPU session 2: whole -m gpu suite, extended VALU micro-benchmark, A/B of {SLP vectoriser on/off} x {lik_ilp} x
+"""[historical: the lik_ilp / lik_trim options it sweeps were folded into lik_coop afterwards] Round-2 GPU session 2: whole -m gpu suite, extended VALU micro-benchmark, A/B of {SLP vectoriser on/off} x {lik_ilp} x
 {lik_trim} at C2, the winner at C3 / C4 / C5 / jittered map, profiles (kernel stats + PMC incl. VALU class counters)."""
 import json
 import os

@@ -1,0 +1,175 @@
+"""SURVEY.md §8f-4 on the GPU: the map from the wire format + map VoxelGrid (src/mcl_3dl.cpp:128-139, 1140-1158), map
+updates (pc_map2 = pc_map + VoxelGrid(update), :141-153, 1355-1369) with an INCREMENTAL update of the candidate-voxel index,
+and the matched / unmatched output (:761-805) as one device pass."""
+import struct
+
+import numpy as np
+import pytest
+
+from mcl_3dl_amd import capi
+from mcl_3dl_amd.synthetic import cube_map, make_scene
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+DW = (1.0, 1.0, 2.0)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not pyoracle.available("ref"):
+        pytest.fail("oracle/_ref is not built")
+    return pyoracle.Oracle("ref")
+
+
+def pc2_bytes(xyz, label, step=20, offs=(0, 4, 8, 16)):
+    buf = bytearray(step * len(xyz))
+    for i in range(len(xyz)):
+        struct.pack_into("<f", buf, i * step + offs[0], xyz[i, 0])
+        struct.pack_into("<f", buf, i * step + offs[1], xyz[i, 1])
+        struct.pack_into("<f", buf, i * step + offs[2], xyz[i, 2])
+        if offs[3] >= 0:
+            struct.pack_into("<I", buf, i * step + offs[3], int(label[i]))
+    return bytes(buf)
+
+
+def dense_raw_map(seed=5):
+    """A raw (not yet down-sampled) map: the 9.1 m cube sampled densely with noise, labels on one wall."""
+    rng = np.random.default_rng(seed)
+    base = cube_map(91)
+    raw = np.concatenate([base + rng.normal(0, 0.01, base.shape).astype(np.float32) for _ in range(3)], 0).astype(np.float32)
+    label = (raw[:, 0] < -4.4).astype(np.uint32) * 2
+    return raw, label
+
+
+def test_map_from_pointcloud2_and_voxel_grid(ref):
+    raw, label = dense_raw_map()
+    eng = capi.Engine(0)
+    try:
+        n_map = eng.set_map_pointcloud2(pc2_bytes(raw, label), len(raw), 20, 0, 4, 8, 16, leaf=(0.1, 0.1, 0.1), stamp=5,
+                                        dist_weight=DW)
+        got_xyz, got_label = eng.map_download()
+        want_xyz, want_label = ref.voxel_grid(raw, label, (0.1, 0.1, 0.1))
+        assert n_map == len(want_xyz) < len(raw)
+        np.testing.assert_array_equal(got_xyz, want_xyz)
+        np.testing.assert_array_equal(got_label, want_label)
+        assert set(np.unique(want_label)) == {0, 2}
+        # the same through the array form, and the engine is a working engine on that map
+        assert eng.set_map_downsampled(raw, label, leaf=(0.1, 0.1, 0.1), stamp=6, dist_weight=DW) == n_map
+        np.testing.assert_array_equal(eng.map_download()[0], want_xyz)
+        sc = make_scene(n=91, n_p=32, n_s=500, seed=2)
+        eng.set_likelihood_params()
+        lik, ratio, _ = eng.measure_batch(sc.poses, sc.scan_lik)
+        o = pyoracle.Oracle("ref")
+        o.set_map(want_xyz, want_label, dist_weight=DW)
+        o.set_likelihood_params(pyoracle.LikelihoodParams())
+        wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
+        np.testing.assert_allclose(lik, wl, rtol=1e-5)
+        np.testing.assert_array_equal(ratio, wq)
+    finally:
+        eng.close()
+
+
+def furniture(rng, n, centre):
+    """A box-shaped obstacle (points on its faces) near `centre`: what a map update adds."""
+    p = rng.uniform(-0.6, 0.6, (n, 3))
+    ax = rng.integers(0, 3, n)
+    p[np.arange(n), ax] = np.sign(p[np.arange(n), ax]) * 0.6
+    return (p + np.asarray(centre)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_s", [300, 2000])
+def test_incremental_map_update_equals_a_fresh_index(ref, n_s):
+    """mapcloud_update: the updated engine (only the touched bricks re-compiled) answers exactly like a fresh engine that
+    was given the merged map — likelihoods bit for bit; then a second update REPLACES the first; then the update is removed."""
+    sc = make_scene(n=91, n_p=96, n_s=n_s, n_b=32, seed=4, sigma_xyz=(0.4, 0.4, 0.1))
+    rng = np.random.default_rng(8)
+    inc, fresh = capi.Engine(0), capi.Engine(0)
+    try:
+        for e in (inc, fresh):
+            e.set_likelihood_params()
+            e.set_beam_params(num_points=32)
+        inc.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=DW)
+        base_lik, _, _ = inc.measure_batch(sc.poses, sc.scan_lik)   # builds the index
+        true_pos = sc.true_pose[:3]
+        updates = [furniture(rng, 4000, true_pos + np.array([1.5, 0.5, 0.0])),
+                   furniture(rng, 2500, true_pos + np.array([-0.5, 1.8, 0.2])),
+                   np.zeros((0, 3), np.float32)]
+        leaf = (0.2, 0.2, 0.2)
+        for step, upd in enumerate(updates):
+            n_map, stats = inc.map_update(upd, None, leaf=leaf, stamp=10 + step)
+            upd_ds = ref.voxel_grid(upd, None, leaf)[0] if len(upd) else np.zeros((0, 3), np.float32)
+            merged = np.concatenate([sc.map_xyz, upd_ds], 0)
+            assert n_map == len(merged)
+            np.testing.assert_array_equal(inc.map_download()[0], merged)
+            # incremental, not a rebuild: a few dozen bricks of the ~thousands, well under the full build time
+            assert 0 < stats["bricks_recompiled"] < 400, stats
+            full_bricks = inc.index_stats()["bricks"]
+            assert stats["bricks_recompiled"] < full_bricks // 4
+            fresh.set_map(merged, None, stamp=100 + step, dist_weight=DW)
+            got = inc.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            want = fresh.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            if len(upd):
+                assert not np.array_equal(got[0], base_lik)   # the update really changes the scores
+            else:
+                np.testing.assert_array_equal(got[0], base_lik)  # update removed: back to the base map's answers
+            print("update %d: %s; full build %.2f ms" % (step, stats, fresh.index_stats()["build_ms"]))
+        # radius search (cell grid) and beam status (DDA grid) see the merged map too
+        q = (true_pos + rng.normal(0, 1.0, (500, 3))).astype(np.float32)
+        np.testing.assert_array_equal(inc.radius_search(q, 0.3)[0], fresh.radius_search(q, 0.3)[0])
+    finally:
+        inc.close()
+        fresh.close()
+
+
+def test_update_outside_the_grid_falls_back_to_a_rebuild():
+    sc = make_scene(n=61, n_p=16, n_s=300, seed=1)
+    a, b = capi.Engine(0), capi.Engine(0)
+    try:
+        for e in (a, b):
+            e.set_likelihood_params()
+        a.set_map(sc.map_xyz, None, stamp=1)
+        a.measure_batch(sc.poses, sc.scan_lik)
+        far = (np.random.default_rng(0).uniform(0, 1, (500, 3)) + np.array([30.0, 0, 0])).astype(np.float32)
+        n_map, stats = a.map_update(far, None, leaf=(0.2, 0.2, 0.2), stamp=2)
+        assert stats["bricks_recompiled"] == 0           # no incremental path: the grid has to be laid out again
+        merged = a.map_download()[0]
+        assert n_map == len(merged) > len(sc.map_xyz)
+        b.set_map(merged, None, stamp=3)
+        poses = sc.poses.copy()
+        poses[:4, :3] = [30.5, 0.5, 0.5]
+        for g, w in zip(a.measure_batch(poses, sc.scan_lik), b.measure_batch(poses, sc.scan_lik)):
+            np.testing.assert_array_equal(g, w)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_matched_unmatched_split(engine):
+    # The node builds its kd-tree with max_search_radius = 0.4 but searches with unmatch_output_dist = 0.5: across a 20 m
+    # chunk border the reference itself can miss a neighbour between 0.4 and 0.5 m away (chunked_kdtree.h:139-201). The
+    # engine returns the global nearest neighbour; the oracle here gets a border margin that covers the radius.
+    ref = pyoracle.Oracle("ref", max_search_radius=0.6)
+    sc = make_scene(n=91, n_p=4, n_s=3000, seed=6)
+    rng = np.random.default_rng(1)
+    cloud = np.concatenate([sc.scan_lik, sc.scan_lik[:800] + rng.normal(0, 0.08, (800, 3)).astype(np.float32),
+                            rng.uniform(-3, 3, (400, 3)).astype(np.float32)], 0)
+    for dw in (DW, None):
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=8201, dist_weight=dw)
+        engine.set_likelihood_params()
+        ref.set_map(sc.map_xyz, sc.map_label, dist_weight=dw)
+        pose = sc.true_pose.copy()
+        pose[3:7] *= np.float32(1.7)  # transform() normalises the quaternion
+        m, u = engine.match_split(pose, cloud, unmatch_dist=0.5, match_dist=0.1)
+        cls, moved = ref.match_split(pose, cloud, 0.5, 0.1)
+        np.testing.assert_array_equal(m, moved[cls == 1])
+        np.testing.assert_array_equal(u, moved[cls == 2])
+        assert len(m) > 1000 and len(u) > 50 and (cls == 0).sum() > 50
+    # on the cloud scan_begin left on the device (pc_local_full)
+    n_full, _, _ = engine.scan_begin(cloud, None, leaf=(0.1, 0.1, 0.1))
+    full, _ = engine.scan_download(0)
+    m2, u2 = engine.match_split(pose, None, unmatch_dist=0.5, match_dist=0.1)
+    cls2, moved2 = ref.match_split(pose, full, 0.5, 0.1)
+    np.testing.assert_array_equal(m2, moved2[cls2 == 1])
+    np.testing.assert_array_equal(u2, moved2[cls2 == 2])

@@ -268,44 +268,53 @@ def test_tiled_kernel_matches_per_particle_kernel(engine, oracle_kind, group, mo
     np.testing.assert_array_equal(ratio1, wq)
 
 
-@pytest.mark.parametrize("variant", [(1, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("group", [4, 8, 16])
+@pytest.mark.parametrize("shape", ["tiled4", "tiled8", "tiled16", "tiled32", "per_particle", "small"])
 @pytest.mark.parametrize("n_p", [100, 37])
-def test_tiled_kernel_variants_are_bit_identical(engine, variant, group, n_p):
-    """lik_ilp (two evaluations in flight per lane) and lik_trim (VALU-trimmed evaluation): the SAME terms summed in the
-    SAME order as the plain tiled kernel, so the results are equal bit for bit (also with strict_order, also when the
-    last particle group is ragged: 37 = 2 x 16 + 5, 100 = 6 x 16 + 4). The wide pose noise sends particles outside the
-    map (lanes that discard their loads)."""
-    ilp, trim = variant
-    sc = make_scene(n=91, n_p=n_p, n_s=1500, seed=6, sigma_xyz=(1.5, 1.5, 0.4), sigma_rpy=(0.05, 0.05, 1.0))
+def test_cooperative_record_fetch_is_bit_identical(engine, shape, n_p):
+    """lik_coop = 1 (the four lanes of a quad fetch each 64-byte record together and split its candidates; VALU-trimmed
+    transform and sqrt) against lik_coop = 0 (every lane fetches its own record): the SAME terms summed in the SAME
+    order, so every kernel family gives equal results bit for bit — also with strict_order, with ragged particle groups
+    (37 = 2 x 16 + 5), a ragged last tile (1500 = 5 x 256 + 220), particles outside the map (lanes that discard their
+    loads), and voxels with more than four candidates (overflow records: the clutter blob)."""
+    n_s = 20 if shape == "small" else 1500
+    n_part = 400 if shape == "small" else n_p
+    sc = make_scene(n=91, n_p=n_part, n_s=n_s, seed=6, sigma_xyz=(1.5, 1.5, 0.4), sigma_rpy=(0.05, 0.05, 1.0))
     sc.poses[::7, 0] += 30.0  # far outside the grid
+    rng = np.random.default_rng(3)
+    blob = (sc.true_pose[:3] + np.array([2.0, 0.5, -1.45]) + rng.normal(0, 0.03, (3000, 3))).astype(np.float32)
+    map_xyz = np.concatenate([sc.map_xyz, blob], 0)
+    scan = np.concatenate([sc.scan_lik, (blob[:40] - sc.true_pose[:3]).astype(np.float32)], 0) if shape != "small" else sc.scan_lik
     res = {}
-    d_ilp, d_trim = engine.get_option("lik_ilp"), engine.get_option("lik_trim")
+    d_coop = engine.get_option("lik_coop")
     try:
-        engine.set_option("lik_group", group)
+        if shape.startswith("tiled"):
+            engine.set_option("lik_group", int(shape[5:]))
+        elif shape == "per_particle":
+            engine.set_option("lik_tiled", 0)
         for dw in ((1.0, 1.0, 3.0), None):
-            setup_engine(engine, sc, dw, stamp=41)
-            for strict in (0, 1):
+            engine.set_map(map_xyz, None, stamp=41, dist_weight=dw)
+            engine.set_likelihood_params()
+            for strict in ((0, 1) if shape.startswith("tiled") else (0,)):
                 engine.set_option("strict_order", strict)
-                for v in ((0, 0), (ilp, trim)):
-                    engine.set_option("lik_ilp", v[0])
-                    engine.set_option("lik_trim", v[1])
-                    res[(dw, strict, v)] = engine.measure_batch(sc.poses, sc.scan_lik)
+                for coop in (0, 1):
+                    engine.set_option("lik_coop", coop)
+                    res[(dw, strict, coop)] = engine.measure_batch(sc.poses, scan)
     finally:
-        engine.set_option("lik_ilp", d_ilp)
-        engine.set_option("lik_trim", d_trim)
+        engine.set_option("lik_coop", d_coop)
         engine.set_option("lik_group", 0)
+        engine.set_option("lik_tiled", 1)
         engine.set_option("strict_order", 0)
-    for dw in ((1.0, 1.0, 3.0), None):
-        for strict in (0, 1):
-            np.testing.assert_array_equal(res[(dw, strict, (ilp, trim))][0], res[(dw, strict, (0, 0))][0])
-            np.testing.assert_array_equal(res[(dw, strict, (ilp, trim))][1], res[(dw, strict, (0, 0))][1])
-    assert np.count_nonzero(res[(None, 0, (0, 0))][0]) > n_p // 3
+    for (dw, strict, coop), r in res.items():
+        if coop == 1:
+            np.testing.assert_array_equal(r[0], res[(dw, strict, 0)][0])
+            np.testing.assert_array_equal(r[1], res[(dw, strict, 0)][1])
+    assert np.count_nonzero(res[(None, 0, 0)][0]) > n_part // 4
+    assert engine.index_stats()["candidates"] > 0
 
 
 @pytest.mark.parametrize("flat", [0.05, 0.0, 1e-21])
 def test_trimmed_sqrt_at_tiny_and_zero_distances(engine, oracle_kind, flat):
-    """lik_trim replaces sqrtf by v_sqrt_f32 + the two residual checks, without the compiler's input scaling below 2^-96:
+    """lik_coop replaces sqrtf by v_sqrt_f32 + the two residual checks, without the compiler's input scaling below 2^-96:
     distances of exactly zero, denormal and sub-2^-96 squared distances must still give the reference's float."""
     rng = np.random.default_rng(11)
     cloud = rng.uniform(-1.0, 1.0, (4000, 3)).astype(np.float32)
@@ -317,16 +326,16 @@ def test_trimmed_sqrt_at_tiny_and_zero_distances(engine, oracle_kind, flat):
     poses = np.zeros((8, 7), np.float32)
     poses[:, 6] = 1.0
     poses[1:, :3] = rng.normal(0, 1e-3, (7, 3)).astype(np.float32)
-    d_trim = engine.get_option("lik_trim")
+    d_trim = engine.get_option("lik_coop")
     try:
         engine.set_map(map_xyz, None, stamp=43, dist_weight=None)
         engine.set_likelihood_params(match_dist_min=0.2, match_dist_flat=flat, match_weight=5.0)
         out = {}
         for trim in (0, 1):
-            engine.set_option("lik_trim", trim)
+            engine.set_option("lik_coop", trim)
             out[trim] = engine.measure_batch(poses, scan)
     finally:
-        engine.set_option("lik_trim", d_trim)
+        engine.set_option("lik_coop", d_trim)
         engine.set_likelihood_params()
     np.testing.assert_array_equal(out[1][0], out[0][0])
     np.testing.assert_array_equal(out[1][1], out[0][1])
