@@ -392,6 +392,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
  *                       (single GPU; costs an n_s x n_p float buffer and two serial passes)
+ *   "pf_fused"          1 (default) = pf::measure of the single-GPU entry points runs as ONE work-group up to 4096 particles
+ *                       (the reference's operating range is launch-bound); 0 = always partial + reduce + apply.
+ *                       Same bits either way.
  *   "lik_coop"          tiled kernel: 1 (default) = the four lanes of a quad fetch each 64-byte voxel record together
  *                       (16 cache-line accesses per load instruction instead of 64) and split its candidates between
  *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record */

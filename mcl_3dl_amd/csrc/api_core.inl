@@ -395,12 +395,32 @@ int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_
 // ---- host entry points -------------------------------------------------------------------------------------
 namespace
 {
+// pf::measure on one GPU: the fused single-work-group kernel up to PF_FUSED_MAX particles (same bits as the split form,
+// two launches fewer), partial + reduce + apply beyond, or with strict_order (which replaces the sum between the two).
+int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
+                      const float* d_ratio, size_t n_p, float* d_stats4)
+{
+  if (n_p <= static_cast<size_t>(PF_FUSED_MAX) && !ctx->strict_order && ctx->pf_fused)
+  {
+    TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+    EventPair ep{};
+    TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+    hipLaunchKernelGGL(pf_fused_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4);
+    TRY(timing_end(ctx, ep));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
+  TRY(mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4));
+  return 0;
+}
+
 int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                    float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
 {
   TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
-  TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
-  TRY(mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4));
+  TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4));
   return 0;
 }
 
@@ -609,11 +629,9 @@ int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float*
     TRY(h2d(ctx, ctx->extra.p, extra, fb));
   if (match_ratio)
     TRY(h2d(ctx, ctx->ratio.p, match_ratio, fb));
-  TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(),
-                                   beam ? ctx->beam.as<float>() : nullptr, extra ? ctx->extra.as<float>() : nullptr,
-                                   match_ratio ? ctx->ratio.as<float>() : nullptr, n_p, 0, 1, ctx->partial4.as<double>()));
-  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, 1, ctx->partial4.as<double>(),
-                                 ctx->stats4.as<float>()));
+  TRY(pf_measure_single(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), beam ? ctx->beam.as<float>() : nullptr,
+                        extra ? ctx->extra.as<float>() : nullptr, match_ratio ? ctx->ratio.as<float>() : nullptr, n_p,
+                        ctx->stats4.as<float>()));
   float st[4];
   TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
   TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));
@@ -660,11 +678,8 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
     TRY(h2d(ctx, ctx->extra.p, extra, fb));
   TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, ctx->lik.as<float>(), ctx->ratio.as<float>(),
                      ctx->beam.as<float>(), false, nullptr));
-  TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
-                                   extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p, 0, 1,
-                                   ctx->partial4.as<double>()));
-  TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n_p, 1, ctx->partial4.as<double>(),
-                                 ctx->stats4.as<float>()));
+  TRY(pf_measure_single(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
+                        extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p, ctx->stats4.as<float>()));
   float st[4];
   TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
   TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));

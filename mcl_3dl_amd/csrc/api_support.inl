@@ -107,6 +107,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_group = static_cast<int>(value);
     return 0;
   }
+  if (key == "pf_fused")
+  {
+    ctx->pf_fused = value != 0.0;
+    return 0;
+  }
   if (key == "lik_coop")
   {
     ctx->lik_coop = value != 0.0;
@@ -140,6 +145,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_tiled") *value = ctx->lik_tiled;
   else if (key == "lik_group") *value = ctx->lik_group;
   else if (key == "lik_coop") *value = ctx->lik_coop;
+  else if (key == "pf_fused") *value = ctx->pf_fused;
   else
     return ctx->fail(-3, "unknown option '%s'", name);
   return 0;

@@ -136,6 +136,121 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
   }
 }
 
+// pf_partial_kernel -> pf_reduce_kernel -> pf_apply_kernel for ONE GPU and at most PF_FUSED_MAX particles, as a single
+// work-group: the reference's real operating range (64 .. a few thousand particles) is launch-bound — three launches of
+// a few microseconds each around ~1 us of work. The arithmetic is the three kernels' own, in the same association (the
+// 256-thread "blocks" of pf_partial_kernel become quarters of this 1024-thread group that walk the same elements, the
+// 64-lane reduce runs in the first wavefront), so weights, entropy and ratio bounds are bit-identical to the split form.
+constexpr int PF_FUSED_MAX = 4096;
+
+__global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, const float* __restrict__ lik,
+                                                        const float* __restrict__ beam, const float* __restrict__ extra,
+                                                        const float* __restrict__ ratio, int n, float* __restrict__ w_new,
+                                                        double* __restrict__ packed, float* __restrict__ stats4)
+{
+  __shared__ double sh[4][16];          // per wavefront of the group
+  __shared__ double part[4][16];        // per virtual block (n <= 4096 -> at most 16 of them)
+  __shared__ double tot[4];
+  const int nb = (n + PF_BLOCK - 1) / PF_BLOCK;  // pf_blocks(n) for n <= 4096
+  const int q = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int vb0 = 0; vb0 < nb; vb0 += 4)
+  {
+    const int vb = vb0 + q;  // this quarter's virtual block
+    double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;
+    const int i = vb * PF_BLOCK + tid;  // stride nb * PF_BLOCK >= n: one element per thread, like pf_partial_kernel
+    if (vb < nb && i < n)
+    {
+      float l = 1.0f;
+      if (beam)
+        l *= beam[i];
+      l *= lik[i];
+      if (extra)
+        l = l * extra[i];
+      const float wn = w[i] * l;
+      w_new[i] = wn;
+      s += static_cast<double>(wn);
+      if (wn > 0.0f)
+        t += static_cast<double>(wn) * log(static_cast<double>(wn));
+      if (ratio)
+      {
+        const double r = static_cast<double>(ratio[i]);
+        rmax = r > rmax ? r : rmax;
+        rneg = -r > rneg ? -r : rneg;
+      }
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+    rmax = wave_max(rmax);
+    rneg = wave_max(rneg);
+    if (lane == 0)
+    {
+      sh[0][wave] = s;
+      sh[1][wave] = t;
+      sh[2][wave] = rmax;
+      sh[3][wave] = rneg;
+    }
+    __syncthreads();
+    if (tid == 0 && vb < nb)
+    {
+      double a = 0, b = 0, c = sh[2][4 * q], d = sh[3][4 * q];
+      for (int k = 0; k < PF_BLOCK / 64; ++k)
+      {
+        a += sh[0][4 * q + k];
+        b += sh[1][4 * q + k];
+        c = sh[2][4 * q + k] > c ? sh[2][4 * q + k] : c;
+        d = sh[3][4 * q + k] > d ? sh[3][4 * q + k] : d;
+      }
+      part[0][vb] = a;
+      part[1][vb] = b;
+      part[2][vb] = c;
+      part[3][vb] = d;
+    }
+    __syncthreads();
+  }
+  if (wave == 0)
+  {
+    // pf_reduce_kernel: 64 lanes stride the block partials, wavefront reduction
+    double a = 0, b = 0, c = 0.0, d = -1.0;
+    for (int k = lane; k < nb; k += 64)
+    {
+      a += part[0][k];
+      b += part[1][k];
+      c = part[2][k] > c ? part[2][k] : c;
+      d = part[3][k] > d ? part[3][k] : d;
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_max(c);
+    d = wave_max(d);
+    if (lane == 0)
+    {
+      tot[0] = a;
+      tot[1] = b;
+      tot[2] = c;
+      tot[3] = d;
+      packed[0] = a;
+      packed[1] = b;
+      packed[2] = c;
+      packed[3] = d;
+    }
+  }
+  __syncthreads();
+  // pf_apply_kernel
+  const double S = tot[0];
+  const float sum_f = static_cast<float>(S);
+  const bool alive = sum_f > 0.0f;
+  if (alive)
+    for (int i = threadIdx.x; i < n; i += 1024)
+      w[i] = w_new[i] / sum_f;
+  if (threadIdx.x == 0 && stats4)
+  {
+    stats4[0] = alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf("");
+    stats4[1] = static_cast<float>(-tot[3]);
+    stats4[2] = static_cast<float>(tot[2]);
+    stats4[3] = alive ? 0.0f : 1.0f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // "Next" row: the reductions that follow pf::measure in the node (src/mcl_3dl.cpp:451-452,706-709):
 // pf::expectationBiased / max / maxBiased (include/mcl_3dl/pf.h:294-303,361-390) with ParticleWeightedMeanQuat
