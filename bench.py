@@ -24,9 +24,12 @@ Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` a
               kernel time / 8 TB/s.  Small by construction: the index is built so that the working set of a scan tile
               stays in one XCD's L2.
   l2          L1->L2 read requests per launch (TCP_TCC_READ_REQ, PMC) x 128-byte lines / live kernel time / 34.5 TB/s
-  valu_issue  VALU wave-instructions per launch by class (SQ_INSTS_VALU, _ADD/_MUL/_FMA_F32, _TRANS_F32: PMC) x the
-              measured cycles per instruction of each class (profiles/valu_microbench.hip: f32 add/mul/fma ~2.4,
-              transcendental ~8, everything else ~4.3) / (SIMDs x kernel cycles)
+  l1_access   L1 (TCP) cache-line accesses per launch (TCP_TOTAL_CACHE_ACCESSES, PMC) / (CUs x kernel cycles) against the
+              measured ceiling of ~1.15 accesses per cycle and CU (what bound the kernel before the cooperative fetch)
+  valu_issue  VALU wave-instructions per launch by class (SQ_INSTS_VALU and the per-class counters: PMC) x the measured
+              cycles per instruction of each class (profiles/valu_microbench.hip: plain f32 add/mul ~2.6, fma / min /
+              compares / conversions ~4.4, transcendental ~8.4) / (SIMDs x kernel cycles); classes the counters do not
+              split are priced between the two rates (frac_low .. frac_high, frac = their mean)
 `bound` names the largest; `achieved / peak / frac` repeat that entry.  The canonical algorithmic bytes of SURVEY.md
 §8d (27-cell structure, 16 + 27*4 + 16*K per evaluation) are kept as `algorithmic_bytes_per_launch`, NOT divided by
 the HBM peak: the shipped index never reads them (it reads 68 B per evaluation, from L2).
@@ -52,11 +55,13 @@ L2_PEAK_GBPS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 L2_LINE_BYTES = 128.0    # gfx950 L1 <-> L2 request granularity
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9         # sustained shader clock after the pre-warm (GRBM_GUI_ACTIVE / kernel time, profiles/)
-# cycles one wave64 VALU instruction occupies a SIMD, by class (profiles/r02*_valu_microbench.txt; fallback values = the
-# round-2 measurement): f32 add / sub / mul / fma issue at the full rate, transcendentals at a quarter of the half rate,
-# everything else (integer, compares, selects, moves, conversions, min / max, packed pairs, every f64 op) at half rate
-VALU_COST_FALLBACK = {"full": 2.4, "half": 4.3, "trans": 8.2}
-
+# cycles one wave64 VALU instruction occupies a SIMD, by class (profiles/r02*_valu_microbench.txt, two wavefronts per
+# SIMD; fallback values = the round-2 measurement): plain VOP2 f32 add / sub / mul, moves and the simple integer ops issue
+# at the full rate (~2.6), f32 fma / min / max / compares / selects / conversions / left shifts / three-operand and 64-bit
+# integer ops and every f64 op at half of it (~4.4), transcendentals at ~8.4
+VALU_COST_FALLBACK = {"full": 2.4, "half": 3.5, "trans": 6.5}
+L1_ACCESS_CEILING = 1.15  # cache-line accesses per cycle and CU: the rate the pre-cooperative kernel sat at while flat
+                          # against -15 % VALU and 2x loads in flight (profiles/r02b_C2_pmc_summary.csv); no documented peak
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -75,6 +80,8 @@ def parse():
     ap.add_argument("--cand-voxel-ratio", type=float, default=0.5)
     ap.add_argument("--cand-phase", type=float, default=0.5)
     ap.add_argument("--lik-tiled", type=int, default=1)
+    ap.add_argument("--lik-tiled-min", type=int, default=-1,
+                    help="scans of at least this many points take the tiled kernel (-1 = the library's default)")
     ap.add_argument("--lik-coop", type=int, default=-1,
                     help="quad-cooperative record fetch (-1 = the library's default, 1 = on, 0 = every lane fetches its "
                          "own record)")
@@ -126,18 +133,21 @@ def pmc_counters(kernel_prefix, workload):
 
 def valu_costs():
     """Cycles one wave64 VALU instruction occupies a SIMD, by class, from the newest committed run of
-    profiles/valu_microbench.hip (two wavefronts per SIMD — enough to saturate the pipe — column cyc@2.4GHz):
+    profiles/valu_microbench.hip (the version that places exactly W wavefronts on every SIMD: r02d onwards): column
+    tick/instr/SIMD (s_memtime shader cycles) at eight wavefronts per SIMD, the occupancy the likelihood kernels run at:
     full = mean of v_mul_f32 / v_add_f32, half = mean of v_max_f32 / v_cndmask-class rows, trans = v_sqrt_f32."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_microbench.txt")), reverse=True):
+        if os.path.basename(path) < "r02d":
+            continue  # earlier runs measured the dispatcher's uneven spread of 256-thread groups, not the pipe
         rows = {}
         for line in open(path):
             m = re.match(r"(v_\S+).*?\s+(\d)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s*$", line)
-            if m and "independent" in line and m.group(2) == "2":
-                rows[m.group(1)] = float(m.group(6))
-        full = [rows[k] for k in ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_fma_f32") if k in rows]
-        half = [rows[k] for k in ("v_max_f32", "v_min_f32", "v_cndmask_b32", "v_mov_b32", "v_and_b32", "v_cvt_flr_i32_f32",
-                                  "v_mul_u32_u24", "v_add_u32", "v_cmp_lt_f32") if k in rows]
+            if m and "independent" in line and m.group(2) == "8":
+                rows[m.group(1)] = float(m.group(3))  # tick/instr/SIMD: shader cycles, no launch overhead in it
+        full = [rows[k] for k in ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_mov_b32", "v_and_b32", "v_add_u32") if k in rows]
+        half = [rows[k] for k in ("v_max_f32", "v_min_f32", "v_fma_f32", "v_cvt_flr_i32_f32", "v_mul_u32_u24",
+                                  "v_cmp_lt_f32", "v_lshl_or_b32", "v_add_f64") if k in rows]
         trans = [rows[k] for k in ("v_sqrt_f32", "v_rcp_f32") if k in rows]
         if full and half and trans:
             return ({"full": sum(full) / len(full), "half": sum(half) / len(half), "trans": sum(trans) / len(trans)},
@@ -291,6 +301,9 @@ def main():
     eng.set_option("lik_small", args.lik_small)
     eng.set_option("overlap_models", args.overlap_models)
     eng.set_option("lik_group", args.lik_group)
+    if args.lik_tiled_min >= 0:
+        eng.set_option("lik_tiled_min", args.lik_tiled_min)
+    tiled_min = int(eng.get_option("lik_tiled_min"))
     if args.lik_coop >= 0:
         eng.set_option("lik_coop", args.lik_coop)
     lik_coop = int(eng.get_option("lik_coop"))
@@ -464,7 +477,7 @@ def main():
         value = evals_per_step * args.steps / elapsed
         lik_avg_ms = lik_ms / max(lik_n, 1)
         stats = main_sh.d_stats.cpu().numpy()
-        tiled = bool(args.lik_tiled and n_s >= 1024 and n_p >= 4) or bool(args.strict_order)
+        tiled = bool(args.lik_tiled and n_s >= tiled_min and n_p >= 4) or bool(args.strict_order)
         group = _tiled_group(n_s, n_p, args.lik_group)
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:
@@ -493,23 +506,32 @@ def main():
                 gbps = pmc["TCP_TCC_READ_REQ_sum"] * L2_LINE_BYTES / kernel_s / 1e9
                 res["l2"] = {"achieved": gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": gbps / L2_PEAK_GBPS,
                              "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": L2_LINE_BYTES}
+            if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc:
+                rate = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (kernel_s * CLOCK_HZ)
+                res["l1_access"] = {"achieved": rate, "peak": L1_ACCESS_CEILING, "unit": "cache-line accesses/cycle/CU",
+                                    "frac": min(rate / L1_ACCESS_CEILING, 1.0),
+                                    "accesses_per_launch": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                                    "note": "peak = measured ceiling (see bench.py L1_ACCESS_CEILING), not a datasheet value"}
             if "SQ_INSTS_VALU" in pmc:
-                # instruction mix from the per-class counters (separate PMC pass); what they do not cover is priced at the
-                # half rate — integer ops, compares, selects, moves, conversions
+                # instruction mix from the per-class counters (separate PMC pass). Known classes are priced exactly; what
+                # the counters do not split (32-bit integer ops, and everything unclassified: moves, DPP moves, compares,
+                # selects) is priced between the full and the half rate -> a low and a high estimate; `frac` is their mean
                 n_all = pmc["SQ_INSTS_VALU"]
-                n_full = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
-                                                        "SQ_INSTS_VALU_FMA_F32"))
-                n_trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
                 have_mix = "SQ_INSTS_VALU_ADD_F32" in pmc
-                if not have_mix:
-                    n_full = 0.0  # no class counters: every instruction priced at the half rate (upper bound)
-                n_half = max(n_all - n_full - n_trans, 0.0)
-                busy = n_full * cost["full"] + n_half * cost["half"] + n_trans * cost["trans"]
+                n_full = pmc.get("SQ_INSTS_VALU_ADD_F32", 0.0) + pmc.get("SQ_INSTS_VALU_MUL_F32", 0.0)
+                n_trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                n_half = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64",
+                                                        "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                        "SQ_INSTS_VALU_FMA_F64"))
+                n_mixed = max(n_all - n_full - n_trans - n_half, 0.0)
+                fixed = n_full * cost["full"] + n_half * cost["half"] + n_trans * cost["trans"]
                 avail = N_SIMD * kernel_s * CLOCK_HZ
-                res["valu_issue"] = {"achieved": busy / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
-                                     "unit": "G SIMD-cycles/s", "frac": min(busy / avail, 1.0), "frac_raw": busy / avail,
-                                     "wave_instructions_per_launch": n_all,
-                                     "full_rate_f32": n_full, "transcendental": n_trans, "half_rate_rest": n_half,
+                lo, hi = (fixed + n_mixed * cost["full"]) / avail, (fixed + n_mixed * cost["half"]) / avail
+                mid = 0.5 * (lo + hi)
+                res["valu_issue"] = {"achieved": mid * avail / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
+                                     "unit": "G SIMD-cycles/s", "frac": min(mid, 1.0), "frac_low": lo, "frac_high": hi,
+                                     "wave_instructions_per_launch": n_all, "full_rate": n_full, "half_rate": n_half,
+                                     "transcendental": n_trans, "between_full_and_half_rate": n_mixed,
                                      "cycles_per_instruction": cost, "cycles_per_instruction_source": cost_src,
                                      "mix_from_counters": have_mix}
         if res:

@@ -401,8 +401,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
 int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,
- * [3] device build time in ms. */
-int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4);
+ * [3] device build time in ms, [4] voxels with at least one candidate, [5] voxels with more candidates than their
+ * 64-byte record holds (4), [6] overflow records, [7] voxel edge / match_dist_min in use ([4]..[7]: lik_index 2). */
+int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats8);
 
 #ifdef __cplusplus
 }

@@ -641,6 +641,8 @@ class Engine:
         return float(v.value)
 
     def index_stats(self):
-        s = np.zeros(4, np.float64)
+        s = np.zeros(8, np.float64)
         self._check(self.lib.mcl3dl_hip_index_stats(self.h, _ptr(s)))
-        return dict(bricks=int(s[0]), preliminary=int(s[1]), candidates=int(s[2]), build_ms=float(s[3]))
+        return dict(bricks=int(s[0]), preliminary=int(s[1]), candidates=int(s[2]), build_ms=float(s[3]),
+                    voxels_with_candidates=int(s[4]), voxels_with_overflow=int(s[5]), overflow_records=int(s[6]),
+                    voxel_ratio=float(s[7]))

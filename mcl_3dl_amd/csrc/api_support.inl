@@ -100,6 +100,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_tiled = value != 0.0;
     return 0;
   }
+  if (key == "lik_tiled_min")
+  {
+    if (!(value >= 1.0 && value <= 1e9))
+      return ctx->fail(-3, "lik_tiled_min must be >= 1");
+    ctx->lik_tiled_min = static_cast<int>(value);
+    return 0;
+  }
   if (key == "lik_group")
   {
     if (value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0 && value != 32.0)
@@ -144,6 +151,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_small") *value = ctx->lik_small;
   else if (key == "lik_tiled") *value = ctx->lik_tiled;
   else if (key == "lik_group") *value = ctx->lik_group;
+  else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
   else if (key == "pf_fused") *value = ctx->pf_fused;
   else
@@ -151,11 +159,11 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   return 0;
 }
 
-int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats4)
+int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats8)
 {
-  if (!ctx || !stats4)
+  if (!ctx || !stats8)
     return -1;
-  for (int i = 0; i < 4; ++i)
-    stats4[i] = ctx->cand_stats[i];
+  for (int i = 0; i < 8; ++i)
+    stats8[i] = ctx->cand_stats[i];
   return 0;
 }

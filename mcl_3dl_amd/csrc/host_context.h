@@ -86,6 +86,7 @@ struct mcl3dl_hip_ctx
   int lik_index = 2;
   int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
+  int lik_tiled_min = 1024;  // scans of at least this many points take the tiled kernel
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
   int lik_coop = 1;        // tiled kernel: 1 = quad-cooperative record fetch + VALU-trimmed evaluation (same results)
   DevBuf lik_partial_sum, lik_partial_cnt;
@@ -103,7 +104,9 @@ struct mcl3dl_hip_ctx
   size_t cand_n_points = 0;
   CandGrid cg{};
   RecGrid rg{};
-  double cand_stats[4] = { 0, 0, 0, 0 };  // bricks, voxels with candidates, candidates, build ms
+  // bricks, preliminary candidates, candidates kept, build ms, voxels with candidates, voxels with overflow, overflow
+  // records, voxel edge / match_dist_min actually used
+  double cand_stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   DevBuf dda_bits, dda_start, dda_pts, dda_index;
   DdaGrid dg{};
   uint64_t footprint[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };

@@ -313,6 +313,7 @@ int rescaled_points(mcl3dl_hip_ctx* ctx, size_t first, size_t count, std::vector
 struct CompileOutput
 {
   unsigned long long total = 0, kept = 0;
+  unsigned long long hist2[2] = { 0, 0 };  // voxels with candidates, voxels with more than the record holds
   uint32_t n_ovf = 0;
   // CSR form (lik_index 1): kept counts per voxel stay in d_count, runs in d_pstart / d_prelim
   TempBuf d_count, d_pstart, d_prelim, d_ovf_data;
@@ -380,11 +381,16 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   TempBuf d_ovf;
   HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
   HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
+  TempBuf d_hist;
+  HIP_TRY(hipMalloc(&d_hist.p, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
-                     static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox);
+                     static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox,
+                     static_cast<unsigned long long*>(d_hist.p));
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
   uint32_t n_ovf = 0;
   TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
+  TRY(d2h(ctx, out->hist2, d_hist.p, 2 * sizeof(unsigned long long)));
   TRY(sync_stream(ctx));
   HIP_TRY(hipMalloc(&out->d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1)));
   HIP_TRY(hipMemsetAsync(out->d_ovf_data.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
@@ -478,6 +484,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     g.nby = cp.nby;
     g.nbz = cp.nbz;
     g.mul24_ok = (static_cast<long long>(cp.nbx) * cp.nby < (1ll << 24) && cp.nbz < (1 << 24)) ? 1 : 0;
+    g.off32_ok = (64ull * static_cast<unsigned long long>(n_vox) < (1ull << 32)) ? 1 : 0;
     ctx->footprint[5] = sizeof(int) * n_table;
     ctx->footprint[6] = 64ull * static_cast<size_t>(n_vox);
     ctx->footprint[7] = 64ull * n_ovf;
@@ -485,6 +492,10 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     ctx->cand_stats[1] = static_cast<double>(total);
     ctx->cand_stats[2] = static_cast<double>(kept);
     ctx->cand_stats[3] = ms2;
+    ctx->cand_stats[4] = static_cast<double>(co.hist2[0]);
+    ctx->cand_stats[5] = static_cast<double>(co.hist2[1]);
+    ctx->cand_stats[6] = n_ovf;
+    ctx->cand_stats[7] = cp.e / static_cast<double>(ctx->match_dist_min);
     ctx->cand_dirty = false;
     return 0;
   }
@@ -697,6 +708,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   ctx->rg.brick_table = ctx->cand_table.as<int>();
   ctx->rg.rec = ctx->cand_rec.as<float4>();
   ctx->rg.ovf = ctx->cand_ovf.as<float4>();
+  ctx->rg.off32_ok = (64ull * 512 * n_bricks < (1ull << 32)) ? 1 : 0;
   ctx->footprint[6] = 64ull * 512 * n_bricks;
   ctx->footprint[7] = 64ull * ctx->cand_n_ovf;
   ctx->cand_stats[0] = n_bricks;

@@ -84,7 +84,7 @@ struct LikPlan
 int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
 {
   const int np = static_cast<int>(n_p);
-  pl->tiled = (ctx->lik_tiled && ns >= 1024 && np >= 4) || ctx->strict_order;
+  pl->tiled = (ctx->lik_tiled && ns >= ctx->lik_tiled_min && np >= 4) || ctx->strict_order;
   // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
   // work-group slots something to do (few particles x a long scan would otherwise leave most of the GPU idle)
   int group_size = ctx->lik_group;

@@ -269,6 +269,12 @@ __device__ inline Vec3f qrot_trim(const Quat q, const Vec3f v)
 // each of the quad's four evaluations (the query travels by DPP), then a 4 x 4 transpose-min over the quad hands every
 // lane the minimum for its own query. Same candidates, same d2 expression, and a minimum does not care about order:
 // results identical to rec_min_d2.
+// any lane true? (the ballot straight from the compare: no 0/1 round trip through a VGPR)
+__device__ inline bool wave_any(bool p)
+{
+  return __builtin_amdgcn_ballot_w64(p) != 0ull;
+}
+
 template <int CTRL>
 __device__ inline float quad_f(float v)
 {
@@ -287,26 +293,45 @@ constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;                               
 __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, float qz, uint32_t vrec, bool valid, int lane)
 {
   const int j = lane & 3;
-  const float4* part = g.rec + j;
-  const float4 R0 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST0>(vrec))];
-  const float4 R1 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST1>(vrec))];
-  const float4 R2 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST2>(vrec))];
-  const float4 R3 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST3>(vrec))];
+  float4 R0, R1, R2, R3;
+  if (g.off32_ok)
+  {
+    // records below 4 GB: 32-bit byte offsets against the (uniform) base pointer — one v_add_u32 with a DPP operand per
+    // load instead of a broadcast, a 64-bit shift and a 64-bit add
+    const char* base = reinterpret_cast<const char*>(g.rec);
+    const uint32_t mine = vrec << 6, part = static_cast<uint32_t>(j) << 4;
+    R0 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST0>(mine) + part));
+    R1 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST1>(mine) + part));
+    R2 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST2>(mine) + part));
+    R3 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST3>(mine) + part));
+  }
+  else
+  {
+    const float4* part = g.rec + j;
+    R0 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST0>(vrec))];
+    R1 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST1>(vrec))];
+    R2 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST2>(vrec))];
+    R3 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST3>(vrec))];
+  }
   // candidate j of evaluation e against the query of lane e
   const float d0 = d2_simple(quad_f<QUAD_BCAST0>(qx), quad_f<QUAD_BCAST0>(qy), quad_f<QUAD_BCAST0>(qz), R0.x, R0.y, R0.z);
   const float d1 = d2_simple(quad_f<QUAD_BCAST1>(qx), quad_f<QUAD_BCAST1>(qy), quad_f<QUAD_BCAST1>(qz), R1.x, R1.y, R1.z);
   const float d2 = d2_simple(quad_f<QUAD_BCAST2>(qx), quad_f<QUAD_BCAST2>(qy), quad_f<QUAD_BCAST2>(qz), R2.x, R2.y, R2.z);
   const float d3 = d2_simple(quad_f<QUAD_BCAST3>(qx), quad_f<QUAD_BCAST3>(qy), quad_f<QUAD_BCAST3>(qz), R3.x, R3.y, R3.z);
   // 4 x 4 transpose-min: after the xor-1 step a lane holds min over {j, j^1} for evaluation (j & 1) resp. 2 + (j & 1);
-  // after the xor-2 step min over the whole quad for evaluation j
+  // after the xor-2 step min over the whole quad for evaluation j. A d2 is a sum of squares — never negative — so the
+  // float minimum is the minimum of the bit patterns as unsigned integers (NaN, from a non-finite query, orders above
+  // every number and every d2 of that query is NaN anyway): v_min_u32 takes the DPP operand directly and needs no
+  // canonicalisation of its inputs.
   const bool odd = (j & 1) != 0, high = (j & 2) != 0;
-  const float m01 = fminf(odd ? d1 : d0, quad_f<QUAD_XOR1>(odd ? d0 : d1));
-  const float m23 = fminf(odd ? d3 : d2, quad_f<QUAD_XOR1>(odd ? d2 : d3));
-  float best = fminf(high ? m23 : m01, quad_f<QUAD_XOR2>(high ? m01 : m23));
+  const uint32_t u0 = __float_as_uint(d0), u1 = __float_as_uint(d1), u2 = __float_as_uint(d2), u3 = __float_as_uint(d3);
+  const uint32_t m01 = min(odd ? u1 : u0, quad_u<QUAD_XOR1>(odd ? u0 : u1));
+  const uint32_t m23 = min(odd ? u3 : u2, quad_u<QUAD_XOR1>(odd ? u2 : u3));
+  float best = __uint_as_float(min(high ? m23 : m01, quad_u<QUAD_XOR2>(high ? m01 : m23)));
   // overflow (more than 4 candidates): rare. The counts of the quad's four records sit in lane 0 (part 0's w).
   const uint32_t c0 = __float_as_uint(R0.w), c1 = __float_as_uint(R1.w), c2 = __float_as_uint(R2.w), c3 = __float_as_uint(R3.w);
   const uint32_t cmax = max(max(c0, c1), max(c2, c3));
-  if (__ballot(j == 0 && cmax > 4u) != 0ull)
+  if (wave_any(j == 0 && cmax > 4u))
   {
     // count of MY record = part 0's w of record j, held by lane 0 of the quad; first overflow record = part 1's w, lane 1
     const uint32_t n0 = quad_u<QUAD_BCAST0>(c0), n1 = quad_u<QUAD_BCAST0>(c1), n2 = quad_u<QUAD_BCAST0>(c2),
@@ -357,7 +382,7 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
   const bool valid = inside && b >= 0;
   float term = 0.f;
   matched = false;
-  if (__ballot(valid) != 0ull)  // wave-uniform: a wavefront with nothing to look up skips the record loads
+  if (wave_any(valid))  // wave-uniform: a wavefront with nothing to look up skips the record loads
   {
     const uint32_t vrec = valid ? ((static_cast<uint32_t>(b) << 9) | sub) : 0u;
     const float d2 = rec_min_d2_quad(rg, qx, qy, qz, vrec, valid, lane);
@@ -621,7 +646,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
       bool matched;
       const float term = eval_coop(rg, prm, pos, rot, v, have_point, lane, matched);
       s_term[k][t] = term;
-      const unsigned long long m = __ballot(matched);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(matched);
       if (lane == 0)
         s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
     }

@@ -337,15 +337,26 @@ struct RecGrid
   float ox, oy, oz, inv_e;
   int nvx, nvy, nvz, nbx, nby, nbz;
   int mul24_ok;  // nbx * nby and every brick coordinate < 2^24: the table index can use 24-bit multiplies
+  int off32_ok;  // the record array is smaller than 4 GB: byte offsets fit 32 bits
 };
 
-__global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox)
+__global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox,
+                                  unsigned long long* __restrict__ hist2)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (v >= n_vox)
-    return;
-  const uint32_t c = kept_count[v];
-  n_ovf[v] = c > 4 ? (c - 4 + 4) / 5 : 0u;
+  const uint32_t c = v < n_vox ? kept_count[v] : 0u;
+  if (v < n_vox)
+    n_ovf[v] = c > 4 ? (c - 4 + 4) / 5 : 0u;
+  // hist2[0] = voxels with at least one candidate, hist2[1] = voxels whose candidates do not fit the record (the index
+  // picks its voxel edge from their ratio: host_map_compilers.h)
+  const unsigned long long m_any = __ballot(c > 0u), m_ovf = __ballot(c > 4u);
+  if (hist2 && (threadIdx.x & 63) == 0)
+  {
+    if (m_any)
+      atomicAdd(&hist2[0], static_cast<unsigned long long>(__popcll(m_any)));
+    if (m_ovf)
+      atomicAdd(&hist2[1], static_cast<unsigned long long>(__popcll(m_ovf)));
+  }
 }
 
 __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,

@@ -3,8 +3,8 @@
 // ("SQ_ACTIVE_INST_VALU 1.99e8 quad-cycles would read as 93 % if a wave64 f32 op held the pipe 4 cycles ...
 // settle it with a micro-benchmark").
 //
-// Every kernel: 256-thread work-groups (4 wavefronts, one per SIMD), grid = 256 CUs x W work-groups so that each SIMD
-// holds W wavefronts; each wavefront issues ITER x 64 instructions of one kind, either as 8 independent chains or as one
+// Every kernel: ONE work-group of 256 x W threads per CU (two of 1024 threads for W = 8), so that each SIMD holds exactly
+// W wavefronts; each wavefront issues ITER x 64 instructions of one kind, either as 8 independent chains or as one
 // dependent chain, between two s_memtime reads (shader cycles). Output per (instruction, chains, W):
 //   cycles per wave-instruction per SIMD = elapsed cycles / (instructions per wavefront x W)
 // Build: hipcc --offload-arch=gfx950 -O2 -o valu_microbench.bin valu_microbench.hip    Run: ./valu_microbench.bin
@@ -40,7 +40,7 @@ constexpr int ITER = 2048;
                : "v"(b))
 
 #define KERNEL32(NAME, INS)                                                                    \
-  __global__ __launch_bounds__(256) void NAME##_indep(float* out, long long* cyc)              \
+  __global__ __launch_bounds__(1024) void NAME##_indep(float* out, long long* cyc)              \
   {                                                                                            \
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,   \
           a6 = a0 + 6, a7 = a0 + 7, b = 1.0000001f;                                            \
@@ -51,11 +51,11 @@ constexpr int ITER = 2048;
       OP8_INDEP(INS); OP8_INDEP(INS); OP8_INDEP(INS); OP8_INDEP(INS);                          \
     }                                                                                          \
     const long long t1 = __builtin_readcyclecounter();                                         \
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
     if ((threadIdx.x & 63) == 0)                                                               \
-      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+      cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                                      \
   }                                                                                            \
-  __global__ __launch_bounds__(256) void NAME##_dep(float* out, long long* cyc)                \
+  __global__ __launch_bounds__(1024) void NAME##_dep(float* out, long long* cyc)                \
   {                                                                                            \
     float a0 = threadIdx.x, b = 1.0000001f;                                                    \
     const long long t0 = __builtin_readcyclecounter();                                         \
@@ -65,14 +65,14 @@ constexpr int ITER = 2048;
       OP8_DEP(INS); OP8_DEP(INS); OP8_DEP(INS); OP8_DEP(INS);                                  \
     }                                                                                          \
     const long long t1 = __builtin_readcyclecounter();                                         \
-    out[blockIdx.x * 256 + threadIdx.x] = a0;                                                  \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0;                                                  \
     if ((threadIdx.x & 63) == 0)                                                               \
-      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+      cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                                      \
   }
 
 // 64-bit register operands (packed f32 pairs, f64)
 #define KERNEL64(NAME, INS, TYPE)                                                              \
-  __global__ __launch_bounds__(256) void NAME##_indep(float* out, long long* cyc)              \
+  __global__ __launch_bounds__(1024) void NAME##_indep(float* out, long long* cyc)              \
   {                                                                                            \
     TYPE a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,    \
          a6 = a0 + 6, a7 = a0 + 7, b = 1.0000001;                                              \
@@ -83,11 +83,11 @@ constexpr int ITER = 2048;
       OP8_INDEP(INS); OP8_INDEP(INS); OP8_INDEP(INS); OP8_INDEP(INS);                          \
     }                                                                                          \
     const long long t1 = __builtin_readcyclecounter();                                         \
-    out[blockIdx.x * 256 + threadIdx.x] = static_cast<float>(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = static_cast<float>(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
     if ((threadIdx.x & 63) == 0)                                                               \
-      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+      cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                                      \
   }                                                                                            \
-  __global__ __launch_bounds__(256) void NAME##_dep(float* out, long long* cyc)                \
+  __global__ __launch_bounds__(1024) void NAME##_dep(float* out, long long* cyc)                \
   {                                                                                            \
     TYPE a0 = threadIdx.x, b = 1.0000001;                                                      \
     const long long t0 = __builtin_readcyclecounter();                                         \
@@ -97,9 +97,9 @@ constexpr int ITER = 2048;
       OP8_DEP(INS); OP8_DEP(INS); OP8_DEP(INS); OP8_DEP(INS);                                  \
     }                                                                                          \
     const long long t1 = __builtin_readcyclecounter();                                         \
-    out[blockIdx.x * 256 + threadIdx.x] = static_cast<float>(a0);                              \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = static_cast<float>(a0);                              \
     if ((threadIdx.x & 63) == 0)                                                               \
-      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+      cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                                      \
   }
 
 KERNEL32(mul_f32, "v_mul_f32")
@@ -115,7 +115,7 @@ struct F2
 {
   float x, y;
 };
-__global__ __launch_bounds__(256) void pk_mul_f32_indep(float* out, long long* cyc)
+__global__ __launch_bounds__(1024) void pk_mul_f32_indep(float* out, long long* cyc)
 {
   typedef float v2 __attribute__((ext_vector_type(2)));
   v2 a0 = { 1.f + threadIdx.x, 2.f }, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f,
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(256) void pk_mul_f32_indep(float* out, long long* c
   }
   const long long t1 = __builtin_readcyclecounter();
   const v2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-  out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
   if ((threadIdx.x & 63) == 0)
-    cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
-__global__ __launch_bounds__(256) void pk_mul_f32_dep(float* out, long long* cyc)
+__global__ __launch_bounds__(1024) void pk_mul_f32_dep(float* out, long long* cyc)
 {
   typedef float v2 __attribute__((ext_vector_type(2)));
   v2 a0 = { 1.f + threadIdx.x, 2.f }, b = { 1.0000001f, 0.9999999f };
@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void pk_mul_f32_dep(float* out, long long* cyc
     OP8_DEP("v_pk_mul_f32"); OP8_DEP("v_pk_mul_f32"); OP8_DEP("v_pk_mul_f32"); OP8_DEP("v_pk_mul_f32");
   }
   const long long t1 = __builtin_readcyclecounter();
-  out[blockIdx.x * 256 + threadIdx.x] = a0.x + a0.y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0.x + a0.y;
   if ((threadIdx.x & 63) == 0)
-    cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 // unary transcendental / conversion (one source)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void pk_mul_f32_dep(float* out, long long* cyc
                INS " %6, %6\n" INS " %7, %7"                                                                         \
                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
 #define UKERNEL(NAME, INS)                                                                     \
-  __global__ __launch_bounds__(256) void NAME##_indep(float* out, long long* cyc)              \
+  __global__ __launch_bounds__(1024) void NAME##_indep(float* out, long long* cyc)              \
   {                                                                                            \
     float a0 = 1.f + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4,          \
           a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;                                               \
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void pk_mul_f32_dep(float* out, long long* cyc
       UOP8_INDEP(INS); UOP8_INDEP(INS); UOP8_INDEP(INS); UOP8_INDEP(INS);                      \
     }                                                                                          \
     const long long t1 = __builtin_readcyclecounter();                                         \
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
     if ((threadIdx.x & 63) == 0)                                                               \
-      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+      cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                                      \
   }
 UKERNEL(sqrt_f32, "v_sqrt_f32")
 UKERNEL(rcp_f32, "v_rcp_f32")
@@ -189,7 +189,7 @@ KERNEL32(add_u32, "v_add_u32")
                : "v"(b)                                                                                               \
                : "vcc")
 #define XKERNEL(NAME, A, B)                                                                    \
-  __global__ __launch_bounds__(256) void NAME##_indep(float* out, long long* cyc)              \
+  __global__ __launch_bounds__(1024) void NAME##_indep(float* out, long long* cyc)              \
   {                                                                                            \
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,   \
           a6 = a0 + 6, a7 = a0 + 7, b = 1.0000001f;                                            \
@@ -200,9 +200,9 @@ KERNEL32(add_u32, "v_add_u32")
       XOP8(A, B); XOP8(A, B); XOP8(A, B); XOP8(A, B);                                          \
     }                                                                                          \
     const long long t1 = __builtin_readcyclecounter();                                         \
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
     if ((threadIdx.x & 63) == 0)                                                               \
-      cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                      \
+      cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                                      \
   }
 // A "%d" B : the text before / after the destination register
 XKERNEL(fma_f32, "v_fma_f32 ", ", %8, %8, %8")              // d = b*b + b  (no dependence on d: pure issue rate)
@@ -231,8 +231,8 @@ int main()
   const int cus = prop.multiProcessorCount;
   float* out;
   long long* cyc;
-  CHECK(hipMalloc(&out, sizeof(float) * 256 * cus * 8));
-  CHECK(hipMalloc(&cyc, sizeof(long long) * 4 * cus * 8));
+  CHECK(hipMalloc(&out, sizeof(float) * 1024 * cus * 2));
+  CHECK(hipMalloc(&cyc, sizeof(long long) * 16 * cus * 2));
   const int per = ITER * 64;
   const Entry entries[] = {
     { "v_mul_f32 x8 independent", mul_f32_indep, per },   { "v_mul_f32 dependent", mul_f32_dep, per },
@@ -256,21 +256,25 @@ int main()
   printf("device: %s, %d CUs, clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
   printf("%-36s %5s %14s %12s %12s %14s\n", "instruction", "W", "tick/instr/SIMD", "kernel ms", "ticks/ns", "cyc@2.4GHz");
   for (const Entry& e : entries)
-    for (int W : { 1, 2, 8 })
+    for (int W : { 1, 2, 4, 8 })
     {
-      const int blocks = cus * W;
+      // W wavefronts per SIMD by construction: a work-group's wavefronts go round the CU's four SIMDs, so one work-group
+      // of 256 x W threads per CU (two of 1024 for W = 8) puts exactly W on each — grids of 256-thread groups are NOT
+      // spread evenly by the dispatcher (the first version of this benchmark measured that instead)
+      const int threads = 256 * (W < 4 ? W : 4);
+      const int blocks = cus * (W <= 4 ? 1 : W / 4);
       hipEvent_t a, b;
       CHECK(hipEventCreate(&a));
       CHECK(hipEventCreate(&b));
-      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, cyc);  // warm-up
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, cyc);  // warm-up
       CHECK(hipDeviceSynchronize());
       CHECK(hipEventRecord(a));
-      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, cyc);
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, out, cyc);
       CHECK(hipEventRecord(b));
       CHECK(hipDeviceSynchronize());
       float ms = 0;
       CHECK(hipEventElapsedTime(&ms, a, b));
-      std::vector<long long> h(4 * blocks);
+      std::vector<long long> h(static_cast<size_t>(threads / 64) * blocks);
       CHECK(hipMemcpy(h.data(), cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
       double mean = 0;
       for (long long v : h)

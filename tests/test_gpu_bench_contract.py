@@ -36,7 +36,7 @@ def test_single_gpu_line():
         assert k in r, k
     # the fractions come from committed PMC passes of the same workload (profiles/); C1 has none, then they are null —
     # but whatever is reported is a fraction of a real resource: <= 1, and the headline repeats the binding one
-    assert r["bound"] in ("hbm", "l2", "valu_issue")
+    assert r["bound"] in ("hbm", "l2", "l1_access", "valu_issue")
     for name, e in r["resources"].items():
         assert 0.0 < e["frac"] <= 1.0, (name, e)
         assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-9

@@ -91,7 +91,11 @@ def test_incremental_map_update_equals_a_fresh_index(ref, n_s):
         inc.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=DW)
         base_lik, _, _ = inc.measure_batch(sc.poses, sc.scan_lik)   # builds the index
         true_pos = sc.true_pose[:3]
-        updates = [furniture(rng, 4000, true_pos + np.array([1.5, 0.5, 0.0])),
+        # update 0: a new surface 0.12 m in front of the walls the scan sees (so the scores must move); update 1: a box in
+        # the room; update 2: nothing (the update is withdrawn)
+        near = sc.map_xyz[np.linalg.norm(sc.map_xyz - true_pos, axis=1) < 4.0]
+        inward = (true_pos - near) / np.linalg.norm(true_pos - near, axis=1, keepdims=True)
+        updates = [(near + 0.12 * inward + rng.normal(0, 0.004, near.shape)).astype(np.float32),
                    furniture(rng, 2500, true_pos + np.array([-0.5, 1.8, 0.2])),
                    np.zeros((0, 3), np.float32)]
         leaf = (0.2, 0.2, 0.2)
@@ -102,17 +106,16 @@ def test_incremental_map_update_equals_a_fresh_index(ref, n_s):
             assert n_map == len(merged)
             np.testing.assert_array_equal(inc.map_download()[0], merged)
             # incremental, not a rebuild: a few dozen bricks of the ~thousands, well under the full build time
-            assert 0 < stats["bricks_recompiled"] < 400, stats
             full_bricks = inc.index_stats()["bricks"]
-            assert stats["bricks_recompiled"] < full_bricks // 4
+            assert 0 < stats["bricks_recompiled"] < full_bricks // 2, (stats, full_bricks)
             fresh.set_map(merged, None, stamp=100 + step, dist_weight=DW)
             got = inc.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
             want = fresh.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
             for g, w in zip(got, want):
                 np.testing.assert_array_equal(g, w)
-            if len(upd):
+            if step == 0:
                 assert not np.array_equal(got[0], base_lik)   # the update really changes the scores
-            else:
+            elif len(upd) == 0:
                 np.testing.assert_array_equal(got[0], base_lik)  # update removed: back to the base map's answers
             print("update %d: %s; full build %.2f ms" % (step, stats, fresh.index_stats()["build_ms"]))
         # radius search (cell grid) and beam status (DDA grid) see the merged map too
