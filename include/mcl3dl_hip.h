@@ -286,9 +286,10 @@ int mcl3dl_hip_scan_download(mcl3dl_hip_ctx* ctx, int which, float* xyz, uint32_
  * VoxelGrid(update, update_downsample); a later update REPLACES the earlier one (n = 0 removes it). The candidate-voxel
  * index is not rebuilt: only the bricks within reach of a removed or an added point are compiled again (from the points
  * that can reach them) and installed over their old records — results identical to a fresh index of the merged map.
- * stats5 (may be NULL) = {bricks re-compiled, bricks added, points that took part, device milliseconds, overflow
- * records appended}; all zero when the update fell back to a full rebuild on next use (nothing built yet, a point outside
- * the grid the index was laid out for, lik_index != 2).
+ * stats6 (may be NULL) = {bricks re-compiled, bricks added, points that took part, device milliseconds, overflow
+ * records appended, outcome}; outcome 0 = incremental update done; otherwise the index is rebuilt as a whole on next use:
+ * 1 nothing was built yet, 2 lik_index != 2, 3 the index was built for another point count, 4 a point outside the grid
+ * the index was laid out for, 5 brick / overflow budget exhausted; 6 = no brick touched (nothing to do).
  * map_download: the map as the engine holds it (base, then update). */
 int mcl3dl_hip_set_map_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step, int off_x,
                                    int off_y, int off_z, int off_label, const float* leaf3, uint64_t stamp,
@@ -296,10 +297,10 @@ int mcl3dl_hip_set_map_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, siz
 int mcl3dl_hip_set_map_downsampled(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n,
                                    const float* leaf3, uint64_t stamp, const float* dist_weight, size_t* n_map);
 int mcl3dl_hip_map_update(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, const float* leaf3,
-                          uint64_t stamp, size_t* n_map, double* stats5);
+                          uint64_t stamp, size_t* n_map, double* stats6);
 int mcl3dl_hip_map_update_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
                                       int off_x, int off_y, int off_z, int off_label, const float* leaf3, uint64_t stamp,
-                                      size_t* n_map, double* stats5);
+                                      size_t* n_map, double* stats6);
 int mcl3dl_hip_map_download(mcl3dl_hip_ctx* ctx, float* xyz, uint32_t* label, size_t capacity, size_t* n);
 /* Replaces the matched / unmatched classification of src/mcl_3dl.cpp:761-805 as ONE device pass: every point of
  * pc_local_full (xyz NULL: the cloud mcl3dl_hip_scan_begin left on the device; otherwise n explicit robot-frame points)

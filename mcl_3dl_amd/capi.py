@@ -534,27 +534,30 @@ class Engine:
                                                             _ptr(self._f3(dist_weight)), C.byref(n)))
         return int(n.value)
 
+    @staticmethod
+    def _update_stats(st):
+        return dict(bricks_recompiled=int(st[0]), bricks_added=int(st[1]), points_involved=int(st[2]),
+                    device_ms=float(st[3]), overflow_appended=int(st[4]), outcome=int(st[5]))
+
     def map_update(self, xyz, label=None, leaf=(0.2, 0.2, 0.2), stamp=2):
         """pc_map2 = pc_map + VoxelGrid(update); returns (n_map, stats dict)."""
         pts = _np_f32(xyz if xyz is not None else np.zeros((0, 3)), 3)
         lab = None if label is None else np.ascontiguousarray(label, dtype=np.uint32)
         n = C.c_size_t(0)
-        st = np.zeros(5, np.float64)
+        st = np.zeros(6, np.float64)
         self._check(self.lib.mcl3dl_hip_map_update(self.h, _ptr(pts), _ptr(lab), len(pts), _ptr(self._f3(leaf)), int(stamp),
                                                    C.byref(n), _ptr(st)))
-        return int(n.value), dict(bricks_recompiled=int(st[0]), bricks_added=int(st[1]), points_involved=int(st[2]),
-                                  device_ms=float(st[3]), overflow_appended=int(st[4]))
+        return int(n.value), self._update_stats(st)
 
     def map_update_pointcloud2(self, data, n_points, point_step, off_x, off_y, off_z, off_label=-1, leaf=(0.2, 0.2, 0.2),
                                stamp=2):
         buf = np.frombuffer(bytes(data), dtype=np.uint8)
         n = C.c_size_t(0)
-        st = np.zeros(5, np.float64)
+        st = np.zeros(6, np.float64)
         self._check(self.lib.mcl3dl_hip_map_update_pointcloud2(self.h, _ptr(buf), n_points, point_step, off_x, off_y, off_z,
                                                                off_label, _ptr(self._f3(leaf)), int(stamp), C.byref(n),
                                                                _ptr(st)))
-        return int(n.value), dict(bricks_recompiled=int(st[0]), bricks_added=int(st[1]), points_involved=int(st[2]),
-                                  device_ms=float(st[3]), overflow_appended=int(st[4]))
+        return int(n.value), self._update_stats(st)
 
     def map_download(self):
         n = C.c_size_t(0)

@@ -573,10 +573,12 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
 {
   const size_t n_total = ctx->map_xyz.size() / 3;
   if (stats5)
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
       stats5[i] = 0;
   if (ctx->cand_dirty || ctx->lik_index != 2 || ctx->cand_n_points != n_base + old_update.size())
   {
+    if (stats5)
+      stats5[5] = ctx->cand_dirty ? 1 : ctx->lik_index != 2 ? 2 : 3;
     ctx->cand_dirty = true;
     return 0;
   }
@@ -593,6 +595,8 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
     for (int a = 0; a < 3; ++a)
       if (v[a] - cp.reach - 1 < 0 || v[a] + cp.reach + 1 >= nv[a])
       {
+        if (stats5)
+          stats5[5] = 4;
         ctx->cand_dirty = true;
         return 0;
       }
@@ -641,6 +645,8 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   const uint32_t n_bricks_old = ctx->cand_n_bricks;
   if (n_dirty == 0)
   {
+    if (stats5)
+      stats5[5] = 6;
     ctx->cand_n_points = n_total;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
@@ -649,6 +655,8 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   if (static_cast<unsigned long long>(n_bricks_old) + n_new > (1u << 22) ||
       ctx->cand_ovf_leaked > std::max<uint32_t>(4096u, ctx->cand_n_ovf / 2))
   {
+    if (stats5)
+      stats5[5] = 5;
     ctx->cand_dirty = true;  // too many bricks, or too many orphaned overflow records: start over
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

@@ -43,6 +43,7 @@ def bench(name, args, timeout=600):
         return None
 
 
+sh("python -m pytest tests/test_gpu_map_path.py -m gpu -q -x 2>&1 | tail -40", "pytest_map.log", 600)
 sh("python -m pytest tests -m gpu -q 2>&1 | tail -60", "pytest.log", 1800)
 sh("./profiles/valu_microbench.bin", "valu_microbench.txt", 300)
 quick = "--steps 20 --warmup 3 --no-extras --no-cpu-baseline"

@@ -153,7 +153,6 @@ def test_matched_unmatched_split(engine):
     # The node builds its kd-tree with max_search_radius = 0.4 but searches with unmatch_output_dist = 0.5: across a 20 m
     # chunk border the reference itself can miss a neighbour between 0.4 and 0.5 m away (chunked_kdtree.h:139-201). The
     # engine returns the global nearest neighbour; the oracle here gets a border margin that covers the radius.
-    ref = pyoracle.Oracle("ref", max_search_radius=0.6)
     sc = make_scene(n=91, n_p=4, n_s=3000, seed=6)
     rng = np.random.default_rng(1)
     cloud = np.concatenate([sc.scan_lik, sc.scan_lik[:800] + rng.normal(0, 0.08, (800, 3)).astype(np.float32),
@@ -161,6 +160,7 @@ def test_matched_unmatched_split(engine):
     for dw in (DW, None):
         engine.set_map(sc.map_xyz, sc.map_label, stamp=8201, dist_weight=dw)
         engine.set_likelihood_params()
+        ref = pyoracle.Oracle("ref", max_search_radius=0.6)  # a fresh kd-tree: its point representation is set once
         ref.set_map(sc.map_xyz, sc.map_label, dist_weight=dw)
         pose = sc.true_pose.copy()
         pose[3:7] *= np.float32(1.7)  # transform() normalises the quaternion
