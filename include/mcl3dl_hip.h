@@ -377,7 +377,8 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
 /* Tuning knobs (no reference counterpart; results are identical for every setting):
  *   "lik_index"         2 (default) = candidate-voxel index, one 64-byte record per voxel; 1 = candidate-voxel index,
  *                       CSR runs; 0 = 27-cell scan of the cell-sorted map
- *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min (default 0.5)
+ *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min; 0 (default) = chosen per map: 0.5, or 0.36 when more than a
+ *                       quarter of the voxels hold more candidates than a record has room for
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
  *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points and >= 4 particles; 0 = one
  *                       work-group per particle always (only the fp64 summation order differs)

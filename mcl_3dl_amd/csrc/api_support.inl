@@ -63,8 +63,8 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   }
   if (key == "cand_voxel_ratio")
   {
-    if (!(value >= 0.125 && value <= 2.0))
-      return ctx->fail(-3, "cand_voxel_ratio must be in [0.125, 2]");
+    if (value != 0.0 && !(value >= 0.125 && value <= 2.0))
+      return ctx->fail(-3, "cand_voxel_ratio must be 0 (chosen per map) or in [0.125, 2]");
     if (value != ctx->cand_voxel_ratio)
       ctx->cand_dirty = true;
     ctx->cand_voxel_ratio = value;

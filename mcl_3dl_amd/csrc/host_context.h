@@ -93,7 +93,7 @@ struct mcl3dl_hip_ctx
   int pf_fused = 1;        // 1 = pf::measure as ONE kernel up to PF_FUSED_MAX particles on one GPU (same bits, two launches fewer)
   int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
   DevBuf scan_perm, strict_terms;
-  double cand_voxel_ratio = 0.5;  // voxel edge / match_dist_min
+  double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
   // kept for map updates (host_map_compilers.h:update_cand_grid): geometry, sizes, every rescaled map point

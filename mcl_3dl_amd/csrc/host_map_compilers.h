@@ -239,10 +239,11 @@ struct TempBuf
 };
 
 // Geometry of the candidate-voxel grid for a point set with the given bounds (rescaled coordinates).
-int cand_geometry(mcl3dl_hip_ctx* ctx, const float mn[3], const float mx[3], CompileParams* out, long long* n_table_out)
+int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const float mn[3], const float mx[3], CompileParams* out,
+                  long long* n_table_out)
 {
   const double r = static_cast<double>(ctx->match_dist_min);
-  const float e_f = static_cast<float>(r * ctx->cand_voxel_ratio);
+  const float e_f = static_cast<float>(r * voxel_ratio);
   if (!(e_f > 0.f) || !std::isfinite(e_f))
     return ctx->fail(-3, "bad candidate voxel edge");
   CompileParams cp{};
@@ -393,7 +394,15 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   TRY(d2h(ctx, out->hist2, d_hist.p, 2 * sizeof(unsigned long long)));
   TRY(sync_stream(ctx));
   HIP_TRY(hipMalloc(&out->d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1)));
-  HIP_TRY(hipMemsetAsync(out->d_ovf_data.p, 0, 64ull * (n_ovf ? n_ovf : 1), ctx->stream));
+  {
+    // unused candidate slots of an overflow record hold the sentinel, like those of a voxel record
+    const long long words = 16ll * (n_ovf ? n_ovf : 1);
+    uint32_t sentinel_bits;
+    const float sentinel = REC_SENTINEL;
+    memcpy(&sentinel_bits, &sentinel, sizeof(sentinel_bits));
+    hipLaunchKernelGGL(mc_fill_u32, dim3(static_cast<unsigned>((words + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<uint32_t*>(out->d_ovf_data.p), sentinel_bits, words);
+  }
   hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
                      static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
                      static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p), rec_out,
@@ -403,7 +412,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   return 0;
 }
 
-int build_cand_grid(mcl3dl_hip_ctx* ctx)
+int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
 {
   const size_t n = ctx->map_xyz.size() / 3;
   hipEvent_t ev0, ev1;
@@ -415,7 +424,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   TRY(rescaled_points(ctx, 0, n, sp, mn, mx));
   CompileParams cp{};
   long long n_table = 0;
-  TRY(cand_geometry(ctx, mn, mx, &cp, &n_table));
+  TRY(cand_geometry(ctx, voxel_ratio, mn, mx, &cp, &n_table));
   cp.n_points = static_cast<int>(n);
 
   // the rescaled points stay on the device: a map update (update_cand_grid) re-compiles single bricks from them
@@ -539,6 +548,24 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   ctx->cand_stats[2] = static_cast<double>(kept);
   ctx->cand_stats[3] = ms;
   ctx->cand_dirty = false;
+  return 0;
+}
+
+// The voxel edge: option "cand_voxel_ratio" x match_dist_min, or — ratio 0, the default — chosen from the map itself: r / 2
+// unless more than a quarter of the voxels with candidates hold more than the four a record has room for (maps of
+// voxel-filter centroids rather than lattice points: DESIGN.md section 6), then 0.36 r: the second fetch round per
+// evaluation costs more than the larger table (measured: jittered C2 0.49 -> 0.37 ms, lattice C2 +2 %).
+int build_cand_grid(mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->cand_voxel_ratio > 0.0)
+    return build_cand_grid_at(ctx, ctx->cand_voxel_ratio);
+  TRY(build_cand_grid_at(ctx, 0.5));
+  if (ctx->lik_index == 2 && ctx->cand_stats[4] > 0 && ctx->cand_stats[5] / ctx->cand_stats[4] > 0.25)
+  {
+    const double first_ms = ctx->cand_stats[3];
+    TRY(build_cand_grid_at(ctx, 0.36));
+    ctx->cand_stats[3] += first_ms;
+  }
   return 0;
 }
 
@@ -699,10 +726,15 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
     HIP_TRY(hipMemcpyAsync(ctx->cand_ovf.as<char>() + 64ull * ovf_base, co.d_ovf_data.p, 64ull * co.n_ovf,
                            hipMemcpyDeviceToDevice, ctx->stream));
   }
+  TempBuf d_orphan;
+  HIP_TRY(hipMalloc(&d_orphan.p, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_orphan.p, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_install_records, dim3(static_cast<unsigned>((n_sub_vox + 255) / 256)), dim3(256), 0, ctx->stream,
-                     static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_sub_vox,
-                     ctx->cand_rec.as<float4>());
+                     static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_bricks_old,
+                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p));
   HIP_TRY(hipGetLastError());
+  unsigned long long orphaned = 0;
+  TRY(d2h(ctx, &orphaned, d_orphan.p, sizeof(orphaned)));
   HIP_TRY(hipEventRecord(ev1, ctx->stream));
   TRY(sync_stream(ctx));
   float ms = 0.f;
@@ -711,7 +743,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   (void)hipEventDestroy(ev1);
   ctx->cand_n_bricks = n_bricks;
   ctx->cand_n_ovf = ovf_base + co.n_ovf;
-  ctx->cand_ovf_leaked += co.n_ovf;  // upper bound of what the replaced bricks orphaned: they had about as many
+  ctx->cand_ovf_leaked += static_cast<uint32_t>(orphaned);  // reclaimed by the next full rebuild
   ctx->cand_n_points = n_total;
   ctx->rg.brick_table = ctx->cand_table.as<int>();
   ctx->rg.rec = ctx->cand_rec.as<float4>();

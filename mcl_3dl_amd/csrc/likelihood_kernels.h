@@ -156,7 +156,7 @@ __global__ void radius_search_kernel(const float* __restrict__ query_xyz, int n,
 // (map_compiler.h:mc_write_records), four 16-byte parts:
 //     part j = { candidate j: x, y, z ; w }      w of part 0 = candidate count, w of part 1 = first overflow record
 // candidates 0..3 inline (unused slots hold REC_SENTINEL coordinates: their d2 never wins a minimum and never passes the
-// radius test), candidates 4.. in overflow records {xyz[5], pad}. One part per lane of a quad is what the tiled kernel's
+// radius test), candidates 4.. in overflow records of the same four-part layout. One part per lane of a quad is what the tiled kernel's
 // cooperative fetch reads (below).
 
 // floor to int in ONE instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for
@@ -188,15 +188,16 @@ __device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz
          static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
 }
 
-// min d2 over the candidates a voxel's overflow records hold (candidates 4 .. count - 1)
+// min d2 over the candidates a voxel's overflow records hold (candidates 4 .. count - 1; four per 64-byte record, laid
+// out like the voxel record itself: part j = {x, y, z, -})
 __device__ inline float rec_overflow_min(const RecGrid& g, float qx, float qy, float qz, uint32_t count, uint32_t ext,
                                          float best)
 {
-  const float* o = reinterpret_cast<const float*>(g.ovf) + 16 * static_cast<size_t>(ext);
+  const float4* o = g.ovf + 4 * static_cast<size_t>(ext);
   for (uint32_t j = 0; j < count - 4; ++j)
   {
-    const float* s = o + 16 * (j / 5) + 3 * (j % 5);
-    const float d = d2_simple(qx, qy, qz, s[0], s[1], s[2]);
+    const float4 c = o[j];
+    const float d = d2_simple(qx, qy, qz, c.x, c.y, c.z);
     best = d < best ? d : best;
   }
   return best;
@@ -288,18 +289,21 @@ __device__ inline uint32_t quad_u(uint32_t v)
 constexpr int QUAD_BCAST0 = 0x00, QUAD_BCAST1 = 0x55, QUAD_BCAST2 = 0xAA, QUAD_BCAST3 = 0xFF;  // quad_perm:[e,e,e,e]
 constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;                                              // [1,0,3,2], [2,3,0,1]
 
-// Every lane of the wavefront must be active here (DPP reads 0 from an inactive lane). vrec = the lane's own record
-// index (0 for a lane without one: it reads record 0 and ignores the answer); returns min d2 for the lane's own query.
-__device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, float qz, uint32_t vrec, bool valid, int lane)
+// One cooperative round: the quad fetches the 64-byte records `rec_index` of its four lanes from `recs` (lane j reads
+// part j of each), lane j computes candidate j of evaluation e against the query of lane e, and the 4 x 4 transpose-min
+// returns to every lane the minimum over the four candidates of ITS record. w[e] = the w word of the part this lane read
+// of record e (part 0's w = count, part 1's w = first overflow record). Every lane of the wavefront must be active (DPP
+// reads 0 from an inactive lane); a lane without a record passes any valid index and ignores the answer.
+__device__ inline float quad_round(const float4* recs, bool off32, uint32_t rec_index, float qx, float qy, float qz, int j,
+                                   uint32_t (&w)[4])
 {
-  const int j = lane & 3;
   float4 R0, R1, R2, R3;
-  if (g.off32_ok)
+  if (off32)
   {
-    // records below 4 GB: 32-bit byte offsets against the (uniform) base pointer — one v_add_u32 with a DPP operand per
+    // array below 4 GB: 32-bit byte offsets against the (uniform) base pointer — one v_add_u32 with a DPP operand per
     // load instead of a broadcast, a 64-bit shift and a 64-bit add
-    const char* base = reinterpret_cast<const char*>(g.rec);
-    const uint32_t mine = vrec << 6, part = static_cast<uint32_t>(j) << 4;
+    const char* base = reinterpret_cast<const char*>(recs);
+    const uint32_t mine = rec_index << 6, part = static_cast<uint32_t>(j) << 4;
     R0 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST0>(mine) + part));
     R1 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST1>(mine) + part));
     R2 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST2>(mine) + part));
@@ -307,11 +311,11 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
   }
   else
   {
-    const float4* part = g.rec + j;
-    R0 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST0>(vrec))];
-    R1 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST1>(vrec))];
-    R2 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST2>(vrec))];
-    R3 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST3>(vrec))];
+    const float4* part = recs + j;
+    R0 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST0>(rec_index))];
+    R1 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST1>(rec_index))];
+    R2 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST2>(rec_index))];
+    R3 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST3>(rec_index))];
   }
   // candidate j of evaluation e against the query of lane e
   const float d0 = d2_simple(quad_f<QUAD_BCAST0>(qx), quad_f<QUAD_BCAST0>(qy), quad_f<QUAD_BCAST0>(qz), R0.x, R0.y, R0.z);
@@ -321,27 +325,45 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
   // 4 x 4 transpose-min: after the xor-1 step a lane holds min over {j, j^1} for evaluation (j & 1) resp. 2 + (j & 1);
   // after the xor-2 step min over the whole quad for evaluation j. A d2 is a sum of squares — never negative — so the
   // float minimum is the minimum of the bit patterns as unsigned integers (NaN, from a non-finite query, orders above
-  // every number and every d2 of that query is NaN anyway): v_min_u32 takes the DPP operand directly and needs no
-  // canonicalisation of its inputs.
+  // every number and every d2 of that query is NaN anyway): v_min_u32 needs no canonicalisation of its inputs.
   const bool odd = (j & 1) != 0, high = (j & 2) != 0;
   const uint32_t u0 = __float_as_uint(d0), u1 = __float_as_uint(d1), u2 = __float_as_uint(d2), u3 = __float_as_uint(d3);
   const uint32_t m01 = min(odd ? u1 : u0, quad_u<QUAD_XOR1>(odd ? u0 : u1));
   const uint32_t m23 = min(odd ? u3 : u2, quad_u<QUAD_XOR1>(odd ? u2 : u3));
-  float best = __uint_as_float(min(high ? m23 : m01, quad_u<QUAD_XOR2>(high ? m01 : m23)));
-  // overflow (more than 4 candidates): rare. The counts of the quad's four records sit in lane 0 (part 0's w).
-  const uint32_t c0 = __float_as_uint(R0.w), c1 = __float_as_uint(R1.w), c2 = __float_as_uint(R2.w), c3 = __float_as_uint(R3.w);
-  const uint32_t cmax = max(max(c0, c1), max(c2, c3));
+  w[0] = __float_as_uint(R0.w);
+  w[1] = __float_as_uint(R1.w);
+  w[2] = __float_as_uint(R2.w);
+  w[3] = __float_as_uint(R3.w);
+  return __uint_as_float(min(high ? m23 : m01, quad_u<QUAD_XOR2>(high ? m01 : m23)));
+}
+
+// vrec = the lane's own record index (0 for a lane without one: it reads record 0 and ignores the answer); returns
+// min d2 over ALL candidates of the lane's voxel: the inline four, then — while any lane of the wavefront still has
+// candidates left — one overflow record per round, fetched and reduced the same cooperative way.
+__device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, float qz, uint32_t vrec, bool valid, int lane)
+{
+  const int j = lane & 3;
+  uint32_t w[4];
+  float best = quad_round(g.rec, g.off32_ok != 0, vrec, qx, qy, qz, j, w);
+  // overflow (more than 4 candidates): the counts of the quad's four records sit in lane 0 (part 0's w)
+  const uint32_t cmax = max(max(w[0], w[1]), max(w[2], w[3]));
   if (wave_any(j == 0 && cmax > 4u))
   {
     // count of MY record = part 0's w of record j, held by lane 0 of the quad; first overflow record = part 1's w, lane 1
-    const uint32_t n0 = quad_u<QUAD_BCAST0>(c0), n1 = quad_u<QUAD_BCAST0>(c1), n2 = quad_u<QUAD_BCAST0>(c2),
-                   n3 = quad_u<QUAD_BCAST0>(c3);
-    const uint32_t e0 = quad_u<QUAD_BCAST1>(c0), e1 = quad_u<QUAD_BCAST1>(c1), e2 = quad_u<QUAD_BCAST1>(c2),
-                   e3 = quad_u<QUAD_BCAST1>(c3);
+    const uint32_t n0 = quad_u<QUAD_BCAST0>(w[0]), n1 = quad_u<QUAD_BCAST0>(w[1]), n2 = quad_u<QUAD_BCAST0>(w[2]),
+                   n3 = quad_u<QUAD_BCAST0>(w[3]);
+    const uint32_t e0 = quad_u<QUAD_BCAST1>(w[0]), e1 = quad_u<QUAD_BCAST1>(w[1]), e2 = quad_u<QUAD_BCAST1>(w[2]),
+                   e3 = quad_u<QUAD_BCAST1>(w[3]);
     const uint32_t count = j == 0 ? n0 : j == 1 ? n1 : j == 2 ? n2 : n3;
     const uint32_t ext = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
-    if (valid && count > 4u)
-      best = rec_overflow_min(g, qx, qy, qz, count, ext, best);
+    const uint32_t rounds = (valid && count > 4u) ? (count - 4u + 3u) / 4u : 0u;
+    for (uint32_t r = 0; wave_any(r < rounds); ++r)
+    {
+      const bool more = r < rounds;
+      uint32_t unused[4];
+      const float m = quad_round(g.ovf, false, more ? ext + r : 0u, qx, qy, qz, j, unused);
+      best = (more && m < best) ? m : best;
+    }
   }
   return best;
 }

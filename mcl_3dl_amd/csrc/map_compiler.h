@@ -325,7 +325,7 @@ __global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* _
 // One 64-byte record per voxel of every allocated brick, so a query is ONE cache line after the brick table. Four 16-byte
 // parts, one per lane of a quad in the tiled kernel's cooperative fetch:
 //   part j   : { candidate j: x, y, z ; w }   w of part 0 = candidate count, w of part 1 = first overflow record (count > 4)
-//   overflow : { xyz[5], pad }                 contiguous, candidates 4, 5, ... five per record
+//   overflow : the same four-part layout       contiguous, candidates 4, 5, ... four per record (unused slots: sentinel)
 // Unused candidate slots hold REC_SENTINEL coordinates.
 constexpr float REC_SENTINEL = 1.0e18f;
 
@@ -346,7 +346,7 @@ __global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint3
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint32_t c = v < n_vox ? kept_count[v] : 0u;
   if (v < n_vox)
-    n_ovf[v] = c > 4 ? (c - 4 + 4) / 5 : 0u;
+    n_ovf[v] = c > 4 ? (c - 4 + 3) / 4 : 0u;
   // hist2[0] = voxels with at least one candidate, hist2[1] = voxels whose candidates do not fit the record (the index
   // picks its voxel edge from their ratio: host_map_compilers.h)
   const unsigned long long m_any = __ballot(c > 0u), m_ovf = __ballot(c > 4u);
@@ -397,7 +397,7 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
     {
       const float4 p = pts[prelim[src + k] & 0x7fffffffu];
       const uint32_t j = k - 4;
-      float* slot = o + 16 * (j / 5) + 3 * (j % 5);
+      float* slot = o + 4 * j;  // record j / 4, part j % 4
       slot[0] = p.x;
       slot[1] = p.y;
       slot[2] = p.z;
@@ -483,15 +483,24 @@ __global__ void mc_compact_points(const float4* __restrict__ pts, const uint32_t
 }
 
 // copies the freshly compiled records of the dirty bricks into the main array; overflow references are rebased onto the
-// main overflow array, where the new overflow records were appended at ovf_base
+// main overflow array, where the new overflow records were appended at ovf_base. The overflow records the replaced
+// voxels of EXISTING bricks referenced become orphans: counted into *orphaned.
 __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int* __restrict__ sub_main, uint32_t ovf_base,
-                                   long long n_sub_vox, float4* __restrict__ rec)
+                                   uint32_t n_bricks_old, long long n_sub_vox, float4* __restrict__ rec,
+                                   unsigned long long* __restrict__ orphaned)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_sub_vox)
     return;
   const int sub = static_cast<int>(v >> 9);
-  const size_t dst = (static_cast<size_t>(sub_main[sub]) << 9) | static_cast<size_t>(v & 511);
+  const uint32_t brick = static_cast<uint32_t>(sub_main[sub]);
+  const size_t dst = (static_cast<size_t>(brick) << 9) | static_cast<size_t>(v & 511);
+  if (brick < n_bricks_old)
+  {
+    const uint32_t old_count = __float_as_uint(rec[4 * dst].w);
+    if (old_count > 4u)
+      atomicAdd(orphaned, static_cast<unsigned long long>((old_count - 4u + 3u) / 4u));
+  }
   const float4 r0 = sub_rec[4 * v];
   float4 r1 = sub_rec[4 * v + 1];
   if (__float_as_uint(r0.w) > 4u)

@@ -47,7 +47,7 @@ def test_candidate_index_on_irregular_maps(engine, name, dist_weight):
                 assert st["candidates"] > 0
     finally:
         engine.set_option("lik_index", 2)
-        engine.set_option("cand_voxel_ratio", 0.5)
+        engine.set_option("cand_voxel_ratio", 0.0)
         engine.set_option("cand_phase", 0.5)
         engine.set_option("lik_tiled", 1)
         engine.set_likelihood_params()

@@ -234,7 +234,7 @@ def test_candidate_index_equals_cell_scan_bit_for_bit(engine, scene_c1, dist_wei
         assert 0 < st["candidates"] <= st["preliminary"]
     finally:
         engine.set_option("lik_index", 2)
-        engine.set_option("cand_voxel_ratio", 0.5)
+        engine.set_option("cand_voxel_ratio", 0.0)
         engine.set_option("cand_phase", 0.5)
     np.testing.assert_array_equal(lik1, lik0)
     np.testing.assert_array_equal(ratio1, ratio0)
@@ -449,3 +449,42 @@ def test_small_scan_kernel(engine, oracle_kind, n_s, mode):
     wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
     np.testing.assert_allclose(lik1, wl, rtol=RTOL)
     np.testing.assert_array_equal(ratio1, wq)
+
+
+def test_voxel_edge_is_chosen_from_the_map_and_overflow_rounds_are_exact(engine, oracle_kind):
+    """A map of voxel-filter centroids (lattice points displaced inside their voxel) fills most candidate voxels beyond the
+    four slots of a record: the index then picks the smaller voxel edge, and what still overflows is fetched in further
+    cooperative rounds. Results: equal to the non-cooperative kernel bit for bit, and to the reference."""
+    sc = make_scene(n=91, n_p=64, n_s=1500, seed=12, map_jitter=0.045)
+    dw = (1.0, 1.0, 1.0)
+    d_coop = engine.get_option("lik_coop")
+    out = {}
+    try:
+        for ratio in (0.0, 0.5):   # chosen per map / forced large voxels (more overflow rounds)
+            engine.set_option("cand_voxel_ratio", ratio)
+            setup_engine(engine, sc, dw, stamp=90)
+            for coop in (0, 1):
+                engine.set_option("lik_coop", coop)
+                out[(ratio, coop)] = engine.measure_batch(sc.poses, sc.scan_lik)
+            st = engine.index_stats()
+            share = st["voxels_with_overflow"] / max(st["voxels_with_candidates"], 1)
+            if ratio == 0.0:
+                assert abs(st["voxel_ratio"] - 0.36) < 1e-6, st   # the jittered map made the index shrink its voxels
+            else:
+                assert abs(st["voxel_ratio"] - 0.5) < 1e-6 and share > 0.25, st
+    finally:
+        engine.set_option("cand_voxel_ratio", 0.0)
+        engine.set_option("lik_coop", d_coop)
+    ref = out[(0.5, 0)]
+    for k, v in out.items():
+        np.testing.assert_array_equal(v[0], ref[0])
+        np.testing.assert_array_equal(v[1], ref[1])
+    o = make_oracle(oracle_kind, sc, dw)
+    wl, wq = o.likelihood_measure(sc.poses, sc.scan_lik)
+    np.testing.assert_allclose(ref[0], wl, rtol=RTOL)
+    np.testing.assert_array_equal(ref[1], wq)
+    # a lattice map keeps the large voxels
+    sc2 = make_scene(n=91, n_p=8, n_s=64, seed=12)
+    setup_engine(engine, sc2, dw, stamp=91)
+    engine.measure_batch(sc2.poses, sc2.scan_lik)
+    assert abs(engine.index_stats()["voxel_ratio"] - 0.5) < 1e-6
