@@ -104,6 +104,8 @@ def parse():
                     help="1 = reference float summation order (bit-identical likelihoods and weights; slower)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
+    ap.add_argument("--also-other-scaling", action="store_true",
+                    help="time the other scaling mode too even with one rank (exercises the N > 1 reporting path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys (post-update reductions, resampling, fused update, route A, jitter check)")
@@ -462,7 +464,7 @@ def main():
 
     # the other scaling mode, same K steps, same bracketing (only when there is more than one rank to tell them apart)
     other = None
-    if world > 1:
+    if world > 1 or args.also_other_scaling:
         other_sh = Shard("strong" if args.scaling == "weak" else "weak")
         for _ in range(max(args.warmup, 3)):
             step(other_sh)

@@ -394,6 +394,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
  *                       (single GPU; costs an n_s x n_p float buffer and two serial passes)
+ *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
+ *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
+ *                       results either way.
  *   "pf_fused"          1 (default) = pf::measure of the single-GPU entry points runs as ONE work-group up to 4096 particles
  *                       (the reference's operating range is launch-bound); 0 = always partial + reduce + apply.
  *                       Same bits either way.

@@ -316,6 +316,38 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
 {
   if (!ctx)
     return -1;
+  // Large scans are ordered on the device (host_cloud.h:device_order_scans: raw points up, min / key / stable radix sort /
+  // gather there — same keys, same order, same bits as the host ordering, which costs ~0.1 ms of one core at 16 k points);
+  // small ones on the host, where a dozen launches would cost more than the sort.
+  if (ctx->scan_order_device > 0 && n_s + n_b >= static_cast<size_t>(ctx->scan_order_device))
+  {
+    if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
+      return ctx->fail(-3, "null scan array");
+    if (n_s > 0x7fffffffu || n_b > 0x7fffffffu)
+      return ctx->fail(-3, "scan too large");
+    if (scan_beam_origin)
+      for (size_t i = 0; i < n_b; ++i)
+        if (scan_beam_origin[i] >= n_o)
+          return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, scan_beam_origin[i], n_o);
+    HIP_TRY(hipSetDevice(ctx->device));
+    TRY(ensure(ctx, ctx->cl_err, sizeof(int)));
+    TRY(upload_cloud(ctx, scan_lik_xyz, nullptr, n_s, ctx->sp_samp[0]));
+    TRY(upload_cloud(ctx, scan_beam_xyz, scan_beam_origin, n_b, ctx->sp_samp[1]));
+    TRY(device_order_scans(ctx, n_s, n_b, origins, n_o));
+    if (sync_at_end)
+      TRY(sync_stream(ctx));
+    if (n_b > ctx->pow_table_len)
+      ctx->pow_table_dirty = true;
+    if (n_s != ctx->n_s || n_b != ctx->n_b || n_o != ctx->n_o || !ctx->has_scan)
+      ++ctx->generation;
+    ctx->n_s = n_s;
+    ctx->n_b = n_b;
+    ctx->n_o = n_o;
+    ctx->has_scan = true;
+    ctx->sp_n_samp[0] = n_s;
+    ctx->sp_n_samp[1] = n_b;
+    return 0;
+  }
   std::string err;
   if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, ctx->h_scan) != 0)
     return ctx->fail(-3, "%s", err.c_str());

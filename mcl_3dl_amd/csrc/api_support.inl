@@ -114,6 +114,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_group = static_cast<int>(value);
     return 0;
   }
+  if (key == "scan_order_device")
+  {
+    if (!(value >= 0.0 && value <= 2e9))
+      return ctx->fail(-3, "scan_order_device must be >= 0");
+    ctx->scan_order_device = static_cast<int>(value);
+    return 0;
+  }
   if (key == "pf_fused")
   {
     ctx->pf_fused = value != 0.0;
@@ -154,6 +161,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
   else if (key == "pf_fused") *value = ctx->pf_fused;
+  else if (key == "scan_order_device") *value = ctx->scan_order_device;
   else
     return ctx->fail(-3, "unknown option '%s'", name);
   return 0;

@@ -126,10 +126,11 @@ struct mcl3dl_hip_ctx
 
   // point-cloud preparation on the device (api_cloud.inl, cloud_kernels.h)
   DevBuf sort_tmp, cl_blocks, cl_minmax, cl_key[2], cl_val[2], cl_scan, cl_scan_ws, cl_start, cl_in_xyz, cl_in_label, cl_idx,
-      cl_err;
+      cl_idx2, cl_err;
   DevBuf sp_raw, sp_full, sp_clip[2], sp_samp[2];   // accumulated cloud, voxel-filtered, clipped (lik / beam), sampled
   size_t sp_n_full = 0, sp_n_clip[2] = { 0, 0 }, sp_n_samp[2] = { 0, 0 };
   bool sp_ready = false;
+  int scan_order_device = 4096;  // scans of at least this many points (both models together) are ordered on the device; 0 = never
   size_t n_base = 0;  // points of the base map; anything behind them in map_xyz is the current map update
   DevBuf ms_xyz, ms_out, ms_flag[2];
 

@@ -25,6 +25,7 @@ using namespace mcl3dl;
 #include "host_context.h"
 #include "host_map_compilers.h"
 #include "host_measure.h"
+#include "host_cloud.h"
 #include "host_group.h"
 
 // =================================================================================================================

@@ -56,3 +56,14 @@ def test_distributed_path_with_one_rank():
     assert d["n_gpus"] == 1 and d["cpu_baseline"] is None
     assert "1 all-reduce/update" in d["config"]["parallelism"]
     assert d["value"] > 1e8
+
+
+def test_strong_scaling_mode_and_the_multi_rank_report_with_one_rank():
+    """--scaling strong splits the workload's particles over the ranks; with N > 1 the line also carries the other mode
+    (`other_scaling`) and the collective's share. One rank here: N = 1 strong == weak == the plain run's particle count."""
+    d = run_bench("--force-dist", "--no-cpu-baseline", "--no-extras", "--scaling", "strong", "--also-other-scaling")
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    assert d["config"]["particles_total"] == d["config"]["particles_per_gpu"] == 64
+    o = d["other_scaling"]
+    assert o["scaling"] == "weak" and o["particles_total"] == 64 and o["value"] > 1e8
+    assert d["kernels_ms_per_step"]["collective"] > 0.0

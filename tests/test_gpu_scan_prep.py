@@ -186,3 +186,37 @@ def test_scan_finish_rejects_bad_draws(engine):
     engine.scan_finish(np.zeros(0, np.uint32), None)   # empty scans are fine: (1, 0) results downstream
     with pytest.raises(capi.EngineError, match="empty clipped cloud"):
         engine.scan_finish(np.array([0], np.uint32), None)
+
+
+def test_scans_ordered_on_the_device_equal_scans_ordered_on_the_host(engine):
+    """upload_scan orders large scans on the device (option scan_order_device) and small ones on the host: same keys, same
+    stable order — the permutation is identical, so every result is, bit for bit (also strict_order, which replays the
+    terms in ORIGINAL scan order through that permutation). The scan holds exact duplicates and many points per Morton cell."""
+    sc = make_scene(n=91, n_p=50, n_s=5000, n_b=300, seed=14)
+    lik = np.concatenate([sc.scan_lik, sc.scan_lik[:700], sc.scan_lik[:50] + np.float32(1e-4)], 0)
+    beam = np.concatenate([sc.scan_beam, sc.scan_beam[:40]], 0)
+    blab = np.concatenate([sc.scan_beam_label, sc.scan_beam_label[:40]], 0)
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=8301, dist_weight=(1.0, 1.0, 2.0))
+    engine.set_likelihood_params()
+    engine.set_beam_params(num_points=len(beam))
+    d = engine.get_option("scan_order_device")
+    out = {}
+    try:
+        for strict in (0, 1):
+            engine.set_option("strict_order", strict)
+            for where in (0, 1):
+                engine.set_option("scan_order_device", where)   # 0 = host, 1 = device for every size
+                out[(strict, where)] = engine.measure_batch(sc.poses, lik, beam, blab, sc.origins)
+    finally:
+        engine.set_option("scan_order_device", d)
+        engine.set_option("strict_order", 0)
+    for strict in (0, 1):
+        for a, b in zip(out[(strict, 0)], out[(strict, 1)]):
+            np.testing.assert_array_equal(a, b)
+    from mcl_3dl_amd import capi
+    engine.set_option("scan_order_device", 1)
+    try:
+        with pytest.raises(capi.EngineError, match="names origin"):
+            engine.measure_batch(sc.poses, lik, beam, np.full(len(beam), 3, np.uint32), sc.origins)
+    finally:
+        engine.set_option("scan_order_device", d)
