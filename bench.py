@@ -722,8 +722,8 @@ def main():
             # robot) — only the touched bricks of the candidate-voxel index are re-compiled; next to it the whole-map build
             full_ms = eng.index_stats()["build_ms"]
             tp = sc.true_pose[:3]
-            dist = np.linalg.norm(sc.map_xyz - tp, axis=1)
-            near = sc.map_xyz[np.argsort(dist)[:max(len(sc.map_xyz) // 100, 16)]]
+            range_to_pose = np.linalg.norm(sc.map_xyz - tp, axis=1)
+            near = sc.map_xyz[np.argsort(range_to_pose)[:max(len(sc.map_xyz) // 100, 16)]]
             inward = (tp - near) / np.maximum(np.linalg.norm(tp - near, axis=1, keepdims=True), 1e-6)
             upd = (near + 0.12 * inward).astype(np.float32)
             t8 = time.perf_counter()
