@@ -243,6 +243,62 @@ def route_a(sc, dist_weight, n_b, reps):
                         "once per update, weights normalised by the reference's pf.h on the CPU)"}
 
 
+def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
+    """SURVEY.md 8f-2 / 8f-4 timings (run last: they replace the context's scan): scan preparation of an accumulated cloud
+    (VoxelGrid with the node's default leaf, both clips, sample gather, device-side ordering) and the matched / unmatched
+    split of the down-sampled cloud for one pose, each next to the reference's code path on one host core."""
+    rng = np.random.default_rng(4)
+    reps = max(60000 // max(len(sc.scan_lik), 1), 1) + 1
+    raw = np.concatenate([sc.scan_lik + rng.normal(0, 0.02, sc.scan_lik.shape).astype(np.float32) for _ in range(reps)], 0)
+    raw = np.ascontiguousarray(raw[:max(60000, 4 * n_s)], dtype=np.float32)
+    leaf = (0.1, 0.1, 0.05)   # downsample_x / _y / _z defaults, src/parameters.cpp:88-90
+    clip_lik, clip_beam = (0.5, 10.0, -2.0, 2.0), (0.5, 4.0, -2.0, 2.0)
+    origins = np.array([[0.0, 0.0, 0.5]], np.float32)
+    n_full, n_lik, n_beam = eng.scan_begin(raw, None, leaf=leaf, clip_lik=clip_lik, clip_beam=clip_beam)
+    ns, nb = min(n_s, max(n_lik, 1)), (min(n_b, max(n_beam, 1)) if n_b else 0)
+    def once():
+        f, l, b = eng.scan_begin(raw, None, leaf=leaf, clip_lik=clip_lik, clip_beam=clip_beam)
+        il = rng.integers(0, max(l, 1), ns).astype(np.uint32)
+        ib = rng.integers(0, max(b, 1), nb).astype(np.uint32) if nb else None
+        eng.scan_finish(il, ib, origins=origins)
+    for _ in range(3):
+        once()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        once()
+    prep_ms = (time.perf_counter() - t0) / 10 * 1e3
+    res = {"scan_preparation": {"ms": prep_ms, "raw_points": int(len(raw)), "after_voxel_grid": int(n_full),
+                                "after_clip": [int(n_lik), int(n_beam)], "sampled": [int(ns), int(nb)], "leaf": list(leaf),
+                                "what": "mcl3dl_hip_scan_begin + _scan_finish: H2D of the accumulated cloud, VoxelGrid, both clip "
+                                        "filters, gather of the drawn samples, device-side scan ordering (host wall time, index "
+                                        "draw included)"}}
+    pose = np.asarray(sc.true_pose, np.float32)
+    eng.scan_begin(raw, None, leaf=leaf, clip_lik=clip_lik, clip_beam=clip_beam)
+    eng.match_split(pose)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        m, u = eng.match_split(pose)
+    res["match_split"] = {"ms": (time.perf_counter() - t0) / 10 * 1e3, "points": int(n_full), "matched": int(len(m)),
+                          "unmatched": int(len(u)),
+                          "what": "mcl3dl_hip_match_split of the down-sampled cloud left on the device (src/mcl_3dl.cpp:761-805): "
+                                  "count pass + output pass + D2H of both clouds"}
+    if with_cpu:
+        from oracle import pyoracle
+        if pyoracle.available("ref"):
+            orc = pyoracle.Oracle("ref")
+            orc.set_likelihood_params(pyoracle.LikelihoodParams(num_points=ns))
+            orc.set_beam_params(pyoracle.BeamParams(num_points=max(nb, 1)))
+            t0 = time.perf_counter()
+            full, full_label = orc.voxel_grid(raw, None, leaf)
+            orc.filter_uniform(0, full, full_label, 1, max(ns, 1))
+            if nb:
+                orc.filter_uniform(1, full, full_label, 2, max(nb, 1))
+            res["scan_preparation"]["cpu_reference_ms"] = (time.perf_counter() - t0) * 1e3
+            res["scan_preparation"]["cpu_note"] = ("restated pcl::VoxelGrid + the reference's filter() and PointCloudUniformSampler, "
+                                                   "1 thread (oracle/_ref)")
+    return res
+
+
 def main():
     args = parse()
     import torch
@@ -752,6 +808,8 @@ def main():
             out["map_jitter"] = {"jitter_m": args.jitter_check, "likelihood_ms": jm / max(jn, 1),
                                  "vs_lattice": (jm / max(jn, 1)) / lik_avg_ms if lik_avg_ms else None,
                                  "index": eng.index_stats()}
+        if world == 1 and not args.no_extras:
+            out.update(cloud_path_extras(eng, sc, n_s, n_b, with_cpu=not args.no_cpu_baseline))
         line = json.dumps(out)
     if use_dist:
         dist.barrier()

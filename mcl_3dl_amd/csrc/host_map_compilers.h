@@ -306,6 +306,12 @@ int rescaled_points(mcl3dl_hip_ctx* ctx, size_t first, size_t count, std::vector
   return 0;
 }
 
+// size of a device array for a buffer-load descriptor: its bytes when they fit 32 bits, else 0 (64-bit addressing)
+uint32_t bytes32(unsigned long long bytes)
+{
+  return bytes < (1ull << 32) ? static_cast<uint32_t>(bytes) : 0u;
+}
+
 // The compiler proper: for the bricks `table` names (ids 0 .. n_bricks - 1, every other entry -1; bxyz = their brick
 // coordinates) and the points `pts` (cp.n_points of them, device), the candidate set of every voxel: D^2 scatter ->
 // preliminary lists -> domination prune -> 64-byte records into rec_out[n_bricks * 512 * 16 floats] (device) with their
@@ -445,10 +451,12 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
   TRY(sync_stream(ctx));
   if (n_bricks == 0 || n_bricks > (1u << 22))
     return ctx->fail(-4, "candidate index: %u bricks", n_bricks);
-  TRY(ensure(ctx, ctx->cand_table, sizeof(int) * n_table));
+  // one entry more than the grid has bricks: entry n_table is always -1, the entry lanes without a voxel read (eval_coop)
+  TRY(ensure(ctx, ctx->cand_table, sizeof(int) * (n_table + 1)));
   int* table = ctx->cand_table.as<int>();
   hipLaunchKernelGGL(mc_brick_ids, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const int*>(d_flag.p), static_cast<const uint32_t*>(d_scan.p), table, n_table);
+  HIP_TRY(hipMemsetAsync(table + n_table, 0xff, sizeof(int), ctx->stream));
   HIP_TRY(hipMalloc(&d_bxyz.p, sizeof(int) * 3 * n_bricks));
   hipLaunchKernelGGL(mc_brick_coords, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
                      table, cp.nbx, cp.nby, n_table, static_cast<int*>(d_bxyz.p));
@@ -494,6 +502,9 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
     g.nbz = cp.nbz;
     g.mul24_ok = (static_cast<long long>(cp.nbx) * cp.nby < (1ll << 24) && cp.nbz < (1 << 24)) ? 1 : 0;
     g.off32_ok = (64ull * static_cast<unsigned long long>(n_vox) < (1ull << 32)) ? 1 : 0;
+    g.rec_bytes32 = bytes32(64ull * static_cast<unsigned long long>(n_vox));
+    g.ovf_bytes32 = bytes32(64ull * (n_ovf ? n_ovf : 1));
+    g.ti_empty = static_cast<uint32_t>(n_table);
     ctx->footprint[5] = sizeof(int) * n_table;
     ctx->footprint[6] = 64ull * static_cast<size_t>(n_vox);
     ctx->footprint[7] = 64ull * n_ovf;
@@ -749,6 +760,8 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   ctx->rg.rec = ctx->cand_rec.as<float4>();
   ctx->rg.ovf = ctx->cand_ovf.as<float4>();
   ctx->rg.off32_ok = (64ull * 512 * n_bricks < (1ull << 32)) ? 1 : 0;
+  ctx->rg.rec_bytes32 = bytes32(64ull * 512 * n_bricks);
+  ctx->rg.ovf_bytes32 = bytes32(64ull * (ctx->cand_n_ovf ? ctx->cand_n_ovf : 1));
   ctx->footprint[6] = 64ull * 512 * n_bricks;
   ctx->footprint[7] = 64ull * ctx->cand_n_ovf;
   ctx->cand_stats[0] = n_bricks;

@@ -289,25 +289,41 @@ __device__ inline uint32_t quad_u(uint32_t v)
 constexpr int QUAD_BCAST0 = 0x00, QUAD_BCAST1 = 0x55, QUAD_BCAST2 = 0xAA, QUAD_BCAST3 = 0xFF;  // quad_perm:[e,e,e,e]
 constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E;                                              // [1,0,3,2], [2,3,0,1]
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline float4 buffer_load_f4(__amdgpu_buffer_rsrc_t rs, uint32_t byte_offset)
+{
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<int>(byte_offset), 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// lanes (as a 64-bit mask, straight from the compare: no 0/1 round trip through a VGPR) where a > b, unsigned
+__device__ inline unsigned long long lanes_gt_u32(uint32_t a, uint32_t b)
+{
+  return __builtin_amdgcn_uicmp(a, b, 34 /* ICMP_UGT */);
+}
+constexpr unsigned long long QUAD_LANE0_MASK = 0x1111111111111111ull;
+
 // One cooperative round: the quad fetches the 64-byte records `rec_index` of its four lanes from `recs` (lane j reads
 // part j of each), lane j computes candidate j of evaluation e against the query of lane e, and the 4 x 4 transpose-min
 // returns to every lane the minimum over the four candidates of ITS record. w[e] = the w word of the part this lane read
 // of record e (part 0's w = count, part 1's w = first overflow record). Every lane of the wavefront must be active (DPP
 // reads 0 from an inactive lane); a lane without a record passes any valid index and ignores the answer.
-__device__ inline float quad_round(const float4* recs, bool off32, uint32_t rec_index, float qx, float qy, float qz, int j,
-                                   uint32_t (&w)[4])
+__device__ inline float quad_round(const float4* recs, uint32_t bytes32, uint32_t rec_index, float qx, float qy, float qz,
+                                   int j, uint32_t (&w)[4])
 {
   float4 R0, R1, R2, R3;
-  if (off32)
+  if (bytes32)
   {
-    // array below 4 GB: 32-bit byte offsets against the (uniform) base pointer — one v_add_u32 with a DPP operand per
-    // load instead of a broadcast, a 64-bit shift and a 64-bit add
-    const char* base = reinterpret_cast<const char*>(recs);
+    // array below 4 GB: buffer loads — the (uniform) base sits in a scalar resource descriptor and the lane supplies a
+    // 32-bit byte offset: one v_add_u32 with a DPP operand per load, no 64-bit address arithmetic. An offset past
+    // `bytes32` (the record index of a lane without a voxel is arbitrary) reads zeros instead of faulting.
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(recs), 0, static_cast<int>(bytes32), 0x00020000);
     const uint32_t mine = rec_index << 6, part = static_cast<uint32_t>(j) << 4;
-    R0 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST0>(mine) + part));
-    R1 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST1>(mine) + part));
-    R2 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST2>(mine) + part));
-    R3 = *reinterpret_cast<const float4*>(base + (quad_u<QUAD_BCAST3>(mine) + part));
+    R0 = buffer_load_f4(rs, quad_u<QUAD_BCAST0>(mine) + part);
+    R1 = buffer_load_f4(rs, quad_u<QUAD_BCAST1>(mine) + part);
+    R2 = buffer_load_f4(rs, quad_u<QUAD_BCAST2>(mine) + part);
+    R3 = buffer_load_f4(rs, quad_u<QUAD_BCAST3>(mine) + part);
   }
   else
   {
@@ -344,10 +360,10 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
 {
   const int j = lane & 3;
   uint32_t w[4];
-  float best = quad_round(g.rec, g.off32_ok != 0, vrec, qx, qy, qz, j, w);
+  float best = quad_round(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w);
   // overflow (more than 4 candidates): the counts of the quad's four records sit in lane 0 (part 0's w)
   const uint32_t cmax = max(max(w[0], w[1]), max(w[2], w[3]));
-  if (wave_any(j == 0 && cmax > 4u))
+  if ((lanes_gt_u32(cmax, 4u) & QUAD_LANE0_MASK) != 0ull)
   {
     // count of MY record = part 0's w of record j, held by lane 0 of the quad; first overflow record = part 1's w, lane 1
     const uint32_t n0 = quad_u<QUAD_BCAST0>(w[0]), n1 = quad_u<QUAD_BCAST0>(w[1]), n2 = quad_u<QUAD_BCAST0>(w[2]),
@@ -361,7 +377,7 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
     {
       const bool more = r < rounds;
       uint32_t unused[4];
-      const float m = quad_round(g.ovf, false, more ? ext + r : 0u, qx, qy, qz, j, unused);
+      const float m = quad_round(g.ovf, g.ovf_bytes32, more ? ext + r : 0u, qx, qy, qz, j, unused);
       best = (more && m < best) ? m : best;
     }
   }
@@ -391,35 +407,32 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
                                   bool have_point, int lane, bool& matched)
 {
   const Vec3f tp = vadd(qrot_trim(rot, Vec3f{ v.x, v.y, v.z }), pos);
-  float qx = tp.x, qy = tp.y, qz = tp.z;
-  if (prm.has_weight)  // wave-uniform; x * 1.0f == x, so skipping the multiplies changes nothing
-  {
-    qx = tp.x * prm.wx;
-    qy = tp.y * prm.wy;
-    qz = tp.z * prm.wz;
-  }
+  // rescale by dist_weight; without one the weights are 1.0f and x * 1.0f == x bit for bit: no select needed
+  const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
   uint32_t ti, sub;
   const bool inside = rec_locate(rg, qx, qy, qz, ti, sub) && have_point;
-  const int b = rg.brick_table[inside ? ti : 0u];
-  const bool valid = inside && b >= 0;
-  float term = 0.f;
-  matched = false;
+  // a lane without a voxel reads the table's extra last entry, which is always -1: `valid` is then ONE compare, and its
+  // ballot comes straight from that compare
+  const int b = rg.brick_table[inside ? ti : rg.ti_empty];
+  const bool valid = b >= 0;
+  float dist = -1.0f;
   if (wave_any(valid))  // wave-uniform: a wavefront with nothing to look up skips the record loads
   {
-    const uint32_t vrec = valid ? ((static_cast<uint32_t>(b) << 9) | sub) : 0u;
+    // with buffer loads (array below 4 GB) the record index of an invalid lane may be anything: no select
+    const uint32_t rec = (static_cast<uint32_t>(b) << 9) | sub;
+    const uint32_t vrec = rg.rec_bytes32 ? rec : (valid ? rec : 0u);
     const float d2 = rec_min_d2_quad(rg, qx, qy, qz, vrec, valid, lane);
     if (valid && d2 < prm.r2)
     {
       const float s = sqrt_in_radius(d2);
-      const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
-      if (!(dist < 0.0f))
-      {
-        term = dist * prm.match_weight;
-        matched = true;
-      }
+      // likelihood.cpp:128 `s > flat ? s : flat`: s is a finite non-negative root here, so v_max_f32 gives the same float
+      dist = prm.match_dist_min - fmaxf(s, prm.match_dist_flat);
     }
   }
-  return term;
+  // likelihood.cpp:129 `if (dist < 0.0) continue;` — one compare decides both the count and the term; max(dist, 0) * w
+  // is dist * w for a match (dist >= 0) and 0 otherwise (the -1 of a lane without a neighbour)
+  matched = !(dist < 0.0f);
+  return fmaxf(dist, 0.0f) * prm.match_weight;
 }
 
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)

@@ -338,6 +338,8 @@ struct RecGrid
   int nvx, nvy, nvz, nbx, nby, nbz;
   int mul24_ok;  // nbx * nby and every brick coordinate < 2^24: the table index can use 24-bit multiplies
   int off32_ok;  // the record array is smaller than 4 GB: byte offsets fit 32 bits
+  uint32_t rec_bytes32, ovf_bytes32;  // size of rec / ovf in bytes when below 4 GB (buffer loads), else 0
+  uint32_t ti_empty;                  // index of the table's extra last entry, always -1 (lanes without a voxel read it)
 };
 
 __global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox,
