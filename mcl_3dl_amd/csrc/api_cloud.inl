@@ -132,6 +132,7 @@ int map_from_device(mcl3dl_hip_ctx* ctx, const float4* src, size_t n, size_t kee
   std::vector<float> xyz(3 * n);
   std::vector<uint32_t> lab(n);
   TRY(download_cloud(ctx, src, n, xyz.data(), lab.data()));
+  ctx->map_dev_valid = false;
   ctx->map_xyz.resize(3 * keep);
   ctx->map_label.resize(keep);
   ctx->map_xyz.insert(ctx->map_xyz.end(), xyz.begin(), xyz.end());

@@ -107,6 +107,7 @@ int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* la
     return ctx->fail(-3, "map too large (index must fit 32 bits)");
   HIP_TRY(hipSetDevice(ctx->device));
   ctx->map_xyz.assign(xyz, xyz + 3 * n_m);
+  ctx->map_dev_valid = false;
   if (label)
     ctx->map_label.assign(label, label + n_m);
   else

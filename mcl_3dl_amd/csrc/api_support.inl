@@ -131,6 +131,17 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_coop = value != 0.0;
     return 0;
   }
+  if (key == "grid_build_host")
+  {
+    const int v = value != 0.0;
+    if (v != ctx->grid_build_host)
+    {
+      ctx->grid_build_host = v;
+      ctx->lik_dirty = ctx->dda_dirty = true;
+      ++ctx->generation;
+    }
+    return 0;
+  }
   if (key == "cand_phase")
   {
     if (!(value >= 0.0 && value < 1.0))
@@ -160,6 +171,11 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_group") *value = ctx->lik_group;
   else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
+  else if (key == "grid_build_host") *value = ctx->grid_build_host;
+  else if (key == "lik_grid_build_ms") *value = ctx->grid_build_ms[0];
+  else if (key == "dda_grid_build_ms") *value = ctx->grid_build_ms[1];
+  else if (key == "lik_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[0];
+  else if (key == "dda_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[1];
   else if (key == "pf_fused") *value = ctx->pf_fused;
   else if (key == "scan_order_device") *value = ctx->scan_order_device;
   else

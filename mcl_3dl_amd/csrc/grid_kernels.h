@@ -1,0 +1,111 @@
+// grid_kernels.h — device side of the two linear-time map structures: the cell-sorted exact-NN grid (LikGrid: radius
+// search, matched / unmatched, lik_index = 0, the K-bar statistics) and the DDA occupancy + voxel index (DdaGrid). Both
+// are counting sorts of the map by a cell id: key per point -> stable radix sort of (key, map index) -> gather; the run
+// delimiters come from a histogram (one atomic per point) and an exclusive scan. Same keys, same order inside a cell
+// (ascending map index) as a sequential counting sort on the host: the structures are bit-identical to what
+// host_map_compilers.h:build_*_grid_host lays out (tests/test_gpu_map_path.py compares results under both builders).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "map_structs.h"
+#pragma clang fp contract(off)
+
+namespace mcl3dl
+{
+// PointRepresentation::vectorize (one float product per coordinate when a dist_weight is set); w = map index
+__global__ void grid_rescale_kernel(const float4* __restrict__ map, long long n, float wx, float wy, float wz, int has_weight,
+                                    float4* __restrict__ out)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const float4 p = map[i];
+  out[i] = make_float4(has_weight ? p.x * wx : p.x, has_weight ? p.y * wy : p.y, has_weight ? p.z * wz : p.z,
+                       __uint_as_float(static_cast<uint32_t>(i)));
+}
+
+struct CellGeom
+{
+  float ox, oy, oz, inv;
+  int nx, ny, nz;
+};
+
+// cell of every rescaled point — floorf((s - o) * inv), the expression nearest_d2 uses for its queries — clamped into the grid
+__global__ void lik_cell_key_kernel(const float4* __restrict__ sp, long long n, CellGeom g, uint32_t* __restrict__ key,
+                                    uint32_t* __restrict__ val, uint32_t* __restrict__ count)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const float4 p = sp[i];
+  int cx = static_cast<int>(floorf((p.x - g.ox) * g.inv));
+  int cy = static_cast<int>(floorf((p.y - g.oy) * g.inv));
+  int cz = static_cast<int>(floorf((p.z - g.oz) * g.inv));
+  cx = min(max(cx, 0), g.nx - 1);
+  cy = min(max(cy, 0), g.ny - 1);
+  cz = min(max(cz, 0), g.nz - 1);
+  const uint32_t k = static_cast<uint32_t>((static_cast<size_t>(cz) * g.ny + cy) * g.nx + cx);
+  key[i] = k;
+  val[i] = static_cast<uint32_t>(i);
+  atomicAdd(&count[k], 1u);
+}
+
+__global__ void grid_gather_kernel(const float4* __restrict__ src, const uint32_t* __restrict__ val, long long n,
+                                   float4* __restrict__ dst)
+{
+  const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k < n)
+    dst[k] = src[val[k]];
+}
+
+struct DdaGeom
+{
+  float mnx, mny, mnz;
+  double grid;
+  int nx, ny;
+  unsigned long long total;
+  int bnx, bny;
+};
+
+// RaycastUsingDDA::updatePointCloud / toIndex / getArrayIndex (raycast_using_dda.h:162-190,205-210,225-228): voxel =
+// trunc((p - min) / grid) with a float difference and a double division, x-fastest array index in int arithmetic;
+// setExists -> the voxel's bit in its 4x4x4 brick word
+__global__ void dda_voxel_key_kernel(const float4* __restrict__ map, long long n, DdaGeom g, uint32_t* __restrict__ key,
+                                     uint32_t* __restrict__ val, uint32_t* __restrict__ count,
+                                     unsigned long long* __restrict__ bricks, int* __restrict__ err)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const float4 p = map[i];
+  const int c0 = static_cast<int>(static_cast<double>(p.x - g.mnx) / g.grid);
+  const int c1 = static_cast<int>(static_cast<double>(p.y - g.mny) / g.grid);
+  const int c2 = static_cast<int>(static_cast<double>(p.z - g.mnz) / g.grid);
+  const size_t v = static_cast<size_t>(c0 + c1 * g.nx + c2 * (g.nx * g.ny));
+  val[i] = static_cast<uint32_t>(i);
+  if (v >= g.total)
+  {
+    key[i] = 0xffffffffu;  // "map point falls outside its own DDA grid"
+    atomicMax(err, 1);
+    return;
+  }
+  key[i] = static_cast<uint32_t>(v);
+  atomicAdd(&count[v], 1u);
+  const size_t brick = (static_cast<size_t>(c2 >> 2) * g.bny + (c1 >> 2)) * g.bnx + (c0 >> 2);
+  atomicOr(&bricks[brick], 1ull << (((c2 & 3) << 4) | ((c1 & 3) << 2) | (c0 & 3)));
+}
+
+// points in voxel order (insertion = map order inside a voxel: the sort is stable) + their original map index
+__global__ void dda_gather_kernel(const float4* __restrict__ map, const uint32_t* __restrict__ val, long long n,
+                                  float4* __restrict__ pts, uint32_t* __restrict__ index)
+{
+  const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= n)
+    return;
+  const uint32_t i = val[k];
+  pts[k] = map[i];
+  index[k] = i;
+}
+
+}  // namespace mcl3dl

@@ -108,6 +108,13 @@ struct mcl3dl_hip_ctx
   // records, voxel edge / match_dist_min actually used
   double cand_stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   DevBuf dda_bits, dda_start, dda_pts, dda_index;
+  // the map as a device cloud (host_grid_builders.h); 1 = build the cell grid / the DDA grid on the host instead
+  DevBuf map_dev;
+  bool map_dev_valid = false;
+  size_t map_dev_n = 0;
+  int grid_build_host = 0;
+  double grid_build_ms[2] = { 0, 0 };       // device time of the last cell-grid / DDA-grid build (device builders)
+  double grid_build_wall_ms[2] = { 0, 0 };  // host wall time of the last build, either builder (upload of the map included)
   DdaGrid dg{};
   uint64_t footprint[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 

@@ -1,0 +1,222 @@
+// host_grid_builders.h — part of the single translation unit mcl3dl_hip.hip: the cell-sorted exact-NN grid and the DDA
+// occupancy / voxel index built ON THE DEVICE (grid_kernels.h). Both used to be sequential counting sorts on the host
+// followed by an upload of the finished arrays (a 10 M-point map: seconds of host time, 1.1 GB of run delimiters over
+// PCIe, at every map stamp and every map update); now the map is uploaded once as float4 {x, y, z, label} and everything
+// else happens in HBM. Geometry (origin, extents) is computed on the host from the device-side min / max with the very
+// expressions of the host builders, so the structures come out bit-identical.
+#pragma once
+
+namespace
+{
+// the map as a device cloud {x, y, z, label bits} in map order; re-uploaded only when the host copy changed
+int ensure_map_dev(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  if (ctx->map_dev_valid && ctx->map_dev_n == n)
+    return 0;
+  TRY(upload_cloud(ctx, ctx->map_xyz.data(), ctx->map_label.data(), n, ctx->map_dev));
+  ctx->map_dev_valid = true;
+  ctx->map_dev_n = n;
+  return 0;
+}
+
+int sort_bits(unsigned long long n_keys)
+{
+  int b = 1;
+  while (b < 32 && (1ull << b) < n_keys)
+    ++b;
+  return b;
+}
+
+struct BuildTimer
+{
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  ~BuildTimer()
+  {
+    if (ev0)
+      (void)hipEventDestroy(ev0);
+    if (ev1)
+      (void)hipEventDestroy(ev1);
+  }
+};
+
+// ---- exact-NN grid (replaces ChunkedKdtree::setInputCloud + pcl::KdTreeFLANN::setInputCloud, see host_map_compilers.h) ----
+int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const long long nn = static_cast<long long>(n);
+  const float cell = ctx->match_dist_min * 1.01f;
+  if (!(cell > 0.f) || !std::isfinite(cell))
+    return ctx->fail(-3, "match_dist_min must be positive and finite");
+  if (n == 0 || n > 0x7fffffffu)
+    return ctx->fail(-3, "bad map size for the likelihood grid");
+  const float inv = 1.0f / cell;
+  BuildTimer tm;
+  HIP_TRY(hipEventCreate(&tm.ev0));
+  HIP_TRY(hipEventCreate(&tm.ev1));
+  TRY(ensure_map_dev(ctx));
+  HIP_TRY(hipEventRecord(tm.ev0, ctx->stream));
+  TempBuf sp;
+  HIP_TRY(hipMalloc(&sp.p, sizeof(float4) * n));
+  hipLaunchKernelGGL(grid_rescale_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn,
+                     ctx->weight[0], ctx->weight[1], ctx->weight[2], ctx->has_weight ? 1 : 0, static_cast<float4*>(sp.p));
+  float mm[6];
+  unsigned long long n_finite = 0;
+  TRY(cloud_minmax(ctx, static_cast<const float4*>(sp.p), nn, mm, &n_finite));
+  if (n_finite != n)
+    return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n) - n_finite);
+  float o[3];
+  int dim[3];
+  double total = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    o[a] = mm[a] - 2.0f * cell;
+    dim[a] = static_cast<int>(floorf((mm[3 + a] - o[a]) * inv)) + 3;
+    total *= dim[a];
+  }
+  if (total > 3.0e9)
+    return ctx->fail(-4, "likelihood grid would need %.3g cells (map extent too large for the dense index)", total);
+  const size_t ncell = static_cast<size_t>(dim[0]) * dim[1] * dim[2];
+  TRY(ensure(ctx, ctx->lik_pts, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->lik_cells, sizeof(uint32_t) * (ncell + 1)));
+  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n + 1)));
+  HIP_TRY(hipMemsetAsync(ctx->lik_cells.p, 0, sizeof(uint32_t) * (ncell + 1), ctx->stream));
+  const CellGeom g{ o[0], o[1], o[2], inv, dim[0], dim[1], dim[2] };
+  hipLaunchKernelGGL(lik_cell_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
+                     nn, g, ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->lik_cells.as<uint32_t>());
+  TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
+                 ctx->cl_val[1].as<uint32_t>(), nn, sort_bits(ncell)));
+  hipLaunchKernelGGL(grid_gather_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
+                     ctx->cl_val[1].as<uint32_t>(), nn, ctx->lik_pts.as<float4>());
+  HIP_TRY(hipGetLastError());
+  TRY(device_exclusive_scan(ctx, ctx->lik_cells.as<uint32_t>(), static_cast<long long>(ncell) + 1));
+  HIP_TRY(hipEventRecord(tm.ev1, ctx->stream));
+  TRY(sync_stream(ctx));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
+  ctx->grid_build_ms[0] = ms;
+  ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
+  ctx->lg.pts = ctx->lik_pts.as<float4>();
+  ctx->lg.ox = o[0];
+  ctx->lg.oy = o[1];
+  ctx->lg.oz = o[2];
+  ctx->lg.inv_cell = inv;
+  ctx->lg.nx = dim[0];
+  ctx->lg.ny = dim[1];
+  ctx->lg.nz = dim[2];
+  ctx->footprint[0] = sizeof(float4) * n;
+  ctx->footprint[1] = sizeof(uint32_t) * (ncell + 1);
+  ctx->lik_dirty = false;
+  return 0;
+}
+
+// ---- DDA occupancy + voxel index (RaycastUsingDDA::updatePointCloud / setExists, raycast_using_dda.h:162-190,230-235) ----
+int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
+{
+  const size_t n = ctx->map_xyz.size() / 3;
+  const long long nn = static_cast<long long>(n);
+  const double grid = static_cast<double>(ctx->dda_grid_size);
+  if (!(grid > 0))
+    return ctx->fail(-3, "dda_grid_size must be positive");
+  if (n == 0 || n > 0x7fffffffu)
+    return ctx->fail(-3, "bad map size for the DDA grid");
+  BuildTimer tm;
+  HIP_TRY(hipEventCreate(&tm.ev0));
+  HIP_TRY(hipEventCreate(&tm.ev1));
+  TRY(ensure_map_dev(ctx));
+  HIP_TRY(hipEventRecord(tm.ev0, ctx->stream));
+  float mm[6];
+  unsigned long long n_finite = 0;
+  TRY(cloud_minmax(ctx, ctx->map_dev.as<float4>(), nn, mm, &n_finite));  // pcl::getMinMax3D
+  if (n_finite != n)
+    return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n) - n_finite);
+  const float* mn = mm;
+  const float* mx = mm + 3;
+  int dim[3];
+  double total_d = 1;
+  for (int a = 0; a < 3; ++a)
+  {
+    dim[a] = static_cast<int>(static_cast<size_t>((mx[a] - mn[a]) / grid) + 1);
+    total_d *= dim[a];
+  }
+  if (total_d >= 2147483647.0)  // the reference keeps point_total in an int (raycast_using_dda.h:176)
+    return ctx->fail(-4, "DDA grid would need %.3g voxels (>= 2^31)", total_d);
+  const size_t total = static_cast<size_t>(total_d);
+  const int bdim[3] = { (dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4 };
+  const size_t n_bricks = static_cast<size_t>(bdim[0]) * bdim[1] * bdim[2];
+  TRY(ensure(ctx, ctx->dda_bits, sizeof(unsigned long long) * n_bricks));
+  TRY(ensure(ctx, ctx->dda_start, sizeof(uint32_t) * (total + 1)));
+  TRY(ensure(ctx, ctx->dda_pts, sizeof(float4) * n));
+  TRY(ensure(ctx, ctx->dda_index, sizeof(uint32_t) * n));
+  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n + 1)));
+  TRY(ensure(ctx, ctx->cl_err, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(ctx->cl_err.p, 0, sizeof(int), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dda_bits.p, 0, sizeof(unsigned long long) * n_bricks, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dda_start.p, 0, sizeof(uint32_t) * (total + 1), ctx->stream));
+  const DdaGeom g{ mn[0], mn[1], mn[2], grid, dim[0], dim[1], static_cast<unsigned long long>(total), bdim[0], bdim[1] };
+  hipLaunchKernelGGL(dda_voxel_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn, g,
+                     ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->dda_start.as<uint32_t>(),
+                     ctx->dda_bits.as<unsigned long long>(), ctx->cl_err.as<int>());
+  TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
+                 ctx->cl_val[1].as<uint32_t>(), nn, sort_bits(total)));
+  hipLaunchKernelGGL(dda_gather_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(),
+                     ctx->cl_val[1].as<uint32_t>(), nn, ctx->dda_pts.as<float4>(), ctx->dda_index.as<uint32_t>());
+  HIP_TRY(hipGetLastError());
+  TRY(device_exclusive_scan(ctx, ctx->dda_start.as<uint32_t>(), static_cast<long long>(total) + 1));
+  int err = 0;
+  TRY(d2h(ctx, &err, ctx->cl_err.p, sizeof(int)));
+  HIP_TRY(hipEventRecord(tm.ev1, ctx->stream));
+  TRY(sync_stream(ctx));
+  if (err)
+    return ctx->fail(-3, "a map point falls outside its own DDA grid");
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
+  ctx->grid_build_ms[1] = ms;
+  DdaGrid& d = ctx->dg;
+  d.bricks = ctx->dda_bits.as<unsigned long long>();
+  d.bnx = bdim[0];
+  d.bny = bdim[1];
+  d.bnz = bdim[2];
+  d.mul24_ok = (bdim[0] < (1 << 24) && static_cast<long long>(bdim[1]) * bdim[2] < (1ll << 24)) ? 1 : 0;
+  d.vox_start = ctx->dda_start.as<uint32_t>();
+  d.pts = ctx->dda_pts.as<float4>();
+  d.pt_index = ctx->dda_index.as<uint32_t>();
+  d.min_x = mn[0];
+  d.min_y = mn[1];
+  d.min_z = mn[2];
+  d.max_x = mx[0];
+  d.max_y = mx[1];
+  d.max_z = mx[2];
+  d.nx = dim[0];
+  d.ny = dim[1];
+  d.nz = dim[2];
+  dda_ray_constants(ctx, d);
+  ctx->footprint[2] = sizeof(unsigned long long) * n_bricks;
+  ctx->footprint[3] = sizeof(uint32_t) * (total + 1);
+  ctx->footprint[4] = sizeof(float4) * n + sizeof(uint32_t) * n;
+  ctx->dda_dirty = false;
+  return 0;
+}
+
+int build_lik_grid(mcl3dl_hip_ctx* ctx)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = ctx->grid_build_host ? build_lik_grid_host(ctx) : build_lik_grid_device(ctx);
+  ctx->grid_build_wall_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+int build_dda_grid(mcl3dl_hip_ctx* ctx)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = ctx->grid_build_host ? build_dda_grid_host(ctx) : build_dda_grid_device(ctx);
+  ctx->grid_build_wall_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+}  // namespace

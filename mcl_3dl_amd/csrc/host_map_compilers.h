@@ -5,11 +5,16 @@
 
 namespace
 {
+int build_lik_grid(mcl3dl_hip_ctx* ctx);  // host_grid_builders.h
+int build_dda_grid(mcl3dl_hip_ctx* ctx);
+
 // ---- map compiler: exact-NN grid -----------------------------------------------------------------------
 // Replaces ChunkedKdtree::setInputCloud + pcl::KdTreeFLANN::setInputCloud.  The reference's chunking is a memory
 // device (20 m chunks with duplicated margins, chunked_kdtree.h:124-216) whose query result equals the global
 // nearest neighbour within the radius whenever radius <= max_search_radius; the grid gives that result directly.
-int build_lik_grid(mcl3dl_hip_ctx* ctx)
+// Host form (option grid_build_host = 1): the sequential counting sort the device builder (host_grid_builders.h) is
+// checked against.
+int build_lik_grid_host(mcl3dl_hip_ctx* ctx)
 {
   const size_t n = ctx->map_xyz.size() / 3;
   const float cell = ctx->match_dist_min * 1.01f;
@@ -89,7 +94,19 @@ int build_lik_grid(mcl3dl_hip_ctx* ctx)
 // RaycastUsingDDA::updatePointCloud / setExists, include/mcl_3dl/raycasts/raycast_using_dda.h:162-190,230-235:
 // AABB by getMinMax3D, map_size = (size_t)((max-min)/grid)+1, voxel = trunc((p-min)/grid) (float difference,
 // double division), x-fastest array index; per voxel the points stay in insertion (map) order.
-int build_dda_grid(mcl3dl_hip_ctx* ctx)
+// the ray-test constants of a DdaGrid (shared by both builders)
+void dda_ray_constants(const mcl3dl_hip_ctx* ctx, DdaGrid& g)
+{
+  g.grid = static_cast<double>(ctx->dda_grid_size);
+  g.ray_angle_half = static_cast<double>(ctx->ray_angle_half);
+  // RaycastUsingDDA ctor, raycast_using_dda.h:59: map_grid_size_y appears twice (reference quirk, kept)
+  const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];
+  g.min_dist_thr_sq = gx * gx + gy * gy + gy * gy;
+  g.hit_tolerance_f = static_cast<float>(static_cast<double>(ctx->hit_range));
+}
+
+// Host form (option grid_build_host = 1); device form in host_grid_builders.h.
+int build_dda_grid_host(mcl3dl_hip_ctx* ctx)
 {
   const size_t n = ctx->map_xyz.size() / 3;
   const double grid = static_cast<double>(ctx->dda_grid_size);
@@ -171,12 +188,7 @@ int build_dda_grid(mcl3dl_hip_ctx* ctx)
   g.nx = dim[0];
   g.ny = dim[1];
   g.nz = dim[2];
-  g.grid = grid;
-  g.ray_angle_half = static_cast<double>(ctx->ray_angle_half);
-  // RaycastUsingDDA ctor, raycast_using_dda.h:59: map_grid_size_y appears twice (reference quirk, kept)
-  const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];
-  g.min_dist_thr_sq = gx * gx + gy * gy + gy * gy;
-  g.hit_tolerance_f = static_cast<float>(static_cast<double>(ctx->hit_range));
+  dda_ray_constants(ctx, g);
   ctx->footprint[2] = sizeof(unsigned long long) * bits.size();
   ctx->footprint[3] = sizeof(uint32_t) * (total + 1);
   ctx->footprint[4] = sizeof(float4) * n + sizeof(uint32_t) * n;

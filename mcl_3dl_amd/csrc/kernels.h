@@ -6,6 +6,7 @@
 //   pf_kernels.h          pf::measure (weights, deterministic fp64 reductions, normalisation, entropy) and the "next" rows
 //                         (expectation / max / covariance, resampling)
 //   map_compiler.h        device-side compiler of the candidate-voxel index (whole map, or the bricks a map update touches)
+//   grid_kernels.h        the cell-sorted exact-NN grid and the DDA occupancy / voxel index, built on the device
 //   cloud_kernels.h       scan / map preparation: PointCloud2 decode, VoxelGrid, clip + compaction, sampling gather, scan
 //                         ordering, matched / unmatched output
 //
@@ -17,3 +18,4 @@
 #include "beam_kernels.h"
 #include "pf_kernels.h"
 #include "cloud_kernels.h"
+#include "grid_kernels.h"

@@ -303,6 +303,13 @@ __device__ inline unsigned long long lanes_gt_u32(uint32_t a, uint32_t b)
 }
 constexpr unsigned long long QUAD_LANE0_MASK = 0x1111111111111111ull;
 
+// Measured and NOT kept (C2, 0.230 ms with the code below): (1) a skewed fetch — load r of lane j = record of lane
+// (j + r) & 3, which turns the transpose-min into three v_min_u32 with a quad rotation as DPP operand and no selects —
+// 0.30 ms: every load instruction then touches 64 different cache lines instead of 16, and the L1's line-access rate is
+// what the cooperative fetch exists to spare; (2) the wavefront's match counts kept in scalar registers and written to
+// LDS once per work-group instead of once per particle (-2 VALU, +10 SALU per evaluation): 0.230 ms, no change; (3) the
+// float constants (grid origin, 1 / edge, weights, r, flat, match weight) forced into vector registers because a v_mul_f32
+// with an SGPR operand is priced at 4.2 instead of 2.6 cycles by profiles/r02d_valu_microbench.txt: 0.233 ms, no gain.
 // One cooperative round: the quad fetches the 64-byte records `rec_index` of its four lanes from `recs` (lane j reads
 // part j of each), lane j computes candidate j of evaluation e against the query of lane e, and the 4 x 4 transpose-min
 // returns to every lane the minimum over the four candidates of ITS record. w[e] = the w word of the part this lane read

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,6 +27,7 @@ using namespace mcl3dl;
 #include "host_map_compilers.h"
 #include "host_measure.h"
 #include "host_cloud.h"
+#include "host_grid_builders.h"
 #include "host_group.h"
 
 // =================================================================================================================

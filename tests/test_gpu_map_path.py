@@ -181,3 +181,40 @@ def test_matched_unmatched_split(engine):
     cls2, moved2 = ref.match_split(pose, full, 0.5, 0.1)
     np.testing.assert_array_equal(m2, moved2[cls2 == 1])
     np.testing.assert_array_equal(u2, moved2[cls2 == 2])
+
+
+def test_device_built_grids_equal_the_host_built_ones():
+    """The cell-sorted exact-NN grid and the DDA occupancy / voxel index are counting sorts of the map: built on the device
+    (default) and by the sequential host form (option grid_build_host) they must answer every query identically — radius
+    search (index AND squared distance), the 27-cell likelihood (lik_index 0), beam scores, per-ray status and the collided
+    map point — on a map with labels, a dist_weight and several points per cell."""
+    sc = make_scene(n=91, n_p=96, n_s=700, n_b=128, seed=21)
+    rng = np.random.default_rng(8)
+    # a second, shifted copy of the walls: up to several points per DDA voxel / grid cell, in a known insertion order
+    map_xyz = np.concatenate([sc.map_xyz, sc.map_xyz + rng.normal(0, 0.03, sc.map_xyz.shape).astype(np.float32)], 0)
+    map_label = np.concatenate([sc.map_label, (np.arange(len(sc.map_xyz)) % 3).astype(np.uint32)])
+    queries = (map_xyz[rng.integers(0, len(map_xyz), 5000)] + rng.normal(0, 0.15, (5000, 3))).astype(np.float32)
+    begin = np.tile(sc.true_pose[:3] + np.array([0, 0, 0.5], np.float32), (3000, 1)).astype(np.float32)
+    end = (begin + rng.normal(0, 4.0, (3000, 3))).astype(np.float32)
+    out = {}
+    for mode in (0, 1):
+        eng = capi.Engine(0)
+        try:
+            eng.set_option("grid_build_host", mode)
+            eng.set_option("lik_index", 0)
+            eng.set_map(map_xyz, map_label, stamp=31 + mode, dist_weight=DW)
+            eng.set_likelihood_params()
+            eng.set_beam_params(num_points=128, filter_label_max=1)
+            lik, ratio, beam = eng.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            idx, sq = eng.radius_search(queries, 0.35)
+            st, hit = eng.beam_status(begin, end)
+            m, u = eng.match_split(sc.true_pose, sc.scan_lik, unmatch_dist=0.5, match_dist=0.1)
+            out[mode] = (lik, ratio, beam, idx, sq, st, hit, m, u)
+            assert eng.get_option("grid_build_host") == mode
+            if mode == 0:
+                assert eng.get_option("lik_grid_build_ms") > 0 and eng.get_option("dda_grid_build_ms") > 0
+        finally:
+            eng.close()
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    assert (out[0][3] >= 0).sum() > 1000 and len(np.unique(out[0][5])) >= 2 and out[0][6].max() >= len(sc.map_xyz)
