@@ -282,6 +282,24 @@ def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
                           "unmatched": int(len(u)),
                           "what": "mcl3dl_hip_match_split of the down-sampled cloud left on the device (src/mcl_3dl.cpp:761-805): "
                                   "count pass + output pass + D2H of both clouds"}
+    # the two linear-time map structures (cell-sorted exact-NN grid, DDA occupancy + voxel index): device builders
+    # (default) next to the sequential host form they replaced
+    q1 = np.asarray(sc.true_pose[:3], np.float32).reshape(1, 3)
+    gb = {}
+    for mode, tag in ((1, "host"), (0, "device")):
+        eng.set_option("grid_build_host", mode)   # marks both structures dirty
+        eng.radius_search(q1, 0.3)
+        gb["lik_grid_%s_wall_ms" % tag] = eng.get_option("lik_grid_build_wall_ms")
+        if n_b:
+            eng.beam_status(q1, q1 + np.float32(1.0))
+            gb["dda_grid_%s_wall_ms" % tag] = eng.get_option("dda_grid_build_wall_ms")
+    gb["lik_grid_device_ms"] = eng.get_option("lik_grid_build_ms")
+    if n_b:
+        gb["dda_grid_device_ms"] = eng.get_option("dda_grid_build_ms")
+    gb["map_points"] = int(len(sc.map_xyz))
+    gb["what"] = ("build of the cell-sorted map (radius search, matched / unmatched, lik_index 0) and of the DDA grid: "
+                  "wall = host time of the whole build incl. map upload; device_ms = hipEvent time of the device builder")
+    res["grid_build"] = gb
     if with_cpu:
         from oracle import pyoracle
         if pyoracle.available("ref"):
