@@ -554,7 +554,7 @@ def main():
         value = evals_per_step * args.steps / elapsed
         lik_avg_ms = lik_ms / max(lik_n, 1)
         stats = main_sh.d_stats.cpu().numpy()
-        tiled = bool(args.lik_tiled and n_s >= tiled_min and n_p >= 4) or bool(args.strict_order)
+        tiled = bool(args.lik_tiled and n_p >= 4 and (n_s >= tiled_min or (n_p >= 256 and 4 * n_s >= 3 * tiled_min))) or bool(args.strict_order)
         group = _tiled_group(n_s, n_p, args.lik_group)
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:

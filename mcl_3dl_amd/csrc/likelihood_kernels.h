@@ -541,6 +541,10 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
   }
 }
 
+// Measured and NOT kept: a wavefront-per-particle kernel for scans of 96-1000 points with thousands of particles (no LDS,
+// no barrier, shuffle-only reduction, four particles per work-group) — 4096 x 512: 23.3 us against 21.8 us for
+// likelihood_kernel<256>, equal or slower at every shape tried (4096 x 96 ... 100 000 x 96): those shapes are bound by the
+// latency of the pose -> table -> record chain at two rounds of resident wavefronts, not by the work-group's fixed costs.
 // ---------------------------------------------------------------------------------------------------------
 // Small-scan variant (global localisation: hundreds of thousands of particles x 8..32 points each,
 // src/lidar_measurement_model_likelihood.cpp:63-77): a wavefront is shared by 64 / W particles, W = the scan size rounded
@@ -623,8 +627,9 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
 //    LDS once per work-group and read back as broadcasts;
 //  * blockIdx -> (tile, particle group) is XCD-aware: work-groups are dispatched round-robin over the 8 XCDs
 //    (block b runs on XCD b % 8), so XCD x is given the tiles t == x (mod 8) and walks them one after the other over all
-//    particle groups. A tile is a spatially compact patch (Morton order), so the voxel records it touches under every
-//    particle pose (~1 MB) stay resident in that XCD's 4 MB L2 instead of every work-group sweeping the whole scan;
+//    particle groups (the last n_tiles % 8 tiles are shared out by particle group). A tile is a spatially compact patch
+//    (Morton order), so the voxel records it touches under every particle pose (~1 MB) stay resident in that XCD's 4 MB
+//    L2 instead of every work-group sweeping the whole scan;
 //  * per-(particle, lane) float terms go to LDS and are summed in fp64 in a fixed order (deterministic), one partial per
 //    (tile, particle); lik_finalize_kernel adds the tiles in order.
 // Same per-point arithmetic as likelihood_kernel — identical terms — only the (fp64) summation order differs.
@@ -646,12 +651,36 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   __shared__ float s_pose[G][8];        // px,py,pz, qx,qy,qz,qw (normalised), valid
   __shared__ float s_term[G][256];
   __shared__ unsigned s_cnt[G][4];
-  const int xcd = blockIdx.x & 7;
-  const int seq = blockIdx.x >> 3;
-  const int tile = (seq / n_groups) * 8 + xcd;
-  const int group = seq % n_groups;
-  if (tile >= n_tiles)
-    return;
+  // Work-groups are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8). The tiles of the largest
+  // multiple of eight are INTERLEAVED: XCD x walks tiles x, x + 8, ... one after the other over all particle groups —
+  // every XCD gets an even sample of cheap (mostly empty bricks) and expensive (along the walls) tiles; contiguous
+  // ranges of tiles per XCD were measured 7 % (C2) to 13 % (C5) slower. The remaining n_tiles % 8 tiles — all of them
+  // for a scan shorter than 2048 points — are cut into eight contiguous ranges of (tile, group) pairs, so that a short
+  // scan still uses every XCD (32-bit arithmetic: the launch has fewer than 2^31 work-groups, plan_lik checks).
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t seq = blockIdx.x >> 3;
+  const uint32_t ng = static_cast<uint32_t>(n_groups);
+  const uint32_t full_tiles = static_cast<uint32_t>(n_tiles) & ~7u;
+  const uint32_t per_xcd_full = (full_tiles >> 3) * ng;
+  int tile, group;
+  if (seq < per_xcd_full)
+  {
+    const uint32_t row = seq / ng;
+    tile = static_cast<int>(row * 8u + xcd);
+    group = static_cast<int>(seq - row * ng);
+  }
+  else
+  {
+    const uint32_t rem_items = (static_cast<uint32_t>(n_tiles) - full_tiles) * ng;
+    const uint32_t per_xcd_rem = (rem_items + 7u) >> 3;
+    const uint32_t s2 = seq - per_xcd_full;
+    const uint32_t item = xcd * per_xcd_rem + s2;
+    if (s2 >= per_xcd_rem || item >= rem_items)
+      return;
+    const uint32_t row = item / ng;
+    tile = static_cast<int>(full_tiles + row);
+    group = static_cast<int>(item - row * ng);
+  }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < G)
   {
