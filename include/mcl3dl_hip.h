@@ -380,8 +380,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min; 0 (default) = chosen per map: 0.5, or 0.36 when more than a
  *                       quarter of the voxels hold more candidates than a record has room for
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
- *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= 1024 points and >= 4 particles; 0 = one
- *                       work-group per particle always (only the fp64 summation order differs)
+ *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= "lik_tiled_min" points and >= 4
+ *                       particles; 0 = one work-group per particle always (only the fp64 summation order differs)
+ *   "lik_tiled_min"     default 1024; with >= 256 particles the tiled kernel already takes over at three quarters of it
  *   "use_graph"         1 = mcl3dl_hip_update_device replays a captured hipGraph; 0 (default) = enqueue kernel by kernel
  *   "timing_mask"       bit k set (default: all) = kernel group k is timed while kernel timing is on
  *   "overlap_models"    1 (default) = the beam kernels run on a second stream concurrently with the likelihood kernels
@@ -402,7 +403,12 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       Same bits either way.
  *   "lik_coop"          tiled kernel: 1 (default) = the four lanes of a quad fetch each 64-byte voxel record together
  *                       (16 cache-line accesses per load instruction instead of 64) and split its candidates between
- *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record */
+ *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record
+ *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
+ *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
+ *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",
+ *                       "dda_grid_build_ms" (device time of the last build), "lik_grid_build_wall_ms",
+ *                       "dda_grid_build_wall_ms" (host wall time of the last build, either builder) */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
 int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,
