@@ -32,6 +32,22 @@ struct RayTrace
   int collided;   // 1 if the walk ended on a collision
 };
 
+// a * b + c on the low 24 bits of a and b in ONE instruction (v_mad_u32_u24; left to itself the compiler picks the 64-bit
+// v_mad_u64_u32 for the first of two chained multiply-adds)
+// b must be wave-uniform (a kernel argument here): it travels as the instruction's one scalar operand
+__device__ inline unsigned mad24(unsigned a, unsigned b, unsigned c)
+{
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+
+// any ACTIVE lane true? (the ballot straight from the predicate)
+__device__ inline bool wave_any_active(bool p)
+{
+  return __builtin_amdgcn_ballot_w64(p) != 0ull;
+}
+
 template <bool STATS, bool TRACE = false>
 __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
                                unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
@@ -82,74 +98,82 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
   // The occupancy word of the brick the ray is currently in stays in registers: stepping inside a brick is pure ALU,
   // a (dependent, high-latency) load happens only when the ray enters a new 4x4x4 brick.
   int cur_brick = -1;
-  unsigned long long word = 0ull;
+  uint32_t word_lo = 0u, word_hi = 0u;  // z = 0, 1 resp. z = 2, 3 of the brick
   // Two nested loops instead of one ("while-while" traversal): the inner loop only WALKS — to the next occupied voxel
   // or to the end of the ray — and the point tests of that voxel run after it. On a wavefront the inner loop ends when
   // every ray has found its voxel (or run out), so the long, double-precision test body executes once per round for all
   // 64 rays together instead of once per step for whichever ray happens to sit on an occupied voxel (a ray visits
   // ~1.0 occupied voxel on its way: measured). The per-ray sequence of operations is unchanged.
+  // The walk itself is straight-line code under per-lane predicates with ONE backward branch on a ballot: a ray that has
+  // found its voxel (or run out) simply stops changing its state while the others walk on. (Written with `break`s the
+  // same loop compiled to ~35 scalar mask operations and 7 branches per step.)
+  const int bnx = g.bnx, bny = g.bny;
   for (;;)
   {
     bool found = false;
-    for (;;)
+    bool walking = true;
+    do
     {
-      // getNextCastResult, :106-159
-      ++pos;
-      if (pos >= max_movement)
-        break;
-      // axis choice of :114-147 (strict <, ties fall to the later axis), written branch-free so the 64 rays of a
-      // wavefront do not serialise on three divergent bodies; only the chosen axis changes (incrementIndex, :192-203).
+      // getNextCastResult, :106-159: ++pos; pos >= max_movement ends the ray
+      const int pos1 = pos + 1;
+      const bool step = walking && (pos1 < max_movement);
+      pos = step ? pos1 : pos;
+      // axis choice of :114-147 (strict <, ties fall to the later axis); only the chosen axis changes (incrementIndex, :192-203)
       const bool x_first = tmx < tmy;
-      const bool ax = x_first && (tmx < tmz);
-      const bool ay = !x_first && (tmy < tmz);
-      const bool az = !(ax || ay);
+      const bool ax = step && x_first && (tmx < tmz);
+      const bool ay = step && !x_first && (tmy < tmz);
+      const bool az = step && !(x_first && (tmx < tmz)) && !(!x_first && (tmy < tmz));
       cx += ax ? sx : 0;
       cy += ay ? sy : 0;
       cz += az ? sz : 0;
-      const float nx_t = iex + tdx * static_cast<float>(abs(cx - bx));
-      const float ny_t = iey + tdy * static_cast<float>(abs(cy - by));
-      const float nz_t = iez + tdz * static_cast<float>(abs(cz - bz));
+      // initial_edges + t_delta * abs(pos - begin) (:131, :139, :147): |(float)(c - b)| == (float)|c - b| for every int, and
+      // the absolute value is a free source modifier of the multiply
+      const float nx_t = iex + tdx * fabsf(static_cast<float>(cx - bx));
+      const float ny_t = iey + tdy * fabsf(static_cast<float>(cy - by));
+      const float nz_t = iez + tdz * fabsf(static_cast<float>(cz - bz));
       tmx = ax ? nx_t : tmx;
       tmy = ay ? ny_t : tmy;
       tmz = az ? nz_t : tmz;
-      // only the moved index can have left the grid (the others were checked when they moved; begin is inside the map)
-      const bool inside = static_cast<unsigned>(cx) < static_cast<unsigned>(g.nx) &&
-                          static_cast<unsigned>(cy) < static_cast<unsigned>(g.ny) &&
-                          static_cast<unsigned>(cz) < static_cast<unsigned>(g.nz);
-      if (!inside)
-        break;
+      // only the moved index can have left the grid (the others were checked when they moved; begin is inside the map);
+      // leaving it ends the ray
+      const bool go = step && static_cast<unsigned>(cx) < static_cast<unsigned>(g.nx) &&
+                      static_cast<unsigned>(cy) < static_cast<unsigned>(g.ny) &&
+                      static_cast<unsigned>(cz) < static_cast<unsigned>(g.nz);
       if (STATS)
-        ++st_steps;
+        st_steps += go ? 1u : 0u;
       if (TRACE)
       {
-        if (tr->n < tr->max)
+        if (go)
         {
-          tr->xyz[3 * tr->n + 0] = static_cast<float>((cx + 0.5) * g.grid + g.min_x);
-          tr->xyz[3 * tr->n + 1] = static_cast<float>((cy + 0.5) * g.grid + g.min_y);
-          tr->xyz[3 * tr->n + 2] = static_cast<float>((cz + 0.5) * g.grid + g.min_z);
+          if (tr->n < tr->max)
+          {
+            tr->xyz[3 * tr->n + 0] = static_cast<float>((cx + 0.5) * g.grid + g.min_x);
+            tr->xyz[3 * tr->n + 1] = static_cast<float>((cy + 0.5) * g.grid + g.min_y);
+            tr->xyz[3 * tr->n + 2] = static_cast<float>((cz + 0.5) * g.grid + g.min_z);
+          }
+          ++tr->n;
         }
-        ++tr->n;
       }
-      // hasIntersection, :237-258: occupancy bit first
-      // < 2^31 / 64 (total voxels < 2^31). 24-bit multiply-adds are full rate, a 32-bit integer multiply is a
-      // quarter-rate instruction: two of them were a sixth of the cycles of a step (build_dda_grid sets mul24_ok)
-      const int brick =
-          g.mul24_ok ? static_cast<int>(__umul24(__umul24(static_cast<unsigned>(cz >> 2), static_cast<unsigned>(g.bny)) +
-                                                     static_cast<unsigned>(cy >> 2),
-                                                 static_cast<unsigned>(g.bnx)) +
-                                        static_cast<unsigned>(cx >> 2)) :
-                       ((cz >> 2) * g.bny + (cy >> 2)) * g.bnx + (cx >> 2);
-      if (brick != cur_brick)
+      // hasIntersection, :237-258: occupancy bit first. Brick index < 2^31 / 64 (total voxels < 2^31); 24-bit
+      // multiply-adds where build_dda_grid found every factor below 2^24 (a 32-bit integer multiply is quarter rate)
+      const int brick = g.mul24_ok ? static_cast<int>(mad24(mad24(static_cast<unsigned>(cz >> 2), static_cast<unsigned>(bny),
+                                                                  static_cast<unsigned>(cy >> 2)),
+                                                            static_cast<unsigned>(bnx), static_cast<unsigned>(cx >> 2))) :
+                                     ((cz >> 2) * bny + (cy >> 2)) * bnx + (cx >> 2);
+      if (go && brick != cur_brick)
       {
         cur_brick = brick;
-        word = g.bricks[brick];
+        const uint2 w2 = reinterpret_cast<const uint2*>(g.bricks)[brick];
+        word_lo = w2.x;
+        word_hi = w2.y;
       }
-      if ((word >> (((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1ull)
-      {
-        found = true;
-        break;
-      }
-    }
+      // bit z * 16 + y * 4 + x of the brick word, as a 32-bit test on the half cz & 2 selects
+      // a ray that did not step reads an all-ones word: "occupied" stops its walk, and `go` keeps it out of `found` — so the
+      // loop condition is ONE compare whose lane mask is the ballot
+      const uint32_t half = go ? ((cz & 2) ? word_hi : word_lo) : 0xffffffffu;
+      walking = __builtin_amdgcn_ubfe(half, static_cast<uint32_t>((((cz & 1) << 2) | (cy & 3)) << 2 | (cx & 3)), 1u) == 0u;
+      found = found || (go && !walking);
+    } while (wave_any_active(walking));
     if (!found)
       break;  // ray exhausted (or left the grid): LONG
     if (STATS)
