@@ -131,6 +131,12 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_coop = value != 0.0;
     return 0;
   }
+  if (key == "beam_prepare")
+  {
+    ctx->beam_prepare = value != 0.0;
+    ++ctx->generation;
+    return 0;
+  }
   if (key == "grid_build_host")
   {
     const int v = value != 0.0;
@@ -171,6 +177,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_group") *value = ctx->lik_group;
   else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
+  else if (key == "beam_prepare") *value = ctx->beam_prepare;
   else if (key == "grid_build_host") *value = ctx->grid_build_host;
   else if (key == "lik_grid_build_ms") *value = ctx->grid_build_ms[0];
   else if (key == "dda_grid_build_ms") *value = ctx->grid_build_ms[1];

@@ -48,26 +48,33 @@ __device__ inline bool wave_any_active(bool p)
   return __builtin_amdgcn_ballot_w64(p) != 0ull;
 }
 
+// isPointWithinMap, raycast_using_dda.h:260-270 (a begin outside the map: max_movement_ = 0 -> getNextCastResult false -> LONG)
+__device__ inline bool point_within_map(const DdaGrid& g, const Vec3f b)
+{
+  return !((b.x < g.min_x) || (g.max_x < b.x) || (b.y < g.min_y) || (g.max_y < b.y) || (b.z < g.min_z) || (g.max_z < b.z));
+}
+
+// toIndex, raycast_using_dda.h:205-210: float difference, double division, truncation toward zero
+__device__ inline void to_index(const DdaGrid& g, const Vec3f p, int& ix, int& iy, int& iz)
+{
+  ix = static_cast<int>(static_cast<double>(p.x - g.min_x) / g.grid);
+  iy = static_cast<int>(static_cast<double>(p.y - g.min_y) / g.grid);
+  iz = static_cast<int>(static_cast<double>(p.z - g.min_z) / g.grid);
+}
+
+// The walk from a begin point that lies within the map and whose voxel (bx, by, bz) = toIndex(begin) is known.
 template <bool STATS, bool TRACE = false>
-__device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
-                               unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
+__device__ inline int cast_ray_from(const DdaGrid& g, const BeamParams& bp, Vec3f b, int bx, int by, int bz, Vec3f e_org,
+                                    int* hit, unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
 {
   *hit = -1;
-  // isPointWithinMap, raycast_using_dda.h:260-270  -> max_movement_ = 0 -> getNextCastResult false -> LONG
-  if ((b.x < g.min_x) || (g.max_x < b.x) || (b.y < g.min_y) || (g.max_y < b.y) || (b.z < g.min_z) || (g.max_z < b.z))
-    return 2;
   // setRay, :76-103
   const Vec3f diff = vsub(e_org, b);
   const float nrm = sqrtf(vdot(diff, diff));
   const Vec3f dir = { diff.x / nrm, diff.y / nrm, diff.z / nrm };
   const Vec3f e = vadd(e_org, vscale(dir, g.hit_tolerance_f));
-  // toIndex, :205-210: float difference, double division, truncation toward zero
-  const int bx = static_cast<int>(static_cast<double>(b.x - g.min_x) / g.grid);
-  const int by = static_cast<int>(static_cast<double>(b.y - g.min_y) / g.grid);
-  const int bz = static_cast<int>(static_cast<double>(b.z - g.min_z) / g.grid);
-  const int ex = static_cast<int>(static_cast<double>(e.x - g.min_x) / g.grid);
-  const int ey = static_cast<int>(static_cast<double>(e.y - g.min_y) / g.grid);
-  const int ez = static_cast<int>(static_cast<double>(e.z - g.min_z) / g.grid);
+  int ex, ey, ez;
+  to_index(g, e, ex, ey, ez);
   const int dix = ex - bx, diy = ey - by, diz = ez - bz;
   const int max_movement = abs(dix) + abs(diy) + abs(diz);
   const int sx = dix < 0 ? -1 : 1, sy = diy < 0 ? -1 : 1, sz = diz < 0 ? -1 : 1;
@@ -224,12 +231,65 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
   return 2;
 }
 
+// Casts one ray from an arbitrary begin point (explicit rays: getBeamStatus for the debug markers, the waypoint trace).
+template <bool STATS, bool TRACE = false>
+__device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
+                               unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
+{
+  *hit = -1;
+  if (!point_within_map(g, b))
+    return 2;
+  int bx, by, bz;
+  to_index(g, b, bx, by, bz);
+  return cast_ray_from<STATS, TRACE>(g, bp, b, bx, by, bz, e_org, hit, st_steps, st_occ, st_tested, tr);
+}
+
+// Everything about a ray that depends only on (particle, origin): all N_b rays of a particle share it, so a small
+// kernel computes it once instead of every ray repeating a quaternion normalisation, a rotation and three
+// double-precision divisions. Same expressions, same order: same bits.
+struct BeamOrigin
+{
+  float4 rot;    // normalised quaternion (x, y, z, w): transforms the end points (beam.cpp:139)
+  float4 begin;  // s.pos_ + s.rot_ * origin with the RAW quaternion (beam.cpp:145); w = 1 if within the map
+  int4 voxel;    // toIndex(begin)
+  float4 pos;    // particle position
+};
+
+__global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, const float4* __restrict__ origins, int n_o,
+                                   DdaGrid g, BeamOrigin* __restrict__ out)
+{
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(n_p) * n_o)
+    return;
+  const long long p = t / n_o;
+  const int o = static_cast<int>(t - p * n_o);
+  const float* ps = pose7 + 7 * p;
+  const Vec3f pos = { ps[0], ps[1], ps[2] };
+  const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
+  const Quat rot = qnormalized(raw);
+  const float4 og = origins[o];
+  const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));
+  BeamOrigin r;
+  r.rot = make_float4(rot.x, rot.y, rot.z, rot.w);
+  const bool within = point_within_map(g, begin);
+  r.begin = make_float4(begin.x, begin.y, begin.z, within ? 1.0f : 0.0f);
+  int bx = 0, by = 0, bz = 0;
+  if (within)
+    to_index(g, begin, bx, by, bz);
+  r.voxel = make_int4(bx, by, bz, 0);
+  r.pos = make_float4(pos.x, pos.y, pos.z, 0.f);
+  out[t] = r;
+}
+
 // One lane per (particle, beam point).  scan_beam.w = origin index (PointXYZIL::label of the scan point).
+// prepared != nullptr: the per-(particle, origin) table of beam_origin_kernel ([n_p][n_o]); nullptr: every ray computes
+// its own begin point (small launches, where one more kernel launch costs more than it saves).
 template <bool STATS>
 __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
                                                    int n_b, const float4* __restrict__ origins, long long n_rays,
                                                    DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
-                                                   RayStats* __restrict__ stats)
+                                                   RayStats* __restrict__ stats,
+                                                   const BeamOrigin* __restrict__ prepared, int n_o)
 {
   const long long ray0 = static_cast<long long>(blockIdx.x) * 256;
   const long long ray = ray0 + threadIdx.x;
@@ -248,16 +308,29 @@ __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pos
   {
     p = ray / n_b;
     const int i = static_cast<int>(ray - p * n_b);
-    const float* ps = pose7 + 7 * p;
-    const Vec3f pos = { ps[0], ps[1], ps[2] };
-    const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
-    const Quat rot = qnormalized(raw);
     const float4 v = scan[i];
-    const Vec3f end = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);  // beam.cpp:139 (transform)
-    const float4 og = origins[__float_as_uint(v.w)];
-    const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
-    int hit;
-    const int status = cast_ray<STATS>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
+    int hit, status;
+    if (prepared)
+    {
+      const BeamOrigin bo = prepared[p * n_o + __float_as_uint(v.w)];
+      const Vec3f end = vadd(qrot(Quat{ bo.rot.x, bo.rot.y, bo.rot.z, bo.rot.w }, Vec3f{ v.x, v.y, v.z }),
+                             Vec3f{ bo.pos.x, bo.pos.y, bo.pos.z });  // beam.cpp:139 (transform)
+      status = 2;
+      if (bo.begin.w != 0.0f)
+        status = cast_ray_from<STATS>(g, bp, Vec3f{ bo.begin.x, bo.begin.y, bo.begin.z }, bo.voxel.x, bo.voxel.y, bo.voxel.z,
+                                      end, &hit, st_steps, st_occ, st_tested);
+    }
+    else
+    {
+      const float* ps = pose7 + 7 * p;
+      const Vec3f pos = { ps[0], ps[1], ps[2] };
+      const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
+      const Quat rot = qnormalized(raw);
+      const Vec3f end = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);  // beam.cpp:139 (transform)
+      const float4 og = origins[__float_as_uint(v.w)];
+      const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
+      status = cast_ray<STATS>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
+    }
     penalised = (status == 0) || (!bp.short_only && (status == 2));  // beam.cpp:146
   }
   const int rel = static_cast<int>(p - p0);  // >= 0; small N_b puts many particles in one work-group

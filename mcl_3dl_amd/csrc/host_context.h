@@ -120,6 +120,10 @@ struct mcl3dl_hip_ctx
 
   // scans of the current update
   DevBuf scan_lik, scan_beam, origins, pow_table;
+  // per-(particle, origin) ray constants (beam_origin_kernel) for launches of at least beam_prepare_min_rays rays
+  DevBuf beam_origin;
+  int beam_prepare = 1;
+  long long beam_prepare_min_rays = 32768;
   size_t n_s = 0, n_b = 0, n_o = 0;
   bool has_scan = false;
   bool pow_table_dirty = true;

@@ -201,6 +201,10 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (blocks > 0x7fffffffLL)
         return ctx->fail(-3, "too many rays for one launch");
       TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+      const bool beam_prepared = !stats && ctx->beam_prepare && n_rays >= ctx->beam_prepare_min_rays &&
+                                 static_cast<long long>(n_p) * static_cast<long long>(ctx->n_o) < 0x7fffffffLL;
+      if (beam_prepared)
+        TRY(ensure(ctx, ctx->beam_origin, sizeof(BeamOrigin) * n_p * ctx->n_o));
       if (stats)
         TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
       const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0;
@@ -220,13 +224,26 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), bs));
         hipLaunchKernelGGL((beam_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
                            ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
-                           ctx->dg, bp, ctx->penalty.as<unsigned>(), ctx->ray_stats.as<RayStats>());
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), ctx->ray_stats.as<RayStats>(),
+                           static_cast<const BeamOrigin*>(nullptr), static_cast<int>(ctx->n_o));
       }
       else
       {
+        // what depends only on (particle, origin) is computed once per pair when the launch is large enough to pay for
+        // one more kernel
+        const BeamOrigin* prepared = nullptr;
+        if (beam_prepared)
+        {
+          const long long n_pairs = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_o);
+          hipLaunchKernelGGL(beam_origin_kernel, dim3(static_cast<unsigned>((n_pairs + 255) / 256)), dim3(256), 0, bs, d_pose,
+                             np, ctx->origins.as<float4>(), static_cast<int>(ctx->n_o), ctx->dg,
+                             ctx->beam_origin.as<BeamOrigin>());
+          prepared = ctx->beam_origin.as<BeamOrigin>();
+        }
         hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
                            ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
-                           ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr));
+                           ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr), prepared,
+                           static_cast<int>(ctx->n_o));
         hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,
                            ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
                            np);

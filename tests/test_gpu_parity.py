@@ -488,3 +488,30 @@ def test_voxel_edge_is_chosen_from_the_map_and_overflow_rounds_are_exact(engine,
     setup_engine(engine, sc2, dw, stamp=91)
     engine.measure_batch(sc2.poses, sc2.scan_lik)
     assert abs(engine.index_stats()["voxel_ratio"] - 0.5) < 1e-6
+
+
+def test_prepared_beam_origins_are_bit_identical(engine, oracle_kind):
+    """Launches of >= 32 768 rays take the per-(particle, origin) constants (normalised quaternion, begin point, its voxel,
+    the within-map flag) from beam_origin_kernel instead of every ray recomputing them: same expressions, same scores —
+    with three origins, unnormalised quaternions, particles whose sensor origin lies outside the map, both penalty modes."""
+    sc = make_scene(n=91, n_p=300, n_s=64, n_b=160, seed=77, sigma_xyz=(1.0, 1.0, 0.3), sigma_rpy=(0.05, 0.05, 1.0))
+    sc.poses[::9, 0] += 25.0          # begin outside the map: LONG for every ray
+    sc.poses[1::5, 3:] *= np.float32(1.7)   # raw quaternion not of unit length (beam.cpp:145 rotates the origin with it)
+    origins = np.array([[0, 0, 0.5], [0.3, -0.1, 0.4], [-0.2, 0.2, 0.8]], np.float32)
+    origin_id = (np.arange(len(sc.scan_beam)) % 3).astype(np.uint32)
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=9100, dist_weight=None)
+    res = {}
+    try:
+        for short_only in (True, False):
+            engine.set_beam_params(num_points=160, add_penalty_short_only_mode=short_only)
+            for prep in (1, 0):
+                engine.set_option("beam_prepare", prep)
+                res[(short_only, prep)] = engine.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, origin_id, origins)[2]
+    finally:
+        engine.set_option("beam_prepare", 1)
+    for short_only in (True, False):
+        np.testing.assert_array_equal(res[(short_only, 1)], res[(short_only, 0)])
+    o = make_oracle(oracle_kind, sc, None, beam_kw=dict(num_points=160, add_penalty_short_only_mode=False))
+    want, _ = o.beam_measure(sc.poses, sc.scan_beam, origin_id, origins)
+    np.testing.assert_array_equal(res[(False, 1)], want)
+    assert len(np.unique(want)) > 3
