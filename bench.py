@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--lik-coop", type=int, default=-1,
                     help="quad-cooperative record fetch (-1 = the library's default, 1 = on, 0 = every lane fetches its "
                          "own record)")
+    ap.add_argument("--pf-fused", type=int, default=-1, help="pf::measure as one kernel on one GPU (-1 = the library's default)")
     ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
     ap.add_argument("--map-jitter", type=float, default=0.0,
                     help="displace every map point uniformly by +-this (m): voxel-filter centroids instead of a lattice")
@@ -384,6 +385,8 @@ def main():
     if args.lik_coop >= 0:
         eng.set_option("lik_coop", args.lik_coop)
     lik_coop = int(eng.get_option("lik_coop"))
+    if args.pf_fused >= 0:
+        eng.set_option("pf_fused", args.pf_fused)
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
@@ -414,6 +417,12 @@ def main():
 
     def step(sh):
         sh.d_w.copy_(sh.d_w0)  # resampling leaves uniform weights before every update (pf.h:203,207)
+        if not use_dist:
+            # one GPU: the single-GPU entry point — measure + pf::measure in ONE C call (pf::measure as one kernel up to
+            # 4096 particles); the split form below exists for the collective between its halves
+            eng.update_device(sh.d_pose, sh.n, sh.d_w, sh.d_stats, d_lik=sh.d_lik, d_ratio=sh.d_ratio,
+                              d_beam=sh.d_beam if n_b else None)
+            return
         eng.measure_device(sh.d_pose, sh.n, sh.d_lik, sh.d_ratio, sh.d_beam if n_b else None)
         eng.pf_partial_device(sh.d_w, sh.d_lik, sh.d_beam if n_b else None, None, sh.d_ratio, sh.n, sh.d_pack, rank, world)
         if use_dist:
@@ -514,6 +523,10 @@ def main():
     for _ in range(args.steps):
         sh = main_sh
         sh.d_w.copy_(sh.d_w0)
+        if not use_dist:
+            eng.update_device(sh.d_pose, sh.n, sh.d_w, sh.d_stats, d_lik=sh.d_lik, d_ratio=sh.d_ratio,
+                              d_beam=sh.d_beam if n_b else None)
+            continue
         eng.measure_device(sh.d_pose, sh.n, sh.d_lik, sh.d_ratio, sh.d_beam if n_b else None)
         eng.pf_partial_device(sh.d_w, sh.d_lik, sh.d_beam if n_b else None, None, sh.d_ratio, sh.n, sh.d_pack, rank, world)
         if use_dist:
@@ -655,7 +668,8 @@ def main():
                                " + beam (DDA) %d rays/particle" % n_b if n_b else "", args.dist_weight_z),
                 "particles_total": n_total, "particles_per_gpu": n_p, "scan_points": n_s, "beam_points": n_b,
                 "map_points": int(len(sc.map_xyz)),
-                "parallelism": "particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world,
+                "parallelism": ("particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world if use_dist else
+                                "one GPU, mcl3dl_hip_update_device (measure + pf::measure in one call, no collective)"),
                 "update_hz": 1e3 / ms_per_step,
                 "accumulate": ("float, reference order (bit-identical results)" if args.strict_order else
                                "fp64 tree (terms bit-identical to the reference's float terms)"),

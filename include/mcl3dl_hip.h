@@ -398,9 +398,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
  *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
  *                       results either way.
- *   "pf_fused"          1 (default) = pf::measure of the single-GPU entry points runs as ONE work-group up to 4096 particles
- *                       (the reference's operating range is launch-bound); 0 = always partial + reduce + apply.
- *                       Same bits either way.
+ *   "pf_fused"          1 (default) = pf::measure of the single-GPU entry points runs as ONE work-group up to
+ *                       "pf_fused_max" particles (default 1024, at most 4096: measured faster than three launches up to
+ *                       1024, slower at 4096); 0 = always partial + reduce + apply. Same bits either way.
  *   "lik_coop"          tiled kernel: 1 (default) = the four lanes of a quad fetch each 64-byte voxel record together
  *                       (16 cache-line accesses per load instruction instead of 64) and split its candidates between
  *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record

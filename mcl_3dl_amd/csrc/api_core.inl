@@ -428,12 +428,12 @@ int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_
 // ---- host entry points -------------------------------------------------------------------------------------
 namespace
 {
-// pf::measure on one GPU: the fused single-work-group kernel up to PF_FUSED_MAX particles (same bits as the split form,
-// two launches fewer), partial + reduce + apply beyond, or with strict_order (which replaces the sum between the two).
+// pf::measure on one GPU: the fused single-work-group kernel up to pf_fused_max particles (default 1024; the kernel takes up
+// to PF_FUSED_MAX = 4096 — same bits as the split form, two launches fewer), partial + reduce + apply beyond, or with strict_order (which replaces the sum between the two).
 int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
                       const float* d_ratio, size_t n_p, float* d_stats4)
 {
-  if (n_p <= static_cast<size_t>(PF_FUSED_MAX) && !ctx->strict_order && ctx->pf_fused)
+  if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && !ctx->strict_order && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
     EventPair ep{};

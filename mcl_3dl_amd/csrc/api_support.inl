@@ -126,6 +126,14 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->pf_fused = value != 0.0;
     return 0;
   }
+  if (key == "pf_fused_max")
+  {
+    if (!(value >= 1.0 && value <= static_cast<double>(PF_FUSED_MAX)))
+      return ctx->fail(-3, "pf_fused_max must be 1..%d", PF_FUSED_MAX);
+    ctx->pf_fused_max = static_cast<int>(value);
+    ++ctx->generation;
+    return 0;
+  }
   if (key == "lik_coop")
   {
     ctx->lik_coop = value != 0.0;
@@ -184,6 +192,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[0];
   else if (key == "dda_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[1];
   else if (key == "pf_fused") *value = ctx->pf_fused;
+  else if (key == "pf_fused_max") *value = ctx->pf_fused_max;
   else if (key == "scan_order_device") *value = ctx->scan_order_device;
   else
     return ctx->fail(-3, "unknown option '%s'", name);

@@ -90,7 +90,8 @@ struct mcl3dl_hip_ctx
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
   int lik_coop = 1;        // tiled kernel: 1 = quad-cooperative record fetch + VALU-trimmed evaluation (same results)
   DevBuf lik_partial_sum, lik_partial_cnt;
-  int pf_fused = 1;        // 1 = pf::measure as ONE kernel up to PF_FUSED_MAX particles on one GPU (same bits, two launches fewer)
+  int pf_fused = 1;        // 1 = pf::measure as ONE kernel up to pf_fused_max particles on one GPU (same bits, two launches fewer)
+  int pf_fused_max = 1024;  // measured: one work-group beats three launches up to 1024 particles, ties at 2048, loses at 4096
   int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
   DevBuf scan_perm, strict_terms;
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
