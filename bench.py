@@ -134,6 +134,55 @@ def pmc_counters(kernel_prefix, workload):
     return vals, os.path.relpath(src, ROOT)
 
 
+def kernel_resources(pmc, kernel_s, cost, cost_src):
+    """Counter-derived utilisation of one kernel: {resource: {achieved, peak, unit, frac}} and the HBM-side bytes per launch.
+    pmc = mean per launch of the counters of separate --pmc passes (profiles/), kernel_s = measured seconds per launch."""
+    res = {}  # resource -> {"achieved", "peak", "unit", "frac"}
+    traffic = None
+    if pmc and kernel_s > 0:
+        if "FETCH_SIZE" in pmc:
+            # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes fetched
+            # (MI355X_MICROARCH.md, HBM section), hence the factor 2
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
+            gbps = traffic / kernel_s / 1e9
+            res["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                          "note": "cache-resident by construction: tile-major, XCD-aware launch keeps a scan "
+                                  "tile's voxel records in one XCD's L2"}
+        if "TCP_TCC_READ_REQ_sum" in pmc:
+            gbps = pmc["TCP_TCC_READ_REQ_sum"] * L2_LINE_BYTES / kernel_s / 1e9
+            res["l2"] = {"achieved": gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": gbps / L2_PEAK_GBPS,
+                         "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": L2_LINE_BYTES}
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc:
+            rate = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (kernel_s * CLOCK_HZ)
+            res["l1_access"] = {"achieved": rate, "peak": L1_ACCESS_CEILING, "unit": "cache-line accesses/cycle/CU",
+                                "frac": min(rate / L1_ACCESS_CEILING, 1.0),
+                                "accesses_per_launch": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                                "note": "peak = measured ceiling (see bench.py L1_ACCESS_CEILING), not a datasheet value"}
+        if "SQ_INSTS_VALU" in pmc:
+            # instruction mix from the per-class counters (separate PMC pass). Known classes are priced exactly; what
+            # the counters do not split (32-bit integer ops, and everything unclassified: moves, DPP moves, compares,
+            # selects) is priced between the full and the half rate -> a low and a high estimate; `frac` is their mean
+            n_all = pmc["SQ_INSTS_VALU"]
+            have_mix = "SQ_INSTS_VALU_ADD_F32" in pmc
+            n_full = pmc.get("SQ_INSTS_VALU_ADD_F32", 0.0) + pmc.get("SQ_INSTS_VALU_MUL_F32", 0.0)
+            n_trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            n_half = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64",
+                                                    "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                    "SQ_INSTS_VALU_FMA_F64"))
+            n_mixed = max(n_all - n_full - n_trans - n_half, 0.0)
+            fixed = n_full * cost["full"] + n_half * cost["half"] + n_trans * cost["trans"]
+            avail = N_SIMD * kernel_s * CLOCK_HZ
+            lo, hi = (fixed + n_mixed * cost["full"]) / avail, (fixed + n_mixed * cost["half"]) / avail
+            mid = 0.5 * (lo + hi)
+            res["valu_issue"] = {"achieved": mid * avail / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
+                                 "unit": "G SIMD-cycles/s", "frac": min(mid, 1.0), "frac_low": lo, "frac_high": hi,
+                                 "wave_instructions_per_launch": n_all, "full_rate": n_full, "half_rate": n_half,
+                                 "transcendental": n_trans, "between_full_and_half_rate": n_mixed,
+                                 "cycles_per_instruction": cost, "cycles_per_instruction_source": cost_src,
+                                 "mix_from_counters": have_mix}
+    return res, traffic
+
+
 def valu_costs():
     """Cycles one wave64 VALU instruction occupies a SIMD, by class, from the newest committed run of
     profiles/valu_microbench.hip (the version that places exactly W wavefronts on every SIMD: r02d onwards): column
@@ -581,49 +630,7 @@ def main():
         pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, args.workload)
         cost, cost_src = valu_costs()
         kernel_s = lik_avg_ms * 1e-3
-        res = {}  # resource -> {"achieved", "peak", "unit", "frac"}
-        traffic = None
-        if pmc and lik_n:
-            if "FETCH_SIZE" in pmc:
-                # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes fetched
-                # (MI355X_MICROARCH.md, HBM section), hence the factor 2
-                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
-                gbps = traffic / kernel_s / 1e9
-                res["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                              "note": "cache-resident by construction: tile-major, XCD-aware launch keeps a scan "
-                                      "tile's voxel records in one XCD's L2"}
-            if "TCP_TCC_READ_REQ_sum" in pmc:
-                gbps = pmc["TCP_TCC_READ_REQ_sum"] * L2_LINE_BYTES / kernel_s / 1e9
-                res["l2"] = {"achieved": gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": gbps / L2_PEAK_GBPS,
-                             "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": L2_LINE_BYTES}
-            if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc:
-                rate = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (kernel_s * CLOCK_HZ)
-                res["l1_access"] = {"achieved": rate, "peak": L1_ACCESS_CEILING, "unit": "cache-line accesses/cycle/CU",
-                                    "frac": min(rate / L1_ACCESS_CEILING, 1.0),
-                                    "accesses_per_launch": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
-                                    "note": "peak = measured ceiling (see bench.py L1_ACCESS_CEILING), not a datasheet value"}
-            if "SQ_INSTS_VALU" in pmc:
-                # instruction mix from the per-class counters (separate PMC pass). Known classes are priced exactly; what
-                # the counters do not split (32-bit integer ops, and everything unclassified: moves, DPP moves, compares,
-                # selects) is priced between the full and the half rate -> a low and a high estimate; `frac` is their mean
-                n_all = pmc["SQ_INSTS_VALU"]
-                have_mix = "SQ_INSTS_VALU_ADD_F32" in pmc
-                n_full = pmc.get("SQ_INSTS_VALU_ADD_F32", 0.0) + pmc.get("SQ_INSTS_VALU_MUL_F32", 0.0)
-                n_trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-                n_half = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64",
-                                                        "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
-                                                        "SQ_INSTS_VALU_FMA_F64"))
-                n_mixed = max(n_all - n_full - n_trans - n_half, 0.0)
-                fixed = n_full * cost["full"] + n_half * cost["half"] + n_trans * cost["trans"]
-                avail = N_SIMD * kernel_s * CLOCK_HZ
-                lo, hi = (fixed + n_mixed * cost["full"]) / avail, (fixed + n_mixed * cost["half"]) / avail
-                mid = 0.5 * (lo + hi)
-                res["valu_issue"] = {"achieved": mid * avail / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
-                                     "unit": "G SIMD-cycles/s", "frac": min(mid, 1.0), "frac_low": lo, "frac_high": hi,
-                                     "wave_instructions_per_launch": n_all, "full_rate": n_full, "half_rate": n_half,
-                                     "transcendental": n_trans, "between_full_and_half_rate": n_mixed,
-                                     "cycles_per_instruction": cost, "cycles_per_instruction_source": cost_src,
-                                     "mix_from_counters": have_mix}
+        res, traffic = kernel_resources(pmc, kernel_s if lik_n else 0.0, cost, cost_src)
         if res:
             bound = max(res, key=lambda k: res[k]["frac"])
             top = res[bound]
@@ -700,7 +707,21 @@ def main():
         if n_b:
             beam_avg = beam_ms / max(beam_n, 1)
             out["beam"] = {"rays_per_s": ws["rays"] / (beam_avg * 1e-3), "dda_steps_per_s": ws["dda_steps"] / (beam_avg * 1e-3),
-                           "algorithmic_GBps": bytes_beam_launch / (beam_avg * 1e-3) / 1e9, "avg_launch_ms": beam_avg}
+                           "algorithmic_GBps": bytes_beam_launch / (beam_avg * 1e-3) / 1e9, "avg_launch_ms": beam_avg,
+                           "avg_launch_ms_includes": "penalty memset + beam_origin_kernel + beam_kernel + beam_finalize_kernel "
+                                                     "(one timed group, run alone: overlap_models = 0)"}
+            # the beam kernel's own counter-derived fractions (same pricing as `roofline`), against the kernel's share of the
+            # timed group: its rocprofv3 share of beam_kernel in the group is > 95 % at these sizes
+            bpmc, bsrc = pmc_counters("void mcl3dl::beam_kernel<false>", args.workload)
+            if bpmc:
+                bres, btraffic = kernel_resources(bpmc, beam_avg * 1e-3, cost, cost_src)
+                for r in bres.values():
+                    r.pop("note", None)
+                if bres:
+                    bb = max(bres, key=lambda k: bres[k]["frac"])
+                    out["beam"]["roofline"] = {"bound": bb, "frac": bres[bb]["frac"], "traffic": btraffic,
+                                               "counters_source": bsrc, "resources": bres,
+                                               "algorithmic_bytes_per_launch": bytes_beam_launch}
         d_pose, d_w, d_w0, d_lik, d_ratio, d_beam, d_stats = (main_sh.d_pose, main_sh.d_w, main_sh.d_w0, main_sh.d_lik,
                                                               main_sh.d_ratio, main_sh.d_beam, main_sh.d_stats)
         if world == 1:
