@@ -515,3 +515,32 @@ def test_prepared_beam_origins_are_bit_identical(engine, oracle_kind):
     want, _ = o.beam_measure(sc.poses, sc.scan_beam, origin_id, origins)
     np.testing.assert_array_equal(res[(False, 1)], want)
     assert len(np.unique(want)) > 3
+
+
+@pytest.mark.parametrize("n_s,n_p", [(2700, 300), (800, 300), (4096, 37), (2048 + 256, 1000), (700, 5)])
+def test_tile_to_xcd_mapping_covers_every_pair_once(engine, oracle_kind, n_s, n_p):
+    """blockIdx -> (tile, particle group): the tiles of the largest multiple of eight are interleaved over the XCDs, the
+    remaining n_tiles % 8 tiles are shared out by particle group. Shapes with both parts (11 and 9 tiles), only the second
+    (4 and 3 tiles, the 768-point rule for >= 256 particles), only the first (16 tiles), ragged particle groups and a ragged
+    last tile: match ratios equal the per-particle kernel's, likelihoods to one float rounding, both within the gate of the
+    reference."""
+    sc = make_scene(n=91, n_p=n_p, n_s=n_s, seed=7 + n_s, sigma_xyz=(0.6, 0.6, 0.1), sigma_rpy=(0.03, 0.03, 0.4))
+    dw = (1.0, 1.0, 2.0)
+    setup_engine(engine, sc, dw, stamp=700 + n_s)
+    try:
+        engine.set_option("lik_tiled", 0)
+        lik0, ratio0, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        engine.set_option("lik_tiled", 1)
+        engine.set_option("lik_tiled_min", 512)
+        lik1, ratio1, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    finally:
+        engine.set_option("lik_tiled", 1)
+        engine.set_option("lik_tiled_min", 1024)
+    np.testing.assert_array_equal(ratio1, ratio0)
+    np.testing.assert_allclose(lik1, lik0, rtol=1.2e-7)
+    k = min(n_p, 64)
+    o = make_oracle(oracle_kind, sc, dw)
+    wl, wq = o.likelihood_measure(sc.poses[:k], sc.scan_lik)
+    np.testing.assert_allclose(lik1[:k], wl, rtol=RTOL)
+    np.testing.assert_array_equal(ratio1[:k], wq)
+    assert np.count_nonzero(wq) == k
