@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--lik-coop", type=int, default=-1,
                     help="quad-cooperative record fetch (-1 = the library's default, 1 = on, 0 = every lane fetches its "
                          "own record)")
+    ap.add_argument("--lik-wide", type=int, default=-1,
+                    help="up to this many particles a scan of > 512 points gets 1024 threads per particle (-1 = default)")
     ap.add_argument("--pf-fused", type=int, default=-1, help="pf::measure as one kernel on one GPU (-1 = the library's default)")
     ap.add_argument("--beam-points", type=int, default=0, help="override the beam scan size N_b")
     ap.add_argument("--map-jitter", type=float, default=0.0,
@@ -436,6 +438,8 @@ def main():
     lik_coop = int(eng.get_option("lik_coop"))
     if args.pf_fused >= 0:
         eng.set_option("pf_fused", args.pf_fused)
+    if args.lik_wide >= 0:
+        eng.set_option("lik_wide_max_particles", args.lik_wide)
     eng.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
     eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
 
@@ -626,7 +630,8 @@ def main():
         elif small:
             kernel_name = "likelihood_small_kernel<"
         else:
-            kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 256, args.lik_index)
+            wide = args.lik_index == 2 and n_s > 512 and n_p <= int(eng.get_option("lik_wide_max_particles"))
+            kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 1024 if wide else 256, args.lik_index)
         pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, args.workload)
         cost, cost_src = valu_costs()
         kernel_s = lik_avg_ms * 1e-3

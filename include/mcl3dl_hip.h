@@ -404,6 +404,11 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "lik_coop"          tiled kernel: 1 (default) = the four lanes of a quad fetch each 64-byte voxel record together
  *                       (16 cache-line accesses per load instruction instead of 64) and split its candidates between
  *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record
+ *   "lik_wide_max_particles"  default 64: up to this many particles a scan of more than 512 points is walked by 1024
+ *                       threads per particle instead of 256 (a quarter of the dependent load chains per lane: the
+ *                       reference's own 64 x 1000 case is latency-bound); 0 = never
+ *   "beam_prepare"      1 (default) = launches of >= 32 768 rays take what depends only on (particle, origin) from a
+ *                       small kernel instead of every ray recomputing it; 0 = never
  *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
  *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
  *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",

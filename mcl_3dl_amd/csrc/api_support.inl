@@ -145,6 +145,14 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ++ctx->generation;
     return 0;
   }
+  if (key == "lik_wide_max_particles")
+  {
+    if (!(value >= 0.0 && value <= 2e9))
+      return ctx->fail(-3, "lik_wide_max_particles must be >= 0");
+    ctx->lik_wide_max_particles = static_cast<int>(value);
+    ++ctx->generation;
+    return 0;
+  }
   if (key == "grid_build_host")
   {
     const int v = value != 0.0;
@@ -186,6 +194,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
   else if (key == "beam_prepare") *value = ctx->beam_prepare;
+  else if (key == "lik_wide_max_particles") *value = ctx->lik_wide_max_particles;
   else if (key == "grid_build_host") *value = ctx->grid_build_host;
   else if (key == "lik_grid_build_ms") *value = ctx->grid_build_ms[0];
   else if (key == "dda_grid_build_ms") *value = ctx->grid_build_ms[1];

@@ -88,6 +88,7 @@ struct mcl3dl_hip_ctx
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_tiled_min = 1024;  // scans of at least this many points take the tiled kernel
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
+  int lik_wide_max_particles = 64;  // up to this many particles a scan of > 512 points gets 1024 threads per particle (C1: 9.9 -> 7.5 us; no gain from 128 particles up)
   int lik_coop = 1;        // tiled kernel: 1 = quad-cooperative record fetch + VALU-trimmed evaluation (same results)
   DevBuf lik_partial_sum, lik_partial_cnt;
   int pf_fused = 1;        // 1 = pf::measure as ONE kernel up to pf_fused_max particles on one GPU (same bits, two launches fewer)

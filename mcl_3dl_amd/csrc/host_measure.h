@@ -392,6 +392,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         {
           if (ns <= 128)
             LAUNCH_LIK(64, 2);
+          else if (np <= ctx->lik_wide_max_particles && ns > 512)
+            LAUNCH_LIK(1024, 2);  // few particles: 16 wavefronts share a scan — a quarter of the dependent load chains per lane
           else
             LAUNCH_LIK(256, 2);
         }
