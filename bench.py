@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--lik-coop", type=int, default=-1,
                     help="quad-cooperative record fetch (-1 = the library's default, 1 = on, 0 = every lane fetches its "
                          "own record)")
+    ap.add_argument("--cand-record-parts", type=int, default=-1,
+                    help="inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map (-1 = default)")
     ap.add_argument("--lik-wide", type=int, default=-1,
                     help="up to this many particles a scan of > 512 points gets 1024 threads per particle (-1 = default)")
     ap.add_argument("--pf-fused", type=int, default=-1, help="pf::measure as one kernel on one GPU (-1 = the library's default)")
@@ -425,6 +427,8 @@ def main():
     eng.set_option("lik_index", args.lik_index)
     eng.set_option("cand_voxel_ratio", args.cand_voxel_ratio)
     eng.set_option("cand_phase", args.cand_phase)
+    if args.cand_record_parts >= 0:
+        eng.set_option("cand_record_parts", args.cand_record_parts)
     eng.set_option("strict_order", args.strict_order)
     eng.set_option("lik_tiled", args.lik_tiled)
     eng.set_option("lik_small", args.lik_small)

@@ -380,6 +380,10 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min; 0 (default) = chosen per map: 0.5, or 0.36 when more than a
  *                       quarter of the voxels hold more candidates than a record has room for
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
+ *   "cand_record_parts" inline candidates per voxel record: 4 (64-byte records), 8 (128-byte records: one 128-byte line
+ *                       per lookup, all eight loads issued together), 0 (default) = 4, or 8 together with the smaller
+ *                       voxel edge on a crowded map when the records stay below 16 GB (measured: -7 % on such a map,
+ *                       +20 % on a lattice). Read-only: "cand_record_parts_in_use", "cand_voxels_over8"
  *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= "lik_tiled_min" points and >= 4
  *                       particles; 0 = one work-group per particle always (only the fp64 summation order differs)
  *   "lik_tiled_min"     default 1024; with >= 256 particles the tiled kernel already takes over at three quarters of it

@@ -648,4 +648,5 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_index_stats(self.h, _ptr(s)))
         return dict(bricks=int(s[0]), preliminary=int(s[1]), candidates=int(s[2]), build_ms=float(s[3]),
                     voxels_with_candidates=int(s[4]), voxels_with_overflow=int(s[5]), overflow_records=int(s[6]),
-                    voxel_ratio=float(s[7]))
+                    voxel_ratio=float(s[7]), voxels_over8=int(self.get_option("cand_voxels_over8")),
+                    record_parts=int(self.get_option("cand_record_parts_in_use")))

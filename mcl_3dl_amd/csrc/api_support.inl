@@ -164,6 +164,18 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     }
     return 0;
   }
+  if (key == "cand_record_parts")
+  {
+    if (value != 0.0 && value != 4.0 && value != 8.0)
+      return ctx->fail(-3, "cand_record_parts must be 0 (chosen per map), 4 (64-byte records) or 8 (128-byte records)");
+    if (static_cast<int>(value) != ctx->cand_record_parts)
+    {
+      ctx->cand_dirty = true;
+      ++ctx->generation;
+    }
+    ctx->cand_record_parts = static_cast<int>(value);
+    return 0;
+  }
   if (key == "cand_phase")
   {
     if (!(value >= 0.0 && value < 1.0))
@@ -184,6 +196,9 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   if (key == "lik_index") *value = ctx->lik_index;
   else if (key == "cand_voxel_ratio") *value = ctx->cand_voxel_ratio;
   else if (key == "cand_phase") *value = ctx->cand_phase;
+  else if (key == "cand_record_parts") *value = ctx->cand_record_parts;
+  else if (key == "cand_record_parts_in_use") *value = ctx->cand_parts;
+  else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "timing_mask") *value = ctx->timing_mask;
   else if (key == "use_graph") *value = ctx->use_graph;

@@ -97,6 +97,9 @@ struct mcl3dl_hip_ctx
   DevBuf scan_perm, strict_terms;
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
+  int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
+  uint32_t cand_parts = 4;        // what the current index was built with
+  double cand_over8 = 0;          // voxels with more than eight candidates (index statistics)
   DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
   // kept for map updates (host_map_compilers.h:update_cand_grid): geometry, sizes, every rescaled map point
   DevBuf cand_all_pts;

@@ -326,20 +326,20 @@ uint32_t bytes32(unsigned long long bytes)
 
 // The compiler proper: for the bricks `table` names (ids 0 .. n_bricks - 1, every other entry -1; bxyz = their brick
 // coordinates) and the points `pts` (cp.n_points of them, device), the candidate set of every voxel: D^2 scatter ->
-// preliminary lists -> domination prune -> 64-byte records into rec_out[n_bricks * 512 * 16 floats] (device) with their
+// preliminary lists -> domination prune -> records of `cap` 16-byte parts into rec_out[n_bricks * 512 * cap * 4 floats] (device) with their
 // overflow records in a fresh allocation (ovf_out, *n_ovf of them). Used for the whole map (build_cand_grid) and for the
 // bricks a map update touches (update_cand_grid).
 struct CompileOutput
 {
   unsigned long long total = 0, kept = 0;
-  unsigned long long hist2[2] = { 0, 0 };  // voxels with candidates, voxels with more than the record holds
+  unsigned long long hist3[3] = { 0, 0, 0 };  // voxels with candidates, with more than four, with more than eight
   uint32_t n_ovf = 0;
   // CSR form (lik_index 1): kept counts per voxel stay in d_count, runs in d_pstart / d_prelim
   TempBuf d_count, d_pstart, d_prelim, d_ovf_data;
 };
 
 int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* pts, const int* table, const int* bxyz,
-                   uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out)
+                   uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out, uint32_t cap = 4)
 {
   const size_t n = static_cast<size_t>(cp.n_points);
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
@@ -401,15 +401,15 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
   HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
   TempBuf d_hist;
-  HIP_TRY(hipMalloc(&d_hist.p, 2 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMalloc(&d_hist.p, 3 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox,
-                     static_cast<unsigned long long*>(d_hist.p));
+                     static_cast<unsigned long long*>(d_hist.p), cap);
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
   uint32_t n_ovf = 0;
   TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
-  TRY(d2h(ctx, out->hist2, d_hist.p, 2 * sizeof(unsigned long long)));
+  TRY(d2h(ctx, out->hist3, d_hist.p, 3 * sizeof(unsigned long long)));
   TRY(sync_stream(ctx));
   HIP_TRY(hipMalloc(&out->d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1)));
   {
@@ -424,14 +424,15 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
                      static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
                      static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p), rec_out,
-                     static_cast<float*>(out->d_ovf_data.p), n_vox);
+                     static_cast<float*>(out->d_ovf_data.p), n_vox, cap);
   HIP_TRY(hipGetLastError());
   out->n_ovf = n_ovf;
   return 0;
 }
 
-int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
+int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4)
 {
+  const unsigned long long rec_bytes = 16ull * cap;  // per voxel
   const size_t n = ctx->map_xyz.size() / 3;
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
@@ -475,10 +476,10 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
   const bool records = ctx->lik_index == 2;
   if (records)
-    TRY(ensure(ctx, ctx->cand_rec, 64ull * static_cast<size_t>(n_vox)));
+    TRY(ensure(ctx, ctx->cand_rec, rec_bytes * static_cast<size_t>(n_vox)));
   CompileOutput co;
   TRY(compile_bricks(ctx, cp, pts, table, static_cast<const int*>(d_bxyz.p), n_bricks, records,
-                     records ? ctx->cand_rec.as<float>() : nullptr, &co));
+                     records ? ctx->cand_rec.as<float>() : nullptr, &co, cap));
   const unsigned long long total = co.total, kept = co.kept;
   ctx->cand_cp = cp;
   ctx->cand_n_table = n_table;
@@ -513,19 +514,22 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
     g.nby = cp.nby;
     g.nbz = cp.nbz;
     g.mul24_ok = (static_cast<long long>(cp.nbx) * cp.nby < (1ll << 24) && cp.nbz < (1 << 24)) ? 1 : 0;
-    g.off32_ok = (64ull * static_cast<unsigned long long>(n_vox) < (1ull << 32)) ? 1 : 0;
-    g.rec_bytes32 = bytes32(64ull * static_cast<unsigned long long>(n_vox));
+    g.off32_ok = (rec_bytes * static_cast<unsigned long long>(n_vox) < (1ull << 32)) ? 1 : 0;
+    g.rec_bytes32 = bytes32(rec_bytes * static_cast<unsigned long long>(n_vox));
+    g.rec_parts = static_cast<int>(cap);
+    ctx->cand_parts = cap;
     g.ovf_bytes32 = bytes32(64ull * (n_ovf ? n_ovf : 1));
     g.ti_empty = static_cast<uint32_t>(n_table);
     ctx->footprint[5] = sizeof(int) * n_table;
-    ctx->footprint[6] = 64ull * static_cast<size_t>(n_vox);
+    ctx->footprint[6] = rec_bytes * static_cast<size_t>(n_vox);
     ctx->footprint[7] = 64ull * n_ovf;
     ctx->cand_stats[0] = n_bricks;
     ctx->cand_stats[1] = static_cast<double>(total);
     ctx->cand_stats[2] = static_cast<double>(kept);
     ctx->cand_stats[3] = ms2;
-    ctx->cand_stats[4] = static_cast<double>(co.hist2[0]);
-    ctx->cand_stats[5] = static_cast<double>(co.hist2[1]);
+    ctx->cand_stats[4] = static_cast<double>(co.hist3[0]);
+    ctx->cand_stats[5] = static_cast<double>(co.hist3[1]);
+    ctx->cand_over8 = static_cast<double>(co.hist3[2]);
     ctx->cand_stats[6] = n_ovf;
     ctx->cand_stats[7] = cp.e / static_cast<double>(ctx->match_dist_min);
     ctx->cand_dirty = false;
@@ -580,13 +584,21 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio)
 // evaluation costs more than the larger table (measured: jittered C2 0.49 -> 0.37 ms, lattice C2 +2 %).
 int build_cand_grid(mcl3dl_hip_ctx* ctx)
 {
+  const uint32_t forced = ctx->cand_record_parts == 8 ? 8u : ctx->cand_record_parts == 4 ? 4u : 0u;
   if (ctx->cand_voxel_ratio > 0.0)
-    return build_cand_grid_at(ctx, ctx->cand_voxel_ratio);
-  TRY(build_cand_grid_at(ctx, 0.5));
-  if (ctx->lik_index == 2 && ctx->cand_stats[4] > 0 && ctx->cand_stats[5] / ctx->cand_stats[4] > 0.25)
+    return build_cand_grid_at(ctx, ctx->cand_voxel_ratio, forced ? forced : 4u);
+  TRY(build_cand_grid_at(ctx, 0.5, forced ? forced : 4u));
+  const double crowded = forced == 8 ? ctx->cand_over8 : ctx->cand_stats[5];  // voxels whose candidates do not fit the record
+  if (ctx->lik_index == 2 && ctx->cand_stats[4] > 0 && crowded / ctx->cand_stats[4] > 0.25)
   {
+    // a crowded map (voxel-filter centroids rather than a lattice): smaller voxels, and — unless the record size is forced —
+    // 128-byte records with eight inline candidates when they stay below 16 GB (estimated from the first build: a voxel of
+    // 0.36 r has (0.5 / 0.36)^3 times as many of them). Measured on the jittered C2 map: 0.42 ms (0.5 r, 64 B) -> 0.364
+    // (0.36 r, 64 B) -> 0.338 (0.36 r, 128 B); on a lattice the wide record costs 20 %, so it is never the default there.
     const double first_ms = ctx->cand_stats[3];
-    TRY(build_cand_grid_at(ctx, 0.36));
+    const double est_bytes = 128.0 * 512.0 * ctx->cand_stats[0] * 2.68;
+    const uint32_t cap = forced ? forced : (est_bytes < 16.0e9 ? 8u : 4u);
+    TRY(build_cand_grid_at(ctx, 0.36, cap));
     ctx->cand_stats[3] += first_ms;
   }
   return 0;
@@ -713,7 +725,9 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
     return 0;
   }
   const uint32_t n_bricks = n_bricks_old + n_new;
-  TRY(ensure_keep(ctx, ctx->cand_rec, 64ull * 512 * n_bricks_old, 64ull * 512 * n_bricks));
+  const uint32_t cap = ctx->cand_parts;
+  const unsigned long long rec_bytes = 16ull * cap;
+  TRY(ensure_keep(ctx, ctx->cand_rec, rec_bytes * 512 * n_bricks_old, rec_bytes * 512 * n_bricks));
   HIP_TRY(hipMalloc(&d_sub_table.p, sizeof(int) * n_table));
   HIP_TRY(hipMalloc(&d_sub_main.p, sizeof(int) * n_dirty));
   HIP_TRY(hipMalloc(&d_sub_bxyz.p, sizeof(int) * 3 * n_dirty));
@@ -737,11 +751,11 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
                      static_cast<float4*>(d_rel.p));
   // 4. compile the dirty bricks and install them
   const long long n_sub_vox = static_cast<long long>(n_dirty) * 512;
-  HIP_TRY(hipMalloc(&d_subrec.p, 64ull * static_cast<size_t>(n_sub_vox)));
+  HIP_TRY(hipMalloc(&d_subrec.p, rec_bytes * static_cast<size_t>(n_sub_vox)));
   cp.n_points = static_cast<int>(n_rel);
   CompileOutput co;
   TRY(compile_bricks(ctx, cp, static_cast<const float4*>(d_rel.p), static_cast<const int*>(d_sub_table.p),
-                     static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co));
+                     static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co, cap));
   const uint32_t ovf_base = ctx->cand_n_ovf;
   if (co.n_ovf)
   {
@@ -754,7 +768,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   HIP_TRY(hipMemsetAsync(d_orphan.p, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_install_records, dim3(static_cast<unsigned>((n_sub_vox + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_bricks_old,
-                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p));
+                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p), cap);
   HIP_TRY(hipGetLastError());
   unsigned long long orphaned = 0;
   TRY(d2h(ctx, &orphaned, d_orphan.p, sizeof(orphaned)));
@@ -771,10 +785,10 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   ctx->rg.brick_table = ctx->cand_table.as<int>();
   ctx->rg.rec = ctx->cand_rec.as<float4>();
   ctx->rg.ovf = ctx->cand_ovf.as<float4>();
-  ctx->rg.off32_ok = (64ull * 512 * n_bricks < (1ull << 32)) ? 1 : 0;
-  ctx->rg.rec_bytes32 = bytes32(64ull * 512 * n_bricks);
+  ctx->rg.off32_ok = (rec_bytes * 512 * n_bricks < (1ull << 32)) ? 1 : 0;
+  ctx->rg.rec_bytes32 = bytes32(rec_bytes * 512 * n_bricks);
   ctx->rg.ovf_bytes32 = bytes32(64ull * (ctx->cand_n_ovf ? ctx->cand_n_ovf : 1));
-  ctx->footprint[6] = 64ull * 512 * n_bricks;
+  ctx->footprint[6] = rec_bytes * 512 * n_bricks;
   ctx->footprint[7] = 64ull * ctx->cand_n_ovf;
   ctx->cand_stats[0] = n_bricks;
   ++ctx->generation;

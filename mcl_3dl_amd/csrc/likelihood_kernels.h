@@ -188,33 +188,18 @@ __device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz
          static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
 }
 
-// min d2 over the candidates a voxel's overflow records hold (candidates 4 .. count - 1; four per 64-byte record, laid
-// out like the voxel record itself: part j = {x, y, z, -})
-__device__ inline float rec_overflow_min(const RecGrid& g, float qx, float qy, float qz, uint32_t count, uint32_t ext,
-                                         float best)
+// min d2 over the candidates a voxel's overflow records hold (candidates cap .. count - 1; four per 64-byte record, laid
+// out like the first half of a voxel record: part j = {x, y, z, -})
+__device__ inline float rec_overflow_min(const RecGrid& g, float qx, float qy, float qz, uint32_t count, uint32_t cap,
+                                         uint32_t ext, float best)
 {
   const float4* o = g.ovf + 4 * static_cast<size_t>(ext);
-  for (uint32_t j = 0; j < count - 4; ++j)
+  for (uint32_t j = 0; j < count - cap; ++j)
   {
     const float4 c = o[j];
     const float d = d2_simple(qx, qy, qz, c.x, c.y, c.z);
     best = d < best ? d : best;
   }
-  return best;
-}
-
-// step 3 of a lookup: min d2 over the candidates of a loaded record
-__device__ inline float rec_min_d2(const RecGrid& g, float qx, float qy, float qz, const float4 r0, const float4 r1,
-                                   const float4 r2, const float4 r3)
-{
-  const float d0 = d2_simple(qx, qy, qz, r0.x, r0.y, r0.z);
-  const float d1 = d2_simple(qx, qy, qz, r1.x, r1.y, r1.z);
-  const float d2 = d2_simple(qx, qy, qz, r2.x, r2.y, r2.z);
-  const float d3 = d2_simple(qx, qy, qz, r3.x, r3.y, r3.z);
-  float best = fminf(fminf(d0, d1), fminf(d2, d3));
-  const uint32_t count = __float_as_uint(r0.w);
-  if (count > 4)
-    best = rec_overflow_min(g, qx, qy, qz, count, __float_as_uint(r1.w), best);
   return best;
 }
 
@@ -228,14 +213,24 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
   const int b = g.brick_table[ti];
   if (b < 0)
     return best;
-  const float4* r = g.rec + 4 * static_cast<size_t>((static_cast<uint32_t>(b) << 9) | sub);
-  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  const uint32_t cap = static_cast<uint32_t>(g.rec_parts);
+  const float4* r = g.rec + static_cast<size_t>(cap) * ((static_cast<uint32_t>(b) << 9) | sub);
+  const float4 r0 = r[0], r1 = r[1];
   const uint32_t count = __float_as_uint(r0.w);
   if (count == 0)
     return best;
   if (STATS)
     n_tested += count;
-  return rec_min_d2(g, qx, qy, qz, r0, r1, r2, r3);
+  // unused slots hold the sentinel: the minimum over all inline slots needs no look at the count
+  best = fminf(d2_simple(qx, qy, qz, r0.x, r0.y, r0.z), d2_simple(qx, qy, qz, r1.x, r1.y, r1.z));
+  for (uint32_t k = 2; k < cap; ++k)
+  {
+    const float4 c = r[k];
+    best = fminf(best, d2_simple(qx, qy, qz, c.x, c.y, c.z));
+  }
+  if (count > cap)
+    best = rec_overflow_min(g, qx, qy, qz, count, cap, __float_as_uint(r1.w), best);
+  return best;
 }
 
 // ---- VALU-trimmed forms (profiles/r02b_valu_microbench.txt prices a wave64 v_mul/v_add_f32 at ~2.4 cycles on a SIMD and
@@ -360,6 +355,63 @@ __device__ inline float quad_round(const float4* recs, uint32_t bytes32, uint32_
   return __uint_as_float(min(high ? m23 : m01, quad_u<QUAD_XOR2>(high ? m01 : m23)));
 }
 
+// The same for 128-byte records (eight inline candidates): all eight 16-byte loads of the quad's four records are issued
+// before any arithmetic, so that the two halves of a 128-byte line are requested together; lane j owns candidates j and
+// j + 4 of each evaluation.
+__device__ inline float quad_round_wide(const float4* recs, uint32_t bytes32, uint32_t voxel_index, float qx, float qy,
+                                        float qz, int j, uint32_t (&w)[4])
+{
+  float4 R0, R1, R2, R3, S0, S1, S2, S3;
+  if (bytes32)
+  {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(recs), 0, static_cast<int>(bytes32), 0x00020000);
+    const uint32_t mine = voxel_index << 7, part = static_cast<uint32_t>(j) << 4;
+    const uint32_t o0 = quad_u<QUAD_BCAST0>(mine) + part, o1 = quad_u<QUAD_BCAST1>(mine) + part,
+                   o2 = quad_u<QUAD_BCAST2>(mine) + part, o3 = quad_u<QUAD_BCAST3>(mine) + part;
+    R0 = buffer_load_f4(rs, o0);
+    S0 = buffer_load_f4(rs, o0 + 64u);
+    R1 = buffer_load_f4(rs, o1);
+    S1 = buffer_load_f4(rs, o1 + 64u);
+    R2 = buffer_load_f4(rs, o2);
+    S2 = buffer_load_f4(rs, o2 + 64u);
+    R3 = buffer_load_f4(rs, o3);
+    S3 = buffer_load_f4(rs, o3 + 64u);
+  }
+  else
+  {
+    const float4* part = recs + j;
+    const float4* p0 = part + 8 * static_cast<size_t>(quad_u<QUAD_BCAST0>(voxel_index));
+    const float4* p1 = part + 8 * static_cast<size_t>(quad_u<QUAD_BCAST1>(voxel_index));
+    const float4* p2 = part + 8 * static_cast<size_t>(quad_u<QUAD_BCAST2>(voxel_index));
+    const float4* p3 = part + 8 * static_cast<size_t>(quad_u<QUAD_BCAST3>(voxel_index));
+    R0 = p0[0];
+    S0 = p0[4];
+    R1 = p1[0];
+    S1 = p1[4];
+    R2 = p2[0];
+    S2 = p2[4];
+    R3 = p3[0];
+    S3 = p3[4];
+  }
+  const float x0 = quad_f<QUAD_BCAST0>(qx), y0 = quad_f<QUAD_BCAST0>(qy), z0 = quad_f<QUAD_BCAST0>(qz);
+  const float x1 = quad_f<QUAD_BCAST1>(qx), y1 = quad_f<QUAD_BCAST1>(qy), z1 = quad_f<QUAD_BCAST1>(qz);
+  const float x2 = quad_f<QUAD_BCAST2>(qx), y2 = quad_f<QUAD_BCAST2>(qy), z2 = quad_f<QUAD_BCAST2>(qz);
+  const float x3 = quad_f<QUAD_BCAST3>(qx), y3 = quad_f<QUAD_BCAST3>(qy), z3 = quad_f<QUAD_BCAST3>(qz);
+  const uint32_t u0 = min(__float_as_uint(d2_simple(x0, y0, z0, R0.x, R0.y, R0.z)), __float_as_uint(d2_simple(x0, y0, z0, S0.x, S0.y, S0.z)));
+  const uint32_t u1 = min(__float_as_uint(d2_simple(x1, y1, z1, R1.x, R1.y, R1.z)), __float_as_uint(d2_simple(x1, y1, z1, S1.x, S1.y, S1.z)));
+  const uint32_t u2 = min(__float_as_uint(d2_simple(x2, y2, z2, R2.x, R2.y, R2.z)), __float_as_uint(d2_simple(x2, y2, z2, S2.x, S2.y, S2.z)));
+  const uint32_t u3 = min(__float_as_uint(d2_simple(x3, y3, z3, R3.x, R3.y, R3.z)), __float_as_uint(d2_simple(x3, y3, z3, S3.x, S3.y, S3.z)));
+  const bool odd = (j & 1) != 0, high = (j & 2) != 0;
+  const uint32_t m01 = min(odd ? u1 : u0, quad_u<QUAD_XOR1>(odd ? u0 : u1));
+  const uint32_t m23 = min(odd ? u3 : u2, quad_u<QUAD_XOR1>(odd ? u2 : u3));
+  w[0] = __float_as_uint(R0.w);
+  w[1] = __float_as_uint(R1.w);
+  w[2] = __float_as_uint(R2.w);
+  w[3] = __float_as_uint(R3.w);
+  return __uint_as_float(min(high ? m23 : m01, quad_u<QUAD_XOR2>(high ? m01 : m23)));
+}
+
 // vrec = the lane's own record index (0 for a lane without one: it reads record 0 and ignores the answer); returns
 // min d2 over ALL candidates of the lane's voxel: the inline four, then — while any lane of the wavefront still has
 // candidates left — one overflow record per round, fetched and reduced the same cooperative way.
@@ -367,10 +419,15 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
 {
   const int j = lane & 3;
   uint32_t w[4];
-  float best = quad_round(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w);
-  // overflow (more than 4 candidates): the counts of the quad's four records sit in lane 0 (part 0's w)
+  // a 128-byte record: parts 0-3 carry the count and the overflow reference like a 64-byte one, parts 4-7 hold four more
+  // inline candidates in the other half of the same 128-byte line
+  const bool wide = g.rec_parts == 8;
+  float best = wide ? quad_round_wide(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w) :
+                      quad_round(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w);
+  const uint32_t cap = wide ? 8u : 4u;
+  // overflow (more than `cap` candidates): the counts of the quad's four records sit in lane 0 (part 0's w)
   const uint32_t cmax = max(max(w[0], w[1]), max(w[2], w[3]));
-  if ((lanes_gt_u32(cmax, 4u) & QUAD_LANE0_MASK) != 0ull)
+  if ((lanes_gt_u32(cmax, cap) & QUAD_LANE0_MASK) != 0ull)
   {
     // count of MY record = part 0's w of record j, held by lane 0 of the quad; first overflow record = part 1's w, lane 1
     const uint32_t n0 = quad_u<QUAD_BCAST0>(w[0]), n1 = quad_u<QUAD_BCAST0>(w[1]), n2 = quad_u<QUAD_BCAST0>(w[2]),
@@ -379,7 +436,7 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
                    e3 = quad_u<QUAD_BCAST1>(w[3]);
     const uint32_t count = j == 0 ? n0 : j == 1 ? n1 : j == 2 ? n2 : n3;
     const uint32_t ext = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
-    const uint32_t rounds = (valid && count > 4u) ? (count - 4u + 3u) / 4u : 0u;
+    const uint32_t rounds = (valid && count > cap) ? (count - cap + 3u) / 4u : 0u;
     for (uint32_t r = 0; wave_any(r < rounds); ++r)
     {
       const bool more = r < rounds;

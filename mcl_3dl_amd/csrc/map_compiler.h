@@ -332,73 +332,76 @@ constexpr float REC_SENTINEL = 1.0e18f;
 struct RecGrid
 {
   const int32_t* brick_table;
-  const float4* rec;  // [n_bricks*512][4]
+  const float4* rec;  // [n_bricks*512][rec_parts]
   const float4* ovf;  // [n_overflow][4]
   float ox, oy, oz, inv_e;
   int nvx, nvy, nvz, nbx, nby, nbz;
   int mul24_ok;  // nbx * nby and every brick coordinate < 2^24: the table index can use 24-bit multiplies
   int off32_ok;  // the record array is smaller than 4 GB: byte offsets fit 32 bits
   uint32_t rec_bytes32, ovf_bytes32;  // size of rec / ovf in bytes when below 4 GB (buffer loads), else 0
+  int rec_parts;                      // 16-byte parts (= inline candidates) per voxel record: 4 (64 bytes) or 8 (128 bytes)
   uint32_t ti_empty;                  // index of the table's extra last entry, always -1 (lanes without a voxel read it)
 };
 
 __global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox,
-                                  unsigned long long* __restrict__ hist2)
+                                  unsigned long long* __restrict__ hist3, uint32_t cap)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint32_t c = v < n_vox ? kept_count[v] : 0u;
   if (v < n_vox)
-    n_ovf[v] = c > 4 ? (c - 4 + 3) / 4 : 0u;
-  // hist2[0] = voxels with at least one candidate, hist2[1] = voxels whose candidates do not fit the record (the index
-  // picks its voxel edge from their ratio: host_map_compilers.h)
-  const unsigned long long m_any = __ballot(c > 0u), m_ovf = __ballot(c > 4u);
-  if (hist2 && (threadIdx.x & 63) == 0)
+    n_ovf[v] = c > cap ? (c - cap + 3) / 4 : 0u;
+  // hist3[0] = voxels with at least one candidate, [1] = voxels with more than four, [2] = with more than eight (the index
+  // picks its voxel edge and its record size from their ratios: host_map_compilers.h)
+  const unsigned long long m_any = __ballot(c > 0u), m_4 = __ballot(c > 4u), m_8 = __ballot(c > 8u);
+  if (hist3 && (threadIdx.x & 63) == 0)
   {
     if (m_any)
-      atomicAdd(&hist2[0], static_cast<unsigned long long>(__popcll(m_any)));
-    if (m_ovf)
-      atomicAdd(&hist2[1], static_cast<unsigned long long>(__popcll(m_ovf)));
+      atomicAdd(&hist3[0], static_cast<unsigned long long>(__popcll(m_any)));
+    if (m_4)
+      atomicAdd(&hist3[1], static_cast<unsigned long long>(__popcll(m_4)));
+    if (m_8)
+      atomicAdd(&hist3[2], static_cast<unsigned long long>(__popcll(m_8)));
   }
 }
 
+// cap = inline candidates per voxel record (4: 64-byte records, 8: 128-byte records); part j = {candidate j: x, y, z; w},
+// w of part 0 = candidate count, w of part 1 = first overflow record; candidates cap.. go to four-candidate overflow records
 __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
                                  const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ kept_count,
                                  const uint32_t* __restrict__ ovf_start, float* __restrict__ rec,
-                                 float* __restrict__ ovf, long long n_vox)
+                                 float* __restrict__ ovf, long long n_vox, uint32_t cap)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vox)
     return;
   const uint32_t c = kept_count[v], src = pstart[v];
   // unused candidate slots hold REC_SENTINEL: a point so far away that its d2 (~3e36, finite) never wins a minimum and
-  // never passes the radius test, so a query may take the minimum over all four inline slots without looking at the count
-  float out[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    out[i] = REC_SENTINEL;
-  const uint32_t inline_n = c < 4 ? c : 4u;
-  for (uint32_t k = 0; k < inline_n; ++k)
+  // never passes the radius test, so a query may take the minimum over all inline slots without looking at the count
+  float4* dst = reinterpret_cast<float4*>(rec) + static_cast<size_t>(cap) * v;
+  const uint32_t inline_n = c < cap ? c : cap;
+  for (uint32_t k = 0; k < cap; ++k)
   {
-    const float4 p = pts[prelim[src + k] & 0x7fffffffu];
-    out[4 * k + 0] = p.x;
-    out[4 * k + 1] = p.y;
-    out[4 * k + 2] = p.z;
-  }
-  out[3] = __uint_as_float(c);
-  out[7] = __uint_as_float(c > 4 ? ovf_start[v] : 0u);
-  out[11] = 0.f;
-  out[15] = 0.f;
-  float4* dst = reinterpret_cast<float4*>(rec + 16 * v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
-  if (c > 4)
-  {
-    float* o = ovf + 16 * static_cast<size_t>(ovf_start[v]);
-    for (uint32_t k = 4; k < c; ++k)
+    float4 o = make_float4(REC_SENTINEL, REC_SENTINEL, REC_SENTINEL, 0.f);
+    if (k < inline_n)
     {
       const float4 p = pts[prelim[src + k] & 0x7fffffffu];
-      const uint32_t j = k - 4;
+      o.x = p.x;
+      o.y = p.y;
+      o.z = p.z;
+    }
+    if (k == 0)
+      o.w = __uint_as_float(c);
+    if (k == 1)
+      o.w = __uint_as_float(c > cap ? ovf_start[v] : 0u);
+    dst[k] = o;
+  }
+  if (c > cap)
+  {
+    float* o = ovf + 16 * static_cast<size_t>(ovf_start[v]);
+    for (uint32_t k = cap; k < c; ++k)
+    {
+      const float4 p = pts[prelim[src + k] & 0x7fffffffu];
+      const uint32_t j = k - cap;
       float* slot = o + 4 * j;  // record j / 4, part j % 4
       slot[0] = p.x;
       slot[1] = p.y;
@@ -489,28 +492,29 @@ __global__ void mc_compact_points(const float4* __restrict__ pts, const uint32_t
 // voxels of EXISTING bricks referenced become orphans: counted into *orphaned.
 __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int* __restrict__ sub_main, uint32_t ovf_base,
                                    uint32_t n_bricks_old, long long n_sub_vox, float4* __restrict__ rec,
-                                   unsigned long long* __restrict__ orphaned)
+                                   unsigned long long* __restrict__ orphaned, uint32_t cap)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_sub_vox)
     return;
   const int sub = static_cast<int>(v >> 9);
   const uint32_t brick = static_cast<uint32_t>(sub_main[sub]);
-  const size_t dst = (static_cast<size_t>(brick) << 9) | static_cast<size_t>(v & 511);
+  const size_t dst = ((static_cast<size_t>(brick) << 9) | static_cast<size_t>(v & 511)) * cap;
+  const size_t src = static_cast<size_t>(v) * cap;
   if (brick < n_bricks_old)
   {
-    const uint32_t old_count = __float_as_uint(rec[4 * dst].w);
-    if (old_count > 4u)
-      atomicAdd(orphaned, static_cast<unsigned long long>((old_count - 4u + 3u) / 4u));
+    const uint32_t old_count = __float_as_uint(rec[dst].w);
+    if (old_count > cap)
+      atomicAdd(orphaned, static_cast<unsigned long long>((old_count - cap + 3u) / 4u));
   }
-  const float4 r0 = sub_rec[4 * v];
-  float4 r1 = sub_rec[4 * v + 1];
-  if (__float_as_uint(r0.w) > 4u)
+  const float4 r0 = sub_rec[src];
+  float4 r1 = sub_rec[src + 1];
+  if (__float_as_uint(r0.w) > cap)
     r1.w = __uint_as_float(__float_as_uint(r1.w) + ovf_base);
-  rec[4 * dst + 0] = r0;
-  rec[4 * dst + 1] = r1;
-  rec[4 * dst + 2] = sub_rec[4 * v + 2];
-  rec[4 * dst + 3] = sub_rec[4 * v + 3];
+  rec[dst + 0] = r0;
+  rec[dst + 1] = r1;
+  for (uint32_t k = 2; k < cap; ++k)
+    rec[dst + k] = sub_rec[src + k];
 }
 
 // ---- exclusive scan of uint32 (3 levels of 1024-element tiles cover 2^30 elements) --------------------------------

@@ -77,8 +77,8 @@ def furniture(rng, n, centre):
     return (p + np.asarray(centre)).astype(np.float32)
 
 
-@pytest.mark.parametrize("n_s", [300, 2000])
-def test_incremental_map_update_equals_a_fresh_index(ref, n_s):
+@pytest.mark.parametrize("n_s,parts", [(300, 0), (2000, 0), (2000, 8)])
+def test_incremental_map_update_equals_a_fresh_index(ref, n_s, parts):
     """mapcloud_update: the updated engine (only the touched bricks re-compiled) answers exactly like a fresh engine that
     was given the merged map — likelihoods bit for bit; then a second update REPLACES the first; then the update is removed."""
     sc = make_scene(n=91, n_p=96, n_s=n_s, n_b=32, seed=4, sigma_xyz=(0.4, 0.4, 0.1))
@@ -88,6 +88,7 @@ def test_incremental_map_update_equals_a_fresh_index(ref, n_s):
         for e in (inc, fresh):
             e.set_likelihood_params()
             e.set_beam_params(num_points=32)
+        inc.set_option("cand_record_parts", parts)   # 8: the incremental path on 128-byte records; `fresh` keeps its own choice
         inc.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=DW)
         base_lik, _, _ = inc.measure_batch(sc.poses, sc.scan_lik)   # builds the index
         true_pos = sc.true_pose[:3]

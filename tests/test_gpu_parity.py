@@ -270,7 +270,8 @@ def test_tiled_kernel_matches_per_particle_kernel(engine, oracle_kind, group, mo
 
 @pytest.mark.parametrize("shape", ["tiled4", "tiled8", "tiled16", "tiled32", "per_particle", "small"])
 @pytest.mark.parametrize("n_p", [100, 37])
-def test_cooperative_record_fetch_is_bit_identical(engine, shape, n_p):
+@pytest.mark.parametrize("parts", [4, 8])
+def test_cooperative_record_fetch_is_bit_identical(engine, shape, n_p, parts):
     """lik_coop = 1 (the four lanes of a quad fetch each 64-byte record together and split its candidates; VALU-trimmed
     transform and sqrt) against lik_coop = 0 (every lane fetches its own record): the SAME terms summed in the SAME
     order, so every kernel family gives equal results bit for bit — also with strict_order, with ragged particle groups
@@ -287,6 +288,7 @@ def test_cooperative_record_fetch_is_bit_identical(engine, shape, n_p):
     res = {}
     d_coop = engine.get_option("lik_coop")
     try:
+        engine.set_option("cand_record_parts", parts)   # 64-byte records (4 inline candidates) / 128-byte records (8)
         if shape.startswith("tiled"):
             engine.set_option("lik_group", int(shape[5:]))
         elif shape == "per_particle":
@@ -299,11 +301,13 @@ def test_cooperative_record_fetch_is_bit_identical(engine, shape, n_p):
                 for coop in (0, 1):
                     engine.set_option("lik_coop", coop)
                     res[(dw, strict, coop)] = engine.measure_batch(sc.poses, scan)
+            assert engine.index_stats()["record_parts"] == parts
     finally:
         engine.set_option("lik_coop", d_coop)
         engine.set_option("lik_group", 0)
         engine.set_option("lik_tiled", 1)
         engine.set_option("strict_order", 0)
+        engine.set_option("cand_record_parts", 0)
     for (dw, strict, coop), r in res.items():
         if coop == 1:
             np.testing.assert_array_equal(r[0], res[(dw, strict, 0)][0])
@@ -469,9 +473,11 @@ def test_voxel_edge_is_chosen_from_the_map_and_overflow_rounds_are_exact(engine,
             st = engine.index_stats()
             share = st["voxels_with_overflow"] / max(st["voxels_with_candidates"], 1)
             if ratio == 0.0:
-                assert abs(st["voxel_ratio"] - 0.36) < 1e-6, st   # the jittered map made the index shrink its voxels
+                # the jittered map made the index shrink its voxels and widen its records to eight inline candidates
+                assert abs(st["voxel_ratio"] - 0.36) < 1e-6 and st["record_parts"] == 8, st
+                assert st["voxels_over8"] < 0.05 * st["voxels_with_candidates"], st
             else:
-                assert abs(st["voxel_ratio"] - 0.5) < 1e-6 and share > 0.25, st
+                assert abs(st["voxel_ratio"] - 0.5) < 1e-6 and share > 0.25 and st["record_parts"] == 4, st
     finally:
         engine.set_option("cand_voxel_ratio", 0.0)
         engine.set_option("lik_coop", d_coop)
@@ -487,7 +493,8 @@ def test_voxel_edge_is_chosen_from_the_map_and_overflow_rounds_are_exact(engine,
     sc2 = make_scene(n=91, n_p=8, n_s=64, seed=12)
     setup_engine(engine, sc2, dw, stamp=91)
     engine.measure_batch(sc2.poses, sc2.scan_lik)
-    assert abs(engine.index_stats()["voxel_ratio"] - 0.5) < 1e-6
+    st = engine.index_stats()
+    assert abs(st["voxel_ratio"] - 0.5) < 1e-6 and st["record_parts"] == 4   # ... and the 64-byte records
 
 
 def test_prepared_beam_origins_are_bit_identical(engine, oracle_kind):
