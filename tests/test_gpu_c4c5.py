@@ -205,3 +205,21 @@ def test_c5_far_corner_of_the_map(engine, c5, c5_oracle, c5_launch):
     np.testing.assert_array_equal(beam[idx], wb)
     np.testing.assert_allclose(lik[idx], wl, rtol=1e-5)
     assert wq.max() > 0.05, "the mirrored poses must actually match the far walls"
+
+
+def test_c5_wide_records_on_the_64_bit_addressing_path(engine, c5, c5_launch):
+    """128-byte voxel records on the 10 M-point map: 15 GB of records, addressed with 64-bit pointers (no buffer
+    descriptor fits). Same candidate sets, same minimum: likelihoods and match ratios equal the 64-byte-record launch bit
+    for bit. Runs last in this module (it rebuilds the index twice)."""
+    lik0, ratio0, _ = c5_launch
+    sc = c5
+    try:
+        engine.set_option("cand_record_parts", 8)
+        lik, ratio, _ = engine.measure_batch(sc.poses[:256], sc.scan_lik)
+        fp = engine.memory_footprint()
+        st = engine.index_stats()
+        assert st["record_parts"] == 8 and fp["cand_start"] > (8 << 30)
+    finally:
+        engine.set_option("cand_record_parts", 0)
+    np.testing.assert_array_equal(lik, lik0[:256])
+    np.testing.assert_array_equal(ratio, ratio0[:256])
