@@ -335,7 +335,7 @@ def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
     res["match_split"] = {"ms": (time.perf_counter() - t0) / 10 * 1e3, "points": int(n_full), "matched": int(len(m)),
                           "unmatched": int(len(u)),
                           "what": "mcl3dl_hip_match_split of the down-sampled cloud left on the device (src/mcl_3dl.cpp:761-805): "
-                                  "count pass + output pass + D2H of both clouds"}
+                                  "classification, two compactions, D2H of both clouds"}
     # the two linear-time map structures (cell-sorted exact-NN grid, DDA occupancy + voxel index): device builders
     # (default) next to the sequential host form they replaced
     q1 = np.asarray(sc.true_pose[:3], np.float32).reshape(1, 3)

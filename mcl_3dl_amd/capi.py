@@ -571,15 +571,19 @@ class Engine:
         """Transformed points classified as (matched, unmatched); xyz=None uses the cloud scan_begin left on the device."""
         pose = _np_f32(pose7)
         pts = None if xyz is None else _np_f32(xyz, 3)
-        n = 0 if pts is None else len(pts)
+        if pts is None:
+            cnt = C.c_size_t(0)
+            self._check(self.lib.mcl3dl_hip_scan_download(self.h, 0, None, None, 0, C.byref(cnt)))
+            n, cap = 0, cnt.value
+        else:
+            n = cap = len(pts)
+        # one call: every point lands in exactly one of the two clouds, so `cap` points of room in each always suffice
         nm, nu = C.c_size_t(0), C.c_size_t(0)
-        self._check(self.lib.mcl3dl_hip_match_split(self.h, _ptr(pose), _ptr(pts), n, unmatch_dist, match_dist, None, 0,
-                                                    C.byref(nm), None, 0, C.byref(nu)))
-        m = np.zeros((nm.value, 3), np.float32)
-        u = np.zeros((nu.value, 3), np.float32)
+        m = np.zeros((max(cap, 1), 3), np.float32)
+        u = np.zeros((max(cap, 1), 3), np.float32)
         self._check(self.lib.mcl3dl_hip_match_split(self.h, _ptr(pose), _ptr(pts), n, unmatch_dist, match_dist, _ptr(m),
-                                                    len(m), C.byref(nm), _ptr(u), len(u), C.byref(nu)))
-        return m, u
+                                                    cap, C.byref(nm), _ptr(u), cap, C.byref(nu)))
+        return m[:nm.value].copy(), u[:nu.value].copy()
 
     # ---- device entry points (torch CUDA tensors or raw device addresses) ---------------------------------------
     def upload_scan(self, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):

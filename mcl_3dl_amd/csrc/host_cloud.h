@@ -121,27 +121,29 @@ int voxel_grid(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf
   return 0;
 }
 
-// clip predicate + order-preserving compaction: in (n) -> out, *n_out kept. One stream synchronisation (the count).
-int clip_compact(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float clip4[4], DevBuf& out, size_t* n_out)
+// clip predicate + order-preserving compaction: in (n) -> out. The number kept arrives in *kept32 at the caller's next
+// sync_stream() (no synchronisation here: the two models' clips share one).
+int clip_compact(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float clip4[4], DevBuf& out, uint32_t* kept32,
+                 int scan_slot)
 {
-  *n_out = 0;
+  *kept32 = 0;
   TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
   if (n == 0)
     return 0;
   const long long nn = static_cast<long long>(n);
-  TRY(ensure(ctx, ctx->cl_scan, sizeof(uint32_t) * (n + 2)));
-  TRY(ensure(ctx, ctx->cl_scan_ws, sizeof(uint32_t) * (n / 1023 + 16)));
+  // each clip has its own flag / scan arrays: the second one is enqueued while the first one's count is still in flight
+  DevBuf& flags = ctx->cl_clip_scan[scan_slot];
+  DevBuf& ws = ctx->cl_clip_ws[scan_slot];
+  TRY(ensure(ctx, flags, sizeof(uint32_t) * (n + 2)));
+  TRY(ensure(ctx, ws, sizeof(uint32_t) * (n / 1023 + 16)));
   // clip_near_sq_ = clip_near * clip_near etc. in float, like refreshParameters (likelihood.cpp:58-59, beam.cpp:60-61)
   const float near_sq = clip4[0] * clip4[0], far_sq = clip4[1] * clip4[1];
   hipLaunchKernelGGL(clip_flag_kernel, dim3(blocks_for(nn + 1)), dim3(256), 0, ctx->stream, in, nn, near_sq, far_sq, clip4[2],
-                     clip4[3], ctx->cl_scan.as<uint32_t>());
-  TRY(device_exclusive_scan_ws(ctx, ctx->cl_scan.as<uint32_t>(), nn + 1, ctx->cl_scan_ws.as<uint32_t>()));
-  hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, in, ctx->cl_scan.as<uint32_t>(), nn,
+                     clip4[3], flags.as<uint32_t>());
+  TRY(device_exclusive_scan_ws(ctx, flags.as<uint32_t>(), nn + 1, ws.as<uint32_t>()));
+  hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, in, flags.as<uint32_t>(), nn,
                      out.as<float4>());
-  uint32_t kept = 0;
-  TRY(d2h(ctx, &kept, ctx->cl_scan.as<uint32_t>() + nn, sizeof(uint32_t)));
-  TRY(sync_stream(ctx));
-  *n_out = kept;
+  TRY(d2h(ctx, kept32, flags.as<uint32_t>() + nn, sizeof(uint32_t)));
   return 0;
 }
 
@@ -214,15 +216,14 @@ int scan_begin_common(mcl3dl_hip_ctx* ctx, size_t n, const float* leaf3, const f
   // ctx->sp_raw holds the accumulated cloud
   ctx->sp_ready = false;
   TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n, leaf3, ctx->sp_full, &ctx->sp_n_full));
+  ctx->sp_kept32[0] = ctx->sp_kept32[1] = 0;
   if (clip_lik4)
-    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_lik4, ctx->sp_clip[0], &ctx->sp_n_clip[0]));
-  else
-    ctx->sp_n_clip[0] = 0;
+    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_lik4, ctx->sp_clip[0], &ctx->sp_kept32[0], 0));
   if (clip_beam4)
-    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_beam4, ctx->sp_clip[1], &ctx->sp_n_clip[1]));
-  else
-    ctx->sp_n_clip[1] = 0;
-  TRY(sync_stream(ctx));
+    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_beam4, ctx->sp_clip[1], &ctx->sp_kept32[1], 1));
+  TRY(sync_stream(ctx));  // ONE synchronisation delivers both counts
+  ctx->sp_n_clip[0] = ctx->sp_kept32[0];
+  ctx->sp_n_clip[1] = ctx->sp_kept32[1];
   ctx->sp_ready = true;
   if (n_full)
     *n_full = ctx->sp_n_full;

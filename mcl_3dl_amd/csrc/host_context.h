@@ -144,6 +144,8 @@ struct mcl3dl_hip_ctx
   DevBuf sort_tmp, cl_blocks, cl_minmax, cl_key[2], cl_val[2], cl_scan, cl_scan_ws, cl_start, cl_in_xyz, cl_in_label, cl_idx,
       cl_idx2, cl_err;
   DevBuf sp_raw, sp_full, sp_clip[2], sp_samp[2];   // accumulated cloud, voxel-filtered, clipped (lik / beam), sampled
+  DevBuf cl_clip_scan[2], cl_clip_ws[2];            // flag / scan arrays of the two clips (enqueued back to back)
+  uint32_t sp_kept32[2] = { 0, 0 };                 // their counts, delivered by one synchronisation
   size_t sp_n_full = 0, sp_n_clip[2] = { 0, 0 }, sp_n_samp[2] = { 0, 0 };
   bool sp_ready = false;
   int scan_order_device = 4096;  // scans of at least this many points (both models together) are ordered on the device; 0 = never
