@@ -119,14 +119,16 @@ __global__ __launch_bounds__(256) void cloud_minmax_kernel(const float4* __restr
     block_cnt[blockIdx.x] = s_n[0];
 }
 
+// one wavefront: the lanes stride the block partials, then butterfly reductions (min / max / integer sum: any order, same
+// result). Launched with 64 threads.
 __global__ void cloud_minmax_final(const float* __restrict__ block_out, const unsigned* __restrict__ block_cnt, int nb,
                                    float* __restrict__ out6, unsigned long long* __restrict__ out_cnt)
 {
-  if (blockIdx.x != 0 || threadIdx.x != 0)
+  if (blockIdx.x != 0 || threadIdx.x >= 64)
     return;
   float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
   unsigned long long cnt = 0;
-  for (int b = 0; b < nb; ++b)
+  for (int b = threadIdx.x; b < nb; b += 64)
   {
     for (int a = 0; a < 3; ++a)
     {
@@ -135,12 +137,24 @@ __global__ void cloud_minmax_final(const float* __restrict__ block_out, const un
     }
     cnt += block_cnt[b];
   }
-  for (int a = 0; a < 3; ++a)
+  for (int off = 32; off > 0; off >>= 1)
   {
-    out6[a] = mn[a];
-    out6[3 + a] = mx[a];
+    for (int a = 0; a < 3; ++a)
+    {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+    }
+    cnt += __shfl_xor(cnt, off, 64);
   }
-  *out_cnt = cnt;
+  if (threadIdx.x == 0)
+  {
+    for (int a = 0; a < 3; ++a)
+    {
+      out6[a] = mn[a];
+      out6[3 + a] = mx[a];
+    }
+    *out_cnt = cnt;
+  }
 }
 
 // ---- pcl::VoxelGrid ---------------------------------------------------------------------------------------------------
