@@ -255,14 +255,17 @@ struct BeamOrigin
   float4 pos;    // particle position
 };
 
+// Also zeroes the particle's penalty counter (the memset the beam kernel would otherwise wait for).
 __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, const float4* __restrict__ origins, int n_o,
-                                   DdaGrid g, BeamOrigin* __restrict__ out)
+                                   DdaGrid g, BeamOrigin* __restrict__ out, unsigned* __restrict__ penalty_count)
 {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= static_cast<long long>(n_p) * n_o)
     return;
   const long long p = t / n_o;
   const int o = static_cast<int>(t - p * n_o);
+  if (o == 0)
+    penalty_count[p] = 0u;
   const float* ps = pose7 + 7 * p;
   const Vec3f pos = { ps[0], ps[1], ps[2] };
   const Quat raw = { ps[3], ps[4], ps[5], ps[6] };

@@ -218,7 +218,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       EventPair ep{};
       if (!stats)
         TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep, bs));
-      HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, bs));
+      if (!beam_prepared)  // (beam_origin_kernel zeroes the counters itself)
+        HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, bs));
       if (stats)
       {
         HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), bs));
@@ -237,7 +238,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const long long n_pairs = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_o);
           hipLaunchKernelGGL(beam_origin_kernel, dim3(static_cast<unsigned>((n_pairs + 255) / 256)), dim3(256), 0, bs, d_pose,
                              np, ctx->origins.as<float4>(), static_cast<int>(ctx->n_o), ctx->dg,
-                             ctx->beam_origin.as<BeamOrigin>());
+                             ctx->beam_origin.as<BeamOrigin>(), ctx->penalty.as<unsigned>());
           prepared = ctx->beam_origin.as<BeamOrigin>();
         }
         hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
