@@ -7,6 +7,8 @@ namespace
 {
 int build_lik_grid(mcl3dl_hip_ctx* ctx);  // host_grid_builders.h
 int build_dda_grid(mcl3dl_hip_ctx* ctx);
+int ensure_map_dev(mcl3dl_hip_ctx* ctx);  // host_grid_builders.h: the map as a device cloud {x, y, z, label}
+int cloud_minmax(mcl3dl_hip_ctx* ctx, const float4* pts, long long n, float* host6, unsigned long long* host_cnt);  // host_cloud.h
 
 // ---- map compiler: exact-NN grid -----------------------------------------------------------------------
 // Replaces ChunkedKdtree::setInputCloud + pcl::KdTreeFLANN::setInputCloud.  The reference's chunking is a memory
@@ -403,7 +405,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   TempBuf d_hist;
   HIP_TRY(hipMalloc(&d_hist.p, 3 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d_hist.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(mc_count_overflow, dim3(blocks_v), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(mc_count_overflow, dim3(std::min(blocks_v, 4096u)), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox,
                      static_cast<unsigned long long*>(d_hist.p), cap);
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
@@ -438,18 +440,26 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
   HIP_TRY(hipEventRecord(ev0, ctx->stream));
-  std::vector<float4> sp;
-  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
-  TRY(rescaled_points(ctx, 0, n, sp, mn, mx));
+  // the rescaled points (PointRepresentation::vectorize; w = map index) and their bounds, on the device from the device copy
+  // of the map; they stay there: a map update (update_cand_grid) re-compiles single bricks from them
+  TRY(ensure_map_dev(ctx));
+  TRY(ensure(ctx, ctx->cand_all_pts, sizeof(float4) * n));
+  hipLaunchKernelGGL(grid_rescale_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->map_dev.as<float4>(), static_cast<long long>(n), ctx->weight[0], ctx->weight[1], ctx->weight[2],
+                     ctx->has_weight ? 1 : 0, ctx->cand_all_pts.as<float4>());
+  float mm[6];
+  unsigned long long n_finite = 0;
+  TRY(cloud_minmax(ctx, ctx->cand_all_pts.as<float4>(), static_cast<long long>(n), mm, &n_finite));
+  if (n_finite != n)
+    return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n) - n_finite);
+  const float* mn = mm;
+  const float* mx = mm + 3;
   CompileParams cp{};
   long long n_table = 0;
   TRY(cand_geometry(ctx, voxel_ratio, mn, mx, &cp, &n_table));
   cp.n_points = static_cast<int>(n);
 
-  // the rescaled points stay on the device: a map update (update_cand_grid) re-compiles single bricks from them
   TempBuf d_flag, d_scan, d_bxyz;
-  TRY(ensure(ctx, ctx->cand_all_pts, sizeof(float4) * n));
-  TRY(h2d(ctx, ctx->cand_all_pts.p, sp.data(), sizeof(float4) * n));
   HIP_TRY(hipMalloc(&d_flag.p, sizeof(int) * n_table));
   HIP_TRY(hipMalloc(&d_scan.p, sizeof(uint32_t) * (n_table + 1)));
   HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(int) * n_table, ctx->stream));

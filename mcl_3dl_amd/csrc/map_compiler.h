@@ -343,25 +343,38 @@ struct RecGrid
   uint32_t ti_empty;                  // index of the table's extra last entry, always -1 (lanes without a voxel read it)
 };
 
-__global__ void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf, long long n_vox,
-                                  unsigned long long* __restrict__ hist3, uint32_t cap)
+// Grid-stride: every wavefront keeps its three tallies in scalar registers and a work-group issues three global atomics in
+// total (one atomic per wavefront and counter used to serialise 125 000 wavefronts on one cache line: 1.3 ms of a 15 ms build).
+__global__ __launch_bounds__(256) void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf,
+                                                         long long n_vox, unsigned long long* __restrict__ hist3, uint32_t cap)
 {
-  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint32_t c = v < n_vox ? kept_count[v] : 0u;
-  if (v < n_vox)
-    n_ovf[v] = c > cap ? (c - cap + 3) / 4 : 0u;
+  __shared__ unsigned long long s_h[3];
+  if (threadIdx.x < 3)
+    s_h[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long h_any = 0, h_4 = 0, h_8 = 0;  // wave-uniform
   // hist3[0] = voxels with at least one candidate, [1] = voxels with more than four, [2] = with more than eight (the index
   // picks its voxel edge and its record size from their ratios: host_map_compilers.h)
-  const unsigned long long m_any = __ballot(c > 0u), m_4 = __ballot(c > 4u), m_8 = __ballot(c > 8u);
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x; base < n_vox; base += stride)
+  {
+    const long long v = base + threadIdx.x;
+    const uint32_t c = v < n_vox ? kept_count[v] : 0u;
+    if (v < n_vox)
+      n_ovf[v] = c > cap ? (c - cap + 3) / 4 : 0u;
+    h_any += static_cast<unsigned long long>(__popcll(__ballot(c > 0u)));
+    h_4 += static_cast<unsigned long long>(__popcll(__ballot(c > 4u)));
+    h_8 += static_cast<unsigned long long>(__popcll(__ballot(c > 8u)));
+  }
   if (hist3 && (threadIdx.x & 63) == 0)
   {
-    if (m_any)
-      atomicAdd(&hist3[0], static_cast<unsigned long long>(__popcll(m_any)));
-    if (m_4)
-      atomicAdd(&hist3[1], static_cast<unsigned long long>(__popcll(m_4)));
-    if (m_8)
-      atomicAdd(&hist3[2], static_cast<unsigned long long>(__popcll(m_8)));
+    atomicAdd(&s_h[0], h_any);
+    atomicAdd(&s_h[1], h_4);
+    atomicAdd(&s_h[2], h_8);
   }
+  __syncthreads();
+  if (hist3 && threadIdx.x < 3 && s_h[threadIdx.x])
+    atomicAdd(&hist3[threadIdx.x], s_h[threadIdx.x]);
 }
 
 // cap = inline candidates per voxel record (4: 64-byte records, 8: 128-byte records); part j = {candidate j: x, y, z; w},
