@@ -128,7 +128,8 @@ def pmc_counters(kernel_prefix, workload):
     import csv
     import glob
     vals, src = {}, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s*pmc*summary.csv" % workload))):
+    # exactly this workload tag (r02h_C2_pmc_summary.csv, not r02h_C2j_...: the jittered map has its own counters)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc*summary.csv" % workload))):
         for row in csv.DictReader(open(path)):
             if row["kernel"].startswith(kernel_prefix):
                 vals[row["counter"]] = float(row["mean_per_launch"])  # a later (newer) file wins, counter by counter
@@ -636,7 +637,9 @@ def main():
         else:
             wide = args.lik_index == 2 and n_s > 512 and n_p <= int(eng.get_option("lik_wide_max_particles"))
             kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 1024 if wide else 256, args.lik_index)
-        pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, args.workload)
+        # counters of the same map kind: profiles/*_C2j_* = C2 with displaced map points (--map-jitter)
+        pmc_tag = args.workload + ("j" if args.map_jitter else "")
+        pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, pmc_tag)
         cost, cost_src = valu_costs()
         kernel_s = lik_avg_ms * 1e-3
         res, traffic = kernel_resources(pmc, kernel_s if lik_n else 0.0, cost, cost_src)
@@ -721,7 +724,7 @@ def main():
                                                      "(one timed group, run alone: overlap_models = 0)"}
             # the beam kernel's own counter-derived fractions (same pricing as `roofline`), against the kernel's share of the
             # timed group: its rocprofv3 share of beam_kernel in the group is > 95 % at these sizes
-            bpmc, bsrc = pmc_counters("void mcl3dl::beam_kernel<false>", args.workload)
+            bpmc, bsrc = pmc_counters("void mcl3dl::beam_kernel<false>", pmc_tag)
             if bpmc:
                 bres, btraffic = kernel_resources(bpmc, beam_avg * 1e-3, cost, cost_src)
                 for r in bres.values():
