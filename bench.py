@@ -640,6 +640,18 @@ def main():
         # counters of the same map kind: profiles/*_C2j_* = C2 with displaced map points (--map-jitter)
         pmc_tag = args.workload + ("j" if args.map_jitter else "")
         pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, pmc_tag)
+        # the committed counters are per launch of ONE shape: use them only for a launch of that many wavefronts
+        if tiled:
+            expected_waves = 4 * ((n_s + 255) // 256) * ((n_p + group - 1) // group)
+        elif small:
+            expected_waves = None
+        else:
+            expected_waves = n_p * (1 if n_s <= 128 else 16 if "<1024" in kernel_name else 4)
+        counters_note = None
+        if pmc and (expected_waves is None or abs(pmc.get("SQ_WAVES", 0.0) - expected_waves) > 0.01 * expected_waves):
+            counters_note = ("committed counters (%s) are for a launch of %.0f wavefronts, this one has %s: not used"
+                             % (pmc_src, pmc.get("SQ_WAVES", 0.0), expected_waves))
+            pmc, pmc_src = None, None
         cost, cost_src = valu_costs()
         kernel_s = lik_avg_ms * 1e-3
         res, traffic = kernel_resources(pmc, kernel_s if lik_n else 0.0, cost, cost_src)
@@ -654,6 +666,7 @@ def main():
             "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": traffic,
             "counters_source": pmc_src,
+            "counters_note": counters_note,
             "avg_launch_ms": lik_avg_ms, "launches": lik_n,
             "resources": res,
             # the canonical structure of SURVEY.md §8d, for the record; NOT priced against the HBM peak (the shipped index
@@ -725,6 +738,9 @@ def main():
             # the beam kernel's own counter-derived fractions (same pricing as `roofline`), against the kernel's share of the
             # timed group: its rocprofv3 share of beam_kernel in the group is > 95 % at these sizes
             bpmc, bsrc = pmc_counters("void mcl3dl::beam_kernel<false>", pmc_tag)
+            beam_waves = 4 * ((n_p * n_b + 255) // 256)
+            if bpmc and abs(bpmc.get("SQ_WAVES", 0.0) - beam_waves) > 0.01 * beam_waves:
+                bpmc = None   # counters of another launch shape
             if bpmc:
                 bres, btraffic = kernel_resources(bpmc, beam_avg * 1e-3, cost, cost_src)
                 for r in bres.values():
