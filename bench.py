@@ -8,7 +8,8 @@
 A step = one pass of the hot path over one batch of synthetic input: likelihood-field kernel over
 N_p particles x N_s scan points (+ beam kernel when the workload has beam points), pf::measure
 (weight multiply, {sum w, sum w ln w, ratio min/max} reduction, one all-reduce when N > 1, normalise +
-entropy).  Inputs (map structures, ordered scan, poses, prior weights) are resident in HBM before the
+entropy).  One GPU steps through the single-GPU entry point mcl3dl_hip_update_device (one C call); with N > 1 (or
+--force-dist) the split form runs with the RCCL all-reduce between its halves.  Inputs (map structures, ordered scan, poses, prior weights) are resident in HBM before the
 timed region starts (the task contract's definition of `value`); the SURVEY.md §8d form of the same update —
 host buffers in, host buffers out: scan upload + pose H2D + kernels + weight D2H — is timed next to it and
 reported as `update_8d`, and the node's own call site through the drop-in C++ classes as `route_a`.
@@ -30,7 +31,9 @@ Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` a
               cycles per instruction of each class (profiles/valu_microbench.hip: plain f32 add/mul ~2.6, fma / min /
               compares / conversions ~4.4, transcendental ~8.4) / (SIMDs x kernel cycles); classes the counters do not
               split are priced between the two rates (frac_low .. frac_high, frac = their mean)
-`bound` names the largest; `achieved / peak / frac` repeat that entry.  The canonical algorithmic bytes of SURVEY.md
+`bound` names the largest; `achieved / peak / frac` repeat that entry.  The committed counters belong to ONE launch shape
+per workload tag (profiles/<session>_<tag>_pmc_summary.csv; C2j = C2 with --map-jitter): they are used only when their
+wavefront count equals this launch's — any other shape gets no fractions (`counters_note` says why).  The canonical algorithmic bytes of SURVEY.md
 §8d (27-cell structure, 16 + 27*4 + 16*K per evaluation) are kept as `algorithmic_bytes_per_launch`, NOT divided by
 the HBM peak: the shipped index never reads them (it reads 68 B per evaluation, from L2).
 """
