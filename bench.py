@@ -38,6 +38,8 @@ wavefront count equals this launch's — any other shape gets no fractions (`cou
 the HBM peak: the shipped index never reads them (it reads 68 B per evaluation, from L2).
 """
 import argparse
+import contextlib
+import gc
 import json
 import os
 import re
@@ -55,7 +57,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 L2_PEAK_GBPS = 34500.0   # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
-L2_LINE_BYTES = 128.0    # gfx950 L1 <-> L2 request granularity
+L2_REQ_BYTES_FALLBACK = 128.0   # bytes one TCP_TCC_READ_REQ moves when no calibration run is committed (profiles/*_l2_calib.json)
+VALU_DOC_CYCLES = 2.0    # same guide, "Wave scheduling" / "Per-instruction cycle constants": a wave64 VALU instruction occupies
+                         # its SIMD for 2 cycles -> documented issue peak = 1024 SIMDs x 2.4 GHz / 2 wave-instructions per second
+HBM_TARGET_FRAC = 0.40   # BASELINE.json north_star: ">= 40 % of HBM-read roofline"
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9         # sustained shader clock after the pre-warm (GRBM_GUI_ACTIVE / kernel time, profiles/)
 # cycles one wave64 VALU instruction occupies a SIMD, by class (profiles/r02*_valu_microbench.txt, two wavefronts per
@@ -142,11 +147,30 @@ def pmc_counters(kernel_prefix, workload):
     return vals, os.path.relpath(src, ROOT)
 
 
-def kernel_resources(pmc, kernel_s, cost, cost_src):
-    """Counter-derived utilisation of one kernel: {resource: {achieved, peak, unit, frac}} and the HBM-side bytes per launch.
-    pmc = mean per launch of the counters of separate --pmc passes (profiles/), kernel_s = measured seconds per launch."""
-    res = {}  # resource -> {"achieved", "peak", "unit", "frac"}
+def l2_calibration():
+    """What one TCP_TCC_READ_REQ is worth, from the newest committed run of profiles/l2_calib.hip (known byte counts per
+    kernel, counters from separate --pmc passes): {"bytes_per_request": coalesced 16 B/lane stream, "requests_per_record64":
+    requests the quad-cooperative fetch of one 64-byte record costs, "record64_requests_per_s": the rate at which the
+    L2s served that fetch from a set resident in every XCD's L2 (a measured ceiling)}. Falls back to 128 B, uncalibrated."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_l2_calib.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("bytes_per_request", 0) > 0:
+                return dict(d, source=os.path.relpath(path, ROOT))
+        except (OSError, ValueError):
+            continue
+    return {"bytes_per_request": L2_REQ_BYTES_FALLBACK, "source": "bench.py L2_REQ_BYTES_FALLBACK (no calibration run committed)"}
+
+
+def kernel_resources(pmc, kernel_s, cost, cost_src, l2cal=None):
+    """Counter-derived utilisation of one kernel: {resource: {achieved, peak, unit, frac, peak_kind}} and the HBM-side bytes
+    per launch. pmc = mean per launch of the counters of separate --pmc passes (profiles/), kernel_s = measured seconds per
+    launch. `peak_kind` says where the denominator comes from: "documented" (/opt/skills/guides/MI355X_MICROARCH.md) or
+    "measured" (a micro-benchmark or an observed ceiling of this repository: profiles/)."""
+    res = {}
     traffic = None
+    l2cal = l2cal or l2_calibration()
     if pmc and kernel_s > 0:
         if "FETCH_SIZE" in pmc:
             # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes fetched
@@ -154,23 +178,45 @@ def kernel_resources(pmc, kernel_s, cost, cost_src):
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
             gbps = traffic / kernel_s / 1e9
             res["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                          "peak_kind": "documented",
                           "note": "cache-resident by construction: tile-major, XCD-aware launch keeps a scan "
                                   "tile's voxel records in one XCD's L2"}
         if "TCP_TCC_READ_REQ_sum" in pmc:
-            gbps = pmc["TCP_TCC_READ_REQ_sum"] * L2_LINE_BYTES / kernel_s / 1e9
+            # calibrated (profiles/l2_calib.hip): a request moves one 128-byte line in a coalesced stream, and ONE request
+            # fetches a whole 64-byte voxel record — these kernels gather records and 4-byte table entries, so their L2 bytes
+            # are requests x 64 B at most; the 128 B per request round 2 assumed is kept as `frac_if_full_lines`
+            bpr = float(l2cal.get("bytes_per_record_request", l2cal["bytes_per_request"]))
+            gbps = pmc["TCP_TCC_READ_REQ_sum"] * bpr / kernel_s / 1e9
             res["l2"] = {"achieved": gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": gbps / L2_PEAK_GBPS,
-                         "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": L2_LINE_BYTES}
+                         "frac_if_full_lines": gbps / L2_PEAK_GBPS * float(l2cal["bytes_per_request"]) / bpr,
+                         "peak_kind": "documented",
+                         "requests_per_launch": pmc["TCP_TCC_READ_REQ_sum"], "bytes_per_request": bpr,
+                         "bytes_per_request_source": l2cal["source"]}
+            if l2cal.get("record64_requests_per_s"):
+                rate = pmc["TCP_TCC_READ_REQ_sum"] / kernel_s
+                res["l2_requests"] = {"achieved": rate / 1e9, "peak": l2cal["record64_requests_per_s"] / 1e9,
+                                      "unit": "G requests/s", "frac": min(rate / l2cal["record64_requests_per_s"], 1.0),
+                                      "peak_kind": "measured",
+                                      "note": "peak = request rate of the quad-cooperative 64-byte record fetch alone over an "
+                                              "L2-resident set (profiles/l2_calib.hip)"}
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc:
             rate = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (kernel_s * CLOCK_HZ)
             res["l1_access"] = {"achieved": rate, "peak": L1_ACCESS_CEILING, "unit": "cache-line accesses/cycle/CU",
-                                "frac": min(rate / L1_ACCESS_CEILING, 1.0),
+                                "frac": min(rate / L1_ACCESS_CEILING, 1.0), "peak_kind": "measured",
                                 "accesses_per_launch": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
                                 "note": "peak = measured ceiling (see bench.py L1_ACCESS_CEILING), not a datasheet value"}
         if "SQ_INSTS_VALU" in pmc:
-            # instruction mix from the per-class counters (separate PMC pass). Known classes are priced exactly; what
-            # the counters do not split (32-bit integer ops, and everything unclassified: moves, DPP moves, compares,
-            # selects) is priced between the full and the half rate -> a low and a high estimate; `frac` is their mean
             n_all = pmc["SQ_INSTS_VALU"]
+            avail = N_SIMD * kernel_s * CLOCK_HZ
+            # (i) against the documented issue rate: every wave64 VALU instruction 2 cycles of its SIMD
+            doc = n_all * VALU_DOC_CYCLES / avail
+            res["valu_issue"] = {"achieved": n_all / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / VALU_DOC_CYCLES / 1e9,
+                                 "unit": "G wave64 VALU instructions/s", "frac": min(doc, 1.0), "peak_kind": "documented",
+                                 "wave_instructions_per_launch": n_all, "cycles_per_instruction": VALU_DOC_CYCLES,
+                                 "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)"}
+            # (ii) the same instructions priced with the measured issue cost of each class (profiles/valu_microbench.hip).
+            # Known classes are priced exactly; what the counters do not split (32-bit integer ops, moves, DPP moves,
+            # compares, selects) is priced between the full and the half rate -> a low and a high estimate; frac = mean
             have_mix = "SQ_INSTS_VALU_ADD_F32" in pmc
             n_full = pmc.get("SQ_INSTS_VALU_ADD_F32", 0.0) + pmc.get("SQ_INSTS_VALU_MUL_F32", 0.0)
             n_trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
@@ -179,37 +225,53 @@ def kernel_resources(pmc, kernel_s, cost, cost_src):
                                                     "SQ_INSTS_VALU_FMA_F64"))
             n_mixed = max(n_all - n_full - n_trans - n_half, 0.0)
             fixed = n_full * cost["full"] + n_half * cost["half"] + n_trans * cost["trans"]
-            avail = N_SIMD * kernel_s * CLOCK_HZ
             lo, hi = (fixed + n_mixed * cost["full"]) / avail, (fixed + n_mixed * cost["half"]) / avail
             mid = 0.5 * (lo + hi)
-            res["valu_issue"] = {"achieved": mid * avail / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
-                                 "unit": "G SIMD-cycles/s", "frac": min(mid, 1.0), "frac_low": lo, "frac_high": hi,
-                                 "wave_instructions_per_launch": n_all, "full_rate": n_full, "half_rate": n_half,
-                                 "transcendental": n_trans, "between_full_and_half_rate": n_mixed,
-                                 "cycles_per_instruction": cost, "cycles_per_instruction_source": cost_src,
-                                 "mix_from_counters": have_mix}
+            res["valu_issue_priced"] = {"achieved": mid * avail / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
+                                        "unit": "G SIMD-cycles/s", "frac": min(mid, 1.0), "frac_low": lo, "frac_high": hi,
+                                        "peak_kind": "measured",
+                                        "full_rate": n_full, "half_rate": n_half, "transcendental": n_trans,
+                                        "between_full_and_half_rate": n_mixed, "cycles_per_instruction": cost,
+                                        "cycles_per_instruction_source": cost_src, "mix_from_counters": have_mix,
+                                        "note": "SIMD cycles the instruction mix needs at the issue cost measured per class "
+                                                "(plain f32 add/mul/mov ~2.4, fma/min/max/cvt/compare/f64 ~4.2, sqrt ~8.2 "
+                                                "cycles at the nominal clock) over the SIMD cycles of the launch"}
     return res, traffic
+
+
+VALU_FULL_ROWS = ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_mov_b32", "v_and_b32", "v_add_u32")
+VALU_HALF_ROWS = ("v_max_f32", "v_min_f32", "v_fma_f32", "v_cvt_flr_i32_f32", "v_mul_u32_u24", "v_cmp_lt_f32", "v_lshl_or_b32",
+                  "v_add_f64")
+VALU_TRANS_ROWS = ("v_sqrt_f32", "v_rcp_f32")
+
+
+def microbench_rows(path, waves_per_simd=8):
+    """{row label: cyc@2.4GHz} of one committed run of profiles/valu_microbench.hip at `waves_per_simd` wavefronts per SIMD,
+    "x8 independent" rows only. The label is everything ahead of that marker, so `v_mul_f32 (sgpr src)` and `v_mul_f32`
+    are different rows (round 2 keyed them by the opcode alone and the former overwrote the latter)."""
+    rows = {}
+    for line in open(path):
+        m = re.match(r"(v_.*?)\s+x8 independent\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s*$", line)
+        if m and int(m.group(2)) == waves_per_simd:
+            rows[m.group(1).strip()] = float(m.group(6))   # kernel time x 2.4 GHz / (instructions x wavefronts per SIMD)
+    return rows
 
 
 def valu_costs():
     """Cycles one wave64 VALU instruction occupies a SIMD, by class, from the newest committed run of
     profiles/valu_microbench.hip (the version that places exactly W wavefronts on every SIMD: r02d onwards): column
-    cyc@2.4GHz (kernel time x the nominal clock, the same clock `valu_issue` prices the likelihood kernel's time with) at
-    eight wavefronts per SIMD, the occupancy the likelihood kernels run at:
-    full = mean of v_mul_f32 / v_add_f32, half = mean of v_max_f32 / v_cndmask-class rows, trans = v_sqrt_f32."""
+    cyc@2.4GHz (kernel time x the nominal clock, the same clock `valu_issue_priced` prices the likelihood kernel's time
+    with) at eight wavefronts per SIMD, the occupancy the likelihood kernels run at: full = mean of the plain
+    v_mul / add / sub_f32, v_mov, v_and, v_add_u32 rows, half = mean of the max / min / fma / cvt / 24-bit multiply /
+    compare / lshl_or / f64-add rows, trans = v_sqrt_f32 and v_rcp_f32."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_microbench.txt")), reverse=True):
         if os.path.basename(path) < "r02d":
             continue  # earlier runs measured the dispatcher's uneven spread of 256-thread groups, not the pipe
-        rows = {}
-        for line in open(path):
-            m = re.match(r"(v_\S+).*?\s+(\d)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s*$", line)
-            if m and "independent" in line and m.group(2) == "8":
-                rows[m.group(1)] = float(m.group(6))  # kernel time x 2.4 GHz / (instructions x wavefronts per SIMD)
-        full = [rows[k] for k in ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_mov_b32", "v_and_b32", "v_add_u32") if k in rows]
-        half = [rows[k] for k in ("v_max_f32", "v_min_f32", "v_fma_f32", "v_cvt_flr_i32_f32", "v_mul_u32_u24",
-                                  "v_cmp_lt_f32", "v_lshl_or_b32", "v_add_f64") if k in rows]
-        trans = [rows[k] for k in ("v_sqrt_f32", "v_rcp_f32") if k in rows]
+        rows = microbench_rows(path)
+        full = [rows[k] for k in VALU_FULL_ROWS if k in rows]
+        half = [rows[k] for k in VALU_HALF_ROWS if k in rows]
+        trans = [rows[k] for k in VALU_TRANS_ROWS if k in rows]
         if full and half and trans:
             return ({"full": sum(full) / len(full), "half": sum(half) / len(half), "trans": sum(trans) / len(trans)},
                     os.path.relpath(path, ROOT))
@@ -259,6 +321,20 @@ def _identity_noise(n):
     a = np.zeros((n, 13), np.float32)
     a[:, 6] = 1.0
     return a
+
+
+@contextlib.contextmanager
+def no_gc():
+    """Timed host loops run with Python's cyclic garbage collector off (a generation-2 pass over a process that has torch
+    loaded takes tens of milliseconds — two orders of magnitude more than one update)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _flush_c_stdio():
@@ -321,11 +397,16 @@ def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
         eng.scan_finish(il, ib, origins=origins)
     for _ in range(3):
         once()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        once()
-    prep_ms = (time.perf_counter() - t0) / 10 * 1e3
-    res = {"scan_preparation": {"ms": prep_ms, "raw_points": int(len(raw)), "after_voxel_grid": int(n_full),
+    # per-call times with Python's cyclic collector off: a generation-2 pass of a torch process takes ~35 ms and once landed
+    # inside this loop (round-2 lines read 4-6 ms instead of 0.3: scripts/r03_scanprep_bisect.py)
+    calls = []
+    with no_gc():
+        for _ in range(10):
+            t0 = time.perf_counter()
+            once()
+            calls.append((time.perf_counter() - t0) * 1e3)
+    prep_ms = float(np.median(calls))
+    res = {"scan_preparation": {"ms": prep_ms, "ms_mean": float(np.mean(calls)), "ms_max": float(np.max(calls)), "raw_points": int(len(raw)), "after_voxel_grid": int(n_full),
                                 "after_clip": [int(n_lik), int(n_beam)], "sampled": [int(ns), int(nb)], "leaf": list(leaf),
                                 "what": "mcl3dl_hip_scan_begin + _scan_finish: H2D of the accumulated cloud, VoxelGrid, both clip "
                                         "filters, gather of the drawn samples, device-side scan ordering (host wall time, index "
@@ -333,11 +414,14 @@ def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
     pose = np.asarray(sc.true_pose, np.float32)
     eng.scan_begin(raw, None, leaf=leaf, clip_lik=clip_lik, clip_beam=clip_beam)
     eng.match_split(pose)
-    t0 = time.perf_counter()
-    for _ in range(10):
-        m, u = eng.match_split(pose)
-    res["match_split"] = {"ms": (time.perf_counter() - t0) / 10 * 1e3, "points": int(n_full), "matched": int(len(m)),
-                          "unmatched": int(len(u)),
+    calls = []
+    with no_gc():
+        for _ in range(10):
+            t0 = time.perf_counter()
+            m, u = eng.match_split(pose)
+            calls.append((time.perf_counter() - t0) * 1e3)
+    res["match_split"] = {"ms": float(np.median(calls)), "ms_max": float(np.max(calls)), "points": int(n_full),
+                          "matched": int(len(m)), "unmatched": int(len(u)),
                           "what": "mcl3dl_hip_match_split of the down-sampled cloud left on the device (src/mcl_3dl.cpp:761-805): "
                                   "classification, two compactions, D2H of both clouds"}
     # the two linear-time map structures (cell-sorted exact-NN grid, DDA occupancy + voxel index): device builders
@@ -495,13 +579,14 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(steps):
-            step(sh)
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        el = time.perf_counter() - t1
+        with no_gc():
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step(sh)
+            torch.cuda.synchronize(dev)
+            if use_dist:
+                dist.barrier()
+            el = time.perf_counter() - t1
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -658,18 +743,37 @@ def main():
         cost, cost_src = valu_costs()
         kernel_s = lik_avg_ms * 1e-3
         res, traffic = kernel_resources(pmc, kernel_s if lik_n else 0.0, cost, cost_src)
-        if res:
-            bound = max(res, key=lambda k: res[k]["frac"])
-            top = res[bound]
+        # `bound` / `frac` are taken over the resources whose peak is a DOCUMENTED figure of the guide; fractions against
+        # peaks this repository measured itself are listed next to them (`frac_vs_measured_peaks`), never as `frac`
+        documented = {k: r for k, r in res.items() if r.get("peak_kind") == "documented"}
+        if documented:
+            bound = max(documented, key=lambda k: documented[k]["frac"])
+            top = documented[bound]
         else:
             bound, top = "hbm", {"achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None}
+        hbm_frac = res["hbm"]["frac"] if "hbm" in res else None
         roofline = {
             "bound": bound,
             "kernel": kernel_name,
             "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+            "frac_definition": ("largest fraction among the resources with a documented peak (hbm 8 TB/s, l2 34.5 TB/s, "
+                                "valu_issue = wave64 VALU instructions/s against 1024 SIMDs x 2.4 GHz / 2 cycles per "
+                                "instruction); the same launch against peaks measured here: frac_vs_measured_peaks"),
+            "frac_vs_measured_peaks": {k: r["frac"] for k, r in res.items() if r.get("peak_kind") == "measured"},
+            # north_star: ">= 40 % of HBM-read roofline" — answered, not dropped
+            "hbm_target": {"frac": hbm_frac, "target": HBM_TARGET_FRAC,
+                           "status": "not applicable: the index is built so that a scan tile's working set is L2-resident "
+                                     "(TCC hit %s); HBM traffic is %s of the algorithmic bytes of SURVEY.md 8d, i.e. nothing is "
+                                     "re-read from HBM — the kernel is bound by VALU issue and L2 request rate, not by HBM"
+                                     % ("%.1f %%" % (100.0 * pmc["TCC_HIT_sum"] / max(pmc["TCC_HIT_sum"] + pmc.get("TCC_MISS_sum", 0.0), 1.0))
+                                        if pmc and "TCC_HIT_sum" in pmc else "n/a",
+                                        "%.2g" % (traffic / bytes_lik_launch) if traffic else "n/a")},
             "traffic": traffic,
             "counters_source": pmc_src,
             "counters_note": counters_note,
+            "counters_box": "counters = mean per launch of the committed --pmc passes (another MI355X box than this run's: "
+                            "instruction and request counts are properties of the launch, identical from box to box; the "
+                            "kernel time they are divided by is this run's)",
             "avg_launch_ms": lik_avg_ms, "launches": lik_n,
             "resources": res,
             # the canonical structure of SURVEY.md §8d, for the record; NOT priced against the HBM peak (the shipped index
@@ -710,8 +814,12 @@ def main():
                                "fp64 tree (terms bit-identical to the reference's float terms)"),
                 "lik_coop": lik_coop,
             },
-            "value_definition": "device-resident update (map structures, ordered scan, poses, prior weights in HBM before "
-                                "the timed region); the host-buffer form of SURVEY.md section 8d is `update_8d`",
+            "value_definition": "value = value_device_resident: inputs (map structures, ordered scan, poses, prior weights) in HBM "
+                                "before the timed region, as the bench contract defines `value` (the PCIe-inclusive rate is "
+                                "never `value`); value_8d = SURVEY.md section 8d's region (scan upload + pose / weight H2D + "
+                                "kernels + weight D2H from / to host buffers), timed in the same run",
+            "value_device_resident": value,
+            "value_8d": None,
             "roofline": roofline,
             "prewarm": prewarm,
             "kernel_timing_pass": kernel_timing_pass,
@@ -748,9 +856,12 @@ def main():
                 bres, btraffic = kernel_resources(bpmc, beam_avg * 1e-3, cost, cost_src)
                 for r in bres.values():
                     r.pop("note", None)
-                if bres:
-                    bb = max(bres, key=lambda k: bres[k]["frac"])
-                    out["beam"]["roofline"] = {"bound": bb, "frac": bres[bb]["frac"], "traffic": btraffic,
+                bdoc = {k: r for k, r in bres.items() if r.get("peak_kind") == "documented"}
+                if bdoc:
+                    bb = max(bdoc, key=lambda k: bdoc[k]["frac"])
+                    out["beam"]["roofline"] = {"bound": bb, "frac": bdoc[bb]["frac"], "traffic": btraffic,
+                                               "frac_vs_measured_peaks": {k: r["frac"] for k, r in bres.items()
+                                                                          if r.get("peak_kind") == "measured"},
                                                "counters_source": bsrc, "resources": bres,
                                                "algorithmic_bytes_per_launch": bytes_beam_launch}
         d_pose, d_w, d_w0, d_lik, d_ratio, d_beam, d_stats = (main_sh.d_pose, main_sh.d_w, main_sh.d_w0, main_sh.d_lik,
@@ -760,10 +871,12 @@ def main():
             # pose and prior-weight H2D, kernels, reduction, weight D2H) through the synchronous host entry point
             eng.set_stream(None)
             eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
-            t2 = time.perf_counter()
-            for _ in range(args.steps):
-                eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
-            host_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            with no_gc():
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+                host_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            out["value_8d"] = n_p * n_s / (host_ms * 1e-3)
             out["update_8d"] = {"ms_per_update": host_ms, "value": n_p * n_s / (host_ms * 1e-3),
                                 "unit": "particle·point evals/s", "update_hz": 1e3 / host_ms, "steps": args.steps,
                                 "what": "mcl3dl_hip_measure_update on host buffers: scan upload + pose/weight H2D + kernels "
