@@ -113,8 +113,10 @@ def parse():
                          "kernel, 1 beam, 2 pf); the others are timed in a second pass of the same steps")
     ap.add_argument("--scan-points", type=int, default=0, help="override the number of likelihood scan points")
     ap.add_argument("--lik-group", type=int, default=0, help="0 = the library's choice (16 / 8 / 4 by launch size)")
-    ap.add_argument("--strict-order", type=int, default=0,
-                    help="1 = reference float summation order (bit-identical likelihoods and weights; slower)")
+    ap.add_argument("--strict-order", type=int, default=-1,
+                    help="-1 = the library's default (2: the likelihood terms are replayed in the reference's float order "
+                         "from 32 768 scan points up), 0 = fp64 sums always, 1 = reference float summation order for "
+                         "likelihoods AND weights (bit-identical; slower)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--also-other-scaling", action="store_true",
@@ -517,7 +519,10 @@ def main():
     eng.set_option("cand_phase", args.cand_phase)
     if args.cand_record_parts >= 0:
         eng.set_option("cand_record_parts", args.cand_record_parts)
-    eng.set_option("strict_order", args.strict_order)
+    if args.strict_order >= 0:
+        eng.set_option("strict_order", args.strict_order)
+    strict_mode = int(eng.get_option("strict_order"))
+    strict_lik = strict_mode == 1 or (strict_mode == 2 and n_s >= int(eng.get_option("strict_auto_min")))
     eng.set_option("lik_tiled", args.lik_tiled)
     eng.set_option("lik_small", args.lik_small)
     eng.set_option("overlap_models", args.overlap_models)
@@ -713,7 +718,7 @@ def main():
         value = evals_per_step * args.steps / elapsed
         lik_avg_ms = lik_ms / max(lik_n, 1)
         stats = main_sh.d_stats.cpu().numpy()
-        tiled = bool(args.lik_tiled and n_p >= 4 and (n_s >= tiled_min or (n_p >= 256 and 4 * n_s >= 3 * tiled_min))) or bool(args.strict_order)
+        tiled = bool(args.lik_tiled and n_p >= 4 and (n_s >= tiled_min or (n_p >= 256 and 4 * n_s >= 3 * tiled_min))) or strict_lik
         group = _tiled_group(n_s, n_p, args.lik_group)
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:
@@ -810,7 +815,10 @@ def main():
                 "parallelism": ("particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world if use_dist else
                                 "one GPU, mcl3dl_hip_update_device (measure + pf::measure in one call, no collective)"),
                 "update_hz": 1e3 / ms_per_step,
-                "accumulate": ("float, reference order (bit-identical results)" if args.strict_order else
+                "accumulate": ("likelihood terms and weights added as floats in the reference's order (bit-identical results)"
+                               if strict_mode == 1 else
+                               "likelihood terms replayed as floats in the reference's order (this scan has >= %d points), "
+                               "weights in an fp64 tree" % int(eng.get_option("strict_auto_min")) if strict_lik else
                                "fp64 tree (terms bit-identical to the reference's float terms)"),
                 "lik_coop": lik_coop,
             },

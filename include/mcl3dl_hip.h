@@ -278,6 +278,11 @@ int mcl3dl_hip_scan_begin_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, 
 int mcl3dl_hip_scan_finish(mcl3dl_hip_ctx* ctx, const uint32_t* idx_lik /*n_s*/, size_t n_s,
                            const uint32_t* idx_beam /*n_b*/, size_t n_b, const float* origins /*n_o*3*/, size_t n_o);
 int mcl3dl_hip_scan_download(mcl3dl_hip_ctx* ctx, int which, float* xyz, uint32_t* label, size_t capacity, size_t* n);
+/* Introspection: the stable radix sort the cloud path runs on the device (VoxelGrid leaf order, scan ordering; replaces the
+ * std::sort of pcl::VoxelGrid and nothing else of the reference), exposed so that it can be checked on its own:
+ * (keys, vals) sorted ascending by key bits [0, end_bit), equal keys in input order. One launch up to 16 384 pairs. */
+int mcl3dl_hip_sort_pairs(mcl3dl_hip_ctx* ctx, const uint32_t* keys, const uint32_t* vals /*NULL: 0..n-1*/, size_t n,
+                          int end_bit, uint32_t* out_keys, uint32_t* out_vals);
 
 /* ---- "next" row: map from the wire format, map updates, matched / unmatched output --------------
  * set_map_*: replaces cbMapcloud + loadMapCloud (src/mcl_3dl.cpp:128-139, 1140-1158): decode, VoxelGrid(map_downsample),
@@ -395,10 +400,13 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       wavefront between 64 / W particles; 0 = always one work-group per particle
  *   "lik_group"         particles per work-group of the tiled kernel: 0 (default) = the largest of 16 / 8 / 4 that
  *                       still yields >= 2048 work-groups, or 4, 8, 16, 32 to force one
- *   "strict_order"      0 (default) = fp64 tree sums; 1 = add the likelihood terms per particle and the weights over the
+ *   "strict_order"      0 = fp64 tree sums always; 1 = add the likelihood terms per particle and the weights over the
  *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
  *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
- *                       (single GPU; costs an n_s x n_p float buffer and two serial passes)
+ *                       (single GPU; costs an n_s x n_p float buffer and two serial passes); 2 (default) = the likelihood
+ *                       terms are replayed in that order for scans of at least "strict_auto_min" points (default 32 768)
+ *                       — from there on the reference's own float rounding, a random walk of n_s roundings, reaches the
+ *                       1e-5 relative tolerance the fp64 sum is held to — and summed in fp64 below
  *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
  *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
  *                       results either way.

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
     "mcl3dl_hip_radius_search": (_i, [_p, _p, _sz, _f, _p, _p]),
     "mcl3dl_hip_dda_trace": (_i, [_p, _p, _p, _p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "mcl3dl_hip_sort_pairs": (_i, [_p, _p, _p, _sz, _i, _p, _p]),
     "mcl3dl_hip_expectation": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_covariance": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
     "mcl3dl_hip_expectation_device": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
@@ -507,6 +508,14 @@ class Engine:
         ib = np.ascontiguousarray(idx_beam if idx_beam is not None else [], dtype=np.uint32)
         og = _np_f32(origins if origins is not None else np.zeros((1, 3)), 3)
         self._check(self.lib.mcl3dl_hip_scan_finish(self.h, _ptr(il), len(il), _ptr(ib), len(ib), _ptr(og), len(og)))
+
+    def sort_pairs(self, keys, vals=None, end_bit=32):
+        """The device radix sort of the cloud path on its own (stable, ascending by key bits [0, end_bit))."""
+        k = np.ascontiguousarray(keys, dtype=np.uint32)
+        v = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint32)
+        ok, ov = np.empty_like(k), np.empty_like(k)
+        self._check(self.lib.mcl3dl_hip_sort_pairs(self.h, _ptr(k), _ptr(v), len(k), int(end_bit), _ptr(ok), _ptr(ov)))
+        return ok, ov
 
     def scan_download(self, which):
         n = C.c_size_t(0)

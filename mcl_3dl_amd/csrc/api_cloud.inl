@@ -12,8 +12,8 @@ int mcl3dl_hip_scan_begin(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t*
   if (n > 0x7fffffffu)
     return ctx->fail(-3, "cloud too large");
   HIP_TRY(hipSetDevice(ctx->device));
-  TRY(upload_cloud(ctx, xyz, label, n, ctx->sp_raw));
-  return scan_begin_common(ctx, n, leaf3, clip_lik4, clip_beam4, n_full, n_lik_clipped, n_beam_clipped);
+  TRY(upload_cloud(ctx, xyz, label, n, ctx->sp_raw, true));
+  return scan_begin_common(ctx, n, leaf3, clip_lik4, clip_beam4, n_full, n_lik_clipped, n_beam_clipped, true);
 }
 
 int mcl3dl_hip_scan_begin_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
@@ -30,10 +30,10 @@ int mcl3dl_hip_scan_begin_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, 
   // per update that index is label_override; pass 0xffffffff to keep the message's own labels
   (void)label_override;
   TRY(decode_cloud(ctx, data, n_points, point_step, off_x, off_y, off_z, label_override == 0xffffffffu ? off_label : -1,
-                   ctx->sp_raw));
+                   ctx->sp_raw, true));
   if (label_override != 0xffffffffu && label_override != 0u)
     return ctx->fail(-3, "label_override must be 0 (single accumulated cloud) or 0xffffffff (keep the message's labels)");
-  return scan_begin_common(ctx, n_points, leaf3, clip_lik4, clip_beam4, n_full, n_lik_clipped, n_beam_clipped);
+  return scan_begin_common(ctx, n_points, leaf3, clip_lik4, clip_beam4, n_full, n_lik_clipped, n_beam_clipped, true);
 }
 
 int mcl3dl_hip_scan_finish(mcl3dl_hip_ctx* ctx, const uint32_t* idx_lik, size_t n_s, const uint32_t* idx_beam, size_t n_b,
@@ -51,33 +51,51 @@ int mcl3dl_hip_scan_finish(mcl3dl_hip_ctx* ctx, const uint32_t* idx_lik, size_t 
   if ((n_s && ctx->sp_n_clip[0] == 0) || (n_b && ctx->sp_n_clip[1] == 0))
     return ctx->fail(-3, "indices given for an empty clipped cloud");
   HIP_TRY(hipSetDevice(ctx->device));
-  TRY(ensure(ctx, ctx->cl_err, sizeof(int)));
-  HIP_TRY(hipMemsetAsync(ctx->cl_err.p, 0, sizeof(int), ctx->stream));
-  // ---- gather the drawn points, then order both scans on the device (same keys and stable order as the host path)
+  // ---- gather the drawn points of both models (one launch, with the likelihood sample's min corner), then order both
+  // scans on the device (same keys and stable order as the host path). ONE host-to-device copy carries the (zeroed) error
+  // word and both index arrays: [error, pad x3][idx_lik n_s][idx_beam n_b]
   TRY(ensure(ctx, ctx->sp_samp[0], sizeof(float4) * std::max<size_t>(n_s, 1)));
   TRY(ensure(ctx, ctx->sp_samp[1], sizeof(float4) * std::max<size_t>(n_b, 1)));
-  if (n_s)
+  const size_t idx_bytes = 16 + sizeof(uint32_t) * (n_s + n_b);
+  TRY(ensure(ctx, ctx->cl_idx, idx_bytes));
+  int* d_err = ctx->cl_idx.as<int>();
+  const uint32_t* d_idx_lik = ctx->cl_idx.as<uint32_t>() + 4;
+  const uint32_t* d_idx_beam = d_idx_lik + n_s;
   {
-    const long long ns = static_cast<long long>(n_s);
-    TRY(ensure(ctx, ctx->cl_idx, sizeof(uint32_t) * n_s));
-    TRY(h2d(ctx, ctx->cl_idx.p, idx_lik, sizeof(uint32_t) * n_s));
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream, ctx->sp_clip[0].as<float4>(),
-                       static_cast<long long>(ctx->sp_n_clip[0]), ctx->cl_idx.as<uint32_t>(), ns,
-                       ctx->sp_samp[0].as<float4>(), ctx->cl_err.as<int>());
+    char* st = idx_bytes <= STAGE_MAX_COPY ? static_cast<char*>(stage_alloc(ctx, idx_bytes)) : nullptr;
+    if (st)
+    {
+      memset(st, 0, 16);
+      if (n_s)
+        memcpy(st + 16, idx_lik, sizeof(uint32_t) * n_s);
+      if (n_b)
+        memcpy(st + 16 + sizeof(uint32_t) * n_s, idx_beam, sizeof(uint32_t) * n_b);
+      HIP_TRY(hipMemcpyAsync(ctx->cl_idx.p, st, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    else
+    {
+      HIP_TRY(hipMemsetAsync(ctx->cl_idx.p, 0, 16, ctx->stream));
+      if (n_s)
+        TRY(h2d(ctx, const_cast<uint32_t*>(d_idx_lik), idx_lik, sizeof(uint32_t) * n_s));
+      if (n_b)
+        TRY(h2d(ctx, const_cast<uint32_t*>(d_idx_beam), idx_beam, sizeof(uint32_t) * n_b));
+    }
   }
-  if (n_b)
+  if (n_s + n_b)
   {
-    const long long nb = static_cast<long long>(n_b);
-    TRY(ensure(ctx, ctx->cl_idx2, sizeof(uint32_t) * n_b));
-    TRY(h2d(ctx, ctx->cl_idx2.p, idx_beam, sizeof(uint32_t) * n_b));
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, ctx->sp_clip[1].as<float4>(),
-                       static_cast<long long>(ctx->sp_n_clip[1]), ctx->cl_idx2.as<uint32_t>(), nb,
-                       ctx->sp_samp[1].as<float4>(), ctx->cl_err.as<int>());
+    const long long na = static_cast<long long>(n_s), nb = static_cast<long long>(n_b);
+    const unsigned blocks = minmax_blocks(na + nb);
+    MinMaxOut mm;
+    TRY(minmax_out(ctx, blocks, &mm));
+    hipLaunchKernelGGL(gather2_minmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sp_clip[0].as<float4>(),
+                       static_cast<long long>(ctx->sp_n_clip[0]), d_idx_lik, na, ctx->sp_samp[0].as<float4>(),
+                       ctx->sp_clip[1].as<float4>(), static_cast<long long>(ctx->sp_n_clip[1]), d_idx_beam, nb,
+                       ctx->sp_samp[1].as<float4>(), d_err, mm);
   }
-  TRY(device_order_scans(ctx, n_s, n_b, origins, n_o));
+  TRY(device_order_scans(ctx, n_s, n_b, origins, n_o, true, d_err));
   HIP_TRY(hipGetLastError());
   int err = 0;
-  TRY(d2h(ctx, &err, ctx->cl_err.p, sizeof(int)));
+  TRY(d2h(ctx, &err, d_err, sizeof(int)));
   TRY(sync_stream(ctx));
   if (err == 1)
     return ctx->fail(-3, "a sample index is outside the clipped cloud");
@@ -123,6 +141,39 @@ int mcl3dl_hip_scan_download(mcl3dl_hip_ctx* ctx, int which, float* xyz, uint32_
   return download_cloud(ctx, src, cnt, xyz, label);
 }
 
+int mcl3dl_hip_sort_pairs(mcl3dl_hip_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int end_bit,
+                          uint32_t* out_keys, uint32_t* out_vals)
+{
+  if (!ctx)
+    return -1;
+  if (n == 0)
+    return 0;
+  if (!keys || !out_keys || !out_vals || end_bit < 1 || end_bit > 32 || n > 0x7fffffffu)
+    return ctx->fail(-3, "bad arguments to sort_pairs");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(uint32_t) * n;
+  for (int k = 0; k < 2; ++k)
+  {
+    TRY(ensure(ctx, ctx->cl_key[k], bytes + 4));
+    TRY(ensure(ctx, ctx->cl_val[k], bytes + 4));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->cl_key[0].p, keys, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (vals)
+  {
+    HIP_TRY(hipMemcpyAsync(ctx->cl_val[0].p, vals, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TRY(sort_pairs(ctx, static_cast<long long>(n), end_bit));
+  }
+  else
+  {
+    RsKeyGen kg{};
+    kg.keys = ctx->cl_key[0].as<uint32_t>();
+    TRY(radix_sort<RS_KEY_ARRAY>(ctx, kg, static_cast<long long>(n), end_bit, nullptr));
+  }
+  HIP_TRY(hipMemcpyAsync(out_keys, ctx->cl_key[1].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out_vals, ctx->cl_val[1].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return sync_stream(ctx);
+}
+
 // ---- §8f-4: the map from the wire format, map updates, matched / unmatched output ------------------------------------
 namespace
 {
@@ -144,7 +195,7 @@ int install_base_map(mcl3dl_hip_ctx* ctx, size_t n_in, const float* leaf3, uint6
                      size_t* n_map)
 {
   size_t n_out = 0;
-  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n_in, leaf3, ctx->sp_full, &n_out));
+  TRY(voxel_grid_now(ctx, ctx->sp_raw.as<float4>(), n_in, leaf3, ctx->sp_full, &n_out));
   if (n_out == 0)
     return ctx->fail(-3, "empty map");
   if (n_out > 0xfffffff0u)
@@ -174,7 +225,7 @@ int install_map_update(mcl3dl_hip_ctx* ctx, size_t n_in, const float* leaf3, uin
   const size_t n_old_total = ctx->map_xyz.size() / 3;
   TRY(rescaled_points(ctx, n_base, n_old_total - n_base, old_update, nullptr, nullptr));
   size_t n_out = 0;
-  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n_in, leaf3, ctx->sp_full, &n_out));
+  TRY(voxel_grid_now(ctx, ctx->sp_raw.as<float4>(), n_in, leaf3, ctx->sp_full, &n_out));
   ctx->sp_ready = false;
   if (n_base + n_out > 0xfffffff0u)
     return ctx->fail(-3, "map too large (index must fit 32 bits)");

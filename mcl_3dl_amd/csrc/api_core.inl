@@ -332,9 +332,9 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
           return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, scan_beam_origin[i], n_o);
     HIP_TRY(hipSetDevice(ctx->device));
     TRY(ensure(ctx, ctx->cl_err, sizeof(int)));
-    TRY(upload_cloud(ctx, scan_lik_xyz, nullptr, n_s, ctx->sp_samp[0]));
+    TRY(upload_cloud(ctx, scan_lik_xyz, nullptr, n_s, ctx->sp_samp[0], true));  // + the min corner of the Morton keys
     TRY(upload_cloud(ctx, scan_beam_xyz, scan_beam_origin, n_b, ctx->sp_samp[1]));
-    TRY(device_order_scans(ctx, n_s, n_b, origins, n_o));
+    TRY(device_order_scans(ctx, n_s, n_b, origins, n_o, n_s != 0, ctx->cl_err.as<int>()));
     if (sync_at_end)
       TRY(sync_stream(ctx));
     if (n_b > ctx->pow_table_len)
@@ -398,7 +398,7 @@ int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, con
                      d_match_ratio, static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
   hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank,
                      world, d_packed);
-  if (ctx->strict_order && world == 1)
+  if (ctx->strict_order == 1 && world == 1)
     hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->wnew.as<float>(),
                        static_cast<int>(n_p), d_packed);
   TRY(timing_end(ctx, ep));
@@ -433,7 +433,7 @@ namespace
 int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
                       const float* d_ratio, size_t n_p, float* d_stats4)
 {
-  if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && !ctx->strict_order && ctx->pf_fused)
+  if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->strict_order != 1 && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
     EventPair ep{};

@@ -62,6 +62,7 @@ int mcl3dl_hip_group_create(mcl3dl_hip_group** out, const int* device_ids, int n
   g->host_packed.resize(n_devices);
   if (n_devices > 1)
     g->pool.start(n_devices);
+  g->vote.resize(n_devices);
   *out = g;
   return 0;
 }
@@ -167,6 +168,12 @@ int mcl3dl_hip_group_set_option(mcl3dl_hip_group* g, const char* name, double va
   if (std::string(name) == "direct_single")
   {
     g->direct_single = value != 0.0;
+    return 0;
+  }
+  if (std::string(name) == "inject_failure_rank")
+  {
+    // test hook: the next sharded update fails on that rank after its kernels are enqueued and before the collective
+    g->inject_failure_rank = static_cast<int>(value);
     return 0;
   }
   for (int r = 0; r < g->n(); ++r)
@@ -332,6 +339,10 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
     return sync_stream(ctx);
   };
   int bad = 0;
+  std::vector<int> rcs(N, 0);
+  const int inject = g->inject_failure_rank;
+  g->inject_failure_rank = -1;
+  constexpr int RC_ABANDONED = -8;
   int rc = g->pool.run_all(
       [&](int r) -> int
       {
@@ -339,46 +350,84 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
         size_t lo, hi;
         shard_bounds(n_p, N, r, &lo, &hi);
         const size_t n = hi - lo, fb = sizeof(float) * n;
-        TRY(push_scan(ctx, g->scan, false));
-        TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
-        ctx->n_pose_uploaded = 0;
-        if (n)
+        // everything up to the collective; nothing in here waits for another rank
+        const auto phase_a = [&]() -> int
         {
-          TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
-          TRY(ensure(ctx, ctx->weightb, fb));
-          TRY(ensure(ctx, ctx->lik, fb));
-          TRY(ensure(ctx, ctx->ratio, fb));
-          TRY(ensure(ctx, ctx->beam, fb));
-          TRY(ensure(ctx, ctx->extra, fb));
-          TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
-          ctx->n_pose_uploaded = n;
-          TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
-          if (extra)
-            TRY(h2d(ctx, ctx->extra.p, extra + lo, fb));
-          TRY(launch_measure(ctx, ctx->pose.as<float>(), n, ctx->lik.as<float>(), ctx->ratio.as<float>(),
-                             ctx->beam.as<float>(), false, nullptr));
-          TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
-                                           extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n, r, N,
-                                           ctx->packed.as<double>()));
+          TRY(push_scan(ctx, g->scan, false));
+          TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
+          ctx->n_pose_uploaded = 0;
+          if (n)
+          {
+            TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
+            TRY(ensure(ctx, ctx->weightb, fb));
+            TRY(ensure(ctx, ctx->lik, fb));
+            TRY(ensure(ctx, ctx->ratio, fb));
+            TRY(ensure(ctx, ctx->beam, fb));
+            TRY(ensure(ctx, ctx->extra, fb));
+            TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
+            ctx->n_pose_uploaded = n;
+            TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
+            if (extra)
+              TRY(h2d(ctx, ctx->extra.p, extra + lo, fb));
+            TRY(launch_measure(ctx, ctx->pose.as<float>(), n, ctx->lik.as<float>(), ctx->ratio.as<float>(),
+                               ctx->beam.as<float>(), false, nullptr));
+            TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
+                                             extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n, r, N,
+                                             ctx->packed.as<double>()));
+          }
+          else
+            TRY(pack_empty(ctx, r, N, ctx->packed.as<double>()));
+          if (r == inject)
+            return ctx->fail(-9, "injected failure ahead of the collective (test hook)");
+          return 0;
+        };
+        int rc_a = phase_a();
+        // the vote: the collective is entered by all ranks or by none
+        const bool all_ok = g->vote.vote(rc_a == 0);
+        if (rc_a == 0 && !all_ok)
+          rc_a = ctx->fail(RC_ABANDONED, "update abandoned: another rank failed ahead of the collective");
+        if (rc_a != 0)
+        {
+          (void)hipStreamSynchronize(ctx->stream);  // drain what this rank enqueued; its results are discarded
+          ctx->stage_out.clear();
+          ctx->stage_cur = 0;
+          ctx->stage_off = 0;
+          return rcs[r] = rc_a;
         }
-        else
-          TRY(pack_empty(ctx, r, N, ctx->packed.as<double>()));
         if (host_combine)
         {
           g->host_packed[r].resize(n_pack);
           TRY(d2h(ctx, g->host_packed[r].data(), ctx->packed.p, sizeof(double) * n_pack));
-          return sync_stream(ctx);
+          return rcs[r] = sync_stream(ctx);
         }
         // the update's single collective: 16 + 16 N bytes over xGMI, on this device's stream
         const ncclResult_t nrc = g->rccl.AllReduce(ctx->packed.p, ctx->packed.p, n_pack, ncclDouble, ncclSum, g->comms[r],
                                                    ctx->stream);
         if (nrc != ncclSuccess)
-          return ctx->fail(-7, "ncclAllReduce failed: %s", g->rccl.GetErrorString(nrc));
-        return phase_b(ctx, r, lo, n);
+          return rcs[r] = ctx->fail(-7, "ncclAllReduce failed: %s", g->rccl.GetErrorString(nrc));
+        return rcs[r] = phase_b(ctx, r, lo, n);
       },
       &bad);
   if (rc)
+  {
+    // report the rank that actually failed, not one that merely stood down
+    for (int r = 0; r < N; ++r)
+      if (rcs[r] != 0 && rcs[r] != RC_ABANDONED)
+      {
+        rc = rcs[r];
+        bad = r;
+        break;
+      }
+    // communicators that saw a failed or abandoned update are rebuilt on next use
+    if (!host_combine && !g->comms.empty())
+    {
+      for (ncclComm_t c : g->comms)
+        if (c)
+          (void)g->rccl.CommDestroy(c);
+      g->comms.clear();
+    }
     return g->fail_rank(rc, bad);
+  }
   if (host_combine)
   {
     // sum the N records in rank order (deterministic) and hand the total back to every device

@@ -72,7 +72,20 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   }
   if (key == "strict_order")
   {
-    ctx->strict_order = value != 0.0;
+    if (!(value == 0.0 || value == 1.0 || value == 2.0))
+      return ctx->fail(-3, "strict_order must be 0 (never), 1 (always, weights too) or 2 (large scans only)");
+    if (static_cast<int>(value) != ctx->strict_order)
+      ++ctx->generation;  // a captured update graph holds the other kernel selection
+    ctx->strict_order = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "strict_auto_min")
+  {
+    if (!(value >= 1.0 && value <= 2147483647.0))
+      return ctx->fail(-3, "strict_auto_min must be a positive point count");
+    if (static_cast<int>(value) != ctx->strict_auto_min)
+      ++ctx->generation;
+    ctx->strict_auto_min = static_cast<int>(value);
     return 0;
   }
   if (key == "timing_mask")
@@ -200,6 +213,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_record_parts_in_use") *value = ctx->cand_parts;
   else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
   else if (key == "strict_order") *value = ctx->strict_order;
+  else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
   else if (key == "timing_mask") *value = ctx->timing_mask;
   else if (key == "use_graph") *value = ctx->use_graph;
   else if (key == "overlap_models") *value = ctx->overlap_models;

@@ -16,16 +16,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cloud_keys.h"
 #include "device_math.h"
 #include "map_structs.h"
 #pragma clang fp contract(off)
 
 namespace mcl3dl
 {
-__device__ inline bool finite3(const float4 p)
-{
-  return isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
-}
 
 __device__ inline uint32_t load_u32_unaligned(const uint8_t* p)
 {
@@ -71,74 +68,38 @@ __global__ void cloud_unpack_kernel(const float4* __restrict__ in, long long n, 
     label[i] = __float_as_uint(p.w);
 }
 
-// ---- min / max over the finite points (pcl::getMinMax3D) -------------------------------------------------------------
-// block partials: [6] = min xyz, max xyz; [6] as float = number of finite points in the block (exact below 2^24)
-__global__ __launch_bounds__(256) void cloud_minmax_kernel(const float4* __restrict__ pts, long long n,
-                                                           float* __restrict__ block_out, unsigned* __restrict__ block_cnt)
+// ---- min / max over the finite points (pcl::getMinMax3D), fused into the kernel that produces the points ------------------
+// Every thread brings its running min / max / finite count; the work-group reduces them, publishes one partial, and the
+// LAST work-group to arrive (atomic ticket, release / acquire fences at agent scope — nobody waits for anybody) folds the
+// partials into out6 = {min xyz, max xyz} and out_cnt, then resets the ticket for the next launch.
+struct MinMaxOut
 {
-  __shared__ float s[6][256];
-  __shared__ unsigned s_n[256];
-  float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-  unsigned cnt = 0;
-  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 256)
-  {
-    const float4 p = pts[i];
-    if (!finite3(p))
-      continue;
-    ++cnt;
-    mn[0] = fminf(mn[0], p.x);
-    mn[1] = fminf(mn[1], p.y);
-    mn[2] = fminf(mn[2], p.z);
-    mx[0] = fmaxf(mx[0], p.x);
-    mx[1] = fmaxf(mx[1], p.y);
-    mx[2] = fmaxf(mx[2], p.z);
-  }
-  for (int a = 0; a < 3; ++a)
-  {
-    s[a][threadIdx.x] = mn[a];
-    s[3 + a][threadIdx.x] = mx[a];
-  }
-  s_n[threadIdx.x] = cnt;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1)
-  {
-    if (threadIdx.x < off)
-    {
-      for (int a = 0; a < 3; ++a)
-      {
-        s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + off]);
-        s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + off]);
-      }
-      s_n[threadIdx.x] += s_n[threadIdx.x + off];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < 6)
-    block_out[6 * blockIdx.x + threadIdx.x] = s[threadIdx.x][0];
-  if (threadIdx.x == 0)
-    block_cnt[blockIdx.x] = s_n[0];
+  float* block_out;            // [6 x gridDim.x]
+  unsigned* block_cnt;         // [gridDim.x]
+  unsigned* ticket;            // zero before the first launch; left zero
+  float* out6;
+  unsigned long long* out_cnt;
+};
+
+__device__ inline void minmax_accumulate(const float4 p, float (&mn)[3], float (&mx)[3], unsigned& cnt)
+{
+  if (!finite3(p))
+    return;
+  ++cnt;
+  mn[0] = fminf(mn[0], p.x);
+  mn[1] = fminf(mn[1], p.y);
+  mn[2] = fminf(mn[2], p.z);
+  mx[0] = fmaxf(mx[0], p.x);
+  mx[1] = fmaxf(mx[1], p.y);
+  mx[2] = fmaxf(mx[2], p.z);
 }
 
-// one wavefront: the lanes stride the block partials, then butterfly reductions (min / max / integer sum: any order, same
-// result). Launched with 64 threads.
-__global__ void cloud_minmax_final(const float* __restrict__ block_out, const unsigned* __restrict__ block_cnt, int nb,
-                                   float* __restrict__ out6, unsigned long long* __restrict__ out_cnt)
+__device__ inline void wave_minmax(float (&mn)[3], float (&mx)[3], unsigned long long& cnt)
 {
-  if (blockIdx.x != 0 || threadIdx.x >= 64)
-    return;
-  float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-  unsigned long long cnt = 0;
-  for (int b = threadIdx.x; b < nb; b += 64)
-  {
-    for (int a = 0; a < 3; ++a)
-    {
-      mn[a] = fminf(mn[a], block_out[6 * b + a]);
-      mx[a] = fmaxf(mx[a], block_out[6 * b + 3 + a]);
-    }
-    cnt += block_cnt[b];
-  }
+#pragma unroll
   for (int off = 32; off > 0; off >>= 1)
   {
+#pragma unroll
     for (int a = 0; a < 3; ++a)
     {
       mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
@@ -146,87 +107,241 @@ __global__ void cloud_minmax_final(const float* __restrict__ block_out, const un
     }
     cnt += __shfl_xor(cnt, off, 64);
   }
-  if (threadIdx.x == 0)
+}
+
+// called by every thread of the work-group (blockDim.x a multiple of 64, at most 1024)
+__device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsigned cnt32, const MinMaxOut& o)
+{
+  __shared__ float s_mm[6][16];
+  __shared__ unsigned long long s_cnt[16];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  unsigned long long cnt = cnt32;
+  wave_minmax(mn, mx, cnt);
+  if (lane == 0)
   {
     for (int a = 0; a < 3; ++a)
     {
-      out6[a] = mn[a];
-      out6[3 + a] = mx[a];
+      s_mm[a][w] = mn[a];
+      s_mm[3 + a][w] = mx[a];
     }
-    *out_cnt = cnt;
+    s_cnt[w] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    float r[6];
+    unsigned long long c = 0;
+    for (int a = 0; a < 3; ++a)
+    {
+      r[a] = 3.0e38f;
+      r[3 + a] = -3.0e38f;
+    }
+    for (int k = 0; k < nw; ++k)
+    {
+      for (int a = 0; a < 3; ++a)
+      {
+        r[a] = fminf(r[a], s_mm[a][k]);
+        r[3 + a] = fmaxf(r[3 + a], s_mm[3 + a][k]);
+      }
+      c += s_cnt[k];
+    }
+    for (int a = 0; a < 6; ++a)
+      o.block_out[6 * blockIdx.x + a] = r[a];
+    o.block_cnt[blockIdx.x] = static_cast<unsigned>(c);
+    __threadfence();  // release: the partial is out of this XCD's L2 before the ticket moves
+    const unsigned t = atomicAdd(o.ticket, 1u);
+    s_last = (t + 1 == gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last || w != 0)
+    return;
+  __threadfence();  // acquire: the other work-groups' partials
+  float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+  unsigned long long total = 0;
+  for (unsigned b = lane; b < gridDim.x; b += 64)
+  {
+    for (int a = 0; a < 3; ++a)
+    {
+      const uint32_t lo = __hip_atomic_load(reinterpret_cast<const uint32_t*>(o.block_out) + 6 * b + a, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t hi = __hip_atomic_load(reinterpret_cast<const uint32_t*>(o.block_out) + 6 * b + 3 + a, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+      fmn[a] = fminf(fmn[a], __uint_as_float(lo));
+      fmx[a] = fmaxf(fmx[a], __uint_as_float(hi));
+    }
+    total += __hip_atomic_load(o.block_cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  wave_minmax(fmn, fmx, total);
+  if (lane == 0)
+  {
+    for (int a = 0; a < 3; ++a)
+    {
+      o.out6[a] = fmn[a];
+      o.out6[3 + a] = fmx[a];
+    }
+    *o.out_cnt = total;
+    *o.ticket = 0u;
   }
 }
 
-// ---- pcl::VoxelGrid ---------------------------------------------------------------------------------------------------
-struct VoxelGridParams
+// xyz + label arrays -> float4 cloud + its min / max (one launch)
+__global__ __launch_bounds__(256) void cloud_pack_minmax_kernel(const float* __restrict__ xyz, const uint32_t* __restrict__ label,
+                                                                long long n, float4* __restrict__ out, MinMaxOut mm)
 {
-  float inv_leaf[3];  // Eigen::Array4f::Ones() / leaf_size
-  int min_b[3];       // floor(min_p * inv_leaf)
-  int mul[3];         // divb_mul_: 1, div_b[0], div_b[0] * div_b[1]
+  float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+  unsigned cnt = 0;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 256)
+  {
+    const float4 p = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __uint_as_float(label ? label[i] : 0u));
+    out[i] = p;
+    minmax_accumulate(p, mn, mx, cnt);
+  }
+  block_minmax_finish(mn, mx, cnt, mm);
+}
+
+// PointCloud2 bytes -> float4 cloud + its min / max (one launch)
+__global__ __launch_bounds__(256) void cloud_decode_minmax_kernel(const uint8_t* __restrict__ data, long long n, uint32_t point_step,
+                                                                  int off_x, int off_y, int off_z, int off_label,
+                                                                  float4* __restrict__ out, MinMaxOut mm)
+{
+  float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+  unsigned cnt = 0;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 256)
+  {
+    const uint8_t* p = data + static_cast<size_t>(i) * point_step;
+    const uint32_t lab = off_label >= 0 ? load_u32_unaligned(p + off_label) : 0u;
+    const float4 q = make_float4(__uint_as_float(load_u32_unaligned(p + off_x)), __uint_as_float(load_u32_unaligned(p + off_y)),
+                                 __uint_as_float(load_u32_unaligned(p + off_z)), __uint_as_float(lab));
+    out[i] = q;
+    minmax_accumulate(q, mn, mx, cnt);
+  }
+  block_minmax_finish(mn, mx, cnt, mm);
+}
+
+// min / max of a device cloud that is already there
+__global__ __launch_bounds__(256) void cloud_minmax_kernel(const float4* __restrict__ pts, long long n, MinMaxOut mm)
+{
+  float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+  unsigned cnt = 0;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * 256)
+    minmax_accumulate(pts[i], mn, mx, cnt);
+  block_minmax_finish(mn, mx, cnt, mm);
+}
+
+// ---- ordered compaction in two launches --------------------------------------------------------------------------------
+// A work-group of 256 threads owns CP_BLOCK consecutive elements, four per thread (a 65 536-point cloud = 64 work-groups:
+// these are latency-bound passes, spread them). Launch 1 counts what each work-group keeps; launch 2 recomputes the
+// predicate, adds up the counts of the work-groups ahead of it (no waiting: they are the previous launch's output) and
+// writes its survivors in order.
+constexpr int CP_THREADS = 256;
+constexpr int CP_BLOCK = 4 * CP_THREADS;
+
+// exclusive scan of one value per thread over the work-group (up to 1024 threads); `total` = sum over the work-group
+__device__ inline uint32_t block_scan_excl(uint32_t v, uint32_t& total)
+{
+  __shared__ uint32_t s_w[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off)
+      inc += o;
+  }
+  __syncthreads();  // s_w may still be read by a previous call
+  if (lane == 63)
+    s_w[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+  const int nw = blockDim.x >> 6;
+  for (int k = 0; k < nw; ++k)
+  {
+    const uint32_t x = s_w[k];
+    base += k < w ? x : 0u;
+    all += x;
+  }
+  total = all;
+  return base + inc - v;
+}
+
+// sum of counts[0 .. blockIdx.x) (computed by the first wavefront, returned to every thread)
+__device__ inline uint32_t blocks_ahead(const uint32_t* __restrict__ counts)
+{
+  __shared__ uint32_t s_ahead;
+  if (threadIdx.x < 64)
+  {
+    uint32_t a = 0;
+    for (unsigned b = threadIdx.x; b < blockIdx.x; b += 64)
+      a += counts[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      a += __shfl_xor(a, off, 64);
+    if (threadIdx.x == 0)
+      s_ahead = a;
+  }
+  __syncthreads();
+  const uint32_t r = s_ahead;
+  __syncthreads();
+  return r;
+}
+
+// -- VoxelGrid: sorted (leaf key, point index) pairs -> one centroid per leaf, in ascending leaf order
+__device__ inline bool vg_is_head(const uint32_t* __restrict__ key, long long i, long long n_finite)
+{
+  return i < n_finite && (i == 0 || key[i] != key[i - 1]);
+}
+
+__global__ __launch_bounds__(CP_THREADS) void vg_head_count_kernel(const uint32_t* __restrict__ key, long long n_finite,
+                                                                   uint32_t* __restrict__ block_heads)
+{
+  const long long base = static_cast<long long>(blockIdx.x) * CP_BLOCK + threadIdx.x * 4;
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    c += vg_is_head(key, base + k, n_finite) ? 1u : 0u;
+  uint32_t total;
+  block_scan_excl(c, total);
+  if (threadIdx.x == 0)
+    block_heads[blockIdx.x] = total;
+}
+
+// pcl::CentroidPoint<PointXYZIL> of one leaf: xyz summed as floats in the order the points arrive (the stable sort keeps
+// the input order inside a leaf; PCL's own std::sort leaves that order unspecified), divided by the count; label = the most
+// frequent one, the smallest on a tie (AccumulatorLabel walks a std::map with a strict `>`).
+// The work-group's CP_BLOCK sorted entries sit in LDS (keys + gathered points: every global load of the leaf sums was
+// issued up front, in parallel); a leaf that runs past the work-group's last entry is finished from global memory.
+struct LeafEntries
+{
+  const uint32_t* s_key;  // LDS, CP_BLOCK entries from sorted position `base`
+  const float4* s_pt;
+  long long base, n_finite;
+  const float4* pts;  // global
+  const uint32_t* key;
+  const uint32_t* val;
+  __device__ inline uint32_t key_at(long long i) const
+  {
+    return i < base + CP_BLOCK ? s_key[i - base] : key[i];
+  }
+  __device__ inline float4 pt_at(long long i) const
+  {
+    return i < base + CP_BLOCK ? s_pt[i - base] : pts[val[i]];
+  }
 };
 
-// leaf index of every point — the expression of voxel_grid.hpp: ijk = int(floor(p * inv_leaf) - float(min_b)),
-// idx = ijk . divb_mul. Non-finite points get the key 0xffffffff (they sort behind every leaf and are dropped).
-__global__ void vg_key_kernel(const float4* __restrict__ pts, long long n, VoxelGridParams vp, uint32_t* __restrict__ key,
-                              uint32_t* __restrict__ val)
+__device__ inline float4 vg_leaf_centroid(const LeafEntries& le, long long s)
 {
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const float4 p = pts[i];
-  uint32_t k = 0xffffffffu;
-  if (finite3(p))
-  {
-    const int i0 = static_cast<int>(floorf(p.x * vp.inv_leaf[0]) - static_cast<float>(vp.min_b[0]));
-    const int i1 = static_cast<int>(floorf(p.y * vp.inv_leaf[1]) - static_cast<float>(vp.min_b[1]));
-    const int i2 = static_cast<int>(floorf(p.z * vp.inv_leaf[2]) - static_cast<float>(vp.min_b[2]));
-    k = static_cast<uint32_t>(i0 * vp.mul[0] + i1 * vp.mul[1] + i2 * vp.mul[2]);
-  }
-  key[i] = k;
-  val[i] = static_cast<uint32_t>(i);
-}
-
-// head[i] = 1 where a new leaf starts in the sorted key array (n = number of finite points); head[n] = 0 (scan slot)
-__global__ void vg_heads_kernel(const uint32_t* __restrict__ key, long long n, uint32_t* __restrict__ head)
-{
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i > n)
-    return;
-  head[i] = (i < n && (i == 0 || key[i] != key[i - 1])) ? 1u : 0u;
-}
-
-// start[leaf] = first sorted position of the leaf; leaf = exclusive scan of head at a head position
-__global__ void vg_starts_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ leaf_of, long long n,
-                                 uint32_t n_leaves, uint32_t* __restrict__ start)
-{
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i > n)
-    return;
-  if (i == n)
-  {
-    start[n_leaves] = static_cast<uint32_t>(n);
-    return;
-  }
-  if (i == 0 || key[i] != key[i - 1])
-    start[leaf_of[i]] = static_cast<uint32_t>(i);
-}
-
-// One thread per leaf: pcl::CentroidPoint<PointXYZIL> — xyz summed as floats in the order the points arrive (the stable
-// sort keeps the input order inside a leaf; PCL's own std::sort leaves that order unspecified), divided by the count;
-// label = the most frequent one, the smallest on a tie (AccumulatorLabel walks a std::map with a strict `>`).
-__global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ val,
-                                   const uint32_t* __restrict__ start, uint32_t n_leaves, float4* __restrict__ out)
-{
-  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= n_leaves)
-    return;
-  const uint32_t s = start[l], e = start[l + 1];
+  const uint32_t k0 = le.key_at(s);
+  long long e = s + 1;
+  while (e < le.n_finite && le.key_at(e) == k0)
+    ++e;
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  const uint32_t first_label = __float_as_uint(pts[val[s]].w);
+  const uint32_t first_label = __float_as_uint(le.pt_at(s).w);
   bool uniform = true;
-  for (uint32_t k = s; k < e; ++k)
+  for (long long k = s; k < e; ++k)
   {
-    const float4 p = pts[val[k]];
+    const float4 p = le.pt_at(k);
     sx += p.x;
     sy += p.y;
     sz += p.z;
@@ -236,12 +351,12 @@ __global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint32_
   if (!uniform)
   {
     uint32_t best_count = 0;
-    for (uint32_t k = s; k < e; ++k)
+    for (long long k = s; k < e; ++k)
     {
-      const uint32_t lab = __float_as_uint(pts[val[k]].w);
+      const uint32_t lab = __float_as_uint(le.pt_at(k).w);
       uint32_t c = 0;
-      for (uint32_t j = s; j < e; ++j)
-        c += __float_as_uint(pts[val[j]].w) == lab ? 1u : 0u;
+      for (long long j = s; j < e; ++j)
+        c += __float_as_uint(le.pt_at(j).w) == lab ? 1u : 0u;
       if (c > best_count || (c == best_count && lab < best_label))
       {
         best_count = c;
@@ -250,27 +365,137 @@ __global__ void vg_centroid_kernel(const float4* __restrict__ pts, const uint32_
     }
   }
   const float cnt = static_cast<float>(e - s);
-  out[l] = make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(best_label));
+  return make_float4(sx / cnt, sy / cnt, sz / cnt, __uint_as_float(best_label));
 }
 
-// ---- clip filter + order-preserving compaction -------------------------------------------------------------------------
-// flag[i] = 1 if the point is KEPT. The reference's lambda returns true (= erase) for x^2 + y^2 > far^2, < near^2,
-// z < z_min or z_max < z; a NaN makes every comparison false, so such a point is kept there too.
-__global__ void clip_flag_kernel(const float4* __restrict__ pts, long long n, float near_sq, float far_sq, float z_min,
-                                 float z_max, uint32_t* __restrict__ flag)
+// the thread that sits on the first entry of a leaf writes the leaf's centroid; the last work-group leaves the number of
+// leaves in *n_leaves
+__global__ __launch_bounds__(CP_THREADS) void vg_centroid_compact_kernel(const float4* __restrict__ pts,
+                                                                         const uint32_t* __restrict__ key,
+                                                                         const uint32_t* __restrict__ val, long long n_finite,
+                                                                         const uint32_t* __restrict__ block_heads,
+                                                                         float4* __restrict__ out, uint32_t* __restrict__ n_leaves)
 {
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i > n)
-    return;
-  if (i == n)
+  __shared__ uint32_t s_key[CP_BLOCK];
+  __shared__ float4 s_pt[CP_BLOCK];
+  const long long block_base = static_cast<long long>(blockIdx.x) * CP_BLOCK;
+  // coalesced: thread t stages entries t, t + 256, t + 512, t + 768 of the work-group's range
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
   {
-    flag[i] = 0;  // scan slot
-    return;
+    const int j = threadIdx.x + k * CP_THREADS;
+    const long long i = block_base + j;
+    if (i < n_finite)
+    {
+      s_key[j] = key[i];
+      s_pt[j] = pts[val[i]];
+    }
   }
-  const float4 p = pts[i];
+  __syncthreads();
+  const long long base = block_base + threadIdx.x * 4;
+  bool head[4];
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const long long i = base + k;
+    head[k] = i < n_finite && (i == 0 || (i > block_base ? s_key[i - block_base - 1] : key[i - 1]) != s_key[i - block_base]);
+    c += head[k] ? 1u : 0u;
+  }
+  const uint32_t ahead = blocks_ahead(block_heads);
+  uint32_t total;
+  uint32_t leaf = ahead + block_scan_excl(c, total);
+  const LeafEntries le{ s_key, s_pt, block_base, n_finite, pts, key, val };
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (head[k])
+      out[leaf++] = vg_leaf_centroid(le, base + k);
+  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0)
+    *n_leaves = ahead + total;
+}
+
+// -- the clip filters of both models (likelihood.cpp:84-93, beam.cpp:103-112), one pass over the cloud for the two of them.
+// The reference's lambda returns true (= erase) for x^2 + y^2 > far^2, < near^2, z < z_min or z_max < z; a NaN makes
+// every comparison false, so such a point is kept there too.
+struct ClipParams
+{
+  float near_sq, far_sq, z_min, z_max;
+  int enabled;
+};
+
+__device__ inline bool clip_keeps(const float4 p, const ClipParams& c)
+{
   const float r2 = p.x * p.x + p.y * p.y;
-  const bool erase = r2 > far_sq || r2 < near_sq || p.z < z_min || z_max < p.z;
-  flag[i] = erase ? 0u : 1u;
+  const bool erase = r2 > c.far_sq || r2 < c.near_sq || p.z < c.z_min || c.z_max < p.z;
+  return !erase;
+}
+
+// n = *n_dev when n_dev is given (the VoxelGrid's leaf count, which the host has not seen yet), n_host otherwise
+__global__ __launch_bounds__(CP_THREADS) void clip2_count_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ n_dev,
+                                                                 long long n_host, ClipParams c0, ClipParams c1,
+                                                                 uint32_t* __restrict__ counts /* [2][gridDim.x] */)
+{
+  const long long n = n_dev ? static_cast<long long>(*n_dev) : n_host;
+  const long long base = static_cast<long long>(blockIdx.x) * CP_BLOCK + threadIdx.x * 4;
+  uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n)
+    {
+      const float4 p = pts[base + k];
+      k0 += (c0.enabled && clip_keeps(p, c0)) ? 1u : 0u;
+      k1 += (c1.enabled && clip_keeps(p, c1)) ? 1u : 0u;
+    }
+  uint32_t t0, t1;
+  block_scan_excl(k0, t0);
+  block_scan_excl(k1, t1);
+  if (threadIdx.x == 0)
+  {
+    counts[blockIdx.x] = t0;
+    counts[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
+__global__ __launch_bounds__(CP_THREADS) void clip2_compact_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ n_dev,
+                                                                   long long n_host, ClipParams c0, ClipParams c1,
+                                                                   const uint32_t* __restrict__ counts, float4* __restrict__ out0,
+                                                                   float4* __restrict__ out1, uint32_t* __restrict__ totals2)
+{
+  const long long n = n_dev ? static_cast<long long>(*n_dev) : n_host;
+  const long long base = static_cast<long long>(blockIdx.x) * CP_BLOCK + threadIdx.x * 4;
+  float4 p[4];
+  bool keep0[4], keep1[4];
+  uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    keep0[k] = keep1[k] = false;
+    if (base + k < n)
+    {
+      p[k] = pts[base + k];
+      keep0[k] = c0.enabled && clip_keeps(p[k], c0);
+      keep1[k] = c1.enabled && clip_keeps(p[k], c1);
+    }
+    k0 += keep0[k] ? 1u : 0u;
+    k1 += keep1[k] ? 1u : 0u;
+  }
+  const uint32_t ahead0 = blocks_ahead(counts), ahead1 = blocks_ahead(counts + gridDim.x);
+  uint32_t t0, t1;
+  uint32_t d0 = ahead0 + block_scan_excl(k0, t0);
+  uint32_t d1 = ahead1 + block_scan_excl(k1, t1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    if (keep0[k])
+      out0[d0++] = p[k];
+    if (keep1[k])
+      out1[d1++] = p[k];
+  }
+  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0)
+  {
+    totals2[0] = ahead0 + t0;
+    totals2[1] = ahead1 + t1;
+  }
 }
 
 // out[pos[i]] = pts[i] where pos = exclusive scan of the keep flags (a kept point is one whose scan value steps)
@@ -284,89 +509,43 @@ __global__ void compact_kernel(const float4* __restrict__ pts, const uint32_t* _
     out[pos[i]] = pts[i];
 }
 
-// out[k] = src[idx[k]]; an index outside [0, n_src) raises the error flag (and reads point 0)
-__global__ void gather_kernel(const float4* __restrict__ src, long long n_src, const uint32_t* __restrict__ idx,
-                              long long n, float4* __restrict__ out, int* __restrict__ error)
+// -- the sampler's `output->push_back(pc->points[i])` for both models in one launch, with the min / max of the likelihood
+// sample (the Morton key's origin): out_a[k] = src_a[idx_a[k]] (k < n_a), out_b[k] = src_b[idx_b[k]] (k < n_b). An index
+// outside its cloud raises error flag 1 (and reads point 0).
+__global__ __launch_bounds__(256) void gather2_minmax_kernel(const float4* __restrict__ src_a, long long n_src_a,
+                                                             const uint32_t* __restrict__ idx_a, long long n_a,
+                                                             float4* __restrict__ out_a, const float4* __restrict__ src_b,
+                                                             long long n_src_b, const uint32_t* __restrict__ idx_b, long long n_b,
+                                                             float4* __restrict__ out_b, int* __restrict__ error, MinMaxOut mm)
 {
-  const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (k >= n)
-    return;
-  uint32_t i = idx[k];
-  if (i >= n_src)
+  float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+  unsigned cnt = 0;
+  for (long long k = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; k < n_a + n_b; k += static_cast<long long>(gridDim.x) * 256)
   {
-    *error = 1;
-    i = 0;
+    if (k < n_a)
+    {
+      uint32_t i = idx_a[k];
+      if (i >= n_src_a)
+      {
+        *error = 1;
+        i = 0;
+      }
+      const float4 p = src_a[i];
+      out_a[k] = p;
+      minmax_accumulate(p, mn, mx, cnt);
+    }
+    else
+    {
+      uint32_t i = idx_b[k - n_a];
+      if (i >= n_src_b)
+      {
+        *error = 1;
+        i = 0;
+      }
+      out_b[k - n_a] = src_b[i];
+    }
   }
-  out[k] = src[i];
-}
-
-// ---- scan ordering (the device form of api_core.inl:order_scan) --------------------------------------------------------
-__device__ inline uint32_t spread10(uint32_t v)
-{
-  // 10 bits -> every third bit (the low 30 bits of the host's 64-bit morton3 spread)
-  v &= 0x3ffu;
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-
-// 30-bit Morton key of a likelihood scan point: 0.25 m cells from the cloud's minimum corner, clamped to 10 bits per axis
-__global__ void order_morton_key_kernel(const float4* __restrict__ pts, long long n, const float* __restrict__ min3,
-                                        uint32_t* __restrict__ key, uint32_t* __restrict__ val)
-{
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const float4 p = pts[i];
-  const float c[3] = { p.x, p.y, p.z };
-  uint32_t q[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-  {
-    const float f = (c[a] - min3[a]) * 4.0f;
-    q[a] = (f >= 0.f) ? (f < 1023.f ? static_cast<uint32_t>(f) : 1023u) : 0u;
-  }
-  key[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-  val[i] = static_cast<uint32_t>(i);
-}
-
-// key = squared range of a beam point from its scan origin, as float bits (non-negative floats order like unsigned ints)
-__global__ void order_range_key_kernel(const float4* __restrict__ pts, long long n, const float4* __restrict__ origins,
-                                       uint32_t n_o, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
-                                       int* __restrict__ error)
-{
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const float4 p = pts[i];
-  uint32_t og = __float_as_uint(p.w);
-  if (og >= n_o)
-  {
-    *error = 2;
-    og = 0;
-  }
-  const float4 o = origins[og];
-  const float dx = p.x - o.x, dy = p.y - o.y, dz = p.z - o.z;
-  key[i] = __float_as_uint(dx * dx + dy * dy + dz * dz);
-  val[i] = static_cast<uint32_t>(i);
-}
-
-// out[k] = src[val[k]] (w kept: the beam scan carries the origin id there; the likelihood scan's is overwritten with 0),
-// perm[k] = val[k]
-__global__ void order_apply_kernel(const float4* __restrict__ src, const uint32_t* __restrict__ val, long long n,
-                                   int zero_w, float4* __restrict__ out, uint32_t* __restrict__ perm)
-{
-  const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (k >= n)
-    return;
-  float4 p = src[val[k]];
-  if (zero_w)
-    p.w = 0.f;
-  out[k] = p;
-  if (perm)
-    perm[k] = val[k];
+  block_minmax_finish(mn, mx, cnt, mm);
 }
 
 // ---- matched / unmatched output (src/mcl_3dl.cpp:761-805) --------------------------------------------------------------

@@ -9,55 +9,253 @@ unsigned blocks_for(long long n)
   return static_cast<unsigned>((std::max<long long>(n, 1) + 255) / 256);
 }
 
-// stable ascending sort of (key, value) pairs on the context's stream; results in keys_out / vals_out
-int sort_pairs(mcl3dl_hip_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-               long long n, int end_bit)
+// ---- min / max --------------------------------------------------------------------------------------------------------
+unsigned minmax_blocks(long long n)
+{
+  return static_cast<unsigned>(std::min<long long>(std::max<long long>((n + 1023) / 1024, 1), 256));
+}
+
+// where a min / max launch of `nb` work-groups leaves its partials and its result (ctx->cl_minmax: 6 floats + the number of
+// finite points as uint64); the ticket the last work-group resets is zeroed once, when it is allocated
+int minmax_out(mcl3dl_hip_ctx* ctx, unsigned nb, MinMaxOut* o)
+{
+  TRY(ensure(ctx, ctx->cl_blocks, (sizeof(float) * 6 + sizeof(unsigned)) * nb));
+  TRY(ensure(ctx, ctx->cl_minmax, sizeof(float) * 6 + sizeof(unsigned long long)));
+  if (!ctx->cl_ticket.p)
+  {
+    TRY(ensure(ctx, ctx->cl_ticket, 64));
+    HIP_TRY(hipMemsetAsync(ctx->cl_ticket.p, 0, 64, ctx->stream));
+  }
+  o->block_out = ctx->cl_blocks.as<float>();
+  o->block_cnt = reinterpret_cast<unsigned*>(o->block_out + 6 * static_cast<size_t>(nb));
+  o->ticket = ctx->cl_ticket.as<unsigned>();
+  o->out6 = ctx->cl_minmax.as<float>();
+  o->out_cnt = reinterpret_cast<unsigned long long*>(o->out6 + 6);
+  return 0;
+}
+
+// ctx->cl_minmax -> the host (one synchronisation)
+int minmax_to_host(mcl3dl_hip_ctx* ctx, float* host6, unsigned long long* host_cnt)
+{
+  float h[8];
+  TRY(d2h(ctx, h, ctx->cl_minmax.p, sizeof(float) * 6 + sizeof(unsigned long long)));
+  TRY(sync_stream(ctx));
+  if (host6)
+    memcpy(host6, h, sizeof(float) * 6);
+  if (host_cnt)
+    memcpy(host_cnt, h + 6, sizeof(unsigned long long));
+  return 0;
+}
+
+// min / max of the finite points of a device cloud -> ctx->cl_minmax (device) and, on request, the host. One launch.
+int cloud_minmax(mcl3dl_hip_ctx* ctx, const float4* pts, long long n, float* host6, unsigned long long* host_cnt)
+{
+  const unsigned nb = minmax_blocks(n);
+  MinMaxOut mm;
+  TRY(minmax_out(ctx, nb, &mm));
+  hipLaunchKernelGGL(cloud_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, pts, n, mm);
+  HIP_TRY(hipGetLastError());
+  if (host6 || host_cnt)
+    TRY(minmax_to_host(ctx, host6, host_cnt));
+  return 0;
+}
+
+// ---- stable radix sort (sort_kernels.h) ---------------------------------------------------------------------------------
+int sort_passes(int end_bit)
+{
+  return std::max(1, (end_bit + 7) / 8);
+}
+
+// Sorts n elements by the key `kg` describes (bits [0, end_bit)). fin == nullptr: the sorted (key, value) pairs land in
+// ctx->cl_key[1] / ctx->cl_val[1]; otherwise the last pass writes fin->src_pts in sorted order to fin->out_pts (and the
+// permutation to fin->out_perm). ctx->cl_key[0..1] / cl_val[0..1] are the work arrays (kg.keys / kg.vals may be
+// cl_key[0] / cl_val[0]). One launch up to 2048 elements, two per pass up to 524 288, rocprim beyond.
+template <int KEYMODE>
+int radix_sort(mcl3dl_hip_ctx* ctx, const RsKeyGen& kg, long long n, int end_bit, const RsFinal* fin)
 {
   if (n <= 0)
     return 0;
   if (n > 0x7fffffffLL)
     return ctx->fail(-3, "too many points to sort");
+  const size_t cap = sizeof(uint32_t) * (static_cast<size_t>(n) + 1);
+  for (int k = 0; k < 2; ++k)
+  {
+    TRY(ensure(ctx, ctx->cl_key[k], cap));
+    TRY(ensure(ctx, ctx->cl_val[k], cap));
+  }
+  RsKeyGen g = kg;  // (ensure() may have moved the work arrays the caller named before growing them: callers size them first)
+  uint32_t* key[2] = { ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>() };
+  uint32_t* val[2] = { ctx->cl_val[0].as<uint32_t>(), ctx->cl_val[1].as<uint32_t>() };
+  const int n_pass = sort_passes(end_bit);
+  const uint32_t mask = end_bit >= 32 ? 0xffffffffu : ((1u << end_bit) - 1u);  // only bits [0, end_bit) order the pairs
+  const RsFinal f = fin ? *fin : RsFinal{ nullptr, nullptr, nullptr, 0 };
+  const int ni = static_cast<int>(n);
+  if (n <= RS_ONE_LAUNCH_MAX)
+  {
+    if (fin)
+      hipLaunchKernelGGL((rs_sort_block_kernel<KEYMODE, true>), dim3(1), dim3(RS_THREADS), 0, ctx->stream, g, f, key[1], val[1],
+                         key[0], val[0], ni, n_pass, mask);
+    else
+      hipLaunchKernelGGL((rs_sort_block_kernel<KEYMODE, false>), dim3(1), dim3(RS_THREADS), 0, ctx->stream, g, f, key[1], val[1],
+                         key[0], val[0], ni, n_pass, mask);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  if (n <= RS_MAX_ELEMS)
+  {
+    // 1024 elements per work-group up to 65 536 (every CU of a quarter of the chip ranks one round), 4096 above
+    const int rounds = n <= 65536 ? 1 : 4;
+    const int elems = RS_THREADS * rounds;
+    const unsigned nb = static_cast<unsigned>((n + elems - 1) / elems);
+    TRY(ensure(ctx, ctx->rs_table, sizeof(uint32_t) * 256 * nb * n_pass));
+    uint32_t* table = ctx->rs_table.as<uint32_t>();
+    // the pairs ping-pong between the two array sets; start in the one that makes the LAST pass write set 1
+    int cur = (n_pass & 1) ? 0 : 1;
+    hipLaunchKernelGGL((rs_keygen_count_kernel<KEYMODE>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, g, key[cur], val[cur],
+                       table, ni, elems, mask);
+    for (int p = 0; p < n_pass; ++p)
+    {
+      const bool apply = fin && p + 1 == n_pass;
+      if (p)
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, key[cur], table, ni, elems, p, mask);
+#define RS_LAUNCH_PASS(AP, RR)                                                                                               \
+  hipLaunchKernelGGL((rs_pass_kernel<AP, RR>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, key[cur], val[cur], key[cur ^ 1], \
+                     val[cur ^ 1], f, table, ni, p, n_pass, mask)
+      if (rounds == 1)
+      {
+        if (apply)
+          RS_LAUNCH_PASS(true, 1);
+        else
+          RS_LAUNCH_PASS(false, 1);
+      }
+      else
+      {
+        if (apply)
+          RS_LAUNCH_PASS(true, 4);
+        else
+          RS_LAUNCH_PASS(false, 4);
+      }
+#undef RS_LAUNCH_PASS
+      cur ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  // whole maps: rocprim's device-wide radix sort (stable), keys made by a kernel of ours, result into set 1
+  if (!(KEYMODE == RS_KEY_ARRAY && g.keys == key[0] && (g.vals == val[0])))
+    hipLaunchKernelGGL((rs_keygen_kernel<KEYMODE>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, g, key[0], val[0], n);
   size_t bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, static_cast<int>(n), 0,
-                                             end_bit, ctx->stream));
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, key[0], key[1], val[0], val[1], static_cast<size_t>(n), 0u,
+                                    static_cast<unsigned>(std::min(end_bit, 32)), ctx->stream));
   TRY(ensure(ctx, ctx->sort_tmp, bytes));
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, bytes, keys_in, keys_out, vals_in, vals_out,
-                                             static_cast<int>(n), 0, end_bit, ctx->stream));
+  HIP_TRY(rocprim::radix_sort_pairs(ctx->sort_tmp.p, bytes, key[0], key[1], val[0], val[1], static_cast<size_t>(n), 0u,
+                                    static_cast<unsigned>(std::min(end_bit, 32)), ctx->stream));
+  if (fin)
+    hipLaunchKernelGGL(rs_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, f, val[1], n);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
-// min / max of the finite points of a device cloud -> ctx->cl_minmax (6 floats, device) and, on request, the host
-int cloud_minmax(mcl3dl_hip_ctx* ctx, const float4* pts, long long n, float* host6, unsigned long long* host_cnt)
+// stable ascending sort of the (key, value) pairs in ctx->cl_key[0] / cl_val[0] (n entries) -> ctx->cl_key[1] / cl_val[1]
+int sort_pairs(mcl3dl_hip_ctx* ctx, long long n, int end_bit)
 {
-  const int nb = static_cast<int>(std::min<long long>((n + 255) / 256, 512));
-  TRY(ensure(ctx, ctx->cl_blocks, sizeof(float) * 6 * std::max(nb, 1) + sizeof(unsigned) * std::max(nb, 1)));
-  TRY(ensure(ctx, ctx->cl_minmax, sizeof(float) * 6 + sizeof(unsigned long long)));
-  float* bo = ctx->cl_blocks.as<float>();
-  unsigned* bc = reinterpret_cast<unsigned*>(bo + 6 * std::max(nb, 1));
-  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(ctx->cl_minmax.as<float>() + 6);
-  hipLaunchKernelGGL(cloud_minmax_kernel, dim3(std::max(nb, 1)), dim3(256), 0, ctx->stream, pts, n, bo, bc);
-  hipLaunchKernelGGL(cloud_minmax_final, dim3(1), dim3(64), 0, ctx->stream, bo, bc, std::max(nb, 1),
-                     ctx->cl_minmax.as<float>(), cnt);
-  HIP_TRY(hipGetLastError());
-  if (host6 || host_cnt)
+  RsKeyGen kg{};
+  kg.keys = ctx->cl_key[0].as<uint32_t>();
+  kg.vals = ctx->cl_val[0].as<uint32_t>();
+  return radix_sort<RS_KEY_ARRAY>(ctx, kg, n, end_bit, nullptr);
+}
+
+int bits_for(unsigned long long max_value)
+{
+  int b = 1;
+  while (b < 64 && (max_value >> b))
+    ++b;
+  return b;
+}
+
+// host xyz (+ label) -> device float4 cloud; with_minmax: its min / max / finite count land in ctx->cl_minmax (same launch)
+int upload_cloud(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, DevBuf& out, bool with_minmax = false)
+{
+  TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
+  if (n == 0)
+    return 0;
+  TRY(ensure(ctx, ctx->cl_in_xyz, sizeof(float) * 3 * n));
+  TRY(h2d(ctx, ctx->cl_in_xyz.p, xyz, sizeof(float) * 3 * n));
+  const uint32_t* d_label = nullptr;
+  if (label)
   {
-    float h[8];
-    TRY(d2h(ctx, h, ctx->cl_minmax.p, sizeof(float) * 6 + sizeof(unsigned long long)));
-    TRY(sync_stream(ctx));
-    if (host6)
-      memcpy(host6, h, sizeof(float) * 6);
-    if (host_cnt)
-      memcpy(host_cnt, h + 6, sizeof(unsigned long long));
+    TRY(ensure(ctx, ctx->cl_in_label, sizeof(uint32_t) * n));
+    TRY(h2d(ctx, ctx->cl_in_label.p, label, sizeof(uint32_t) * n));
+    d_label = ctx->cl_in_label.as<uint32_t>();
   }
+  const long long nn = static_cast<long long>(n);
+  if (with_minmax)
+  {
+    const unsigned nb = minmax_blocks(nn);
+    MinMaxOut mm;
+    TRY(minmax_out(ctx, nb, &mm));
+    hipLaunchKernelGGL(cloud_pack_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->cl_in_xyz.as<float>(), d_label, nn,
+                       out.as<float4>(), mm);
+  }
+  else
+  {
+    hipLaunchKernelGGL(cloud_pack_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->cl_in_xyz.as<float>(), d_label,
+                       nn, out.as<float4>());
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// PointCloud2 bytes -> device float4 cloud (mcl_3dl::fromROSMsg, point_conversion.h:64-92: x, y, z are required; a
+// "label" field is used when present; "intensity" is not on the measurement path). The buffer must be tightly packed
+// little-endian rows: n_points * point_step bytes (row_step == width * point_step; include/mcl3dl_hip.h).
+int decode_cloud(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step, int off_x, int off_y,
+                 int off_z, int off_label, DevBuf& out, bool with_minmax = false)
+{
+  if (off_x < 0 || off_y < 0 || off_z < 0)
+    return ctx->fail(-3, "Given PointCloud2 doesn't have x, y, z fields");
+  if (n_points == 0)
+    return ctx->fail(-3, "Given PointCloud2 is empty");
+  const int offs[4] = { off_x, off_y, off_z, off_label };
+  for (int k = 0; k < 4; ++k)
+    if (offs[k] >= 0 && static_cast<uint32_t>(offs[k]) + 4 > point_step)
+      return ctx->fail(-3, "field offset %d does not fit point_step %u", offs[k], point_step);
+  if (!data)
+    return ctx->fail(-3, "null PointCloud2 data");
+  const size_t bytes = n_points * static_cast<size_t>(point_step);
+  TRY(ensure(ctx, ctx->cl_in_xyz, bytes));
+  TRY(ensure(ctx, out, sizeof(float4) * n_points));
+  TRY(h2d(ctx, ctx->cl_in_xyz.p, data, bytes));
+  const long long nn = static_cast<long long>(n_points);
+  if (with_minmax)
+  {
+    const unsigned nb = minmax_blocks(nn);
+    MinMaxOut mm;
+    TRY(minmax_out(ctx, nb, &mm));
+    hipLaunchKernelGGL(cloud_decode_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->cl_in_xyz.as<uint8_t>(), nn,
+                       point_step, off_x, off_y, off_z, off_label, out.as<float4>(), mm);
+  }
+  else
+  {
+    hipLaunchKernelGGL(cloud_decode_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->cl_in_xyz.as<uint8_t>(), nn,
+                       point_step, off_x, off_y, off_z, off_label, out.as<float4>());
+  }
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
 // pcl::VoxelGrid<PointXYZIL> with only setLeafSize set (the node's three call sites): `in` (n points, device) ->
 // `out` (one centroid per occupied leaf, in ascending leaf-index order). A leaf component <= 0 skips the filter.
-int voxel_grid(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf[3], DevBuf& out, size_t* n_out)
+// have_minmax: ctx->cl_minmax already holds the min / max / finite count of `in` (the kernel that produced it computed them).
+// The number of leaves stays on the device (ctx->cl_counts, word 0) when *deferred comes back true — the caller reads it
+// with its next synchronisation — and is in *n_out otherwise (pass-through cases).
+int voxel_grid(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf[3], DevBuf& out, size_t* n_out, bool* deferred,
+               bool have_minmax = false)
 {
   *n_out = 0;
+  *deferred = false;
   TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
+  TRY(ensure(ctx, ctx->cl_counts, sizeof(uint32_t) * 4));
   if (n == 0)
     return 0;
   if (!leaf || !(leaf[0] > 0.f && leaf[1] > 0.f && leaf[2] > 0.f))
@@ -68,7 +266,10 @@ int voxel_grid(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf
   }
   float mm[6];
   unsigned long long n_finite = 0;
-  TRY(cloud_minmax(ctx, in, static_cast<long long>(n), mm, &n_finite));
+  if (have_minmax)
+    TRY(minmax_to_host(ctx, mm, &n_finite));
+  else
+    TRY(cloud_minmax(ctx, in, static_cast<long long>(n), mm, &n_finite));
   if (n_finite == 0)
     return 0;
   VoxelGridParams vp{};
@@ -89,108 +290,50 @@ int voxel_grid(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf
     *n_out = n;
     return 0;
   }
-  const int div0 = max_b[0] - vp.min_b[0] + 1, div1 = max_b[1] - vp.min_b[1] + 1;
+  const long long div0 = max_b[0] - vp.min_b[0] + 1, div1 = max_b[1] - vp.min_b[1] + 1, div2 = max_b[2] - vp.min_b[2] + 1;
   vp.mul[0] = 1;
-  vp.mul[1] = div0;
-  vp.mul[2] = div0 * div1;
-  const long long nn = static_cast<long long>(n);
-  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_scan, sizeof(uint32_t) * (n + 2)));
-  TRY(ensure(ctx, ctx->cl_scan_ws, sizeof(uint32_t) * (n / 1023 + 16)));
-  hipLaunchKernelGGL(vg_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, in, nn, vp,
-                     ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>());
-  TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
-                 ctx->cl_val[1].as<uint32_t>(), nn, 32));
-  const long long nf = static_cast<long long>(n_finite);  // the non-finite points carry key 0xffffffff: sorted last
-  hipLaunchKernelGGL(vg_heads_kernel, dim3(blocks_for(nf + 1)), dim3(256), 0, ctx->stream, ctx->cl_key[1].as<uint32_t>(),
-                     nf, ctx->cl_scan.as<uint32_t>());
-  TRY(device_exclusive_scan_ws(ctx, ctx->cl_scan.as<uint32_t>(), nf + 1, ctx->cl_scan_ws.as<uint32_t>()));
-  uint32_t n_leaves = 0;
-  TRY(d2h(ctx, &n_leaves, ctx->cl_scan.as<uint32_t>() + nf, sizeof(uint32_t)));
-  TRY(sync_stream(ctx));
-  TRY(ensure(ctx, ctx->cl_start, sizeof(uint32_t) * (static_cast<size_t>(n_leaves) + 1)));
-  hipLaunchKernelGGL(vg_starts_kernel, dim3(blocks_for(nf + 1)), dim3(256), 0, ctx->stream, ctx->cl_key[1].as<uint32_t>(),
-                     ctx->cl_scan.as<uint32_t>(), nf, n_leaves, ctx->cl_start.as<uint32_t>());
-  hipLaunchKernelGGL(vg_centroid_kernel, dim3(blocks_for(n_leaves)), dim3(256), 0, ctx->stream, in,
-                     ctx->cl_val[1].as<uint32_t>(), ctx->cl_start.as<uint32_t>(), n_leaves, out.as<float4>());
-  HIP_TRY(hipGetLastError());
-  *n_out = n_leaves;
-  return 0;
-}
-
-// clip predicate + order-preserving compaction: in (n) -> out. The number kept arrives in *kept32 at the caller's next
-// sync_stream() (no synchronisation here: the two models' clips share one).
-int clip_compact(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float clip4[4], DevBuf& out, uint32_t* kept32,
-                 int scan_slot)
-{
-  *kept32 = 0;
-  TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
-  if (n == 0)
-    return 0;
-  const long long nn = static_cast<long long>(n);
-  // each clip has its own flag / scan arrays: the second one is enqueued while the first one's count is still in flight
-  DevBuf& flags = ctx->cl_clip_scan[scan_slot];
-  DevBuf& ws = ctx->cl_clip_ws[scan_slot];
-  TRY(ensure(ctx, flags, sizeof(uint32_t) * (n + 2)));
-  TRY(ensure(ctx, ws, sizeof(uint32_t) * (n / 1023 + 16)));
-  // clip_near_sq_ = clip_near * clip_near etc. in float, like refreshParameters (likelihood.cpp:58-59, beam.cpp:60-61)
-  const float near_sq = clip4[0] * clip4[0], far_sq = clip4[1] * clip4[1];
-  hipLaunchKernelGGL(clip_flag_kernel, dim3(blocks_for(nn + 1)), dim3(256), 0, ctx->stream, in, nn, near_sq, far_sq, clip4[2],
-                     clip4[3], flags.as<uint32_t>());
-  TRY(device_exclusive_scan_ws(ctx, flags.as<uint32_t>(), nn + 1, ws.as<uint32_t>()));
-  hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, in, flags.as<uint32_t>(), nn,
-                     out.as<float4>());
-  TRY(d2h(ctx, kept32, flags.as<uint32_t>() + nn, sizeof(uint32_t)));
-  return 0;
-}
-
-// host xyz (+ label) -> device float4 cloud
-int upload_cloud(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* label, size_t n, DevBuf& out)
-{
-  TRY(ensure(ctx, out, sizeof(float4) * std::max<size_t>(n, 1)));
-  if (n == 0)
-    return 0;
-  TRY(ensure(ctx, ctx->cl_in_xyz, sizeof(float) * 3 * n));
-  TRY(h2d(ctx, ctx->cl_in_xyz.p, xyz, sizeof(float) * 3 * n));
-  const uint32_t* d_label = nullptr;
-  if (label)
+  vp.mul[1] = static_cast<int>(div0);
+  vp.mul[2] = static_cast<int>(div0 * div1);
+  // leaf indices are below div0 div1 div2 (<= 2^31 by the check above, up to rounding of the two extent formulas);
+  // non-finite points sort behind all of them
+  const unsigned long long cells = static_cast<unsigned long long>(div0) * div1 * div2;
+  int end_bit = 32;
+  vp.nonfinite_key = 0xffffffffu;
+  if (cells < 0x7fffffffULL)
   {
-    TRY(ensure(ctx, ctx->cl_in_label, sizeof(uint32_t) * n));
-    TRY(h2d(ctx, ctx->cl_in_label.p, label, sizeof(uint32_t) * n));
-    d_label = ctx->cl_in_label.as<uint32_t>();
+    vp.nonfinite_key = static_cast<uint32_t>(cells);
+    end_bit = bits_for(cells);
   }
-  hipLaunchKernelGGL(cloud_pack_kernel, dim3(blocks_for(static_cast<long long>(n))), dim3(256), 0, ctx->stream,
-                     ctx->cl_in_xyz.as<float>(), d_label, static_cast<long long>(n), out.as<float4>());
+  const long long nn = static_cast<long long>(n), nf = static_cast<long long>(n_finite);
+  RsKeyGen kg{};
+  kg.pts = in;
+  kg.vp = vp;
+  TRY(radix_sort<RS_KEY_LEAF>(ctx, kg, nn, end_bit, nullptr));
+  const unsigned nb = static_cast<unsigned>((nf + CP_BLOCK - 1) / CP_BLOCK);
+  TRY(ensure(ctx, ctx->cl_scan_ws, sizeof(uint32_t) * (2 * static_cast<size_t>((nn + CP_BLOCK - 1) / CP_BLOCK) + 16)));
+  hipLaunchKernelGGL(vg_head_count_kernel, dim3(nb), dim3(CP_THREADS), 0, ctx->stream, ctx->cl_key[1].as<uint32_t>(), nf,
+                     ctx->cl_scan_ws.as<uint32_t>());
+  hipLaunchKernelGGL(vg_centroid_compact_kernel, dim3(nb), dim3(CP_THREADS), 0, ctx->stream, in, ctx->cl_key[1].as<uint32_t>(),
+                     ctx->cl_val[1].as<uint32_t>(), nf, ctx->cl_scan_ws.as<uint32_t>(), out.as<float4>(),
+                     ctx->cl_counts.as<uint32_t>());
   HIP_TRY(hipGetLastError());
+  *deferred = true;
   return 0;
 }
 
-// PointCloud2 bytes -> device float4 cloud (mcl_3dl::fromROSMsg, point_conversion.h:64-92: x, y, z are required; a
-// "label" field is used when present; "intensity" is not on the measurement path)
-int decode_cloud(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step, int off_x, int off_y,
-                 int off_z, int off_label, DevBuf& out)
+// the same, with the leaf count brought to the host (one more synchronisation)
+int voxel_grid_now(mcl3dl_hip_ctx* ctx, const float4* in, size_t n, const float leaf[3], DevBuf& out, size_t* n_out,
+                   bool have_minmax = false)
 {
-  if (off_x < 0 || off_y < 0 || off_z < 0)
-    return ctx->fail(-3, "Given PointCloud2 doesn't have x, y, z fields");
-  if (n_points == 0)
-    return ctx->fail(-3, "Given PointCloud2 is empty");
-  const int offs[4] = { off_x, off_y, off_z, off_label };
-  for (int k = 0; k < 4; ++k)
-    if (offs[k] >= 0 && static_cast<uint32_t>(offs[k]) + 4 > point_step)
-      return ctx->fail(-3, "field offset %d does not fit point_step %u", offs[k], point_step);
-  if (!data)
-    return ctx->fail(-3, "null PointCloud2 data");
-  const size_t bytes = n_points * static_cast<size_t>(point_step);
-  TRY(ensure(ctx, ctx->cl_in_xyz, bytes));
-  TRY(ensure(ctx, out, sizeof(float4) * n_points));
-  TRY(h2d(ctx, ctx->cl_in_xyz.p, data, bytes));
-  hipLaunchKernelGGL(cloud_decode_kernel, dim3(blocks_for(static_cast<long long>(n_points))), dim3(256), 0, ctx->stream,
-                     ctx->cl_in_xyz.as<uint8_t>(), static_cast<long long>(n_points), point_step, off_x, off_y, off_z,
-                     off_label, out.as<float4>());
-  HIP_TRY(hipGetLastError());
+  bool deferred = false;
+  TRY(voxel_grid(ctx, in, n, leaf, out, n_out, &deferred, have_minmax));
+  if (deferred)
+  {
+    uint32_t n_leaves = 0;
+    TRY(d2h(ctx, &n_leaves, ctx->cl_counts.p, sizeof(uint32_t)));
+    TRY(sync_stream(ctx));
+    *n_out = n_leaves;
+  }
   return 0;
 }
 
@@ -211,19 +354,56 @@ int download_cloud(mcl3dl_hip_ctx* ctx, const float4* src, size_t n, float* xyz,
 }
 
 int scan_begin_common(mcl3dl_hip_ctx* ctx, size_t n, const float* leaf3, const float* clip_lik4, const float* clip_beam4,
-                      size_t* n_full, size_t* n_lik, size_t* n_beam)
+                      size_t* n_full, size_t* n_lik, size_t* n_beam, bool have_minmax)
 {
-  // ctx->sp_raw holds the accumulated cloud
+  // ctx->sp_raw holds the accumulated cloud. VoxelGrid -> both clips, the three counts delivered by ONE synchronisation
+  // (the VoxelGrid's own min / max round trip is the only other one).
   ctx->sp_ready = false;
-  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n, leaf3, ctx->sp_full, &ctx->sp_n_full));
-  ctx->sp_kept32[0] = ctx->sp_kept32[1] = 0;
-  if (clip_lik4)
-    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_lik4, ctx->sp_clip[0], &ctx->sp_kept32[0], 0));
-  if (clip_beam4)
-    TRY(clip_compact(ctx, ctx->sp_full.as<float4>(), ctx->sp_n_full, clip_beam4, ctx->sp_clip[1], &ctx->sp_kept32[1], 1));
-  TRY(sync_stream(ctx));  // ONE synchronisation delivers both counts
-  ctx->sp_n_clip[0] = ctx->sp_kept32[0];
-  ctx->sp_n_clip[1] = ctx->sp_kept32[1];
+  bool deferred = false;
+  TRY(voxel_grid(ctx, ctx->sp_raw.as<float4>(), n, leaf3, ctx->sp_full, &ctx->sp_n_full, &deferred, have_minmax));
+  const size_t n_upper = deferred ? n : ctx->sp_n_full;  // what the clips may have to look at
+  TRY(ensure(ctx, ctx->sp_clip[0], sizeof(float4) * std::max<size_t>(n_upper, 1)));
+  TRY(ensure(ctx, ctx->sp_clip[1], sizeof(float4) * std::max<size_t>(n_upper, 1)));
+  uint32_t counts[3] = { 0, 0, 0 };
+  uint32_t* d_counts = ctx->cl_counts.as<uint32_t>();
+  if (n_upper && (clip_lik4 || clip_beam4))
+  {
+    // clip_near_sq_ = clip_near * clip_near etc. in float, like refreshParameters (likelihood.cpp:58-59, beam.cpp:60-61)
+    auto params = [](const float* c4) {
+      ClipParams c{};
+      if (c4)
+      {
+        c.near_sq = c4[0] * c4[0];
+        c.far_sq = c4[1] * c4[1];
+        c.z_min = c4[2];
+        c.z_max = c4[3];
+        c.enabled = 1;
+      }
+      return c;
+    };
+    const ClipParams c0 = params(clip_lik4), c1 = params(clip_beam4);
+    const unsigned nb = static_cast<unsigned>((n_upper + CP_BLOCK - 1) / CP_BLOCK);
+    DevBuf& cnt = ctx->cl_clip_scan[0];
+    TRY(ensure(ctx, cnt, sizeof(uint32_t) * 2 * nb));
+    const uint32_t* n_dev = deferred ? d_counts : nullptr;
+    hipLaunchKernelGGL(clip2_count_kernel, dim3(nb), dim3(CP_THREADS), 0, ctx->stream, ctx->sp_full.as<float4>(), n_dev,
+                       static_cast<long long>(n_upper), c0, c1, cnt.as<uint32_t>());
+    hipLaunchKernelGGL(clip2_compact_kernel, dim3(nb), dim3(CP_THREADS), 0, ctx->stream, ctx->sp_full.as<float4>(), n_dev,
+                       static_cast<long long>(n_upper), c0, c1, cnt.as<uint32_t>(), ctx->sp_clip[0].as<float4>(),
+                       ctx->sp_clip[1].as<float4>(), d_counts + 1);
+    HIP_TRY(hipGetLastError());
+    TRY(d2h(ctx, counts, d_counts, sizeof(uint32_t) * 3));
+    TRY(sync_stream(ctx));
+  }
+  else if (deferred)
+  {
+    TRY(d2h(ctx, counts, d_counts, sizeof(uint32_t)));
+    TRY(sync_stream(ctx));
+  }
+  if (deferred)
+    ctx->sp_n_full = counts[0];
+  ctx->sp_n_clip[0] = counts[1];
+  ctx->sp_n_clip[1] = counts[2];
   ctx->sp_ready = true;
   if (n_full)
     *n_full = ctx->sp_n_full;
@@ -237,14 +417,18 @@ int scan_begin_common(mcl3dl_hip_ctx* ctx, size_t n, const float* leaf3, const f
 // The two sampled clouds in ctx->sp_samp[0] (likelihood, n_s points) and ctx->sp_samp[1] (beam, n_b points, w = origin id)
 // -> the context's ordered scan buffers, on the device: the ordering api_core.inl:order_scan does on the host — 30-bit
 // Morton key from the cloud's minimum corner resp. squared range from the scan origin, stable sort — so both entry paths
-// produce the same order and with it bit-identical results. Raises error flag 2 (ctx->cl_err) for a bad origin id.
-int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float* origins, size_t n_o)
+// produce the same order and with it bit-identical results. Keys are made inside the sort's first pass and the points are
+// written by its last one. have_minmax: ctx->cl_minmax holds the min corner of sp_samp[0] already. Raises error flag 2
+// (*d_err, device memory) for a bad origin id.
+int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float* origins, size_t n_o, bool have_minmax,
+                       int* d_err)
 {
   const size_t n_max = std::max<size_t>(std::max(n_s, n_b), 1);
-  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n_max + 1)));
-  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n_max + 1)));
-  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n_max + 1)));
-  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n_max + 1)));
+  for (int k = 0; k < 2; ++k)
+  {
+    TRY(ensure(ctx, ctx->cl_key[k], sizeof(uint32_t) * (n_max + 1)));
+    TRY(ensure(ctx, ctx->cl_val[k], sizeof(uint32_t) * (n_max + 1)));
+  }
   TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
   TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
   TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
@@ -252,14 +436,13 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
   if (n_s)
   {
     const long long ns = static_cast<long long>(n_s);
-    TRY(cloud_minmax(ctx, ctx->sp_samp[0].as<float4>(), ns, nullptr, nullptr));
-    hipLaunchKernelGGL(order_morton_key_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream,
-                       ctx->sp_samp[0].as<float4>(), ns, ctx->cl_minmax.as<float>(), ctx->cl_key[0].as<uint32_t>(),
-                       ctx->cl_val[0].as<uint32_t>());
-    TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
-                   ctx->cl_val[1].as<uint32_t>(), ns, 30));
-    hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream, ctx->sp_samp[0].as<float4>(),
-                       ctx->cl_val[1].as<uint32_t>(), ns, 1, ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>());
+    if (!have_minmax)
+      TRY(cloud_minmax(ctx, ctx->sp_samp[0].as<float4>(), ns, nullptr, nullptr));
+    RsKeyGen kg{};
+    kg.pts = ctx->sp_samp[0].as<float4>();
+    kg.min3 = ctx->cl_minmax.as<float>();
+    const RsFinal fin{ ctx->sp_samp[0].as<float4>(), ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>(), 1 };
+    TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, ns, 30, &fin));
   }
   if (n_o)
   {
@@ -270,14 +453,13 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
   }
   if (n_b)
   {
-    const long long nb = static_cast<long long>(n_b);
-    hipLaunchKernelGGL(order_range_key_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream,
-                       ctx->sp_samp[1].as<float4>(), nb, ctx->origins.as<float4>(), static_cast<uint32_t>(n_o),
-                       ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->cl_err.as<int>());
-    TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
-                   ctx->cl_val[1].as<uint32_t>(), nb, 32));
-    hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, ctx->sp_samp[1].as<float4>(),
-                       ctx->cl_val[1].as<uint32_t>(), nb, 0, ctx->scan_beam.as<float4>(), static_cast<uint32_t*>(nullptr));
+    RsKeyGen kg{};
+    kg.pts = ctx->sp_samp[1].as<float4>();
+    kg.origins = ctx->origins.as<float4>();
+    kg.n_o = static_cast<uint32_t>(n_o);
+    kg.error = d_err;
+    const RsFinal fin{ ctx->sp_samp[1].as<float4>(), ctx->scan_beam.as<float4>(), nullptr, 0 };
+    TRY(radix_sort<RS_KEY_RANGE>(ctx, kg, static_cast<long long>(n_b), 32, &fin));
   }
   HIP_TRY(hipGetLastError());
   return 0;

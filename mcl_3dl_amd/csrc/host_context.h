@@ -93,7 +93,11 @@ struct mcl3dl_hip_ctx
   DevBuf lik_partial_sum, lik_partial_cnt;
   int pf_fused = 1;        // 1 = pf::measure as ONE kernel up to pf_fused_max particles on one GPU (same bits, two launches fewer)
   int pf_fused_max = 1024;  // measured: one work-group beats three launches up to 1024 particles, ties at 2048, loses at 4096
-  int strict_order = 0;    // 1 = add the likelihood terms / the weights in the reference's float order (single GPU)
+  // 1 = add the likelihood terms AND the weights in the reference's float order (single GPU; bit-identical results);
+  // 2 (default) = replay the likelihood terms in that order for scans of at least strict_auto_min points, where the
+  // reference's own float rounding (a random walk of n_s roundings) reaches the 1e-5 tolerance of north_star; 0 = never
+  int strict_order = 2;
+  int strict_auto_min = 32768;
   DevBuf scan_perm, strict_terms;
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
@@ -143,6 +147,9 @@ struct mcl3dl_hip_ctx
   // point-cloud preparation on the device (api_cloud.inl, cloud_kernels.h)
   DevBuf sort_tmp, cl_blocks, cl_minmax, cl_key[2], cl_val[2], cl_scan, cl_scan_ws, cl_start, cl_in_xyz, cl_in_label, cl_idx,
       cl_idx2, cl_err;
+  DevBuf cl_ticket;  // arrival counter of the fused min / max reductions (zero between launches)
+  DevBuf cl_counts;  // {VoxelGrid leaves, points the likelihood clip keeps, points the beam clip keeps}: one D2H for the three
+  DevBuf rs_table;   // per-pass, per-work-group digit totals of the multi-work-group radix sort (sort_kernels.h)
   DevBuf sp_raw, sp_full, sp_clip[2], sp_samp[2];   // accumulated cloud, voxel-filtered, clipped (lik / beam), sampled
   DevBuf cl_clip_scan[2], cl_clip_ws[2];            // flag / scan arrays of the two clips (enqueued back to back)
   uint32_t sp_kept32[2] = { 0, 0 };                 // their counts, delivered by one synchronisation

@@ -87,8 +87,7 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
   const CellGeom g{ o[0], o[1], o[2], inv, dim[0], dim[1], dim[2] };
   hipLaunchKernelGGL(lik_cell_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
                      nn, g, ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->lik_cells.as<uint32_t>());
-  TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
-                 ctx->cl_val[1].as<uint32_t>(), nn, sort_bits(ncell)));
+  TRY(sort_pairs(ctx, nn, sort_bits(ncell)));
   hipLaunchKernelGGL(grid_gather_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
                      ctx->cl_val[1].as<uint32_t>(), nn, ctx->lik_pts.as<float4>());
   HIP_TRY(hipGetLastError());
@@ -163,8 +162,7 @@ int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
   hipLaunchKernelGGL(dda_voxel_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn, g,
                      ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->dda_start.as<uint32_t>(),
                      ctx->dda_bits.as<unsigned long long>(), ctx->cl_err.as<int>());
-  TRY(sort_pairs(ctx, ctx->cl_key[0].as<uint32_t>(), ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(),
-                 ctx->cl_val[1].as<uint32_t>(), nn, sort_bits(total)));
+  TRY(sort_pairs(ctx, nn, sort_bits(total)));
   hipLaunchKernelGGL(dda_gather_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(),
                      ctx->cl_val[1].as<uint32_t>(), nn, ctx->dda_pts.as<float4>(), ctx->dda_index.as<uint32_t>());
   HIP_TRY(hipGetLastError());

@@ -135,6 +135,45 @@ private:
   bool stop_ = false;
   std::vector<int> rc_;
 };
+
+// Every worker of one run_all() casts one vote and gets the conjunction of all votes back. The update's collective is
+// enqueued only when every rank reached it: a rank whose upload / launch failed must not leave the others blocked inside
+// an all-reduce that can never complete (api_group.inl, the RCCL path).
+class VoteBarrier
+{
+public:
+  void resize(int n)
+  {
+    n_ = n;
+  }
+  bool vote(bool ok)
+  {
+    if (n_ <= 1)
+      return ok;
+    std::unique_lock<std::mutex> lk(m_);
+    const uint64_t gen = gen_;
+    if (count_ == 0)
+      all_ok_ = true;
+    all_ok_ = all_ok_ && ok;
+    if (++count_ == n_)
+    {
+      result_[gen & 1] = all_ok_;
+      count_ = 0;
+      ++gen_;
+      cv_.notify_all();
+      return result_[gen & 1];
+    }
+    cv_.wait(lk, [&] { return gen_ != gen; });
+    return result_[gen & 1];
+  }
+
+private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int n_ = 1, count_ = 0;
+  uint64_t gen_ = 0;
+  bool all_ok_ = true, result_[2] = { true, true };
+};
 }  // namespace
 
 struct mcl3dl_hip_group
@@ -146,6 +185,8 @@ struct mcl3dl_hip_group
   int direct_single = 1;  // 1 = a group of one device calls its context directly; 0 = it takes the sharded path too
   bool devices_distinct = true;
   WorkerPool pool;
+  VoteBarrier vote;
+  int inject_failure_rank = -1;  // test hook (option "inject_failure_rank"): that rank fails ahead of the collective, once
   OrderedScan scan;  // ordered once per update, pushed to every device
   // RCCL (created on first use by a group of more than one device)
   RcclApi rccl;

@@ -81,14 +81,21 @@ struct LikPlan
   float* strict_terms = nullptr;
 };
 
+// does an update over ns scan points replay the likelihood terms in the reference's float order?
+bool lik_strict(const mcl3dl_hip_ctx* ctx, int ns)
+{
+  return ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min);
+}
+
 int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
 {
   const int np = static_cast<int>(n_p);
+  const bool strict = lik_strict(ctx, ns);
   // tiled from lik_tiled_min points up (default 1024), and already from three quarters of that when there are enough particles
   // to fill the GPU with (tile, group) pairs (4096 x 1000: 30.6 us tiled against 34.9 us; 64 x 1000 and 4096 x 512: no gain)
   pl->tiled = (ctx->lik_tiled && np >= 4 &&
                (ns >= ctx->lik_tiled_min || (np >= 256 && 4 * static_cast<long long>(ns) >= 3ll * ctx->lik_tiled_min))) ||
-              ctx->strict_order;
+              strict;
   // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
   // work-group slots something to do (few particles x a long scan would otherwise leave most of the GPU idle)
   int group_size = ctx->lik_group;
@@ -127,7 +134,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
       return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
     TRY(ensure(ctx, ctx->lik_partial_sum, sizeof(double) * static_cast<size_t>(pl->n_tiles) * n_p));
     TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(pl->n_tiles) * n_p));
-    if (ctx->strict_order)
+    if (strict)
     {
       // rows of G floats per particle group
       TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));

@@ -7,8 +7,10 @@
 //                         (expectation / max / covariance, resampling)
 //   map_compiler.h        device-side compiler of the candidate-voxel index (whole map, or the bricks a map update touches)
 //   grid_kernels.h        the cell-sorted exact-NN grid and the DDA occupancy / voxel index, built on the device
-//   cloud_kernels.h       scan / map preparation: PointCloud2 decode, VoxelGrid, clip + compaction, sampling gather, scan
-//                         ordering, matched / unmatched output
+//   cloud_kernels.h       scan / map preparation: PointCloud2 decode, VoxelGrid, clip + compaction, sampling gather,
+//                         matched / unmatched output (each with the min / max or the count the next step needs fused in)
+//   sort_kernels.h        stable radix sort of the cloud path: keys made in the first pass, points written by the last
+//   cloud_keys.h          the sort keys (VoxelGrid leaf index, Morton key, range key)
 //
 // These are gather / traversal kernels (bound by L2/HBM reads and the texture-addresser, not by MFMA):
 // there is no dense contraction anywhere on this path, so no matrix-core code.
@@ -18,4 +20,5 @@
 #include "beam_kernels.h"
 #include "pf_kernels.h"
 #include "cloud_kernels.h"
+#include "sort_kernels.h"
 #include "grid_kernels.h"

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>  // radix_sort_pairs for whole-map arrays only (host_cloud.h:radix_sort)
 
 #include "kernels.h"
 #include "mcl3dl_hip.h"

@@ -30,6 +30,9 @@ def run_bench(*extra):
                               cwd=ROOT, env=env)
         if proc.returncode == 0 or "--force-dist" not in extra:
             break
+        # an intermittent communicator bring-up is information: say so where the test log shows it
+        print("bench.py %s failed (rc %d) on attempt %d; retrying once. stderr tail:\n%s"
+              % (" ".join(extra), proc.returncode, attempt + 1, proc.stderr[-1500:]), file=sys.stderr)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     return json.loads(lines[-1])  # must be the last line
@@ -48,13 +51,26 @@ def test_single_gpu_line():
         assert k in r, k
     # the fractions come from committed PMC passes of the same workload (profiles/); C1 has none, then they are null —
     # but whatever is reported is a fraction of a real resource: <= 1, and the headline repeats the binding one
-    assert r["bound"] in ("hbm", "l2", "l1_access", "valu_issue")
+    assert r["bound"] in ("hbm", "l2", "valu_issue")   # resources with a documented peak only
     for name, e in r["resources"].items():
         assert 0.0 < e["frac"] <= 1.0, (name, e)
-        assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-9
+        assert e["peak_kind"] in ("documented", "measured")
+        if name not in ("l1_access", "l2_requests", "valu_issue", "valu_issue_priced"):   # (those clamp at 1)
+            assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-9
     if r["frac"] is not None:
-        assert r["frac"] == r["resources"][r["bound"]]["frac"] == max(e["frac"] for e in r["resources"].values())
+        documented = [e["frac"] for e in r["resources"].values() if e["peak_kind"] == "documented"]
+        assert r["frac"] == r["resources"][r["bound"]]["frac"] == max(documented)
+        assert set(r["frac_vs_measured_peaks"]) == {k for k, e in r["resources"].items() if e["peak_kind"] == "measured"}
+    assert r["hbm_target"]["target"] == 0.40 and r["hbm_target"]["status"].startswith("not applicable")
     assert r["algorithmic_bytes_per_launch"] > 0 and d["update_8d"]["value"] > 1e7
+    # the two fixed names of the headline: device-resident (= value, the bench contract) and SURVEY.md 8d's region
+    assert d["value_device_resident"] == d["value"] and 0 < d["value_8d"] == d["update_8d"]["value"] <= d["value"]
+    # the rows either side of the path stay far ahead of the reference's CPU code (round 2 shipped a line where a Python
+    # garbage-collector pause inside the timed loop read as a 16x regression)
+    sp = d["scan_preparation"]
+    assert sp["ms"] < sp["cpu_reference_ms"] / 5, sp
+    assert sp["ms_max"] < sp["cpu_reference_ms"], sp
+    assert d["match_split"]["ms"] < 1.0, d["match_split"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

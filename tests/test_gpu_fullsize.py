@@ -98,7 +98,7 @@ def test_strict_order_slice_is_bit_identical(engine, c3, oracle_kind):
         engine.set_option("strict_order", 1)
         lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
     finally:
-        engine.set_option("strict_order", 0)
+        engine.set_option("strict_order", 2)
     o = pyoracle.Oracle(oracle_kind)
     o.set_map(sc.map_xyz, sc.map_label, dist_weight=(1.0, 1.0, 1.0))
     o.set_likelihood_params(pyoracle.LikelihoodParams())

@@ -179,6 +179,6 @@ def test_random_configuration(engine, oracle_kind, seed):
             assert got["match_ratio_min"] == want["match_ratio_min"]
             assert got["match_ratio_max"] == want["match_ratio_max"]
     finally:
-        engine.set_option("strict_order", 0)
+        engine.set_option("strict_order", 2)
         engine.set_likelihood_params()
         engine.set_beam_params()

@@ -128,6 +128,48 @@ def test_fewer_particles_than_devices_and_dead_filter(scene, engine):
         g.close()
 
 
+@pytest.mark.parametrize("bad_rank", [0, 1, 2])
+def test_a_rank_that_fails_ahead_of_the_collective_does_not_strand_the_others(scene, single, bad_rank):
+    """The update's collective is entered by every rank or by none (host_group.h:VoteBarrier): a rank that fails after its
+    kernels are enqueued makes the call return ITS error — promptly, the other ranks stand down instead of waiting inside an
+    all-reduce that cannot complete — weights untouched, and the next update on the same group is correct."""
+    sc = scene
+    w0, extra, want = single
+    g = make_group([0, 0, 0], sc, collective="host")
+    try:
+        g.set_option("inject_failure_rank", bad_rank)
+        w_in = w0.copy()
+        with pytest.raises(capi.EngineError, match=r"rank %d\): injected failure" % bad_rank):
+            g.measure_update(sc.poses, w_in, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+        np.testing.assert_array_equal(w_in, w0)
+        got = g.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+        for k in ("lik", "quality", "beam"):
+            np.testing.assert_array_equal(got[k], want[k])
+        np.testing.assert_allclose(got["weights"], want["weights"], rtol=2e-7)
+        assert g.collective_stats()["host"] == 1   # the abandoned update combined nothing
+    finally:
+        g.close()
+
+
+def test_injected_failure_on_the_rccl_path_rebuilds_the_communicator(scene, single):
+    """One rank, RCCL all-reduce (the only RCCL shape one GPU allows): the failed update destroys the communicator, the next
+    one brings it up again and is correct."""
+    sc = scene
+    w0, extra, want = single
+    g = make_group([0], sc)
+    try:
+        g.set_option("direct_single", 0)
+        g.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+        g.set_option("inject_failure_rank", 0)
+        with pytest.raises(capi.EngineError, match="injected failure"):
+            g.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+        got = g.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+        np.testing.assert_array_equal(got["weights"], want["weights"])
+        assert g.collective_stats() == dict(rccl=2, host=0)
+    finally:
+        g.close()
+
+
 def test_rccl_refuses_repeated_devices_with_a_clear_error(scene):
     g = make_group([0, 0], scene)  # collective left at RCCL
     try:

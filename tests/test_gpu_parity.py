@@ -306,7 +306,7 @@ def test_cooperative_record_fetch_is_bit_identical(engine, shape, n_p, parts):
         engine.set_option("lik_coop", d_coop)
         engine.set_option("lik_group", 0)
         engine.set_option("lik_tiled", 1)
-        engine.set_option("strict_order", 0)
+        engine.set_option("strict_order", 2)
         engine.set_option("cand_record_parts", 0)
     for (dw, strict, coop), r in res.items():
         if coop == 1:
@@ -419,7 +419,7 @@ def test_strict_order_is_bit_identical_to_the_reference(engine, oracle_kind, dis
         got = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
                                     extra=extra)
     finally:
-        engine.set_option("strict_order", 0)
+        engine.set_option("strict_order", 2)
     o = make_oracle(oracle_kind, sc, dist_weight, beam_kw=kw)
     want = o.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
                             odom_err=None, odom_sigma=float(sigma))

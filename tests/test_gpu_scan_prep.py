@@ -209,7 +209,7 @@ def test_scans_ordered_on_the_device_equal_scans_ordered_on_the_host(engine):
                 out[(strict, where)] = engine.measure_batch(sc.poses, lik, beam, blab, sc.origins)
     finally:
         engine.set_option("scan_order_device", d)
-        engine.set_option("strict_order", 0)
+        engine.set_option("strict_order", 2)
     for strict in (0, 1):
         for a, b in zip(out[(strict, 0)], out[(strict, 1)]):
             np.testing.assert_array_equal(a, b)

@@ -1,0 +1,69 @@
+"""The device radix sort of the cloud path (mcl_3dl_amd/csrc/sort_kernels.h) on its own: stable, ascending, every size class
+— one launch of one work-group (<= 2048 pairs), one launch per pass over n / 1024 or n / 4096 work-groups (<= 524 288),
+rocprim beyond — against numpy's
+stable argsort. The sort stands where pcl::VoxelGrid calls std::sort (src/mcl_3dl.cpp:363-367) and where
+mcl3dl_hip_upload_scan orders the scans; its users are compared with the reference in test_gpu_scan_prep.py / test_gpu_map_path.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check(engine, keys, vals, end_bit):
+    mask = np.uint32((1 << end_bit) - 1 if end_bit < 32 else 0xFFFFFFFF)
+    order = np.argsort(keys & mask, kind="stable")
+    ok, ov = engine.sort_pairs(keys, vals, end_bit=end_bit)
+    v_in = np.arange(len(keys), dtype=np.uint32) if vals is None else vals
+    np.testing.assert_array_equal(ok, keys[order])
+    np.testing.assert_array_equal(ov, v_in[order])
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 2048])
+@pytest.mark.parametrize("end_bit", [8, 22, 30, 32])
+def test_one_launch_sizes(engine, n, end_bit):
+    rng = np.random.default_rng(n * 37 + end_bit)
+    keys = rng.integers(0, 2**32 - 1, n, dtype=np.uint64, endpoint=True).astype(np.uint32)   # bits above end_bit: ignored
+    check(engine, keys, None, end_bit)
+    check(engine, keys, rng.integers(0, 2**32 - 1, n, dtype=np.uint64).astype(np.uint32), end_bit)
+
+
+@pytest.mark.parametrize("n", [2049, 4096, 16384, 16385, 65535, 65536, 65537, 100000, 131072 + 17, 524288])
+@pytest.mark.parametrize("end_bit", [9, 24, 32])
+def test_one_launch_per_pass_sizes(engine, n, end_bit):
+    rng = np.random.default_rng(n + end_bit)
+    keys = rng.integers(0, 2**32 - 1, n, dtype=np.uint64, endpoint=True).astype(np.uint32)
+    check(engine, keys, None, end_bit)
+
+
+def test_library_sort_above_the_work_group_forms(engine):
+    rng = np.random.default_rng(5)
+    n = 524288 + 4097
+    keys = rng.integers(0, 2**27, n, dtype=np.uint64).astype(np.uint32)
+    check(engine, keys, None, 27)
+
+
+@pytest.mark.parametrize("n", [777, 2048, 16384, 70000])
+def test_stability_with_few_distinct_keys(engine, n):
+    """Ties everywhere: equal keys must keep their input order (the VoxelGrid sums a leaf's points in that order,
+    the scan ordering is defined as a stable sort)."""
+    rng = np.random.default_rng(n)
+    for distinct in (1, 2, 5, 300):
+        keys = (rng.integers(0, distinct, n) * 0x01010101).astype(np.uint32)
+        check(engine, keys, None, 32)
+
+
+@pytest.mark.parametrize("n", [1500, 5000, 16384, 80000])
+def test_sorted_reversed_and_extreme_keys(engine, n):
+    asc = np.arange(n, dtype=np.uint32) * np.uint32(3)
+    check(engine, asc, None, 32)
+    check(engine, asc[::-1].copy(), None, 32)
+    ext = np.where(np.arange(n) % 3 == 0, 0xFFFFFFFF, np.where(np.arange(n) % 3 == 1, 0, 0x80000000)).astype(np.uint32)
+    check(engine, ext, None, 32)
+
+
+def test_only_bits_below_end_bit_order_the_pairs(engine):
+    """end_bit = 30 (the Morton sort): two keys that differ only in bits 30-31 are a tie and keep their input order."""
+    rng = np.random.default_rng(11)
+    low = rng.integers(0, 2**30, 9000, dtype=np.uint64).astype(np.uint32)
+    keys = low | (rng.integers(0, 4, 9000).astype(np.uint32) << np.uint32(30))
+    check(engine, keys, None, 30)
