@@ -270,7 +270,20 @@ int mcl3dl_hip_scan_begin(mcl3dl_hip_ctx* ctx, const float* xyz /*n*3*/, const u
 /* The same from the wire format (mcl_3dl::fromROSMsg, include/mcl_3dl/point_conversion.h:64-92): little-endian
  * sensor_msgs/PointCloud2 data with FLOAT32 x / y / z at the given byte offsets and an optional UINT32 "label" field
  * (off_label < 0: none). label_override = 0 stamps every point with accumulated-cloud index 0 (what accumCloud does for
- * the first / only cloud), 0xffffffff keeps the message's labels. */
+ * the first / only cloud), 0xffffffff keeps the message's labels.
+ * LAYOUT REQUIRED by every *_pointcloud2 entry point: `data` is n_points * point_step bytes, i.e. rows without padding
+ * (row_step == width * point_step), is_bigendian == false, and x / y / z (label) of datatype FLOAT32 (UINT32). The
+ * reference's pcl::fromROSMsg also takes padded rows and big-endian data; a caller holding such a message checks it with
+ * mcl3dl_hip_pointcloud2_layout_ok() below and repacks it (or passes plain arrays) when that returns 0 — the entry points
+ * cannot see width / row_step / endianness and would decode shifted points without an error. */
+static inline int mcl3dl_hip_pointcloud2_layout_ok(uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                                                   int is_bigendian, int datatype_x, int datatype_y, int datatype_z,
+                                                   int datatype_label /* -1: no label field */)
+{
+  /* sensor_msgs/PointField: FLOAT32 = 7, UINT32 = 6 */
+  return !is_bigendian && (height <= 1 || row_step == width * point_step) && datatype_x == 7 && datatype_y == 7 &&
+         datatype_z == 7 && (datatype_label < 0 || datatype_label == 6);
+}
 int mcl3dl_hip_scan_begin_pointcloud2(mcl3dl_hip_ctx* ctx, const uint8_t* data, size_t n_points, uint32_t point_step,
                                       int off_x, int off_y, int off_z, int off_label, uint32_t label_override,
                                       const float* leaf3, const float* clip_lik4, const float* clip_beam4, size_t* n_full,

@@ -50,6 +50,8 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
 {
   if (!ctx || !name)
     return -1;
+  // any option may change which kernels an update enqueues: a captured update graph (use_graph) is re-captured after every
+  // call, whichever option it names (options are set once per deployment, captures cost microseconds)
   ++ctx->generation;
   const std::string key(name);
   if (key == "lik_index")

@@ -198,6 +198,19 @@ int build_dda_grid_host(mcl3dl_hip_ctx* ctx)
   return 0;
 }
 
+// two events that are destroyed on every return path of the builders below
+struct EventPairRaii
+{
+  hipEvent_t a = nullptr, b = nullptr;
+  ~EventPairRaii()
+  {
+    if (a)
+      (void)hipEventDestroy(a);
+    if (b)
+      (void)hipEventDestroy(b);
+  }
+};
+
 // ---- map compiler: candidate-voxel index (device side in map_compiler.h) ------------------------------------------
 int device_exclusive_scan(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n)  // in place
 {
@@ -436,9 +449,10 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
 {
   const unsigned long long rec_bytes = 16ull * cap;  // per voxel
   const size_t n = ctx->map_xyz.size() / 3;
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
+  EventPairRaii evs;
+  HIP_TRY(hipEventCreate(&evs.a));
+  HIP_TRY(hipEventCreate(&evs.b));
+  const hipEvent_t ev0 = evs.a, ev1 = evs.b;
   HIP_TRY(hipEventRecord(ev0, ctx->stream));
   // the rescaled points (PointRepresentation::vectorize; w = map index) and their bounds, on the device from the device copy
   // of the map; they stay there: a map update (update_cand_grid) re-compiles single bricks from them
@@ -507,8 +521,6 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     TRY(sync_stream(ctx));
     float ms2 = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms2, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     RecGrid& g = ctx->rg;
     g.brick_table = table;
     g.rec = ctx->cand_rec.as<float4>();
@@ -561,8 +573,6 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   TRY(sync_stream(ctx));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
   CandGrid& g = ctx->cg;
   g.brick_table = table;
   g.vox_start = ctx->cand_start.as<uint32_t>();
@@ -606,10 +616,27 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     // 0.36 r has (0.5 / 0.36)^3 times as many of them). Measured on the jittered C2 map: 0.42 ms (0.5 r, 64 B) -> 0.364
     // (0.36 r, 64 B) -> 0.338 (0.36 r, 128 B); on a lattice the wide record costs 20 %, so it is never the default there.
     const double first_ms = ctx->cand_stats[3];
-    const double est_bytes = 128.0 * 512.0 * ctx->cand_stats[0] * 2.68;
+    const double est_bricks = ctx->cand_stats[0] * 2.68;
+    const double est_bytes = 128.0 * 512.0 * est_bricks;
     const uint32_t cap = forced ? forced : (est_bytes < 16.0e9 ? 8u : 4u);
-    TRY(build_cand_grid_at(ctx, 0.36, cap));
-    ctx->cand_stats[3] += first_ms;
+    // the finer index is an optimisation of a valid one: only attempt it where it fits (brick limit of the dense table,
+    // memory), and if it fails all the same, put the r / 2 index back — a map the coarser default handles must keep working
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const double need = (cap == 8 ? 128.0 : 64.0) * 512.0 * est_bricks * 1.5;
+    if (est_bricks < 0.9 * static_cast<double>(1u << 22) && need < 0.8 * static_cast<double>(free_b))
+    {
+      if (build_cand_grid_at(ctx, 0.36, cap) == 0)
+        ctx->cand_stats[3] += first_ms;
+      else
+      {
+        const std::string why = ctx->err;
+        ctx->cand_dirty = true;  // its buffers may have been re-allocated under the first index
+        TRY(build_cand_grid_at(ctx, 0.5, forced ? forced : 4u));
+        ctx->cand_stats[3] += first_ms;
+        ctx->graph_note = "finer candidate index not built (" + why + "): voxel edge r / 2 kept";
+      }
+    }
   }
   return 0;
 }
@@ -673,9 +700,10 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
         return 0;
       }
   }
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
+  EventPairRaii evs;
+  HIP_TRY(hipEventCreate(&evs.a));
+  HIP_TRY(hipEventCreate(&evs.b));
+  const hipEvent_t ev0 = evs.a, ev1 = evs.b;
   HIP_TRY(hipEventRecord(ev0, ctx->stream));
   // 1. dirty bricks: within reach of a removed or an added point
   TempBuf d_dirty, d_old, d_newflag, d_dirtyrank, d_sub_table, d_sub_main, d_sub_bxyz, d_relflag, d_rel, d_subrec;
@@ -720,8 +748,6 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
     if (stats5)
       stats5[5] = 6;
     ctx->cand_n_points = n_total;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     return 0;
   }
   if (static_cast<unsigned long long>(n_bricks_old) + n_new > (1u << 22) ||
@@ -730,8 +756,6 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
     if (stats5)
       stats5[5] = 5;
     ctx->cand_dirty = true;  // too many bricks, or too many orphaned overflow records: start over
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     return 0;
   }
   const uint32_t n_bricks = n_bricks_old + n_new;
@@ -786,8 +810,6 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   TRY(sync_stream(ctx));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
   ctx->cand_n_bricks = n_bricks;
   ctx->cand_n_ovf = ovf_base + co.n_ovf;
   ctx->cand_ovf_leaked += static_cast<uint32_t>(orphaned);  // reclaimed by the next full rebuild

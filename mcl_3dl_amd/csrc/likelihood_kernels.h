@@ -499,21 +499,15 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
   return fmaxf(dist, 0.0f) * prm.match_weight;
 }
 
-// MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
-// MODE 1: candidate-voxel index
+// One particle's likelihood-field score by one work-group of BLOCK threads: lanes stride the (Morton-ordered) scan, fp64
+// per-lane accumulators, wavefront __shfl reduction, then across the work-group's wavefronts through LDS in wavefront order.
+// Thread 0 returns the sum of the float terms (fp64), the match count and (STATS) the candidates tested; shared by
+// likelihood_kernel and the one-launch update (update_kernels.h), which therefore produce the same bits.
 template <int BLOCK, int MODE, bool STATS>
-__global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
-                                                           const float4* __restrict__ scan, int n_s, LikGrid g,
-                                                           CandGrid cg, RecGrid rg, LikParams prm,
-                                                           float* __restrict__ out_lik,
-                                                           float* __restrict__ out_ratio,
-                                                           double* __restrict__ out_tested, int coop)
+__device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, const float4* __restrict__ scan, int n_s,
+                                             const LikGrid& g, const CandGrid& cg, const RecGrid& rg, const LikParams& prm,
+                                             int coop, double& sum_out, unsigned& num_out, unsigned& tested_out)
 {
-  const int p = blockIdx.x;
-  const float* ps = pose7 + 7 * static_cast<size_t>(p);
-  const Vec3f pos = { ps[0], ps[1], ps[2] };
-  const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
-
   double acc = 0.0;   // sum of float terms, each exactly representable: fp64 sum is exact to ~1e-16
   unsigned num = 0;   // matched points
   unsigned tested = 0;
@@ -589,6 +583,31 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
       if (STATS)
         tt += s_tested[w];
     }
+    sum_out = a;
+    num_out = n;
+    tested_out = tt;
+  }
+}
+
+// MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
+// MODE 1: candidate-voxel index
+template <int BLOCK, int MODE, bool STATS>
+__global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
+                                                           const float4* __restrict__ scan, int n_s, LikGrid g,
+                                                           CandGrid cg, RecGrid rg, LikParams prm,
+                                                           float* __restrict__ out_lik,
+                                                           float* __restrict__ out_ratio,
+                                                           double* __restrict__ out_tested, int coop)
+{
+  const int p = blockIdx.x;
+  const float* ps = pose7 + 7 * static_cast<size_t>(p);
+  const Vec3f pos = { ps[0], ps[1], ps[2] };
+  const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
+  double a = 0.0;
+  unsigned n = 0, tt = 0;
+  lik_particle<BLOCK, MODE, STATS>(pos, rot, scan, n_s, g, cg, rg, prm, coop, a, n, tt);
+  if (threadIdx.x == 0)
+  {
     if (out_lik)
       out_lik[p] = static_cast<float>(a);
     if (out_ratio)
@@ -896,6 +915,9 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
 // they fetch the next ROWS rows and store them TRANSPOSED ([particle][row]) into the other LDS buffer; wavefront 0 is the
 // adder: lanes 0..G-1, one per particle, read four consecutive rows per ds_read_b128 and run the dependent add chain.
 // The chain (n_s adds per particle) is the critical path; the loads hide behind it.
+// Measured and NOT kept (round 3, C5: 512 groups x 65 536 terms, 0.68 ms): 32 KB chunks with two chunks in flight in
+// registers and two work-groups per CU (0.91 ms: slower), and two adjacent groups per work-group so that 512 groups run in
+// one round of 256 work-groups (0.68 ms: no change) — the kernel reads its 2.1 GB of terms at ~3.1 TB/s either way.
 template <int G>
 __global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
                                                              float* __restrict__ out_lik)

@@ -13,6 +13,7 @@ HEADER = os.path.join(ROOT, "include", "mcl3dl_hip.h")
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"static inline[^{;]*\{.*?\n\}", "", text, flags=re.S)   # header-only helpers are not exports
     return sorted(set(re.findall(r"\b(mcl3dl_hip_[a-z0-9_]+)\s*\(", text)))
 
 

@@ -106,3 +106,28 @@ def test_strict_order_slice_is_bit_identical(engine, c3, oracle_kind):
     wl, wq = o.likelihood_measure(sc.poses[idx], sc.scan_lik)
     np.testing.assert_array_equal(lik[idx], wl)
     np.testing.assert_array_equal(ratio[idx], wq)
+
+
+@pytest.mark.parametrize("n_p,n_s,group", [(8200, 2100, 16), (4203, 1100, 8), (1100, 1300, 4)])
+def test_strict_order_with_more_particle_groups_than_cus(engine, oracle_kind, n_p, n_s, group):
+    """More than 256 particle groups of every size the tiled kernel uses (ragged last group, odd group count): particles of
+    the first groups, of the last ones and a sample in between equal the reference bit for bit."""
+    sc = make_config("C2", n_p=n_p, n_s=n_s)
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=902, dist_weight=(1.0, 1.0, 1.0))
+    engine.set_likelihood_params()
+    try:
+        engine.set_option("strict_order", 1)
+        engine.set_option("lik_group", group)
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    finally:
+        engine.set_option("strict_order", 2)
+        engine.set_option("lik_group", 0)
+    assert (n_p + group - 1) // group > 256
+    o = pyoracle.Oracle(oracle_kind)
+    o.set_map(sc.map_xyz, sc.map_label, dist_weight=(1.0, 1.0, 1.0))
+    o.set_likelihood_params(pyoracle.LikelihoodParams())
+    idx = np.unique(np.concatenate([np.arange(0, n_p, n_p // 40), np.arange(group - 3, group + 5),
+                                    np.arange(n_p - 2 * group - 1, n_p)]))
+    wl, wq = o.likelihood_measure(sc.poses[idx], sc.scan_lik)
+    np.testing.assert_array_equal(lik[idx], wl)
+    np.testing.assert_array_equal(ratio[idx], wq)
