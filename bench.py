@@ -121,6 +121,10 @@ def parse():
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--also-other-scaling", action="store_true",
                     help="time the other scaling mode too even with one rank (exercises the N > 1 reporting path)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="drive all --gpus N devices from THIS one process through the device-group C ABI "
+                         "(mcl3dl_hip_group_*: worker thread per GPU, RCCL all-reduce inside the library) — the route the "
+                         "reference's single process would use — instead of one process per GPU; prints the same JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys (post-update reductions, resampling, fused update, route A, jitter check)")
@@ -373,10 +377,60 @@ def route_a(sc, dist_weight, n_b, reps):
         if proc.returncode != 0 or not m:
             return {"error": (proc.stdout + proc.stderr)[-300:]}
         ms = float(m.group(1))
-        return {"ms_per_update": ms, "evals_per_s": len(sc.poses) * len(sc.scan_lik) / (ms * 1e-3), "reps": reps,
+        bd = re.search(r"route_a_breakdown_us pose_gather_upload (\S+) cloud_pack (\S+) measure_batch (\S+) "
+                       r"batched_calls_per_update (\S+)", proc.stdout)
+        breakdown = None
+        if bd:
+            inside = float(bd.group(1)) + float(bd.group(2)) + float(bd.group(3))
+            breakdown = {"pose_gather_upload_us": float(bd.group(1)), "cloud_pack_us": float(bd.group(2)),
+                         "measure_batch_us": float(bd.group(3)), "batched_calls_per_update": float(bd.group(4)),
+                         "reference_pf_loop_us": ms * 1e3 - inside,
+                         "note": "measure_batch = scan upload + ordering + kernels of BOTH models + D2H + the one "
+                                 "synchronisation; reference_pf_loop = the rest: pf.h's particle copy, 2 N virtual calls, "
+                                 "weight product, normalisation and entropy on the CPU"}
+        return {"ms_per_update": ms, "breakdown": breakdown, "evals_per_s": len(sc.poses) * len(sc.scan_lik) / (ms * 1e-3), "reps": reps,
                 "what": "pf_->measure(measure_func) through the drop-in LidarMeasurementModel{Likelihood,Beam} classes "
-                        "(per-particle virtuals, host pose/cloud packing, one measure_batch per model, poses uploaded "
-                        "once per update, weights normalised by the reference's pf.h on the CPU)"}
+                        "(per-particle virtuals, host pose/cloud packing, ONE measure_batch for both models — launched by the "
+                        "first measure() of the update —, poses uploaded once per update, weights normalised by the "
+                        "reference's pf.h on the CPU)"}
+
+
+def in_process_group_run(workload, n_cfg, extra_cfg, dist_weight, devices, steps, warmup, collective=None):
+    """One process, len(devices) GPUs: the update through mcl3dl_hip_group_measure_update (host arrays in, host arrays out;
+    particles sharded inside the library, scan ordered once and pushed to every device, one all-reduce per update). Weak
+    scaling like the main line: n_cfg particles per GPU. Returns a dict for the bench line."""
+    from mcl_3dl_amd import capi
+    from mcl_3dl_amd.synthetic import make_config
+    n_dev = len(devices)
+    parts = [make_config(workload, n_p=n_cfg, seed=12345 + r, **extra_cfg) for r in range(n_dev)]
+    sc = parts[0]
+    poses = np.ascontiguousarray(np.concatenate([p.poses for p in parts], 0))
+    n_total = len(poses)
+    w0 = np.full(n_total, 1.0 / n_total, np.float32)
+    n_b = len(sc.scan_beam)
+    g = capi.Group(devices, collective=collective)
+    try:
+        if n_dev == 1:
+            g.set_option("direct_single", 0)   # one GPU: still the sharded path with the (one-rank) RCCL all-reduce
+        g.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=dist_weight)
+        g.set_likelihood_params()
+        g.set_beam_params(num_points=max(n_b, 1), dda_grid_size=0.2)
+        args_u = (poses, w0, sc.scan_lik, sc.scan_beam if n_b else None, sc.scan_beam_label if n_b else None, sc.origins)
+        for _ in range(max(warmup, 3)):
+            g.measure_update(*args_u)
+        with no_gc():
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.measure_update(*args_u)
+            el = time.perf_counter() - t0
+        st = g.collective_stats()
+        return {"n_gpus": n_dev, "particles_total": n_total, "ms_per_update": el / steps * 1e3,
+                "value": float(n_total) * len(sc.scan_lik) * steps / el, "unit": "particle·point evals/s",
+                "collective": "rccl" if st["rccl"] else "host", "collectives": st,
+                "what": "mcl3dl_hip_group_measure_update from ONE process over %d GPU(s): host arrays in / out (PCIe included, "
+                        "like update_8d), particles sharded inside the library, one all-reduce per update" % n_dev}
+    finally:
+        g.close()
 
 
 def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
@@ -472,6 +526,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.in_process and world == 1:
+        # ---- one process, N GPUs (no torch.distributed): the line's headline is the in-process group's update
+        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--in-process --gpus %d needs that many visible GPUs" % args.gpus)
+        cfg = CONFIGS[args.workload]
+        n_cfg = args.particles or cfg["n_p"]
+        extra_cfg = dict(n_s=args.scan_points) if args.scan_points else {}
+        if args.beam_points:
+            extra_cfg["n_b"] = args.beam_points
+        r = in_process_group_run(args.workload, n_cfg, extra_cfg, (1.0, 1.0, args.dist_weight_z), list(range(args.gpus)),
+                                 args.steps, args.warmup)
+        print(json.dumps({
+            "metric": "particle·point evals/sec; filter-update Hz @ 4096 particles × 16k-pt scan", "value": r["value"],
+            "unit": r["unit"], "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_update"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d particles/GPU, in-process device group" % (args.workload, n_cfg),
+                       "parallelism": "ONE process, particles sharded x%d inside libmcl3dl_hip (worker thread per GPU), "
+                                      "map+scan replicated, 1 %s all-reduce/update" % (args.gpus, r["collective"]),
+                       "particles_total": r["particles_total"]},
+            "value_definition": "host arrays in, host arrays out (PCIe included): the in-process route has no device-resident "
+                                "form — the reference's process keeps its particles on the host",
+            "roofline": None, "cpu_baseline": None, "in_process_group": r}), flush=True)
+        return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -492,6 +570,9 @@ def main():
         dist.all_reduce(warm)
         torch.cuda.synchronize(dev)
         _flush_c_stdio()
+        # a CPU-side group: the other ranks wait THERE (no kernel spinning on their GPUs) while rank 0 drives every GPU
+        # from its one process (in_process_group, below)
+        cpu_pg = dist.new_group(backend="gloo") if world > 1 else None
 
     cfg = CONFIGS[args.workload]
     n_cfg = args.particles or cfg["n_p"]
@@ -924,6 +1005,33 @@ def main():
                 _src, _dup, n_dup2 = eng.resample_plan(0, 0.37 * pstep, want_plan=False)
                 eng.resample_apply_device(d_st_in, ident[:n_dup2], d_st_out)
             out["resample"]["ms_device_resident"] = (time.perf_counter() - t6) / 5 * 1e3
+            # where the float prefix recurrence of pf.h:193-197 should run: on the host (D2H of the
+            # weights + one core + H2D of the prefixes) or on the device (one lane, nothing crosses PCIe), at this size and at
+            # the global-localisation size
+            pre = {}
+            for n_big in (n_p, 262144):
+                wb = torch.rand(n_big, device=dev) + 0.1
+                wb /= wb.sum()
+                torch.cuda.synchronize(dev)
+                for where, tag in ((0, "host"), (1, "device")):
+                    eng.set_option("resample_prefix_device", where)
+                    eng.resample_begin_device(wb, n_big)
+                    with no_gc():
+                        tp = time.perf_counter()
+                        for _ in range(5):
+                            eng.resample_begin_device(wb, n_big)
+                        pre["%s_ms_%d" % (tag, n_big)] = (time.perf_counter() - tp) / 5 * 1e3
+                eng.set_option("resample_prefix_device", 0)
+                pstep = eng.resample_begin_device(wb, n_big)
+                with no_gc():
+                    tp = time.perf_counter()
+                    for _ in range(5):
+                        eng.resample_plan(0, 0.37 * pstep, want_plan=False)
+                    pre["plan_ms_%d" % n_big] = (time.perf_counter() - tp) / 5 * 1e3
+            pre["what"] = ("mcl3dl_hip_resample_begin_device with the prefix recurrence on the host (default) / on the device "
+                           "(option resample_prefix_device), and mcl3dl_hip_resample_plan (lower_bound searches, duplicate "
+                           "ranks) at the same sizes")
+            out["resample"]["prefix"] = pre
         if world == 1 and not args.no_extras:
             # the fused device-resident call (measure + pf::measure in one C call) replaying its captured hipGraph, next
             # to the same call enqueuing kernel by kernel: what launch overhead is worth at this size. Not `value`.
@@ -1018,7 +1126,17 @@ def main():
                                  "index": eng.index_stats()}
         if world == 1 and not args.no_extras:
             out.update(cloud_path_extras(eng, sc, n_s, n_b, with_cpu=not args.no_cpu_baseline))
+        # the in-process route (the one the reference's single process would use) on the same GPUs, next to the
+        # one-process-per-GPU figures above: a group of 1 with the RCCL call in the loop on one GPU, of all N on a node
+        if not args.no_extras or world > 1:
+            try:
+                out["in_process_group"] = in_process_group_run(args.workload, n_cfg, extra_cfg, dist_weight,
+                                                               list(range(world)), args.steps, args.warmup)
+            except Exception as e:  # never lose the line over the side measurement
+                out["in_process_group"] = {"error": str(e)[-300:]}
         line = json.dumps(out)
+    if use_dist and world > 1:
+        dist.barrier(group=cpu_pg)   # ranks 1.. waited on the CPU while rank 0 ran the in-process group
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -51,6 +51,8 @@ int mcl3dl_hip_abi_version(void);
 
 /* ---- lifecycle ------------------------------------------------------------------------------------ */
 /* Replaces: construction of the two LiDAR models + kd-tree in MCL3dlNode (src/mcl_3dl.cpp:1315-1329). */
+/* Number of HIP devices this process sees (0 when there is none: the library has no CPU path). */
+int mcl3dl_hip_device_count(void);
 int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id);
 void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx);
 const char* mcl3dl_hip_last_error(const mcl3dl_hip_ctx* ctx);
@@ -136,6 +138,11 @@ int mcl3dl_hip_radius_search(mcl3dl_hip_ctx* ctx, const float* query_xyz /*n*3*/
  * max_out. Introspection only: not on the per-update path. */
 int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* end3, float* out_xyz /*max_out*3*/,
                          int max_out, int* n_visited, int* collided, int* hit_index);
+
+/* Introspection: the beam kernel sets a ray up without its nine double-precision divisions (reciprocal multiplies with an
+ * exactness check, the division as the rare fallback: beam_kernels.h). This runs both forms on n pseudo-random inputs —
+ * half of them constructed on the undecidable cases — and returns how many results differ (must be 0). */
+int mcl3dl_hip_selftest_divisions(mcl3dl_hip_ctx* ctx, size_t n, uint64_t seed, uint64_t* mismatches);
 
 /* ---- device entry points (asynchronous on the context's stream) ------------------------------------- */
 /* Upload (and spatially order) the two filtered scans `pc_locals` of one update (src/mcl_3dl.cpp:377-383). */

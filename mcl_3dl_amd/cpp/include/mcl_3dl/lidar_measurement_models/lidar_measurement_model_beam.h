@@ -41,6 +41,7 @@ public:
 
 private:
   void pushParameters() const;
+  static void pushBeamParameters(const Params& p);
 
   std::shared_ptr<Params> params_;
   float search_range_ = 0.f;

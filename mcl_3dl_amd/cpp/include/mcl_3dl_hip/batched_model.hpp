@@ -19,6 +19,16 @@ namespace hip
 class BatchedLidarModel : public LidarMeasurementModelBase
 {
 public:
+  ~BatchedLidarModel()  // (the reference base class declares no virtual destructor; the node holds models in shared_ptrs made from the derived type)
+  {
+    if (registered_)
+    {
+      Engine& e = Engine::shared();
+      e.push_params[kind_] = nullptr;
+      e.filtered[kind_] = Engine::FilteredScan();
+    }
+  }
+
   // reference: both models' setGlobalLocalizationStatus (src/lidar_measurement_model_likelihood.cpp:63-77,
   // src/lidar_measurement_model_beam.cpp:82-96)
   void setGlobalLocalizationStatus(const size_t num_particles, const size_t current_num_particles) override
@@ -26,11 +36,25 @@ public:
     points_now_ = pointsPerParticle(points_default_, points_global_, num_particles, current_num_particles);
   }
 
-  // reference: both models' filter() (likelihood.cpp:79-103, beam.cpp:98-122): clip, then sampler.sample(num_points_)
+  // reference: both models' filter() (likelihood.cpp:79-103, beam.cpp:98-122): clip, then sampler.sample(num_points_).
+  // The sampled cloud is also packed for the engine right here, so that the first measure() of the coming pf::measure —
+  // whichever model it reaches — can evaluate BOTH models' scans in one launch (engine.hpp, "one launch for BOTH models").
   Cloud::Ptr filter(const Cloud::ConstPtr& pc, const PointCloudRandomSampler<PointType>& sampler) const override
   {
     const Cloud::Ptr clipped = clipCloud(*pc, clip_.near_sq, clip_.far_sq, clip_.z_min, clip_.z_max);
-    return sampler.sample(clipped, points_now_);
+    const Cloud::Ptr sampled = sampler.sample(clipped, points_now_);
+    if (registered_ && sampled)
+    {
+      Engine& e = Engine::shared();
+      Engine::FilteredScan& f = e.filtered[kind_];
+      const double t0 = Engine::nowUs();
+      packCloud(*sampled, f.xyz, &f.label);
+      e.profile.pack_us += Engine::nowUs() - t0;
+      f.cloud = sampled.get();
+      f.from_filter = true;
+      last_filtered_ = sampled;  // alive until the next filter(): its address cannot be handed to another cloud meanwhile
+    }
+    return sampled;
   }
 
 protected:
@@ -38,28 +62,27 @@ protected:
   {
     float near_sq = 0.f, far_sq = 0.f, z_min = 0.f, z_max = 0.f;
   };
-  void configureFilter(const std::size_t points_default, const std::size_t points_global, const float clip_near,
-                       const float clip_far, const float clip_z_min, const float clip_z_max)
+  // `push` sends this model's parameters to the engine (called ahead of every launch that evaluates this model's scan)
+  void configureFilter(const Engine::Kind kind, std::function<void()> push, const std::size_t points_default,
+                       const std::size_t points_global, const float clip_near, const float clip_far, const float clip_z_min,
+                       const float clip_z_max)
   {
+    kind_ = kind;
     points_default_ = points_now_ = points_default;
     points_global_ = points_global;
     clip_.near_sq = clip_near * clip_near;
     clip_.far_sq = clip_far * clip_far;
     clip_.z_min = clip_z_min;
     clip_.z_max = clip_z_max;
-    results_ = Results();
+    Engine& e = Engine::shared();
+    e.push_params[kind_] = std::move(push);
+    e.results[kind_] = Engine::Results();
+    registered_ = true;
   }
 
-  // Results of the last batched launch, valid for one (pf::measure epoch, scan cloud) pair.
-  struct Results
-  {
-    std::uint64_t epoch = 0;
-    const void* cloud = nullptr;
-    std::vector<float> likelihood, quality;
-  };
-  // Where `s` sits in the published batch and whether this model's cached results answer it. The cache is tested FIRST:
-  // inside pf::measure this runs once per particle, so nothing here may cost more than a few comparisons (packing the
-  // poses of the whole batch happens in refreshPoses(), once per epoch).
+  // Where `s` sits in the published batch and whether the cached results of this model answer it. The cache is tested
+  // FIRST: inside pf::measure this runs once per particle, so nothing here may cost more than a few comparisons (packing
+  // the poses of the whole batch happens in refreshPoses(), once per epoch).
   struct Slot
   {
     std::size_t index = 0, count = 1;
@@ -78,16 +101,13 @@ protected:
       slot.count = b.count;
       slot.epoch = b.epoch;
     }
-    slot.refresh = !(slot.epoch != 0 && results_.epoch == slot.epoch && results_.cloud == cloud &&
-                     results_.likelihood.size() == slot.count);
-    if (slot.refresh)
-    {
-      results_.epoch = slot.epoch;
-      results_.cloud = cloud;
-      results_.likelihood.assign(slot.count, 0.f);
-      results_.quality.assign(slot.count, 0.f);
-    }
+    const Engine::Results& r = results();
+    slot.refresh = !(slot.epoch != 0 && r.epoch == slot.epoch && r.cloud == cloud && r.likelihood.size() == slot.count);
     return slot;
+  }
+  Engine::Results& results() const
+  {
+    return Engine::shared().results[kind_];
   }
 
   // Makes sure the engine holds the poses of this epoch: packed and uploaded by whichever model asks first (the node
@@ -105,9 +125,76 @@ protected:
     e.pose_count = poses.size() / 7;
   }
 
+  // The batched launch behind a measure() call that the cache could not answer: this model's scan `pc` and — inside
+  // pf::measure, when the other model's filter() result is waiting — the other model's scan too. Fills results() (and the
+  // other model's results).
+  void evaluate(ChunkedKdtree<PointType>& kdtree, const Cloud& pc, const std::vector<Vec3>& origins, const State6DOF& s,
+                const Slot& slot) const
+  {
+    Engine& e = Engine::shared();
+    syncMap(e, kdtree);
+    e.push_params[kind_]();
+    const double t0 = Engine::nowUs();
+    refreshPoses(e, s, slot);
+    const double t1 = Engine::nowUs();
+    e.profile.poses_us += t1 - t0;
+    Engine::FilteredScan& mine = e.filtered[kind_];
+    if (mine.cloud != &pc || mine.xyz.size() != 3 * pc.points.size())
+    {
+      packCloud(pc, mine.xyz, &mine.label);  // a cloud filter() has not seen (tests, the debug-marker path)
+      mine.cloud = &pc;
+      mine.from_filter = false;
+      e.profile.pack_us += Engine::nowUs() - t1;
+    }
+    const Engine::Kind other_kind = kind_ == Engine::LIKELIHOOD ? Engine::BEAM : Engine::LIKELIHOOD;
+    Engine::FilteredScan& oth = e.filtered[other_kind];
+    const bool both = slot.epoch != 0 && oth.from_filter && oth.cloud && !oth.xyz.empty() && e.push_params[other_kind] &&
+                      e.results[other_kind].epoch != slot.epoch;
+    if (both)
+      e.push_params[other_kind]();
+    const Engine::FilteredScan* lik = kind_ == Engine::LIKELIHOOD ? &mine : (both ? &oth : nullptr);
+    const Engine::FilteredScan* beam = kind_ == Engine::BEAM ? &mine : (both ? &oth : nullptr);
+    for (int k = 0; k < 2; ++k)
+    {
+      if (k != kind_ && !both)
+        continue;
+      Engine::Results& r = e.results[k];
+      r.epoch = slot.epoch;
+      r.cloud = e.filtered[k].cloud;
+      r.likelihood.assign(slot.count, 0.f);
+      r.quality.assign(slot.count, k == Engine::BEAM ? 1.f : 0.f);  // beam.cpp:154: quality 1
+    }
+    std::vector<float>& org = e.origin_scratch;
+    org.resize(3 * origins.size());
+    for (std::size_t i = 0; i < origins.size(); ++i)
+    {
+      org[3 * i + 0] = origins[i].x_;
+      org[3 * i + 1] = origins[i].y_;
+      org[3 * i + 2] = origins[i].z_;
+    }
+    const double t2 = Engine::nowUs();
+    ++e.profile.launches;
+    struct Stop
+    {
+      Engine& e;
+      double t;
+      ~Stop()
+      {
+        e.profile.batch_us += Engine::nowUs() - t;
+      }
+    } stop{ e, t2 };
+    e.check(mcl3dl_hip_group_measure_batch(
+        e.group(), nullptr, slot.count, lik ? lik->xyz.data() : nullptr, lik ? lik->xyz.size() / 3 : 0,
+        beam ? beam->xyz.data() : nullptr, beam ? beam->label.data() : nullptr, beam ? beam->xyz.size() / 3 : 0,
+        beam ? org.data() : nullptr, beam ? origins.size() : 0, lik ? e.results[Engine::LIKELIHOOD].likelihood.data() : nullptr,
+        lik ? e.results[Engine::LIKELIHOOD].quality.data() : nullptr, beam ? e.results[Engine::BEAM].likelihood.data() : nullptr));
+  }
+
   std::size_t points_default_ = 0, points_global_ = 0, points_now_ = 0;
   Clip clip_;
-  mutable Results results_;
+  Engine::Kind kind_ = Engine::LIKELIHOOD;
+  bool registered_ = false;
+  mutable Cloud::ConstPtr last_filtered_;
 };
 }  // namespace hip
 }  // namespace mcl_3dl

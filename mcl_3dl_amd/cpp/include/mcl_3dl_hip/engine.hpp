@@ -9,8 +9,10 @@
 #ifndef MCL_3DL_HIP_ENGINE_HPP
 #define MCL_3DL_HIP_ENGINE_HPP
 
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -76,10 +78,48 @@ public:
   std::size_t map_size = 0;
   float dist_weight[3] = { 1.f, 1.f, 1.f };
   bool has_weight = false;
+  float map_min[3] = { 0.f, 0.f, 0.f };  // pcl::getMinMax3D's minimum of the map (RaycastUsingDDA::min_p_): voxel centres
   // ---- poses of the current pf::measure epoch, uploaded once and shared by both models ---------------------------
   std::uint64_t pose_epoch = 0;
   std::size_t pose_count = 0;
   std::vector<float> pose_scratch;
+  // ---- one launch for BOTH models. The node filters every model's cloud first (src/mcl_3dl.cpp:378-383) and only then
+  // runs pf_->measure, whose lambda asks "beam", then "likelihood", for every particle (:409). filter() therefore leaves
+  // its result here, packed; the first measure() of an epoch — whichever model it reaches — evaluates both scans in one
+  // batched call and both models answer their remaining calls from `results`.
+  enum Kind
+  {
+    LIKELIHOOD = 0,
+    BEAM = 1
+  };
+  struct FilteredScan
+  {
+    const void* cloud = nullptr;  // identity of the cloud filter() returned (the model keeps it alive: no address reuse)
+    bool from_filter = false;     // false: packed by measure() itself for a cloud filter() has not seen
+    std::vector<float> xyz;
+    std::vector<std::uint32_t> label;
+  };
+  struct Results
+  {
+    std::uint64_t epoch = 0;
+    const void* cloud = nullptr;
+    std::vector<float> likelihood, quality;
+  };
+  FilteredScan filtered[2];
+  Results results[2];
+  std::function<void()> push_params[2];  // each model's parameters -> the engine (set by the model, cleared when it dies)
+  std::vector<float> origin_scratch;
+  // ---- where an update through the per-particle virtuals spends its host time (microseconds, accumulated; read and reset
+  // by whoever wants a breakdown: tests/cpp/adapter_demo.cpp prints it next to the total)
+  struct Profile
+  {
+    double pack_us = 0, poses_us = 0, batch_us = 0;
+    std::uint64_t launches = 0;
+  } profile;
+  static double nowUs()
+  {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
 
 private:
   mcl3dl_hip_group* group_ = nullptr;

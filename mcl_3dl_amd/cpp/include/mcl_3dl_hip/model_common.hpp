@@ -55,13 +55,17 @@ inline void syncMap(Engine& e, const ChunkedKdtree<PointType>& kdtree)
     return;
   std::vector<float> xyz(3 * map->points.size());
   std::vector<std::uint32_t> label(map->points.size());
+  float mn[3] = { map->points[0].x, map->points[0].y, map->points[0].z };
   for (std::size_t i = 0; i < map->points.size(); ++i)
   {
     xyz[3 * i + 0] = map->points[i].x;
     xyz[3 * i + 1] = map->points[i].y;
     xyz[3 * i + 2] = map->points[i].z;
     label[i] = map->points[i].label;
+    for (int a = 0; a < 3; ++a)
+      mn[a] = xyz[3 * i + a] < mn[a] ? xyz[3 * i + a] : mn[a];  // pcl::getMinMax3D (raycast_using_dda.h:175)
   }
+  std::memcpy(e.map_min, mn, sizeof(mn));
   e.check(mcl3dl_hip_group_set_map(e.group(), xyz.data(), label.data(), label.size(), map->header.stamp,
                                    has_w ? w : nullptr));
   e.map_cloud = map.get();

@@ -23,18 +23,24 @@ void LidarMeasurementModelBeam::refreshParameters()
                              "beam/use_raycast_using_dda to true");
   search_range_ = std::max({ params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_ }) * 4;
   sin_total_ref_ = sinf(params_->ang_total_ref_);
-  configureFilter(params_->num_points_default_, params_->num_points_global_, params_->clip_near_, params_->clip_far_,
-                  params_->clip_z_min_, params_->clip_z_max_);
+  const std::shared_ptr<Params> params = params_;
+  configureFilter(hip::Engine::BEAM, [params] { pushBeamParameters(*params); }, params_->num_points_default_,
+                  params_->num_points_global_, params_->clip_near_, params_->clip_far_, params_->clip_z_min_,
+                  params_->clip_z_max_);
+}
+
+void LidarMeasurementModelBeam::pushBeamParameters(const Params& p)
+{
+  hip::Engine& e = hip::Engine::shared();
+  e.check(mcl3dl_hip_group_set_beam_params(e.group(), p.map_grid_x_, p.map_grid_y_, p.map_grid_z_, p.dda_grid_size_,
+                                           p.ray_angle_half_, p.hit_range_, p.beam_likelihood_min_,
+                                           static_cast<std::uint32_t>(p.num_points_default_), p.ang_total_ref_,
+                                           p.filter_label_max_, p.add_penalty_short_only_mode_ ? 1 : 0));
 }
 
 void LidarMeasurementModelBeam::pushParameters() const
 {
-  hip::Engine& e = hip::Engine::shared();
-  e.check(mcl3dl_hip_group_set_beam_params(e.group(), params_->map_grid_x_, params_->map_grid_y_, params_->map_grid_z_,
-                                     params_->dda_grid_size_, params_->ray_angle_half_, params_->hit_range_,
-                                     params_->beam_likelihood_min_,
-                                     static_cast<std::uint32_t>(params_->num_points_default_), params_->ang_total_ref_,
-                                     params_->filter_label_max_, params_->add_penalty_short_only_mode_ ? 1 : 0));
+  pushBeamParameters(*params_);
 }
 
 // reference: src/lidar_measurement_model_beam.cpp:124-155
@@ -47,30 +53,15 @@ LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointTyp
 
   const Slot slot = lookup(s, pc.get());
   if (slot.refresh)
-  {
-    hip::Engine& e = hip::Engine::shared();
-    hip::syncMap(e, *kdtree);
-    pushParameters();
-    refreshPoses(e, s, slot);
-    std::vector<float> scan, org(3 * origins.size());
-    std::vector<std::uint32_t> label;
-    hip::packCloud(*pc, scan, &label);
-    for (std::size_t i = 0; i < origins.size(); ++i)
-    {
-      org[3 * i + 0] = origins[i].x_;
-      org[3 * i + 1] = origins[i].y_;
-      org[3 * i + 2] = origins[i].z_;
-    }
-    e.check(mcl3dl_hip_group_measure_batch(e.group(), nullptr, slot.count, nullptr, 0, scan.data(), label.data(), pc->size(),
-                                     org.data(), origins.size(), nullptr, nullptr, results_.likelihood.data()));
-  }
-  const std::size_t index = slot.index;
-  return LidarMeasurementResult(results_.likelihood[index], 1.0);
+    evaluate(*kdtree, *pc, origins, s, slot);
+  return LidarMeasurementResult(results().likelihood[slot.index], 1.0);
 }
 
 // reference: src/lidar_measurement_model_beam.cpp:157-192. result.point_ points into the kd-tree's input cloud like the
-// reference's; result.pos_ is the collided map point's position (the reference reports the voxel centre — only the
-// debug-marker path reads it, and only through point_).
+// reference's; result.pos_ is the centre of the voxel the ray collided in (raycast_using_dda.h:150-156 returns
+// fromIndex(current_index_), :219-223 — the node draws the collision marker there, src/mcl_3dl.cpp:489-491). The collided
+// voxel is the collided point's voxel: toIndex (:205-217: float difference, double division, truncation), then the
+// centre in double, rounded to float by Vec3's constructor.
 LidarMeasurementModelBeam::BeamStatus LidarMeasurementModelBeam::getBeamStatus(ChunkedKdtree<PointType>::Ptr& kdtree,
                                                                                const Vec3& lidar_pos,
                                                                                const Vec3& scan_pos,
@@ -86,7 +77,15 @@ LidarMeasurementModelBeam::BeamStatus LidarMeasurementModelBeam::getBeamStatus(C
   if (hit >= 0)
   {
     const PointType* p = &kdtree->getInputCloud()->points[hit];
-    result = CastResult(Vec3(p->x, p->y, p->z), true, 1.0, p);
+    const double grid = params_->dda_grid_size_;
+    const float c[3] = { p->x, p->y, p->z };
+    float centre[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      const int index = static_cast<int>((c[a] - e.map_min[a]) / grid);
+      centre[a] = static_cast<float>((index + 0.5) * grid + e.map_min[a]);
+    }
+    result = CastResult(Vec3(centre[0], centre[1], centre[2]), true, 1.0, p);
   }
   return static_cast<BeamStatus>(status);
 }

@@ -13,7 +13,15 @@ LidarMeasurementModelLikelihood::LidarMeasurementModelLikelihood(const std::shar
 // are pushed to the engine at every batched launch, so a parameter object mutated by dynamic_reconfigure is always seen.
 void LidarMeasurementModelLikelihood::refreshParameters()
 {
-  configureFilter(params_->num_points_default_, params_->num_points_global_, params_->clip_near_, params_->clip_far_,
+  const std::shared_ptr<Params> params = params_;
+  configureFilter(hip::Engine::LIKELIHOOD,
+                  [params]
+                  {
+                    hip::Engine& e = hip::Engine::shared();
+                    e.check(mcl3dl_hip_group_set_likelihood_params(e.group(), params->match_dist_min_,
+                                                                   params->match_dist_flat_, params->match_weight_));
+                  },
+                  params_->num_points_default_, params_->num_points_global_, params_->clip_near_, params_->clip_far_,
                   params_->clip_z_min_, params_->clip_z_max_);
 }
 
@@ -21,7 +29,7 @@ void LidarMeasurementModelLikelihood::refreshParameters()
 // pf::measure the first call evaluates every particle of the batch in one launch.
 LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<PointType>::Ptr& kdtree,
                                                                 const hip::Cloud::ConstPtr& pc,
-                                                                const std::vector<Vec3>& /*origins*/,
+                                                                const std::vector<Vec3>& origins,
                                                                 const State6DOF& s) const
 {
   if (!pc || pc->size() == 0)
@@ -29,18 +37,8 @@ LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<Po
 
   const Slot slot = lookup(s, pc.get());
   if (slot.refresh)
-  {
-    hip::Engine& e = hip::Engine::shared();
-    hip::syncMap(e, *kdtree);
-    e.check(mcl3dl_hip_group_set_likelihood_params(e.group(), params_->match_dist_min_, params_->match_dist_flat_,
-                                             params_->match_weight_));
-    refreshPoses(e, s, slot);
-    std::vector<float> scan;
-    hip::packCloud(*pc, scan, nullptr);
-    e.check(mcl3dl_hip_group_measure_batch(e.group(), nullptr, slot.count, scan.data(), pc->size(), nullptr, nullptr, 0, nullptr,
-                                     0, results_.likelihood.data(), results_.quality.data(), nullptr));
-  }
-  const std::size_t index = slot.index;
-  return LidarMeasurementResult(results_.likelihood[index], results_.quality[index]);
+    evaluate(*kdtree, *pc, origins, s, slot);
+  const hip::Engine::Results& r = results();
+  return LidarMeasurementResult(r.likelihood[slot.index], r.quality[slot.index]);
 }
 }  // namespace mcl_3dl

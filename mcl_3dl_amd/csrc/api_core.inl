@@ -5,6 +5,17 @@ int mcl3dl_hip_abi_version(void)
   return MCL3DL_HIP_ABI_VERSION;
 }
 
+int mcl3dl_hip_device_count(void)
+{
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count > 0 ? count : 0;
+}
+
 int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
 {
   if (!out)
@@ -452,6 +463,9 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
 int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                    float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
 {
+  const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4);
+  if (one != 0)
+    return one < 0 ? one : 0;
   TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
   TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4));
   return 0;
@@ -709,10 +723,8 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
   TRY(h2d(ctx, ctx->weightb.p, weight_inout, fb));
   if (extra)
     TRY(h2d(ctx, ctx->extra.p, extra, fb));
-  TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, ctx->lik.as<float>(), ctx->ratio.as<float>(),
-                     ctx->beam.as<float>(), false, nullptr));
-  TRY(pf_measure_single(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
-                        extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n_p, ctx->stats4.as<float>()));
+  TRY(enqueue_update(ctx, ctx->pose.as<float>(), n_p, ctx->weightb.as<float>(), extra ? ctx->extra.as<float>() : nullptr,
+                     ctx->lik.as<float>(), ctx->ratio.as<float>(), ctx->beam.as<float>(), ctx->stats4.as<float>()));
   float st[4];
   TRY(d2h(ctx, weight_inout, ctx->weightb.p, fb));
   TRY(d2h(ctx, st, ctx->stats4.p, sizeof(st)));

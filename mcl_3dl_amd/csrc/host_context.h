@@ -54,6 +54,7 @@ struct mcl3dl_hip_ctx
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap_models = 1;
+  long long overlap_min_rays = 262144;  // launches below this many rays keep both models on one stream
   std::string err;
 
   // host copy of the map (kept to rebuild the device structures when parameters change)
@@ -99,6 +100,13 @@ struct mcl3dl_hip_ctx
   int strict_order = 2;
   int strict_auto_min = 32768;
   DevBuf scan_perm, strict_terms;
+  // the whole update as one launch (update_kernels.h) up to update_small_max particles when the per-particle likelihood
+  // kernel would run anyway: same bits, two to four launches fewer. Measured (profiles/r03*_update_small.txt): ahead of the
+  // separate kernels up to ~500 particles (64 x 96 + 3: 26.9 -> 22.4 us, 64 x 1000: 13.7 -> 10.3), behind from 1024 on —
+  // every work-group's arrival is an atomic the memory side serialises, and there are as many as particles
+  int update_small = 1;
+  int update_small_max = 512;
+  DevBuf us_tickets;
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
@@ -132,6 +140,7 @@ struct mcl3dl_hip_ctx
   // per-(particle, origin) ray constants (beam_origin_kernel) for launches of at least beam_prepare_min_rays rays
   DevBuf beam_origin;
   int beam_prepare = 1;
+  int beam_fast_div = 1;  // the ray set-up's nine double divisions as reciprocal multiplies + exactness check (same bits)
   long long beam_prepare_min_rays = 32768;
   size_t n_s = 0, n_b = 0, n_o = 0;
   bool has_scan = false;
@@ -169,6 +178,7 @@ struct mcl3dl_hip_ctx
   DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out, rs_d_order, rs_d_flag,
       rs_d_ws, rs_d_dup8;
   bool rs_sorted = false;  // std::sort had ties to order: rs_order is not the identity
+  int resample_prefix_device = 0;  // 1 = resample_begin_device runs the float prefix recurrence on the device (one lane)
 
   // mcl3dl_hip_update_device: the launch sequence of one device-resident update, captured into a hipGraph the second
   // time the same arguments arrive and replayed afterwards (small updates are launch-bound: 8-10 launches of a few

@@ -100,6 +100,8 @@ int build_lik_grid_host(mcl3dl_hip_ctx* ctx)
 void dda_ray_constants(const mcl3dl_hip_ctx* ctx, DdaGrid& g)
 {
   g.grid = static_cast<double>(ctx->dda_grid_size);
+  g.inv_grid = 1.0 / g.grid;
+  g.fast_div = ctx->beam_fast_div;
   g.ray_angle_half = static_cast<double>(ctx->ray_angle_half);
   // RaycastUsingDDA ctor, raycast_using_dda.h:59: map_grid_size_y appears twice (reference quirk, kept)
   const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];

@@ -70,6 +70,27 @@ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z)
   return spread(x) | (spread(y) << 1) | (spread(z) << 2);
 }
 
+// table[k] = score_beam after k penalised rays: `score_beam *= beam_likelihood_` repeated k times (beam.cpp:148), float. Built
+// for at least 1024 counts so that alternating scan sizes (the adapter launches the two models separately) do not rebuild it
+// every update.
+int ensure_pow_table(mcl3dl_hip_ctx* ctx)
+{
+  if (!(ctx->pow_table_dirty || ctx->n_b > ctx->pow_table_len))
+    return 0;
+  const size_t len = std::max<size_t>(ctx->n_b, 1024);
+  std::vector<float> table(len + 1);
+  table[0] = 1.0f;
+  for (size_t k = 1; k <= len; ++k)
+    table[k] = table[k - 1] * ctx->beam_likelihood;
+  TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
+  TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
+  TRY(sync_stream(ctx));
+  ctx->pow_table_dirty = false;
+  ctx->pow_table_len = len;
+  ++ctx->generation;
+  return 0;
+}
+
 // Which likelihood kernel an update of np particles x ns points runs, with every size check and every buffer the launch
 // needs done HERE — before launch_measure forks the beam kernels onto the second stream, so that no error path can
 // return with un-joined work in flight.
@@ -186,22 +207,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     }
     else
     {
-      if (ctx->pow_table_dirty || ctx->n_b > ctx->pow_table_len)
-      {
-        // score_beam *= beam_likelihood_ repeated k times (beam.cpp:148), float. Built for at least 1024 counts so that
-        // alternating scan sizes (the adapter launches the two models separately) do not rebuild it every update.
-        const size_t len = std::max<size_t>(ctx->n_b, 1024);
-        std::vector<float> table(len + 1);
-        table[0] = 1.0f;
-        for (size_t k = 1; k <= len; ++k)
-          table[k] = table[k - 1] * ctx->beam_likelihood;
-        TRY(ensure(ctx, ctx->pow_table, sizeof(float) * table.size()));
-        TRY(h2d(ctx, ctx->pow_table.p, table.data(), sizeof(float) * table.size()));
-        TRY(sync_stream(ctx));
-        ctx->pow_table_dirty = false;
-        ctx->pow_table_len = len;
-        ++ctx->generation;
-      }
+      TRY(ensure_pow_table(ctx));
       const BeamParams bp = beam_params(ctx);
       const long long n_rays = static_cast<long long>(n_p) * static_cast<long long>(ctx->n_b);
       const long long blocks = (n_rays + 255) / 256;
@@ -214,7 +220,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         TRY(ensure(ctx, ctx->beam_origin, sizeof(BeamOrigin) * n_p * ctx->n_o));
       if (stats)
         TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
-      const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0;
+      // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
+      // 52 us per update with them, 17 without), the overlap itself is worth ~5 % at C3 (2.1 M rays)
+      const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
       hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
       if (overlap)
       {
@@ -226,7 +234,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (!stats)
         TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep, bs));
       if (!beam_prepared)  // (beam_origin_kernel zeroes the counters itself)
-        HIP_TRY(hipMemsetAsync(ctx->penalty.p, 0, sizeof(unsigned) * n_p, bs));
+      {
+        // a kernel, not hipMemsetAsync: a memset node at the head of a single-stream captured update faulted on its third
+        // replay (ROCm 7.2; 700 particles x 3 rays, 128 x 48 — scripts/r03_dbg.py), the same zeroing as a kernel node does not
+        hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, bs, reinterpret_cast<float*>(ctx->penalty.p), 0.0f,
+                           static_cast<float*>(nullptr), 0.0f, np);
+      }
       if (stats)
       {
         HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(RayStats), bs));
@@ -448,6 +461,105 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     stats6[5] = static_cast<double>(n_p) * static_cast<double>(ctx->n_b);
   }
   return 0;
+}
+
+// The whole update — both models and pf::measure — as ONE launch (update_kernels.h) where the sizes are launch-bound:
+// returns 1 when it was enqueued, 0 when this update is not eligible (the caller then runs the separate kernels), < 0 on
+// error. Eligible: one GPU, per-particle likelihood kernel (not the tiled / small-scan forms), at most update_small_max
+// particles and 256 beam points, no float-order replay.
+int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
+                        float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
+{
+  if (!ctx->update_small || n_p == 0 || n_p > static_cast<size_t>(ctx->update_small_max) || ctx->n_b > 256 ||
+      ctx->strict_order == 1 || !ctx->has_scan || !d_lik || !d_ratio || !d_beam)
+    return 0;
+  const int ns = static_cast<int>(ctx->n_s);
+  LikPlan plan;
+  if (ns > 0)
+  {
+    // (decided without plan_lik's buffer allocations: the tiled form needs per-tile partials this path never touches)
+    const int np = static_cast<int>(n_p);
+    const bool tiled = (ctx->lik_tiled && np >= 4 &&
+                        (ns >= ctx->lik_tiled_min || (np >= 256 && 4ll * ns >= 3ll * ctx->lik_tiled_min))) ||
+                       lik_strict(ctx, ns);
+    const bool small = !tiled && ns <= 32 && np >= 256 && ctx->lik_small;
+    if (tiled || small)
+      return 0;
+  }
+  TRY(ensure_structures(ctx, ns > 0, ctx->n_b > 0));
+  if (ctx->n_b > 0)
+    TRY(ensure_pow_table(ctx));
+  const int nvb = static_cast<int>((n_p + PF_BLOCK - 1) / PF_BLOCK);
+  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * static_cast<size_t>(nvb)));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  const size_t n_tickets = static_cast<size_t>(nvb) * 37 + static_cast<size_t>(ticket_tree_size(nvb)) + 1;
+  if (ctx->us_tickets.cap < sizeof(unsigned) * n_tickets)
+  {
+    TRY(ensure(ctx, ctx->us_tickets, sizeof(unsigned) * n_tickets));
+    HIP_TRY(hipMemsetAsync(ctx->us_tickets.p, 0, ctx->us_tickets.cap, ctx->stream));  // the kernel leaves them zero
+  }
+  UpdateSmallArgs a{};
+  a.pose7 = d_pose;
+  a.n_p = static_cast<int>(n_p);
+  a.scan_lik = ctx->scan_lik.as<float4>();
+  a.n_s = ns;
+  a.g = ctx->lg;
+  a.cg = ctx->cg;
+  a.rg = ctx->rg;
+  a.prm = lik_params(ctx);
+  a.coop = (ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f) ? 1 : 0;
+  a.scan_beam = ctx->scan_beam.as<float4>();
+  a.n_b = static_cast<int>(ctx->n_b);
+  a.origins = ctx->origins.as<float4>();
+  a.dg = ctx->dg;
+  a.bp = beam_params(ctx);
+  a.pow_table = ctx->pow_table.as<float>();
+  a.w = d_weight;
+  a.extra = d_extra;
+  a.use_beam = 1;
+  a.out_lik = d_lik;
+  a.out_ratio = d_ratio;
+  a.out_beam = d_beam;
+  a.w_new = ctx->wnew.as<float>();
+  a.vb_partials = ctx->block_partials.as<double>();
+  a.tickets = ctx->us_tickets.as<unsigned>();
+  a.packed = ctx->partial4.as<double>();
+  a.stats4 = d_stats4;
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
+  const unsigned grid = static_cast<unsigned>(n_p);
+#define LAUNCH_US(BLOCK, MODE) hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a)
+  // the work-group size the separate likelihood kernel would get (launch_measure), so that the lanes add in the same order
+  const bool narrow = ns <= 128 && ctx->n_b <= 128;
+  if (ctx->lik_index == 2)
+  {
+    if (ns <= 128)
+      LAUNCH_US(64, 2);
+    else if (static_cast<int>(n_p) <= ctx->lik_wide_max_particles && ns > 512)
+      LAUNCH_US(1024, 2);
+    else
+      LAUNCH_US(256, 2);
+  }
+  else if (ctx->lik_index == 1)
+  {
+    if (ns <= 128)
+      LAUNCH_US(64, 1);
+    else
+      LAUNCH_US(256, 1);
+  }
+  else
+  {
+    if (ns <= 128)
+      LAUNCH_US(64, 0);
+    else
+      LAUNCH_US(256, 0);
+  }
+  (void)narrow;
+#undef LAUNCH_US
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 1;
 }
 
 int pf_blocks(size_t n)

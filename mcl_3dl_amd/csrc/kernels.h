@@ -5,6 +5,7 @@
 //   beam_kernels.h        beam model: one lane per ray, DDA walk through 4x4x4 occupancy bricks, point tests, penalty count
 //   pf_kernels.h          pf::measure (weights, deterministic fp64 reductions, normalisation, entropy) and the "next" rows
 //                         (expectation / max / covariance, resampling)
+//   update_kernels.h      likelihood + beam + pf::measure in ONE launch for the reference's operating range (launch-bound sizes)
 //   map_compiler.h        device-side compiler of the candidate-voxel index (whole map, or the bricks a map update touches)
 //   grid_kernels.h        the cell-sorted exact-NN grid and the DDA occupancy / voxel index, built on the device
 //   cloud_kernels.h       scan / map preparation: PointCloud2 decode, VoxelGrid, clip + compaction, sampling gather,
@@ -19,6 +20,7 @@
 #include "likelihood_kernels.h"
 #include "beam_kernels.h"
 #include "pf_kernels.h"
+#include "update_kernels.h"
 #include "cloud_kernels.h"
 #include "sort_kernels.h"
 #include "grid_kernels.h"

@@ -41,6 +41,8 @@ struct CompileParams
   double grow;    // V+ = V grown by this on every side
   double r2_hi;   // (r*(1+1e-5))^2
   double margin;  // domination margin m
+  int refine;        // crowded voxels: domination tested per sub-box of a refine^3 subdivision (1 = whole voxel only)
+  int refine_above;  // ... when more than this many candidates survive the whole-voxel test
   int reach;      // voxels to visit around a point's own voxel
   int nvx, nvy, nvz, nbx, nby, nbz;
   int n_points;
@@ -279,6 +281,54 @@ __global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, 
     }
     if (dominated)
       prelim[i] |= 0x80000000u;
+  }
+  // pass 1b (crowded voxels only: more survivors than a record holds inline): the pairwise test asks for ONE rival that beats
+  // p everywhere in V+; a point whose Voronoi cell misses the voxel is often beaten by DIFFERENT rivals in different parts
+  // of it. So cut V+ into refine^3 sub-boxes and drop p when every sub-box has its own dominator — still a proof that p is
+  // nowhere the nearest neighbour (any point, dominated or not, is a valid rival), just a sharper one.
+  if (c.refine > 1 && k_all <= PRUNE_K)
+  {
+    uint32_t alive = 0;
+    for (uint32_t i = s; i < e; ++i)
+      alive += (prelim[i] & 0x80000000u) ? 0u : 1u;
+    if (alive > static_cast<uint32_t>(c.refine_above))
+    {
+      const int R = c.refine;
+      const double h = half / R;
+      uint32_t drop_mask = 0u;  // decided against the UNrefined survivor set, applied afterwards (k_all <= 32)
+      for (uint32_t i = s; i < e; ++i)
+      {
+        if (prelim[i] & 0x80000000u)
+          continue;
+        const float4 p = pts[prelim[i] & 0x7fffffffu];
+        const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
+        const double pp = px * px + py * py + pz * pz;
+        bool needed = false;
+        for (int cell = 0; cell < R * R * R && !needed; ++cell)
+        {
+          const double ox = -half + (2 * (cell % R) + 1) * h, oy = -half + (2 * ((cell / R) % R) + 1) * h,
+                       oz = -half + (2 * (cell / (R * R)) + 1) * h;
+          bool dominated_here = false;
+          for (uint32_t j = s; j < e && !dominated_here; ++j)
+          {
+            if (j == i)
+              continue;
+            const float4 q = pts[prelim[j] & 0x7fffffffu];
+            const double qx = q.x - ctr[0], qy = q.y - ctr[1], qz = q.z - ctr[2];
+            const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
+            const double gmin = pp - (qx * qx + qy * qy + qz * qz) + (ox * cx + oy * cy + oz * cz) -
+                                h * (fabs(cx) + fabs(cy) + fabs(cz));
+            dominated_here = gmin > c.margin;
+          }
+          needed = !dominated_here;
+        }
+        if (!needed)
+          drop_mask |= 1u << (i - s);
+      }
+      for (uint32_t i = s; i < e; ++i)
+        if (drop_mask & (1u << (i - s)))
+          prelim[i] |= 0x80000000u;
+    }
   }
   // pass 2: compact survivors to the front, ascending point id (selection sort; runs are short)
   uint32_t n = 0;

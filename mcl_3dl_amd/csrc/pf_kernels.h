@@ -471,6 +471,65 @@ __global__ __launch_bounds__(64) void pf_covariance_reduce_kernel(const double* 
 // stay on the host in mcl3dl_hip.hip; the device does the n_out independent std::lower_bound searches and the
 // gather of the 13-dof states with State6DOF::operator+ / normalize() for the duplicated ones.
 // ---------------------------------------------------------------------------------------------------------
+// accum += p.probability_ ; p.accum_probability_ = accum (pf.h:193-197 / 401-405) on the device: a float recurrence in
+// particle order, so ONE lane runs it; the work-group's 256 threads stage 4096 weights at a time in LDS (coalesced) and
+// write the 4096 prefixes back. out2[0] = the total, out2[1] = 1 if any prefix failed to grow (a weight of zero: the
+// reference's std::sort then decides the order inside the tie group, which only the host path reproduces).
+__global__ __launch_bounds__(256) void resample_prefix_kernel(const float* __restrict__ w, int n, float* __restrict__ keys,
+                                                              float* __restrict__ out2)
+{
+  __shared__ float buf[4096];
+  if (blockIdx.x != 0)
+    return;
+  float accum = 0.0f;
+  int ties = 0;
+  for (int base = 0; base < n; base += 4096)
+  {
+    const int m = min(4096, n - base);
+    for (int j = threadIdx.x; j < m; j += 256)
+      buf[j] = w[base + j];
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int i = 0;
+      for (; i + 16 <= m; i += 16)
+      {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          v[j] = buf[i + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+          const float prev = accum;
+          accum += v[j];
+          ties |= (base + i + j > 0 && !(prev < accum)) ? 1 : 0;
+          v[j] = accum;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          buf[i + j] = v[j];
+      }
+      for (; i < m; ++i)
+      {
+        const float prev = accum;
+        accum += buf[i];
+        ties |= (base + i > 0 && !(prev < accum)) ? 1 : 0;
+        buf[i] = accum;
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += 256)
+      keys[base + j] = buf[j];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    out2[0] = accum;
+    out2[1] = ties ? 1.0f : 0.0f;
+  }
+}
+
 __global__ void resample_lower_bound_kernel(const float* __restrict__ keys, int n, const float* __restrict__ pscan,
                                             float pstep, float initial_p, int n_out, uint32_t* __restrict__ it_out,
                                             uint32_t* __restrict__ last_valid)

@@ -1,0 +1,301 @@
+// update_kernels.h — the whole measurement update in ONE launch for the reference's own operating range (N_p <= a few
+// thousand particles, N_s <= 2048 likelihood points, N_b <= 256 beam points; parameters.h:68,98 default to 64 x 96 + 3):
+// there the update is launch-bound — three to five launches of ~4 us around ~10 us of work.
+//
+//   work-group p  = particle p: likelihood score (lik_particle — the code of likelihood_kernel), beam score (cast_ray —
+//                   the code of beam_kernel; penalty count -> power table -> clamp), results written to out_lik / _ratio / _beam
+//   256 particles = one "virtual block" of pf::measure's split form (pf_partial_kernel's 256-thread blocks): the LAST of
+//                   its work-groups to finish (an arrival ticket) computes that block's partial {sum w, sum w ln w, max
+//                   ratio, -min ratio} with the split form's association
+//   the LAST virtual block to finish runs pf_reduce_kernel's 64-lane reduction and pf_apply_kernel's normalisation
+//
+// Nobody waits for anybody: a ticket is an atomic counter, the work-group that draws the last number does the next stage.
+// Arrivals are counted through an 8-ary TREE of tickets: atomics on one address from many CUs are served one after the
+// other by the memory side (~0.25 us each, measured: 256 arrivals on one counter cost 60 us), eight per node cost 2 us a level.
+// Hand-offs between work-groups follow the guide's fence-free form for inter-workgroup visibility on gfx950: every payload
+// word is written with an agent-scope (sc1, write-through) store and read with an agent-scope (sc1, past the L1) load, the
+// stores are drained (s_waitcnt vmcnt(0)) before the ticket is drawn. (A release fence per work-group — buffer_wbl2, a
+// write-back of the XCD's L2 — was measured first: 4096 work-groups x 96 points went from 20 to 110 us.) Same arithmetic, same association as likelihood_kernel + beam_kernel (+ finalize) +
+// pf_partial / reduce / apply: bit-identical results (tests/test_gpu_update_small.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "beam_kernels.h"
+#include "likelihood_kernels.h"
+#include "pf_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace mcl3dl
+{
+struct UpdateSmallArgs
+{
+  const float* pose7;
+  int n_p;
+  // likelihood-field model
+  const float4* scan_lik;
+  int n_s;
+  LikGrid g;
+  CandGrid cg;
+  RecGrid rg;
+  LikParams prm;
+  int coop;
+  // beam model (n_b == 0: score 1)
+  const float4* scan_beam;
+  int n_b;
+  const float4* origins;
+  DdaGrid dg;
+  BeamParams bp;
+  const float* pow_table;
+  // pf::measure
+  float* w;            // in / out
+  const float* extra;  // may be null
+  int use_beam;        // 1: the weight product includes the beam score (pf_partial_kernel's `beam` pointer non-null)
+  float* out_lik;
+  float* out_ratio;
+  float* out_beam;
+  float* w_new;
+  double* vb_partials;  // [4 x number of virtual blocks]
+  unsigned* tickets;    // [37 per virtual block + ticket_tree_size(number of virtual blocks)], zero between launches
+  double* packed;       // [4]
+  float* stats4;
+};
+
+__device__ __forceinline__ void store_agent(float* p, float v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_agent(double* p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread 0 draws a ticket once every wavefront's stores are drained; every thread learns whether it was the last of `expected`
+__device__ __forceinline__ bool last_arrival(unsigned* ticket, unsigned expected)
+{
+  __shared__ int s_last;
+  // every wavefront drains its own (write-through) stores before the barrier — a barrier does not wait for memory
+  // operations in flight — so that what lane 0 releases below includes them
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // (also: a previous call's s_last has been read)
+  if (threadIdx.x == 0)
+  {
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = (t + 1u == expected) ? 1 : 0;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+constexpr int US_FAN = 8;
+// counters one tree over `width` leaves needs (levels of ceil(width / 8) nodes down to one)
+__host__ __device__ inline int ticket_tree_size(int width)
+{
+  int n = 0;
+  while (width > 1)
+  {
+    width = (width + US_FAN - 1) / US_FAN;
+    n += width;
+  }
+  return n;
+}
+
+// true for exactly one work-group among the `width` that call this with their index and the same tree: the one whose
+// arrival completes the root. A work-group leaves as soon as it is not the last arrival at a node.
+__device__ __forceinline__ bool last_of_tree(unsigned* tree, int idx, int width)
+{
+  while (width > 1)
+  {
+    const int node = idx / US_FAN, nodes = (width + US_FAN - 1) / US_FAN;
+    const int children = min(US_FAN, width - node * US_FAN);
+    if (!last_arrival(tree + node, static_cast<unsigned>(children)))
+      return false;
+    tree += nodes;
+    idx = node;
+    width = nodes;
+  }
+  return true;
+}
+
+template <int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
+{
+  constexpr int NW = BLOCK / 64;
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* ps = a.pose7 + 7 * static_cast<size_t>(p);
+  const Vec3f pos = { ps[0], ps[1], ps[2] };
+  const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
+  const Quat rot = qnormalized(raw);  // state_6dof.h:217
+  // ---- likelihood-field model (likelihood.cpp:105-139; empty scan -> (1, 0), :111-114)
+  float lik = 1.0f, ratio = 0.0f;
+  if (a.n_s > 0)
+  {
+    double sum = 0.0;
+    unsigned num = 0, unused = 0;
+    lik_particle<BLOCK, MODE, false>(pos, rot, a.scan_lik, a.n_s, a.g, a.cg, a.rg, a.prm, a.coop, sum, num, unused);
+    lik = static_cast<float>(sum);
+    ratio = static_cast<float>(num) / static_cast<float>(a.n_s);  // :136
+  }
+  // ---- beam model (beam.cpp:124-155): one lane per ray, the non-prepared form of beam_kernel
+  float beam = 1.0f;
+  if (a.n_b > 0)
+  {
+    __shared__ unsigned s_pen;
+    if (threadIdx.x == 0)
+      s_pen = 0u;
+    __syncthreads();
+    for (int base = 0; base < a.n_b; base += BLOCK)
+    {
+      const int i = base + static_cast<int>(threadIdx.x);
+      bool penalised = false;
+      if (i < a.n_b)
+      {
+        const float4 v = a.scan_beam[i];
+        const Vec3f end = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);  // beam.cpp:139 (transform)
+        const float4 og = a.origins[__float_as_uint(v.w)];
+        const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
+        int hit;
+        unsigned s0 = 0, s1 = 0, s2 = 0;
+        const int status = cast_ray<false>(a.dg, a.bp, begin, end, &hit, s0, s1, s2);
+        penalised = (status == 0) || (!a.bp.short_only && (status == 2));  // beam.cpp:146
+      }
+      const unsigned long long m = __ballot(penalised);
+      if (m != 0ull && lane == 0)
+        atomicAdd(&s_pen, static_cast<unsigned>(__popcll(m)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      float s = a.pow_table[s_pen];  // beam_likelihood_^k by k float multiplications (beam.cpp:148)
+      if (s < a.bp.beam_likelihood_min)
+        s = a.bp.beam_likelihood_min;  // :151-152
+      beam = s;
+    }
+  }
+  if (threadIdx.x == 0)
+  {
+    store_agent(a.out_lik + p, lik);
+    store_agent(a.out_ratio + p, ratio);
+    store_agent(a.out_beam + p, beam);
+  }
+  // ---- pf::measure (pf.h:252-279). Stage 1: the last work-group of each 256-particle virtual block.
+  const int nvb = (a.n_p + PF_BLOCK - 1) / PF_BLOCK;
+  const int vb = p / PF_BLOCK;
+  const int in_vb = min(PF_BLOCK, a.n_p - vb * PF_BLOCK);
+  constexpr int VB_TREE = 32 + 4 + 1;  // ticket_tree_size(256)
+  if (!last_of_tree(a.tickets + vb * VB_TREE, p - vb * PF_BLOCK, in_vb))
+    return;
+  __shared__ double sh[4][4];
+  for (int chunk = wave; chunk < 4; chunk += NW)  // pf_partial_kernel: wavefront `chunk` of the block, one element per lane
+  {
+    double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;  // match_ratio_max = 0, match_ratio_min = 1 (mcl_3dl.cpp:398-399)
+    const int i = vb * PF_BLOCK + chunk * 64 + lane;
+    if (i < a.n_p)
+    {
+      float l = 1.0f;
+      if (a.use_beam)
+        l *= load_agent(a.out_beam + i);
+      l *= load_agent(a.out_lik + i);
+      if (a.extra)
+        l = l * a.extra[i];
+      const float wn = a.w[i] * l;  // pf.h:258
+      store_agent(a.w_new + i, wn);
+      s += static_cast<double>(wn);
+      if (wn > 0.0f)
+        t += static_cast<double>(wn) * log(static_cast<double>(wn));
+      const double r = static_cast<double>(load_agent(a.out_ratio + i));
+      rmax = r > rmax ? r : rmax;
+      rneg = -r > rneg ? -r : rneg;
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+    rmax = wave_max(rmax);
+    rneg = wave_max(rneg);
+    if (lane == 0)
+    {
+      sh[0][chunk] = s;
+      sh[1][chunk] = t;
+      sh[2][chunk] = rmax;
+      sh[3][chunk] = rneg;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double x = 0, y = 0, c = sh[2][0], d = sh[3][0];
+    for (int k = 0; k < 4; ++k)
+    {
+      x += sh[0][k];
+      y += sh[1][k];
+      c = sh[2][k] > c ? sh[2][k] : c;
+      d = sh[3][k] > d ? sh[3][k] : d;
+    }
+    store_agent(a.vb_partials + 4 * vb + 0, x);
+    store_agent(a.vb_partials + 4 * vb + 1, y);
+    store_agent(a.vb_partials + 4 * vb + 2, c);
+    store_agent(a.vb_partials + 4 * vb + 3, d);
+  }
+  // ---- Stage 2: the last virtual block to finish
+  if (!last_of_tree(a.tickets + nvb * VB_TREE, vb, nvb))
+    return;
+  __shared__ double tot[4];
+  if (wave == 0)
+  {
+    // pf_reduce_kernel: 64 lanes stride the block partials, wavefront reduction
+    double x = 0, y = 0, c = 0.0, d = -1.0;
+    for (int k = lane; k < nvb; k += 64)
+    {
+      x += load_agent(a.vb_partials + 4 * k + 0);
+      y += load_agent(a.vb_partials + 4 * k + 1);
+      const double ck = load_agent(a.vb_partials + 4 * k + 2), dk = load_agent(a.vb_partials + 4 * k + 3);
+      c = ck > c ? ck : c;
+      d = dk > d ? dk : d;
+    }
+    x = wave_sum(x);
+    y = wave_sum(y);
+    c = wave_max(c);
+    d = wave_max(d);
+    if (lane == 0)
+    {
+      tot[0] = x;
+      tot[1] = y;
+      tot[2] = c;
+      tot[3] = d;
+      a.packed[0] = x;
+      a.packed[1] = y;
+      a.packed[2] = c;
+      a.packed[3] = d;
+    }
+  }
+  __syncthreads();
+  // pf_apply_kernel
+  const double S = tot[0];
+  const float sum_f = static_cast<float>(S);
+  const bool alive = sum_f > 0.0f;
+  if (alive)
+    for (int i = threadIdx.x; i < a.n_p; i += BLOCK)
+      a.w[i] = load_agent(a.w_new + i) / sum_f;
+  if (threadIdx.x == 0)
+  {
+    if (a.stats4)
+    {
+      a.stats4[0] = alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf("");
+      a.stats4[1] = static_cast<float>(-tot[3]);
+      a.stats4[2] = static_cast<float>(tot[2]);
+      a.stats4[3] = alive ? 0.0f : 1.0f;
+    }
+  }
+  for (int k = threadIdx.x; k < nvb * VB_TREE + ticket_tree_size(nvb); k += BLOCK)
+    a.tickets[k] = 0u;  // ready for the next launch
+}
+}  // namespace mcl3dl

@@ -135,6 +135,7 @@ class Oracle:
         s("expectation", None, [_p, _p, _p, _sz, _p, _p, _p])
         s("covariance", None, [_p, _p, _sz, _p, _p])
         if self.kind == "ref":
+            s("set_flann_epsilon_mode", None, [_i])
             s("resample", None, [_p, _p, _sz, C.c_uint, _p, _p, _p])
             s("resample_draws", None, [C.c_uint, _f, _p, _sz, _p, _p])
             s("resize", None, [_p, _p, _sz, _sz, _p, _p])
@@ -160,6 +161,12 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    def set_flann_epsilon_mode(self, mode):
+        """Reference-backed oracle only. 1: the kd-tree stand-in honours setEpsilon() through a restated FLANN
+        KDTreeSingleIndex with (1 + eps) pruning — a probe of what the node's eps = map_grid_min / 16 is worth; 0 (default):
+        exact search, the definition parity is measured against. PROCESS-WIDE: set it back to 0 when done."""
+        self._fn("set_flann_epsilon_mode")(int(mode))
 
     # ---- SURVEY.md 8f-2 / 8f-4 (reference-backed oracle only) ---------------------------------------------------------
     def voxel_grid(self, xyz, label, leaf):

@@ -143,6 +143,13 @@ int ref_max_threads()
   return maxThreads();
 }
 
+// 1: the kd-tree shim honours setEpsilon() through the restated FLANN KDTreeSingleIndex (a sensitivity probe, see
+// shims/pcl/kdtree/kdtree_flann.h); 0 (default): exact search — the definition every parity test is measured against
+void ref_set_flann_epsilon_mode(int mode)
+{
+  pcl::kdtree_flann_epsilon_mode() = mode;
+}
+
 // src/mcl_3dl.cpp:1270,1327-1329 (setRescaleValues / setEpsilon / setPointRepresentation) + :1369 setInputCloud.
 void ref_set_map(void* h, const float* xyz, const uint32_t* label, size_t n, uint64_t stamp,
                  const float* dist_weight, float epsilon)

@@ -13,6 +13,9 @@
 // Deviation (stated in DESIGN.md, "parity unpinned at the PCL/FLANN boundary"): setEpsilon() is
 // accepted and IGNORED — the search is exact (eps = 0). Ties in d2 resolve to the lower index.
 // The spatial index is a uniform grid (ours), not FLANN's kd-tree; results do not depend on it.
+// For MEASURING what the ignored epsilon is worth, kdtree_flann_epsilon_mode() = 1 routes max_nn = 1 searches with
+// eps > 0 through a restated FLANN KDTreeSingleIndex with (1 + eps) pruning (flann_single_index.h): a sensitivity probe
+// for tests/test_flann_eps_sensitivity.py, never the oracle's definition.
 #ifndef ORACLE_SHIM_PCL_KDTREE_KDTREE_FLANN_H
 #define ORACLE_SHIM_PCL_KDTREE_KDTREE_FLANN_H
 #include <algorithm>
@@ -21,11 +24,19 @@
 #include <memory>
 #include <utility>
 #include <vector>
+#include <pcl/kdtree/flann_single_index.h>
 #include <pcl/kdtree/kdtree.h>
 #include <pcl/point_cloud.h>
 
 namespace pcl
 {
+// 0 (default): exact search whatever setEpsilon() was given; 1: honour it through the restated FLANN single index
+inline int& kdtree_flann_epsilon_mode()
+{
+  static int mode = 0;
+  return mode;
+}
+
 template <typename PointT>
 class KdTreeFLANN
 {
@@ -89,6 +100,8 @@ public:
     std::vector<std::uint32_t> fill(cell_start_.begin(), cell_start_.end() - 1);
     pts_.resize(3 * n);
     ids_.resize(n);
+    raw_ = raw;
+    approx_built_ = false;
     for (std::size_t i = 0; i < n; ++i)  // stable: ascending original index inside a cell
     {
       const std::uint32_t dst = fill[cell_of[i]]++;
@@ -109,6 +122,21 @@ public:
     float q[3];
     point_representation_->vectorize(point, q);
     const float r2 = static_cast<float>(radius * radius);
+    if (max_nn == 1 && epsilon_ > 0.0f && kdtree_flann_epsilon_mode() == 1)
+    {
+      if (!approx_built_)
+      {
+        approx_.build(raw_.data(), raw_.size() / 3, 15);  // KDTreeSingleIndexParams(15), kdtree_flann.hpp
+        approx_built_ = true;
+      }
+      int id;
+      float d2;
+      if (!approx_.nearestWithin(q, r2, epsilon_, &id, &d2))
+        return 0;
+      k_indices.push_back(id);
+      k_sqr_distances.push_back(d2);
+      return 1;
+    }
     int lo[3], hi[3];
     for (int a = 0; a < 3; ++a)
     {
@@ -201,6 +229,9 @@ private:
   std::vector<std::uint32_t> cell_start_;
   std::vector<float> pts_;
   std::vector<int> ids_;
+  std::vector<float> raw_;  // vectorised points in input order (the restated FLANN index is built over them on demand)
+  mutable flann_restated::KDTreeSingleIndex approx_;
+  mutable bool approx_built_ = false;
 };
 }  // namespace pcl
 #endif

@@ -19,6 +19,7 @@
 #include <mcl_3dl/lidar_measurement_models/lidar_measurement_model_beam.h>
 #include <mcl_3dl/lidar_measurement_models/lidar_measurement_model_likelihood.h>
 #include <mcl_3dl/pf.h>
+#include <mcl_3dl/point_cloud_random_sampler.h>
 #include <mcl_3dl/point_types.h>
 #include <mcl_3dl/state_6dof.h>
 
@@ -41,6 +42,20 @@ public:
     out[0] = p.x;
     out[1] = p.y;
     out[2] = p.z;
+  }
+};
+
+// The scene file holds the clouds AFTER sampling; the node's filter() step (src/mcl_3dl.cpp:378-383) still runs — with
+// clips wide open and this sampler, which hands the clipped cloud through — because the drop-in models learn about the
+// update's clouds there.
+class PassThroughSampler : public mcl_3dl::PointCloudRandomSampler<PointType>
+{
+public:
+  Cloud::Ptr sample(const Cloud::ConstPtr& pc, const size_t) const final
+  {
+    Cloud::Ptr out(new Cloud);
+    *out = *pc;
+    return out;
   }
 };
 
@@ -103,6 +118,10 @@ int main(int argc, char** argv)
   beam_params->add_penalty_short_only_mode_ = hdr[6] != 0;
   beam_params->filter_label_max_ = static_cast<uint32_t>(hdr[7]);
   beam_params->use_raycast_using_dda_ = true;
+  lik_params->clip_near_ = beam_params->clip_near_ = 0.0f;
+  lik_params->clip_far_ = beam_params->clip_far_ = 1.0e9f;
+  lik_params->clip_z_min_ = beam_params->clip_z_min_ = -1.0e9f;
+  lik_params->clip_z_max_ = beam_params->clip_z_max_ = 1.0e9f;
   std::shared_ptr<MyPointRepresentation> point_rep(new MyPointRepresentation);
   if (fl[3] != 0.f)
     point_rep->setRescaleValues(fl.data());
@@ -139,9 +158,16 @@ int main(int argc, char** argv)
   }
 
   // ---- the measurement update, src/mcl_3dl.cpp:377-426 ---------------------------------------------------------
-  std::map<std::string, Cloud::ConstPtr> pc_locals;
-  pc_locals["likelihood"] = makeCloud(scan_lik, {});
-  pc_locals["beam"] = makeCloud(scan_beam, beam_label);
+  // :377-383: every model filters the accumulated cloud into its own pc_local (here: the scene's per-model clouds)
+  std::map<std::string, Cloud::ConstPtr> pc_raw, pc_locals;
+  pc_raw["likelihood"] = makeCloud(scan_lik, {});
+  pc_raw["beam"] = makeCloud(scan_beam, beam_label);
+  const PassThroughSampler sampler;
+  for (auto& lm : lidar_measurements_)
+  {
+    lm.second->setGlobalLocalizationStatus(n_p, n_p);
+    pc_locals[lm.first] = lm.second->filter(pc_raw[lm.first], sampler);
+  }
   std::vector<mcl_3dl::Vec3> origins;
   for (size_t i = 0; i < n_o; ++i)
     origins.emplace_back(origins_f[3 * i], origins_f[3 * i + 1], origins_f[3 * i + 2]);
@@ -186,8 +212,11 @@ int main(int argc, char** argv)
         posterior[i] = it->probability_;
     }
     double total_ms = 0;
+    mcl_3dl::hip::Engine& eng = mcl_3dl::hip::Engine::shared();
     for (int r = 0; r < reps + 1; ++r)
     {
+      if (r == 1)
+        eng.profile = mcl_3dl::hip::Engine::Profile();
       size_t i = 0;
       for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
         it->probability_ = weights[i];
@@ -199,6 +228,11 @@ int main(int argc, char** argv)
         total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
     }
     printf("route_a_ms_per_update %.6f\n", total_ms / reps);
+    // of which inside the engine-side adapter (the rest is the reference's pf.h loop: particle copy, 2 N virtual calls,
+    // weight product, normalisation, entropy)
+    printf("route_a_breakdown_us pose_gather_upload %.1f cloud_pack %.1f measure_batch %.1f batched_calls_per_update %.2f\n",
+           eng.profile.poses_us / reps, eng.profile.pack_us / reps, eng.profile.batch_us / reps,
+           static_cast<double>(eng.profile.launches) / reps);
     size_t i = 0;
     for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
       if (it->probability_ != posterior[i])

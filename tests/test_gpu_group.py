@@ -170,6 +170,18 @@ def test_injected_failure_on_the_rccl_path_rebuilds_the_communicator(scene, sing
         g.close()
 
 
+def test_group_over_every_device_of_the_box_plain_c():
+    """tests/cpp/group_all_devices.c (C99, the C ABI only): one group over mcl3dl_hip_device_count() GPUs with the RCCL
+    all-reduce — an N-rank in-process RCCL test wherever this suite meets more than one GPU, one rank here."""
+    exe = os.path.join(ROOT, "tests", "cpp", "group_all_devices.bin")
+    assert os.path.exists(exe), "tests/cpp/group_all_devices.bin is not built: run __graft_entry__.build()"
+    for n_p in ("3001", "5"):   # also fewer particles than a large box has GPUs
+        proc = subprocess.run([exe, n_p], capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stdout + proc.stderr
+        assert "device(s)" in proc.stdout and "mismatching likelihood/ratio/beam 0" in proc.stdout
+        print(proc.stdout.strip())
+
+
 def test_rccl_refuses_repeated_devices_with_a_clear_error(scene):
     g = make_group([0, 0], scene)  # collective left at RCCL
     try:
