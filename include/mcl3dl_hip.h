@@ -139,11 +139,6 @@ int mcl3dl_hip_radius_search(mcl3dl_hip_ctx* ctx, const float* query_xyz /*n*3*/
 int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* end3, float* out_xyz /*max_out*3*/,
                          int max_out, int* n_visited, int* collided, int* hit_index);
 
-/* Introspection: the beam kernel sets a ray up without its nine double-precision divisions (reciprocal multiplies with an
- * exactness check, the division as the rare fallback: beam_kernels.h). This runs both forms on n pseudo-random inputs —
- * half of them constructed on the undecidable cases — and returns how many results differ (must be 0). */
-int mcl3dl_hip_selftest_divisions(mcl3dl_hip_ctx* ctx, size_t n, uint64_t seed, uint64_t* mismatches);
-
 /* ---- device entry points (asynchronous on the context's stream) ------------------------------------- */
 /* Upload (and spatially order) the two filtered scans `pc_locals` of one update (src/mcl_3dl.cpp:377-383). */
 int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,

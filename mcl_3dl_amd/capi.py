@@ -37,7 +37,6 @@ SIGNATURES = {
     "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
     "mcl3dl_hip_radius_search": (_i, [_p, _p, _sz, _f, _p, _p]),
     "mcl3dl_hip_device_count": (_i, []),
-    "mcl3dl_hip_selftest_divisions": (_i, [_p, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mcl3dl_hip_dda_trace": (_i, [_p, _p, _p, _p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mcl3dl_hip_sort_pairs": (_i, [_p, _p, _p, _sz, _i, _p, _p]),
     "mcl3dl_hip_expectation": (_i, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
@@ -510,11 +509,6 @@ class Engine:
         ib = np.ascontiguousarray(idx_beam if idx_beam is not None else [], dtype=np.uint32)
         og = _np_f32(origins if origins is not None else np.zeros((1, 3)), 3)
         self._check(self.lib.mcl3dl_hip_scan_finish(self.h, _ptr(il), len(il), _ptr(ib), len(ib), _ptr(og), len(og)))
-
-    def selftest_divisions(self, n, seed=1):
-        bad = C.c_uint64(0)
-        self._check(self.lib.mcl3dl_hip_selftest_divisions(self.h, int(n), int(seed), C.byref(bad)))
-        return int(bad.value)
 
     def sort_pairs(self, keys, vals=None, end_bit=32):
         """The device radix sort of the cloud path on its own (stable, ascending by key bits [0, end_bit))."""

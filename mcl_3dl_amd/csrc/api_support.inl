@@ -81,12 +81,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->strict_order = static_cast<int>(value);
     return 0;
   }
-  if (key == "beam_fast_div")
-  {
-    ctx->beam_fast_div = value != 0.0;
-    ctx->dg.fast_div = ctx->beam_fast_div;
-    return 0;
-  }
   if (key == "overlap_min_rays")
   {
     if (!(value >= 0.0 && value <= 9.0e18))
@@ -221,6 +215,17 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->cand_record_parts = static_cast<int>(value);
     return 0;
   }
+  if (key == "cand_refine" || key == "cand_refine_above")
+  {
+    const bool which = key == "cand_refine";
+    if (!(value >= (which ? 1.0 : 0.0) && value <= (which ? 4.0 : 32.0)))
+      return ctx->fail(-3, "cand_refine must be in [1, 4], cand_refine_above in [0, 32]");
+    int& field = which ? ctx->cand_refine : ctx->cand_refine_above;
+    if (static_cast<int>(value) != field)
+      ctx->cand_dirty = true;
+    field = static_cast<int>(value);
+    return 0;
+  }
   if (key == "cand_phase")
   {
     if (!(value >= 0.0 && value < 1.0))
@@ -246,9 +251,10 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
-  else if (key == "beam_fast_div") *value = ctx->beam_fast_div;
   else if (key == "overlap_min_rays") *value = static_cast<double>(ctx->overlap_min_rays);
   else if (key == "resample_prefix_device") *value = ctx->resample_prefix_device;
+  else if (key == "cand_refine") *value = ctx->cand_refine;
+  else if (key == "cand_refine_above") *value = ctx->cand_refine_above;
   else if (key == "update_small") *value = ctx->update_small;
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "timing_mask") *value = ctx->timing_mask;
@@ -272,26 +278,6 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else
     return ctx->fail(-3, "unknown option '%s'", name);
   return 0;
-}
-
-int mcl3dl_hip_selftest_divisions(mcl3dl_hip_ctx* ctx, size_t n, uint64_t seed, uint64_t* mismatches)
-{
-  if (!ctx)
-    return -1;
-  if (!mismatches || n == 0 || n > (1ull << 32))
-    return ctx->fail(-3, "bad arguments to selftest_divisions");
-  HIP_TRY(hipSetDevice(ctx->device));
-  TRY(ensure(ctx, ctx->ray_stats, sizeof(unsigned long long) * 3));
-  HIP_TRY(hipMemsetAsync(ctx->ray_stats.p, 0, sizeof(unsigned long long) * 3, ctx->stream));
-  hipLaunchKernelGGL(div_selftest_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                     static_cast<long long>(n), static_cast<unsigned long long>(seed),
-                     static_cast<unsigned long long*>(ctx->ray_stats.p));
-  HIP_TRY(hipGetLastError());
-  unsigned long long out3[3] = { 0, 0, 0 };
-  TRY(d2h(ctx, out3, ctx->ray_stats.p, sizeof(out3)));
-  TRY(sync_stream(ctx));
-  *mismatches = out3[0];
-  return out3[1] == n ? 0 : ctx->fail(-2, "division self-test did not run");
 }
 
 int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats8)

@@ -54,87 +54,17 @@ __device__ inline bool point_within_map(const DdaGrid& g, const Vec3f b)
   return !((b.x < g.min_x) || (g.max_x < b.x) || (b.y < g.min_y) || (g.max_y < b.y) || (b.z < g.min_z) || (g.max_z < b.z));
 }
 
-// ---- the ray set-up's double-precision divisions without dividing ----------------------------------------------------
-// setRay (raycast_using_dda.h:66-104) costs nine fp64 divisions per ray: toIndex of the end point (three), t_delta and
-// initial_edges per axis (two each). An IEEE fp64 division is ~35 instructions at the fp64 rate on gfx950. Both forms below
-// produce the very bits the division gives and fall back to the division itself in the (rare, ~1e-8) cases they cannot decide.
-
-// (int)(x / g) — double division, truncation toward zero — for g > 0 with inv_g = 1 / g. For x >= 0: k = floor of the TRUE
-// quotient from one multiply and an exact fma remainder; the rounded quotient fl(x / g) truncates to k as well unless the
-// true quotient lies within half an ulp below k + 1 (then fl() rounds up to the integer): that sliver — and any negative x,
-// where truncation is not floor — takes the division.
-__device__ inline int div_trunc(double x, double g, double inv_g)
-{
-  const double q = x * inv_g;
-  if (!(x >= 0.0) || !(q < 2.0e9))
-    return static_cast<int>(x / g);
-  int k = static_cast<int>(q);
-  double r = fma(-static_cast<double>(k), g, x);  // x - k g, exact (|r| < 2 g)
-  if (r < 0.0)
-  {
-    k -= 1;
-    r += g;
-  }
-  else if (r >= g)
-  {
-    k += 1;
-    r -= g;
-  }
-  if (!(r >= 0.0 && r < g) || (g - r) <= x * 4.5e-16)  // within 2 ulp below the next integer (or the correction failed)
-    return static_cast<int>(x / g);
-  return k;
-}
-
-// 1 / b to ~2 ulp: v_rcp_f64 + two Newton steps (b finite, non-zero, normal)
-__device__ inline double rcp_refined(double b)
-{
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  return r;
-}
-
-// (float)fabs(a / b) with the division in double (t_delta_, initial_edges, raycast_using_dda.h:97-100). y = |a| * (1 / |b|)
-// is within a few ulp (double) of the quotient; rounding either to float gives the same float unless they straddle the
-// midpoint between two floats, i.e. unless the 29 bits the float drops sit within 64 ulp of 2^28 — then divide.
-__device__ inline float div_abs_to_float(double a, double b, double inv_abs_b)
-{
-  const double y = fabs(a) * inv_abs_b;
-  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(y));
-  const uint32_t low = static_cast<uint32_t>(bits) & 0x1fffffffu;
-  const bool undecided = (low - 0x0fffffc0u) <= 0x80u || !(y > 1.0e-30 && y < 1.0e30);
-  return undecided ? static_cast<float>(fabs(a / b)) : static_cast<float>(y);
-}
-
+// Measured and NOT kept (round 3, commit ae2f9a2): the nine fp64 divisions of the ray set-up (toIndex of the end point,
+// t_delta and initial_edges per axis) as reciprocal multiplies with an exactness check and the division as the rare
+// fallback — bit-identical on 3 x 2^24 self-test inputs built on the undecidable cases, and no faster: C3 beam group
+// 0.1263 -> 0.1270 ms, 16 384 rays per particle 4.57 -> 4.65 ms (profiles/r03m_beam_fast_div_ab.txt). The set-up is not
+// where a ray's time goes; the walk is.
 // toIndex, raycast_using_dda.h:205-210: float difference, double division, truncation toward zero
 __device__ inline void to_index(const DdaGrid& g, const Vec3f p, int& ix, int& iy, int& iz)
 {
-  if (g.fast_div)
-  {
-    ix = div_trunc(static_cast<double>(p.x - g.min_x), g.grid, g.inv_grid);
-    iy = div_trunc(static_cast<double>(p.y - g.min_y), g.grid, g.inv_grid);
-    iz = div_trunc(static_cast<double>(p.z - g.min_z), g.grid, g.inv_grid);
-    return;
-  }
   ix = static_cast<int>(static_cast<double>(p.x - g.min_x) / g.grid);
   iy = static_cast<int>(static_cast<double>(p.y - g.min_y) / g.grid);
   iz = static_cast<int>(static_cast<double>(p.z - g.min_z) / g.grid);
-}
-
-// initial_edges and t_delta of one axis (raycast_using_dda.h:93-101): dir = the ray's direction component (non-zero where
-// this is called: the ray changes voxel along the axis), edge = nearest voxel boundary minus the begin coordinate
-__device__ inline void axis_times(const DdaGrid& g, double edge, float dir, float& initial_edge, float& t_delta)
-{
-  const double d = static_cast<double>(dir);
-  if (g.fast_div && fabsf(dir) > 1.0e-30f)
-  {
-    const double inv = rcp_refined(fabs(d));
-    initial_edge = div_abs_to_float(edge, d, inv);
-    t_delta = div_abs_to_float(g.grid, d, inv);
-    return;
-  }
-  initial_edge = static_cast<float>(fabs(edge / d));
-  t_delta = static_cast<float>(fabs(g.grid / d));
 }
 
 // The walk from a begin point that lies within the map and whose voxel (bx, by, bz) = toIndex(begin) is known.
@@ -158,17 +88,20 @@ __device__ inline int cast_ray_from(const DdaGrid& g, const BeamParams& bp, Vec3
   if (dix != 0)
   {
     const double nearest = (dir.x < 0) ? bx * g.grid + g.min_x : (bx + 1) * g.grid + g.min_x;
-    axis_times(g, nearest - b.x, dir.x, iex, tdx);
+    iex = static_cast<float>(fabs((nearest - b.x) / dir.x));
+    tdx = static_cast<float>(fabs(g.grid / dir.x));
   }
   if (diy != 0)
   {
     const double nearest = (dir.y < 0) ? by * g.grid + g.min_y : (by + 1) * g.grid + g.min_y;
-    axis_times(g, nearest - b.y, dir.y, iey, tdy);
+    iey = static_cast<float>(fabs((nearest - b.y) / dir.y));
+    tdy = static_cast<float>(fabs(g.grid / dir.y));
   }
   if (diz != 0)
   {
     const double nearest = (dir.z < 0) ? bz * g.grid + g.min_z : (bz + 1) * g.grid + g.min_z;
-    axis_times(g, nearest - b.z, dir.z, iez, tdz);
+    iez = static_cast<float>(fabs((nearest - b.z) / dir.z));
+    tdz = static_cast<float>(fabs(g.grid / dir.z));
   }
   float tmx = iex, tmy = iey, tmz = iez;
   int cx = bx, cy = by, cz = bz;
@@ -458,66 +391,6 @@ __global__ void beam_status_kernel(const float* __restrict__ begin_xyz, const fl
   status[i] = s;
   if (hit_index)
     hit_index[i] = (s == 2) ? -1 : hit;
-}
-
-// Self-test of the division-free forms above against the divisions they stand for, on n pseudo-random inputs per call,
-// half of them built to sit ON the undecidable cases (a quotient a few ulp from an integer; a quotient a few ulp from the
-// midpoint between two floats). out3: [0] results that differ (must be 0), [1] trunc inputs, [2] float inputs generated.
-__global__ void div_selftest_kernel(long long n, unsigned long long seed, unsigned long long* __restrict__ out3)
-{
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  unsigned long long s = seed + 0x9e3779b97f4a7c15ull * static_cast<unsigned long long>(i + 1);
-  const auto next = [&]() {
-    s ^= s << 13;
-    s ^= s >> 7;
-    s ^= s << 17;
-    return s;
-  };
-  const auto unit = [&]() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); };
-  unsigned long long bad = 0;
-  // ---- (int)(x / g): grid sizes around the ones in use, x over a few kilometres of map, every other input within +-4 ulp
-  // of an exact multiple of g
-  const double g = static_cast<double>(static_cast<float>(0.05 + 0.5 * unit()));
-  const double inv_g = 1.0 / g;
-  double x = static_cast<double>(static_cast<float>(4000.0 * unit()));
-  if (i & 1)
-  {
-    const double k = floor(20000.0 * unit());
-    x = k * g;
-    const int nudge = static_cast<int>(next() % 9) - 4;
-    x = __longlong_as_double(__double_as_longlong(x) + nudge);
-    if (!(x >= 0.0))
-      x = 0.0;
-  }
-  if (i % 17 == 0)
-    x = -x;  // a ray end outside the map
-  if (div_trunc(x, g, inv_g) != static_cast<int>(x / g))
-    ++bad;
-  // ---- (float)fabs(a / b): direction components from 1e-6 to 1, numerators up to a voxel; every other input has its
-  // quotient within a few ulp of the midpoint between two floats
-  double b = static_cast<double>(static_cast<float>((unit() < 0.5 ? -1.0 : 1.0) * exp(-14.0 * unit())));
-  double a = (unit() - 0.5) * 0.6;
-  if (i & 1)
-  {
-    const float f = static_cast<float>(exp(20.0 * unit() - 8.0));
-    const double mid = 0.5 * (static_cast<double>(f) + static_cast<double>(__uint_as_float(__float_as_uint(f) + 1u)));
-    a = mid * b;
-    const int nudge = static_cast<int>(next() % 7) - 3;
-    a = __longlong_as_double(__double_as_longlong(a) + nudge);
-  }
-  const float want = static_cast<float>(fabs(a / b));
-  const float got = div_abs_to_float(a, b, rcp_refined(fabs(b)));
-  if (__float_as_uint(want) != __float_as_uint(got))
-    ++bad;
-  if (bad)
-    atomicAdd(&out3[0], bad);
-  if (i == 0)
-  {
-    out3[1] = static_cast<unsigned long long>(n);
-    out3[2] = static_cast<unsigned long long>(n);
-  }
 }
 
 // One ray, one lane: the waypoint introspection used by the known-answer tests.

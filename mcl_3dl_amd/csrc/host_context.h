@@ -110,6 +110,10 @@ struct mcl3dl_hip_ctx
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
+  // sharper pruning of crowded voxels (map_compiler.h:mc_prune_boxed, pass 1b): voxels that keep more than
+  // cand_refine_above candidates have them tested per sub-box of a cand_refine^3 subdivision (1 = off)
+  int cand_refine = 1;
+  int cand_refine_above = 4;
   uint32_t cand_parts = 4;        // what the current index was built with
   double cand_over8 = 0;          // voxels with more than eight candidates (index statistics)
   DevBuf cand_table, cand_start, cand_pts, cand_rec, cand_ovf;
@@ -140,7 +144,6 @@ struct mcl3dl_hip_ctx
   // per-(particle, origin) ray constants (beam_origin_kernel) for launches of at least beam_prepare_min_rays rays
   DevBuf beam_origin;
   int beam_prepare = 1;
-  int beam_fast_div = 1;  // the ray set-up's nine double divisions as reciprocal multiplies + exactness check (same bits)
   long long beam_prepare_min_rays = 32768;
   size_t n_s = 0, n_b = 0, n_o = 0;
   bool has_scan = false;

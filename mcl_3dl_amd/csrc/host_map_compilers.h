@@ -100,8 +100,6 @@ int build_lik_grid_host(mcl3dl_hip_ctx* ctx)
 void dda_ray_constants(const mcl3dl_hip_ctx* ctx, DdaGrid& g)
 {
   g.grid = static_cast<double>(ctx->dda_grid_size);
-  g.inv_grid = 1.0 / g.grid;
-  g.fast_div = ctx->beam_fast_div;
   g.ray_angle_half = static_cast<double>(ctx->ray_angle_half);
   // RaycastUsingDDA ctor, raycast_using_dda.h:59: map_grid_size_y appears twice (reference quirk, kept)
   const double gx = ctx->map_grid[0], gy = ctx->map_grid[1];
@@ -282,6 +280,8 @@ int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const float mn[3], co
   const double r_hi = r * (1.0 + 1e-5);
   cp.r2_hi = r_hi * r_hi;
   cp.margin = 1e-5 * r * r;
+  cp.refine = ctx->cand_refine;
+  cp.refine_above = ctx->cand_refine_above;
   cp.reach = static_cast<int>(std::floor((r_hi + cp.grow) / cp.e)) + 1;
   float o[3];
   int nv[3], nb[3];

@@ -178,7 +178,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   const bool want_beam = (d_beam || stats);
   TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0, stats));
   const int np = static_cast<int>(n_p);
-  bool beam_forked = false;
+  bool beam_forked = false, beam_ones_by_finalize = false;
   // any return between the fork and the join below (a failing HIP call) first waits for the second stream, so the caller
   // never gets control back with beam kernels still writing its buffers
   struct ForkGuard
@@ -201,7 +201,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   {
     if (ctx->n_b == 0)
     {
-      if (!stats)
+      // (1, 0) for every particle; with the tiled likelihood kernel behind it the per-particle finalize writes the ones
+      beam_ones_by_finalize = !stats && d_beam && want_lik && ctx->n_s > 0 && plan.tiled;
+      if (!stats && !beam_ones_by_finalize)
         hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
                            static_cast<float*>(nullptr), 0.0f, np);
     }
@@ -381,7 +383,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
 #undef LAUNCH_TILED
           hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
                              ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
-                             d_lik, d_ratio);
+                             d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
           if (strict_terms && d_lik)
           {
 #define LAUNCH_STRICT(GG)                                                                                             \

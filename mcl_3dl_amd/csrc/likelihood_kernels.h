@@ -873,10 +873,12 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
 
 // Sums the per-tile partials of each particle: 32 particles per work-group, 8 lanes per particle each walk every 8th tile
 // (independent loads, 1/8 of the dependent chain), then lane-slice 0 adds the 8 sub-sums in fixed order (deterministic).
+// also_fill (may be null): an array of n_p floats set to 1 on the way — the beam score of an update without beam points
+// (beam.cpp:130-133), which would otherwise cost a launch of its own.
 __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restrict__ partial_sum,
                                                            const unsigned* __restrict__ partial_cnt, int n_tiles, int n_p,
                                                            int n_s, float* __restrict__ out_lik,
-                                                           float* __restrict__ out_ratio)
+                                                           float* __restrict__ out_ratio, float* __restrict__ also_fill)
 {
   __shared__ double s_a[8][32];
   __shared__ unsigned s_n[8][32];
@@ -907,6 +909,8 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
     out_lik[p] = static_cast<float>(a);
   if (out_ratio)
     out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
+  if (also_fill)
+    also_fill[p] = 1.0f;
 }
 
 // "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): float adds,

@@ -48,8 +48,6 @@ struct DdaGrid
   float max_x, max_y, max_z;
   int nx, ny, nz;
   double grid;             // dda_grid_size_
-  double inv_grid;         // 1 / grid (double division on the host): the multiply form of toIndex, beam_kernels.h:div_trunc
-  int fast_div;            // 1 = the ray set-up's double divisions as reciprocal multiplies with an exactness check
   double ray_angle_half;   // ray_angle_half_
   double min_dist_thr_sq;  // min_dist_thr_sq_
   float hit_tolerance_f;   // (float)hit_tolerance_  (Vec3::operator*(float))

@@ -74,5 +74,6 @@ if args.shapes:
         bench("shape_%dx%d" % (p, s), "--workload C2 --particles %d --scan-points %d %s" % (p, s, quick), 300)
 for w in args.profiles:
     extra = " --particles 8192" if w == "C5" else ""
-    sh("bash profiles/run_profiles.sh %s_%s --workload %s%s" % (args.tag, w, w, extra), "prof_%s.log" % w, 900)
+    wl = "C2 --map-jitter 0.045" if w == "C2j" else w   # C2j = C2 on the map of displaced points (voxel-filter centroids)
+    sh("bash profiles/run_profiles.sh %s_%s --workload %s%s" % (args.tag, w, wl, extra), "prof_%s.log" % w, 900)
 print("total %.0f s" % (time.time() - T0))

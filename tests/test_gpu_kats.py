@@ -178,33 +178,3 @@ def test_beam_wall_fixture_goldens(engine):
                     pose = np.array([[xs[i], 0, 0, 0, 0, 0, 1]], np.float32)
                     _, _, b = engine.measure_batch(pose, None, pc, np.zeros(len(pc), np.uint32), pose[:, :3])
                     assert b[0] == g["lik_m%d_h%d" % (mode, k)][i]
-
-
-def test_division_free_ray_setup_gives_the_divisions_bits(engine):
-    """beam_kernels.h:div_trunc / div_abs_to_float (the ray set-up without its nine fp64 divisions) against the divisions
-    themselves on 2^24 inputs, half of them constructed on the cases the multiply form cannot decide (quotients a few ulp
-    from an integer resp. from the midpoint between two floats) and must hand to the division: no result may differ."""
-    for seed in (1, 2, 3):
-        assert engine.selftest_divisions(1 << 24, seed) == 0
-
-
-def test_fast_division_option_does_not_change_any_ray(engine, oracle_kind):
-    from mcl_3dl_amd.synthetic import make_scene
-    sc = make_scene(n=91, n_p=300, n_s=64, n_b=200, seed=41)
-    engine.set_map(sc.map_xyz, sc.map_label, stamp=9200, dist_weight=(1.0, 1.0, 1.0))
-    engine.set_likelihood_params()
-    engine.set_beam_params(num_points=200)
-    rng = np.random.default_rng(3)
-    begin = (sc.poses[rng.integers(0, 300, 20000), :3] + rng.normal(0, 0.3, (20000, 3))).astype(np.float32)
-    end = (begin + rng.normal(0, 2.5, (20000, 3))).astype(np.float32)
-    out = {}
-    try:
-        for fast in (0, 1):
-            engine.set_option("beam_fast_div", fast)
-            out[fast] = (engine.beam_status(begin, end), engine.measure_batch(sc.poses, None, sc.scan_beam, sc.scan_beam_label, sc.origins)[2])
-    finally:
-        engine.set_option("beam_fast_div", 1)
-    np.testing.assert_array_equal(out[0][0][0], out[1][0][0])
-    np.testing.assert_array_equal(out[0][0][1], out[1][0][1])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    assert len(np.unique(out[1][0][0])) >= 3
