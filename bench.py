@@ -330,17 +330,32 @@ def _identity_noise(n):
 
 
 @contextlib.contextmanager
-def no_gc():
+def no_gc(collect=False):
     """Timed host loops run with Python's cyclic garbage collector off (a generation-2 pass over a process that has torch
-    loaded takes tens of milliseconds — two orders of magnitude more than one update)."""
+    loaded takes tens of milliseconds — two orders of magnitude more than one update). It does NOT collect on entry unless
+    asked to: a collection right before a timed region leaves the GPU idle for ~35 ms, the clocks fall back, and the first
+    tens of launches of the region run ~20 % slow (profiles/r03o_C2_gc_gap_trace.txt: 231 us per launch through the
+    pre-warm, 34 ms of nothing, then 281 us decaying to 255 us over the 20 timed steps). main() collects once, before the
+    pre-warm, and freezes what is left."""
     was = gc.isenabled()
-    gc.collect()
+    if collect:
+        gc.collect()
     gc.disable()
     try:
         yield
     finally:
         if was:
             gc.enable()
+
+
+def keep_gpu_warm(call, seconds=0.15, sync=None):
+    """Run `call` back to back for `seconds` of wall time (clock ramp before a side measurement that follows host-only work)."""
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        for _ in range(4):
+            call()
+        if sync is not None:
+            sync()
 
 
 def _flush_c_stdio():
@@ -418,6 +433,7 @@ def in_process_group_run(workload, n_cfg, extra_cfg, dist_weight, devices, steps
         args_u = (poses, w0, sc.scan_lik, sc.scan_beam if n_b else None, sc.scan_beam_label if n_b else None, sc.origins)
         for _ in range(max(warmup, 3)):
             g.measure_update(*args_u)
+        keep_gpu_warm(lambda: g.measure_update(*args_u), 0.15)   # clock ramp on every GPU of the group (set-up, not timed)
         with no_gc():
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -537,6 +553,7 @@ def main():
             extra_cfg["n_b"] = args.beam_points
         r = in_process_group_run(args.workload, n_cfg, extra_cfg, (1.0, 1.0, args.dist_weight_z), list(range(args.gpus)),
                                  args.steps, args.warmup)
+        _flush_c_stdio()   # RCCL announces itself through C stdio: out before the line, which must be the last one
         print(json.dumps({
             "metric": "particle·point evals/sec; filter-update Hz @ 4096 particles × 16k-pt scan", "value": r["value"],
             "unit": r["unit"], "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -681,6 +698,10 @@ def main():
     main_sh = Shard(args.scaling)
     n_p = main_sh.n
 
+    def rewarm(seconds=0.1):
+        """Side measurements follow host-only stretches (D2H of results, the CPU baseline): bring the clocks back first."""
+        keep_gpu_warm(lambda: step(main_sh), seconds, lambda: torch.cuda.synchronize(dev))
+
     # first call builds + uploads the map structures (outside every timed region)
     step(main_sh)
     torch.cuda.synchronize(dev)
@@ -700,6 +721,11 @@ def main():
     # Clock ramp: a GPU coming out of idle needs tens of milliseconds of load before it holds its sustained clocks, far
     # more than W steps of a sub-millisecond update. Run the update for --prewarm-ms of wall time first (set-up, like the
     # map upload above; not part of W or K), then the W warm-up steps the contract asks for.
+    # one collection of the set-up's garbage NOW (before the clock ramp), survivors frozen out of later passes, collector off
+    # until the line is printed: nothing below may put a ~35 ms host pause between the pre-warm and the timed steps
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     prewarm = {"ms": 0.0, "batches": 0}
     if args.prewarm_ms > 0:
         torch.cuda.synchronize(dev)
@@ -959,7 +985,8 @@ def main():
             # SURVEY.md section 8d's definition of one update: host buffers in, host buffers out (scan ordering + upload,
             # pose and prior-weight H2D, kernels, reduction, weight D2H) through the synchronous host entry point
             eng.set_stream(None)
-            eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            keep_gpu_warm(lambda: eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label,
+                                                     sc.origins), 0.15)
             with no_gc():
                 t2 = time.perf_counter()
                 for _ in range(args.steps):
@@ -974,7 +1001,7 @@ def main():
         if not args.no_extras:
             # the reductions that follow the update in the node (expectationBiased + max + covariance) on the
             # device-resident particles; each call ends with a D2H of a dozen scalars
-            torch.cuda.synchronize(dev)
+            rewarm()
             t3 = time.perf_counter()
             for _ in range(10):
                 mean7, _tot, _im, _ib = eng.expectation_device(d_pose, d_w, None, n_p)
@@ -1036,6 +1063,7 @@ def main():
             # the fused device-resident call (measure + pf::measure in one C call) replaying its captured hipGraph, next
             # to the same call enqueuing kernel by kernel: what launch overhead is worth at this size. Not `value`.
             fused = {}
+            rewarm()
             for use_graph in (0, 1):
                 eng.set_option("use_graph", use_graph)
                 for _ in range(3):
@@ -1051,7 +1079,7 @@ def main():
             # one whole filter iteration with everything resident on the device: measurement update -> expectation + max
             # (the node publishes the pose from it) -> resampling of the 13-float states; noise = identity
             eng.set_option("use_graph", 0)
-            torch.cuda.synchronize(dev)
+            rewarm()
             t7 = time.perf_counter()
             for _ in range(args.steps):
                 d_w.copy_(d_w0)

@@ -390,7 +390,11 @@ int timing_begin(mcl3dl_hip_ctx* ctx, int kernel, EventPair* ep, hipStream_t on 
     }
     else
     {
-      HIP_TRY(hipEventCreate(&ev[i]));
+      // timing only: no system-scope fence when the event is recorded. A default event writes the L2s back and invalidates
+      // them, and the kernel bracketed by two of them then starts on cold L2s — the tiled likelihood kernel measured
+      // 272 us between default events against 230 us without them (profiles/r03n_C2 kernel trace), i.e. the probe
+      // changed what it measured.
+      HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableSystemFence));
     }
   }
   ep->start = ev[0];

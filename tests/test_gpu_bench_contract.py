@@ -71,12 +71,26 @@ def test_single_gpu_line():
     assert sp["ms"] < sp["cpu_reference_ms"] / 5, sp
     assert sp["ms_max"] < sp["cpu_reference_ms"], sp
     assert d["match_split"]["ms"] < 1.0, d["match_split"]
+    # the in-process route (device group, one process) on the same GPU: the sharded path with the one-rank RCCL all-reduce
+    ip = d["in_process_group"]
+    assert "error" not in ip, ip
+    assert ip["n_gpus"] == 1 and ip["collective"] == "rccl" and ip["collectives"]["rccl"] >= 3 and ip["value"] > 1e7
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0
     # the run checks itself against the CPU path
     assert d["result_check"]["max_rel_err_vs_cpu"] < 1e-5 and d["result_check"]["match_ratio_equal"] is True
+
+
+def test_in_process_mode_prints_the_contract_line():
+    """bench.py --in-process: ONE process drives the GPUs through mcl3dl_hip_group_* (what the reference's single process
+    would do); same contract keys, no torch.distributed."""
+    d = run_bench("--in-process")
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 1e7 and d["in_process_group"]["collective"] == "rccl"
+    assert "ONE process" in d["config"]["parallelism"]
 
 
 def test_distributed_path_with_one_rank():
