@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--lik-coop", type=int, default=-1,
                     help="quad-cooperative record fetch (-1 = the library's default, 1 = on, 0 = every lane fetches its "
                          "own record)")
+    ap.add_argument("--lik-defer", type=int, default=-1,
+                    help="overflow rounds of the tiled kernel deferred and run densely: 0 never, 1 whenever the records allow it, "
+                         "2 on crowded maps (library default); -1 = leave the default")
     ap.add_argument("--cand-record-parts", type=int, default=-1,
                     help="inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map (-1 = default)")
     ap.add_argument("--lik-wide", type=int, default=-1,
@@ -617,6 +620,8 @@ def main():
     eng.set_option("cand_phase", args.cand_phase)
     if args.cand_record_parts >= 0:
         eng.set_option("cand_record_parts", args.cand_record_parts)
+    if args.lik_defer >= 0:
+        eng.set_option("lik_defer", args.lik_defer)
     if args.strict_order >= 0:
         eng.set_option("strict_order", args.strict_order)
     strict_mode = int(eng.get_option("strict_order"))

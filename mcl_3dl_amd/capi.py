@@ -663,4 +663,6 @@ class Engine:
         return dict(bricks=int(s[0]), preliminary=int(s[1]), candidates=int(s[2]), build_ms=float(s[3]),
                     voxels_with_candidates=int(s[4]), voxels_with_overflow=int(s[5]), overflow_records=int(s[6]),
                     voxel_ratio=float(s[7]), voxels_over8=int(self.get_option("cand_voxels_over8")),
-                    record_parts=int(self.get_option("cand_record_parts_in_use")))
+                    record_parts=int(self.get_option("cand_record_parts_in_use")),
+                    packed_words=int(self.get_option("cand_packed_active")),
+                    deferred_overflow=int(self.get_option("lik_defer_active")))

@@ -178,6 +178,33 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_coop = value != 0.0;
     return 0;
   }
+  if (key == "lik_defer")
+  {
+    if (!(value == 0.0 || value == 1.0 || value == 2.0))
+      return ctx->fail(-3, "lik_defer must be 0 (never), 1 (whenever the records allow it) or 2 (crowded maps only)");
+    if (static_cast<int>(value) != ctx->lik_defer)
+    {
+      ctx->cand_dirty = true;  // the record size of a crowded map follows it (host_map_compilers.h:build_cand_grid)
+      ++ctx->generation;       // a captured update graph holds the other kernel
+    }
+    ctx->lik_defer = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "lik_defer_min_frac")
+  {
+    if (!(value >= 0.0 && value <= 1.0))
+      return ctx->fail(-3, "lik_defer_min_frac must be in [0, 1]");
+    ctx->lik_defer_min_frac = value;
+    ++ctx->generation;
+    return 0;
+  }
+  if (key == "cand_packed")
+  {
+    if ((value != 0.0) != (ctx->cand_packed != 0))
+      ctx->cand_dirty = true;
+    ctx->cand_packed = value != 0.0 ? 1 : 0;
+    return 0;
+  }
   if (key == "beam_prepare")
   {
     ctx->beam_prepare = value != 0.0;
@@ -265,6 +292,11 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_group") *value = ctx->lik_group;
   else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
+  else if (key == "lik_defer") *value = ctx->lik_defer;
+  else if (key == "lik_defer_min_frac") *value = ctx->lik_defer_min_frac;
+  else if (key == "lik_defer_active") *value = lik_defer_active(ctx) ? 1.0 : 0.0;
+  else if (key == "cand_packed") *value = ctx->cand_packed;
+  else if (key == "cand_packed_active") *value = ctx->rg.packed;
   else if (key == "beam_prepare") *value = ctx->beam_prepare;
   else if (key == "lik_wide_max_particles") *value = ctx->lik_wide_max_particles;
   else if (key == "grid_build_host") *value = ctx->grid_build_host;

@@ -349,14 +349,19 @@ uint32_t bytes32(unsigned long long bytes)
 struct CompileOutput
 {
   unsigned long long total = 0, kept = 0;
-  unsigned long long hist3[3] = { 0, 0, 0 };  // voxels with candidates, with more than four, with more than eight
+  // voxels with candidates, with more than four, with more than eight, with more than REC_COUNT_MAX
+  unsigned long long hist3[4] = { 0, 0, 0, 0 };
   uint32_t n_ovf = 0;
+  int packed = 0;  // form of the w words written (RecGrid::packed)
   // CSR form (lik_index 1): kept counts per voxel stay in d_count, runs in d_pstart / d_prelim
   TempBuf d_count, d_pstart, d_prelim, d_ovf_data;
 };
 
+// want_packed: -1 = packed w words when the counts and ovf_base + the overflow records allow it (whole-map build), 0 = plain,
+// 1 = packed or nothing (a map update into a packed index): returns 1 without writing records when that is impossible.
 int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* pts, const int* table, const int* bxyz,
-                   uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out, uint32_t cap = 4)
+                   uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out, uint32_t cap = 4,
+                   int want_packed = -1, uint32_t ovf_base = 0)
 {
   const size_t n = static_cast<size_t>(cp.n_points);
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
@@ -418,16 +423,20 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
   HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
   TempBuf d_hist;
-  HIP_TRY(hipMalloc(&d_hist.p, 3 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMalloc(&d_hist.p, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_count_overflow, dim3(std::min(blocks_v, 4096u)), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox,
                      static_cast<unsigned long long*>(d_hist.p), cap);
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
   uint32_t n_ovf = 0;
   TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
-  TRY(d2h(ctx, out->hist3, d_hist.p, 3 * sizeof(unsigned long long)));
+  TRY(d2h(ctx, out->hist3, d_hist.p, 4 * sizeof(unsigned long long)));
   TRY(sync_stream(ctx));
+  const bool can_pack = out->hist3[3] == 0 && static_cast<unsigned long long>(ovf_base) + n_ovf <= REC_EXT_MASK;
+  if (want_packed == 1 && !can_pack)
+    return 1;
+  out->packed = (want_packed != 0 && can_pack && ctx->cand_packed) ? 1 : 0;
   HIP_TRY(hipMalloc(&out->d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1)));
   {
     // unused candidate slots of an overflow record hold the sentinel, like those of a voxel record
@@ -441,7 +450,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
                      static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
                      static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p), rec_out,
-                     static_cast<float*>(out->d_ovf_data.p), n_vox, cap);
+                     static_cast<float*>(out->d_ovf_data.p), n_vox, cap, out->packed);
   HIP_TRY(hipGetLastError());
   out->n_ovf = n_ovf;
   return 0;
@@ -541,6 +550,7 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     g.off32_ok = (rec_bytes * static_cast<unsigned long long>(n_vox) < (1ull << 32)) ? 1 : 0;
     g.rec_bytes32 = bytes32(rec_bytes * static_cast<unsigned long long>(n_vox));
     g.rec_parts = static_cast<int>(cap);
+    g.packed = co.packed;
     ctx->cand_parts = cap;
     g.ovf_bytes32 = bytes32(64ull * (n_ovf ? n_ovf : 1));
     g.ti_empty = static_cast<uint32_t>(n_table);
@@ -618,9 +628,13 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     // 0.36 r has (0.5 / 0.36)^3 times as many of them). Measured on the jittered C2 map: 0.42 ms (0.5 r, 64 B) -> 0.364
     // (0.36 r, 64 B) -> 0.338 (0.36 r, 128 B); on a lattice the wide record costs 20 %, so it is never the default there.
     const double first_ms = ctx->cand_stats[3];
-    const double est_bricks = ctx->cand_stats[0] * 2.68;
+    const bool defer = ctx->lik_defer != 0 && ctx->cand_packed != 0 && ctx->rg.packed != 0;
+    const double fine = 0.36;  // with the queue: 0.30 r measured 1.6 % faster at +-0.045 m, 2.6 % slower at +-0.02 m, twice the memory
+    const double est_bricks = ctx->cand_stats[0] * std::pow(0.5 / fine, 3.0);
     const double est_bytes = 128.0 * 512.0 * est_bricks;
-    const uint32_t cap = forced ? forced : (est_bytes < 16.0e9 ? 8u : 4u);
+    // with the tiled kernel's overflow rounds deferred (lik_defer, packed records) the 64-byte record wins again:
+    // 0.326 ms against 0.340 with 128-byte records at 0.36 r on that map, 0.316 at 0.30 r (profiles/r03u_defer_ab.txt)
+    const uint32_t cap = forced ? forced : (defer ? 4u : est_bytes < 16.0e9 ? 8u : 4u);
     // the finer index is an optimisation of a valid one: only attempt it where it fits (brick limit of the dense table,
     // memory), and if it fails all the same, put the r / 2 index back — a map the coarser default handles must keep working
     size_t free_b = 0, total_b = 0;
@@ -628,7 +642,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     const double need = (cap == 8 ? 128.0 : 64.0) * 512.0 * est_bricks * 1.5;
     if (est_bricks < 0.9 * static_cast<double>(1u << 22) && need < 0.8 * static_cast<double>(free_b))
     {
-      if (build_cand_grid_at(ctx, 0.36, cap) == 0)
+      if (build_cand_grid_at(ctx, fine, cap) == 0)
         ctx->cand_stats[3] += first_ms;
       else
       {
@@ -790,8 +804,22 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   HIP_TRY(hipMalloc(&d_subrec.p, rec_bytes * static_cast<size_t>(n_sub_vox)));
   cp.n_points = static_cast<int>(n_rel);
   CompileOutput co;
-  TRY(compile_bricks(ctx, cp, static_cast<const float4*>(d_rel.p), static_cast<const int*>(d_sub_table.p),
-                     static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co, cap));
+  {
+    const int rc = compile_bricks(ctx, cp, static_cast<const float4*>(d_rel.p), static_cast<const int*>(d_sub_table.p),
+                                  static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co,
+                                  cap, ctx->rg.packed ? 1 : 0, ctx->cand_n_ovf);
+    if (rc == 1)
+    {
+      // the update does not fit the packed w words (a voxel with more than REC_COUNT_MAX candidates, or 2^26 overflow
+      // records): the next query rebuilds the whole index, which then picks the plain form
+      if (stats5)
+        stats5[5] = 7;
+      ctx->cand_dirty = true;
+      return 0;
+    }
+    if (rc != 0)
+      return rc;
+  }
   const uint32_t ovf_base = ctx->cand_n_ovf;
   if (co.n_ovf)
   {
@@ -804,7 +832,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   HIP_TRY(hipMemsetAsync(d_orphan.p, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_install_records, dim3(static_cast<unsigned>((n_sub_vox + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_bricks_old,
-                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p), cap);
+                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p), cap, ctx->rg.packed);
   HIP_TRY(hipGetLastError());
   unsigned long long orphaned = 0;
   TRY(d2h(ctx, &orphaned, d_orphan.p, sizeof(orphaned)));

@@ -103,6 +103,18 @@ struct LikPlan
 };
 
 // does an update over ns scan points replay the likelihood terms in the reference's float order?
+// the tiled kernel with its overflow rounds deferred (likelihood_kernels.h): needs packed 64-byte records; mode 2 = only
+// on maps where enough voxels overflow for a wavefront to meet one in nearly every round
+bool lik_defer_active(const mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->lik_defer == 0 || ctx->lik_index != 2 || !ctx->rg.packed || ctx->rg.rec_parts != 4)
+    return false;
+  if (ctx->lik_defer == 1)
+    return true;
+  const double with_cand = ctx->cand_stats[4], over4 = ctx->cand_stats[5];
+  return with_cand > 0 && over4 / with_cand > ctx->lik_defer_min_frac;
+}
+
 bool lik_strict(const mcl3dl_hip_ctx* ctx, int ns)
 {
   return ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min);
@@ -346,23 +358,26 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const int G = group_size;
           const int n_tiles = plan.n_tiles, n_groups = plan.n_groups;
           const long long blocks = plan.blocks;
-#define LAUNCH_TILED(GG, MODE, WW, CC)                                                                                 \
-  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,   \
+#define LAUNCH_TILED(GG, MODE, WW, CC, DD)                                                                             \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC, DD>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
                      ctx->scan_perm.as<uint32_t>(), strict_terms)
           const bool coop = coop_arg != 0;
+          const bool defer = coop && lik_defer_active(ctx);
 #define LAUNCH_TILED_G(GG, WW)         \
   do                                   \
   {                                    \
-    if (coop)                          \
-      LAUNCH_TILED(GG, 2, WW, true);   \
+    if (coop && defer)                 \
+      LAUNCH_TILED(GG, 2, WW, true, true);   \
+    else if (coop)                     \
+      LAUNCH_TILED(GG, 2, WW, true, false);  \
     else if (ctx->lik_index == 2)      \
-      LAUNCH_TILED(GG, 2, WW, false);  \
+      LAUNCH_TILED(GG, 2, WW, false, false); \
     else if (ctx->lik_index == 1)      \
-      LAUNCH_TILED(GG, 1, WW, false);  \
+      LAUNCH_TILED(GG, 1, WW, false, false); \
     else                               \
-      LAUNCH_TILED(GG, 0, WW, false);  \
+      LAUNCH_TILED(GG, 0, WW, false, false); \
   } while (0)
           switch (G)
           {

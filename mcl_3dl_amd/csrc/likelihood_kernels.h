@@ -154,7 +154,7 @@ __global__ void radius_search_kernel(const float* __restrict__ query_xyz, int n,
 
 // MODE 2: fat voxel records — brick table, then ONE 64-byte line holding the voxel's candidates. Record layout
 // (map_compiler.h:mc_write_records), four 16-byte parts:
-//     part j = { candidate j: x, y, z ; w }      w of part 0 = candidate count, w of part 1 = first overflow record
+//     part j = { candidate j: x, y, z ; w }      w: count and first overflow record, packed or plain (map_compiler.h)
 // candidates 0..3 inline (unused slots hold REC_SENTINEL coordinates: their d2 never wins a minimum and never passes the
 // radius test), candidates 4.. in overflow records of the same four-part layout. One part per lane of a quad is what the tiled kernel's
 // cooperative fetch reads (below).
@@ -216,7 +216,8 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
   const uint32_t cap = static_cast<uint32_t>(g.rec_parts);
   const float4* r = g.rec + static_cast<size_t>(cap) * ((static_cast<uint32_t>(b) << 9) | sub);
   const float4 r0 = r[0], r1 = r[1];
-  const uint32_t count = __float_as_uint(r0.w);
+  const uint32_t w0 = __float_as_uint(r0.w);
+  const uint32_t count = g.packed ? w0 >> REC_EXT_BITS : w0;
   if (count == 0)
     return best;
   if (STATS)
@@ -229,7 +230,7 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
     best = fminf(best, d2_simple(qx, qy, qz, c.x, c.y, c.z));
   }
   if (count > cap)
-    best = rec_overflow_min(g, qx, qy, qz, count, cap, __float_as_uint(r1.w), best);
+    best = rec_overflow_min(g, qx, qy, qz, count, cap, g.packed ? (w0 & REC_EXT_MASK) : __float_as_uint(r1.w), best);
   return best;
 }
 
@@ -412,6 +413,12 @@ __device__ inline float quad_round_wide(const float4* recs, uint32_t bytes32, ui
   return __uint_as_float(min(high ? m23 : m01, quad_u<QUAD_XOR2>(high ? m01 : m23)));
 }
 
+// w[e] = the w word of part j of record e, as quad_round returns them: w[j] is the word of this lane's own record
+__device__ inline uint32_t own_word(const uint32_t (&w)[4], int j)
+{
+  return j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
+}
+
 // vrec = the lane's own record index (0 for a lane without one: it reads record 0 and ignores the answer); returns
 // min d2 over ALL candidates of the lane's voxel: the inline four, then — while any lane of the wavefront still has
 // candidates left — one overflow record per round, fetched and reduced the same cooperative way.
@@ -425,6 +432,24 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
   float best = wide ? quad_round_wide(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w) :
                       quad_round(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w);
   const uint32_t cap = wide ? 8u : 4u;
+  if (g.packed)
+  {
+    // packed w words: part j of record j — the part this lane fetched of its OWN record — says count and overflow reference
+    const uint32_t mine = own_word(w, j);
+    if (lanes_gt_u32(mine, (cap << REC_EXT_BITS) | REC_EXT_MASK) != 0ull)
+    {
+      const uint32_t count = mine >> REC_EXT_BITS, ext = mine & REC_EXT_MASK;
+      const uint32_t rounds = (valid && count > cap) ? (count - cap + 3u) / 4u : 0u;
+      for (uint32_t r = 0; wave_any(r < rounds); ++r)
+      {
+        const bool more = r < rounds;
+        uint32_t unused[4];
+        const float m = quad_round(g.ovf, g.ovf_bytes32, more ? ext + r : 0u, qx, qy, qz, j, unused);
+        best = (more && m < best) ? m : best;
+      }
+    }
+    return best;
+  }
   // overflow (more than `cap` candidates): the counts of the quad's four records sit in lane 0 (part 0's w)
   const uint32_t cmax = max(max(w[0], w[1]), max(w[2], w[3]));
   if ((lanes_gt_u32(cmax, cap) & QUAD_LANE0_MASK) != 0ull)
@@ -696,6 +721,99 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
   }
 }
 
+// ---- deferred overflow rounds (tiled kernel, packed 64-byte records) ------------------------------------------------
+// On a map of voxel-filter centroids a quarter of the voxels hold more than four candidates. A wavefront runs an overflow
+// round as soon as ONE of its 64 evaluations needs it — practically always — with a quarter of its lanes doing useful work
+// (or, with 128-byte records, every evaluation pays for eight candidates and two L2 requests). Here an evaluation whose
+// record overflows parks its best-so-far in its own term slot and queues (overflow reference, count, lane, particle slot) in
+// a per-wavefront LDS queue; whenever 64 are queued the wavefront runs ONE dense overflow round for them — each lane
+// rebuilds its query from the queued lane's scan point (ds_bpermute) and the particle's pose (LDS), exactly the arithmetic
+// of the first pass, so the minimum, the term and therefore every result are the same bits as without the queue.
+constexpr int DEFER_QCAP = 96;   // entries per wavefront: a push never finds more than 63 queued, and flushes first if it would not fit
+
+struct DeferQueue
+{
+  uint32_t word[4][DEFER_QCAP];  // packed w of the record: (count << REC_EXT_BITS) | first overflow record
+  uint16_t who[4][DEFER_QCAP];   // (particle slot k << 6) | lane
+};
+
+// The first four candidates of one evaluation on the cooperative path (all lanes of the wavefront arrive): like eval_coop,
+// but a lane whose record holds more than four candidates returns `over` = true with its best-so-far in `best` and the
+// record's packed word in `mine` instead of running the overflow rounds.
+__device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm, const Vec3f pos, const Quat rot, const float4 v,
+                                        bool have_point, int lane, bool& matched, bool& over, float& best, uint32_t& mine)
+{
+  const Vec3f tp = vadd(qrot_trim(rot, Vec3f{ v.x, v.y, v.z }), pos);
+  const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
+  uint32_t ti, sub;
+  const bool inside = rec_locate(rg, qx, qy, qz, ti, sub) && have_point;
+  const int b = rg.brick_table[inside ? ti : rg.ti_empty];
+  const bool valid = b >= 0;
+  float dist = -1.0f;
+  over = false;
+  best = 0.0f;
+  mine = 0u;
+  if (wave_any(valid))
+  {
+    const uint32_t rec = (static_cast<uint32_t>(b) << 9) | sub;
+    const uint32_t vrec = rg.rec_bytes32 ? rec : (valid ? rec : 0u);
+    uint32_t w[4];
+    best = quad_round(rg.rec, rg.rec_bytes32, vrec, qx, qy, qz, lane & 3, w);
+    mine = own_word(w, lane & 3);
+    over = valid && mine > ((4u << REC_EXT_BITS) | REC_EXT_MASK);
+    if (valid && !over && best < prm.r2)
+    {
+      const float s = sqrt_in_radius(best);
+      dist = prm.match_dist_min - fmaxf(s, prm.match_dist_flat);
+    }
+  }
+  matched = !(dist < 0.0f);
+  return fmaxf(dist, 0.0f) * prm.match_weight;
+}
+
+// One dense overflow round for entries [base, base + n) of this wavefront's queue, n <= 64 (all lanes arrive; lane l takes
+// entry base + l). s_term / s_cnt rows are the tiled kernel's: the parked best is replaced by the term, a match is counted.
+template <int G>
+__device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, const float (&s_pose)[G][8], float (&s_term)[G][256],
+                                   unsigned (&s_cnt)[G][4], const DeferQueue& q, int wave, int lane, uint32_t base, uint32_t n,
+                                   const float4 v)
+{
+  const bool act = static_cast<uint32_t>(lane) < n;
+  const uint32_t slot = act ? base + static_cast<uint32_t>(lane) : base;
+  const uint32_t word = q.word[wave][slot];
+  const uint32_t who = q.who[wave][slot];
+  const int src = static_cast<int>(who & 63u), k = static_cast<int>(who >> 6);
+  // the queued lane's scan point, from its registers
+  const Vec3f pt = { __shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src) };
+  const Vec3f pos = { s_pose[k][0], s_pose[k][1], s_pose[k][2] };
+  const Quat rot = { s_pose[k][3], s_pose[k][4], s_pose[k][5], s_pose[k][6] };
+  const Vec3f tp = vadd(qrot_trim(rot, pt), pos);
+  const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
+  const int t_src = wave * 64 + src;
+  float best = s_term[k][t_src];
+  const uint32_t count = word >> REC_EXT_BITS, ext = word & REC_EXT_MASK;
+  const uint32_t rounds = act ? (count - 4u + 3u) / 4u : 0u;
+  for (uint32_t r = 0; wave_any(r < rounds); ++r)
+  {
+    const bool more = r < rounds;
+    uint32_t unused[4];
+    const float m = quad_round(rg.ovf, rg.ovf_bytes32, more ? ext + r : 0u, qx, qy, qz, lane & 3, unused);
+    best = (more && m < best) ? m : best;
+  }
+  float dist = -1.0f;
+  if (act && best < prm.r2)
+  {
+    const float s = sqrt_in_radius(best);
+    dist = prm.match_dist_min - fmaxf(s, prm.match_dist_flat);
+  }
+  if (act)
+  {
+    s_term[k][t_src] = fmaxf(dist, 0.0f) * prm.match_weight;
+    if (!(dist < 0.0f))
+      atomicAdd(&s_cnt[k][wave], 1u);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tile-major variant for large scans: one work-group = one 256-point scan tile x G particles.
 //
@@ -713,7 +831,8 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
 // COOP (MODE 2 only): the quad-cooperative record fetch of rec_min_d2_quad plus the VALU-trimmed transform / sqrt. Same
 // terms, bit for bit. MINW = wavefronts per SIMD the register allocation must leave room for (G = 32 holds 33 KB of LDS:
 // 4 at most).
-template <int G, int MODE, int MINW = 8, bool COOP = false>
+// DEFER (COOP only; packed 64-byte records): overflow rounds queued per wavefront and run densely (above).
+template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false>
 __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
                                                                int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
@@ -782,7 +901,59 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   const float4 v = have_point ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const int n_valid = min(G, n_p - group * G);
-  if constexpr (COOP && MODE == 2)
+  if constexpr (COOP && MODE == 2 && DEFER)
+  {
+    __shared__ DeferQueue s_q;
+    uint32_t qn = 0;  // entries queued by this wavefront (uniform)
+    for (int k = 0; k < n_valid; ++k)
+    {
+      const Vec3f pos = { s_pose[k][0], s_pose[k][1], s_pose[k][2] };
+      const Quat rot = { s_pose[k][3], s_pose[k][4], s_pose[k][5], s_pose[k][6] };
+      bool matched, over;
+      float best;
+      uint32_t mine;
+      const float term = eval_coop_first(rg, prm, pos, rot, v, have_point, lane, matched, over, best, mine);
+      s_term[k][t] = over ? best : term;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(matched);
+      if (lane == 0)
+        s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
+      const unsigned long long om = __builtin_amdgcn_ballot_w64(over);
+      if (om != 0ull)
+      {
+        const uint32_t n_new = static_cast<uint32_t>(__popcll(om));
+        if (qn + n_new > static_cast<uint32_t>(DEFER_QCAP))
+        {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          defer_drain<G>(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, 0u, qn, v);
+          qn = 0;
+        }
+        if (over)
+        {
+          const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(om >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(om), 0u));
+          s_q.word[wave][slot] = mine;
+          s_q.who[wave][slot] = static_cast<uint16_t>((static_cast<uint32_t>(k) << 6) | static_cast<uint32_t>(lane));
+        }
+        qn += n_new;
+        if (qn >= 64u)
+        {
+          // the LAST 64 entries: what stays queued keeps its place
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          defer_drain<G>(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, qn - 64u, 64u, v);
+          qn -= 64u;
+        }
+      }
+    }
+    if (qn != 0u)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      defer_drain<G>(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, 0u, qn, v);
+    }
+  }
+  else if constexpr (COOP && MODE == 2)
   {
     // every lane stays active through the cooperative fetch (DPP reads 0 from an inactive lane): a lane without a scan
     // point, outside the grid or without a brick simply carries valid = false

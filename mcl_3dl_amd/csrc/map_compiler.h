@@ -374,10 +374,16 @@ __global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* _
 // ---- "fat" voxel records (query MODE 2) -------------------------------------------------------------------------
 // One 64-byte record per voxel of every allocated brick, so a query is ONE cache line after the brick table. Four 16-byte
 // parts, one per lane of a quad in the tiled kernel's cooperative fetch:
-//   part j   : { candidate j: x, y, z ; w }   w of part 0 = candidate count, w of part 1 = first overflow record (count > 4)
+//   part j   : { candidate j: x, y, z ; w }
 //   overflow : the same four-part layout       contiguous, candidates 4, 5, ... four per record (unused slots: sentinel)
-// Unused candidate slots hold REC_SENTINEL coordinates.
+// Unused candidate slots hold REC_SENTINEL coordinates. The w words, two forms (RecGrid::packed):
+//   packed   : w of parts 0..3 all = (candidate count << 26) | first overflow record — the lane of a quad that fetched part j
+//              of ITS OWN record (the cooperative fetch reads part j of the records of lanes 0..3) has count and overflow
+//              reference in the word it loaded, no cross-lane traffic. Needs every count <= 63 and fewer than 2^26
+//              overflow records; the compiler falls back to the plain form otherwise.
+//   plain    : w of part 0 = candidate count, w of part 1 = first overflow record (count > cap)
 constexpr float REC_SENTINEL = 1.0e18f;
+constexpr uint32_t REC_EXT_BITS = 26u, REC_EXT_MASK = (1u << REC_EXT_BITS) - 1u, REC_COUNT_MAX = 63u;
 
 struct RecGrid
 {
@@ -391,6 +397,7 @@ struct RecGrid
   uint32_t rec_bytes32, ovf_bytes32;  // size of rec / ovf in bytes when below 4 GB (buffer loads), else 0
   int rec_parts;                      // 16-byte parts (= inline candidates) per voxel record: 4 (64 bytes) or 8 (128 bytes)
   uint32_t ti_empty;                  // index of the table's extra last entry, always -1 (lanes without a voxel read it)
+  int packed;                         // w words in the packed form (above)
 };
 
 // Grid-stride: every wavefront keeps its three tallies in scalar registers and a work-group issues three global atomics in
@@ -398,13 +405,14 @@ struct RecGrid
 __global__ __launch_bounds__(256) void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf,
                                                          long long n_vox, unsigned long long* __restrict__ hist3, uint32_t cap)
 {
-  __shared__ unsigned long long s_h[3];
-  if (threadIdx.x < 3)
+  __shared__ unsigned long long s_h[4];
+  if (threadIdx.x < 4)
     s_h[threadIdx.x] = 0ull;
   __syncthreads();
-  unsigned long long h_any = 0, h_4 = 0, h_8 = 0;  // wave-uniform
+  unsigned long long h_any = 0, h_4 = 0, h_8 = 0, h_max = 0;  // wave-uniform
   // hist3[0] = voxels with at least one candidate, [1] = voxels with more than four, [2] = with more than eight (the index
-  // picks its voxel edge and its record size from their ratios: host_map_compilers.h)
+  // picks its voxel edge and its record size from their ratios: host_map_compilers.h), [3] = with more than REC_COUNT_MAX
+  // (any of those: no packed w words)
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x; base < n_vox; base += stride)
   {
@@ -415,29 +423,32 @@ __global__ __launch_bounds__(256) void mc_count_overflow(const uint32_t* __restr
     h_any += static_cast<unsigned long long>(__popcll(__ballot(c > 0u)));
     h_4 += static_cast<unsigned long long>(__popcll(__ballot(c > 4u)));
     h_8 += static_cast<unsigned long long>(__popcll(__ballot(c > 8u)));
+    h_max += static_cast<unsigned long long>(__popcll(__ballot(c > REC_COUNT_MAX)));
   }
   if (hist3 && (threadIdx.x & 63) == 0)
   {
     atomicAdd(&s_h[0], h_any);
     atomicAdd(&s_h[1], h_4);
     atomicAdd(&s_h[2], h_8);
+    atomicAdd(&s_h[3], h_max);
   }
   __syncthreads();
-  if (hist3 && threadIdx.x < 3 && s_h[threadIdx.x])
+  if (hist3 && threadIdx.x < 4 && s_h[threadIdx.x])
     atomicAdd(&hist3[threadIdx.x], s_h[threadIdx.x]);
 }
 
 // cap = inline candidates per voxel record (4: 64-byte records, 8: 128-byte records); part j = {candidate j: x, y, z; w},
-// w of part 0 = candidate count, w of part 1 = first overflow record; candidates cap.. go to four-candidate overflow records
+// w words in the packed or the plain form (RecGrid); candidates cap.. go to four-candidate overflow records
 __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
                                  const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ kept_count,
                                  const uint32_t* __restrict__ ovf_start, float* __restrict__ rec,
-                                 float* __restrict__ ovf, long long n_vox, uint32_t cap)
+                                 float* __restrict__ ovf, long long n_vox, uint32_t cap, int packed)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vox)
     return;
   const uint32_t c = kept_count[v], src = pstart[v];
+  const uint32_t packed_w = (c << REC_EXT_BITS) | (c > cap ? ovf_start[v] : 0u);
   // unused candidate slots hold REC_SENTINEL: a point so far away that its d2 (~3e36, finite) never wins a minimum and
   // never passes the radius test, so a query may take the minimum over all inline slots without looking at the count
   float4* dst = reinterpret_cast<float4*>(rec) + static_cast<size_t>(cap) * v;
@@ -452,10 +463,18 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
       o.y = p.y;
       o.z = p.z;
     }
-    if (k == 0)
-      o.w = __uint_as_float(c);
-    if (k == 1)
-      o.w = __uint_as_float(c > cap ? ovf_start[v] : 0u);
+    if (packed)
+    {
+      if (k < 4)
+        o.w = __uint_as_float(packed_w);
+    }
+    else
+    {
+      if (k == 0)
+        o.w = __uint_as_float(c);
+      if (k == 1)
+        o.w = __uint_as_float(c > cap ? ovf_start[v] : 0u);
+    }
     dst[k] = o;
   }
   if (c > cap)
@@ -555,7 +574,7 @@ __global__ void mc_compact_points(const float4* __restrict__ pts, const uint32_t
 // voxels of EXISTING bricks referenced become orphans: counted into *orphaned.
 __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int* __restrict__ sub_main, uint32_t ovf_base,
                                    uint32_t n_bricks_old, long long n_sub_vox, float4* __restrict__ rec,
-                                   unsigned long long* __restrict__ orphaned, uint32_t cap)
+                                   unsigned long long* __restrict__ orphaned, uint32_t cap, int packed)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_sub_vox)
@@ -566,12 +585,31 @@ __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int
   const size_t src = static_cast<size_t>(v) * cap;
   if (brick < n_bricks_old)
   {
-    const uint32_t old_count = __float_as_uint(rec[dst].w);
+    const uint32_t w0 = __float_as_uint(rec[dst].w);
+    const uint32_t old_count = packed ? w0 >> REC_EXT_BITS : w0;
     if (old_count > cap)
       atomicAdd(orphaned, static_cast<unsigned long long>((old_count - cap + 3u) / 4u));
   }
-  const float4 r0 = sub_rec[src];
+  float4 r0 = sub_rec[src];
   float4 r1 = sub_rec[src + 1];
+  if (packed)
+  {
+    // the caller made sure ovf_base + (the sub-compile's overflow records) stays below 2^26: the sum cannot carry into the count
+    const uint32_t w = __float_as_uint(r0.w);
+    const uint32_t moved = (w >> REC_EXT_BITS) > cap ? w + ovf_base : w;
+    r0.w = __uint_as_float(moved);
+    r1.w = __uint_as_float(moved);
+    rec[dst + 0] = r0;
+    rec[dst + 1] = r1;
+    for (uint32_t k = 2; k < cap; ++k)
+    {
+      float4 rk = sub_rec[src + k];
+      if (k < 4)
+        rk.w = __uint_as_float(moved);
+      rec[dst + k] = rk;
+    }
+    return;
+  }
   if (__float_as_uint(r0.w) > cap)
     r1.w = __uint_as_float(__float_as_uint(r1.w) + ovf_base);
   rec[dst + 0] = r0;

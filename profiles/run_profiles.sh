@@ -15,4 +15,9 @@ for SET in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" "SQ_WAVES SQ_INS
   timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/pmc_$NAME" -o "$TAG" -- $BENCH > "$OUT/pmc_$NAME.log" 2>&1
   echo "pmc [$SET] rc=$?"
 done
-find "$OUT" -name "*.csv" | head -40
+# summaries next to the raw data, then drop the per-dispatch CSVs (gpurun merges at most 64 MiB of gpurun_out/ back)
+python profiles/summarize_pmc.py "$TAG" --out "$OUT"
+find "$OUT" -name "*_counter_collection.csv" -delete
+find "$OUT"/pmc_* -name "*_kernel_trace.csv" -delete
+find "$OUT" -name "*_kernel_trace.csv" -size +4M -delete
+du -sh "$OUT"

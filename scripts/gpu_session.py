@@ -8,6 +8,7 @@ parameterised form of the seven near-identical round-2 session drivers (r02_run1
   --suite        python -m pytest tests -m gpu (+ the C4 / C5 tests with their worst-case print-outs)
   --workloads    bench lines: C2 (full), jittered C2, C3, C3 stress, C1, C2 strict, C2 with the RCCL call, C4 shards, C5 shard
   --shapes       bench lines of the launch-bound shapes (4096 x 96 ... 100 000 x 96)
+  --prep         scripts/time_scan_prep.py plain and under rocprofv3 --kernel-trace --stats (launch count of the scan preparation)
   --profiles W.. profiles/run_profiles.sh for the named workloads (kernel stats + separate PMC passes)"""
 import argparse
 import json
@@ -21,6 +22,7 @@ ap.add_argument("--suite", action="store_true")
 ap.add_argument("--workloads", action="store_true")
 ap.add_argument("--shapes", action="store_true")
 ap.add_argument("--profiles", nargs="*", default=[])
+ap.add_argument("--prep", action="store_true")
 args = ap.parse_args()
 OUT = "gpurun_out/" + args.tag
 os.makedirs(OUT, exist_ok=True)
@@ -76,4 +78,8 @@ for w in args.profiles:
     extra = " --particles 8192" if w == "C5" else ""
     wl = "C2 --map-jitter 0.045" if w == "C2j" else w   # C2j = C2 on the map of displaced points (voxel-filter centroids)
     sh("bash profiles/run_profiles.sh %s_%s --workload %s%s" % (args.tag, w, wl, extra), "prof_%s.log" % w, 900)
+if args.prep:
+    sh("python scripts/time_scan_prep.py 50", "prep_plain.log", 300)
+    sh("cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv "
+       "-d %s/prep_stats -o prep -- python scripts/time_scan_prep.py 50" % OUT, "prep_under_rocprof.log", 400)
 print("total %.0f s" % (time.time() - T0))

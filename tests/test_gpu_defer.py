@@ -1,0 +1,116 @@
+"""Deferred overflow rounds of the tile-major likelihood kernel (likelihood_kernels.h: DeferQueue / defer_drain) and the packed
+w words of the voxel records (map_compiler.h) against the plain forms: a minimum over the same candidates, the same term
+arithmetic and the same fixed-order fp64 sums — likelihoods, match ratios and (strict_order) reference-order sums are
+bit-identical, on maps where few, a quarter and most of the voxels hold more than four candidates."""
+import numpy as np
+import pytest
+
+from mcl_3dl_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def crowded_scene(jitter, n_p, n_s, seed=5, extra_copies=0):
+    sc = make_scene(n=61, n_p=n_p, n_s=n_s, n_b=0, seed=seed, map_jitter=jitter)
+    if extra_copies:
+        # several points per lattice site, a few centimetres apart: most voxels of the candidate index overflow, many hold
+        # more than eight candidates (two and more overflow records per evaluation)
+        rng = np.random.default_rng(seed + 1)
+        parts = [sc.map_xyz] + [sc.map_xyz + rng.uniform(-0.03, 0.03, sc.map_xyz.shape).astype(np.float32)
+                                for _ in range(extra_copies)]
+        sc.map_xyz = np.ascontiguousarray(np.concatenate(parts, 0), np.float32)
+        sc.map_label = np.zeros(len(sc.map_xyz), np.uint32)
+    return sc
+
+
+def run(engine, sc, n_p, n_s, defer, packed=1, parts=4, group=0, strict=0, stamp=9000, dist_weight=(1.0, 1.0, 5.0), ratio=0.0):
+    try:
+        engine.set_option("cand_voxel_ratio", ratio)
+        engine.set_option("cand_record_parts", parts)
+        engine.set_option("cand_packed", packed)
+        engine.set_option("lik_defer", defer)
+        engine.set_option("lik_group", group)
+        engine.set_option("strict_order", strict)
+        engine.set_option("lik_tiled_min", 256)
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=stamp, dist_weight=dist_weight)
+        engine.set_likelihood_params()
+        lik, ratio, _beam = engine.measure_batch(sc.poses[:n_p], sc.scan_lik[:n_s])
+        st = engine.index_stats()
+        active = int(engine.get_option("lik_defer_active")), int(engine.get_option("cand_packed_active"))
+        return lik.copy(), ratio.copy(), st, active
+    finally:
+        engine.set_option("cand_voxel_ratio", 0.0)
+        engine.set_option("cand_record_parts", 0)
+        engine.set_option("cand_packed", 1)
+        engine.set_option("lik_defer", 1)
+        engine.set_option("lik_group", 0)
+        engine.set_option("strict_order", 2)
+        engine.set_option("lik_tiled_min", 1024)
+
+
+@pytest.mark.parametrize("jitter,copies", [(0.0, 0), (0.045, 0), (0.02, 10)])
+@pytest.mark.parametrize("n_p,n_s", [(64, 1500), (300, 4096), (37, 2049)])
+def test_deferred_equals_immediate(engine, jitter, copies, n_p, n_s):
+    sc = crowded_scene(jitter, n_p, n_s, extra_copies=copies)
+    ratio = 0.5 if copies else 0.0   # eleven points per site in voxels of r / 2: most of them overflow, many twice and more
+    a = run(engine, sc, n_p, n_s, defer=0, stamp=9001, ratio=ratio)
+    b = run(engine, sc, n_p, n_s, defer=1, stamp=9001, ratio=ratio)
+    assert b[3] == (1, 1) and a[3][0] == 0
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    assert np.count_nonzero(b[0] != 1.0) > 0
+    if copies:
+        assert b[2]["voxels_with_overflow"] > 0.45 * b[2]["voxels_with_candidates"]
+        assert b[2]["voxels_over8"] > 0.1 * b[2]["voxels_with_candidates"]
+
+
+@pytest.mark.parametrize("group", [4, 8, 32])
+def test_every_particle_group_size(engine, group):
+    sc = crowded_scene(0.045, 200, 3000)
+    a = run(engine, sc, 200, 3000, defer=0, group=group, stamp=9002)
+    b = run(engine, sc, 200, 3000, defer=1, group=group, stamp=9002)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_packed_words_equal_plain_words_on_every_query_path(engine):
+    """tiled (immediate), per-particle and wide-record kernels read the packed form; the plain form stays available."""
+    sc = crowded_scene(0.045, 96, 2500)
+    for n_s in (2500, 700, 100):   # tiled / likelihood_kernel<256> / likelihood_kernel<64>
+        ref = run(engine, sc, 96, n_s, defer=0, packed=0, stamp=9003)
+        assert ref[3] == (0, 0)
+        for parts in (4, 8):
+            got = run(engine, sc, 96, n_s, defer=0, packed=1, parts=parts, stamp=9003)
+            assert got[3][1] == 1
+            np.testing.assert_array_equal(ref[0], got[0])
+            np.testing.assert_array_equal(ref[1], got[1])
+
+
+def test_strict_order_terms_go_through_the_queue_unchanged(engine):
+    sc = crowded_scene(0.045, 64, 3000)
+    a = run(engine, sc, 64, 3000, defer=0, strict=1, stamp=9004)
+    b = run(engine, sc, 64, 3000, defer=1, strict=1, stamp=9004)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_modes_follow_the_map(engine):
+    """lik_defer = 1 (default): the queue wherever the records are packed 64-byte ones — a map of centroids is then built with
+    those instead of 128-byte records; lik_defer = 2: only where more than lik_defer_min_frac of the voxels overflow."""
+    lattice = crowded_scene(0.0, 64, 2048)
+    crowded = crowded_scene(0.045, 64, 2048)
+    try:
+        engine.set_likelihood_params()
+        for mode, want in ((1, (1, 1)), (2, (0, 1)), (0, (0, 0))):
+            engine.set_option("lik_defer", mode)
+            engine.set_map(lattice.map_xyz, lattice.map_label, stamp=9005 + 10 * mode, dist_weight=(1.0, 1.0, 5.0))
+            engine.measure_batch(lattice.poses[:64], lattice.scan_lik[:2048])
+            assert int(engine.get_option("lik_defer_active")) == want[0]
+            engine.set_map(crowded.map_xyz, crowded.map_label, stamp=9006 + 10 * mode, dist_weight=(1.0, 1.0, 5.0))
+            engine.measure_batch(crowded.poses[:64], crowded.scan_lik[:2048])
+            assert int(engine.get_option("lik_defer_active")) == want[1]
+            if mode:
+                assert engine.index_stats()["record_parts"] == 4   # never the 128-byte records once the queue is available
+    finally:
+        engine.set_option("lik_defer", 1)
+        engine.set_map(lattice.map_xyz, lattice.map_label, stamp=9007, dist_weight=(1.0, 1.0, 5.0))
