@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--lik-defer", type=int, default=-1,
                     help="overflow rounds of the tiled kernel deferred and run densely: 0 never, 1 whenever the records allow it, "
                          "2 on crowded maps (library default); -1 = leave the default")
+    ap.add_argument("--cand-packed", type=int, default=-1, help="packed w words in the voxel records (library default 1)")
     ap.add_argument("--cand-record-parts", type=int, default=-1,
                     help="inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map (-1 = default)")
     ap.add_argument("--lik-wide", type=int, default=-1,
@@ -622,6 +623,8 @@ def main():
         eng.set_option("cand_record_parts", args.cand_record_parts)
     if args.lik_defer >= 0:
         eng.set_option("lik_defer", args.lik_defer)
+    if args.cand_packed >= 0:
+        eng.set_option("cand_packed", args.cand_packed)
     if args.strict_order >= 0:
         eng.set_option("strict_order", args.strict_order)
     strict_mode = int(eng.get_option("strict_order"))
