@@ -45,18 +45,41 @@ __device__ inline uint32_t spread10(uint32_t v)
   return v;
 }
 
-// 30-bit Morton key of a likelihood scan point: 0.25 m cells from the cloud's minimum corner, clamped to 10 bits per axis
-__device__ inline uint32_t morton_scan_key(const float4 p, const float* __restrict__ min3)
+// Morton key of a likelihood scan point: 0.25 m cells from the cloud's minimum corner, 10 bits per axis, of which the
+// MCL3DL_MORTON_BITS most significant bits the cloud's extent can set are kept (mm6 = the cloud's {min x, y, z, max x, y, z},
+// device memory). The order only decides which evaluations share a work-group. 22 bits hold the whole key of a cloud up to
+// 32 m across (128 cells per axis) — three radix passes instead of the four a 30-bit key costs, two launches each — and drop
+// the lowest bits of larger ones (cells of 0.5 m up to 64 m, ...). Measured at C2 / C5 / the map of centroids with 16, 22 and
+// 30 bits (scripts/r03_s22.sh): likelihood kernel within 1 % of each other (16 bits: +0.5..1 %), host-buffer update 1-2 %
+// faster with fewer passes. api_core.inl:order_scan makes the same key on the host.
+#ifndef MCL3DL_MORTON_BITS
+#define MCL3DL_MORTON_BITS 22   // (A/B builds: 16 / 30)
+#endif
+__device__ inline uint32_t morton_key_drop(const float* __restrict__ mm6)
+{
+  uint32_t cells = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    const float e = (mm6[3 + a] - mm6[a]) * 4.0f;
+    const uint32_t c = (e >= 0.f) ? (e < 1023.f ? static_cast<uint32_t>(e) : 1023u) : 0u;
+    cells = c > cells ? c : cells;
+  }
+  const uint32_t bits = cells ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(cells))) : 0u;
+  return 3u * bits > MCL3DL_MORTON_BITS ? 3u * bits - MCL3DL_MORTON_BITS : 0u;
+}
+
+__device__ inline uint32_t morton_scan_key(const float4 p, const float* __restrict__ mm6)
 {
   const float c[3] = { p.x, p.y, p.z };
   uint32_t q[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
   {
-    const float f = (c[a] - min3[a]) * 4.0f;
+    const float f = (c[a] - mm6[a]) * 4.0f;
     q[a] = (f >= 0.f) ? (f < 1023.f ? static_cast<uint32_t>(f) : 1023u) : 0u;
   }
-  return spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+  return (spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2)) >> morton_key_drop(mm6);
 }
 
 // squared range of a beam point from its scan origin, as float bits (non-negative floats order like unsigned ints)

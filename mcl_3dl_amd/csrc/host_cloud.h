@@ -442,7 +442,7 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
     kg.pts = ctx->sp_samp[0].as<float4>();
     kg.min3 = ctx->cl_minmax.as<float>();
     const RsFinal fin{ ctx->sp_samp[0].as<float4>(), ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>(), 1 };
-    TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, ns, 30, &fin));
+    TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, ns, MCL3DL_MORTON_BITS, &fin));
   }
   if (n_o)
   {

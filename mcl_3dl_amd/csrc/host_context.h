@@ -156,6 +156,7 @@ struct mcl3dl_hip_ctx
 
   // work buffers
   size_t n_pose_uploaded = 0;  // poses `pose` holds from mcl3dl_hip_upload_poses / the last host-buffer call
+  DevBuf upd_block;  // measure_update: { stats4 | weights | lik | ratio | beam } in one allocation, so that the results go home in ONE copy
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
       tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset,
       packed;  // 2 + 2N doubles: this rank's record of a device group's all-reduce (host_group.h)
@@ -361,6 +362,31 @@ int d2h(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
     }
   }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+// One D2H copy of `bytes` from `src`, handed out in pieces at sync_stream(): piece = { caller's array (may be null: skipped),
+// offset into the block, bytes }. Falls back to one copy per piece when the block does not fit the staging memory.
+struct D2hPiece
+{
+  void* user;
+  size_t offset, bytes;
+};
+
+int d2h_block(mcl3dl_hip_ctx* ctx, const void* src, size_t bytes, const D2hPiece* pieces, int n_pieces)
+{
+  void* p = bytes <= STAGE_MAX_COPY ? stage_alloc(ctx, bytes) : nullptr;
+  if (!p)
+  {
+    for (int i = 0; i < n_pieces; ++i)
+      if (pieces[i].user)
+        TRY(d2h(ctx, pieces[i].user, static_cast<const char*>(src) + pieces[i].offset, pieces[i].bytes));
+    return 0;
+  }
+  HIP_TRY(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  for (int i = 0; i < n_pieces; ++i)
+    if (pieces[i].user && pieces[i].bytes)
+      ctx->stage_out.push_back({ pieces[i].user, static_cast<char*>(p) + pieces[i].offset, pieces[i].bytes });
   return 0;
 }
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>

@@ -38,7 +38,7 @@ constexpr int RS_MAX_ELEMS = 524288;                              // above: rocp
 enum
 {
   RS_KEY_ARRAY = 0,   // keys (and values, or the index when vals == nullptr) come from arrays
-  RS_KEY_MORTON = 1,  // 30-bit Morton key of a likelihood scan point (api_core.inl:order_scan)
+  RS_KEY_MORTON = 1,  // 22-bit Morton key of a likelihood scan point (cloud_keys.h, api_core.inl:order_scan)
   RS_KEY_RANGE = 2,   // squared range of a beam point from its origin, as float bits
   RS_KEY_LEAF = 3     // pcl::VoxelGrid leaf index
 };
@@ -48,7 +48,7 @@ struct RsKeyGen
   const uint32_t* keys;
   const uint32_t* vals;
   const float4* pts;
-  const float* min3;       // RS_KEY_MORTON: minimum corner of the cloud (device memory)
+  const float* min3;       // RS_KEY_MORTON: the cloud's {min x, y, z, max x, y, z} (device memory)
   const float4* origins;   // RS_KEY_RANGE
   uint32_t n_o;
   int* error;              // RS_KEY_RANGE: set to 2 when a point names an origin that does not exist
