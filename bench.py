@@ -838,8 +838,10 @@ def main():
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:
             coop = bool(lik_coop and args.lik_index == 2)
-            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %s>" % (group, args.lik_index, 4 if group == 32 else 8,
-                                                                       "true" if coop else "false")
+            defer = bool(coop and int(eng.get_option("lik_defer_active")))
+            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %s, %s>" % (group, args.lik_index, 4 if group == 32 else 8,
+                                                                           "true" if coop else "false",
+                                                                           "true" if defer else "false")
         elif small:
             kernel_name = "likelihood_small_kernel<"
         else:
