@@ -453,6 +453,33 @@ def in_process_group_run(workload, n_cfg, extra_cfg, dist_weight, devices, steps
         g.close()
 
 
+def in_process_group_child(args, n_dev, timeout_s=240):
+    """The in-process group over n_dev GPUs in a process of its OWN (`bench.py --in-process`), with a time limit: the N-rank
+    RCCL bring-up inside one process has never run on more than one GPU before the driver's scaling run, and a hang there
+    must cost this extra key, not the line. The child sees every GPU and none of the launcher's rendezvous variables."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                        "MASTER_ADDR", "MASTER_PORT", "GROUP_WORLD_SIZE", "ROLE_NAME")
+           and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process", "--gpus", str(n_dev), "--workload", args.workload,
+           "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.particles:
+        cmd += ["--particles", str(args.particles)]
+    if args.scan_points:
+        cmd += ["--scan-points", str(args.scan_points)]
+    if args.beam_points:
+        cmd += ["--beam-points", str(args.beam_points)]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "bench.py --in-process --gpus %d did not finish within %d s" % (n_dev, timeout_s)}
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": "bench.py --in-process --gpus %d: rc %d: %s" % (n_dev, p.returncode, (p.stderr or p.stdout)[-300:])}
+    return json.loads(lines[-1])["in_process_group"]
+
+
 def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
     """SURVEY.md 8f-2 / 8f-4 timings (run last: they replace the context's scan): scan preparation of an accumulated cloud
     (VoxelGrid with the node's default leaf, both clips, sample gather, device-side ordering) and the matched / unmatched
@@ -1168,8 +1195,11 @@ def main():
         # one-process-per-GPU figures above: a group of 1 with the RCCL call in the loop on one GPU, of all N on a node
         if not args.no_extras or world > 1:
             try:
-                out["in_process_group"] = in_process_group_run(args.workload, n_cfg, extra_cfg, dist_weight,
-                                                               list(range(world)), args.steps, args.warmup)
+                if world == 1:
+                    out["in_process_group"] = in_process_group_run(args.workload, n_cfg, extra_cfg, dist_weight,
+                                                                   [0], args.steps, args.warmup)
+                else:
+                    out["in_process_group"] = in_process_group_child(args, world)
             except Exception as e:  # never lose the line over the side measurement
                 out["in_process_group"] = {"error": str(e)[-300:]}
         line = json.dumps(out)

@@ -109,3 +109,21 @@ def test_strong_scaling_mode_and_the_multi_rank_report_with_one_rank():
     o = d["other_scaling"]
     assert o["scaling"] == "weak" and o["particles_total"] == 64 and o["value"] > 1e8
     assert d["kernels_ms_per_step"]["collective"] > 0.0
+
+
+def test_in_process_group_in_a_child_process_ignores_the_launcher_environment(monkeypatch):
+    """Under torch.distributed.run rank 0 measures the N-GPU in-process group in a child `bench.py --in-process` with a time
+    limit (bench.py:in_process_group_child); the child must not inherit the launcher's rendezvous variables."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "2"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "1"),
+                 ("TORCHELASTIC_RUN_ID", "x")):
+        monkeypatch.setenv(k, v)
+    a = argparse.Namespace(workload="C1", steps=3, warmup=1, particles=0, scan_points=0, beam_points=0)
+    g = bench.in_process_group_child(a, 1)
+    assert "error" not in g, g
+    assert g["n_gpus"] == 1 and g["collective"] == "rccl" and g["value"] > 0
+    # a time limit that cannot be met is reported, not raised
+    g = bench.in_process_group_child(a, 1, timeout_s=0.05)
+    assert "did not finish" in g["error"]
