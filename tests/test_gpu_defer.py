@@ -114,3 +114,60 @@ def test_modes_follow_the_map(engine):
     finally:
         engine.set_option("lik_defer", 1)
         engine.set_map(lattice.map_xyz, lattice.map_label, stamp=9007, dist_weight=(1.0, 1.0, 5.0))
+
+
+def sphere_cluster(centre, n, radius, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return (np.asarray(centre, np.float32) + radius * d).astype(np.float32)
+
+
+def test_a_voxel_with_more_than_63_candidates_keeps_the_plain_words(engine):
+    """150 points on a 2 cm sphere: each is the nearest neighbour of the queries in its direction, so the voxels around the
+    cluster keep far more than 63 candidates — the count no longer fits the packed word, the compiler writes the plain
+    form, the queue stays off, and the answers are those of the cell scan (lik_index = 0) bit for bit."""
+    sc = crowded_scene(0.0, 64, 2048)
+    near = sc.map_xyz[np.argmin(np.linalg.norm(sc.map_xyz - (sc.true_pose[:3] + np.array([2.0, 0.0, 0.0], np.float32)), axis=1))]
+    sc.map_xyz = np.ascontiguousarray(np.concatenate([sc.map_xyz, sphere_cluster(near, 150, 0.02, 3)], 0), np.float32)
+    sc.map_label = np.zeros(len(sc.map_xyz), np.uint32)
+    got = run(engine, sc, 64, 2048, defer=1, stamp=9100)
+    assert got[3] == (0, 0), got[3]
+    try:
+        engine.set_option("lik_index", 0)
+        engine.set_option("lik_tiled_min", 256)
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=9101, dist_weight=(1.0, 1.0, 5.0))
+        want = engine.measure_batch(sc.poses[:64], sc.scan_lik[:2048])
+    finally:
+        engine.set_option("lik_index", 2)
+        engine.set_option("lik_tiled_min", 1024)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+
+
+def test_a_map_update_that_does_not_fit_the_packed_words_rebuilds_the_index():
+    from mcl_3dl_amd import capi
+    sc = crowded_scene(0.0, 48, 1500)
+    near = sc.map_xyz[np.argmin(np.linalg.norm(sc.map_xyz - (sc.true_pose[:3] + np.array([2.0, 0.0, 0.0], np.float32)), axis=1))]
+    cluster = sphere_cluster(near, 150, 0.02, 4)
+    a, b = capi.Engine(0), capi.Engine(0)
+    try:
+        for e in (a, b):
+            e.set_likelihood_params()
+            e.set_option("lik_tiled_min", 256)
+        a.set_map(sc.map_xyz, None, stamp=1, dist_weight=(1.0, 1.0, 5.0))
+        a.measure_batch(sc.poses[:48], sc.scan_lik[:1500])
+        assert int(a.get_option("cand_packed_active")) == 1
+        n_map, stats = a.map_update(cluster, None, leaf=(0.0005, 0.0005, 0.0005), stamp=2)
+        assert stats["outcome"] == 7, stats          # "does not fit the packed words": the next query rebuilds
+        merged = a.map_download()[0]
+        assert n_map == len(merged) == len(sc.map_xyz) + len(cluster)
+        got = a.measure_batch(sc.poses[:48], sc.scan_lik[:1500])
+        assert int(a.get_option("cand_packed_active")) == 0 and int(a.get_option("lik_defer_active")) == 0
+        b.set_map(merged, None, stamp=3, dist_weight=(1.0, 1.0, 5.0))
+        want = b.measure_batch(sc.poses[:48], sc.scan_lik[:1500])
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+    finally:
+        a.close()
+        b.close()
