@@ -53,6 +53,8 @@ int mcl3dl_hip_abi_version(void);
 /* Replaces: construction of the two LiDAR models + kd-tree in MCL3dlNode (src/mcl_3dl.cpp:1315-1329). */
 /* Number of HIP devices this process sees (0 when there is none: the library has no CPU path). */
 int mcl3dl_hip_device_count(void);
+/* The environment variable MCL3DL_HIP_OPTIONS ("name=value,name=value", names of mcl3dl_hip_set_option) is applied to every
+ * context at creation; an entry that mcl3dl_hip_set_option rejects fails the creation (-3, reason on stderr). */
 int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id);
 void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx);
 const char* mcl3dl_hip_last_error(const mcl3dl_hip_ctx* ctx);

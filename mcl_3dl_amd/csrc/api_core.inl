@@ -42,6 +42,36 @@ int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
     return -2;
   }
   beam_refresh(ctx);
+  // MCL3DL_HIP_OPTIONS="name=value,name=value": tuning knobs (mcl3dl_hip_set_option) for a deployment that cannot change the
+  // code that creates the context — and for running the whole test suite on a non-default kernel selection. A bad entry
+  // fails the creation (a silently ignored knob is worse than no context).
+  if (const char* env = getenv("MCL3DL_HIP_OPTIONS"))
+  {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size())
+    {
+      size_t end = all.find_first_of(",;", pos);
+      if (end == std::string::npos)
+        end = all.size();
+      std::string item = all.substr(pos, end - pos);
+      pos = end + 1;
+      const size_t first = item.find_first_not_of(" \t"), last = item.find_last_not_of(" \t");
+      if (first == std::string::npos)
+        continue;
+      item = item.substr(first, last - first + 1);
+      const size_t eq = item.find('=');
+      char* tail = nullptr;
+      const double v = eq == std::string::npos ? 0.0 : strtod(item.c_str() + eq + 1, &tail);
+      if (eq == std::string::npos || eq == 0 || tail == item.c_str() + eq + 1 || *tail != '\0' ||
+          mcl3dl_hip_set_option(ctx, item.substr(0, eq).c_str(), v) != 0)
+      {
+        fprintf(stderr, "mcl3dl_hip_create: MCL3DL_HIP_OPTIONS entry '%s' rejected (%s)\n", item.c_str(), ctx->err.c_str());
+        mcl3dl_hip_destroy(ctx);
+        return -3;
+      }
+    }
+  }
   *out = ctx;
   return 0;
 }

@@ -171,3 +171,23 @@ def test_a_map_update_that_does_not_fit_the_packed_words_rebuilds_the_index():
     finally:
         a.close()
         b.close()
+
+
+def test_options_from_the_environment(monkeypatch):
+    from mcl_3dl_amd import capi
+    monkeypatch.setenv("MCL3DL_HIP_OPTIONS", "lik_defer=0, cand_packed=0;strict_order=1")
+    e = capi.Engine(0)
+    try:
+        assert (int(e.get_option("lik_defer")), int(e.get_option("cand_packed")), int(e.get_option("strict_order"))) == (0, 0, 1)
+    finally:
+        e.close()
+    for bad in ("lik_defer=7", "no_such_option=1", "lik_defer", "lik_defer=abc"):
+        monkeypatch.setenv("MCL3DL_HIP_OPTIONS", bad)
+        with pytest.raises(Exception):
+            capi.Engine(0)
+    monkeypatch.setenv("MCL3DL_HIP_OPTIONS", "")
+    e = capi.Engine(0)
+    try:
+        assert int(e.get_option("lik_defer")) == 1 and int(e.get_option("cand_packed")) == 1
+    finally:
+        e.close()
