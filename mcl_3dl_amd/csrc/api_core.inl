@@ -41,12 +41,6 @@ int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
     delete ctx;
     return -2;
   }
-  if (hipMalloc(&ctx->pf_tickets.p, 256) != hipSuccess || hipMemset(ctx->pf_tickets.p, 0, 256) != hipSuccess)
-  {
-    mcl3dl_hip_destroy(ctx);
-    return -2;
-  }
-  ctx->pf_tickets.cap = 256;
   beam_refresh(ctx);
   // MCL3DL_HIP_OPTIONS="name=value,name=value": tuning knobs (mcl3dl_hip_set_option) for a deployment that cannot change the
   // code that creates the context — and for running the whole test suite on a non-default kernel selection. A bad entry
@@ -507,21 +501,6 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(pf_fused_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
                        static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4);
-    TRY(timing_end(ctx, ep));
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  if (ctx->pf_ticket && ctx->strict_order != 1 && n_p <= static_cast<size_t>(std::min(ctx->pf_ticket_max, PF_TICKET_MAX)))
-  {
-    // more particles than one work-group takes, few enough for the last work-group to normalise them all: one launch
-    const int nb = pf_blocks(n_p);   // <= 64 here: a ticket tree of at most 8 + 1 counters
-    TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
-    TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * nb));
-    EventPair ep{};
-    TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-    hipLaunchKernelGGL(pf_ticket_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
-                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>(),
-                       ctx->pf_tickets.as<unsigned>(), ctx->partial4.as<double>(), d_stats4);
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     return 0;

@@ -178,19 +178,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_coop = value != 0.0;
     return 0;
   }
-  if (key == "pf_ticket" || key == "pf_ticket_max")
-  {
-    if (key == "pf_ticket")
-      ctx->pf_ticket = value != 0.0 ? 1 : 0;
-    else
-    {
-      if (!(value >= 0.0 && value <= PF_TICKET_MAX))
-        return ctx->fail(-3, "pf_ticket_max must be in [0, %d]", PF_TICKET_MAX);
-      ctx->pf_ticket_max = static_cast<int>(value);
-    }
-    ++ctx->generation;  // a captured update graph holds the other kernels
-    return 0;
-  }
   if (key == "lik_defer")
   {
     if (!(value == 0.0 || value == 1.0 || value == 2.0))
@@ -305,8 +292,6 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_group") *value = ctx->lik_group;
   else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
   else if (key == "lik_coop") *value = ctx->lik_coop;
-  else if (key == "pf_ticket") *value = ctx->pf_ticket;
-  else if (key == "pf_ticket_max") *value = ctx->pf_ticket_max;
   else if (key == "lik_defer") *value = ctx->lik_defer;
   else if (key == "lik_defer_min_frac") *value = ctx->lik_defer_min_frac;
   else if (key == "lik_defer_active") *value = lik_defer_active(ctx) ? 1.0 : 0.0;

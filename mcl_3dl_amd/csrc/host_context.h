@@ -107,7 +107,6 @@ struct mcl3dl_hip_ctx
   int update_small = 1;
   int update_small_max = 512;
   DevBuf us_tickets;
-  DevBuf pf_tickets;              // pf_ticket_kernel's arrival counters (allocated and zeroed at creation; the kernel leaves them zero)
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
@@ -116,8 +115,6 @@ struct mcl3dl_hip_ctx
   int cand_refine = 1;
   int cand_refine_above = 4;
   uint32_t cand_parts = 4;        // what the current index was built with
-  int pf_ticket = 1;              // option: pf::measure of the single-GPU entry points as ONE launch (arrival tickets) between
-  int pf_ticket_max = 16384;      // pf_fused_max and this many particles
   int cand_packed = 1;            // option: packed w words in the voxel records when the map allows it (map_compiler.h)
   int lik_defer = 1;              // option: overflow rounds of the tiled kernel deferred and run densely: 0 never, 1 always
                                   // (packed 64-byte records), 2 = when more than lik_defer_min_frac of the voxels overflow

@@ -126,121 +126,6 @@ __device__ __forceinline__ bool last_of_tree(unsigned* tree, int idx, int width)
   return true;
 }
 
-// ---- pf::measure alone in one launch (single GPU, more particles than pf_fused_kernel's one work-group takes) -----------
-// pf_partial_kernel's grid with two more stages behind arrival tickets: the work-group whose arrival completes the ticket
-// tree runs pf_reduce_kernel's 64-lane reduction over the block partials and then pf_apply_kernel's normalisation for ALL
-// particles (one work-group: n / 256 divisions per thread — a few microseconds up to 16 384 particles, less than the two
-// launches it replaces). Same arithmetic in the same association as the three kernels: bit-identical.
-constexpr int PF_TICKET_MAX = 16384;
-
-__global__ __launch_bounds__(PF_BLOCK) void pf_ticket_kernel(float* __restrict__ w, const float* __restrict__ lik,
-                                                             const float* __restrict__ beam, const float* __restrict__ extra,
-                                                             const float* __restrict__ ratio, int n, float* __restrict__ w_new,
-                                                             double* __restrict__ block_partials, unsigned* __restrict__ tickets,
-                                                             double* __restrict__ packed, float* __restrict__ stats4)
-{
-  // pf_partial_kernel
-  double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;
-  for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
-  {
-    float l = 1.0f;
-    if (beam)
-      l *= beam[i];
-    l *= lik[i];
-    if (extra)
-      l = l * extra[i];
-    const float wn = w[i] * l;  // pf.h:258
-    store_agent(w_new + i, wn);
-    s += static_cast<double>(wn);
-    if (wn > 0.0f)
-      t += static_cast<double>(wn) * log(static_cast<double>(wn));
-    if (ratio)
-    {
-      const double r = static_cast<double>(ratio[i]);
-      rmax = r > rmax ? r : rmax;
-      rneg = -r > rneg ? -r : rneg;
-    }
-  }
-  __shared__ double sh[4][PF_BLOCK / 64];
-  s = wave_sum(s);
-  t = wave_sum(t);
-  rmax = wave_max(rmax);
-  rneg = wave_max(rneg);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0)
-  {
-    sh[0][wave] = s;
-    sh[1][wave] = t;
-    sh[2][wave] = rmax;
-    sh[3][wave] = rneg;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    double a = 0, b = 0, c = sh[2][0], d = sh[3][0];
-    for (int k = 0; k < PF_BLOCK / 64; ++k)
-    {
-      a += sh[0][k];
-      b += sh[1][k];
-      c = sh[2][k] > c ? sh[2][k] : c;
-      d = sh[3][k] > d ? sh[3][k] : d;
-    }
-    store_agent(block_partials + 4 * blockIdx.x + 0, a);
-    store_agent(block_partials + 4 * blockIdx.x + 1, b);
-    store_agent(block_partials + 4 * blockIdx.x + 2, c);
-    store_agent(block_partials + 4 * blockIdx.x + 3, d);
-  }
-  const int nb = static_cast<int>(gridDim.x);
-  if (!last_of_tree(tickets, static_cast<int>(blockIdx.x), nb))
-    return;
-  // pf_reduce_kernel (world = 1)
-  __shared__ double tot[4];
-  if (wave == 0)
-  {
-    double a = 0, b = 0, c = 0.0, d = -1.0;
-    for (int k = lane; k < nb; k += 64)
-    {
-      a += load_agent(block_partials + 4 * k + 0);
-      b += load_agent(block_partials + 4 * k + 1);
-      const double ck = load_agent(block_partials + 4 * k + 2), dk = load_agent(block_partials + 4 * k + 3);
-      c = ck > c ? ck : c;
-      d = dk > d ? dk : d;
-    }
-    a = wave_sum(a);
-    b = wave_sum(b);
-    c = wave_max(c);
-    d = wave_max(d);
-    if (lane == 0)
-    {
-      tot[0] = a;
-      tot[1] = b;
-      tot[2] = c;
-      tot[3] = d;
-      packed[0] = a;
-      packed[1] = b;
-      packed[2] = c;
-      packed[3] = d;
-    }
-  }
-  __syncthreads();
-  // pf_apply_kernel
-  const double S = tot[0];
-  const float sum_f = static_cast<float>(S);
-  const bool alive = sum_f > 0.0f;
-  if (alive)
-    for (int i = threadIdx.x; i < n; i += PF_BLOCK)
-      w[i] = load_agent(w_new + i) / sum_f;
-  if (threadIdx.x == 0 && stats4)
-  {
-    stats4[0] = alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf("");
-    stats4[1] = static_cast<float>(-tot[3]);
-    stats4[2] = static_cast<float>(tot[2]);
-    stats4[3] = alive ? 0.0f : 1.0f;
-  }
-  for (int k = threadIdx.x; k < ticket_tree_size(nb); k += PF_BLOCK)
-    tickets[k] = 0u;  // ready for the next launch
-}
-
 template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
 {
