@@ -141,6 +141,10 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
 // a few microseconds each around ~1 us of work. The arithmetic is the three kernels' own, in the same association (the
 // 256-thread "blocks" of pf_partial_kernel become quarters of this 1024-thread group that walk the same elements, the
 // 64-lane reduce runs in the first wavefront), so weights, entropy and ratio bounds are bit-identical to the split form.
+// Measured and NOT kept (round 3, commit 5b571a1): pf_partial_kernel's grid with the reduce and the apply run by the last
+// work-group behind an arrival-ticket tree, for 1024 < n <= 16 384 — bit-identical, and the group cost 24 us instead of
+// 12.5 us at 4096 particles (49 at 16 384): three launches enqueued back to back cost 4.2 us each, less than two ticket
+// levels plus one work-group's sc1 loads of every weight (profiles/r03z_pf_one_launch_ab.txt).
 constexpr int PF_FUSED_MAX = 4096;
 
 __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, const float* __restrict__ lik,
