@@ -92,16 +92,16 @@ def test_bench_lines_of_the_profiled_shapes_keep_their_fractions_below_one():
 
 def test_round3_kernel_name_selects_the_round3_counters():
     """The tiled kernel gained a template parameter (DEFER) in round 3: the name bench.py builds must select the counters of
-    that instantiation (profiles/r03s_*), not fall back to the round-2 kernel's; DESIGN.md 6.0's fractions follow from them."""
+    that instantiation (profiles/r03z_*), not fall back to the round-2 kernel's; DESIGN.md 6.0's fractions follow from them."""
     for tag in ("C2", "C3", "C5", "C2j"):
         pmc, src = bench.pmc_counters("void mcl3dl::likelihood_tiled_kernel<16, 2, 8, true, true>", tag)
         assert pmc and os.path.basename(src).startswith("r03"), (tag, src)
     pmc, src = bench.pmc_counters("void mcl3dl::likelihood_tiled_kernel<16, 2, 8, true, true>", "C2")
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03s_bench_C2_full.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03z_bench_C2_full.json")))
     res, _t = bench.kernel_resources(pmc, d["roofline"]["avg_launch_ms"] * 1e-3, bench.valu_costs()[0], "test", bench.l2_calibration())
-    assert abs(res["valu_issue"]["frac"] - 0.631) < 0.005
-    assert abs(res["l2_requests"]["frac"] - 0.920) < 0.005
-    assert abs(res["valu_issue_priced"]["frac"] - 0.92) < 0.02
+    assert abs(res["valu_issue"]["frac"] - 0.620) < 0.005
+    assert abs(res["l2_requests"]["frac"] - 0.904) < 0.005
+    assert abs(res["valu_issue_priced"]["frac"] - 0.90) < 0.02
     assert res["hbm"]["frac"] < 0.03
     for r in res.values():
         assert r["frac"] <= 1.0

@@ -191,3 +191,46 @@ def test_options_from_the_environment(monkeypatch):
         assert int(e.get_option("lik_defer")) == 1 and int(e.get_option("cand_packed")) == 1
     finally:
         e.close()
+
+
+def irregular_map(name, rng):
+    if name == "clutter":       # hundreds of points per cubic metre: dozens of candidates per voxel (may exceed 63: plain words)
+        return rng.uniform(-2.0, 2.0, (60000, 3))
+    if name == "plane":         # a noisy plane: crowded voxels in a sheet
+        return np.stack([rng.uniform(-3, 3, 40000), rng.uniform(-3, 3, 40000), rng.normal(0, 0.01, 40000)], 1)
+    if name == "duplicates":    # eight exactly coincident copies of each point
+        return np.repeat(rng.uniform(-1, 1, (500, 3)), 8, 0)
+    return np.concatenate([rng.uniform(-2.0, 2.0, (8000, 3)), np.repeat(rng.uniform(-1, 1, (300, 3)), 8, 0),
+                           rng.uniform(-6, 6, (300, 3))], 0)
+
+
+@pytest.mark.parametrize("name", ["clutter", "plane", "duplicates", "mix"])
+@pytest.mark.parametrize("ratio", [0.0, 0.5, 1.0])
+def test_irregular_maps_through_the_tiled_kernel(engine, name, ratio):
+    """Random clutter, a noisy sheet, exactly coincident points: the tiled kernel with the queue (or, where a voxel exceeds 63
+    candidates, with the plain words and immediate rounds) against the cell scan (lik_index = 0), bit for bit."""
+    rng = np.random.default_rng(abs(hash(name)) % 1000 + int(ratio * 10))
+    m = irregular_map(name, rng).astype(np.float32)
+    scan = (m[rng.integers(0, len(m), 4096)] + rng.normal(0, 0.08, (4096, 3))).astype(np.float32)
+    poses = np.zeros((24, 7), np.float32)
+    poses[:, :3] = rng.normal(0, 0.05, (24, 3))
+    poses[:, 3:6] = rng.normal(0, 0.01, (24, 3))
+    poses[:, 6] = 1.0
+    out = {}
+    try:
+        engine.set_likelihood_params(match_dist_min=0.2, match_dist_flat=0.0, match_weight=1.0)
+        engine.set_option("cand_voxel_ratio", ratio)
+        for mode in (0, 2):
+            engine.set_option("lik_index", mode)
+            engine.set_map(m, None, stamp=9300 + mode, dist_weight=(1.0, 2.0, 5.0) if name == "mix" else None)
+            out[mode] = engine.measure_batch(poses, scan)
+            if mode == 2:
+                st = engine.index_stats()
+                assert st["deferred_overflow"] == st["packed_words"]   # the queue whenever the words are packed
+    finally:
+        engine.set_option("lik_index", 2)
+        engine.set_option("cand_voxel_ratio", 0.0)
+        engine.set_likelihood_params()
+    np.testing.assert_array_equal(out[0][0], out[2][0])
+    np.testing.assert_array_equal(out[0][1], out[2][1])
+    assert out[2][1].max() > 0.2
