@@ -403,9 +403,17 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       quarter of the voxels hold more candidates than a record has room for
  *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
  *   "cand_record_parts" inline candidates per voxel record: 4 (64-byte records), 8 (128-byte records: one 128-byte line
- *                       per lookup, all eight loads issued together), 0 (default) = 4, or 8 together with the smaller
- *                       voxel edge on a crowded map when the records stay below 16 GB (measured: -7 % on such a map,
- *                       +20 % on a lattice). Read-only: "cand_record_parts_in_use", "cand_voxels_over8"
+ *                       per lookup, all eight loads issued together), 0 (default) = 4 — or, only when "lik_defer" is 0, 8
+ *                       together with the smaller voxel edge on a crowded map when the records stay below 16 GB.
+ *                       Read-only: "cand_record_parts_in_use", "cand_voxels_over8"
+ *   "lik_defer"         1 (default) = the tiled kernel queues the evaluations whose voxel holds more than four candidates
+ *                       per wavefront and runs their overflow rounds densely (needs "cand_packed" records of 4 parts; same
+ *                       bits, -5 % on a lattice, -7..-15 % on maps of voxel-filter centroids); 0 = overflow rounds at once;
+ *                       2 = the queue only where more than "lik_defer_min_frac" (0.03) of the voxels overflow.
+ *                       Read-only: "lik_defer_active"
+ *   "cand_packed"       1 (default) = every part of a voxel record carries (candidate count << 26) | first overflow record
+ *                       when the map allows it (every count <= 63, fewer than 2^26 overflow records), else — and with 0 —
+ *                       count and reference in parts 0 and 1. Read-only: "cand_packed_active"
  *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= "lik_tiled_min" points and >= 4
  *                       particles; 0 = one work-group per particle always (only the fp64 summation order differs)
  *   "lik_tiled_min"     default 1024; with >= 256 particles the tiled kernel already takes over at three quarters of it

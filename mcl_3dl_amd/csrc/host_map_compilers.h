@@ -623,10 +623,11 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
   const double crowded = forced == 8 ? ctx->cand_over8 : ctx->cand_stats[5];  // voxels whose candidates do not fit the record
   if (ctx->lik_index == 2 && ctx->cand_stats[4] > 0 && crowded / ctx->cand_stats[4] > 0.25)
   {
-    // a crowded map (voxel-filter centroids rather than a lattice): smaller voxels, and — unless the record size is forced —
-    // 128-byte records with eight inline candidates when they stay below 16 GB (estimated from the first build: a voxel of
-    // 0.36 r has (0.5 / 0.36)^3 times as many of them). Measured on the jittered C2 map: 0.42 ms (0.5 r, 64 B) -> 0.364
-    // (0.36 r, 64 B) -> 0.338 (0.36 r, 128 B); on a lattice the wide record costs 20 %, so it is never the default there.
+    // a crowded map (voxel-filter centroids rather than a lattice): smaller voxels, and — unless the record size is forced
+    // or the tiled kernel queues its overflow rounds (below) — 128-byte records with eight inline candidates when they stay
+    // below 16 GB (estimated from the first build: a voxel of 0.36 r has (0.5 / 0.36)^3 times as many of them). Measured on
+    // the jittered C2 map with immediate overflow rounds: 0.42 ms (0.5 r, 64 B) -> 0.364 (0.36 r, 64 B) -> 0.338 (0.36 r,
+    // 128 B); on a lattice the wide record costs 20 %, so it is never the default there.
     const double first_ms = ctx->cand_stats[3];
     const bool defer = ctx->lik_defer != 0 && ctx->cand_packed != 0 && ctx->rg.packed != 0;
     const double fine = 0.36;  // with the queue: 0.30 r measured 1.6 % faster at +-0.045 m, 2.6 % slower at +-0.02 m, twice the memory
