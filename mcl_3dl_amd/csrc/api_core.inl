@@ -41,6 +41,11 @@ int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
     delete ctx;
     return -2;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+      ctx->n_cus = cus;
+  }
   beam_refresh(ctx);
   // MCL3DL_HIP_OPTIONS="name=value,name=value": tuning knobs (mcl3dl_hip_set_option) for a deployment that cannot change the
   // code that creates the context — and for running the whole test suite on a non-default kernel selection. A bad entry

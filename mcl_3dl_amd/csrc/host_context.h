@@ -115,6 +115,7 @@ struct mcl3dl_hip_ctx
   int cand_refine = 1;
   int cand_refine_above = 4;
   uint32_t cand_parts = 4;        // what the current index was built with
+  int n_cus = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int cand_packed = 1;            // option: packed w words in the voxel records when the map allows it (map_compiler.h)
   int lik_defer = 1;              // option: overflow rounds of the tiled kernel deferred and run densely: 0 never, 1 always
                                   // (packed 64-byte records), 2 = when more than lik_defer_min_frac of the voxels overflow

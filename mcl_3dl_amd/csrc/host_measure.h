@@ -402,7 +402,15 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           if (strict_terms && d_lik)
           {
 #define LAUNCH_STRICT(GG)                                                                                             \
-  hipLaunchKernelGGL(lik_strict_sum_kernel<GG>, dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, ns, np, d_lik)
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (n_groups > ctx->n_cus)                                                                                        \
+      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 32768>), dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, \
+                         ns, np, d_lik);                                                                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 65536>), dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, \
+                         ns, np, d_lik);                                                                              \
+  } while (0)
             switch (G)
             {
               case 4:

@@ -1093,12 +1093,16 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
 // Measured and NOT kept (round 3, C5: 512 groups x 65 536 terms, 0.68 ms): 32 KB chunks with two chunks in flight in
 // registers and two work-groups per CU (0.91 ms: slower), and two adjacent groups per work-group so that 512 groups run in
 // one round of 256 work-groups (0.68 ms: no change) — the kernel reads its 2.1 GB of terms at ~3.1 TB/s either way.
-template <int G>
+// CHUNK = bytes of terms per LDS buffer: 65536 (one work-group per CU: 2 x 64 KB) while the groups fit the chip in one round,
+// 32768 (two work-groups per CU) beyond — the kernel is bound by the adder's dependent chain (~11 cycles per term: 65 536
+// terms = 0.31 ms per group, profiles/r03z_C5_pmc_summary.csv), so 512 groups in ONE round of two per CU beat two rounds:
+// C5 likelihood group 2.48-2.60 -> 2.40-2.42 ms; at 256 groups the smaller chunk costs 2 % (scripts/r03_s27.sh).
+template <int G, int CHUNK>
 __global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
                                                              float* __restrict__ out_lik)
 {
   constexpr int Q = G / 4;               // float4s per row
-  constexpr int ROWS = 65536 / (4 * G);  // rows per chunk (64 KB of terms)
+  constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk
   constexpr int LD = ROWS + 4;           // padded row length of the transposed buffer (keeps 16-byte alignment)
   constexpr int LOADERS = 192;
   constexpr int PER = (ROWS * Q + LOADERS - 1) / LOADERS;
