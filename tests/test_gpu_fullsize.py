@@ -131,3 +131,41 @@ def test_strict_order_with_more_particle_groups_than_cus(engine, oracle_kind, n_
     wl, wq = o.likelihood_measure(sc.poses[idx], sc.scan_lik)
     np.testing.assert_array_equal(lik[idx], wl)
     np.testing.assert_array_equal(ratio[idx], wq)
+
+
+def test_c2_on_a_map_of_centroids(engine, oracle_kind):
+    """C2's sizes on the map whose points are displaced inside their voxels (a voxel-filtered real map: a quarter of the
+    candidate voxels overflow their record): the default path — 64-byte packed records, overflow rounds queued per wavefront —
+    against the reference on a slice, against the immediate rounds and against the cell scan bit for bit."""
+    sc = make_config("C2", map_jitter=0.045)
+    engine.set_likelihood_params()
+    try:
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=950, dist_weight=(1.0, 1.0, 1.0))
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        st = engine.index_stats()
+        assert st["deferred_overflow"] == 1 and st["packed_words"] == 1 and st["record_parts"] == 4
+        assert st["voxels_with_overflow"] > 0.2 * st["voxels_with_candidates"]
+        o = pyoracle.Oracle(oracle_kind)
+        o.set_map(sc.map_xyz, sc.map_label, dist_weight=(1.0, 1.0, 1.0))
+        o.set_likelihood_params(pyoracle.LikelihoodParams())
+        idx = np.arange(0, len(sc.poses), len(sc.poses) // 32)[:32]
+        wl, wq = o.likelihood_measure(sc.poses[idx], sc.scan_lik)
+        np.testing.assert_allclose(lik[idx], wl, rtol=1e-5)
+        np.testing.assert_array_equal(ratio[idx], wq)
+        sub = sc.poses[:512]
+        engine.set_option("lik_defer", 0)
+        engine.set_option("cand_record_parts", 4)
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=951, dist_weight=(1.0, 1.0, 1.0))
+        l0, r0, _ = engine.measure_batch(sub, sc.scan_lik)
+        engine.set_option("lik_index", 0)
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=952, dist_weight=(1.0, 1.0, 1.0))
+        lc, rc, _ = engine.measure_batch(sub, sc.scan_lik)
+    finally:
+        engine.set_option("lik_index", 2)
+        engine.set_option("lik_defer", 1)
+        engine.set_option("cand_record_parts", 0)
+    # (the particle groups of a 512-particle launch are the first 32 groups of the 4096-particle launch: same sums)
+    np.testing.assert_array_equal(l0, lik[:512])
+    np.testing.assert_array_equal(r0, ratio[:512])
+    np.testing.assert_array_equal(lc, lik[:512])
+    np.testing.assert_array_equal(rc, ratio[:512])
