@@ -91,7 +91,8 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
  * scan_beam_origin[i] = PointXYZIL::label of beam point i = index into origins. Any out_* may be NULL. */
 /* Upload the particle poses once per update; measure_batch calls with pose == NULL and the same n_p then use them. The
  * node asks each model separately (src/mcl_3dl.cpp:409-415): with this the drop-in classes send the poses once per
- * pf::measure, not once per model. Any host-buffer call that is given a pose array replaces the uploaded set. */
+ * pf::measure, not once per model. Any host-buffer call that is given a pose array replaces the uploaded set. The pose array
+ * may be reused as soon as the call returns (it does not wait for the stream unless the copy could not be staged). */
 int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, size_t n_p);
 int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7 or NULL*/, size_t n_p,
                              const float* scan_lik_xyz /*n_s*3*/, size_t n_s, const float* scan_beam_xyz /*n_b*3*/,

@@ -661,8 +661,13 @@ int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
   HIP_TRY(hipSetDevice(ctx->device));
   ctx->n_pose_uploaded = 0;
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
-  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
-  TRY(sync_stream(ctx));  // the staging copy is done with the caller's array
+  bool staged = false;
+  TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p, &staged));
+  // a staged copy is done with the caller's array already: no need to wait for the stream (the call that uses the poses
+  // synchronises, and recycles the staging memory); a direct copy from the caller's memory — or a pile of unsynchronised
+  // uploads — is waited for here
+  if (!staged || ctx->stage_pending > (8u << 20))
+    TRY(sync_stream(ctx));
   ctx->n_pose_uploaded = n_p;
   return 0;
 }

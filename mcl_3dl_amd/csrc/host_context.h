@@ -157,6 +157,7 @@ struct mcl3dl_hip_ctx
 
   // work buffers
   size_t n_pose_uploaded = 0;  // poses `pose` holds from mcl3dl_hip_upload_poses / the last host-buffer call
+  size_t stage_pending = 0;       // bytes staged for H2D copies since the last sync_stream
   DevBuf upd_block;  // measure_update: { stats4 | weights | lik | ratio | beam } in one allocation, so that the results go home in ONE copy
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
       tested, ray_begin, ray_end, ray_status, ray_hit, mom_blocks, mom_arg, mom_out, mom_idx, subset,
@@ -331,8 +332,12 @@ void* stage_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
   return p;
 }
 
-int h2d(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+// *staged (optional) = the caller's array has been copied into page-locked staging memory: it may be reused as soon as this
+// returns, whatever the stream is doing (the staging memory itself is recycled by the next sync_stream).
+int h2d(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes, bool* staged = nullptr)
 {
+  if (staged)
+    *staged = bytes == 0;
   if (bytes == 0)
     return 0;
   if (bytes <= STAGE_MAX_COPY)
@@ -341,6 +346,9 @@ int h2d(mcl3dl_hip_ctx* ctx, void* dst, const void* src, size_t bytes)
     {
       memcpy(p, src, bytes);
       HIP_TRY(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+      ctx->stage_pending += bytes;
+      if (staged)
+        *staged = true;
       return 0;
     }
   }
@@ -400,6 +408,7 @@ int sync_stream(mcl3dl_hip_ctx* ctx)
   ctx->stage_out.clear();
   ctx->stage_cur = 0;
   ctx->stage_off = 0;
+  ctx->stage_pending = 0;
   return 0;
 }
 
