@@ -356,14 +356,27 @@ static int push_scan(mcl3dl_hip_ctx* ctx, const OrderedScan& o, bool sync_at_end
 {
   const size_t n_s = o.lik.size(), n_b = o.beam.size(), n_o = o.origins.size();
   HIP_TRY(hipSetDevice(ctx->device));
-  TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
-  TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
-  TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
-  TRY(ensure(ctx, ctx->origins, sizeof(float4) * n_o));
-  TRY(h2d(ctx, ctx->scan_perm.p, o.perm.data(), sizeof(uint32_t) * n_s));
-  TRY(h2d(ctx, ctx->scan_lik.p, o.lik.data(), sizeof(float4) * n_s));
-  TRY(h2d(ctx, ctx->scan_beam.p, o.beam.data(), sizeof(float4) * n_b));
-  TRY(h2d(ctx, ctx->origins.p, o.origins.data(), sizeof(float4) * n_o));
+  size_t off[4];
+  TRY(ensure_scan_block(ctx, n_s, n_b, n_o, off));
+  const void* src[4] = { o.perm.data(), o.lik.data(), o.beam.data(), o.origins.data() };
+  const size_t bytes[4] = { sizeof(uint32_t) * n_s, sizeof(float4) * n_s, sizeof(float4) * n_b, sizeof(float4) * n_o };
+  const size_t total = off[3] + bytes[3];
+  void* staged = total <= STAGE_MAX_COPY ? stage_alloc(ctx, total) : nullptr;
+  if (staged)
+  {
+    // the four arrays in the block's own layout, ONE copy (the gaps between the parts travel too: < 1 KB)
+    for (int k = 0; k < 4; ++k)
+      if (bytes[k])
+        memcpy(static_cast<char*>(staged) + off[k], src[k], bytes[k]);
+    HIP_TRY(hipMemcpyAsync(ctx->scan_block.p, staged, total, hipMemcpyHostToDevice, ctx->stream));
+    ctx->stage_pending += total;
+  }
+  else
+  {
+    DevBuf* dst[4] = { &ctx->scan_perm, &ctx->scan_lik, &ctx->scan_beam, &ctx->origins };
+    for (int k = 0; k < 4; ++k)
+      TRY(h2d(ctx, dst[k]->p, src[k], bytes[k]));
+  }
   if (sync_at_end)
     TRY(sync_stream(ctx));
   if (n_b > ctx->pow_table_len)

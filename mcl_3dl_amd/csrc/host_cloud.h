@@ -429,10 +429,7 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
     TRY(ensure(ctx, ctx->cl_key[k], sizeof(uint32_t) * (n_max + 1)));
     TRY(ensure(ctx, ctx->cl_val[k], sizeof(uint32_t) * (n_max + 1)));
   }
-  TRY(ensure(ctx, ctx->scan_perm, sizeof(uint32_t) * n_s));
-  TRY(ensure(ctx, ctx->scan_lik, sizeof(float4) * n_s));
-  TRY(ensure(ctx, ctx->scan_beam, sizeof(float4) * n_b));
-  TRY(ensure(ctx, ctx->origins, sizeof(float4) * n_o));
+  TRY(ensure_scan_block(ctx, n_s, n_b, n_o));
   if (n_s)
   {
     const long long ns = static_cast<long long>(n_s);

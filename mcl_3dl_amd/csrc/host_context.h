@@ -10,12 +10,13 @@ struct DevBuf
 {
   void* p = nullptr;
   size_t cap = 0;
+  bool view = false;  // p points into another DevBuf's allocation (ensure_scan_block): never freed, never grown by ensure()
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf()
   {
-    if (p)
+    if (p && !view)
       (void)hipFree(p);
   }
   template <typename T>
@@ -99,6 +100,7 @@ struct mcl3dl_hip_ctx
   // reference's own float rounding (a random walk of n_s roundings) reaches the 1e-5 tolerance of north_star; 0 = never
   int strict_order = 2;
   int strict_auto_min = 32768;
+  DevBuf scan_block;  // { perm | lik scan | beam scan | origins } of the current update in ONE allocation (ensure_scan_block)
   DevBuf scan_perm, strict_terms;
   // the whole update as one launch (update_kernels.h) up to update_small_max particles when the per-particle likelihood
   // kernel would run anyway: same bits, two to four launches fewer. Measured (profiles/r03*_update_small.txt): ahead of the
@@ -285,6 +287,8 @@ int ensure(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t bytes)
     bytes = 16;
   if (b.cap >= bytes)
     return 0;
+  if (b.view)
+    return ctx->fail(-2, "internal: ensure() on a view buffer");
   if (b.p)
   {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -296,6 +300,35 @@ int ensure(mcl3dl_hip_ctx* ctx, DevBuf& b, size_t bytes)
   HIP_TRY(hipMalloc(&b.p, cap));
   b.cap = cap;
   ++ctx->generation;  // a captured update graph holds the old address
+  return 0;
+}
+
+// The per-update scan arrays as views into ONE device block, laid out for the current sizes: { permutation (n_s uint32) |
+// likelihood scan (n_s float4) | beam scan (n_b float4) | origins (n_o float4) }, each part on a 256-byte boundary — a
+// host-ordered scan then goes up in ONE copy instead of four (each small copy costs ~4 us on the device: at the reference's
+// own sizes the four of them were a third of a host-buffer update). off4 (optional) = the parts' byte offsets.
+int ensure_scan_block(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, size_t n_o, size_t* off4 = nullptr)
+{
+  const auto up = [](size_t b) { return (std::max<size_t>(b, 16) + 255) & ~static_cast<size_t>(255); };
+  const size_t part[4] = { up(sizeof(uint32_t) * n_s), up(sizeof(float4) * n_s), up(sizeof(float4) * n_b), up(sizeof(float4) * n_o) };
+  const size_t total = part[0] + part[1] + part[2] + part[3];
+  TRY(ensure(ctx, ctx->scan_block, total));
+  DevBuf* view[4] = { &ctx->scan_perm, &ctx->scan_lik, &ctx->scan_beam, &ctx->origins };
+  size_t off = 0;
+  bool moved = false;
+  for (int k = 0; k < 4; ++k)
+  {
+    void* at = ctx->scan_block.as<char>() + off;
+    moved = moved || view[k]->p != at;
+    view[k]->p = at;
+    view[k]->cap = part[k];
+    view[k]->view = true;
+    if (off4)
+      off4[k] = off;
+    off += part[k];
+  }
+  if (moved)
+    ++ctx->generation;  // a captured update graph holds the old addresses
   return 0;
 }
 

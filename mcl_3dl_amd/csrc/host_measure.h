@@ -499,7 +499,6 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
       ctx->strict_order == 1 || !ctx->has_scan || !d_lik || !d_ratio || !d_beam)
     return 0;
   const int ns = static_cast<int>(ctx->n_s);
-  LikPlan plan;
   if (ns > 0)
   {
     // (decided without plan_lik's buffer allocations: the tiled form needs per-tile partials this path never touches)
