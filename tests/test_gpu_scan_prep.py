@@ -220,3 +220,31 @@ def test_scans_ordered_on_the_device_equal_scans_ordered_on_the_host(engine):
             engine.measure_batch(sc.poses, lik, beam, np.full(len(beam), 3, np.uint32), sc.origins)
     finally:
         engine.set_option("scan_order_device", d)
+
+
+@pytest.mark.parametrize("reach", [40.0, 130.0, 400.0])
+def test_device_and_host_ordering_agree_when_the_morton_key_drops_bits(engine, reach):
+    """The scan ordering keeps the 22 most significant Morton bits the scan's extent can set (cloud_keys.h): a scan wider than
+    32 m drops low bits, one wider than 256 m also clamps cells — host and device must still make the same keys (same
+    permutation: bit-identical results, also through strict_order's replay in original order)."""
+    sc = make_scene(n=91, n_p=40, n_s=5000, n_b=0, seed=15)
+    rng = np.random.default_rng(3)
+    far = (rng.uniform(-1.0, 1.0, (300, 3)) * np.array([reach, reach, 0.1 * reach])).astype(np.float32)
+    lik = np.ascontiguousarray(np.concatenate([sc.scan_lik, far, sc.scan_lik[:200]], 0))
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=8302)
+    engine.set_likelihood_params()
+    d = engine.get_option("scan_order_device")
+    out = {}
+    try:
+        for strict in (0, 1):
+            engine.set_option("strict_order", strict)
+            for where in (0, 1):
+                engine.set_option("scan_order_device", where)
+                out[(strict, where)] = engine.measure_batch(sc.poses, lik)
+    finally:
+        engine.set_option("scan_order_device", d)
+        engine.set_option("strict_order", 2)
+    for strict in (0, 1):
+        for a, b in zip(out[(strict, 0)], out[(strict, 1)]):
+            np.testing.assert_array_equal(a, b)
+    assert np.count_nonzero(out[(0, 1)][1]) > 0
