@@ -564,6 +564,10 @@ def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
 
 def main():
     args = parse()
+    if os.environ.get("MCL3DL_BENCH_TRACE_HANG"):
+        # debugging aid: every thread's Python stack on stderr after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MCL3DL_BENCH_TRACE_HANG"]), exit=True)
     import torch
     import torch.distributed as dist
     from mcl_3dl_amd import capi
@@ -603,6 +607,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # MCL3DL_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0 with the collective over gloo — RCCL refuses two ranks on one
+    # device — so that the multi-rank control flow of this file (shards, both scaling modes, barriers, MAX over ranks, the
+    # in-process child) runs on a one-GPU box before the driver's N-GPU run. The line says so; its numbers mean nothing.
+    share_gpu = os.environ.get("MCL3DL_BENCH_SHARE_GPU") == "1" and world > 1
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -611,7 +621,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         # RCCL writes a version banner through C stdio when its communicator comes up; push it out NOW so that rank 0's
         # JSON line is the last thing on stdout
         warm = torch.zeros(1, device=dev)
@@ -734,8 +747,15 @@ def main():
     n_p = main_sh.n
 
     def rewarm(seconds=0.1):
-        """Side measurements follow host-only stretches (D2H of results, the CPU baseline): bring the clocks back first."""
-        keep_gpu_warm(lambda: step(main_sh), seconds, lambda: torch.cuda.synchronize(dev))
+        """Side measurements follow host-only stretches (D2H of results, the CPU baseline): bring the clocks back first.
+        Rank-local work only — the single-GPU entry point, NO collective: rank 0 runs its extras alone while the other ranks
+        wait at the final barrier (with step() here, the all-reduce inside it hung a two-rank run:
+        tests/test_gpu_bench_contract.py::test_two_ranks_through_the_launcher_on_one_gpu)."""
+        def local_step():
+            main_sh.d_w.copy_(main_sh.d_w0)
+            eng.update_device(main_sh.d_pose, main_sh.n, main_sh.d_w, main_sh.d_stats, d_lik=main_sh.d_lik,
+                              d_ratio=main_sh.d_ratio, d_beam=main_sh.d_beam if n_b else None)
+        keep_gpu_warm(local_step, seconds, lambda: torch.cuda.synchronize(dev))
 
     # first call builds + uploads the map structures (outside every timed region)
     step(main_sh)
@@ -956,7 +976,9 @@ def main():
                                " + beam (DDA) %d rays/particle" % n_b if n_b else "", args.dist_weight_z),
                 "particles_total": n_total, "particles_per_gpu": n_p, "scan_points": n_s, "beam_points": n_b,
                 "map_points": int(len(sc.map_xyz)),
-                "parallelism": ("particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world if use_dist else
+                "parallelism": (("TEST MODE MCL3DL_BENCH_SHARE_GPU: %d ranks on ONE GPU, collective over gloo — control flow only, "
+                                 "the numbers mean nothing" % world) if share_gpu else
+                                "particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world if use_dist else
                                 "one GPU, mcl3dl_hip_update_device (measure + pf::measure in one call, no collective)"),
                 "update_hz": 1e3 / ms_per_step,
                 "accumulate": ("likelihood terms and weights added as floats in the reference's order (bit-identical results)"

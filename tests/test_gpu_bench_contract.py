@@ -127,3 +127,29 @@ def test_in_process_group_in_a_child_process_ignores_the_launcher_environment(mo
     # a time limit that cannot be met is reported, not raised
     g = bench.in_process_group_child(a, 1, timeout_s=0.05)
     assert "did not finish" in g["error"]
+
+
+def test_two_ranks_through_the_launcher_on_one_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` exactly as the driver launches it, with
+    MCL3DL_BENCH_SHARE_GPU=1 putting both ranks on cuda:0 (collective over gloo): the multi-rank control flow — shards of both
+    scaling modes, barriers, MAX over ranks, the in-process child and its failure report (two GPUs are not there), rank 0
+    printing the one line last — runs before the driver's N-GPU run does."""
+    env = dict(os.environ, MCL3DL_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "3", "--warmup", "1",
+                           "--prewarm-ms", "20"], capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    d = json.loads(lines[-1])
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert "TEST MODE" in d["config"]["parallelism"]
+    assert d["config"]["particles_total"] == 2 * d["config"]["particles_per_gpu"]
+    assert d["other_scaling"]["scaling"] == "strong" and d["other_scaling"]["value"] > 0
+    assert d["kernels_ms_per_step"]["collective"] > 0
+    # the child that would drive both GPUs from one process reports why it could not: the line survives
+    assert "error" in d["in_process_group"] and "--gpus 2" in d["in_process_group"]["error"]
