@@ -453,7 +453,7 @@ def in_process_group_run(workload, n_cfg, extra_cfg, dist_weight, devices, steps
         g.close()
 
 
-def in_process_group_child(args, n_dev, timeout_s=240):
+def in_process_group_child(args, n_dev, timeout_s=120):
     """The in-process group over n_dev GPUs in a process of its OWN (`bench.py --in-process`), with a time limit: the N-rank
     RCCL bring-up inside one process has never run on more than one GPU before the driver's scaling run, and a hang there
     must cost this extra key, not the line. The child sees every GPU and none of the launcher's rendezvous variables."""
