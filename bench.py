@@ -20,22 +20,34 @@ N > 1 both are measured (the one not asked for under `other_scaling`).
 
 Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` and `cpu_baseline`.
 
-`roofline` (dominant kernel = the likelihood kernel): every fraction is <= 1 and tied to a resource —
-  hbm         HBM-side bytes per launch from the committed PMC pass (FETCH_SIZE x 2 + WRITE_SIZE, profiles/) / live
-              kernel time / 8 TB/s.  Small by construction: the index is built so that the working set of a scan tile
-              stays in one XCD's L2.
-  l2          L1->L2 read requests per launch (TCP_TCC_READ_REQ, PMC) x 128-byte lines / live kernel time / 34.5 TB/s
-  l1_access   L1 (TCP) cache-line accesses per launch (TCP_TOTAL_CACHE_ACCESSES, PMC) / (CUs x kernel cycles) against the
-              measured ceiling of ~1.15 accesses per cycle and CU (what bound the kernel before the cooperative fetch)
-  valu_issue  VALU wave-instructions per launch by class (SQ_INSTS_VALU and the per-class counters: PMC) x the measured
-              cycles per instruction of each class (profiles/valu_microbench.hip: plain f32 add/mul ~2.6, fma / min /
-              compares / conversions ~4.4, transcendental ~8.4) / (SIMDs x kernel cycles); classes the counters do not
-              split are priced between the two rates (frac_low .. frac_high, frac = their mean)
-`bound` names the largest; `achieved / peak / frac` repeat that entry.  The committed counters belong to ONE launch shape
-per workload tag (profiles/<session>_<tag>_pmc_summary.csv; C2j = C2 with --map-jitter): they are used only when their
-wavefront count equals this launch's — any other shape gets no fractions (`counters_note` says why).  The canonical algorithmic bytes of SURVEY.md
-§8d (27-cell structure, 16 + 27*4 + 16*K per evaluation) are kept as `algorithmic_bytes_per_launch`, NOT divided by
-the HBM peak: the shipped index never reads them (it reads 68 B per evaluation, from L2).
+`roofline` (dominant kernel = the likelihood kernel): every fraction is <= 1 and tied to a resource. Resources whose peak is
+a DOCUMENTED figure of /opt/skills/guides/MI355X_MICROARCH.md (`peak_kind` "documented"):
+  hbm          HBM-side bytes per launch from the committed PMC pass (FETCH_SIZE x 2 + WRITE_SIZE, profiles/) / live kernel
+               time / 8 TB/s.  Small by construction: the index is built so that the working set of a scan tile stays in one
+               XCD's L2 — `hbm_target` answers north_star's 40 %-of-HBM target explicitly ("not applicable", with the reason).
+  l2           L1->L2 read requests per launch (TCP_TCC_READ_REQ, PMC) x the bytes one request of THIS access pattern moves
+               (64: calibrated by profiles/l2_calib.hip, profiles/r03a_l2_calib.json) / live kernel time / 34.5 TB/s
+  valu_issue   wave64 VALU instructions per launch (SQ_INSTS_VALU, PMC) / live kernel time against 1024 SIMDs x 2.4 GHz / 2
+               cycles per instruction
+`bound` names the largest of these three; `achieved / peak / frac` repeat that entry.  Next to them, against ceilings this
+repository MEASURED on the part (`peak_kind` "measured", listed under `frac_vs_measured_peaks`, never as `frac`):
+  l2_requests        the request rate against what a kernel doing nothing but the quad-cooperative 64-byte record fetch
+                     sustains from an L2-resident set (profiles/l2_calib.hip)
+  l1_access          L1 (TCP) cache-line accesses per launch / (CUs x kernel cycles) against ~1.15 per cycle and CU (what bound
+                     the kernel before the cooperative fetch)
+  valu_issue_priced  the instruction mix by class (per-class PMC counters) x the measured cycles per instruction of each class
+                     (profiles/r02d_valu_microbench.txt: plain f32 add / mul / mov 2.44, fma / min / compares / conversions
+                     4.17, transcendental 8.18); classes the counters do not split are priced between the two rates
+                     (frac_low .. frac_high, frac = their mean)
+The committed counters belong to ONE launch shape per workload tag (profiles/<session>_<tag>_pmc_summary.csv; C2j = C2 with
+--map-jitter): they are used only when their wavefront count equals this launch's — any other shape gets no fractions
+(`counters_note` says why).  The canonical algorithmic bytes of SURVEY.md §8d (27-cell structure, 16 + 27*4 + 16*K per
+evaluation) are kept as `algorithmic_bytes_per_launch`, NOT divided by the HBM peak: the shipped index never reads them (it
+reads 68 B per evaluation, from L2).
+
+Environment (debugging / tests only): MCL3DL_BENCH_SHARE_GPU=1 puts every rank of a torch.distributed.run launch on cuda:0
+with the collective over gloo (the multi-rank control flow on a one-GPU box; the line announces the mode, its numbers mean
+nothing); MCL3DL_BENCH_TRACE_HANG=<seconds> dumps every thread's Python stack after that long and exits.
 """
 import argparse
 import contextlib
