@@ -392,6 +392,7 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
           ctx->stage_out.clear();
           ctx->stage_cur = 0;
           ctx->stage_off = 0;
+          ctx->stage_pending = 0;
           return rcs[r] = rc_a;
         }
         if (host_combine)
