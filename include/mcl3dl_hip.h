@@ -44,7 +44,9 @@ enum
   MCL3DL_KERNEL_LIKELIHOOD = 0,
   MCL3DL_KERNEL_BEAM = 1,
   MCL3DL_KERNEL_PF = 2,
-  MCL3DL_KERNEL_COUNT = 3
+  MCL3DL_KERNEL_UPDATE = 3, /* the whole update as one launch (<= update_small_max particles): likelihood + beam + pf::measure */
+  MCL3DL_KERNEL_STAGE = 4,  /* scan_stage_kernel of a host-buffer update: scan ordering + pose / weight take-over */
+  MCL3DL_KERNEL_COUNT = 5
 };
 
 int mcl3dl_hip_abi_version(void);
@@ -119,6 +121,15 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7*/, 
                               const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
                               float* out_beam, float* entropy, float* match_ratio_min, float* match_ratio_max,
                               int* restored);
+
+/* Page-locked host memory for the arrays of the host-buffer entry points. The reference keeps its particles in a
+ * std::vector (include/mcl_3dl/pf.h:457) and its scans in pcl::PointCloud objects; a caller that packs poses / scan
+ * points for this library anyway can pack them straight into a block from mcl3dl_hip_host_alloc: mcl3dl_hip_measure_update
+ * then reads such arrays where they lie (no staging copy, no DMA copy) and writes weight_inout / out_* arrays that lie in
+ * such a block directly from the update's last kernel. Arrays anywhere else keep working (staged through the library's
+ * own page-locked block). Blocks belong to the context (freed with it); host_free waits for the context's stream. */
+int mcl3dl_hip_host_alloc(mcl3dl_hip_ctx* ctx, size_t bytes, void** out);
+int mcl3dl_hip_host_free(mcl3dl_hip_ctx* ctx, void* p);
 
 /* Replaces: LidarMeasurementModelBeam::getBeamStatus (src/lidar_measurement_model_beam.cpp:157-192; used for the
  * debug markers at src/mcl_3dl.cpp:471-478) for n explicit rays. hit_index = map index of CastResult::point_
@@ -447,6 +458,13 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       reference's own 64 x 1000 case is latency-bound); 0 = never
  *   "beam_prepare"      1 (default) = launches of >= 32 768 rays take what depends only on (particle, origin) from a
  *                       small kernel instead of every ray recomputing it; 0 = never
+ *   "update_stage"      1 (default) = mcl3dl_hip_measure_update hands scans (<= 16 384 points per model), poses and prior
+ *                       weights to the device with ONE launch that also orders the scans (stage_kernels.h), 0 = upload +
+ *                       ordering as separate copies and launches (the path larger scans always take; same results)
+ *   "update_zero_copy"  1 (default) = that launch reads the arrays in page-locked host memory and the update's last
+ *                       kernel writes the results there; 0 = one H2D copy in front, one D2H copy behind
+ *   "pf_tail"           1 (default) = lik_finalize + pf::measure of up to 8192 particles on one GPU as ONE launch
+ *                       (pf_tail_kernel; bit-identical to the separate kernels), 0 = separate launches
  *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
  *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
  *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",

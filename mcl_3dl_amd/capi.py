@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # file is an error, never a reason to fall back to anything
 LIB_PATH = os.environ.get("MCL3DL_HIP_LIB") or os.path.join(_HERE, "libmcl3dl_hip.so")
 
-KERNEL_LIKELIHOOD, KERNEL_BEAM, KERNEL_PF = 0, 1, 2
+KERNEL_LIKELIHOOD, KERNEL_BEAM, KERNEL_PF, KERNEL_UPDATE, KERNEL_STAGE = 0, 1, 2, 3, 4
 BEAM_STATUS = {0: "SHORT", 1: "HIT", 2: "LONG", 3: "TOTAL_REFLECTION"}
 
 _f, _d, _sz, _u32, _u64, _i, _p = C.c_float, C.c_double, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p
@@ -34,6 +34,8 @@ SIGNATURES = {
     "mcl3dl_hip_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_pf_measure": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
+    "mcl3dl_hip_host_alloc": (_i, [_p, _sz, C.POINTER(_p)]),
+    "mcl3dl_hip_host_free": (_i, [_p, _p]),
     "mcl3dl_hip_beam_status": (_i, [_p, _p, _p, _sz, _p, _p]),
     "mcl3dl_hip_radius_search": (_i, [_p, _p, _sz, _f, _p, _p]),
     "mcl3dl_hip_device_count": (_i, []),
@@ -119,6 +121,25 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_benchloop = None
+
+
+def load_benchloop():
+    """tools/libmcl3dl_benchloop.so (measurement helper, not product): the timed host-buffer loop in C."""
+    global _benchloop
+    if _benchloop is None:
+        load_library()
+        path = os.path.join(os.path.dirname(_HERE), "tools", "libmcl3dl_benchloop.so")
+        if not os.path.exists(path):
+            raise EngineError("%s is missing: run __graft_entry__.build()" % path)
+        lib = C.CDLL(path)
+        fn = lib.mcl3dl_benchloop_measure_update
+        fn.restype = C.c_double
+        fn.argtypes = [_p, _p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _i, C.c_double, _p]
+        _benchloop = lib
+    return _benchloop
 
 
 def _np_f32(a, cols=None):
@@ -348,6 +369,56 @@ class Engine:
             len(og), _ptr(lik), _ptr(ratio), _ptr(beam), C.byref(ent), C.byref(rmin), C.byref(rmax), C.byref(rest)))
         return dict(weights=w, lik=lik, quality=ratio, beam=beam, entropy=float(ent.value),
                     match_ratio_min=float(rmin.value), match_ratio_max=float(rmax.value), restored=bool(rest.value))
+
+    def host_array(self, shape, dtype=np.float32):
+        """A numpy array in page-locked memory of this context (mcl3dl_hip_host_alloc): measure_update reads / writes such
+        arrays in place. The block lives as long as the engine (or until host_free(array))."""
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        n_bytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
+        out = C.c_void_p()
+        self._check(self.lib.mcl3dl_hip_host_alloc(self.h, n_bytes, C.byref(out)))
+        buf = (C.c_char * n_bytes).from_address(out.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = out.value
+        return arr
+
+    def host_free(self, arr):
+        base = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if base is None:
+            raise EngineError("host_free: not an array of host_array()")
+        self._check(self.lib.mcl3dl_hip_host_free(self.h, C.c_void_p(base)))
+
+    def measure_update_into(self, poses, weights_inout, scan_lik, scan_beam, scan_beam_origin, origins, out_lik, out_ratio,
+                            out_beam, extra=None):
+        """mcl3dl_hip_measure_update on the caller's own float32 C-contiguous arrays, nothing allocated or converted here
+        (weights are updated in place). Returns (entropy, match_ratio_min, match_ratio_max, restored)."""
+        ent, rmin, rmax, rest = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        n_s = 0 if scan_lik is None else len(scan_lik)
+        n_b = 0 if scan_beam is None else len(scan_beam)
+        n_o = 0 if origins is None else len(origins)
+        self._check(self.lib.mcl3dl_hip_measure_update(
+            self.h, _ptr(poses), _ptr(extra), _ptr(weights_inout), len(poses), _ptr(scan_lik), n_s, _ptr(scan_beam),
+            _ptr(scan_beam_origin), n_b, _ptr(origins), n_o, _ptr(out_lik), _ptr(out_ratio), _ptr(out_beam), C.byref(ent),
+            C.byref(rmin), C.byref(rmax), C.byref(rest)))
+        return float(ent.value), float(rmin.value), float(rmax.value), bool(rest.value)
+
+    def time_measure_update(self, poses, w0, w, scan_lik, scan_beam, scan_beam_origin, origins, out_lik, out_ratio, out_beam,
+                            steps, warm_ms=100.0, extra=None):
+        """`steps` host-buffer updates timed from C (tools/benchloop.c) on the caller's own arrays (float32 / uint32,
+        C-contiguous; w is reset from w0 before every step). Returns (mean ms per update, per-step ms)."""
+        lib = load_benchloop()
+        per = np.zeros(steps, np.float64)
+        n_s = 0 if scan_lik is None else len(scan_lik)
+        n_b = 0 if scan_beam is None else len(scan_beam)
+        n_o = 0 if origins is None else len(origins)
+        ms = lib.mcl3dl_benchloop_measure_update(self.h, _ptr(poses), _ptr(extra), _ptr(w0), _ptr(w), len(poses), _ptr(scan_lik),
+                                                 n_s, _ptr(scan_beam), _ptr(scan_beam_origin), n_b, _ptr(origins), n_o,
+                                                 _ptr(out_lik), _ptr(out_ratio), _ptr(out_beam), int(steps), float(warm_ms),
+                                                 _ptr(per))
+        if ms < 0:
+            self._check(int(ms))
+        return float(ms), per
 
     def beam_status(self, begin, end):
         b = _np_f32(begin, 3)

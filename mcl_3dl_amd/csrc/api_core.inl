@@ -102,6 +102,8 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     (void)hipGraphDestroy(ctx->graph);
   for (const mcl3dl_hip_ctx::StageChunk& ch : ctx->stage)
     (void)hipHostFree(ch.p);
+  for (const mcl3dl_hip_ctx::PinnedBlock& b : ctx->pinned)
+    (void)hipHostFree(b.p);
   if (ctx->ev_fork)
     (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join)
@@ -528,13 +530,27 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
   return 0;
 }
 
+// ho (optional): page-locked arrays for the results; *host_written comes back true when the update's last kernel wrote
+// them (pf_tail_kernel) — otherwise the caller copies the device arrays home.
 int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
-                   float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
+                   float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const HostOut* ho = nullptr,
+                   bool* host_written = nullptr)
 {
+  if (host_written)
+    *host_written = false;
   const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4);
   if (one != 0)
     return one < 0 ? one : 0;
-  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
+  MeasureTail mt;
+  mt.want = pf_tail_eligible(ctx, n_p) && d_lik && d_ratio && d_beam;
+  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr, &mt));
+  if (mt.want)
+  {
+    TRY(launch_pf_tail(ctx, mt, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho));
+    if (host_written)
+      *host_written = ho != nullptr;
+    return 0;
+  }
   TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4));
   return 0;
 }
@@ -767,6 +783,190 @@ int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float*
   return 0;
 }
 
+namespace
+{
+// The host-buffer update with scan_stage_kernel in front (one launch takes over scans, poses and weights: ordering included)
+// and, where pf_tail_kernel runs, the results written straight into page-locked memory. Returns 1 when the update was run
+// this way (results delivered, stream synchronised), 0 when it is not eligible (the caller runs the general path), < 0 on
+// error.
+int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,
+                          const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
+                          size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
+                          float* out_beam, float* st4)
+{
+  if (!ctx->update_stage || n_s > static_cast<size_t>(ST_MAX_POINTS) || n_b > static_cast<size_t>(ST_MAX_POINTS) ||
+      n_o > 4096 || n_p > 0x7fffffffu / 8)
+    return 0;
+  if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
+    return ctx->fail(-3, "null scan array");
+  if (scan_beam_origin)
+    for (size_t i = 0; i < n_b; ++i)
+      if (scan_beam_origin[i] >= n_o)
+        return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, scan_beam_origin[i], n_o);
+  if (!origins)
+    n_o = 0;
+  const size_t fb = sizeof(float) * n_p;
+  // ---- the input block: { poses | weights | odometry factor | likelihood xyz | beam xyz | beam origin ids | origins }
+  struct Part
+  {
+    const void* src;
+    size_t bytes;
+    const void* dev;  // where the kernel reads it
+  };
+  Part part[7] = { { pose, 7 * fb, nullptr },
+                   { weight_inout, fb, nullptr },
+                   { extra, extra ? fb : 0, nullptr },
+                   { scan_lik_xyz, sizeof(float) * 3 * n_s, nullptr },
+                   { scan_beam_xyz, sizeof(float) * 3 * n_b, nullptr },
+                   { scan_beam_origin, scan_beam_origin ? sizeof(uint32_t) * n_b : 0, nullptr },
+                   { origins, sizeof(float) * 3 * n_o, nullptr } };
+  const bool zero_copy = ctx->update_zero_copy != 0;
+  const auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+  size_t staged_bytes = 0, off[7];
+  for (int k = 0; k < 7; ++k)
+  {
+    off[k] = staged_bytes;
+    if (part[k].bytes && !(zero_copy && ctx->is_pinned(part[k].src, part[k].bytes)))
+      staged_bytes += up(part[k].bytes);
+  }
+  char* staged = nullptr;
+  if (staged_bytes)
+  {
+    if (staged_bytes > STAGE_MAX_COPY)
+      return 0;
+    staged = static_cast<char*>(stage_alloc(ctx, staged_bytes));
+    if (!staged)
+      return 0;
+  }
+  // ---- device arrays
+  const size_t rpart = (fb + 63) & ~static_cast<size_t>(63);
+  TRY(ensure(ctx, ctx->pose, 7 * fb));
+  TRY(ensure(ctx, ctx->upd_block, 64 + 4 * rpart));
+  TRY(ensure(ctx, ctx->extra, fb));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  TRY(ensure(ctx, ctx->sp_samp[0], sizeof(float4) * std::max<size_t>(n_s, 1)));
+  TRY(ensure(ctx, ctx->sp_samp[1], sizeof(float4) * std::max<size_t>(n_b, 1)));
+  TRY(ensure(ctx, ctx->cl_minmax, sizeof(float) * 6 + sizeof(unsigned long long)));
+  TRY(ensure(ctx, ctx->cl_err, sizeof(int)));
+  TRY(ensure_scan_block(ctx, n_s, n_b, n_o));
+  if (!zero_copy && staged_bytes)
+    TRY(ensure(ctx, ctx->stage_in_dev, staged_bytes));
+  for (int k = 0; k < 7; ++k)
+  {
+    if (!part[k].bytes)
+      continue;
+    if (zero_copy && ctx->is_pinned(part[k].src, part[k].bytes))
+    {
+      part[k].dev = part[k].src;
+      continue;
+    }
+    memcpy(staged + off[k], part[k].src, part[k].bytes);
+    part[k].dev = zero_copy ? staged + off[k] : ctx->stage_in_dev.as<char>() + off[k];
+  }
+  if (!zero_copy && staged_bytes)
+  {
+    HIP_TRY(hipMemcpyAsync(ctx->stage_in_dev.p, staged, staged_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->stage_pending += staged_bytes;
+  }
+  char* blk = ctx->upd_block.as<char>();
+  float* d_stats = reinterpret_cast<float*>(blk);
+  float* d_w = reinterpret_cast<float*>(blk + 64);
+  float* d_lik = reinterpret_cast<float*>(blk + 64 + rpart);
+  float* d_ratio = reinterpret_cast<float*>(blk + 64 + 2 * rpart);
+  float* d_beam = reinterpret_cast<float*>(blk + 64 + 3 * rpart);
+  StageArgs a{};
+  a.in_pose = static_cast<const float*>(part[0].dev);
+  a.in_w = static_cast<const float*>(part[1].dev);
+  a.in_extra = static_cast<const float*>(part[2].dev);
+  a.d_pose = ctx->pose.as<float>();
+  a.d_w = d_w;
+  a.d_extra = ctx->extra.as<float>();
+  a.n_p = static_cast<int>(n_p);
+  a.in_lik_xyz = static_cast<const float*>(part[3].dev);
+  a.n_s = static_cast<int>(n_s);
+  a.raw_lik = ctx->sp_samp[0].as<float4>();
+  a.mm6 = ctx->cl_minmax.as<float>();
+  a.mm_cnt = reinterpret_cast<unsigned long long*>(ctx->cl_minmax.as<float>() + 6);
+  a.out_lik = ctx->scan_lik.as<float4>();
+  a.out_perm = ctx->scan_perm.as<uint32_t>();
+  a.in_beam_xyz = static_cast<const float*>(part[4].dev);
+  a.in_beam_origin = static_cast<const uint32_t*>(part[5].dev);
+  a.n_b = static_cast<int>(n_b);
+  a.raw_beam = ctx->sp_samp[1].as<float4>();
+  a.out_beam = ctx->scan_beam.as<float4>();
+  a.in_origins = static_cast<const float*>(part[6].dev);
+  a.n_o = static_cast<int>(n_o);
+  a.d_origins = ctx->origins.as<float4>();
+  a.d_err = ctx->cl_err.as<int>();
+  const size_t n_copy = 9 * n_p;
+  const unsigned grid = 2u + static_cast<unsigned>(std::min<size_t>(std::max<size_t>((n_copy + RS_THREADS - 1) / RS_THREADS, 1), 64));
+  const size_t n_max = std::max(n_s, n_b);
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_STAGE, &ep));
+  if (n_max <= 2 * RS_THREADS)
+    hipLaunchKernelGGL((scan_stage_kernel<2>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
+  else if (n_max <= 8 * RS_THREADS)
+    hipLaunchKernelGGL((scan_stage_kernel<8>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((scan_stage_kernel<16>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  // the context's scan state, as upload_scan_impl leaves it
+  if (n_b > ctx->pow_table_len)
+    ctx->pow_table_dirty = true;
+  if (n_s != ctx->n_s || n_b != ctx->n_b || n_o != ctx->n_o || !ctx->has_scan)
+    ++ctx->generation;
+  ctx->n_s = n_s;
+  ctx->n_b = n_b;
+  ctx->n_o = n_o;
+  ctx->has_scan = true;
+  ctx->sp_n_samp[0] = n_s;
+  ctx->sp_n_samp[1] = n_b;
+  ctx->n_pose_uploaded = n_p;
+  // ---- results: written by the update's last kernel into page-locked memory (the caller's own arrays where they are
+  // page-locked), or copied home in one block
+  HostOut ho;
+  char* out_blk = zero_copy ? static_cast<char*>(stage_alloc(ctx, 64 + 4 * rpart)) : nullptr;
+  struct Res
+  {
+    float* user;
+    size_t offset, bytes;
+    float** slot;
+  };
+  const Res res[5] = { { st4, 0, 4 * sizeof(float), &ho.stats4 },
+                       { weight_inout, 64, fb, &ho.w },
+                       { out_lik, 64 + rpart, fb, &ho.lik },
+                       { out_match_ratio, 64 + 2 * rpart, fb, &ho.ratio },
+                       { out_beam, 64 + 3 * rpart, fb, &ho.beam } };
+  if (out_blk)
+    for (int k = 0; k < 5; ++k)
+      if (res[k].user)
+        *res[k].slot = (k > 0 && ctx->is_pinned(res[k].user, res[k].bytes)) ? res[k].user
+                                                                            : reinterpret_cast<float*>(out_blk + res[k].offset);
+  bool host_written = false;
+  TRY(enqueue_update(ctx, ctx->pose.as<float>(), n_p, d_w, extra ? ctx->extra.as<float>() : nullptr, d_lik, d_ratio, d_beam,
+                     d_stats, out_blk ? &ho : nullptr, &host_written));
+  if (host_written)
+  {
+    for (int k = 0; k < 5; ++k)
+      if (res[k].user && *res[k].slot != res[k].user)
+        ctx->stage_out.push_back({ res[k].user, *res[k].slot, res[k].bytes });
+  }
+  else
+  {
+    const D2hPiece pieces[5] = { { st4, 0, 4 * sizeof(float) },
+                                 { weight_inout, 64, fb },
+                                 { out_lik, 64 + rpart, fb },
+                                 { out_match_ratio, 64 + 2 * rpart, fb },
+                                 { out_beam, 64 + 3 * rpart, fb } };
+    const size_t upto = out_beam ? 64 + 3 * rpart + fb : out_match_ratio ? 64 + 2 * rpart + fb : out_lik ? 64 + rpart + fb : 64 + fb;
+    TRY(d2h_block(ctx, blk, upto, pieces, 5));
+  }
+  TRY(sync_stream(ctx));
+  return 1;
+}
+}  // namespace
+
 int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout,
                               size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
                               const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
@@ -781,6 +981,25 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
     return ctx->fail(-3, "null pose / weight array");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t fb = sizeof(float) * n_p;
+  {
+    float st[4] = { 0.f, 0.f, 0.f, 0.f };
+    const int staged = measure_update_staged(ctx, pose, extra, weight_inout, n_p, scan_lik_xyz, n_s, scan_beam_xyz,
+                                             scan_beam_origin, n_b, origins, n_o, out_lik, out_match_ratio, out_beam, st);
+    if (staged < 0)
+      return staged;
+    if (staged == 1)
+    {
+      if (entropy)
+        *entropy = st[0];
+      if (match_ratio_min)
+        *match_ratio_min = st[1];
+      if (match_ratio_max)
+        *match_ratio_max = st[2];
+      if (restored)
+        *restored = st[3] != 0.0f;
+      return 0;
+    }
+  }
   TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
   // { stats4 | weights (in / out) | lik | ratio | beam }, each part on a 64-byte boundary, in ONE allocation: the results go
   // home in one copy instead of five (~5 us each at C2's sizes)

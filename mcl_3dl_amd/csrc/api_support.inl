@@ -98,6 +98,21 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->update_small = value != 0.0;
     return 0;
   }
+  if (key == "update_stage")
+  {
+    ctx->update_stage = value != 0.0;
+    return 0;
+  }
+  if (key == "update_zero_copy")
+  {
+    ctx->update_zero_copy = value != 0.0;
+    return 0;
+  }
+  if (key == "pf_tail")
+  {
+    ctx->pf_tail = value != 0.0;
+    return 0;
+  }
   if (key == "update_small_max")
   {
     if (!(value >= 1.0 && value <= 65536.0))
@@ -283,6 +298,9 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_refine") *value = ctx->cand_refine;
   else if (key == "cand_refine_above") *value = ctx->cand_refine_above;
   else if (key == "update_small") *value = ctx->update_small;
+  else if (key == "update_stage") *value = ctx->update_stage;
+  else if (key == "update_zero_copy") *value = ctx->update_zero_copy;
+  else if (key == "pf_tail") *value = ctx->pf_tail;
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "timing_mask") *value = ctx->timing_mask;
   else if (key == "use_graph") *value = ctx->use_graph;
@@ -310,6 +328,41 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else
     return ctx->fail(-3, "unknown option '%s'", name);
   return 0;
+}
+
+// ---- page-locked host memory for the caller's arrays ---------------------------------------------------------------------
+int mcl3dl_hip_host_alloc(mcl3dl_hip_ctx* ctx, size_t bytes, void** out)
+{
+  if (!ctx || !out)
+    return -1;
+  *out = nullptr;
+  if (bytes == 0)
+    return ctx->fail(-3, "mcl3dl_hip_host_alloc of 0 bytes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  void* p = pinned_alloc(ctx, bytes);
+  if (!p)
+    return ctx->fail(-2, "hipHostMalloc of %zu bytes failed", bytes);
+  ctx->pinned.push_back({ static_cast<char*>(p), bytes });
+  *out = p;
+  return 0;
+}
+
+int mcl3dl_hip_host_free(mcl3dl_hip_ctx* ctx, void* p)
+{
+  if (!ctx)
+    return -1;
+  if (!p)
+    return 0;
+  for (size_t k = 0; k < ctx->pinned.size(); ++k)
+    if (ctx->pinned[k].p == p)
+    {
+      HIP_TRY(hipSetDevice(ctx->device));
+      TRY(sync_stream(ctx));  // nothing in flight reads or writes it
+      HIP_TRY(hipHostFree(p));
+      ctx->pinned.erase(ctx->pinned.begin() + static_cast<long>(k));
+      return 0;
+    }
+  return ctx->fail(-3, "mcl3dl_hip_host_free: not a block of mcl3dl_hip_host_alloc");
 }
 
 int mcl3dl_hip_index_stats(mcl3dl_hip_ctx* ctx, double* stats8)

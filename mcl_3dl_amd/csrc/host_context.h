@@ -109,6 +109,30 @@ struct mcl3dl_hip_ctx
   int update_small = 1;
   int update_small_max = 512;
   DevBuf us_tickets;
+  // host-buffer updates (mcl3dl_hip_measure_update): update_stage = 1: the caller's scans / poses / weights are taken over by
+  // ONE launch (stage_kernels.h:scan_stage_kernel — ordering included) for scans up to ST_MAX_POINTS points per model;
+  // update_zero_copy = 1: that kernel reads them where they lie in page-locked host memory and the last kernel of the update
+  // writes the results there (no DMA copy either way), 0 = one H2D copy of the staged block, one D2H copy of the results;
+  // pf_tail = 1: lik_finalize + pf::measure of up to PF_TAIL_MAX_BLOCKS x 256 particles as one launch (pf_tail_kernel)
+  int update_stage = 1;
+  int update_zero_copy = 1;
+  int pf_tail = 1;
+  DevBuf stage_in_dev, tail_ticket;
+  // page-locked host memory handed out by mcl3dl_hip_host_alloc: arrays inside it are read / written in place
+  struct PinnedBlock
+  {
+    char* p;
+    size_t bytes;
+  };
+  std::vector<PinnedBlock> pinned;
+  bool is_pinned(const void* q, size_t bytes) const
+  {
+    const char* c = static_cast<const char*>(q);
+    for (const PinnedBlock& b : pinned)
+      if (c >= b.p && c + bytes <= b.p + b.bytes)
+        return true;
+    return false;
+  }
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
   int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
@@ -240,8 +264,8 @@ struct mcl3dl_hip_ctx
   unsigned timing_mask = 0xffffffffu;  // bit k = time kernel group k (MCL3DL_KERNEL_*); each timed group costs two event records
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> free_events;
-  double kernel_ms[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
-  uint64_t kernel_launches[MCL3DL_KERNEL_COUNT] = { 0, 0, 0 };
+  double kernel_ms[MCL3DL_KERNEL_COUNT] = {};
+  uint64_t kernel_launches[MCL3DL_KERNEL_COUNT] = {};
 
   int fail(int code, const char* fmt, ...)
   {
@@ -334,6 +358,30 @@ int ensure_scan_block(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, size_t n_o, s
 
 constexpr size_t STAGE_MAX_COPY = 4u << 20;  // larger copies go straight from / to the caller's (pageable) memory
 
+// Page-locked host memory that kernels can read and write in place (mapped, coherent: a kernel's stores are visible to the
+// host once the stream has been synchronised). The device must see it at the host's address — the zero-copy update passes
+// host pointers straight to its kernels; a platform where it does not gets update_zero_copy switched off.
+void* pinned_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != p)
+  {
+    (void)hipGetLastError();
+    ctx->update_zero_copy = 0;
+  }
+  return p;
+}
+
 // bump allocation in page-locked chunks; everything is released for reuse by sync_stream. nullptr = allocation failed
 // (the caller then falls back to a direct copy).
 void* stage_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
@@ -353,12 +401,9 @@ void* stage_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
   }
   const size_t last = ctx->stage.empty() ? (512u << 10) : ctx->stage.back().cap;
   const size_t cap = std::max(bytes, 2 * last);
-  void* p = nullptr;
-  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
-  {
-    (void)hipGetLastError();
+  void* p = pinned_alloc(ctx, cap);
+  if (!p)
     return nullptr;
-  }
   ctx->stage.push_back({ static_cast<char*>(p), cap });
   ctx->stage_cur = ctx->stage.size() - 1;
   ctx->stage_off = bytes;

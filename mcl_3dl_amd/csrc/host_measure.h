@@ -177,8 +177,18 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
   return 0;
 }
 
+// What launch_measure leaves to pf_tail_kernel when the caller asks for it (`want`): the sum over the tiled kernel's per-tile
+// partials (lik_partials: d_lik / d_ratio are NOT written by launch_measure then) and the beam score of an update without
+// beam points (beam_fill: d_beam is not written).
+struct MeasureTail
+{
+  bool want = false;
+  bool lik_partials = false, beam_fill = false;
+  int n_tiles = 0;
+};
+
 int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
-                   bool stats, double* stats6)
+                   bool stats, double* stats6, MeasureTail* tail = nullptr)
 {
   if (!ctx->has_scan)
     return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
@@ -215,7 +225,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     {
       // (1, 0) for every particle; with the tiled likelihood kernel behind it the per-particle finalize writes the ones
       beam_ones_by_finalize = !stats && d_beam && want_lik && ctx->n_s > 0 && plan.tiled;
-      if (!stats && !beam_ones_by_finalize)
+      if (tail && tail->want && !stats && d_beam)
+      {
+        tail->beam_fill = true;
+        beam_ones_by_finalize = false;
+      }
+      else if (!stats && !beam_ones_by_finalize)
         hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
                            static_cast<float*>(nullptr), 0.0f, np);
     }
@@ -396,9 +411,15 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           }
 #undef LAUNCH_TILED_G
 #undef LAUNCH_TILED
-          hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
-                             ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
-                             d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
+          if (tail && tail->want && !strict_terms && d_lik && d_ratio)
+          {
+            tail->lik_partials = true;  // pf_tail_kernel adds the tiles up
+            tail->n_tiles = n_tiles;
+          }
+          else
+            hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
+                               ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
+                               d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
           if (strict_terms && d_lik)
           {
 #define LAUNCH_STRICT(GG)                                                                                             \
@@ -521,7 +542,11 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   if (ctx->us_tickets.cap < sizeof(unsigned) * n_tickets)
   {
     TRY(ensure(ctx, ctx->us_tickets, sizeof(unsigned) * n_tickets));
-    HIP_TRY(hipMemsetAsync(ctx->us_tickets.p, 0, ctx->us_tickets.cap, ctx->stream));  // the kernel leaves them zero
+    // (a kernel, not hipMemsetAsync: see launch_measure — a memset node in a captured update faulted on replay)
+    const int n_words = static_cast<int>(ctx->us_tickets.cap / sizeof(unsigned));
+    hipLaunchKernelGGL(fill_kernel, dim3((n_words + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<float*>(ctx->us_tickets.p), 0.0f, static_cast<float*>(nullptr), 0.0f,
+                       n_words);  // the update kernel leaves them zero
   }
   UpdateSmallArgs a{};
   a.pose7 = d_pose;
@@ -551,7 +576,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.packed = ctx->partial4.as<double>();
   a.stats4 = d_stats4;
   EventPair ep{};
-  TRY(timing_begin(ctx, MCL3DL_KERNEL_LIKELIHOOD, &ep));
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_UPDATE, &ep));
   const unsigned grid = static_cast<unsigned>(n_p);
 #define LAUNCH_US(BLOCK, MODE) hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a)
   // the work-group size the separate likelihood kernel would get (launch_measure), so that the lanes add in the same order
@@ -590,5 +615,67 @@ int pf_blocks(size_t n)
 {
   const size_t b = (n + PF_BLOCK - 1) / PF_BLOCK;
   return static_cast<int>(std::min<size_t>(std::max<size_t>(b, 1), 1024));
+}
+
+// Page-locked, device-mapped arrays the last kernel of an update writes its results to (each may be null).
+struct HostOut
+{
+  float *stats4 = nullptr, *w = nullptr, *lik = nullptr, *ratio = nullptr, *beam = nullptr;
+};
+
+// is pf::measure of n_p particles run by pf_tail_kernel (one launch, lik_finalize folded in)?
+bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
+{
+  return ctx->pf_tail && ctx->strict_order != 1 && n_p >= 1 &&
+         n_p <= static_cast<size_t>(PF_TAIL_MAX_BLOCKS) * PF_BLOCK;
+}
+
+int launch_pf_tail(mcl3dl_hip_ctx* ctx, const MeasureTail& mt, size_t n_p, float* d_weight, const float* d_extra, float* d_lik,
+                   float* d_ratio, float* d_beam, float* d_stats4, const HostOut* ho)
+{
+  const int nb = pf_blocks(n_p);
+  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * static_cast<size_t>(nb)));
+  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
+  if (!ctx->tail_ticket.p)
+  {
+    TRY(ensure(ctx, ctx->tail_ticket, 64));
+    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->tail_ticket.as<float>(), 0.0f,
+                       static_cast<float*>(nullptr), 0.0f, 16);  // the kernel leaves it zero
+  }
+  TailArgs a{};
+  if (mt.lik_partials)
+  {
+    a.partial_sum = ctx->lik_partial_sum.as<double>();
+    a.partial_cnt = ctx->lik_partial_cnt.as<unsigned>();
+    a.n_tiles = mt.n_tiles;
+  }
+  a.n_s = static_cast<int>(ctx->n_s);
+  a.lik = d_lik;
+  a.ratio = d_ratio;
+  a.beam = d_beam;
+  a.beam_fill = mt.beam_fill ? 1 : 0;
+  a.w = d_weight;
+  a.extra = d_extra;
+  a.n = static_cast<int>(n_p);
+  a.w_new = ctx->wnew.as<float>();
+  a.block_partials = ctx->block_partials.as<double>();
+  a.ticket = ctx->tail_ticket.as<unsigned>();
+  a.packed = ctx->partial4.as<double>();
+  a.stats4 = d_stats4;
+  if (ho)
+  {
+    a.h_stats4 = ho->stats4;
+    a.h_w = ho->w;
+    a.h_lik = ho->lik;
+    a.h_ratio = ho->ratio;
+    a.h_beam = ho->beam;
+  }
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  hipLaunchKernelGGL(pf_tail_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, a);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 }  // namespace

@@ -12,6 +12,8 @@
 //                         matched / unmatched output (each with the min / max or the count the next step needs fused in)
 //   sort_kernels.h        stable radix sort of the cloud path: keys made in the first pass, points written by the last
 //   cloud_keys.h          the sort keys (VoxelGrid leaf index, Morton key, range key)
+//   stage_kernels.h       head and tail of a host-buffer update as one launch each: scan ordering + pose / weight take-over
+//                         from page-locked host memory; lik_finalize + pf::measure with the results written back there
 //
 // These are gather / traversal kernels (bound by L2/HBM reads and the texture-addresser, not by MFMA):
 // there is no dense contraction anywhere on this path, so no matrix-core code.
@@ -23,4 +25,5 @@
 #include "update_kernels.h"
 #include "cloud_kernels.h"
 #include "sort_kernels.h"
+#include "stage_kernels.h"
 #include "grid_kernels.h"

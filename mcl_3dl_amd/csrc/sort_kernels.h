@@ -144,11 +144,12 @@ __device__ __forceinline__ void rs_rank_pass(const uint32_t (&key)[ROUNDS], uint
       const uint32_t below = rs_lanes_below(m), total = static_cast<uint32_t>(__popcll(m));
       uint32_t base = 0;
       if (have)
-      {
         base = cnt[w][d];
-        if (below + 1 == total)
-          cnt[w][d] = base + total;  // the group's highest lane; the read above is ordered ahead of it (same wavefront)
-      }
+      // every lane of a digit group has ISSUED its read before the group's highest lane writes the same word: LDS operations
+      // of one wavefront complete in order, and the wave barrier keeps the compiler from moving either across the other
+      __builtin_amdgcn_wave_barrier();
+      if (have && below + 1 == total)
+        cnt[w][d] = base + total;
       dst[r] = base + below;
     }
   }
