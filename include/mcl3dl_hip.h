@@ -463,8 +463,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       ordering as separate copies and launches (the path larger scans always take; same results)
  *   "update_zero_copy"  1 (default) = that launch reads the arrays in page-locked host memory and the update's last
  *                       kernel writes the results there; 0 = one H2D copy in front, one D2H copy behind
- *   "pf_tail"           1 (default) = lik_finalize + pf::measure of up to 8192 particles on one GPU as ONE launch
- *                       (pf_tail_kernel; bit-identical to the separate kernels), 0 = separate launches
+ *   "pf_tail"           1 = lik_finalize + pf::measure of up to 8192 particles on one GPU as ONE launch (pf_tail_kernel;
+ *                       bit-identical to the separate kernels); 0 (default) = separate launches, which measured faster at
+ *                       every size tried (one launch costs ~4 us, the arrival ticket's agent-scope release more)
  *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
  *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
  *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",

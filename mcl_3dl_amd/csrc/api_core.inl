@@ -511,22 +511,31 @@ namespace
 {
 // pf::measure on one GPU: the fused single-work-group kernel up to pf_fused_max particles (default 1024; the kernel takes up
 // to PF_FUSED_MAX = 4096 — same bits as the split form, two launches fewer), partial + reduce + apply beyond, or with strict_order (which replaces the sum between the two).
+// ho (optional): page-locked arrays the last kernel writes the results to as well (PfEmit).
 int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
-                      const float* d_ratio, size_t n_p, float* d_stats4)
+                      const float* d_ratio, size_t n_p, float* d_stats4, const PfEmit* ho = nullptr)
 {
+  const PfEmit emit = ho ? *ho : PfEmit{};
   if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->strict_order != 1 && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
     EventPair ep{};
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(pf_fused_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
-                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4);
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit);
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     return 0;
   }
   TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
-  TRY(mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4));
+  if (!ho)
+    return mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4);
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
+                     static_cast<int>(n_p), 1, ctx->partial4.as<double>(), d_stats4, emit, d_lik, d_ratio, d_beam);
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -537,8 +546,8 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                    bool* host_written = nullptr)
 {
   if (host_written)
-    *host_written = false;
-  const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4);
+    *host_written = ho != nullptr;  // every path below writes them
+  const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho);
   if (one != 0)
     return one < 0 ? one : 0;
   MeasureTail mt;
@@ -547,11 +556,9 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   if (mt.want)
   {
     TRY(launch_pf_tail(ctx, mt, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho));
-    if (host_written)
-      *host_written = ho != nullptr;
     return 0;
   }
-  TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4));
+  TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4, ho));
   return 0;
 }
 
@@ -794,8 +801,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
                           size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
                           float* out_beam, float* st4)
 {
-  if (!ctx->update_stage || n_s > static_cast<size_t>(ST_MAX_POINTS) || n_b > static_cast<size_t>(ST_MAX_POINTS) ||
-      n_o > 4096 || n_p > 0x7fffffffu / 8)
+  if (!ctx->update_stage || n_s > 0x0fffffffu || n_b > 0x0fffffffu || n_o > 4096 || n_p > 0x7fffffffu / 8)
     return 0;
   if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
     return ctx->fail(-3, "null scan array");
@@ -899,18 +905,30 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   a.d_origins = ctx->origins.as<float4>();
   a.d_err = ctx->cl_err.as<int>();
   const size_t n_copy = 9 * n_p;
-  const unsigned grid = 2u + static_cast<unsigned>(std::min<size_t>(std::max<size_t>((n_copy + RS_THREADS - 1) / RS_THREADS, 1), 64));
   const size_t n_max = std::max(n_s, n_b);
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_STAGE, &ep));
-  if (n_max <= 2 * RS_THREADS)
-    hipLaunchKernelGGL((scan_stage_kernel<2>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
-  else if (n_max <= 8 * RS_THREADS)
-    hipLaunchKernelGGL((scan_stage_kernel<8>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
+  if (n_max <= static_cast<size_t>(ST_MAX_POINTS))
+  {
+    // everything in one launch: one work-group orders each scan
+    const unsigned grid = 2u + static_cast<unsigned>(std::min<size_t>(std::max<size_t>((n_copy + RS_THREADS - 1) / RS_THREADS, 1), 64));
+    hipLaunchKernelGGL((scan_stage_kernel<ST_MAX_ROUNDS>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   else
-    hipLaunchKernelGGL((scan_stage_kernel<16>), dim3(grid), dim3(RS_THREADS), 0, ctx->stream, a);
+  {
+    // larger scans: one launch brings the arrays over (+ the min / max the Morton keys need), the chip-wide sort orders them
+    const unsigned nb_lik = n_s ? minmax_blocks(static_cast<long long>(n_s)) : 0u;
+    const unsigned nb_beam = n_b ? static_cast<unsigned>(std::min<size_t>((n_b + 1023) / 1024, 64)) : (n_o ? 1u : 0u);
+    const unsigned nb_copy = static_cast<unsigned>(std::min<size_t>(std::max<size_t>((n_copy + 1023) / 1024, 1), 64));
+    MinMaxOut mm{};
+    if (nb_lik)
+      TRY(minmax_out(ctx, nb_lik, &mm));
+    hipLaunchKernelGGL(stage_pack_kernel, dim3(nb_lik + nb_beam + nb_copy), dim3(256), 0, ctx->stream, a, mm, nb_lik, nb_beam);
+    HIP_TRY(hipGetLastError());
+    TRY(device_order_scans(ctx, n_s, n_b, nullptr, n_o, true, ctx->cl_err.as<int>()));
+  }
   TRY(timing_end(ctx, ep));
-  HIP_TRY(hipGetLastError());
   // the context's scan state, as upload_scan_impl leaves it
   if (n_b > ctx->pow_table_len)
     ctx->pow_table_dirty = true;
@@ -925,7 +943,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   ctx->n_pose_uploaded = n_p;
   // ---- results: written by the update's last kernel into page-locked memory (the caller's own arrays where they are
   // page-locked), or copied home in one block
-  HostOut ho;
+  HostOut ho{};
   char* out_blk = zero_copy ? static_cast<char*>(stage_alloc(ctx, 64 + 4 * rpart)) : nullptr;
   struct Res
   {

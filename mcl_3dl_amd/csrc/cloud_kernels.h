@@ -110,7 +110,9 @@ __device__ inline void wave_minmax(float (&mn)[3], float (&mx)[3], unsigned long
 }
 
 // called by every thread of the work-group (blockDim.x a multiple of 64, at most 1024)
-__device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsigned cnt32, const MinMaxOut& o)
+// bid / n_blocks: this work-group's slot and the number of work-groups that take part (default: the whole grid)
+__device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsigned cnt32, const MinMaxOut& o, unsigned bid,
+                                           unsigned n_blocks)
 {
   __shared__ float s_mm[6][16];
   __shared__ unsigned long long s_cnt[16];
@@ -147,11 +149,11 @@ __device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsig
       c += s_cnt[k];
     }
     for (int a = 0; a < 6; ++a)
-      o.block_out[6 * blockIdx.x + a] = r[a];
-    o.block_cnt[blockIdx.x] = static_cast<unsigned>(c);
+      o.block_out[6 * bid + a] = r[a];
+    o.block_cnt[bid] = static_cast<unsigned>(c);
     __threadfence();  // release: the partial is out of this XCD's L2 before the ticket moves
     const unsigned t = atomicAdd(o.ticket, 1u);
-    s_last = (t + 1 == gridDim.x) ? 1 : 0;
+    s_last = (t + 1 == n_blocks) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last || w != 0)
@@ -159,7 +161,7 @@ __device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsig
   __threadfence();  // acquire: the other work-groups' partials
   float fmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, fmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
   unsigned long long total = 0;
-  for (unsigned b = lane; b < gridDim.x; b += 64)
+  for (unsigned b = lane; b < n_blocks; b += 64)
   {
     for (int a = 0; a < 3; ++a)
     {
@@ -183,6 +185,11 @@ __device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsig
     *o.out_cnt = total;
     *o.ticket = 0u;
   }
+}
+
+__device__ inline void block_minmax_finish(float (&mn)[3], float (&mx)[3], unsigned cnt32, const MinMaxOut& o)
+{
+  block_minmax_finish(mn, mx, cnt32, o, blockIdx.x, gridDim.x);
 }
 
 // xyz + label arrays -> float4 cloud + its min / max (one launch)

@@ -441,7 +441,7 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
     const RsFinal fin{ ctx->sp_samp[0].as<float4>(), ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>(), 1 };
     TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, ns, MCL3DL_MORTON_BITS, &fin));
   }
-  if (n_o)
+  if (n_o && origins)  // (origins == nullptr: the caller's kernel has put them into ctx->origins already)
   {
     ctx->h_scan.origins.resize(n_o);
     for (size_t i = 0; i < n_o; ++i)

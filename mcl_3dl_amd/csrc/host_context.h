@@ -113,10 +113,13 @@ struct mcl3dl_hip_ctx
   // ONE launch (stage_kernels.h:scan_stage_kernel — ordering included) for scans up to ST_MAX_POINTS points per model;
   // update_zero_copy = 1: that kernel reads them where they lie in page-locked host memory and the last kernel of the update
   // writes the results there (no DMA copy either way), 0 = one H2D copy of the staged block, one D2H copy of the results;
-  // pf_tail = 1: lik_finalize + pf::measure of up to PF_TAIL_MAX_BLOCKS x 256 particles as one launch (pf_tail_kernel)
+  // pf_tail = 1: lik_finalize + pf::measure of up to PF_TAIL_MAX_BLOCKS x 256 particles as one launch (pf_tail_kernel).
+  // Measured (profiles/r04a_time8d_*.json) and off by default: bit-identical, but 16 work-groups adding 64 tiles x 256
+  // particles of partials and one agent-scope release per work-group cost 32 us against 12 us for lik_finalize + the three pf
+  // launches at 4096 x 16 384 (device-resident step 0.252 against 0.234 ms), and +2.5 us at 4096 x 96
   int update_stage = 1;
   int update_zero_copy = 1;
-  int pf_tail = 1;
+  int pf_tail = 0;
   DevBuf stage_in_dev, tail_ticket;
   // page-locked host memory handed out by mcl3dl_hip_host_alloc: arrays inside it are read / written in place
   struct PinnedBlock

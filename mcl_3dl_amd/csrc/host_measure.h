@@ -17,6 +17,9 @@ int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda, bool ne
   return 0;
 }
 
+// Page-locked, device-mapped arrays the last kernel of an update writes its results to (each may be null).
+using HostOut = PfEmit;
+
 LikParams lik_params(const mcl3dl_hip_ctx* ctx)
 {
   LikParams p;
@@ -514,7 +517,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
 // error. Eligible: one GPU, per-particle likelihood kernel (not the tiled / small-scan forms), at most update_small_max
 // particles and 256 beam points, no float-order replay.
 int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
-                        float* d_lik, float* d_ratio, float* d_beam, float* d_stats4)
+                        float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho = nullptr)
 {
   if (!ctx->update_small || n_p == 0 || n_p > static_cast<size_t>(ctx->update_small_max) || ctx->n_b > 256 ||
       ctx->strict_order == 1 || !ctx->has_scan || !d_lik || !d_ratio || !d_beam)
@@ -575,6 +578,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.tickets = ctx->us_tickets.as<unsigned>();
   a.packed = ctx->partial4.as<double>();
   a.stats4 = d_stats4;
+  a.emit = ho ? *ho : PfEmit{};
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_UPDATE, &ep));
   const unsigned grid = static_cast<unsigned>(n_p);
@@ -617,11 +621,6 @@ int pf_blocks(size_t n)
   return static_cast<int>(std::min<size_t>(std::max<size_t>(b, 1), 1024));
 }
 
-// Page-locked, device-mapped arrays the last kernel of an update writes its results to (each may be null).
-struct HostOut
-{
-  float *stats4 = nullptr, *w = nullptr, *lik = nullptr, *ratio = nullptr, *beam = nullptr;
-};
 
 // is pf::measure of n_p particles run by pf_tail_kernel (one launch, lik_finalize folded in)?
 bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)

@@ -14,6 +14,18 @@ namespace mcl3dl
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PF_BLOCK = 256;
 
+// The results of an update written a second time, into page-locked (device-mapped) host memory, by the kernel that produces
+// the final weights — a host-buffer update then ends without a D2H copy (SURVEY.md 8d's region: "D2H of weights"). Any
+// pointer may be null.
+struct PfEmit
+{
+  float* stats4;
+  float* w;
+  float* lik;
+  float* ratio;
+  float* beam;
+};
+
 // w_new = w * (((1 * beam) * lik) * extra); per-block partials {sum w, sum w ln w, max ratio, -min ratio}.
 __global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __restrict__ w, const float* __restrict__ lik,
                                                               const float* __restrict__ beam,
@@ -107,9 +119,13 @@ __global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict_
 
 // Normalise (pf.h:262-272) or restore (pf.h:274-278); entropy = ln S - T/S == -sum (w/S) ln (w/S).
 // `packed` is the (all-reduced) vector described above.
+// emit (+ the device arrays its lik / ratio / beam copies come from): see PfEmit.
 __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ w, const float* __restrict__ w_new,
                                                             int n, int world, const double* __restrict__ packed,
-                                                            float* __restrict__ stats4)
+                                                            float* __restrict__ stats4, PfEmit emit = PfEmit{},
+                                                            const float* __restrict__ lik = nullptr,
+                                                            const float* __restrict__ ratio = nullptr,
+                                                            const float* __restrict__ beam = nullptr)
 {
   const double S = packed[0];
   const float sum_f = static_cast<float>(S);
@@ -117,9 +133,29 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
   if (alive)
   {
     for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
-      w[i] = w_new[i] / sum_f;
+    {
+      const float wv = w_new[i] / sum_f;
+      w[i] = wv;
+      if (emit.w)
+        emit.w[i] = wv;
+    }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && stats4)
+  else if (emit.w)
+  {
+    for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+      emit.w[i] = w[i];
+  }
+  if (emit.lik || emit.ratio || emit.beam)
+    for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+    {
+      if (emit.lik)
+        emit.lik[i] = lik[i];
+      if (emit.ratio)
+        emit.ratio[i] = ratio[i];
+      if (emit.beam)
+        emit.beam[i] = beam[i];
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (stats4 || emit.stats4))
   {
     // every rank's slot holds a value in [0,1] resp. [-1,0] (0 in both for a rank whose shard saw no ratios is impossible:
     // an empty shard reports max 0 / -min -1); the maxima over the slots are the global max ratio and -min ratio
@@ -129,10 +165,15 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
       rmax = packed[2 + 2 * r] > rmax ? packed[2 + 2 * r] : rmax;
       rneg = packed[3 + 2 * r] > rneg ? packed[3 + 2 * r] : rneg;
     }
-    stats4[0] = alive ? static_cast<float>(log(S) - packed[1] / S) : __builtin_nanf("");
-    stats4[1] = static_cast<float>(-rneg);
-    stats4[2] = static_cast<float>(rmax);
-    stats4[3] = alive ? 0.0f : 1.0f;
+    const float st[4] = { alive ? static_cast<float>(log(S) - packed[1] / S) : __builtin_nanf(""), static_cast<float>(-rneg),
+                          static_cast<float>(rmax), alive ? 0.0f : 1.0f };
+    for (int k = 0; k < 4; ++k)
+    {
+      if (stats4)
+        stats4[k] = st[k];
+      if (emit.stats4)
+        emit.stats4[k] = st[k];
+    }
   }
 }
 
@@ -150,7 +191,8 @@ constexpr int PF_FUSED_MAX = 4096;
 __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, const float* __restrict__ lik,
                                                         const float* __restrict__ beam, const float* __restrict__ extra,
                                                         const float* __restrict__ ratio, int n, float* __restrict__ w_new,
-                                                        double* __restrict__ packed, float* __restrict__ stats4)
+                                                        double* __restrict__ packed, float* __restrict__ stats4,
+                                                        PfEmit emit = PfEmit{})
 {
   __shared__ double sh[4][16];          // per wavefront of the group
   __shared__ double part[4][16];        // per virtual block (n <= 4096 -> at most 16 of them)
@@ -243,15 +285,36 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
   const double S = tot[0];
   const float sum_f = static_cast<float>(S);
   const bool alive = sum_f > 0.0f;
-  if (alive)
-    for (int i = threadIdx.x; i < n; i += 1024)
-      w[i] = w_new[i] / sum_f;
-  if (threadIdx.x == 0 && stats4)
+  for (int i = threadIdx.x; i < n; i += 1024)
   {
-    stats4[0] = alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf("");
-    stats4[1] = static_cast<float>(-tot[3]);
-    stats4[2] = static_cast<float>(tot[2]);
-    stats4[3] = alive ? 0.0f : 1.0f;
+    float wv;
+    if (alive)
+    {
+      wv = w_new[i] / sum_f;
+      w[i] = wv;
+    }
+    else
+      wv = w[i];
+    if (emit.w)
+      emit.w[i] = wv;
+    if (emit.lik)
+      emit.lik[i] = lik[i];
+    if (emit.ratio)
+      emit.ratio[i] = ratio ? ratio[i] : 0.f;
+    if (emit.beam)
+      emit.beam[i] = beam ? beam[i] : 1.f;
+  }
+  if (threadIdx.x == 0 && (stats4 || emit.stats4))
+  {
+    const float st[4] = { alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf(""), static_cast<float>(-tot[3]),
+                          static_cast<float>(tot[2]), alive ? 0.0f : 1.0f };
+    for (int k = 0; k < 4; ++k)
+    {
+      if (stats4)
+        stats4[k] = st[k];
+      if (emit.stats4)
+        emit.stats4[k] = st[k];
+    }
   }
 }
 

@@ -28,7 +28,10 @@
 
 namespace mcl3dl
 {
-constexpr int ST_MAX_ROUNDS = 16;                          // one work-group orders up to 16 384 points
+// One work-group orders up to 2048 points (measured with 16 rounds per thread, 149 KB of LDS: a 16 384-point scan took 83 us —
+// ~100 VALU instructions per 64 elements and pass on ONE CU — against ~35 us for the seven launches of the chip-wide sort:
+// profiles/r04a_time8d_C2.json; larger scans go through stage_pack_kernel + device_order_scans)
+constexpr int ST_MAX_ROUNDS = 2;
 constexpr int ST_MAX_POINTS = RS_THREADS * ST_MAX_ROUNDS;
 
 struct StageArgs
@@ -230,6 +233,52 @@ __global__ __launch_bounds__(RS_THREADS) void scan_stage_kernel(StageArgs a)
   const long long total = n_pose + n_w + n_e;
   const long long stride = static_cast<long long>(gridDim.x - 2) * RS_THREADS;
   for (long long i = static_cast<long long>(blockIdx.x - 2) * RS_THREADS + threadIdx.x; i < total; i += stride)
+  {
+    if (i < n_pose)
+      a.d_pose[i] = a.in_pose[i];
+    else if (i < n_pose + n_w)
+      a.d_w[i - n_pose] = a.in_w[i - n_pose];
+    else
+      a.d_extra[i - n_pose - n_w] = a.in_extra[i - n_pose - n_w];
+  }
+}
+
+// Scans of more than 2 * RS_THREADS points: one CU ranks ~1000 elements per microsecond and pass, so a 16 384-point scan is
+// ordered by the multi-work-group sort of sort_kernels.h (host_cloud.h:device_order_scans) — this kernel only brings the
+// caller's arrays over: work-groups [0, nb_lik) the likelihood scan as float4 + its min / max (last work-group to arrive
+// folds the partials: cloud_kernels.h:block_minmax_finish), [nb_lik, nb_lik + nb_beam) the beam scan (+ origins), the rest
+// the poses / weights / odometry factor. 256 threads per work-group.
+__global__ __launch_bounds__(256) void stage_pack_kernel(StageArgs a, MinMaxOut mm, unsigned nb_lik, unsigned nb_beam)
+{
+  const unsigned b = blockIdx.x;
+  if (b < nb_lik)
+  {
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    unsigned cnt = 0;
+    for (int i = static_cast<int>(b) * 256 + threadIdx.x; i < a.n_s; i += static_cast<int>(nb_lik) * 256)
+    {
+      const float4 p = make_float4(a.in_lik_xyz[3 * i], a.in_lik_xyz[3 * i + 1], a.in_lik_xyz[3 * i + 2], 0.f);
+      a.raw_lik[i] = p;
+      minmax_accumulate(p, mn, mx, cnt);
+    }
+    block_minmax_finish(mn, mx, cnt, mm, b, nb_lik);
+    return;
+  }
+  if (b < nb_lik + nb_beam)
+  {
+    const unsigned bb = b - nb_lik;
+    if (bb == 0)
+      for (int i = threadIdx.x; i < a.n_o; i += 256)
+        a.d_origins[i] = make_float4(a.in_origins[3 * i], a.in_origins[3 * i + 1], a.in_origins[3 * i + 2], 0.f);
+    for (int i = static_cast<int>(bb) * 256 + threadIdx.x; i < a.n_b; i += static_cast<int>(nb_beam) * 256)
+      a.raw_beam[i] = make_float4(a.in_beam_xyz[3 * i], a.in_beam_xyz[3 * i + 1], a.in_beam_xyz[3 * i + 2],
+                                  __uint_as_float(a.in_beam_origin ? a.in_beam_origin[i] : 0u));
+    return;
+  }
+  const long long n_pose = a.in_pose ? 7ll * a.n_p : 0, n_w = a.in_w ? a.n_p : 0, n_e = a.in_extra ? a.n_p : 0;
+  const long long total = n_pose + n_w + n_e;
+  const long long stride = static_cast<long long>(gridDim.x - nb_lik - nb_beam) * 256;
+  for (long long i = static_cast<long long>(b - nb_lik - nb_beam) * 256 + threadIdx.x; i < total; i += stride)
   {
     if (i < n_pose)
       a.d_pose[i] = a.in_pose[i];

@@ -60,6 +60,7 @@ struct UpdateSmallArgs
   unsigned* tickets;    // [37 per virtual block + ticket_tree_size(number of virtual blocks)], zero between launches
   double* packed;       // [4]
   float* stats4;
+  PfEmit emit;          // page-locked host copies of the results (pf_kernels.h), each may be null
 };
 
 __device__ __forceinline__ void store_agent(float* p, float v)
@@ -187,6 +188,12 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
     store_agent(a.out_lik + p, lik);
     store_agent(a.out_ratio + p, ratio);
     store_agent(a.out_beam + p, beam);
+    if (a.emit.lik)
+      a.emit.lik[p] = lik;
+    if (a.emit.ratio)
+      a.emit.ratio[p] = ratio;
+    if (a.emit.beam)
+      a.emit.beam[p] = beam;
   }
   // ---- pf::measure (pf.h:252-279). Stage 1: the last work-group of each 256-particle virtual block.
   const int nvb = (a.n_p + PF_BLOCK - 1) / PF_BLOCK;
@@ -284,15 +291,25 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
   const bool alive = sum_f > 0.0f;
   if (alive)
     for (int i = threadIdx.x; i < a.n_p; i += BLOCK)
-      a.w[i] = load_agent(a.w_new + i) / sum_f;
+    {
+      const float wv = load_agent(a.w_new + i) / sum_f;
+      a.w[i] = wv;
+      if (a.emit.w)
+        a.emit.w[i] = wv;
+    }
+  else if (a.emit.w)
+    for (int i = threadIdx.x; i < a.n_p; i += BLOCK)
+      a.emit.w[i] = a.w[i];
   if (threadIdx.x == 0)
   {
-    if (a.stats4)
+    const float st[4] = { alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf(""), static_cast<float>(-tot[3]),
+                          static_cast<float>(tot[2]), alive ? 0.0f : 1.0f };
+    for (int k = 0; k < 4; ++k)
     {
-      a.stats4[0] = alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf("");
-      a.stats4[1] = static_cast<float>(-tot[3]);
-      a.stats4[2] = static_cast<float>(tot[2]);
-      a.stats4[3] = alive ? 0.0f : 1.0f;
+      if (a.stats4)
+        a.stats4[k] = st[k];
+      if (a.emit.stats4)
+        a.emit.stats4[k] = st[k];
     }
   }
   for (int k = threadIdx.x; k < nvb * VB_TREE + ticket_tree_size(nvb); k += BLOCK)

@@ -49,7 +49,7 @@ def run_modes(engine, sc, n_p, n_s, n_b, extra, modes, origins=None, beam_label=
     finally:
         engine.set_option("update_stage", 1)
         engine.set_option("update_zero_copy", 1)
-        engine.set_option("pf_tail", 1)
+        engine.set_option("pf_tail", 0)
     return out
 
 
@@ -58,7 +58,7 @@ ALL_MODES = [(0, 0, 0), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 0, 1)]
 
 @pytest.mark.parametrize("n_p,n_s,n_b", [(64, 96, 3), (64, 1000, 32), (700, 300, 0), (513, 2048, 40), (1024, 2049, 0),
                                          (1025, 4096, 7), (4096, 1000, 96), (2000, 8192, 512), (2049, 8193, 0),
-                                         (600, 16384, 2048), (8192, 1024, 3), (8193, 1500, 3), (1, 96, 3), (3, 1, 1),
+                                         (600, 16384, 2048), (700, 2048, 2049), (650, 2049, 2048), (8192, 1024, 3), (8193, 1500, 3), (1, 96, 3), (3, 1, 1),
                                          (4096, 0, 48), (300, 5, 0)])
 @pytest.mark.parametrize("extra", [False, True])
 def test_staged_update_equals_the_general_path(engine, scene, n_p, n_s, n_b, extra):
@@ -70,8 +70,7 @@ def test_staged_update_equals_the_general_path(engine, scene, n_p, n_s, n_b, ext
 
 
 def test_full_c2_scan_with_all_particles(engine, scene):
-    """16 384 points (the one-work-group ordering at its maximum) x 9000 particles (above pf_tail's 8192: separate pf kernels
-    behind the staged head)."""
+    """16 384 points (stage_pack_kernel + the chip-wide sort) x 9000 particles (above pf_tail's 8192)."""
     configure(engine, scene, 0, stamp=9200, dist_weight=(1.0, 1.0, 1.0))
     res = run_modes(engine, scene, 9000, 16384, 0, True, [(0, 0, 0), (1, 1, 1), (1, 0, 1)])
     same(res[0], res[1])
@@ -123,7 +122,7 @@ def test_restore_rule(engine, scene):
             outs.append(engine.measure_update(far, w0, sc.scan_lik[:600], None, None, sc.origins))
     finally:
         engine.set_option("update_stage", 1)
-        engine.set_option("pf_tail", 1)
+        engine.set_option("pf_tail", 0)
     for o in outs:
         assert o["restored"]
         np.testing.assert_array_equal(o["weights"], w0)
@@ -187,11 +186,12 @@ def test_device_resident_update_with_and_without_the_tail(engine, scene):
                 d_stats = torch.zeros(4, dtype=torch.float32, device=dev)
                 for _ in range(2):   # twice: the ticket is left zero for the next launch
                     d_w.fill_(1.0 / n_p)
+                    torch.cuda.synchronize()   # (torch's stream is not the engine's)
                     engine.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam)
-                torch.cuda.synchronize()
+                    engine.synchronize()
                 got.append([t.cpu().numpy() for t in (d_w, d_lik, d_ratio, d_beam, d_stats)])
         finally:
-            engine.set_option("pf_tail", 1)
+            engine.set_option("pf_tail", 0)
         for x, y in zip(got[0], got[1]):
             np.testing.assert_array_equal(x, y)
         assert abs(float(got[1][0].astype(np.float64).sum()) - 1.0) < 1e-5
