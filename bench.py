@@ -1010,7 +1010,7 @@ def main():
             "prewarm": prewarm,
             "kernel_timing_pass": kernel_timing_pass,
             "kernels_ms_per_step": {"likelihood": lik_avg_ms, "beam": beam_ms / max(beam_n, 1) if n_b else 0.0,
-                                    "pf": 2.0 * pf_ms / max(pf_n, 1),
+                                    "pf": pf_ms / max(args.steps, 1),
                                     "collective": coll_ms / args.steps if use_dist else 0.0},
             "setup_seconds": setup_s,
             "index": dict(eng.index_stats(), lik_index=args.lik_index, voxel_ratio=args.cand_voxel_ratio,

@@ -458,14 +458,21 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       reference's own 64 x 1000 case is latency-bound); 0 = never
  *   "beam_prepare"      1 (default) = launches of >= 32 768 rays take what depends only on (particle, origin) from a
  *                       small kernel instead of every ray recomputing it; 0 = never
+ *   "sort_full_pass"    1 = arrays of 2049 .. 32 768 elements (a 16 384-point scan) are radix-sorted with ONE launch per
+ *                       8-bit pass — every work-group counts every work-group's digits itself —, 0 (default; measured
+ *                       faster) = a counting launch and a scatter launch per pass. Same order either way.
  *   "update_stage"      1 (default) = mcl3dl_hip_measure_update hands scans (<= 16 384 points per model), poses and prior
  *                       weights to the device with ONE launch that also orders the scans (stage_kernels.h), 0 = upload +
  *                       ordering as separate copies and launches (the path larger scans always take; same results)
  *   "update_zero_copy"  1 (default) = that launch reads the arrays in page-locked host memory and the update's last
  *                       kernel writes the results there; 0 = one H2D copy in front, one D2H copy behind
- *   "pf_tail"           1 = lik_finalize + pf::measure of up to 8192 particles on one GPU as ONE launch (pf_tail_kernel;
- *                       bit-identical to the separate kernels); 0 (default) = separate launches, which measured faster at
- *                       every size tried (one launch costs ~4 us, the arrival ticket's agent-scope release more)
+ *   "pf_tail"           1 (default) = pf::measure of up to 8192 particles on one GPU in two launches without hand-offs
+ *                       between work-groups (the un-normalised weights come out of lik_finalize / a small kernel; every
+ *                       work-group of pf_norm_kernel recomputes the reduction and normalises its own 256 weights);
+ *                       0 = pf_partial + pf_reduce + pf_apply. Bit-identical either way.
+ *   "update_particle"   1 (default) = between update_small_max and 8192 particles, updates the per-particle likelihood
+ *                       kernel serves (scans below ~768 points, <= 256 beam points) run likelihood + beam + weight in ONE
+ *                       launch (one work-group per particle) followed by pf_norm_kernel; 0 = separate model kernels
  *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
  *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
  *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",

@@ -527,6 +527,18 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  if (pf_tail_eligible(ctx, n_p))
+  {
+    // two launches, no hand-off: the weights, then every work-group reduces all of them and normalises its own (pf_norm_kernel)
+    TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+    EventPair ep{};
+    TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+    hipLaunchKernelGGL(pf_weights_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
+                       static_cast<int>(n_p), ctx->wnew.as<float>());
+    TRY(timing_end(ctx, ep));
+    HIP_TRY(hipGetLastError());
+    return launch_pf_norm(ctx, n_p, d_weight, d_lik, d_ratio, d_beam, d_stats4, ho);
+  }
   TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
   if (!ho)
     return mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4);
@@ -540,7 +552,7 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
 }
 
 // ho (optional): page-locked arrays for the results; *host_written comes back true when the update's last kernel wrote
-// them (pf_tail_kernel) — otherwise the caller copies the device arrays home.
+// them — otherwise the caller copies the device arrays home.
 int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                    float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const HostOut* ho = nullptr,
                    bool* host_written = nullptr)
@@ -548,6 +560,8 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   if (host_written)
     *host_written = ho != nullptr;  // every path below writes them
   const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho);
+  if (one == 2)  // the per-particle half ran: likelihood, beam score, un-normalised weights
+    return launch_pf_norm(ctx, n_p, d_weight, d_lik, d_ratio, d_beam, d_stats4, ho);
   if (one != 0)
     return one < 0 ? one : 0;
   MeasureTail mt;
@@ -793,7 +807,7 @@ int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float*
 namespace
 {
 // The host-buffer update with scan_stage_kernel in front (one launch takes over scans, poses and weights: ordering included)
-// and, where pf_tail_kernel runs, the results written straight into page-locked memory. Returns 1 when the update was run
+// and the results written straight into page-locked memory by the kernel that normalises the weights. Returns 1 when the update was run
 // this way (results delivered, stream synchronised), 0 when it is not eligible (the caller runs the general path), < 0 on
 // error.
 int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,

@@ -113,6 +113,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->pf_tail = value != 0.0;
     return 0;
   }
+  if (key == "update_particle")
+  {
+    ctx->update_particle = value != 0.0;
+    return 0;
+  }
   if (key == "update_small_max")
   {
     if (!(value >= 1.0 && value <= 65536.0))
@@ -178,6 +183,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   if (key == "pf_fused")
   {
     ctx->pf_fused = value != 0.0;
+    return 0;
+  }
+  if (key == "sort_full_pass")
+  {
+    ctx->sort_full_pass = value != 0.0;
     return 0;
   }
   if (key == "pf_fused_max")
@@ -301,6 +311,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "update_stage") *value = ctx->update_stage;
   else if (key == "update_zero_copy") *value = ctx->update_zero_copy;
   else if (key == "pf_tail") *value = ctx->pf_tail;
+  else if (key == "update_particle") *value = ctx->update_particle;
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "timing_mask") *value = ctx->timing_mask;
   else if (key == "use_graph") *value = ctx->use_graph;
@@ -323,6 +334,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[0];
   else if (key == "dda_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[1];
   else if (key == "pf_fused") *value = ctx->pf_fused;
+  else if (key == "sort_full_pass") *value = ctx->sort_full_pass;
   else if (key == "pf_fused_max") *value = ctx->pf_fused_max;
   else if (key == "scan_order_device") *value = ctx->scan_order_device;
   else

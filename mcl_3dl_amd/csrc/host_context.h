@@ -113,13 +113,16 @@ struct mcl3dl_hip_ctx
   // ONE launch (stage_kernels.h:scan_stage_kernel — ordering included) for scans up to ST_MAX_POINTS points per model;
   // update_zero_copy = 1: that kernel reads them where they lie in page-locked host memory and the last kernel of the update
   // writes the results there (no DMA copy either way), 0 = one H2D copy of the staged block, one D2H copy of the results;
-  // pf_tail = 1: lik_finalize + pf::measure of up to PF_TAIL_MAX_BLOCKS x 256 particles as one launch (pf_tail_kernel).
-  // Measured (profiles/r04a_time8d_*.json) and off by default: bit-identical, but 16 work-groups adding 64 tiles x 256
-  // particles of partials and one agent-scope release per work-group cost 32 us against 12 us for lik_finalize + the three pf
-  // launches at 4096 x 16 384 (device-resident step 0.252 against 0.234 ms), and +2.5 us at 4096 x 96
+  // pf_tail = 1: pf::measure of up to 8192 particles on one GPU finished by pf_norm_kernel (pf_kernels.h: every work-group
+  // recomputes the reduction, no hand-off), the weights formed by the kernel in front of it — two launches behind the tiled
+  // likelihood kernel instead of four, two in all (update_particle = 1: likelihood + beam + weight per work-group) where the
+  // per-particle likelihood kernel runs (4096 x 96 + 3: two launches instead of seven). 0 = the split kernels.
+  // (Round 4's first form — ONE launch with an arrival ticket per work-group — measured slower than the split kernels at every
+  // size: profiles/r04a_time8d_*.json.)
   int update_stage = 1;
   int update_zero_copy = 1;
-  int pf_tail = 0;
+  int pf_tail = 1;
+  int update_particle = 1;
   DevBuf stage_in_dev, tail_ticket;
   // page-locked host memory handed out by mcl3dl_hip_host_alloc: arrays inside it are read / written in place
   struct PinnedBlock
@@ -203,6 +206,10 @@ struct mcl3dl_hip_ctx
   uint32_t sp_kept32[2] = { 0, 0 };                 // their counts, delivered by one synchronisation
   size_t sp_n_full = 0, sp_n_clip[2] = { 0, 0 }, sp_n_samp[2] = { 0, 0 };
   bool sp_ready = false;
+  // arrays of 2049 .. 32 768 elements: 1 = one launch per radix pass, every work-group counting every work-group's digits itself
+  // (rs_pass_full_kernel). Measured and off: n LDS atomics per work-group on <= 256 addresses serialise — a 16 384-point scan took
+  // 55 us to stage against 43 us with the count + scatter launches (profiles/r04d_time8d_C2.json)
+  int sort_full_pass = 0;
   int scan_order_device = 4096;  // scans of at least this many points (both models together) are ordered on the device; 0 = never
   size_t n_base = 0;  // points of the base map; anything behind them in map_xyz is the current map update
   DevBuf ms_xyz, ms_out, ms_flag[2];

@@ -180,7 +180,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
   return 0;
 }
 
-// What launch_measure leaves to pf_tail_kernel when the caller asks for it (`want`): the sum over the tiled kernel's per-tile
+// What launch_measure leaves to launch_pf_tail when the caller asks for it (`want`): the sum over the tiled kernel's per-tile
 // partials (lik_partials: d_lik / d_ratio are NOT written by launch_measure then) and the beam score of an update without
 // beam points (beam_fill: d_beam is not written).
 struct MeasureTail
@@ -416,7 +416,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
 #undef LAUNCH_TILED
           if (tail && tail->want && !strict_terms && d_lik && d_ratio)
           {
-            tail->lik_partials = true;  // pf_tail_kernel adds the tiles up
+            tail->lik_partials = true;  // launch_pf_tail adds the tiles up (lik_finalize_kernel with the weights folded in)
             tail->n_tiles = n_tiles;
           }
           else
@@ -512,15 +512,35 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   return 0;
 }
 
+int pf_blocks(size_t n)
+{
+  const size_t b = (n + PF_BLOCK - 1) / PF_BLOCK;
+  return static_cast<int>(std::min<size_t>(std::max<size_t>(b, 1), 1024));
+}
+
+
+// is pf::measure of n_p particles on this GPU finished by pf_norm_kernel (weights formed by the kernel in front of it)?
+bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
+{
+  return ctx->pf_tail && ctx->strict_order != 1 && n_p >= 1 && n_p <= static_cast<size_t>(PF_NORM_MAX);
+}
+
 // The whole update — both models and pf::measure — as ONE launch (update_kernels.h) where the sizes are launch-bound:
 // returns 1 when it was enqueued, 0 when this update is not eligible (the caller then runs the separate kernels), < 0 on
 // error. Eligible: one GPU, per-particle likelihood kernel (not the tiled / small-scan forms), at most update_small_max
 // particles and 256 beam points, no float-order replay.
+// Returns 2 when only the per-particle half ran (more than update_small_max particles, pf_tail on): likelihood, beam score
+// and ctx->wnew are enqueued, the caller finishes with launch_pf_norm.
 int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                         float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho = nullptr)
 {
-  if (!ctx->update_small || n_p == 0 || n_p > static_cast<size_t>(ctx->update_small_max) || ctx->n_b > 256 ||
-      ctx->strict_order == 1 || !ctx->has_scan || !d_lik || !d_ratio || !d_beam)
+  if (!ctx->update_small || n_p == 0 || ctx->n_b > 256 || ctx->strict_order == 1 || !ctx->has_scan || !d_lik || !d_ratio ||
+      !d_beam)
+    return 0;
+  const bool tickets = n_p <= static_cast<size_t>(ctx->update_small_max);
+  // (above update_small_max only with a handful of beam points — the reference's default is 3: a work-group per particle
+  // walks its rays with mostly idle wavefronts, the flat beam kernel packs the rays of all particles)
+  if (!tickets && !(pf_tail_eligible(ctx, n_p) && ctx->update_particle && ctx->n_b <= 32))
     return 0;
   const int ns = static_cast<int>(ctx->n_s);
   if (ns > 0)
@@ -542,7 +562,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * static_cast<size_t>(nvb)));
   TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
   const size_t n_tickets = static_cast<size_t>(nvb) * 37 + static_cast<size_t>(ticket_tree_size(nvb)) + 1;
-  if (ctx->us_tickets.cap < sizeof(unsigned) * n_tickets)
+  if (tickets && ctx->us_tickets.cap < sizeof(unsigned) * n_tickets)
   {
     TRY(ensure(ctx, ctx->us_tickets, sizeof(unsigned) * n_tickets));
     // (a kernel, not hipMemsetAsync: see launch_measure — a memset node in a captured update faulted on replay)
@@ -578,11 +598,18 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.tickets = ctx->us_tickets.as<unsigned>();
   a.packed = ctx->partial4.as<double>();
   a.stats4 = d_stats4;
-  a.emit = ho ? *ho : PfEmit{};
+  a.emit = (ho && tickets) ? *ho : PfEmit{};  // (the particle-only form leaves the host copies to pf_norm_kernel)
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_UPDATE, &ep));
   const unsigned grid = static_cast<unsigned>(n_p);
-#define LAUNCH_US(BLOCK, MODE) hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a)
+#define LAUNCH_US(BLOCK, MODE)                                                                                      \
+  do                                                                                                                \
+  {                                                                                                                 \
+    if (tickets)                                                                                                    \
+      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a);     \
+    else                                                                                                            \
+      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a);    \
+  } while (0)
   // the work-group size the separate likelihood kernel would get (launch_measure), so that the lanes add in the same order
   const bool narrow = ns <= 128 && ctx->n_b <= 128;
   if (ctx->lik_index == 2)
@@ -612,69 +639,41 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
 #undef LAUNCH_US
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
-  return 1;
+  return tickets ? 1 : 2;
 }
 
-int pf_blocks(size_t n)
+// pf_norm_kernel over ctx->wnew (filled by lik_finalize_kernel / pf_weights_kernel / update_particle_kernel)
+int launch_pf_norm(mcl3dl_hip_ctx* ctx, size_t n_p, float* d_weight, const float* d_lik, const float* d_ratio,
+                   const float* d_beam, float* d_stats4, const PfEmit* ho)
 {
-  const size_t b = (n + PF_BLOCK - 1) / PF_BLOCK;
-  return static_cast<int>(std::min<size_t>(std::max<size_t>(b, 1), 1024));
-}
-
-
-// is pf::measure of n_p particles run by pf_tail_kernel (one launch, lik_finalize folded in)?
-bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
-{
-  return ctx->pf_tail && ctx->strict_order != 1 && n_p >= 1 &&
-         n_p <= static_cast<size_t>(PF_TAIL_MAX_BLOCKS) * PF_BLOCK;
-}
-
-int launch_pf_tail(mcl3dl_hip_ctx* ctx, const MeasureTail& mt, size_t n_p, float* d_weight, const float* d_extra, float* d_lik,
-                   float* d_ratio, float* d_beam, float* d_stats4, const HostOut* ho)
-{
-  const int nb = pf_blocks(n_p);
-  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
-  TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * static_cast<size_t>(nb)));
   TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
-  if (!ctx->tail_ticket.p)
-  {
-    TRY(ensure(ctx, ctx->tail_ticket, 64));
-    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->tail_ticket.as<float>(), 0.0f,
-                       static_cast<float*>(nullptr), 0.0f, 16);  // the kernel leaves it zero
-  }
-  TailArgs a{};
-  if (mt.lik_partials)
-  {
-    a.partial_sum = ctx->lik_partial_sum.as<double>();
-    a.partial_cnt = ctx->lik_partial_cnt.as<unsigned>();
-    a.n_tiles = mt.n_tiles;
-  }
-  a.n_s = static_cast<int>(ctx->n_s);
-  a.lik = d_lik;
-  a.ratio = d_ratio;
-  a.beam = d_beam;
-  a.beam_fill = mt.beam_fill ? 1 : 0;
-  a.w = d_weight;
-  a.extra = d_extra;
-  a.n = static_cast<int>(n_p);
-  a.w_new = ctx->wnew.as<float>();
-  a.block_partials = ctx->block_partials.as<double>();
-  a.ticket = ctx->tail_ticket.as<unsigned>();
-  a.packed = ctx->partial4.as<double>();
-  a.stats4 = d_stats4;
-  if (ho)
-  {
-    a.h_stats4 = ho->stats4;
-    a.h_w = ho->w;
-    a.h_lik = ho->lik;
-    a.h_ratio = ho->ratio;
-    a.h_beam = ho->beam;
-  }
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-  hipLaunchKernelGGL(pf_tail_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, a);
+  hipLaunchKernelGGL(pf_norm_kernel, dim3(pf_blocks(n_p)), dim3(1024), 0, ctx->stream, d_weight, ctx->wnew.as<float>(), d_ratio,
+                     static_cast<int>(n_p), ctx->partial4.as<double>(), d_stats4, ho ? *ho : PfEmit{}, d_lik, d_beam);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// The weights behind launch_measure(&mt): folded into lik_finalize_kernel where the tiled kernel left per-tile partials,
+// a launch of their own otherwise; then pf_norm_kernel.
+int launch_pf_tail(mcl3dl_hip_ctx* ctx, const MeasureTail& mt, size_t n_p, float* d_weight, const float* d_extra, float* d_lik,
+                   float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho)
+{
+  const int np = static_cast<int>(n_p);
+  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  if (mt.lik_partials)
+    hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, ctx->lik_partial_sum.as<double>(),
+                       ctx->lik_partial_cnt.as<unsigned>(), mt.n_tiles, np, static_cast<int>(ctx->n_s), d_lik, d_ratio,
+                       mt.beam_fill ? d_beam : static_cast<float*>(nullptr), d_weight, d_beam, d_extra, ctx->wnew.as<float>());
+  else
+    hipLaunchKernelGGL(pf_weights_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
+                       np, ctx->wnew.as<float>(), mt.beam_fill ? d_beam : static_cast<float*>(nullptr));
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return launch_pf_norm(ctx, n_p, d_weight, d_lik, d_ratio, d_beam, d_stats4, ho);
 }
 }  // namespace

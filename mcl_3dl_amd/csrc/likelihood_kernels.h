@@ -1046,10 +1046,17 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
 // (independent loads, 1/8 of the dependent chain), then lane-slice 0 adds the 8 sub-sums in fixed order (deterministic).
 // also_fill (may be null): an array of n_p floats set to 1 on the way — the beam score of an update without beam points
 // (beam.cpp:130-133), which would otherwise cost a launch of its own.
+// w_new (may be null): the particle's un-normalised weight w * (((1 * beam) * lik) * extra) formed on the way (pf.h:258 with
+// the lambda's product, src/mcl_3dl.cpp:407-424) — pf_kernels.h:pf_norm_kernel then needs no pf_partial launch. beam_in is
+// read for it unless also_fill is set (the beam score of this update is 1); has_beam = pf_partial_kernel's `beam` non-null.
 __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restrict__ partial_sum,
                                                            const unsigned* __restrict__ partial_cnt, int n_tiles, int n_p,
                                                            int n_s, float* __restrict__ out_lik,
-                                                           float* __restrict__ out_ratio, float* __restrict__ also_fill)
+                                                           float* __restrict__ out_ratio, float* __restrict__ also_fill,
+                                                           const float* __restrict__ w = nullptr,
+                                                           const float* __restrict__ beam_in = nullptr,
+                                                           const float* __restrict__ extra = nullptr,
+                                                           float* __restrict__ w_new = nullptr)
 {
   __shared__ double s_a[8][32];
   __shared__ unsigned s_n[8][32];
@@ -1076,12 +1083,24 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
     a += s_a[k][pl];
     n += s_n[k][pl];
   }
+  const float lik = static_cast<float>(a);
   if (out_lik)
-    out_lik[p] = static_cast<float>(a);
+    out_lik[p] = lik;
   if (out_ratio)
     out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
   if (also_fill)
     also_fill[p] = 1.0f;
+  if (w_new)
+  {
+    const bool has_beam = also_fill != nullptr || beam_in != nullptr;
+    float l = 1.0f;
+    if (has_beam)
+      l *= also_fill ? 1.0f : beam_in[p];
+    l *= lik;
+    if (extra)
+      l = l * extra[p];
+    w_new[p] = w[p] * l;
+  }
 }
 
 // "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): float adds,

@@ -319,6 +319,210 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// pf::measure of ONE GPU and at most PF_NORM_MAX particles in two launches without any hand-off between work-groups:
+//   pf_weights_kernel   w_new = w * (((1 * beam) * lik) * extra)            (or folded into the kernel that produces lik:
+//                       lik_finalize_kernel on the tiled path, update_particle_kernel on the per-particle path)
+//   pf_norm_kernel      pf_blocks(n) work-groups of 1024 threads; EVERY work-group recomputes the whole reduction — the 256-
+//                       particle partials of pf_partial_kernel and the 64-lane reduce of pf_reduce_kernel, in their association
+//                       (the loop of pf_fused_kernel), from the <= 32 KB of w_new / ratio in L2 — and then normalises ITS 256
+//                       weights (pf_apply_kernel). No ticket, no fence, nobody waits: redundant arithmetic (n log()s per
+//                       work-group) instead of a launch boundary. Same bits as the split form.
+// Replaces pf_partial + pf_reduce + pf_apply (three launches, ~4 us each on an idle queue) where one GPU holds every particle.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PF_NORM_MAX_BLOCKS = 32;
+constexpr int PF_NORM_MAX = PF_NORM_MAX_BLOCKS * PF_BLOCK;
+
+__device__ __forceinline__ float pf_weight_product(float w, float lik, float beam, bool has_beam, const float* __restrict__ extra,
+                                                   int i)
+{
+  float l = 1.0f;
+  if (has_beam)
+    l *= beam;
+  l *= lik;
+  if (extra)
+    l = l * extra[i];
+  return w * l;  // pf.h:258
+}
+
+// fill_beam (may be null): the update has no beam points — the beam score 1 (beam.cpp:130-133) is written there on the way
+// and used for the product (`beam` is not read then)
+__global__ __launch_bounds__(PF_BLOCK) void pf_weights_kernel(const float* __restrict__ w, const float* __restrict__ lik,
+                                                              const float* beam, const float* __restrict__ extra, int n,
+                                                              float* __restrict__ w_new, float* fill_beam = nullptr)
+{
+  const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
+  if (i >= n)
+    return;
+  if (fill_beam)
+    fill_beam[i] = 1.0f;
+  const bool has_beam = fill_beam != nullptr || beam != nullptr;
+  w_new[i] = pf_weight_product(w[i], lik[i], fill_beam ? 1.0f : (beam ? beam[i] : 1.0f), has_beam, extra, i);
+}
+
+// lik / beam: only read for `emit` (the device arrays its host copies come from); ratio: pf_partial_kernel's (may be null).
+// Latency, not work, is what this kernel costs (every load is a ~1 us round trip to data another kernel has just written):
+// all loads of a thread — its <= 8 weights / ratios of the reduction and what its own particle needs at the end — are issued
+// up front, and the work-group meets at three barriers in all.
+__global__ __launch_bounds__(1024) void pf_norm_kernel(float* __restrict__ w, const float* __restrict__ w_new,
+                                                       const float* __restrict__ ratio, int n, double* __restrict__ packed,
+                                                       float* __restrict__ stats4, PfEmit emit, const float* __restrict__ lik,
+                                                       const float* __restrict__ beam)
+{
+  constexpr int MAXIT = PF_NORM_MAX_BLOCKS / 4;
+  __shared__ double sh[4][MAXIT][16];   // per iteration, per wavefront of the group
+  __shared__ double part[4][PF_NORM_MAX_BLOCKS];
+  __shared__ double tot[4];
+  const int nb = (n + PF_BLOCK - 1) / PF_BLOCK;  // == gridDim.x == pf_blocks(n)
+  const int q = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mine = static_cast<int>(blockIdx.x);
+  const int n_it = (nb + 3) >> 2;
+  float wn_r[MAXIT], ra_r[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+  {
+    const int i = (4 * it + q) * PF_BLOCK + tid;
+    const bool ok = it < n_it && 4 * it + q < nb && i < n;
+    wn_r[it] = ok ? w_new[i] : 0.0f;
+    ra_r[it] = (ok && ratio) ? ratio[i] : 0.0f;
+  }
+  // this thread's own particle (quarter mine & 3 of the group finishes work-group `mine`'s 256 weights)
+  const int own_i = mine * PF_BLOCK + tid;
+  const bool owner = q == (mine & 3) && own_i < n;
+  float w_old = 0.f, e_lik = 0.f, e_beam = 1.f;
+  if (owner)
+  {
+    w_old = w[own_i];
+    if (emit.lik)
+      e_lik = lik[own_i];
+    if (emit.beam && beam)
+      e_beam = beam[own_i];
+  }
+  float own = 0.0f, own_ratio = 0.0f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+  {
+    if (it < n_it)  // (uniform over the work-group)
+    {
+      const int vb = 4 * it + q;
+      const int i = vb * PF_BLOCK + tid;
+      double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;
+      if (vb < nb && i < n)
+      {
+        const float wn = wn_r[it];
+        if (vb == mine)
+        {
+          own = wn;
+          own_ratio = ra_r[it];
+        }
+        s += static_cast<double>(wn);
+        if (wn > 0.0f)
+          t += static_cast<double>(wn) * log(static_cast<double>(wn));
+        if (ratio)
+        {
+          const double r = static_cast<double>(ra_r[it]);
+          rmax = r > rmax ? r : rmax;
+          rneg = -r > rneg ? -r : rneg;
+        }
+      }
+      s = wave_sum(s);
+      t = wave_sum(t);
+      rmax = wave_max(rmax);
+      rneg = wave_max(rneg);
+      if (lane == 0)
+      {
+        sh[0][it][wave] = s;
+        sh[1][it][wave] = t;
+        sh[2][it][wave] = rmax;
+        sh[3][it][wave] = rneg;
+      }
+    }
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < nb)
+  {
+    // pf_partial_kernel's thread 0 of virtual block vb: its four wavefronts in order
+    const int vb = threadIdx.x, it = vb >> 2, qq = vb & 3;
+    double a = 0, b = 0, c = sh[2][it][4 * qq], d = sh[3][it][4 * qq];
+    for (int k = 0; k < PF_BLOCK / 64; ++k)
+    {
+      a += sh[0][it][4 * qq + k];
+      b += sh[1][it][4 * qq + k];
+      c = sh[2][it][4 * qq + k] > c ? sh[2][it][4 * qq + k] : c;
+      d = sh[3][it][4 * qq + k] > d ? sh[3][it][4 * qq + k] : d;
+    }
+    part[0][vb] = a;
+    part[1][vb] = b;
+    part[2][vb] = c;
+    part[3][vb] = d;
+  }
+  __syncthreads();
+  if (wave == 0)
+  {
+    // pf_reduce_kernel
+    double a = 0, b = 0, c = 0.0, d = -1.0;
+    for (int k = lane; k < nb; k += 64)
+    {
+      a += part[0][k];
+      b += part[1][k];
+      c = part[2][k] > c ? part[2][k] : c;
+      d = part[3][k] > d ? part[3][k] : d;
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_max(c);
+    d = wave_max(d);
+    if (lane == 0)
+    {
+      tot[0] = a;
+      tot[1] = b;
+      tot[2] = c;
+      tot[3] = d;
+      if (mine == 0)
+      {
+        packed[0] = a;
+        packed[1] = b;
+        packed[2] = c;
+        packed[3] = d;
+      }
+    }
+  }
+  __syncthreads();
+  // pf_apply_kernel
+  const double S = tot[0];
+  const float sum_f = static_cast<float>(S);
+  const bool alive = sum_f > 0.0f;
+  if (owner)
+  {
+    float wv = w_old;
+    if (alive)
+    {
+      wv = own / sum_f;
+      w[own_i] = wv;
+    }
+    if (emit.w)
+      emit.w[own_i] = wv;
+    if (emit.lik)
+      emit.lik[own_i] = e_lik;
+    if (emit.ratio)
+      emit.ratio[own_i] = own_ratio;
+    if (emit.beam)
+      emit.beam[own_i] = e_beam;
+  }
+  if (mine == 0 && threadIdx.x == 0 && (stats4 || emit.stats4))
+  {
+    const float st[4] = { alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf(""), static_cast<float>(-tot[3]),
+                          static_cast<float>(tot[2]), alive ? 0.0f : 1.0f };
+    for (int k = 0; k < 4; ++k)
+    {
+      if (stats4)
+        stats4[k] = st[k];
+      if (emit.stats4)
+        emit.stats4[k] = st[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // "Next" row: the reductions that follow pf::measure in the node (src/mcl_3dl.cpp:451-452,706-709):
 // pf::expectationBiased / max / maxBiased (include/mcl_3dl/pf.h:294-303,361-390) with ParticleWeightedMeanQuat
 // (include/mcl_3dl/state_6dof.h:316-355), and pf::covariance (pf.h:304-360) with State6DOF::covElement (:162-184).

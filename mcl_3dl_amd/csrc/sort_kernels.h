@@ -379,6 +379,80 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(const uint32_t* __r
     }
 }
 
+// ---- RS_ONE_LAUNCH_MAX < n <= RS_FULL_MAX: ONE launch per pass, no counting launches ------------------------------------
+// What a pass needs from the other work-groups is how many elements with each digit every one of them owns — a property of
+// the keys alone. For arrays this small every work-group can count that ITSELF: it reads all n keys (64 KB at 16 384; pass 0
+// derives them from the points) and histograms them per owning work-group into LDS (n LDS atomics, ~2 us) — less than the
+// ~5 us a separate counting launch costs between two dependent kernels. A 16 384-point scan is ordered by three launches
+// instead of seven (keygen + count, then count / scatter pairs). Same ranks, same stable order as rs_pass_kernel.
+constexpr int RS_FULL_MAX_BLOCKS = 32;
+constexpr int RS_FULL_MAX = RS_THREADS * RS_FULL_MAX_BLOCKS;
+
+template <int KEYMODE, bool FIRST, bool APPLY>
+__global__ __launch_bounds__(RS_THREADS) void rs_pass_full_kernel(RsKeyGen kg, const uint32_t* __restrict__ keys_src,
+                                                                  const uint32_t* __restrict__ vals_src,
+                                                                  uint32_t* __restrict__ keys_dst, uint32_t* __restrict__ vals_dst,
+                                                                  RsFinal fin, int n, int pass, int n_pass, uint32_t mask)
+{
+  __shared__ uint32_t cnt[RS_WAVES][256];
+  __shared__ uint32_t dbase[256];
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t tab[RS_FULL_MAX_BLOCKS][256];
+  __shared__ uint32_t s_part[4][256];
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int shift = 8 * pass;
+  for (int k = threadIdx.x; k < nb * 256; k += RS_THREADS)
+    (&tab[0][0])[k] = 0u;
+  __syncthreads();
+  // every work-group's digit counts, from all n keys (element idx belongs to work-group idx / RS_THREADS)
+  uint32_t key[1] = { 0xffffffffu }, val[1] = { 0u }, dst[1] = { 0u };
+  const int own = b * RS_THREADS + w * 64 + lane;
+  for (int idx = threadIdx.x; idx < n; idx += RS_THREADS)
+  {
+    const uint32_t k = FIRST ? rs_make_key<KEYMODE>(kg, static_cast<uint32_t>(idx)) : keys_src[idx];
+    atomicAdd(&tab[idx / RS_THREADS][((k & mask) >> shift) & 255u], 1u);
+    if (idx == own)
+      key[0] = k;
+  }
+  const bool have = own < n;
+  const uint32_t valid = have ? 1u : 0u;
+  if (have)
+    val[0] = FIRST ? ((KEYMODE == RS_KEY_ARRAY && kg.vals) ? kg.vals[own] : static_cast<uint32_t>(own)) : vals_src[own];
+  // (rs_rank_pass starts with a barrier: tab is complete behind it)
+  rs_rank_pass<1>(key, valid, 1, shift, mask, dst, cnt, dbase, wsum, [&](uint32_t total_d, uint32_t* ws) {
+    (void)total_d;  // == tab[b][d]
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+    uint32_t all = 0, ahead = 0;
+    for (int bb = q; bb < nb; bb += 4)
+    {
+      const uint32_t x = tab[bb][d];
+      all += x;
+      ahead += bb < b ? x : 0u;
+    }
+    s_part[q][d] = all;
+    __syncthreads();
+    if (q == 0)
+      all = s_part[0][d] + s_part[1][d] + s_part[2][d] + s_part[3][d];
+    __syncthreads();
+    s_part[q][d] = ahead;
+    __syncthreads();
+    if (q == 0)
+      ahead = s_part[0][d] + s_part[1][d] + s_part[2][d] + s_part[3][d];
+    return rs_scan256(all, ws) + ahead;
+  });
+  if (APPLY && pass + 1 == n_pass)
+  {
+    rs_apply<1>(fin, val, dst, valid);
+    return;
+  }
+  if (have)
+  {
+    keys_dst[dst[0]] = key[0];
+    vals_dst[dst[0]] = val[0];
+  }
+}
+
 // ---- the two ends of a sort that goes to rocprim (more than RS_MAX_ELEMS elements) -------------------------
 template <int KEYMODE>
 __global__ void rs_keygen_kernel(RsKeyGen kg, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, long long n)

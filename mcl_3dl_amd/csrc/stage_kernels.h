@@ -1,5 +1,6 @@
-// stage_kernels.h — the head and the tail of a HOST-BUFFER measurement update (mcl3dl_hip_measure_update, SURVEY.md §8d's
-// timed region) as one launch each, so that an update of 4096 particles x 16 384 points is three launches and no DMA copy:
+// stage_kernels.h — the head of a HOST-BUFFER measurement update (mcl3dl_hip_measure_update, SURVEY.md §8d's timed region):
+// the caller's arrays are taken over by ONE launch and no DMA copy (the tail — results written back into page-locked memory by
+// the kernel that normalises the weights — is pf_kernels.h:PfEmit):
 //
 //   scan_stage_kernel   reads the caller's arrays where they lie in page-locked host memory (or in a device mirror of that
 //                       block after one copy) and leaves everything the update kernels need in device memory:
@@ -10,12 +11,7 @@
 //                         work-groups 2+ poses, prior weights and the odometry factor copied to their device arrays
 //                       Same keys, same stable order as host_cloud.h:device_order_scans (pack + min / max, key + count, three
 //                       count / scatter pairs: seven launches) and as the host ordering: bit-identical results on every path.
-//   pf_tail_kernel      lik_finalize_kernel + pf_partial_kernel + pf_reduce_kernel + pf_apply_kernel of one GPU in one launch
-//                       of pf_blocks(n) <= 32 work-groups: every work-group adds the per-tile partials of its 256 particles,
-//                       forms its weights and its partial sums in the association of the split kernels (same bits), and the
-//                       LAST one to arrive (one acq_rel ticket at agent scope: a single-level hand-off) reduces the <= 32
-//                       partials, normalises every weight and writes the results — optionally straight into page-locked host
-//                       memory, so that no D2H copy follows.
+//   stage_pack_kernel   scans of more than 2048 points: the same take-over without the ordering (the chip-wide sort follows)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -167,7 +163,7 @@ __device__ __forceinline__ void stage_order(const float* __restrict__ in_xyz, co
   }
   constexpr int END_BIT = KEYMODE == RS_KEY_MORTON ? MCL3DL_MORTON_BITS : 32;
   constexpr int N_PASS = (END_BIT + 7) / 8;
-  constexpr uint32_t MASK = END_BIT >= 32 ? 0xffffffffu : ((1u << END_BIT) - 1u);
+  constexpr uint32_t MASK = END_BIT >= 32 ? 0xffffffffu : ((1u << (END_BIT & 31)) - 1u);
   for (int p = 0; p < N_PASS; ++p)
   {
     rs_rank_pass<ROUNDS>(key, valid, rounds, 8 * p, MASK, dst, s.cnt, s.dbase, s.wsum,
@@ -289,213 +285,4 @@ __global__ __launch_bounds__(256) void stage_pack_kernel(StageArgs a, MinMaxOut 
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-struct TailArgs
-{
-  // the tiled likelihood kernel's per-(tile, particle) partials; null = lik[] / ratio[] hold the final values already
-  const double* partial_sum;
-  const unsigned* partial_cnt;
-  int n_tiles, n_s;
-  float* lik;
-  float* ratio;
-  float* beam;
-  int beam_fill;   // 1 = an update without beam points: beam[] := 1 (beam.cpp:130-133), written here
-  float* w;        // prior weights in, normalised weights out (untouched when every weight became 0: pf.h:274-278)
-  const float* extra;
-  int n;
-  float* w_new;
-  double* block_partials;  // [gridDim.x][4]
-  unsigned* ticket;        // zero before the launch; left zero
-  double* packed;          // [4] the reduced {sum w, sum w ln w, max ratio, -min ratio}
-  float* stats4;           // device copy of {entropy, min ratio, max ratio, restored}
-  // host-visible (page-locked, device-mapped) result arrays, each may be null
-  float* h_stats4;
-  float* h_w;
-  float* h_lik;
-  float* h_ratio;
-  float* h_beam;
-};
-
-constexpr int PF_TAIL_MAX_BLOCKS = 32;  // n <= 8192: the last work-group normalises every weight itself
-
-__global__ __launch_bounds__(PF_BLOCK) void pf_tail_kernel(TailArgs a)
-{
-  __shared__ double s_a[8][8][32];
-  __shared__ unsigned s_n[8][8][32];
-  __shared__ double sh[4][PF_BLOCK / 64];
-  __shared__ double s_tot[4];
-  __shared__ int s_last;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = blockIdx.x * PF_BLOCK + tid;  // this thread's particle (gridDim.x * PF_BLOCK >= n: one per thread)
-  float lik_i = 0.f, ratio_i = 0.f;
-  if (a.partial_sum)
-  {
-    // lik_finalize_kernel: 8 lane-slices per particle each walk every 8th tile, slice 0 adds the 8 sub-sums in order
-    const int pl = tid & 31, slice = tid >> 5;
-#pragma unroll 1
-    for (int sub = 0; sub < 8; ++sub)
-    {
-      const int p = blockIdx.x * PF_BLOCK + sub * 32 + pl;
-      double acc = 0.0;
-      unsigned cn = 0;
-      if (p < a.n)
-        for (int tl = slice; tl < a.n_tiles; tl += 8)
-        {
-          acc += a.partial_sum[static_cast<size_t>(tl) * a.n + p];
-          cn += a.partial_cnt[static_cast<size_t>(tl) * a.n + p];
-        }
-      s_a[sub][slice][pl] = acc;
-      s_n[sub][slice][pl] = cn;
-    }
-    __syncthreads();
-    const int sub = tid >> 5;
-    double acc = s_a[sub][0][pl];
-    unsigned cn = s_n[sub][0][pl];
-#pragma unroll
-    for (int k = 1; k < 8; ++k)
-    {
-      acc += s_a[sub][k][pl];
-      cn += s_n[sub][k][pl];
-    }
-    lik_i = static_cast<float>(acc);
-    ratio_i = static_cast<float>(cn) / static_cast<float>(a.n_s);
-    if (i < a.n)
-    {
-      a.lik[i] = lik_i;
-      a.ratio[i] = ratio_i;
-    }
-  }
-  else if (i < a.n)
-  {
-    lik_i = a.lik[i];
-    ratio_i = a.ratio[i];
-  }
-  // pf_partial_kernel
-  double sum = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;
-  if (i < a.n)
-  {
-    const float beam_i = a.beam_fill ? 1.0f : a.beam[i];
-    if (a.beam_fill)
-      a.beam[i] = 1.0f;
-    float l = 1.0f;
-    l *= beam_i;
-    l *= lik_i;
-    if (a.extra)
-      l = l * a.extra[i];
-    const float wn = a.w[i] * l;  // pf.h:258
-    a.w_new[i] = wn;
-    sum += static_cast<double>(wn);
-    if (wn > 0.0f)
-      t += static_cast<double>(wn) * log(static_cast<double>(wn));
-    const double r = static_cast<double>(ratio_i);
-    rmax = r > rmax ? r : rmax;
-    rneg = -r > rneg ? -r : rneg;
-    if (a.h_lik)
-      a.h_lik[i] = lik_i;
-    if (a.h_ratio)
-      a.h_ratio[i] = ratio_i;
-    if (a.h_beam)
-      a.h_beam[i] = beam_i;
-  }
-  sum = wave_sum(sum);
-  t = wave_sum(t);
-  rmax = wave_max(rmax);
-  rneg = wave_max(rneg);
-  if (lane == 0)
-  {
-    sh[0][wave] = sum;
-    sh[1][wave] = t;
-    sh[2][wave] = rmax;
-    sh[3][wave] = rneg;
-  }
-  __syncthreads();
-  if (tid == 0)
-  {
-    double pa = 0, pb = 0, pc = sh[2][0], pd = sh[3][0];
-    for (int k = 0; k < PF_BLOCK / 64; ++k)
-    {
-      pa += sh[0][k];
-      pb += sh[1][k];
-      pc = sh[2][k] > pc ? sh[2][k] : pc;
-      pd = sh[3][k] > pd ? sh[3][k] : pd;
-    }
-    a.block_partials[4 * blockIdx.x + 0] = pa;
-    a.block_partials[4 * blockIdx.x + 1] = pb;
-    a.block_partials[4 * blockIdx.x + 2] = pc;
-    a.block_partials[4 * blockIdx.x + 3] = pd;
-    // the hand-off: everything this work-group wrote (ordered before this thread by the barrier above) is released at
-    // agent scope with the arrival; the last arrival acquires every other work-group's writes with the same operation
-    const unsigned arrived = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (arrived + 1 == gridDim.x) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last)
-    return;
-  // ---- the last work-group: pf_reduce_kernel (64 lanes stride the partials) ...
-  const int nb = static_cast<int>(gridDim.x);
-  if (wave == 0)
-  {
-    double ra = 0, rb = 0, rc = 0.0, rd = -1.0;
-    for (int k = lane; k < nb; k += 64)
-    {
-      ra += a.block_partials[4 * k + 0];
-      rb += a.block_partials[4 * k + 1];
-      rc = a.block_partials[4 * k + 2] > rc ? a.block_partials[4 * k + 2] : rc;
-      rd = a.block_partials[4 * k + 3] > rd ? a.block_partials[4 * k + 3] : rd;
-    }
-    ra = wave_sum(ra);
-    rb = wave_sum(rb);
-    rc = wave_max(rc);
-    rd = wave_max(rd);
-    if (lane == 0)
-    {
-      s_tot[0] = ra;
-      s_tot[1] = rb;
-      s_tot[2] = rc;
-      s_tot[3] = rd;
-      a.packed[0] = ra;
-      a.packed[1] = rb;
-      a.packed[2] = rc;
-      a.packed[3] = rd;
-      *a.ticket = 0u;  // for the next launch (kernel boundary orders it)
-    }
-  }
-  __syncthreads();
-  // ... and pf_apply_kernel over every particle
-  const double S = s_tot[0];
-  const float sum_f = static_cast<float>(S);
-  const bool alive = sum_f > 0.0f;
-  for (int k = tid; k < a.n; k += PF_BLOCK)
-  {
-    float wv;
-    if (alive)
-    {
-      wv = a.w_new[k] / sum_f;
-      a.w[k] = wv;
-    }
-    else
-      wv = a.w[k];
-    if (a.h_w)
-      a.h_w[k] = wv;
-  }
-  if (tid == 0)
-  {
-    const float st0 = alive ? static_cast<float>(log(S) - s_tot[1] / S) : __builtin_nanf("");
-    const float st1 = static_cast<float>(-s_tot[3]), st2 = static_cast<float>(s_tot[2]), st3 = alive ? 0.0f : 1.0f;
-    if (a.stats4)
-    {
-      a.stats4[0] = st0;
-      a.stats4[1] = st1;
-      a.stats4[2] = st2;
-      a.stats4[3] = st3;
-    }
-    if (a.h_stats4)
-    {
-      a.h_stats4[0] = st0;
-      a.h_stats4[1] = st1;
-      a.h_stats4[2] = st2;
-      a.h_stats4[3] = st3;
-    }
-  }
-}
 }  // namespace mcl3dl

@@ -49,7 +49,7 @@ def run_modes(engine, sc, n_p, n_s, n_b, extra, modes, origins=None, beam_label=
     finally:
         engine.set_option("update_stage", 1)
         engine.set_option("update_zero_copy", 1)
-        engine.set_option("pf_tail", 0)
+        engine.set_option("pf_tail", 1)
     return out
 
 
@@ -58,7 +58,9 @@ ALL_MODES = [(0, 0, 0), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 0, 1)]
 
 @pytest.mark.parametrize("n_p,n_s,n_b", [(64, 96, 3), (64, 1000, 32), (700, 300, 0), (513, 2048, 40), (1024, 2049, 0),
                                          (1025, 4096, 7), (4096, 1000, 96), (2000, 8192, 512), (2049, 8193, 0),
-                                         (600, 16384, 2048), (700, 2048, 2049), (650, 2049, 2048), (8192, 1024, 3), (8193, 1500, 3), (1, 96, 3), (3, 1, 1),
+                                         (600, 16384, 2048), (700, 2048, 2049), (650, 2049, 2048), (8192, 1024, 3),
+                                         (8193, 1500, 3), (1, 96, 3), (3, 1, 1), (4096, 96, 3), (2000, 500, 20), (5000, 700, 0),
+                                         (8192, 64, 32), (1500, 767, 33),
                                          (4096, 0, 48), (300, 5, 0)])
 @pytest.mark.parametrize("extra", [False, True])
 def test_staged_update_equals_the_general_path(engine, scene, n_p, n_s, n_b, extra):
@@ -122,7 +124,7 @@ def test_restore_rule(engine, scene):
             outs.append(engine.measure_update(far, w0, sc.scan_lik[:600], None, None, sc.origins))
     finally:
         engine.set_option("update_stage", 1)
-        engine.set_option("pf_tail", 0)
+        engine.set_option("pf_tail", 1)
     for o in outs:
         assert o["restored"]
         np.testing.assert_array_equal(o["weights"], w0)
@@ -168,12 +170,13 @@ def test_arrays_in_the_callers_page_locked_block(engine, scene):
 
 
 def test_device_resident_update_with_and_without_the_tail(engine, scene):
-    """mcl3dl_hip_update_device: pf_tail_kernel against lik_finalize + pf_partial + pf_reduce + pf_apply (and the single
-    work-group form up to 1024 particles), tiled and per-particle likelihood kernels in front of it."""
+    """mcl3dl_hip_update_device: the two-launch tail (weights folded into lik_finalize / the per-particle kernel, pf_norm_kernel)
+    against lik_finalize + pf_partial + pf_reduce + pf_apply (and the single work-group form up to 1024 particles), tiled and
+    per-particle likelihood kernels in front of it."""
     sc = scene
     configure(engine, sc, 16, stamp=9500)
     dev = torch.device("cuda", 0)
-    for n_p, n_s, n_b in [(600, 300, 16), (1000, 2048, 0), (4096, 2048, 16), (8192, 700, 3), (5000, 96, 0)]:
+    for n_p, n_s, n_b in [(600, 300, 16), (1000, 2048, 0), (4096, 2048, 16), (8192, 700, 3), (5000, 96, 0), (4096, 96, 3)]:
         engine.upload_scan(sc.scan_lik[:n_s], sc.scan_beam[:n_b] if n_b else None, sc.scan_beam_label[:n_b] if n_b else None,
                            sc.origins)
         d_pose = torch.from_numpy(np.ascontiguousarray(sc.poses[:n_p])).to(dev)
@@ -191,7 +194,7 @@ def test_device_resident_update_with_and_without_the_tail(engine, scene):
                     engine.synchronize()
                 got.append([t.cpu().numpy() for t in (d_w, d_lik, d_ratio, d_beam, d_stats)])
         finally:
-            engine.set_option("pf_tail", 0)
+            engine.set_option("pf_tail", 1)
         for x, y in zip(got[0], got[1]):
             np.testing.assert_array_equal(x, y)
         assert abs(float(got[1][0].astype(np.float64).sum()) - 1.0) < 1e-5
