@@ -466,13 +466,17 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       ordering as separate copies and launches (the path larger scans always take; same results)
  *   "update_zero_copy"  1 (default) = that launch reads the arrays in page-locked host memory and the update's last
  *                       kernel writes the results there; 0 = one H2D copy in front, one D2H copy behind
- *   "pf_tail"           1 (default) = pf::measure of up to 8192 particles on one GPU in two launches without hand-offs
- *                       between work-groups (the un-normalised weights come out of lik_finalize / a small kernel; every
- *                       work-group of pf_norm_kernel recomputes the reduction and normalises its own 256 weights);
- *                       0 = pf_partial + pf_reduce + pf_apply. Bit-identical either way.
- *   "update_particle"   1 (default) = between update_small_max and 8192 particles, updates the per-particle likelihood
- *                       kernel serves (scans below ~768 points, <= 256 beam points) run likelihood + beam + weight in ONE
- *                       launch (one work-group per particle) followed by pf_norm_kernel; 0 = separate model kernels
+ *   "poll_sync"         1 (default) = a zero-copy host-buffer update learns of its completion from a word in page-locked
+ *                       memory that a one-thread kernel behind it writes (polled by the caller's thread), 0 =
+ *                       hipStreamSynchronize (6 us slower on MI355X / ROCm 7)
+ *   "pf_tail"           1 = pf::measure of up to 8192 particles on one GPU in two launches without hand-offs between
+ *                       work-groups (the un-normalised weights come out of lik_finalize / a small kernel; every work-group
+ *                       of pf_norm_kernel recomputes the reduction and normalises its own 256 weights); 0 (default) =
+ *                       pf_partial + pf_reduce + pf_apply. Bit-identical either way; the three small launches measured
+ *                       3-5 us faster behind a long likelihood kernel (they are enqueued while it runs).
+ *   "update_particle"   1 = with pf_tail, between update_small_max and 8192 particles, updates the per-particle likelihood
+ *                       kernel serves (scans below ~768 points, <= 32 beam points) run likelihood + beam + weight in ONE
+ *                       launch (one work-group per particle) followed by pf_norm_kernel; 0 (default) = separate kernels
  *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
  *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
  *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",

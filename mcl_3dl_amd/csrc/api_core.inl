@@ -104,6 +104,8 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     (void)hipHostFree(ch.p);
   for (const mcl3dl_hip_ctx::PinnedBlock& b : ctx->pinned)
     (void)hipHostFree(b.p);
+  if (ctx->done_flag)
+    (void)hipHostFree(const_cast<unsigned*>(ctx->done_flag));
   if (ctx->ev_fork)
     (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join)
@@ -994,7 +996,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
     const size_t upto = out_beam ? 64 + 3 * rpart + fb : out_match_ratio ? 64 + 2 * rpart + fb : out_lik ? 64 + rpart + fb : 64 + fb;
     TRY(d2h_block(ctx, blk, upto, pieces, 5));
   }
-  TRY(sync_stream(ctx));
+  TRY(sync_stream(ctx, host_written));  // (results behind a D2H copy: the stream itself is waited for)
   return 1;
 }
 }  // namespace

@@ -113,6 +113,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->pf_tail = value != 0.0;
     return 0;
   }
+  if (key == "poll_sync")
+  {
+    ctx->poll_sync = value != 0.0;
+    return 0;
+  }
   if (key == "update_particle")
   {
     ctx->update_particle = value != 0.0;
@@ -312,6 +317,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "update_zero_copy") *value = ctx->update_zero_copy;
   else if (key == "pf_tail") *value = ctx->pf_tail;
   else if (key == "update_particle") *value = ctx->update_particle;
+  else if (key == "poll_sync") *value = ctx->poll_sync;
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "timing_mask") *value = ctx->timing_mask;
   else if (key == "use_graph") *value = ctx->use_graph;

@@ -116,13 +116,21 @@ struct mcl3dl_hip_ctx
   // pf_tail = 1: pf::measure of up to 8192 particles on one GPU finished by pf_norm_kernel (pf_kernels.h: every work-group
   // recomputes the reduction, no hand-off), the weights formed by the kernel in front of it — two launches behind the tiled
   // likelihood kernel instead of four, two in all (update_particle = 1: likelihood + beam + weight per work-group) where the
-  // per-particle likelihood kernel runs (4096 x 96 + 3: two launches instead of seven). 0 = the split kernels.
+  // per-particle likelihood kernel runs (4096 x 96 + 3: two launches instead of seven). 0 = the split kernels (default:
+  // behind a long likelihood kernel the three pf launches are already queued and cost ~1.6 us each on the device, less than
+  // the redundant 1024-thread reduction — C2 host-buffer update 0.2884 with, 0.2833 ms without: profiles/r04e_time8d_C2.json).
   // (Round 4's first form — ONE launch with an arrival ticket per work-group — measured slower than the split kernels at every
   // size: profiles/r04a_time8d_*.json.)
   int update_stage = 1;
   int update_zero_copy = 1;
-  int pf_tail = 1;
-  int update_particle = 1;
+  int pf_tail = 0;
+  int update_particle = 0;
+  // host-buffer updates end by POLLING a word in page-locked memory that a one-thread kernel behind the update's last kernel
+  // writes, instead of hipStreamSynchronize: 6.3 against 12.2 us for launch + completion of one kernel on this part
+  // (profiles/r04e_launch_cost.txt). 0 = hipStreamSynchronize.
+  int poll_sync = 1;
+  volatile unsigned* done_flag = nullptr;
+  unsigned done_seq = 0;
   DevBuf stage_in_dev, tail_ticket;
   // page-locked host memory handed out by mcl3dl_hip_host_alloc: arrays inside it are read / written in place
   struct PinnedBlock
@@ -487,10 +495,52 @@ int d2h_block(mcl3dl_hip_ctx* ctx, const void* src, size_t bytes, const D2hPiece
   return 0;
 }
 
-// hipStreamSynchronize + hand the staged results to the caller's arrays + recycle the staging memory.
-int sync_stream(mcl3dl_hip_ctx* ctx)
+__global__ void done_flag_kernel(volatile unsigned* flag, unsigned seq)
 {
+  __threadfence_system();
+  *flag = seq;
+}
+
+// Completion of everything enqueued on ctx->stream so far, observed through page-locked memory: a one-thread kernel behind
+// it writes a sequence number, the host spins on it (bounded: ~2 s, then hipStreamSynchronize decides). What the kernels in
+// front wrote into page-locked memory left the device before the flag did (uncached stores, one ordered path to the host).
+int wait_done_flag(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx->done_flag)
+  {
+    ctx->done_flag = static_cast<volatile unsigned*>(pinned_alloc(ctx, 64));
+    if (!ctx->done_flag || !ctx->update_zero_copy)
+    {
+      ctx->poll_sync = 0;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      return 0;
+    }
+    *ctx->done_flag = 0u;
+  }
+  const unsigned seq = ++ctx->done_seq;
+  hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->done_flag, seq);
+  HIP_TRY(hipGetLastError());
+  for (long long spin = 0; spin < 2000000000LL; ++spin)
+  {
+    if (*ctx->done_flag == seq)
+    {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return 0;
+    }
+    __builtin_ia32_pause();
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// hipStreamSynchronize (or, polled = true and the option on, the polled completion flag) + hand the staged results to the
+// caller's arrays + recycle the staging memory.
+int sync_stream(mcl3dl_hip_ctx* ctx, bool polled = false)
+{
+  if (polled && ctx->poll_sync)
+    TRY(wait_done_flag(ctx));
+  else
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (const mcl3dl_hip_ctx::StagedResult& r : ctx->stage_out)
     memcpy(r.user, r.staged, r.bytes);
   ctx->stage_out.clear();

@@ -38,7 +38,7 @@ constexpr int RS_MAX_ELEMS = 524288;                              // above: rocp
 enum
 {
   RS_KEY_ARRAY = 0,   // keys (and values, or the index when vals == nullptr) come from arrays
-  RS_KEY_MORTON = 1,  // 22-bit Morton key of a likelihood scan point (cloud_keys.h, api_core.inl:order_scan)
+  RS_KEY_MORTON = 1,  // MCL3DL_MORTON_BITS-bit Morton key of a likelihood scan point (cloud_keys.h, api_core.inl:order_scan)
   RS_KEY_RANGE = 2,   // squared range of a beam point from its origin, as float bits
   RS_KEY_LEAF = 3     // pcl::VoxelGrid leaf index
 };

@@ -4,7 +4,7 @@
 //
 //   scan_stage_kernel   reads the caller's arrays where they lie in page-locked host memory (or in a device mirror of that
 //                       block after one copy) and leaves everything the update kernels need in device memory:
-//                         work-group 0   the likelihood scan: xyz -> float4, min corner, 22-bit Morton keys, stable LSD radix
+//                         work-group 0   the likelihood scan: xyz -> float4, min corner, Morton keys (cloud_keys.h), stable LSD radix
 //                                        sort of (key, index) with the pairs exchanged through LDS, ordered points + the
 //                                        permutation written by the last pass                 (api_core.inl:order_scan)
 //                         work-group 1   the beam scan the same way, keyed by squared range from its origin
