@@ -152,21 +152,52 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_counters(kernel_prefix, workload):
+PMC_SOURCES = {"beam": ["beam_kernels.h", "device_math.h", "map_structs.h", "Makefile"],
+               "lik": ["likelihood_kernels.h", "device_math.h", "map_structs.h", "map_compiler.h", "Makefile"]}
+
+
+def source_sha(name):
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "mcl_3dl_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+
+
+def pmc_counters(kernel_prefix, workload, check_sources=True, only=None):
     """Mean per launch of every counter the newest committed PMC summary for this workload holds for the kernel
-    (profiles/*_pmc_summary.csv, separate --pmc passes: profiles/run_profiles.sh). Returns (dict, path) or (None, None)."""
+    (profiles/*_pmc_summary.csv, separate --pmc passes: profiles/run_profiles.sh). Returns (dict, path, note); the counters
+    are REFUSED (None, None, why) when the summary does not say which sources it profiled or when one of the kernel's sources
+    (or the build flags) has changed since: a kernel edit after the last --pmc session must not keep the old counters.
+    check_sources=False / only="r03" (file-name prefix): the historical summaries, for the tests that pin their arithmetic."""
     import csv
     import glob
-    vals, src = {}, None
+    vals, src, shas = {}, None, {}
     # exactly this workload tag (r02h_C2_pmc_summary.csv, not r02h_C2j_...: the jittered map has its own counters)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc*summary.csv" % workload))):
+        if only and not os.path.basename(path).startswith(only):
+            continue
+        here, tags = {}, {}
         for row in csv.DictReader(open(path)):
-            if row["kernel"].startswith(kernel_prefix):
-                vals[row["counter"]] = float(row["mean_per_launch"])  # a later (newer) file wins, counter by counter
-                src = path
+            if row["kernel"] == "__source__":
+                tags[row["counter"]] = row["mean_per_launch"]
+            elif row["kernel"].startswith(kernel_prefix):
+                here[row["counter"]] = float(row["mean_per_launch"])
+        if here:
+            if tags != shas and src is not None and tags.get("git_head") != shas.get("git_head"):
+                vals = {}   # counters of different builds are not mixed: the newest file that has this kernel wins whole
+            vals.update(here)
+            src, shas = path, tags
     if not vals:
-        return None, None
-    return vals, os.path.relpath(src, ROOT)
+        return None, None, None
+    rel = os.path.relpath(src, ROOT)
+    family = "beam" if "beam_kernel" in kernel_prefix else "lik"
+    if not check_sources:
+        return vals, rel, None
+    if not shas:
+        return None, None, "%s does not record the sources it profiled (written before round 4): not used" % rel
+    changed = [n for n in PMC_SOURCES[family] if shas.get(n) != source_sha(n)]
+    if changed:
+        return None, None, ("%s profiled commit %s; %s changed since (sha %s then): counters not used — run profiles/run_profiles.sh again"
+                            % (rel, shas.get("git_head", "?"), ", ".join(changed), ", ".join(str(shas.get(n)) for n in changed)))
+    return vals, rel, None
 
 
 def l2_calibration():
@@ -217,14 +248,16 @@ def kernel_resources(pmc, kernel_s, cost, cost_src, l2cal=None):
             if l2cal.get("record64_requests_per_s"):
                 rate = pmc["TCP_TCC_READ_REQ_sum"] / kernel_s
                 res["l2_requests"] = {"achieved": rate / 1e9, "peak": l2cal["record64_requests_per_s"] / 1e9,
-                                      "unit": "G requests/s", "frac": min(rate / l2cal["record64_requests_per_s"], 1.0),
+                                      "unit": "G requests/s", "frac": rate / l2cal["record64_requests_per_s"],
                                       "peak_kind": "measured",
                                       "note": "peak = request rate of the quad-cooperative 64-byte record fetch alone over an "
-                                              "L2-resident set (profiles/l2_calib.hip)"}
+                                              "L2-resident set (profiles/l2_calib.hip) — a ceiling of THAT access pattern, not "
+                                              "of the part: a kernel that also fetches overflow records (map of centroids) has "
+                                              "been measured above it, and the fraction is printed unclamped"}
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc:
             rate = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (kernel_s * CLOCK_HZ)
             res["l1_access"] = {"achieved": rate, "peak": L1_ACCESS_CEILING, "unit": "cache-line accesses/cycle/CU",
-                                "frac": min(rate / L1_ACCESS_CEILING, 1.0), "peak_kind": "measured",
+                                "frac": rate / L1_ACCESS_CEILING, "peak_kind": "measured",
                                 "accesses_per_launch": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
                                 "note": "peak = measured ceiling (see bench.py L1_ACCESS_CEILING), not a datasheet value"}
         if "SQ_INSTS_VALU" in pmc:
@@ -233,7 +266,7 @@ def kernel_resources(pmc, kernel_s, cost, cost_src, l2cal=None):
             # (i) against the documented issue rate: every wave64 VALU instruction 2 cycles of its SIMD
             doc = n_all * VALU_DOC_CYCLES / avail
             res["valu_issue"] = {"achieved": n_all / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / VALU_DOC_CYCLES / 1e9,
-                                 "unit": "G wave64 VALU instructions/s", "frac": min(doc, 1.0), "peak_kind": "documented",
+                                 "unit": "G wave64 VALU instructions/s", "frac": doc, "peak_kind": "documented",
                                  "wave_instructions_per_launch": n_all, "cycles_per_instruction": VALU_DOC_CYCLES,
                                  "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)"}
             # (ii) the same instructions priced with the measured issue cost of each class (profiles/valu_microbench.hip).
@@ -250,7 +283,7 @@ def kernel_resources(pmc, kernel_s, cost, cost_src, l2cal=None):
             lo, hi = (fixed + n_mixed * cost["full"]) / avail, (fixed + n_mixed * cost["half"]) / avail
             mid = 0.5 * (lo + hi)
             res["valu_issue_priced"] = {"achieved": mid * avail / kernel_s / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9,
-                                        "unit": "G SIMD-cycles/s", "frac": min(mid, 1.0), "frac_low": lo, "frac_high": hi,
+                                        "unit": "G SIMD-cycles/s", "frac": mid, "frac_low": lo, "frac_high": hi,
                                         "peak_kind": "measured",
                                         "full_rate": n_full, "half_rate": n_half, "transcendental": n_trans,
                                         "between_full_and_half_rate": n_mixed, "cycles_per_instruction": cost,
@@ -830,17 +863,22 @@ def main():
         prewarm["ms"] = (time.perf_counter() - t_pre) * 1e3
     for _ in range(args.warmup):
         step(main_sh)
-    eng.set_option("timing_mask", args.timing_mask)
+    # (bit 3 = the whole update as one launch, which stands in for the likelihood kernel up to update_small_max particles)
+    eng.set_option("timing_mask", args.timing_mask | (8 if args.timing_mask & 1 else 0))
     eng.set_kernel_timing(True)
     eng.reset_kernel_time()
     elapsed = timed(main_sh, args.steps)
     lik_ms, lik_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
+    one_launch = False
+    if lik_n == 0:
+        lik_ms, lik_n = eng.kernel_time(capi.KERNEL_UPDATE)
+        one_launch = lik_n > 0
     # Second pass of the same K steps, outside `elapsed`, every kernel group timed and the two models one after the other:
     # the beam / pf durations (each timed group costs two event records per launch, so only the roofline kernel is
     # timed inside the timed region), and the likelihood duration too when it ran concurrently with the beam kernels
     # above (overlapping event intervals say nothing about either kernel).
     overlapped = bool(n_b and n_s and args.overlap_models)
-    eng.set_option("timing_mask", 7)
+    eng.set_option("timing_mask", 31)
     eng.set_option("overlap_models", 0)
     eng.reset_kernel_time()
     coll_ms = 0.0
@@ -864,14 +902,19 @@ def main():
             coll_ms += ev0.elapsed_time(ev1)
     torch.cuda.synchronize(dev)
     lik2_ms, lik2_n = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
+    if lik2_n == 0:
+        lik2_ms, lik2_n = eng.kernel_time(capi.KERNEL_UPDATE)
     beam_ms, beam_n = eng.kernel_time(capi.KERNEL_BEAM)
     pf_ms, pf_n = eng.kernel_time(capi.KERNEL_PF)
+    upd_ms, upd_n = eng.kernel_time(capi.KERNEL_UPDATE)
     eng.set_option("overlap_models", args.overlap_models)
     if overlapped or not (args.timing_mask & 1):
         lik_ms, lik_n = lik2_ms, lik2_n
         kernel_timing_pass = "second pass of the same steps (overlap_models=0, all kernel groups timed)"
     else:
         kernel_timing_pass = "likelihood: hipEvents inside the timed region; beam, pf: second pass of the same steps"
+    if one_launch:
+        kernel_timing_pass += "; `likelihood` = the one-launch update (likelihood + beam + pf::measure in one kernel)"
     eng.set_kernel_timing(False)
 
     # the other scaling mode, same K steps, same bracketing (only when there is more than one rank to tell them apart)
@@ -908,7 +951,7 @@ def main():
             kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 1024 if wide else 256, args.lik_index)
         # counters of the same map kind: profiles/*_C2j_* = C2 with displaced map points (--map-jitter)
         pmc_tag = args.workload + ("j" if args.map_jitter else "")
-        pmc, pmc_src = pmc_counters("void mcl3dl::" + kernel_name, pmc_tag)
+        pmc, pmc_src, pmc_refused = pmc_counters("void mcl3dl::" + kernel_name, pmc_tag)
         # the committed counters are per launch of ONE shape: use them only for a launch of that many wavefronts
         if tiled:
             expected_waves = 4 * ((n_s + 255) // 256) * ((n_p + group - 1) // group)
@@ -916,7 +959,7 @@ def main():
             expected_waves = None
         else:
             expected_waves = n_p * (1 if n_s <= 128 else 16 if "<1024" in kernel_name else 4)
-        counters_note = None
+        counters_note = pmc_refused
         if pmc and (expected_waves is None or abs(pmc.get("SQ_WAVES", 0.0) - expected_waves) > 0.01 * expected_waves):
             counters_note = ("committed counters (%s) are for a launch of %.0f wavefronts, this one has %s: not used"
                              % (pmc_src, pmc.get("SQ_WAVES", 0.0), expected_waves))
@@ -1011,6 +1054,8 @@ def main():
             "kernel_timing_pass": kernel_timing_pass,
             "kernels_ms_per_step": {"likelihood": lik_avg_ms, "beam": beam_ms / max(beam_n, 1) if n_b else 0.0,
                                     "pf": pf_ms / max(args.steps, 1),
+                                    # the whole update as ONE launch (<= update_small_max particles): then the three above are 0
+                                    "update_one_launch": upd_ms / max(args.steps, 1),
                                     "collective": coll_ms / args.steps if use_dist else 0.0},
             "setup_seconds": setup_s,
             "index": dict(eng.index_stats(), lik_index=args.lik_index, voxel_ratio=args.cand_voxel_ratio,
@@ -1034,7 +1079,9 @@ def main():
                                                      "(one timed group, run alone: overlap_models = 0)"}
             # the beam kernel's own counter-derived fractions (same pricing as `roofline`), against the kernel's share of the
             # timed group: its rocprofv3 share of beam_kernel in the group is > 95 % at these sizes
-            bpmc, bsrc = pmc_counters("void mcl3dl::beam_kernel<false>", pmc_tag)
+            bpmc, bsrc, bnote = pmc_counters("void mcl3dl::beam_kernel<false>", pmc_tag)
+            if bnote:
+                out["beam"]["counters_note"] = bnote
             beam_waves = 4 * ((n_p * n_b + 255) // 256)
             if bpmc and abs(bpmc.get("SQ_WAVES", 0.0) - beam_waves) > 0.01 * beam_waves:
                 bpmc = None   # counters of another launch shape
@@ -1056,18 +1103,57 @@ def main():
             # SURVEY.md section 8d's definition of one update: host buffers in, host buffers out (scan ordering + upload,
             # pose and prior-weight H2D, kernels, reduction, weight D2H) through the synchronous host entry point
             eng.set_stream(None)
+            # timed from C (tools/benchloop.c: the reference's caller is C++; ctypes spends ~15 us per call converting the 19
+            # arguments) on pageable arrays — every array staged through the library's page-locked block — and on arrays the
+            # caller allocated with mcl3dl_hip_host_alloc (read and written in place); the Python-call figure next to them
+            h_pose = np.ascontiguousarray(sc.poses, np.float32)
+            h_w0 = np.ascontiguousarray(sc.weights, np.float32)
+            h_lik = np.ascontiguousarray(sc.scan_lik, np.float32)
+            h_beam = np.ascontiguousarray(sc.scan_beam, np.float32) if n_b else None
+            h_lab = np.ascontiguousarray(sc.scan_beam_label, np.uint32) if n_b else None
+            h_org = np.ascontiguousarray(sc.origins, np.float32)
+            o_lik, o_ratio, o_beam = (np.zeros(n_p, np.float32) for _ in range(3))
+            with no_gc():
+                host_ms, per = eng.time_measure_update(h_pose, h_w0, h_w0.copy(), h_lik, h_beam, h_lab, h_org, o_lik, o_ratio,
+                                                       o_beam, args.steps, warm_ms=150.0)
+            pin = dict(pose=eng.host_array((n_p, 7)), w=eng.host_array(n_p), lik=eng.host_array((n_s, 3)),
+                       beam=eng.host_array((n_b, 3)) if n_b else None, lab=eng.host_array(n_b, np.uint32) if n_b else None,
+                       org=eng.host_array((len(h_org), 3)), o_lik=eng.host_array(n_p), o_ratio=eng.host_array(n_p),
+                       o_beam=eng.host_array(n_p))
+            pin["pose"][:] = h_pose
+            pin["lik"][:] = h_lik
+            pin["org"][:] = h_org
+            if n_b:
+                pin["beam"][:] = h_beam
+                pin["lab"][:] = h_lab
+            with no_gc():
+                pinned_ms, _per = eng.time_measure_update(pin["pose"], h_w0, pin["w"], pin["lik"], pin["beam"], pin["lab"],
+                                                          pin["org"], pin["o_lik"], pin["o_ratio"], pin["o_beam"], args.steps,
+                                                          warm_ms=100.0)
+            same_results = bool(np.array_equal(pin["o_lik"], o_lik) and np.array_equal(pin["o_ratio"], o_ratio))
             keep_gpu_warm(lambda: eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label,
-                                                     sc.origins), 0.15)
+                                                     sc.origins), 0.1)
             with no_gc():
                 t2 = time.perf_counter()
                 for _ in range(args.steps):
                     eng.measure_update(sc.poses, sc.weights, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
-                host_ms = (time.perf_counter() - t2) / args.steps * 1e3
+                python_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            for a in pin.values():
+                if a is not None:
+                    eng.host_free(a)
             out["value_8d"] = n_p * n_s / (host_ms * 1e-3)
             out["update_8d"] = {"ms_per_update": host_ms, "value": n_p * n_s / (host_ms * 1e-3),
                                 "unit": "particle·point evals/s", "update_hz": 1e3 / host_ms, "steps": args.steps,
-                                "what": "mcl3dl_hip_measure_update on host buffers: scan upload + pose/weight H2D + kernels "
-                                        "+ weight/likelihood D2H, PCIe included (SURVEY.md section 8d's timed region)"}
+                                "median_ms": float(np.median(per)), "min_ms": float(per.min()),
+                                "overhead_over_device_resident_ms": host_ms - ms_per_step,
+                                "ms_per_update_page_locked_arrays": pinned_ms,
+                                "value_page_locked_arrays": n_p * n_s / (pinned_ms * 1e-3),
+                                "page_locked_results_equal": same_results,
+                                "ms_per_update_called_from_python": python_ms,
+                                "what": "mcl3dl_hip_measure_update on host buffers, timed from C (tools/benchloop.c): scan upload + "
+                                        "ordering + pose/weight H2D + kernels + weight/likelihood D2H, PCIe included (SURVEY.md "
+                                        "section 8d's timed region); pageable caller arrays (ms_per_update) and arrays from "
+                                        "mcl3dl_hip_host_alloc (ms_per_update_page_locked_arrays)"}
             eng.set_stream(stream.cuda_stream)
         if not args.no_extras:
             # the reductions that follow the update in the node (expectationBiased + max + covariance) on the

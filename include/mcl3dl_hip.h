@@ -429,6 +429,13 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= "lik_tiled_min" points and >= 4
  *                       particles; 0 = one work-group per particle always (only the fp64 summation order differs)
  *   "lik_tiled_min"     default 1024; with >= 256 particles the tiled kernel already takes over at three quarters of it
+ *   "update_small"      1 (default) = up to "update_small_max" particles (default 512) an update whose scans the per-particle
+ *                       kernels serve (<= ~768 likelihood points, <= 256 beam points) runs as ONE launch: likelihood + beam
+ *                       + pf::measure, the stages handed over by arrival tickets (update_kernels.h); 0 = separate kernels
+ *   "update_small_conformant"  0 (default) = the tickets are relaxed increments behind drained agent-scope stores (the
+ *                       fence-free form the gfx950 guide gives); 1 = acq_rel increments at agent scope, the form the
+ *                       HIP / LLVM memory model defines (one L2 write-back per arrival: slower). Same results; a one-line
+ *                       mitigation should the default ever misbehave on a future part (tests/test_gpu_soak.py runs both)
  *   "use_graph"         1 = mcl3dl_hip_update_device replays a captured hipGraph; 0 (default) = enqueue kernel by kernel
  *   "timing_mask"       bit k set (default: all) = kernel group k is timed while kernel timing is on
  *   "overlap_models"    1 (default) = the beam kernels run on a second stream concurrently with the likelihood kernels
@@ -443,7 +450,12 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       (single GPU; costs an n_s x n_p float buffer and two serial passes); 2 (default) = the likelihood
  *                       terms are replayed in that order for scans of at least "strict_auto_min" points (default 32 768)
  *                       — from there on the reference's own float rounding, a random walk of n_s roundings, reaches the
- *                       1e-5 relative tolerance the fp64 sum is held to — and summed in fp64 below
+ *                       1e-5 relative tolerance the fp64 sum is held to — and summed in fp64 below. The automatic replay
+ *                       needs n_s x n_p floats of device memory (0.5 GB at 32 768 x 4096, 26 GB at 65 536 x 100 000): a
+ *                       launch whose buffer would take more than half of the free device memory (or more than
+ *                       "strict_auto_max_bytes" when that is set, or whose allocation fails) sums in fp64 instead — the
+ *                       update never fails over it; read-only "strict_auto_skipped" counts such launches. Mode 1 fails
+ *                       loudly when its buffer cannot be had.
  *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
  *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
  *                       results either way.

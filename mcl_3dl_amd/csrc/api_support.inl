@@ -123,6 +123,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->update_particle = value != 0.0;
     return 0;
   }
+  if (key == "update_small_conformant")
+  {
+    ctx->update_small_conformant = value != 0.0;
+    return 0;
+  }
   if (key == "update_small_max")
   {
     if (!(value >= 1.0 && value <= 65536.0))
@@ -137,6 +142,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     if (static_cast<int>(value) != ctx->strict_auto_min)
       ++ctx->generation;
     ctx->strict_auto_min = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "strict_auto_max_bytes")
+  {
+    if (!(value >= 0.0))
+      return ctx->fail(-3, "strict_auto_max_bytes must be >= 0");
+    ctx->strict_auto_max_bytes = value;
     return 0;
   }
   if (key == "timing_mask")
@@ -308,6 +320,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
+  else if (key == "strict_auto_max_bytes") *value = ctx->strict_auto_max_bytes;
+  else if (key == "strict_auto_skipped") *value = static_cast<double>(ctx->strict_auto_skipped);
   else if (key == "overlap_min_rays") *value = static_cast<double>(ctx->overlap_min_rays);
   else if (key == "resample_prefix_device") *value = ctx->resample_prefix_device;
   else if (key == "cand_refine") *value = ctx->cand_refine;
@@ -319,6 +333,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "update_particle") *value = ctx->update_particle;
   else if (key == "poll_sync") *value = ctx->poll_sync;
   else if (key == "update_small_max") *value = ctx->update_small_max;
+  else if (key == "update_small_conformant") *value = ctx->update_small_conformant;
   else if (key == "timing_mask") *value = ctx->timing_mask;
   else if (key == "use_graph") *value = ctx->use_graph;
   else if (key == "overlap_models") *value = ctx->overlap_models;

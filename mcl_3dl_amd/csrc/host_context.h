@@ -100,6 +100,8 @@ struct mcl3dl_hip_ctx
   // reference's own float rounding (a random walk of n_s roundings) reaches the 1e-5 tolerance of north_star; 0 = never
   int strict_order = 2;
   int strict_auto_min = 32768;
+  double strict_auto_max_bytes = 0.0;  // > 0: the automatic replay is also skipped when its buffer would exceed this many bytes
+  uint64_t strict_auto_skipped = 0;  // launches of the automatic mode that summed in fp64 because the replay buffer did not fit
   DevBuf scan_block;  // { perm | lik scan | beam scan | origins } of the current update in ONE allocation (ensure_scan_block)
   DevBuf scan_perm, strict_terms;
   // the whole update as one launch (update_kernels.h) up to update_small_max particles when the per-particle likelihood
@@ -108,6 +110,7 @@ struct mcl3dl_hip_ctx
   // every work-group's arrival is an atomic the memory side serialises, and there are as many as particles
   int update_small = 1;
   int update_small_max = 512;
+  int update_small_conformant = 0;  // 1 = acq_rel arrival tickets at agent scope (update_kernels.h:last_arrival)
   DevBuf us_tickets;
   // host-buffer updates (mcl3dl_hip_measure_update): update_stage = 1: the caller's scans / poses / weights are taken over by
   // ONE launch (stage_kernels.h:scan_stage_kernel — ordering included) for scans up to ST_MAX_POINTS points per model;

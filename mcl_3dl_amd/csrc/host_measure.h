@@ -123,15 +123,15 @@ bool lik_strict(const mcl3dl_hip_ctx* ctx, int ns)
   return ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min);
 }
 
-int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
+// rows of G floats per particle group: what the float-order replay of ns points x n_p particles stores
+size_t strict_terms_bytes(size_t n_p, int ns, int group_size)
 {
-  const int np = static_cast<int>(n_p);
-  const bool strict = lik_strict(ctx, ns);
-  // tiled from lik_tiled_min points up (default 1024), and already from three quarters of that when there are enough particles
-  // to fill the GPU with (tile, group) pairs (4096 x 1000: 30.6 us tiled against 34.9 us; 64 x 1000 and 4096 x 512: no gain)
-  pl->tiled = (ctx->lik_tiled && np >= 4 &&
-               (ns >= ctx->lik_tiled_min || (np >= 256 && 4 * static_cast<long long>(ns) >= 3ll * ctx->lik_tiled_min))) ||
-              strict;
+  const size_t G = static_cast<size_t>(group_size);
+  return sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G;
+}
+
+int plan_group_size(const mcl3dl_hip_ctx* ctx, int np, int ns)
+{
   // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
   // work-group slots something to do (few particles x a long scan would otherwise leave most of the GPU idle)
   int group_size = ctx->lik_group;
@@ -146,6 +146,50 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
         break;
       }
   }
+  return group_size;
+}
+
+int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
+{
+  const int np = static_cast<int>(n_p);
+  bool strict = lik_strict(ctx, ns);
+  const int group_size = plan_group_size(ctx, np, ns);
+  if (strict && ctx->strict_order == 2)
+  {
+    // The AUTOMATIC replay (scans of at least strict_auto_min points) costs ns x n_p floats of device memory — 0.5 GB at
+    // 32 768 x 4096, 26 GB at 65 536 x 100 000. It is a refinement (the fp64 sums are within ~1e-5 of the reference's
+    // float at such sizes), so it must never make an update fail: when the buffer would take more than half of the free
+    // device memory, or its allocation fails, this launch sums in fp64 like smaller scans do. (strict_order = 1 — asked for
+    // explicitly — still fails loudly.)
+    const size_t need = strict_terms_bytes(n_p, ns, group_size);
+    if (ctx->strict_auto_max_bytes > 0.0 && static_cast<double>(need) > ctx->strict_auto_max_bytes)
+    {
+      strict = false;
+      ++ctx->strict_auto_skipped;
+    }
+    else if (need > ctx->strict_terms.cap)
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+      {
+        (void)hipGetLastError();
+        free_b = 0;
+      }
+      const bool over_cap = ctx->strict_auto_max_bytes > 0.0 && static_cast<double>(need) > ctx->strict_auto_max_bytes;
+      if (over_cap || need + need / 4 > (free_b + ctx->strict_terms.cap) / 2 || ensure(ctx, ctx->strict_terms, need) != 0)
+      {
+        (void)hipGetLastError();
+        ctx->err.clear();
+        strict = false;
+        ++ctx->strict_auto_skipped;
+      }
+    }
+  }
+  // tiled from lik_tiled_min points up (default 1024), and already from three quarters of that when there are enough particles
+  // to fill the GPU with (tile, group) pairs (4096 x 1000: 30.6 us tiled against 34.9 us; 64 x 1000 and 4096 x 512: no gain)
+  pl->tiled = (ctx->lik_tiled && np >= 4 &&
+               (ns >= ctx->lik_tiled_min || (np >= 256 && 4 * static_cast<long long>(ns) >= 3ll * ctx->lik_tiled_min))) ||
+              strict;
   pl->group_size = group_size;
   pl->small = !pl->tiled && ns <= 32 && np >= 256 && ctx->lik_small;
   if (pl->small)
@@ -160,7 +204,6 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
   }
   else if (pl->tiled)
   {
-    const size_t G = static_cast<size_t>(group_size);
     pl->n_tiles = (ns + 255) / 256;
     pl->n_groups = (np + group_size - 1) / group_size;
     // per XCD: the interleaved tiles of the largest multiple of eight, then an eighth of the remaining (tile, group) pairs
@@ -172,8 +215,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
     TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(pl->n_tiles) * n_p));
     if (strict)
     {
-      // rows of G floats per particle group
-      TRY(ensure(ctx, ctx->strict_terms, sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G));
+      TRY(ensure(ctx, ctx->strict_terms, strict_terms_bytes(n_p, ns, group_size)));
       pl->strict_terms = ctx->strict_terms.as<float>();
     }
   }
@@ -598,6 +640,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.tickets = ctx->us_tickets.as<unsigned>();
   a.packed = ctx->partial4.as<double>();
   a.stats4 = d_stats4;
+  a.conformant = ctx->update_small_conformant;
   a.emit = (ho && tickets) ? *ho : PfEmit{};  // (the particle-only form leaves the host copies to pf_norm_kernel)
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_UPDATE, &ep));

@@ -61,6 +61,7 @@ struct UpdateSmallArgs
   double* packed;       // [4]
   float* stats4;
   PfEmit emit;          // page-locked host copies of the results (pf_kernels.h), each may be null
+  int conformant;       // 1: every arrival is an acq_rel read-modify-write at agent scope (see last_arrival)
 };
 
 __device__ __forceinline__ void store_agent(float* p, float v)
@@ -80,10 +81,32 @@ __device__ __forceinline__ double load_agent(const double* p)
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// thread 0 draws a ticket once every wavefront's stores are drained; every thread learns whether it was the last of `expected`
-__device__ __forceinline__ bool last_arrival(unsigned* ticket, unsigned expected)
+// thread 0 draws a ticket once every wavefront's stores are drained; every thread learns whether it was the last of `expected`.
+// Two forms of the hand-off:
+//   default     what the guide gives as the fence-free form on gfx950: the payload was written with agent-scope (sc1,
+//               write-through) stores, every wavefront waits for its own stores (s_waitcnt vmcnt(0)), then a RELAXED ticket
+//               increment; the last arrival reads the payload with agent-scope (sc1) loads. Correct on this ISA, but the
+//               ordering between payload and ticket rests on the waitcnt, not on the language's memory model.
+//   conformant  (option "update_small_conformant") the ticket increment is an ACQ_REL read-modify-write at agent scope,
+//               issued by thread 0 behind a work-group barrier: the barrier orders every thread's payload stores before it
+//               (release is cumulative), the last arrival's increment acquires every earlier one. This is the form the
+//               HIP / LLVM memory model defines; it costs a write-back of the XCD's L2 per arrival (measured in round 3:
+//               4096 work-groups x 96 points 20 -> 110 us), which is why it is a switch for a field problem, not the default.
+//               tests/test_gpu_soak.py runs both.
+__device__ __forceinline__ bool last_arrival(unsigned* ticket, unsigned expected, int conformant)
 {
   __shared__ int s_last;
+  if (conformant)
+  {
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t + 1u == expected) ? 1 : 0;
+    }
+    __syncthreads();
+    return s_last != 0;
+  }
   // every wavefront drains its own (write-through) stores before the barrier — a barrier does not wait for memory
   // operations in flight — so that what lane 0 releases below includes them
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -112,13 +135,13 @@ __host__ __device__ inline int ticket_tree_size(int width)
 
 // true for exactly one work-group among the `width` that call this with their index and the same tree: the one whose
 // arrival completes the root. A work-group leaves as soon as it is not the last arrival at a node.
-__device__ __forceinline__ bool last_of_tree(unsigned* tree, int idx, int width)
+__device__ __forceinline__ bool last_of_tree(unsigned* tree, int idx, int width, int conformant)
 {
   while (width > 1)
   {
     const int node = idx / US_FAN, nodes = (width + US_FAN - 1) / US_FAN;
     const int children = min(US_FAN, width - node * US_FAN);
-    if (!last_arrival(tree + node, static_cast<unsigned>(children)))
+    if (!last_arrival(tree + node, static_cast<unsigned>(children), conformant))
       return false;
     tree += nodes;
     idx = node;
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
   const int vb = p / PF_BLOCK;
   const int in_vb = min(PF_BLOCK, a.n_p - vb * PF_BLOCK);
   constexpr int VB_TREE = 32 + 4 + 1;  // ticket_tree_size(256)
-  if (!last_of_tree(a.tickets + vb * VB_TREE, p - vb * PF_BLOCK, in_vb))
+  if (!last_of_tree(a.tickets + vb * VB_TREE, p - vb * PF_BLOCK, in_vb, a.conformant))
     return;
   __shared__ double sh[4][4];
   for (int chunk = wave; chunk < 4; chunk += NW)  // pf_partial_kernel: wavefront `chunk` of the block, one element per lane
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
     store_agent(a.vb_partials + 4 * vb + 3, d);
   }
   // ---- Stage 2: the last virtual block to finish
-  if (!last_of_tree(a.tickets + nvb * VB_TREE, vb, nvb))
+  if (!last_of_tree(a.tickets + nvb * VB_TREE, vb, nvb, a.conformant))
     return;
   __shared__ double tot[4];
   if (wave == 0)

@@ -6,8 +6,24 @@ profiles/run_profiles.sh runs it ON the GPU box with --out gpurun_out/prof_<tag>
 import collections
 import csv
 import glob
+import hashlib
+import os
 import shutil
 import sys
+
+# what the counters belong to: sha256 of the kernel sources (and the build flags) they were collected from — bench.py
+# refuses counters whose sources differ from the tree it runs in — and the commit (GIT_HEAD=... in the environment of the
+# profiling command: the GPU box has no .git)
+SOURCES = ["likelihood_kernels.h", "beam_kernels.h", "device_math.h", "map_structs.h", "map_compiler.h", "Makefile"]
+
+
+def source_rows(root="."):
+    rows = [["__source__", "git_head", os.environ.get("GIT_HEAD", "unknown"), 0]]
+    for name in SOURCES:
+        path = os.path.join(root, "mcl_3dl_amd", "csrc", name)
+        rows.append(["__source__", name, hashlib.sha256(open(path, "rb").read()).hexdigest()[:16], 0])
+    return rows
+
 
 tag = sys.argv[1]
 out_dir = 'profiles'
@@ -30,6 +46,8 @@ for f in sorted(glob.glob('gpurun_out/prof_%s/pmc_*/%s_counter_collection.csv' %
             out.setdefault(k, {})[c] = (s / n, n)
 w = csv.writer(open('%s/%s_pmc_summary.csv' % (out_dir, tag), 'w'))
 w.writerow(["kernel", "counter", "mean_per_launch", "launches"])
+for row in source_rows():
+    w.writerow(row)
 for k in sorted(out):
     for c in sorted(out[k]):
         w.writerow([k, c, "%.6g" % out[k][c][0], out[k][c][1]])

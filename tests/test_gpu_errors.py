@@ -113,3 +113,27 @@ def test_two_contexts_are_independent():
     assert not np.array_equal(la1, lb)
     a.close()
     b.close()
+
+
+def test_automatic_strict_order_never_fails_an_update_over_memory(engine):
+    """strict_order = 2 replays scans of >= strict_auto_min points in the reference's float order, at the cost of an n_s x n_p
+    float buffer; when that buffer is refused (here: by the byte cap) the launch sums in fp64 like a smaller scan — within the
+    reference's own rounding of the strict result — instead of failing."""
+    import numpy as np
+    from mcl_3dl_amd.synthetic import make_scene
+    sc = make_scene(n=91, n_p=300, n_s=4000, seed=99)
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=7700, dist_weight=(1.0, 1.0, 1.0))
+    engine.set_likelihood_params()
+    try:
+        engine.set_option("strict_auto_min", 3000)
+        strict, ratio_s, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        before = engine.get_option("strict_auto_skipped")
+        engine.set_option("strict_auto_max_bytes", 1 << 20)   # 4000 x 304 x 4 B = 4.9 MB does not fit
+        loose, ratio_l, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        assert engine.get_option("strict_auto_skipped") == before + 1
+    finally:
+        engine.set_option("strict_auto_min", 32768)
+        engine.set_option("strict_auto_max_bytes", 0)
+    np.testing.assert_array_equal(ratio_s, ratio_l)
+    np.testing.assert_allclose(loose, strict, rtol=1e-5)
+    assert not np.array_equal(loose, strict)   # (the float recurrence and the fp64 tree do differ somewhere over 300 particles)
