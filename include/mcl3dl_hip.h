@@ -391,6 +391,47 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
                                     const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
                                     float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
                                     float* match_ratio_min, float* match_ratio_max, int* restored);
+/* ---- the group's particles RESIDENT on its GPUs: a whole filter iteration without a per-update pose upload ----------------
+ * Replaces, for N GPUs, what the node does with pf_ around the measurement (src/mcl_3dl.cpp:398-452, 706-709, 809):
+ *   upload_state      the particle vector (include/mcl_3dl/pf.h:457) as 13 floats per particle {pos 3, rot 4 (x,y,z,w),
+ *                     odom_err_integ lin 3, ang 3} (State6DOF, state_6dof.h:56-66) + probabilities (NULL: 1 / n_p each),
+ *                     scattered into contiguous shards (mcl3dl_hip_group_shard); they stay on the devices until the next
+ *                     upload. The motion model (prediction) is the caller's: download, predict, upload — or keep the states
+ *                     where they are when nothing moved.
+ *   update_resident   pf::measure (pf.h:252-279 with the lambda of src/mcl_3dl.cpp:402-425) over the resident particles:
+ *                     only the scan (and the odometry factor `extra`, n_p floats or NULL) goes up, one all-reduce of
+ *                     2 + 2N doubles, four scalars come back; out_weight / out_lik / out_match_ratio / out_beam (each may be
+ *                     NULL) fetch per-particle results. Same results as mcl3dl_hip_group_measure_update on the same particles.
+ *   expectation       pf::expectationBiased + max + maxBiased (pf.h:294-303, 361-390): one 16-double record per shard,
+ *                     combined on the host (mcl3dl_hip_moments_finish); bias = probability_bias_ per particle or NULL.
+ *   covariance        pf::covariance about mean7 (pf.h:304-360, all particles): 22 sums per shard, added in rank order.
+ *   resample_begin    accum_probability_ (pf.h:193-197 / 401-405): the float recurrence is sequential over ALL particles, so
+ *                     every weight comes to the host once (4 B per particle) and the prefixes go to every device; n_out = 0
+ *                     keeps the particle count (resample), another value is resizeParticle (pf.h:399-436). *out_pstep for
+ *                     the caller's uniform draw (pf.h:203).
+ *   resample_plan     mode / initial_p / outputs as mcl3dl_hip_resample_plan (every rank plans all slots: n_out searches).
+ *   resample_apply    all-gather of the 13-float states (ncclAllGather over xGMI; through the host with "collective" 1), every
+ *                     rank writes ITS shard of the new generation (duplicates get noise13[slot], State6DOF::operator+ and
+ *                     normalize(): pf.h:214-218), weights 1 / n_out (pf.h:207), poses refreshed. The particles are resident
+ *                     again, n_out of them.
+ * With one device and "direct_single" 1 none of this touches RCCL. */
+int mcl3dl_hip_group_upload_state(mcl3dl_hip_group* g, const float* state13 /*n_p*13*/, const float* weight /*n_p or NULL*/,
+                                  size_t n_p);
+int mcl3dl_hip_group_download_state(mcl3dl_hip_group* g, float* state13 /*n_p*13 or NULL*/, float* weight /*n_p or NULL*/,
+                                    size_t n_p);
+size_t mcl3dl_hip_group_resident(const mcl3dl_hip_group* g);
+int mcl3dl_hip_group_update_resident(mcl3dl_hip_group* g, const float* extra /*n_p or NULL*/, const float* scan_lik_xyz,
+                                     size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
+                                     const float* origins, size_t n_o, float* out_weight, float* out_lik,
+                                     float* out_match_ratio, float* out_beam, float* entropy, float* match_ratio_min,
+                                     float* match_ratio_max, int* restored);
+int mcl3dl_hip_group_expectation(mcl3dl_hip_group* g, const float* bias /*n_p or NULL*/, float* out_mean7, float* out_total,
+                                 int64_t* out_max_index, int64_t* out_max_biased_index);
+int mcl3dl_hip_group_covariance(mcl3dl_hip_group* g, const float* mean7, float* out_cov36);
+int mcl3dl_hip_group_resample_begin(mcl3dl_hip_group* g, size_t n_out /*0 = as many as there are*/, float* out_pstep);
+int mcl3dl_hip_group_resample_plan(mcl3dl_hip_group* g, int mode, float initial_p, uint32_t* out_source /*n_out or NULL*/,
+                                   uint8_t* out_duplicate /*n_out or NULL*/, size_t* out_n_duplicates);
+int mcl3dl_hip_group_resample_apply(mcl3dl_hip_group* g, const float* noise13 /*n_dup*13, host*/, size_t n_noise);
 /* How many updates went through each kind of collective so far. */
 int mcl3dl_hip_group_collective_stats(const mcl3dl_hip_group* g, uint64_t* rccl_all_reduces, uint64_t* host_combines);
 

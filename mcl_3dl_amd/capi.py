@@ -94,6 +94,15 @@ SIGNATURES = {
     "mcl3dl_hip_group_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p,
                                             _p]),
     "mcl3dl_hip_group_collective_stats": (_i, [_p, C.POINTER(_u64), C.POINTER(_u64)]),
+    "mcl3dl_hip_group_upload_state": (_i, [_p, _p, _p, _sz]),
+    "mcl3dl_hip_group_download_state": (_i, [_p, _p, _p, _sz]),
+    "mcl3dl_hip_group_resident": (_sz, [_p]),
+    "mcl3dl_hip_group_update_resident": (_i, [_p, _p, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mcl3dl_hip_group_expectation": (_i, [_p, _p, _p, _p, _p, _p]),
+    "mcl3dl_hip_group_covariance": (_i, [_p, _p, _p]),
+    "mcl3dl_hip_group_resample_begin": (_i, [_p, _sz, _p]),
+    "mcl3dl_hip_group_resample_plan": (_i, [_p, _i, _f, _p, _p, _p]),
+    "mcl3dl_hip_group_resample_apply": (_i, [_p, _p, _sz]),
     "mcl3dl_hip_get_option": (_i, [_p, C.c_char_p, C.POINTER(_d)]),
     "mcl3dl_hip_index_stats": (_i, [_p, _p]),
 }
@@ -253,6 +262,65 @@ class Group:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._check(self.lib.mcl3dl_hip_group_collective_stats(self.h, C.byref(a), C.byref(b)))
         return dict(rccl=int(a.value), host=int(b.value))
+
+    # ---- particles resident on the group's devices (include/mcl3dl_hip.h) -------------------------------------------------
+    def upload_state(self, state13, weights=None):
+        s = _np_f32(state13, 13)
+        w = None if weights is None else _np_f32(weights)
+        self._check(self.lib.mcl3dl_hip_group_upload_state(self.h, _ptr(s), _ptr(w), len(s)))
+
+    def resident(self):
+        return int(self.lib.mcl3dl_hip_group_resident(self.h))
+
+    def download_state(self):
+        n = self.resident()
+        s, w = np.zeros((n, 13), np.float32), np.zeros(n, np.float32)
+        self._check(self.lib.mcl3dl_hip_group_download_state(self.h, _ptr(s), _ptr(w), n))
+        return s, w
+
+    def update_resident(self, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None, extra=None, fetch=True):
+        n_p = self.resident()
+        ex = None if extra is None else _np_f32(extra)
+        sl, sb, so, og = Engine._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        w, lik, ratio, beam = ((np.zeros(n_p, np.float32) for _ in range(4)) if fetch else (None, None, None, None))
+        ent, rmin, rmax, rest = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        self._check(self.lib.mcl3dl_hip_group_update_resident(
+            self.h, _ptr(ex), _ptr(sl), len(sl), _ptr(sb), _ptr(so), len(sb), _ptr(og), len(og), _ptr(w), _ptr(lik), _ptr(ratio),
+            _ptr(beam), C.byref(ent), C.byref(rmin), C.byref(rmax), C.byref(rest)))
+        return dict(weights=w, lik=lik, quality=ratio, beam=beam, entropy=float(ent.value),
+                    match_ratio_min=float(rmin.value), match_ratio_max=float(rmax.value), restored=bool(rest.value))
+
+    def expectation(self, bias=None):
+        b = None if bias is None else _np_f32(bias)
+        mean = np.zeros(7, np.float32)
+        total = C.c_float(0)
+        im, ib = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.mcl3dl_hip_group_expectation(self.h, _ptr(b), _ptr(mean), C.byref(total), C.byref(im), C.byref(ib)))
+        return mean, float(total.value), int(im.value), int(ib.value)
+
+    def covariance(self, mean7):
+        m = _np_f32(mean7)
+        cov = np.zeros((6, 6), np.float32)
+        self._check(self.lib.mcl3dl_hip_group_covariance(self.h, _ptr(m), _ptr(cov)))
+        return cov
+
+    def resample_begin(self, n_out=0):
+        pstep = C.c_float(0)
+        self._check(self.lib.mcl3dl_hip_group_resample_begin(self.h, int(n_out), C.byref(pstep)))
+        self._rs_n_out = n_out or self.resident()
+        return float(pstep.value)
+
+    def resample_plan(self, mode, initial_p=0.0):
+        nd = C.c_size_t(0)
+        src = np.zeros(self._rs_n_out, np.uint32)
+        dup = np.zeros(self._rs_n_out, np.uint8)
+        self._check(self.lib.mcl3dl_hip_group_resample_plan(self.h, int(mode), float(initial_p), _ptr(src), _ptr(dup),
+                                                            C.byref(nd)))
+        return src, dup, int(nd.value)
+
+    def resample_apply(self, noise13=None):
+        nz = None if noise13 is None or len(noise13) == 0 else _np_f32(noise13, 13)
+        self._check(self.lib.mcl3dl_hip_group_resample_apply(self.h, _ptr(nz), 0 if nz is None else len(nz)))
 
 
 class Engine:

@@ -80,6 +80,7 @@ void mcl3dl_hip_group_destroy(mcl3dl_hip_group* g)
   for (ncclComm_t c : g->comms)
     if (c)
       (void)g->rccl.CommDestroy(c);
+  g->comms.clear();
   for (mcl3dl_hip_ctx* c : g->ctx)
     mcl3dl_hip_destroy(c);
   delete g;
@@ -172,7 +173,11 @@ int mcl3dl_hip_group_set_option(mcl3dl_hip_group* g, const char* name, double va
   }
   if (std::string(name) == "inject_failure_rank")
   {
-    // test hook: the next sharded update fails on that rank after its kernels are enqueued and before the collective
+    // test hook (only with MCL3DL_HIP_TEST_HOOKS=1 in the environment): the next sharded update fails on that rank after its
+    // kernels are enqueued and before the collective
+    const char* hooks = getenv("MCL3DL_HIP_TEST_HOOKS");
+    if (!hooks || std::string(hooks) != "1")
+      return g->fail(-3, "inject_failure_rank is a test hook: set MCL3DL_HIP_TEST_HOOKS=1 in the environment to enable it");
     g->inject_failure_rank = static_cast<int>(value);
     return 0;
   }
@@ -290,34 +295,45 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
   return 0;
 }
 
-int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, const float* extra, float* weight_inout,
-                                    size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
-                                    const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
-                                    float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
-                                    float* match_ratio_min, float* match_ratio_max, int* restored)
+namespace
 {
-  if (!g)
-    return -1;
+// One update over the group's shards. resident = false: mcl3dl_hip_group_measure_update (poses and prior weights come from the
+// host, the weights go back). resident = true: the particles mcl3dl_hip_group_upload_state / _resample_apply left on the
+// devices (pose = first 7 floats of each 13-float state, kept as ctx->pose; weights in ctx->gs_weight, updated in place);
+// weight_inout is then an optional OUTPUT (may be null: nothing but four scalars comes back).
+int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, const float* extra, float* weight_inout,
+                      size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                      const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o, float* out_lik,
+                      float* out_match_ratio, float* out_beam, float* entropy, float* match_ratio_min, float* match_ratio_max,
+                      int* restored)
+{
   if (n_p == 0)
     return g->fail(-3, "no particles");
-  if (!pose || !weight_inout)
+  if (!resident && (!pose || !weight_inout))
     return g->fail(-3, "null pose / weight array");
-  if (g->n() == 1 && g->direct_single)
+  if (resident && g->n_resident != n_p)
+    return g->fail(-5, "%zu particles are resident on the group's devices, not %zu (mcl3dl_hip_group_upload_state first)",
+                   g->n_resident, n_p);
+  if (!resident && g->n() == 1 && g->direct_single)
   {
     const int rc = mcl3dl_hip_measure_update(g->ctx[0], pose, extra, weight_inout, n_p, scan_lik_xyz, n_s, scan_beam_xyz,
                                              scan_beam_origin, n_b, origins, n_o, out_lik, out_match_ratio, out_beam,
                                              entropy, match_ratio_min, match_ratio_max, restored);
     return rc ? g->fail_rank(rc, 0) : 0;
   }
-  TRY(group_comms(g));
+  // a group of one device that may call its context directly needs no collective (and never loads RCCL)
+  const bool no_collective = g->n() == 1 && g->direct_single;
+  if (!no_collective)
+    TRY(group_comms(g));
   std::string err;
   if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
     return g->fail(-3, "%s", err.c_str());
   const int N = g->n();
   const size_t n_pack = 2 + 2 * static_cast<size_t>(N);
-  const bool host_combine = g->collective == 1;
+  const bool host_combine = g->collective == 1 && !no_collective;
   std::vector<float> stats(4 * static_cast<size_t>(N), 0.f);
-  g->n_pose_uploaded = 0;
+  if (!resident)
+    g->n_pose_uploaded = 0;
 
   // phase A: upload the shard, measure, partial sums, (RCCL) all-reduce, and — with RCCL — straight on to phase B
   const auto phase_b = [&](mcl3dl_hip_ctx* ctx, int r, size_t lo, size_t n) -> int
@@ -326,8 +342,10 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
     TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
     if (n)
     {
-      TRY(mcl3dl_hip_pf_apply_device(ctx, ctx->weightb.as<float>(), n, N, ctx->packed.as<double>(), ctx->stats4.as<float>()));
-      TRY(d2h(ctx, weight_inout + lo, ctx->weightb.p, fb));
+      float* d_w = resident ? ctx->gs_weight.as<float>() : ctx->weightb.as<float>();
+      TRY(mcl3dl_hip_pf_apply_device(ctx, d_w, n, N, ctx->packed.as<double>(), ctx->stats4.as<float>()));
+      if (weight_inout)
+        TRY(d2h(ctx, weight_inout + lo, d_w, fb));
       TRY(d2h(ctx, &stats[4 * r], ctx->stats4.p, sizeof(float) * 4));
       if (out_lik)
         TRY(d2h(ctx, out_lik + lo, ctx->lik.p, fb));
@@ -355,23 +373,30 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
         {
           TRY(push_scan(ctx, g->scan, false));
           TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
-          ctx->n_pose_uploaded = 0;
+          if (!resident)
+            ctx->n_pose_uploaded = 0;
           if (n)
           {
-            TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
-            TRY(ensure(ctx, ctx->weightb, fb));
+            if (resident && (ctx->gs_n != n || ctx->n_pose_uploaded != n))
+              return ctx->fail(-5, "this device holds %zu resident particles, its shard has %zu", ctx->gs_n, n);
             TRY(ensure(ctx, ctx->lik, fb));
             TRY(ensure(ctx, ctx->ratio, fb));
             TRY(ensure(ctx, ctx->beam, fb));
             TRY(ensure(ctx, ctx->extra, fb));
-            TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
-            ctx->n_pose_uploaded = n;
-            TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
+            if (!resident)
+            {
+              TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
+              TRY(ensure(ctx, ctx->weightb, fb));
+              TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
+              ctx->n_pose_uploaded = n;
+              TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
+            }
+            float* d_w = resident ? ctx->gs_weight.as<float>() : ctx->weightb.as<float>();
             if (extra)
               TRY(h2d(ctx, ctx->extra.p, extra + lo, fb));
             TRY(launch_measure(ctx, ctx->pose.as<float>(), n, ctx->lik.as<float>(), ctx->ratio.as<float>(),
                                ctx->beam.as<float>(), false, nullptr));
-            TRY(mcl3dl_hip_pf_partial_device(ctx, ctx->weightb.as<float>(), ctx->lik.as<float>(), ctx->beam.as<float>(),
+            TRY(mcl3dl_hip_pf_partial_device(ctx, d_w, ctx->lik.as<float>(), ctx->beam.as<float>(),
                                              extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n, r, N,
                                              ctx->packed.as<double>()));
           }
@@ -395,6 +420,8 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
           ctx->stage_pending = 0;
           return rcs[r] = rc_a;
         }
+        if (no_collective)
+          return rcs[r] = phase_b(ctx, r, lo, n);
         if (host_combine)
         {
           g->host_packed[r].resize(n_pack);
@@ -404,8 +431,16 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
         // the update's single collective: 16 + 16 N bytes over xGMI, on this device's stream
         const ncclResult_t nrc = g->rccl.AllReduce(ctx->packed.p, ctx->packed.p, n_pack, ncclDouble, ncclSum, g->comms[r],
                                                    ctx->stream);
+        // second vote: a collective that one rank could not enqueue never completes on the ranks that did — nobody may
+        // wait for its stream then; the communicators are aborted below
+        const bool enqueued = g->vote.vote(nrc == ncclSuccess);
         if (nrc != ncclSuccess)
           return rcs[r] = ctx->fail(-7, "ncclAllReduce failed: %s", g->rccl.GetErrorString(nrc));
+        if (!enqueued)
+        {
+          ctx->stage_out.clear();
+          return rcs[r] = ctx->fail(RC_ABANDONED, "update abandoned: another rank could not enqueue the all-reduce");
+        }
         return rcs[r] = phase_b(ctx, r, lo, n);
       },
       &bad);
@@ -421,12 +456,7 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
       }
     // communicators that saw a failed or abandoned update are rebuilt on next use
     if (!host_combine && !g->comms.empty())
-    {
-      for (ncclComm_t c : g->comms)
-        if (c)
-          (void)g->rccl.CommDestroy(c);
-      g->comms.clear();
-    }
+      g->drop_comms();
     return g->fail_rank(rc, bad);
   }
   if (host_combine)
@@ -451,7 +481,7 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
       return g->fail_rank(rc, bad);
     ++g->collectives_host;
   }
-  else
+  else if (!no_collective)
     ++g->collectives_rccl;
   g->n_pose_uploaded = n_p;
   // every rank computed the same four scalars from the same all-reduced record: take the first non-empty shard's
@@ -475,4 +505,18 @@ int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, cons
   if (restored)
     *restored = stats[4 * src + 3] != 0.0f;
   return 0;
+}
+}  // namespace
+
+int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, const float* extra, float* weight_inout,
+                                    size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                                    const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                                    float* out_lik, float* out_match_ratio, float* out_beam, float* entropy,
+                                    float* match_ratio_min, float* match_ratio_max, int* restored)
+{
+  if (!g)
+    return -1;
+  return group_update_impl(g, false, pose, extra, weight_inout, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b,
+                           origins, n_o, out_lik, out_match_ratio, out_beam, entropy, match_ratio_min, match_ratio_max,
+                           restored);
 }

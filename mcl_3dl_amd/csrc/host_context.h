@@ -225,6 +225,12 @@ struct mcl3dl_hip_ctx
   size_t n_base = 0;  // points of the base map; anything behind them in map_xyz is the current map update
   DevBuf ms_xyz, ms_out, ms_flag[2];
 
+  // this rank's shard of a device group's resident particles (api_group_state.inl): 13-float states (ping-pong), weights;
+  // the 7-float poses the measurement kernels read are kept in `pose`
+  DevBuf gs_state[2], gs_weight, gs_all, gs_pad, gs_rec;
+  int gs_cur = 0;
+  size_t gs_n = 0;
+
   // resampling plan
   std::vector<float> rs_keys;        // accumulated probabilities, in particles_dup_ order after std::sort
   std::vector<uint32_t> rs_order;    // which particle sits at each position of particles_dup_

@@ -22,7 +22,9 @@ struct RcclApi
   void* lib = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;   // optional: tears a communicator down with a collective still pending
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 
   // "" on success, otherwise why RCCL is not usable
@@ -44,11 +46,13 @@ struct RcclApi
     CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    if (!CommInitAll || !CommDestroy || !AllReduce || !GetErrorString)
+    if (!CommInitAll || !CommDestroy || !AllReduce || !AllGather || !GetErrorString)
     {
       lib = nullptr;
-      return "librccl lacks ncclCommInitAll / ncclAllReduce";
+      return "librccl lacks ncclCommInitAll / ncclAllReduce / ncclAllGather";
     }
     return "";
   }
@@ -196,6 +200,29 @@ struct mcl3dl_hip_group
   std::vector<std::vector<double>> host_packed;
   // poses kept on the devices by group_upload_poses
   size_t n_pose_uploaded = 0;
+  // particles resident on the devices (api_group_state.inl): 13-float states + weights, sharded by shard_bounds
+  size_t n_resident = 0;
+  std::vector<float> h_weight, h_state;  // host gather buffers of the resampling steps
+  std::vector<double> h_parts;           // per-rank records of the reductions
+  size_t rs_n_out = 0;                   // set by group_resample_begin
+  bool rs_begun = false, rs_planned = false;
+  size_t rs_n_dup = 0;
+
+  // a communicator that saw a failed or abandoned collective: aborted where RCCL can (a pending collective would block a
+  // plain destroy), rebuilt by group_comms on next use
+  void drop_comms()
+  {
+    for (ncclComm_t& c : comms)
+      if (c)
+      {
+        if (rccl.CommAbort)
+          (void)rccl.CommAbort(c);
+        else
+          (void)rccl.CommDestroy(c);
+        c = nullptr;
+      }
+    comms.clear();
+  }
 
   int n() const
   {

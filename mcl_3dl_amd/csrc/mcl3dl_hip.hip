@@ -42,4 +42,5 @@ extern "C"
 #include "api_support.inl"
 #include "api_cloud.inl"
 #include "api_group.inl"
+#include "api_group_state.inl"
 }  // extern "C"

@@ -129,7 +129,77 @@ int main(int argc, char** argv)
   }
   uint64_t n_rccl = 0, n_host = 0;
   mcl3dl_hip_group_collective_stats(g, &n_rccl, &n_host);
+  /* ---- a whole filter iteration with the particles RESIDENT on the devices: upload once, then pf::measure (all-reduce),
+   * expectation + covariance (host combine of one record per shard), resample (all-gather of the 13-float states) — and the
+   * second update reads the NEW generation without any pose upload. Checked against the first update above and against the
+   * single-context functions on the same inputs. */
+  float* st13 = (float*)calloc(13 * n_p, sizeof(float));
+  for (size_t i = 0; i < n_p; ++i)
+    memcpy(st13 + 13 * i, pose + 7 * i, sizeof(float) * 7);
+  float ent_r = 0, rmin_r = 0, rmax_r = 0, mean7[7], total = 0, cov[36], pstep = 0;
+  int restored_r = 0;
+  int64_t imax = -1, imax_b = -1;
+  size_t n_dup = 0, bad_r = 0;
+  float* w_r = (float*)malloc(sizeof(float) * n_p);
+  float* lik_r = (float*)malloc(sizeof(float) * n_p);
+  rc = mcl3dl_hip_group_upload_state(g, st13, w0, n_p);
+  rc = rc ? rc : mcl3dl_hip_group_update_resident(g, NULL, scan, n_s, beam, beam_org, n_b, origins, 1, w_r, lik_r, NULL, NULL, &ent_r,
+                                                  &rmin_r, &rmax_r, &restored_r);
+  rc = rc ? rc : mcl3dl_hip_group_expectation(g, NULL, mean7, &total, &imax, &imax_b);
+  rc = rc ? rc : mcl3dl_hip_group_covariance(g, mean7, cov);
+  rc = rc ? rc : mcl3dl_hip_group_resample_begin(g, 0, &pstep);
+  rc = rc ? rc : mcl3dl_hip_group_resample_plan(g, 0, 0.37f * pstep, NULL, NULL, &n_dup);
+  float* noise = (float*)calloc(13 * (n_dup + 1), sizeof(float));
+  for (size_t i = 0; i < n_dup; ++i)
+  {
+    noise[13 * i + 0] = 0.01f * (uniform01() - 0.5f);
+    noise[13 * i + 6] = 1.0f; /* identity rotation */
+  }
+  rc = rc ? rc : mcl3dl_hip_group_resample_apply(g, noise, n_dup);
+  float* st_new = (float*)malloc(sizeof(float) * 13 * n_p);
+  float* w_new = (float*)malloc(sizeof(float) * n_p);
+  rc = rc ? rc : mcl3dl_hip_group_download_state(g, st_new, w_new, n_p);
+  float ent_2 = 0;
+  rc = rc ? rc : mcl3dl_hip_group_update_resident(g, NULL, scan, n_s, beam, beam_org, n_b, origins, 1, NULL, NULL, NULL, NULL, &ent_2,
+                                                  NULL, NULL, NULL);
+  if (rc)
+  {
+    fprintf(stderr, "resident iteration over %d device(s): %s\n", n_dev, mcl3dl_hip_group_last_error(g));
+    return 7;
+  }
+  uint64_t n_rccl2 = 0;
+  mcl3dl_hip_group_collective_stats(g, &n_rccl2, &n_host);
   mcl3dl_hip_group_destroy(g);
+  /* the resident update = the host-array update of the same particles */
+  double worst_r = 0;
+  for (size_t i = 0; i < n_p; ++i)
+  {
+    bad_r += memcmp(&lik_r[i], &lik[1][i], 4) != 0;
+    const double rel = fabs((double)w_r[i] - (double)w[1][i]) / fmax(fabs((double)w[1][i]), 1e-30);
+    worst_r = rel > worst_r ? rel : worst_r;
+  }
+  /* the new generation against one context resampling the same weights */
+  mcl3dl_hip_ctx* c2 = NULL;
+  size_t n_dup1 = 0, bad_st = 0;
+  float pstep1 = 0;
+  float* st_ref = (float*)malloc(sizeof(float) * 13 * n_p);
+  rc = mcl3dl_hip_create(&c2, 0);
+  rc = rc ? rc : mcl3dl_hip_resample_begin(c2, w_r, n_p, n_p, &pstep1);
+  rc = rc ? rc : mcl3dl_hip_resample_plan(c2, 0, 0.37f * pstep1, NULL, NULL, &n_dup1);
+  rc = rc ? rc : mcl3dl_hip_resample_apply(c2, st13, noise, n_dup, st_ref);
+  if (rc)
+    return 8;
+  mcl3dl_hip_destroy(c2);
+  bad_st = (size_t)(memcmp(st_ref, st_new, sizeof(float) * 13 * n_p) != 0);
+  printf("group_all_devices (resident): update %zu mismatching likelihoods, worst weight rel err %.3g, mean (%.4f %.4f %.4f), sum w %.6f, "
+         "max at %lld, cov[0] %.3g, %zu duplicates (%zu on one context), new generation %s, weights %.3g, entropy after %.4f, "
+         "collectives %llu\n",
+         bad_r, worst_r, mean7[0], mean7[1], mean7[2], total, (long long)imax, cov[0], n_dup, n_dup1, bad_st ? "DIFFERS" : "identical",
+         w_new[0], ent_2, (unsigned long long)n_rccl2);
+  if (bad_r || worst_r > 2e-7 || bad_st || n_dup != n_dup1 || pstep != pstep1 || fabs(total - 1.0f) > 1e-5f || imax < 0 ||
+      imax >= (int64_t)n_p || !(cov[0] > 0.f) || fabs(w_new[0] * (float)n_p - 1.0f) > 1e-6f || !(ent_2 > 0.f) ||
+      n_rccl2 != n_rccl + 3 /* two all-reduces + one all-gather */)
+    return 9;
   size_t bad = 0, matched = 0;
   double worst = 0;
   for (size_t i = 0; i < n_p; ++i)

@@ -129,7 +129,7 @@ def test_fewer_particles_than_devices_and_dead_filter(scene, engine):
 
 
 @pytest.mark.parametrize("bad_rank", [0, 1, 2])
-def test_a_rank_that_fails_ahead_of_the_collective_does_not_strand_the_others(scene, single, bad_rank):
+def test_a_rank_that_fails_ahead_of_the_collective_does_not_strand_the_others(scene, single, bad_rank, monkeypatch):
     """The update's collective is entered by every rank or by none (host_group.h:VoteBarrier): a rank that fails after its
     kernels are enqueued makes the call return ITS error — promptly, the other ranks stand down instead of waiting inside an
     all-reduce that cannot complete — weights untouched, and the next update on the same group is correct."""
@@ -137,6 +137,9 @@ def test_a_rank_that_fails_ahead_of_the_collective_does_not_strand_the_others(sc
     w0, extra, want = single
     g = make_group([0, 0, 0], sc, collective="host")
     try:
+        with pytest.raises(capi.EngineError, match="test hook"):
+            g.set_option("inject_failure_rank", bad_rank)   # off unless the environment enables the hooks
+        monkeypatch.setenv("MCL3DL_HIP_TEST_HOOKS", "1")
         g.set_option("inject_failure_rank", bad_rank)
         w_in = w0.copy()
         with pytest.raises(capi.EngineError, match=r"rank %d\): injected failure" % bad_rank):
@@ -151,7 +154,7 @@ def test_a_rank_that_fails_ahead_of_the_collective_does_not_strand_the_others(sc
         g.close()
 
 
-def test_injected_failure_on_the_rccl_path_rebuilds_the_communicator(scene, single):
+def test_injected_failure_on_the_rccl_path_rebuilds_the_communicator(scene, single, monkeypatch):
     """One rank, RCCL all-reduce (the only RCCL shape one GPU allows): the failed update destroys the communicator, the next
     one brings it up again and is correct."""
     sc = scene
@@ -160,6 +163,7 @@ def test_injected_failure_on_the_rccl_path_rebuilds_the_communicator(scene, sing
     try:
         g.set_option("direct_single", 0)
         g.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
+        monkeypatch.setenv("MCL3DL_HIP_TEST_HOOKS", "1")
         g.set_option("inject_failure_rank", 0)
         with pytest.raises(capi.EngineError, match="injected failure"):
             g.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, extra=extra)
