@@ -312,8 +312,9 @@ class Group:
 
     def resample_plan(self, mode, initial_p=0.0):
         nd = C.c_size_t(0)
-        src = np.zeros(self._rs_n_out, np.uint32)
-        dup = np.zeros(self._rs_n_out, np.uint8)
+        n_out = getattr(self, "_rs_n_out", 0) or self.resident()
+        src = np.zeros(n_out, np.uint32)
+        dup = np.zeros(n_out, np.uint8)
         self._check(self.lib.mcl3dl_hip_group_resample_plan(self.h, int(mode), float(initial_p), _ptr(src), _ptr(dup),
                                                             C.byref(nd)))
         return src, dup, int(nd.value)

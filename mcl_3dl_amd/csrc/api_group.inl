@@ -307,6 +307,8 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
                       float* out_match_ratio, float* out_beam, float* entropy, float* match_ratio_min, float* match_ratio_max,
                       int* restored)
 {
+  if (resident && g->n_resident == 0)
+    return g->fail(-5, "no resident particles (mcl3dl_hip_group_upload_state first)");
   if (n_p == 0)
     return g->fail(-3, "no particles");
   if (!resident && (!pose || !weight_inout))

@@ -144,6 +144,18 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->strict_auto_min = static_cast<int>(value);
     return 0;
   }
+  if (key == "strict_skew")
+  {
+    ctx->strict_skew = value != 0.0;
+    return 0;
+  }
+  if (key == "strict_gpw")
+  {
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return ctx->fail(-3, "strict_gpw must be 0 (chosen per launch), 1 or 2");
+    ctx->strict_gpw = static_cast<int>(value);
+    return 0;
+  }
   if (key == "strict_auto_max_bytes")
   {
     if (!(value >= 0.0))
@@ -320,6 +332,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
+  else if (key == "strict_gpw") *value = ctx->strict_gpw;
+  else if (key == "strict_skew") *value = ctx->strict_skew;
   else if (key == "strict_auto_max_bytes") *value = ctx->strict_auto_max_bytes;
   else if (key == "strict_auto_skipped") *value = static_cast<double>(ctx->strict_auto_skipped);
   else if (key == "overlap_min_rays") *value = static_cast<double>(ctx->overlap_min_rays);

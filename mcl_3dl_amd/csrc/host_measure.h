@@ -127,7 +127,7 @@ bool lik_strict(const mcl3dl_hip_ctx* ctx, int ns)
 size_t strict_terms_bytes(size_t n_p, int ns, int group_size)
 {
   const size_t G = static_cast<size_t>(group_size);
-  return sizeof(float) * static_cast<size_t>(ns) * ((n_p + G - 1) / G) * G;
+  return ((n_p + G - 1) / G) * (sizeof(float) * static_cast<size_t>(ns) * G + sizeof(float4) * STRICT_SKEW4);
 }
 
 int plan_group_size(const mcl3dl_hip_ctx* ctx, int np, int ns)
@@ -220,6 +220,34 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
     }
   }
   return 0;
+}
+
+// lik_strict_sum_kernel with as many particle groups per work-group as keep the launch in ONE round of work-groups, up to a
+// full adder wavefront (64 lanes / GG particles per group)
+template <int GG>
+void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, int np, int n_groups, float* d_lik)
+{
+  constexpr int MAX_GPW = 64 / GG >= 4 ? 4 : (64 / GG >= 2 ? 2 : 1);
+  int gpw = n_groups <= ctx->n_cus ? 1 : (n_groups <= 2 * ctx->n_cus ? 2 : 4);
+  gpw = std::min(gpw, MAX_GPW);
+  if (ctx->strict_gpw)
+    gpw = std::min(gpw, ctx->strict_gpw);
+  if constexpr (MAX_GPW >= 4)
+    if (gpw == 4)
+    {
+      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 16384, 4>), dim3((n_groups + 3) / 4), dim3(1024), 0, ctx->stream, strict_terms, ns,
+                         np, n_groups, d_lik, ctx->strict_skew ? STRICT_SKEW4 : 0);
+      return;
+    }
+  if constexpr (MAX_GPW >= 2)
+    if (gpw >= 2)
+    {
+      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 32768, 2>), dim3((n_groups + 1) / 2), dim3(1024), 0, ctx->stream, strict_terms, ns,
+                         np, n_groups, d_lik, ctx->strict_skew ? STRICT_SKEW4 : 0);
+      return;
+    }
+  hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 65536, 1>), dim3(n_groups), dim3(1024), 0, ctx->stream, strict_terms, ns, np, n_groups,
+                     d_lik, ctx->strict_skew ? STRICT_SKEW4 : 0);
 }
 
 // What launch_measure leaves to launch_pf_tail when the caller asks for it (`want`): the sum over the tiled kernel's per-tile
@@ -422,7 +450,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC, DD>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
                      ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
-                     ctx->scan_perm.as<uint32_t>(), strict_terms)
+                     ctx->scan_perm.as<uint32_t>(), strict_terms, ctx->strict_skew ? STRICT_SKEW4 : 0)
           const bool coop = coop_arg != 0;
           const bool defer = coop && lik_defer_active(ctx);
 #define LAUNCH_TILED_G(GG, WW)         \
@@ -467,32 +495,21 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                                d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
           if (strict_terms && d_lik)
           {
-#define LAUNCH_STRICT(GG)                                                                                             \
-  do                                                                                                                  \
-  {                                                                                                                   \
-    if (n_groups > ctx->n_cus)                                                                                        \
-      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 32768>), dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, \
-                         ns, np, d_lik);                                                                              \
-    else                                                                                                              \
-      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 65536>), dim3(n_groups), dim3(256), 0, ctx->stream, strict_terms, \
-                         ns, np, d_lik);                                                                              \
-  } while (0)
             switch (G)
             {
               case 4:
-                LAUNCH_STRICT(4);
+                launch_strict_sum<4>(ctx, strict_terms, ns, np, n_groups, d_lik);
                 break;
               case 8:
-                LAUNCH_STRICT(8);
+                launch_strict_sum<8>(ctx, strict_terms, ns, np, n_groups, d_lik);
                 break;
               case 32:
-                LAUNCH_STRICT(32);
+                launch_strict_sum<32>(ctx, strict_terms, ns, np, n_groups, d_lik);
                 break;
               default:
-                LAUNCH_STRICT(16);
+                launch_strict_sum<16>(ctx, strict_terms, ns, np, n_groups, d_lik);
                 break;
             }
-#undef LAUNCH_STRICT
           }
         }
         else

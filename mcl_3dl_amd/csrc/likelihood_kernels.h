@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
                                                                LikParams prm, double* __restrict__ partial_sum,
                                                                unsigned* __restrict__ partial_cnt,
                                                                const uint32_t* __restrict__ scan_perm,
-                                                               float* __restrict__ strict_terms)
+                                                               float* __restrict__ strict_terms, int strict_skew4 = 0)
 {
   // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
   // [particle group][original scan index][G] so that lik_strict_sum_kernel can add them in the reference's own order.
@@ -1006,7 +1006,8 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   {
     // rows of G floats, [group][original scan index][G]: G / 4 lanes write one row as float4s (one 16..128-byte run)
     constexpr int Q = G / 4;
-    float4* rows = reinterpret_cast<float4*>(strict_terms) + static_cast<size_t>(group) * n_s * Q;
+    // (group regions are strict_skew4 float4s further apart than their n_s rows: see lik_strict_sum_kernel)
+    float4* rows = reinterpret_cast<float4*>(strict_terms) + static_cast<size_t>(group) * (static_cast<size_t>(n_s) * Q + strict_skew4);
 #pragma unroll
     for (int j = 0; j < Q; ++j)
     {
@@ -1112,63 +1113,105 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
 // Measured and NOT kept (round 3, C5: 512 groups x 65 536 terms, 0.68 ms): 32 KB chunks with two chunks in flight in
 // registers and two work-groups per CU (0.91 ms: slower), and two adjacent groups per work-group so that 512 groups run in
 // one round of 256 work-groups (0.68 ms: no change) — the kernel reads its 2.1 GB of terms at ~3.1 TB/s either way.
-// CHUNK = bytes of terms per LDS buffer: 65536 (one work-group per CU: 2 x 64 KB) while the groups fit the chip in one round,
-// 32768 (two work-groups per CU) beyond — the kernel is bound by the adder's dependent chain (~11 cycles per term: 65 536
-// terms = 0.31 ms per group, profiles/r03z_C5_pmc_summary.csv), so 512 groups in ONE round of two per CU beat two rounds:
-// C5 likelihood group 2.48-2.60 -> 2.40-2.42 ms; at 256 groups the smaller chunk costs 2 % (scripts/r03_s27.sh).
-template <int G, int CHUNK>
-__global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p,
-                                                             float* __restrict__ out_lik)
+// What the kernel costs (C5: 512 groups x 65 536 rows of 64 B = 2.1 GB of terms, written by the tiled kernel just before):
+//   * the adder's dependent chain, ~11 cycles per term: 0.34 ms for 65 536 terms whatever the number of chains a wavefront
+//     carries side by side — so GPW particle groups share one adder wavefront (lane = (group, particle), GPW x G <= 64): the
+//     512 groups of C5 are 256 work-groups, ONE round of one chain (round 3: one group per work-group, two rounds or two
+//     work-groups per CU: 0.75 / 0.55 ms);
+//   * streaming the terms: with one 64 KB batch of loads in flight per CU the stream ran at 2.9 TB/s — 5.8 us per batch,
+//     i.e. bound by memory LATENCY, with either grouping (profiles/r04i_C5_strict_gpw.txt: 0.727 / 0.734 ms). Hence 15 loader
+//     wavefronts per work-group with TWO chunks in flight in their registers (the chunk the adder needs next is already in
+//     LDS): ~190 KB in flight per CU.
+//   * where the groups' regions lie: 65 536 rows of 64 B are exactly 4 MiB, so with the regions back to back every work-group
+//     (and, in the tiled kernel, every writer of one scan tile) is at the same offset modulo 4 MiB at the same time — the same
+//     HBM channel. The regions are therefore `skew4` float4s (4352 B: 4 KiB + 256 B) further apart than their rows.
+// CHUNK = bytes of terms per group and LDS buffer (2 x GPW x CHUNK <= 128 KB): 65536 / 32768 / 16384 for GPW 1 / 2 / 4.
+constexpr int STRICT_SKEW4 = 272;
+
+template <int G, int CHUNK, int GPW>
+__global__ __launch_bounds__(1024) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p, int n_groups,
+                                                              float* __restrict__ out_lik, int skew4)
 {
   constexpr int Q = G / 4;               // float4s per row
-  constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk
+  constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk and group
   constexpr int LD = ROWS + 4;           // padded row length of the transposed buffer (keeps 16-byte alignment)
-  constexpr int LOADERS = 192;
-  constexpr int PER = (ROWS * Q + LOADERS - 1) / LOADERS;
-  __shared__ __attribute__((aligned(16))) float buf[2][G * LD];
-  const int group = blockIdx.x, t = threadIdx.x;
-  const float4* rows = reinterpret_cast<const float4*>(terms) + static_cast<size_t>(group) * n_s * Q;
+  constexpr int LOADERS = 960;
+  constexpr int ELEMS = GPW * ROWS * Q;  // float4s per chunk
+  constexpr int PER = (ELEMS + LOADERS - 1) / LOADERS;
+  static_assert(GPW * G <= 64, "one adder wavefront");
+  __shared__ __attribute__((aligned(16))) float buf[2][GPW * G * LD];
+  const int group0 = blockIdx.x * GPW, t = threadIdx.x;
+  const float4* base = reinterpret_cast<const float4*>(terms);
   const int n_chunks = (n_s + ROWS - 1) / ROWS;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const auto stage = [&](int c)
+  // loaders: chunk c of the GPW groups into registers ...
+  const auto fetch = [&](int c, float4 (&reg)[PER])
   {
-    // loaders only: chunk c -> buf[c & 1], transposed; rows past n_s are zero-filled up to the next multiple of 4
     const int lt = t - 64;
     const int first = c * ROWS, n_rows = min(ROWS, n_s - first);
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+    {
+      const int e = lt + LOADERS * j;
+      const int gl = e / (ROWS * Q), rem = e - gl * (ROWS * Q), r = rem / Q;
+      const bool live = c < n_chunks && e < ELEMS && r < n_rows && group0 + gl < n_groups;
+      reg[j] = live ? base[static_cast<size_t>(group0 + gl) * (static_cast<size_t>(n_s) * Q + skew4) + static_cast<size_t>(first) * Q + rem] : z4;
+    }
+  };
+  // ... and from there into buf[c & 1], transposed ([group][particle][row]); rows past n_s (and groups past the last one) are
+  // zero-filled up to the next multiple of 4 rows
+  const auto park = [&](int c, const float4 (&reg)[PER])
+  {
+    const int lt = t - 64;
+    const int n_rows = min(ROWS, n_s - c * ROWS);
     const int padded = (n_rows + 3) & ~3;
     float* dst = buf[c & 1];
-    float4 reg[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j)
     {
-      const int e = lt + LOADERS * j, r = e / Q;
-      reg[j] = r < n_rows ? rows[static_cast<size_t>(first) * Q + e] : z4;
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-    {
-      const int e = lt + LOADERS * j, r = e / Q, k4 = (e % Q) * 4;
-      if (r < padded)
+      const int e = lt + LOADERS * j;
+      const int gl = e / (ROWS * Q), rem = e - gl * (ROWS * Q), r = rem / Q, k4 = (rem % Q) * 4;
+      if (e < ELEMS && r < padded)
       {
-        dst[(k4 + 0) * LD + r] = reg[j].x;
-        dst[(k4 + 1) * LD + r] = reg[j].y;
-        dst[(k4 + 2) * LD + r] = reg[j].z;
-        dst[(k4 + 3) * LD + r] = reg[j].w;
+        float* d = dst + (gl * G + k4) * LD + r;
+        d[0 * LD] = reg[j].x;
+        d[1 * LD] = reg[j].y;
+        d[2 * LD] = reg[j].z;
+        d[3 * LD] = reg[j].w;
       }
     }
   };
-  if (t >= 64 && n_chunks > 0)
-    stage(0);
+  float4 ra[PER], rb[PER];  // chunks in flight: even ones in ra, odd ones in rb
+  const bool loader = t >= 64;
+  if (loader && n_chunks > 0)
+  {
+    fetch(0, ra);
+    park(0, ra);
+    fetch(1, rb);
+    fetch(2, ra);
+  }
   __syncthreads();
   float score = 0.0f;
   for (int c = 0; c < n_chunks; ++c)
   {
-    if (t >= 64)
+    if (loader)
     {
+      // chunk c + 1 has been in flight since iteration c - 1 (its buffer was last read in iteration c - 1: behind the barrier)
       if (c + 1 < n_chunks)
-        stage(c + 1);
+      {
+        if ((c + 1) & 1)
+        {
+          park(c + 1, rb);
+          fetch(c + 3, rb);
+        }
+        else
+        {
+          park(c + 1, ra);
+          fetch(c + 3, ra);
+        }
+      }
     }
-    else if (t < G)
+    else if (t < GPW * G)
     {
       const float4* cur = reinterpret_cast<const float4*>(buf[c & 1] + t * LD);
       const int n4 = (min(ROWS, n_s - c * ROWS) + 3) >> 2;  // zero padding: x + 0.0f == x
@@ -1189,8 +1232,8 @@ __global__ __launch_bounds__(256) void lik_strict_sum_kernel(const float* __rest
     }
     __syncthreads();
   }
-  const int p = group * G + t;
-  if (t < G && p < n_p)
+  const int p = (group0 + t / G) * G + (t % G);
+  if (t < GPW * G && group0 + t / G < n_groups && p < n_p)
     out_lik[p] = score;
 }
 
