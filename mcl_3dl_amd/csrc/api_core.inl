@@ -100,6 +100,8 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
     (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->graph)
     (void)hipGraphDestroy(ctx->graph);
+  for (const mcl3dl_hip_ctx::ScratchBlk& b : ctx->scratch)
+    (void)hipFree(b.p);
   for (const mcl3dl_hip_ctx::StageChunk& ch : ctx->stage)
     (void)hipHostFree(ch.p);
   for (const mcl3dl_hip_ctx::PinnedBlock& b : ctx->pinned)

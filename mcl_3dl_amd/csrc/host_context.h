@@ -288,6 +288,15 @@ struct mcl3dl_hip_ctx
   // host-side scan staging (kept in the context so that it outlives the asynchronous copies)
   OrderedScan h_scan;
 
+  // scratch memory of the map compilers (host_map_compilers.h:TempBuf): recycled instead of hipMalloc / hipFree per use
+  struct ScratchBlk
+  {
+    void* p;
+    size_t cap;
+    bool used;
+  };
+  std::vector<ScratchBlk> scratch;
+
   // timing
   bool timing = false;
   unsigned timing_mask = 0xffffffffu;  // bit k = time kernel group k (MCL3DL_KERNEL_*); each timed group costs two event records
@@ -311,6 +320,43 @@ struct mcl3dl_hip_ctx
 
 namespace
 {
+void scratch_release(mcl3dl_hip_ctx* ctx, void* p)
+{
+  for (mcl3dl_hip_ctx::ScratchBlk& b : ctx->scratch)
+    if (b.p == p)
+    {
+      b.used = false;
+      return;
+    }
+  (void)hipFree(p);
+}
+
+// frees idle scratch blocks until at most keep_bytes of them stay parked (largest first)
+void scratch_trim(mcl3dl_hip_ctx* ctx, size_t keep_bytes)
+{
+  size_t idle = 0;
+  for (const mcl3dl_hip_ctx::ScratchBlk& b : ctx->scratch)
+    idle += b.used ? 0 : b.cap;
+  bool synced = false;
+  while (idle > keep_bytes)
+  {
+    int big = -1;
+    for (size_t k = 0; k < ctx->scratch.size(); ++k)
+      if (!ctx->scratch[k].used && (big < 0 || ctx->scratch[k].cap > ctx->scratch[static_cast<size_t>(big)].cap))
+        big = static_cast<int>(k);
+    if (big < 0)
+      break;
+    if (!synced)
+    {
+      (void)hipStreamSynchronize(ctx->stream);  // enqueued kernels may still read an idle block
+      synced = true;
+    }
+    (void)hipFree(ctx->scratch[static_cast<size_t>(big)].p);
+    idle -= ctx->scratch[static_cast<size_t>(big)].cap;
+    ctx->scratch.erase(ctx->scratch.begin() + big);
+  }
+}
+
 #define HIP_TRY(expr)                                                                            \
   do                                                                                             \
   {                                                                                              \

@@ -57,7 +57,7 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
   TRY(ensure_map_dev(ctx));
   HIP_TRY(hipEventRecord(tm.ev0, ctx->stream));
   TempBuf sp;
-  HIP_TRY(hipMalloc(&sp.p, sizeof(float4) * n));
+  TRY(scratch_alloc(ctx, sp, sizeof(float4) * n));
   hipLaunchKernelGGL(grid_rescale_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn,
                      ctx->weight[0], ctx->weight[1], ctx->weight[2], ctx->has_weight ? 1 : 0, static_cast<float4*>(sp.p));
   float mm[6];

@@ -255,15 +255,60 @@ int device_exclusive_scan_ws(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n, u
   return 0;
 }
 
+// Scratch memory of the map compilers. Blocks come from — and go back to — a pool in the context (scratch_alloc /
+// scratch_release) instead of hipMalloc / hipFree: a map update used two dozen of each (every hipFree a device
+// synchronisation), a millisecond and more of a 4 ms mapcloud_update (src/mcl_3dl.cpp:141-153). All work is enqueued on the
+// context's ONE stream, so a block handed out again is written only behind the kernels that still read it. After a whole-map
+// build the pool is trimmed (scratch_trim): the big temporaries of a 10 M-point compile do not stay resident.
 struct TempBuf
 {
   void* p = nullptr;
+  mcl3dl_hip_ctx* owner = nullptr;
   ~TempBuf()
   {
-    if (p)
+    if (!p)
+      return;
+    if (owner)
+      scratch_release(owner, p);
+    else
       (void)hipFree(p);
   }
 };
+
+int scratch_alloc(mcl3dl_hip_ctx* ctx, TempBuf& b, size_t bytes)
+{
+  if (bytes == 0)
+    bytes = 16;
+  // best fit among the free blocks that are not wastefully large
+  int best = -1;
+  for (size_t k = 0; k < ctx->scratch.size(); ++k)
+  {
+    const mcl3dl_hip_ctx::ScratchBlk& blk = ctx->scratch[k];
+    if (!blk.used && blk.cap >= bytes && blk.cap <= 4 * bytes + (1u << 16) &&
+        (best < 0 || blk.cap < ctx->scratch[static_cast<size_t>(best)].cap))
+      best = static_cast<int>(k);
+  }
+  if (best >= 0)
+  {
+    ctx->scratch[static_cast<size_t>(best)].used = true;
+    b.p = ctx->scratch[static_cast<size_t>(best)].p;
+    b.owner = ctx;
+    return 0;
+  }
+  void* p = nullptr;
+  const size_t cap = bytes + bytes / 8;
+  if (hipMalloc(&p, cap) != hipSuccess)
+  {
+    // out of memory with idle blocks parked: give them back and try once more
+    (void)hipGetLastError();
+    scratch_trim(ctx, 0);
+    HIP_TRY(hipMalloc(&p, cap));
+  }
+  ctx->scratch.push_back({ p, cap, true });
+  b.p = p;
+  b.owner = ctx;
+  return 0;
+}
 
 // Geometry of the candidate-voxel grid for a point set with the given bounds (rescaled coordinates).
 int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const float mn[3], const float mx[3], CompileParams* out,
@@ -373,10 +418,10 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
   TempBuf d_d2, d_total;
   TempBuf &d_count = out->d_count, &d_pstart = out->d_pstart, &d_prelim = out->d_prelim;
-  HIP_TRY(hipMalloc(&d_d2.p, sizeof(uint32_t) * n_vox));
-  HIP_TRY(hipMalloc(&d_count.p, sizeof(uint32_t) * (n_vox + 1)));
-  HIP_TRY(hipMalloc(&d_pstart.p, sizeof(uint32_t) * (n_vox + 1)));
-  HIP_TRY(hipMalloc(&d_total.p, sizeof(unsigned long long)));
+  TRY(scratch_alloc(ctx, d_d2, sizeof(uint32_t) * n_vox));
+  TRY(scratch_alloc(ctx, d_count, sizeof(uint32_t) * (n_vox + 1)));
+  TRY(scratch_alloc(ctx, d_pstart, sizeof(uint32_t) * (n_vox + 1)));
+  TRY(scratch_alloc(ctx, d_total, sizeof(unsigned long long)));
   hipLaunchKernelGGL(mc_fill_u32, dim3(blocks_v), dim3(256), 0, ctx->stream, static_cast<uint32_t*>(d_d2.p), 0x7f800000u,
                      n_vox);
   if (n)
@@ -398,7 +443,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
     return ctx->fail(-4, "candidate index: %llu preliminary candidates exceed 32-bit offsets", total);
   HIP_TRY(hipMemcpyAsync(d_pstart.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice, ctx->stream));
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_pstart.p), n_vox + 1));
-  HIP_TRY(hipMalloc(&d_prelim.p, sizeof(uint32_t) * (total ? total : 1)));
+  TRY(scratch_alloc(ctx, d_prelim, sizeof(uint32_t) * (total ? total : 1)));
   HIP_TRY(hipMemsetAsync(d_count.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
   if (n)
     hipLaunchKernelGGL((mc_prelim<true>), dim3(blocks_t), dim3(256), 0, ctx->stream, cp, pts, table,
@@ -420,10 +465,10 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
     return 0;
   // fat records: overflow slots per voxel -> exclusive scan -> write
   TempBuf d_ovf;
-  HIP_TRY(hipMalloc(&d_ovf.p, sizeof(uint32_t) * (n_vox + 1)));
+  TRY(scratch_alloc(ctx, d_ovf, sizeof(uint32_t) * (n_vox + 1)));
   HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
   TempBuf d_hist;
-  HIP_TRY(hipMalloc(&d_hist.p, 4 * sizeof(unsigned long long)));
+  TRY(scratch_alloc(ctx, d_hist, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d_hist.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_count_overflow, dim3(std::min(blocks_v, 4096u)), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox,
@@ -437,7 +482,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   if (want_packed == 1 && !can_pack)
     return 1;
   out->packed = (want_packed != 0 && can_pack && ctx->cand_packed) ? 1 : 0;
-  HIP_TRY(hipMalloc(&out->d_ovf_data.p, 64ull * (n_ovf ? n_ovf : 1)));
+  TRY(scratch_alloc(ctx, out->d_ovf_data, 64ull * (n_ovf ? n_ovf : 1)));
   {
     // unused candidate slots of an overflow record hold the sentinel, like those of a voxel record
     const long long words = 16ll * (n_ovf ? n_ovf : 1);
@@ -485,8 +530,8 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   cp.n_points = static_cast<int>(n);
 
   TempBuf d_flag, d_scan, d_bxyz;
-  HIP_TRY(hipMalloc(&d_flag.p, sizeof(int) * n_table));
-  HIP_TRY(hipMalloc(&d_scan.p, sizeof(uint32_t) * (n_table + 1)));
+  TRY(scratch_alloc(ctx, d_flag, sizeof(int) * n_table));
+  TRY(scratch_alloc(ctx, d_scan, sizeof(uint32_t) * (n_table + 1)));
   HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(int) * n_table, ctx->stream));
   const float4* pts = ctx->cand_all_pts.as<float4>();
   hipLaunchKernelGGL(mc_mark_bricks, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, cp, pts,
@@ -505,7 +550,7 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   hipLaunchKernelGGL(mc_brick_ids, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const int*>(d_flag.p), static_cast<const uint32_t*>(d_scan.p), table, n_table);
   HIP_TRY(hipMemsetAsync(table + n_table, 0xff, sizeof(int), ctx->stream));
-  HIP_TRY(hipMalloc(&d_bxyz.p, sizeof(int) * 3 * n_bricks));
+  TRY(scratch_alloc(ctx, d_bxyz, sizeof(int) * 3 * n_bricks));
   hipLaunchKernelGGL(mc_brick_coords, dim3(static_cast<unsigned>((n_table + 255) / 256)), dim3(256), 0, ctx->stream,
                      table, cp.nbx, cp.nby, n_table, static_cast<int*>(d_bxyz.p));
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
@@ -724,11 +769,11 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   HIP_TRY(hipEventRecord(ev0, ctx->stream));
   // 1. dirty bricks: within reach of a removed or an added point
   TempBuf d_dirty, d_old, d_newflag, d_dirtyrank, d_sub_table, d_sub_main, d_sub_bxyz, d_relflag, d_rel, d_subrec;
-  HIP_TRY(hipMalloc(&d_dirty.p, sizeof(int) * n_table));
+  TRY(scratch_alloc(ctx, d_dirty, sizeof(int) * n_table));
   HIP_TRY(hipMemsetAsync(d_dirty.p, 0, sizeof(int) * n_table, ctx->stream));
   if (!old_update.empty())
   {
-    HIP_TRY(hipMalloc(&d_old.p, sizeof(float4) * old_update.size()));
+    TRY(scratch_alloc(ctx, d_old, sizeof(float4) * old_update.size()));
     TRY(h2d(ctx, d_old.p, old_update.data(), sizeof(float4) * old_update.size()));
     CompileParams c2 = cp;
     c2.n_points = static_cast<int>(old_update.size());
@@ -747,8 +792,8 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   }
   // 2. ids: new bricks are appended; dense sub ids for the dirty ones
   const unsigned blocks_tab = static_cast<unsigned>((n_table + 1 + 255) / 256);
-  HIP_TRY(hipMalloc(&d_newflag.p, sizeof(uint32_t) * (n_table + 1)));
-  HIP_TRY(hipMalloc(&d_dirtyrank.p, sizeof(uint32_t) * (n_table + 1)));
+  TRY(scratch_alloc(ctx, d_newflag, sizeof(uint32_t) * (n_table + 1)));
+  TRY(scratch_alloc(ctx, d_dirtyrank, sizeof(uint32_t) * (n_table + 1)));
   hipLaunchKernelGGL(mc_new_brick_flags, dim3(blocks_tab), dim3(256), 0, ctx->stream, static_cast<const int*>(d_dirty.p),
                      ctx->cand_table.as<int>(), static_cast<uint32_t*>(d_newflag.p), n_table);
   HIP_TRY(hipMemsetAsync(d_dirtyrank.p, 0, sizeof(uint32_t) * (n_table + 1), ctx->stream));
@@ -779,16 +824,16 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   const uint32_t cap = ctx->cand_parts;
   const unsigned long long rec_bytes = 16ull * cap;
   TRY(ensure_keep(ctx, ctx->cand_rec, rec_bytes * 512 * n_bricks_old, rec_bytes * 512 * n_bricks));
-  HIP_TRY(hipMalloc(&d_sub_table.p, sizeof(int) * n_table));
-  HIP_TRY(hipMalloc(&d_sub_main.p, sizeof(int) * n_dirty));
-  HIP_TRY(hipMalloc(&d_sub_bxyz.p, sizeof(int) * 3 * n_dirty));
+  TRY(scratch_alloc(ctx, d_sub_table, sizeof(int) * n_table));
+  TRY(scratch_alloc(ctx, d_sub_main, sizeof(int) * n_dirty));
+  TRY(scratch_alloc(ctx, d_sub_bxyz, sizeof(int) * 3 * n_dirty));
   hipLaunchKernelGGL(mc_dirty_tables, dim3(blocks_tab), dim3(256), 0, ctx->stream, static_cast<const int*>(d_dirty.p),
                      static_cast<const uint32_t*>(d_newflag.p), static_cast<const uint32_t*>(d_dirtyrank.p), n_bricks_old,
                      cp.nbx, cp.nby, n_table, ctx->cand_table.as<int>(), static_cast<int*>(d_sub_table.p),
                      static_cast<int*>(d_sub_main.p), static_cast<int*>(d_sub_bxyz.p));
   // 3. the points that can reach a dirty brick, in map order
   cp.n_points = static_cast<int>(n_total);
-  HIP_TRY(hipMalloc(&d_relflag.p, sizeof(uint32_t) * (n_total + 1)));
+  TRY(scratch_alloc(ctx, d_relflag, sizeof(uint32_t) * (n_total + 1)));
   hipLaunchKernelGGL(mc_relevant_points, dim3(static_cast<unsigned>((n_total + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                      cp, ctx->cand_all_pts.as<float4>(), static_cast<const int*>(d_dirty.p),
                      static_cast<uint32_t*>(d_relflag.p));
@@ -796,13 +841,13 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   uint32_t n_rel = 0;
   TRY(d2h(ctx, &n_rel, static_cast<uint32_t*>(d_relflag.p) + n_total, sizeof(uint32_t)));
   TRY(sync_stream(ctx));
-  HIP_TRY(hipMalloc(&d_rel.p, sizeof(float4) * (n_rel ? n_rel : 1)));
+  TRY(scratch_alloc(ctx, d_rel, sizeof(float4) * (n_rel ? n_rel : 1)));
   hipLaunchKernelGGL(mc_compact_points, dim3(static_cast<unsigned>((n_total + 255) / 256)), dim3(256), 0, ctx->stream,
                      ctx->cand_all_pts.as<float4>(), static_cast<const uint32_t*>(d_relflag.p), static_cast<int>(n_total),
                      static_cast<float4*>(d_rel.p));
   // 4. compile the dirty bricks and install them
   const long long n_sub_vox = static_cast<long long>(n_dirty) * 512;
-  HIP_TRY(hipMalloc(&d_subrec.p, rec_bytes * static_cast<size_t>(n_sub_vox)));
+  TRY(scratch_alloc(ctx, d_subrec, rec_bytes * static_cast<size_t>(n_sub_vox)));
   cp.n_points = static_cast<int>(n_rel);
   CompileOutput co;
   {
@@ -829,7 +874,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
                            hipMemcpyDeviceToDevice, ctx->stream));
   }
   TempBuf d_orphan;
-  HIP_TRY(hipMalloc(&d_orphan.p, sizeof(unsigned long long)));
+  TRY(scratch_alloc(ctx, d_orphan, sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(d_orphan.p, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_install_records, dim3(static_cast<unsigned>((n_sub_vox + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_bricks_old,

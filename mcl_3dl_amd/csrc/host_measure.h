@@ -8,12 +8,24 @@ int ensure_structures(mcl3dl_hip_ctx* ctx, bool need_lik, bool need_dda, bool ne
 {
   if (!ctx->has_map)
     return ctx->fail(-5, "no map: call mcl3dl_hip_set_map first");
+  bool built = false;
   if (need_lik && (ctx->lik_index == 0 || need_cells) && ctx->lik_dirty)
+  {
     TRY(build_lik_grid(ctx));
+    built = true;
+  }
   if (need_lik && ctx->lik_index >= 1 && !need_cells && ctx->cand_dirty)
+  {
     TRY(build_cand_grid(ctx));
+    built = true;
+  }
   if (need_dda && ctx->dda_dirty)
+  {
     TRY(build_dda_grid(ctx));
+    built = true;
+  }
+  if (built)
+    scratch_trim(ctx, 64u << 20);  // the temporaries of a whole-map build do not stay parked (map updates keep their small ones)
   return 0;
 }
 
