@@ -2,10 +2,15 @@
 //
 // The reference's pf::ParticleFilter is used untouched (it is pulled in with #include_next under a different class
 // name); this shim only derives from it to hide measure() with a version that publishes the particle batch
-// (first state, stride, count) before running the reference's own loop (include/mcl_3dl/pf.h:252-279).  The GPU-backed
-// LiDAR models read that descriptor inside their per-particle measure() (SURVEY.md §8b "batch-prepass protocol"), so
-// src/mcl_3dl.cpp compiles and behaves unchanged: weights are still multiplied, summed and normalised by the reference's
-// code, in the reference's float order; only the per-particle likelihoods now come from one GPU launch per model.
+// (first state, stride, count) around the reference's loop (include/mcl_3dl/pf.h:252-279).  The GPU-backed LiDAR models read
+// that descriptor inside their per-particle measure() (SURVEY.md §8b "batch-prepass protocol"), so src/mcl_3dl.cpp compiles
+// and behaves unchanged: weights are multiplied, summed and normalised in the reference's statements and float order; only
+// the per-particle likelihoods now come from one GPU launch.
+//
+// measure() restates pf.h:252-279 line by line with ONE difference that cannot be observed: the backup the restore rule
+// needs (`auto particles_prev = particles_`, :254 — 112 bytes per particle copied on every update) is reduced to the
+// probabilities. The callback takes the state by const reference (:252), and nothing else of a particle is written by the
+// loop, so restoring the probabilities restores the vector (:274-278).
 #ifndef MCL_3DL_HIP_PF_SHIM_H
 #define MCL_3DL_HIP_PF_SHIM_H
 
@@ -13,8 +18,10 @@
 #include_next <mcl_3dl/pf.h>
 #undef ParticleFilter
 
+#include <cmath>
 #include <functional>
 #include <random>
+#include <vector>
 
 #include <mcl_3dl_hip/engine.hpp>
 
@@ -40,8 +47,38 @@ public:
     }
     const mcl_3dl::hip::BatchScope scope(&this->particles_[0].state_, sizeof(this->particles_[0]),
                                          this->particles_.size());
-    Base::measure(likelihood);
+    auto& particles = this->particles_;
+    prev_probability_.resize(particles.size());
+    for (std::size_t i = 0; i < particles.size(); ++i)
+      prev_probability_[i] = particles[i].probability_;  // pf.h:254 (what the loop below can change of it)
+    FLT_TYPE sum = 0;
+    for (auto& p : particles)
+    {
+      p.probability_ *= likelihood(p.state_);  // pf.h:258
+      sum += p.probability_;
+    }
+    if (sum > 0.0)
+    {
+      this->entropy_ = 0;
+      for (auto& p : particles)
+      {
+        p.probability_ /= sum;
+        if (p.probability_ > 0)
+        {
+          this->entropy_ += p.probability_ * std::log(p.probability_);
+        }
+      }
+      this->entropy_ *= -1;
+    }
+    else
+    {
+      for (std::size_t i = 0; i < particles.size(); ++i)
+        particles[i].probability_ = prev_probability_[i];  // pf.h:276
+    }
   }
+
+private:
+  std::vector<FLT_TYPE> prev_probability_;
 };
 }  // namespace pf
 }  // namespace mcl_3dl

@@ -726,6 +726,14 @@ int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
   return 0;
 }
 
+namespace
+{
+int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,
+                          const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
+                          size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
+                          float* out_beam, float* st4, bool with_pf = true);
+}  // namespace
+
 int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
                              const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
                              const float* origins, size_t n_o, float* out_lik, float* out_match_ratio, float* out_beam)
@@ -738,6 +746,14 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p,
     return ctx->fail(-3, "null pose array (and mcl3dl_hip_upload_poses holds %zu poses, not %zu)", ctx->n_pose_uploaded,
                      n_p);
   HIP_TRY(hipSetDevice(ctx->device));
+  {
+    // scans (and poses) taken over by one launch, results written into page-locked memory (stage_kernels.h)
+    const int staged = measure_update_staged(ctx, pose, nullptr, nullptr, n_p, scan_lik_xyz, n_s, scan_beam_xyz,
+                                             scan_beam_origin, n_b, origins, n_o, out_lik, out_match_ratio, out_beam, nullptr,
+                                             false);
+    if (staged != 0)
+      return staged < 0 ? staged : 0;
+  }
   TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
   TRY(ensure(ctx, ctx->lik, sizeof(float) * n_p));
   TRY(ensure(ctx, ctx->ratio, sizeof(float) * n_p));
@@ -814,10 +830,12 @@ namespace
 // and the results written straight into page-locked memory by the kernel that normalises the weights. Returns 1 when the update was run
 // this way (results delivered, stream synchronised), 0 when it is not eligible (the caller runs the general path), < 0 on
 // error.
+// with_pf = false: mcl3dl_hip_measure_batch — the two models only (no weights, no pf::measure); pose may then be null (the
+// poses mcl3dl_hip_upload_poses left on the device).
 int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,
                           const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
                           size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
-                          float* out_beam, float* st4)
+                          float* out_beam, float* st4, bool with_pf)
 {
   if (!ctx->update_stage || n_s > 0x0fffffffu || n_b > 0x0fffffffu || n_o > 4096 || n_p > 0x7fffffffu / 8)
     return 0;
@@ -837,8 +855,8 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
     size_t bytes;
     const void* dev;  // where the kernel reads it
   };
-  Part part[7] = { { pose, 7 * fb, nullptr },
-                   { weight_inout, fb, nullptr },
+  Part part[7] = { { pose, pose ? 7 * fb : 0, nullptr },
+                   { weight_inout, weight_inout ? fb : 0, nullptr },
                    { extra, extra ? fb : 0, nullptr },
                    { scan_lik_xyz, sizeof(float) * 3 * n_s, nullptr },
                    { scan_beam_xyz, sizeof(float) * 3 * n_b, nullptr },
@@ -958,7 +976,42 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   ctx->has_scan = true;
   ctx->sp_n_samp[0] = n_s;
   ctx->sp_n_samp[1] = n_b;
-  ctx->n_pose_uploaded = n_p;
+  if (pose)
+    ctx->n_pose_uploaded = n_p;
+  if (!with_pf)
+  {
+    // the two models only: their per-particle results go home through a copy kernel into page-locked memory (or one D2H copy)
+    const bool lik_wanted = out_lik || out_match_ratio;
+    TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? d_lik : nullptr, lik_wanted ? d_ratio : nullptr,
+                       out_beam ? d_beam : nullptr, false, nullptr));
+    float* const user[3] = { out_lik, out_match_ratio, out_beam };
+    const float* const dev[3] = { d_lik, d_ratio, d_beam };
+    char* blk3 = zero_copy ? static_cast<char*>(stage_alloc(ctx, 3 * rpart)) : nullptr;
+    if (blk3)
+    {
+      PfEmit e{};
+      float** slot[3] = { &e.lik, &e.ratio, &e.beam };
+      for (int k = 0; k < 3; ++k)
+        if (user[k])
+        {
+          *slot[k] = ctx->is_pinned(user[k], fb) ? user[k] : reinterpret_cast<float*>(blk3 + k * rpart);
+          if (*slot[k] != user[k])
+            ctx->stage_out.push_back({ user[k], *slot[k], fb });
+        }
+      hipLaunchKernelGGL(emit3_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, e, d_lik, d_ratio, d_beam,
+                         static_cast<int>(n_p));
+      HIP_TRY(hipGetLastError());
+      TRY(sync_stream(ctx, true));
+    }
+    else
+    {
+      for (int k = 0; k < 3; ++k)
+        if (user[k])
+          TRY(d2h(ctx, user[k], dev[k], fb));
+      TRY(sync_stream(ctx));
+    }
+    return 1;
+  }
   // ---- results: written by the update's last kernel into page-locked memory (the caller's own arrays where they are
   // page-locked), or copied home in one block
   HostOut ho{};

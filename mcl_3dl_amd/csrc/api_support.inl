@@ -330,6 +330,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_record_parts") *value = ctx->cand_record_parts;
   else if (key == "cand_record_parts_in_use") *value = ctx->cand_parts;
   else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
+  else if (key == "cand_ovf_compactions") *value = static_cast<double>(ctx->cand_ovf_compactions);
+  else if (key == "cand_ovf_leaked") *value = ctx->cand_ovf_leaked;
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
   else if (key == "strict_gpw") *value = ctx->strict_gpw;

@@ -172,6 +172,7 @@ struct mcl3dl_hip_ctx
   CompileParams cand_cp{};
   long long cand_n_table = 0;
   uint32_t cand_n_bricks = 0, cand_n_ovf = 0, cand_ovf_leaked = 0;
+  uint64_t cand_ovf_compactions = 0;  // times the orphaned overflow records were reclaimed in place (compact_overflow)
   size_t cand_n_points = 0;
   CandGrid cg{};
   RecGrid rg{};

@@ -618,6 +618,53 @@ __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int
     rec[dst + k] = sub_rec[src + k];
 }
 
+// ---- reclaiming orphaned overflow records (host_map_compilers.h:compact_overflow) ------------------------------------------
+// A map update appends the overflow records of the bricks it re-compiles and orphans the ones those bricks referenced before;
+// mapcloud_update replaces the previous update every time (src/mcl_3dl.cpp:141-153), so the orphans pile up at the rate of
+// the live update's records. Counting pass: overflow records each voxel references, from its own record's w word.
+__global__ void mc_ovf_counts(const float4* __restrict__ rec, long long n_vox, uint32_t cap, int packed,
+                              uint32_t* __restrict__ n_ovf /*[n_vox + 1]*/)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v > n_vox)
+    return;
+  uint32_t n = 0;
+  if (v < n_vox)
+  {
+    const uint32_t w0 = __float_as_uint(rec[static_cast<size_t>(v) * cap].w);
+    const uint32_t count = packed ? w0 >> REC_EXT_BITS : w0;
+    n = count > cap ? (count - cap + 3u) / 4u : 0u;
+  }
+  n_ovf[v] = n;
+}
+
+// moves every voxel's overflow records to new_start[v] .. of a fresh array and rewrites the reference in its record
+__global__ void mc_ovf_move(float4* __restrict__ rec, long long n_vox, uint32_t cap, int packed,
+                            const uint32_t* __restrict__ new_start, const float4* __restrict__ old_ovf,
+                            float4* __restrict__ new_ovf)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vox)
+    return;
+  float4* r = rec + static_cast<size_t>(v) * cap;
+  const uint32_t w0 = __float_as_uint(r[0].w);
+  const uint32_t count = packed ? w0 >> REC_EXT_BITS : w0;
+  if (count <= cap)
+    return;
+  const uint32_t old_ext = packed ? (w0 & REC_EXT_MASK) : __float_as_uint(r[1].w);
+  const uint32_t n = (count - cap + 3u) / 4u, dst = new_start[v];
+  for (uint32_t j = 0; j < 4u * n; ++j)
+    new_ovf[4 * static_cast<size_t>(dst) + j] = old_ovf[4 * static_cast<size_t>(old_ext) + j];
+  if (packed)
+  {
+    const float w = __uint_as_float((count << REC_EXT_BITS) | dst);
+    for (uint32_t k = 0; k < 4u; ++k)
+      r[k].w = w;
+  }
+  else
+    r[1].w = __uint_as_float(dst);
+}
+
 // ---- exclusive scan of uint32 (3 levels of 1024-element tiles cover 2^30 elements) --------------------------------
 constexpr int SCAN_TILE = 1024;  // 256 threads x 4 elements
 

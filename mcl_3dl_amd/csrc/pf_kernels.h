@@ -329,6 +329,21 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
 //                       work-group) instead of a launch boundary. Same bits as the split form.
 // Replaces pf_partial + pf_reduce + pf_apply (three launches, ~4 us each on an idle queue) where one GPU holds every particle.
 // ---------------------------------------------------------------------------------------------------------
+// per-particle results of the two models -> page-locked host memory (mcl3dl_hip_measure_batch without a D2H copy)
+__global__ __launch_bounds__(PF_BLOCK) void emit3_kernel(PfEmit emit, const float* __restrict__ lik, const float* __restrict__ ratio,
+                                                         const float* __restrict__ beam, int n)
+{
+  for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
+  {
+    if (emit.lik)
+      emit.lik[i] = lik[i];
+    if (emit.ratio)
+      emit.ratio[i] = ratio[i];
+    if (emit.beam)
+      emit.beam[i] = beam[i];
+  }
+}
+
 constexpr int PF_NORM_MAX_BLOCKS = 32;
 constexpr int PF_NORM_MAX = PF_NORM_MAX_BLOCKS * PF_BLOCK;
 

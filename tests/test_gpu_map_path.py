@@ -132,6 +132,44 @@ def test_incremental_map_update_equals_a_fresh_index(ref, n_s, parts):
         fresh.close()
 
 
+def test_a_stream_of_replacing_updates_reclaims_its_orphaned_overflow_records():
+    """mapcloud_update REPLACES the previous update every time (src/mcl_3dl.cpp:141-153): each update orphans the overflow records
+    the previous one appended. They are reclaimed in place (compact_overflow) — every update stays incremental (outcome 0, no
+    whole-map rebuild in between) and every answer equals a fresh engine's on the merged map, bit for bit. The map is a cloud of
+    voxel-filter centroids (displaced lattice points): a quarter of its voxels keep overflow records."""
+    sc = make_scene(n=91, n_p=64, n_s=1500, n_b=0, seed=14, sigma_xyz=(0.3, 0.3, 0.1), map_jitter=0.045)
+    rng = np.random.default_rng(18)
+    inc, fresh = capi.Engine(0), capi.Engine(0)
+    try:
+        for e in (inc, fresh):
+            e.set_likelihood_params()
+        inc.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=(1.0, 1.0, 1.0))
+        inc.measure_batch(sc.poses, sc.scan_lik)
+        true_pos = sc.true_pose[:3]
+        near = sc.map_xyz[np.linalg.norm(sc.map_xyz - true_pos, axis=1) < 3.5]
+        inward = (true_pos - near) / np.linalg.norm(true_pos - near, axis=1, keepdims=True)
+        leaf = (0.1, 0.1, 0.1)
+        rebuilds = 0
+        for step in range(9):
+            upd = (near + (0.08 + 0.015 * step) * inward + rng.normal(0, 0.02, near.shape)).astype(np.float32)
+            n_map, stats = inc.map_update(upd, None, leaf=leaf, stamp=20 + step)
+            rebuilds += stats["outcome"] != 0
+            merged = inc.map_download()[0]
+            assert n_map == len(merged)
+            fresh.set_map(merged, None, stamp=200 + step, dist_weight=(1.0, 1.0, 1.0))
+            got = inc.measure_batch(sc.poses, sc.scan_lik)
+            want = fresh.measure_batch(sc.poses, sc.scan_lik)
+            np.testing.assert_array_equal(got[0], want[0], err_msg="update %d" % step)
+            np.testing.assert_array_equal(got[1], want[1], err_msg="update %d" % step)
+        assert rebuilds == 0
+        assert inc.get_option("cand_ovf_compactions") >= 1
+        # the orphans never outgrow the array they live in (they are reclaimed at half of it)
+        assert inc.get_option("cand_ovf_leaked") < inc.index_stats()["overflow_records"]
+    finally:
+        inc.close()
+        fresh.close()
+
+
 def test_update_outside_the_grid_falls_back_to_a_rebuild():
     sc = make_scene(n=61, n_p=16, n_s=300, seed=1)
     a, b = capi.Engine(0), capi.Engine(0)
