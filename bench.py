@@ -109,6 +109,7 @@ def parse():
                     help="overflow rounds of the tiled kernel deferred and run densely: 0 never, 1 whenever the records allow it, "
                          "2 on crowded maps (library default); -1 = leave the default")
     ap.add_argument("--cand-packed", type=int, default=-1, help="packed w words in the voxel records (library default 1)")
+    ap.add_argument("--cand-bound", type=int, default=-1, help="skip bound of the overflow candidates in the voxel records (library default 1)")
     ap.add_argument("--cand-record-parts", type=int, default=-1,
                     help="inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map (-1 = default)")
     ap.add_argument("--lik-wide", type=int, default=-1,
@@ -144,7 +145,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys (post-update reductions, resampling, fused update, route A, jitter check)")
-    ap.add_argument("--route-a-reps", type=int, default=5,
+    ap.add_argument("--route-a-reps", type=int, default=40,
                     help="timed repetitions of the node's call site through the drop-in C++ classes "
                          "(tests/cpp/adapter_demo.bin), 0 = skip")
     ap.add_argument("--cpu-particles", type=int, default=0,
@@ -710,6 +711,8 @@ def main():
         eng.set_option("lik_defer", args.lik_defer)
     if args.cand_packed >= 0:
         eng.set_option("cand_packed", args.cand_packed)
+    if args.cand_bound >= 0:
+        eng.set_option("cand_bound", args.cand_bound)
     if args.strict_order >= 0:
         eng.set_option("strict_order", args.strict_order)
     strict_mode = int(eng.get_option("strict_order"))

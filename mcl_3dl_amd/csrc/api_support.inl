@@ -252,6 +252,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ++ctx->generation;
     return 0;
   }
+  if (key == "cand_bound")
+  {
+    if ((value != 0.0) != (ctx->cand_bound != 0))
+      ctx->cand_dirty = true;
+    ctx->cand_bound = value != 0.0 ? 1 : 0;
+    return 0;
+  }
   if (key == "cand_packed")
   {
     if ((value != 0.0) != (ctx->cand_packed != 0))
@@ -363,6 +370,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "lik_defer_active") *value = lik_defer_active(ctx) ? 1.0 : 0.0;
   else if (key == "cand_packed") *value = ctx->cand_packed;
   else if (key == "cand_packed_active") *value = ctx->rg.packed;
+  else if (key == "cand_bound") *value = ctx->cand_bound;
+  else if (key == "cand_bound_active") *value = ctx->rg.bound_step > 0.0f ? 1.0 : 0.0;
   else if (key == "beam_prepare") *value = ctx->beam_prepare;
   else if (key == "lik_wide_max_particles") *value = ctx->lik_wide_max_particles;
   else if (key == "grid_build_host") *value = ctx->grid_build_host;

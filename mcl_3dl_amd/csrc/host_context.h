@@ -162,6 +162,7 @@ struct mcl3dl_hip_ctx
   uint32_t cand_parts = 4;        // what the current index was built with
   int n_cus = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int cand_packed = 1;            // option: packed w words in the voxel records when the map allows it (map_compiler.h)
+  int cand_bound = 1;             // option: ... with the skip bound of the overflow candidates (the bounded form) when the map allows it
   int lik_defer = 1;              // option: overflow rounds of the tiled kernel deferred and run densely: 0 never, 1 always
                                   // (packed 64-byte records), 2 = when more than lik_defer_min_frac of the voxels overflow
   double lik_defer_min_frac = 0.03;

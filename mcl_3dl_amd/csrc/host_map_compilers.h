@@ -391,19 +391,36 @@ uint32_t bytes32(unsigned long long bytes)
 // preliminary lists -> domination prune -> records of `cap` 16-byte parts into rec_out[n_bricks * 512 * cap * 4 floats] (device) with their
 // overflow records in a fresh allocation (ovf_out, *n_ovf of them). Used for the whole map (build_cand_grid) and for the
 // bricks a map update touches (update_cand_grid).
+// the fields of RecGrid that say how the records' w words are read (map_compiler.h: plain / packed / bounded)
+void set_word_format(RecGrid& g, int fmt, float r)
+{
+  g.packed = fmt != 0 ? 1 : 0;
+  g.count_shift = fmt == 2 ? REC2_COUNT_SHIFT : REC_EXT_BITS;
+  g.ext_bits = fmt == 2 ? REC2_EXT_BITS : REC_EXT_BITS;
+  g.count_is_records = fmt == 2 ? 1 : 0;
+  g.over_thr = fmt == 2 ? (1u << REC2_COUNT_SHIFT) - 1u : ((4u << REC_EXT_BITS) | REC_EXT_MASK);
+  g.bound_step = fmt == 2 ? r / static_cast<float>(REC2_BOUND_MAX) : 0.0f;
+}
+
+int word_format(const RecGrid& g)
+{
+  return !g.packed ? 0 : (g.bound_step > 0.0f ? 2 : 1);
+}
+
 struct CompileOutput
 {
   unsigned long long total = 0, kept = 0;
-  // voxels with candidates, with more than four, with more than eight, with more than REC_COUNT_MAX
-  unsigned long long hist3[4] = { 0, 0, 0, 0 };
+  // voxels with candidates, with more than four, with more than eight, with more than REC_COUNT_MAX, with more than REC2_COUNT_MAX
+  unsigned long long hist3[5] = { 0, 0, 0, 0, 0 };
   uint32_t n_ovf = 0;
-  int packed = 0;  // form of the w words written (RecGrid::packed)
+  int packed = 0;  // form of the w words written: 0 plain, 1 packed, 2 bounded (map_compiler.h)
   // CSR form (lik_index 1): kept counts per voxel stay in d_count, runs in d_pstart / d_prelim
   TempBuf d_count, d_pstart, d_prelim, d_ovf_data;
 };
 
-// want_packed: -1 = packed w words when the counts and ovf_base + the overflow records allow it (whole-map build), 0 = plain,
-// 1 = packed or nothing (a map update into a packed index): returns 1 without writing records when that is impossible.
+// want_packed: -1 = the richest form of the w words the counts and ovf_base + the overflow records allow — bounded, packed,
+// plain (whole-map build; options cand_packed / cand_bound restrict the choice), 0 = plain, 1 = packed or nothing, 2 = bounded or
+// nothing (a map update into an index of that form): returns 1 without writing records when that is impossible.
 int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* pts, const int* table, const int* bxyz,
                    uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out, uint32_t cap = 4,
                    int want_packed = -1, uint32_t ovf_base = 0)
@@ -468,20 +485,25 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   TRY(scratch_alloc(ctx, d_ovf, sizeof(uint32_t) * (n_vox + 1)));
   HIP_TRY(hipMemsetAsync(d_ovf.p, 0, sizeof(uint32_t) * (n_vox + 1), ctx->stream));
   TempBuf d_hist;
-  TRY(scratch_alloc(ctx, d_hist, 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  TRY(scratch_alloc(ctx, d_hist, 5 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_hist.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_count_overflow, dim3(std::min(blocks_v, 4096u)), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t*>(d_count.p), static_cast<uint32_t*>(d_ovf.p), n_vox,
                      static_cast<unsigned long long*>(d_hist.p), cap);
   TRY(device_exclusive_scan(ctx, static_cast<uint32_t*>(d_ovf.p), n_vox + 1));
   uint32_t n_ovf = 0;
   TRY(d2h(ctx, &n_ovf, static_cast<uint32_t*>(d_ovf.p) + n_vox, sizeof(uint32_t)));
-  TRY(d2h(ctx, out->hist3, d_hist.p, 4 * sizeof(unsigned long long)));
+  TRY(d2h(ctx, out->hist3, d_hist.p, 5 * sizeof(unsigned long long)));
   TRY(sync_stream(ctx));
   const bool can_pack = out->hist3[3] == 0 && static_cast<unsigned long long>(ovf_base) + n_ovf <= REC_EXT_MASK;
-  if (want_packed == 1 && !can_pack)
+  const bool can_bound = cap == 4 && out->hist3[3] == 0 &&
+                         static_cast<unsigned long long>(ovf_base) + n_ovf < (1ull << REC2_EXT_BITS);
+  if ((want_packed == 1 && !can_pack) || (want_packed == 2 && !can_bound))
     return 1;
-  out->packed = (want_packed != 0 && can_pack && ctx->cand_packed) ? 1 : 0;
+  if (want_packed >= 0)
+    out->packed = want_packed;
+  else
+    out->packed = (can_bound && ctx->cand_packed && ctx->cand_bound) ? 2 : (can_pack && ctx->cand_packed) ? 1 : 0;
   TRY(scratch_alloc(ctx, out->d_ovf_data, 64ull * (n_ovf ? n_ovf : 1)));
   {
     // unused candidate slots of an overflow record hold the sentinel, like those of a voxel record
@@ -495,7 +517,8 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   hipLaunchKernelGGL(mc_write_records, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
                      static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
                      static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p), rec_out,
-                     static_cast<float*>(out->d_ovf_data.p), n_vox, cap, out->packed);
+                     static_cast<float*>(out->d_ovf_data.p), n_vox, cap, out->packed, cp, bxyz,
+                     static_cast<double>(ctx->match_dist_min));
   HIP_TRY(hipGetLastError());
   out->n_ovf = n_ovf;
   return 0;
@@ -595,7 +618,7 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     g.off32_ok = (rec_bytes * static_cast<unsigned long long>(n_vox) < (1ull << 32)) ? 1 : 0;
     g.rec_bytes32 = bytes32(rec_bytes * static_cast<unsigned long long>(n_vox));
     g.rec_parts = static_cast<int>(cap);
-    g.packed = co.packed;
+    set_word_format(g, co.packed, ctx->match_dist_min);
     ctx->cand_parts = cap;
     g.ovf_bytes32 = bytes32(64ull * (n_ovf ? n_ovf : 1));
     g.ti_empty = static_cast<uint32_t>(n_table);
@@ -734,7 +757,7 @@ int compact_overflow(mcl3dl_hip_ctx* ctx)
   TRY(scratch_alloc(ctx, d_cnt, sizeof(uint32_t) * static_cast<size_t>(n_vox + 1)));
   uint32_t* cnt = static_cast<uint32_t*>(d_cnt.p);
   hipLaunchKernelGGL(mc_ovf_counts, dim3(static_cast<unsigned>((n_vox + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->cand_rec.as<float4>(), n_vox, cap, ctx->rg.packed, cnt);
+                     ctx->cand_rec.as<float4>(), n_vox, cap, ctx->rg.packed, ctx->rg.count_shift, ctx->rg.count_is_records, cnt);
   TRY(device_exclusive_scan(ctx, cnt, n_vox + 1));
   uint32_t live = 0;
   TRY(d2h(ctx, &live, cnt + n_vox, sizeof(uint32_t)));
@@ -743,7 +766,8 @@ int compact_overflow(mcl3dl_hip_ctx* ctx)
   const size_t cap_bytes = 64ull * (static_cast<size_t>(live) + live / 2 + 1024);
   HIP_TRY(hipMalloc(&fresh, cap_bytes));
   hipLaunchKernelGGL(mc_ovf_move, dim3(static_cast<unsigned>((n_vox + 255) / 256)), dim3(256), 0, ctx->stream,
-                     ctx->cand_rec.as<float4>(), n_vox, cap, ctx->rg.packed, cnt, ctx->cand_ovf.as<float4>(),
+                     ctx->cand_rec.as<float4>(), n_vox, cap, ctx->rg.packed, ctx->rg.count_shift, ctx->rg.ext_bits, ctx->rg.count_is_records, cnt,
+                     ctx->cand_ovf.as<float4>(),
                      static_cast<float4*>(fresh));
   HIP_TRY(hipGetLastError());
   TRY(sync_stream(ctx));
@@ -895,11 +919,12 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   {
     const int rc = compile_bricks(ctx, cp, static_cast<const float4*>(d_rel.p), static_cast<const int*>(d_sub_table.p),
                                   static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co,
-                                  cap, ctx->rg.packed ? 1 : 0, ctx->cand_n_ovf);
+                                  cap, word_format(ctx->rg), ctx->cand_n_ovf);
     if (rc == 1)
     {
-      // the update does not fit the packed w words (a voxel with more than REC_COUNT_MAX candidates, or 2^26 overflow
-      // records): the next query rebuilds the whole index, which then picks the plain form
+      // the update does not fit the index's w words (a voxel with more candidates than the count field holds, or more
+      // overflow records than the reference field addresses): the next query rebuilds the whole index, which then picks a
+      // form that fits
       if (stats5)
         stats5[5] = 7;
       ctx->cand_dirty = true;
@@ -920,7 +945,8 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   HIP_TRY(hipMemsetAsync(d_orphan.p, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(mc_install_records, dim3(static_cast<unsigned>((n_sub_vox + 255) / 256)), dim3(256), 0, ctx->stream,
                      static_cast<const float4*>(d_subrec.p), static_cast<const int*>(d_sub_main.p), ovf_base, n_bricks_old,
-                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p), cap, ctx->rg.packed);
+                     n_sub_vox, ctx->cand_rec.as<float4>(), static_cast<unsigned long long*>(d_orphan.p), cap, ctx->rg.packed,
+                     ctx->rg.count_shift, ctx->rg.count_is_records);
   HIP_TRY(hipGetLastError());
   unsigned long long orphaned = 0;
   TRY(d2h(ctx, &orphaned, d_orphan.p, sizeof(orphaned)));

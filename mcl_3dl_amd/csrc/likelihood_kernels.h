@@ -190,11 +190,12 @@ __device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz
 
 // min d2 over the candidates a voxel's overflow records hold (candidates cap .. count - 1; four per 64-byte record, laid
 // out like the first half of a voxel record: part j = {x, y, z, -})
-__device__ inline float rec_overflow_min(const RecGrid& g, float qx, float qy, float qz, uint32_t count, uint32_t cap,
-                                         uint32_t ext, float best)
+// (n_records whole records: their unused slots hold the sentinel, which never wins)
+__device__ inline float rec_overflow_min(const RecGrid& g, float qx, float qy, float qz, uint32_t n_records, uint32_t ext,
+                                         float best)
 {
   const float4* o = g.ovf + 4 * static_cast<size_t>(ext);
-  for (uint32_t j = 0; j < count - cap; ++j)
+  for (uint32_t j = 0; j < 4u * n_records; ++j)
   {
     const float4 c = o[j];
     const float d = d2_simple(qx, qy, qz, c.x, c.y, c.z);
@@ -217,11 +218,12 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
   const float4* r = g.rec + static_cast<size_t>(cap) * ((static_cast<uint32_t>(b) << 9) | sub);
   const float4 r0 = r[0], r1 = r[1];
   const uint32_t w0 = __float_as_uint(r0.w);
-  const uint32_t count = g.packed ? w0 >> REC_EXT_BITS : w0;
-  if (count == 0)
+  const uint32_t field = g.packed ? w0 >> g.count_shift : w0;
+  const uint32_t n_records = rec_overflow_records(field, cap, g.count_is_records);
+  if (!g.count_is_records && field == 0)
     return best;
   if (STATS)
-    n_tested += count;
+    n_tested += g.count_is_records ? cap + 4u * n_records : field;
   // unused slots hold the sentinel: the minimum over all inline slots needs no look at the count
   best = fminf(d2_simple(qx, qy, qz, r0.x, r0.y, r0.z), d2_simple(qx, qy, qz, r1.x, r1.y, r1.z));
   for (uint32_t k = 2; k < cap; ++k)
@@ -229,8 +231,10 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
     const float4 c = r[k];
     best = fminf(best, d2_simple(qx, qy, qz, c.x, c.y, c.z));
   }
-  if (count > cap)
-    best = rec_overflow_min(g, qx, qy, qz, count, cap, g.packed ? (w0 & REC_EXT_MASK) : __float_as_uint(r1.w), best);
+  // (bounded records: the overflow candidates cannot improve on a best that is within their skip bound — RecGrid::bound_step;
+  // STATS counts the candidates of the canonical set either way)
+  if (n_records && !(g.bound_step > 0.0f && best <= rec_bound2(g, w0)))
+    best = rec_overflow_min(g, qx, qy, qz, n_records, g.packed ? (w0 & rec_ext_mask(g)) : __float_as_uint(r1.w), best);
   return best;
 }
 
@@ -436,10 +440,13 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
   {
     // packed w words: part j of record j — the part this lane fetched of its OWN record — says count and overflow reference
     const uint32_t mine = own_word(w, j);
-    if (lanes_gt_u32(mine, (cap << REC_EXT_BITS) | REC_EXT_MASK) != 0ull)
+    const uint32_t thr = g.count_is_records ? g.over_thr : ((cap << g.count_shift) | ((1u << g.count_shift) - 1u));
+    if (lanes_gt_u32(mine, thr) != 0ull)
     {
-      const uint32_t count = mine >> REC_EXT_BITS, ext = mine & REC_EXT_MASK;
-      const uint32_t rounds = (valid && count > cap) ? (count - cap + 3u) / 4u : 0u;
+      const uint32_t ext = mine & rec_ext_mask(g);
+      // bounded records: a lane whose best inline d2 is within the skip bound of its overflow candidates runs no round
+      const bool skip = g.bound_step > 0.0f && best <= rec_bound2(g, mine);
+      const uint32_t rounds = (valid && !skip) ? rec_overflow_records(mine >> g.count_shift, cap, g.count_is_records) : 0u;
       for (uint32_t r = 0; wave_any(r < rounds); ++r)
       {
         const bool more = r < rounds;
@@ -733,7 +740,7 @@ constexpr int DEFER_QCAP = 96;   // entries per wavefront: a push never finds mo
 
 struct DeferQueue
 {
-  uint32_t word[4][DEFER_QCAP];  // packed w of the record: (count << REC_EXT_BITS) | first overflow record
+  uint32_t word[4][DEFER_QCAP];  // packed w of the record: count | (bound) | first overflow record (RecGrid::count_shift / ext_bits)
   uint16_t who[4][DEFER_QCAP];   // (particle slot k << 6) | lane
 };
 
@@ -760,7 +767,11 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
     uint32_t w[4];
     best = quad_round(rg.rec, rg.rec_bytes32, vrec, qx, qy, qz, lane & 3, w);
     mine = own_word(w, lane & 3);
-    over = valid && mine > ((4u << REC_EXT_BITS) | REC_EXT_MASK);
+    over = valid && mine > rg.over_thr;
+    // bounded records (RecGrid::bound_step): no overflow candidate is nearer than the voxel's skip bound to ANY query inside
+    // the voxel, so a best inline d2 within it is final — the evaluation is not queued
+    if (rg.bound_step > 0.0f && wave_any(over))
+      over = over && best > rec_bound2(rg, mine);
     if (valid && !over && best < prm.r2)
     {
       const float s = sqrt_in_radius(best);
@@ -791,8 +802,8 @@ __device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, cons
   const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
   const int t_src = wave * 64 + src;
   float best = s_term[k][t_src];
-  const uint32_t count = word >> REC_EXT_BITS, ext = word & REC_EXT_MASK;
-  const uint32_t rounds = act ? (count - 4u + 3u) / 4u : 0u;
+  const uint32_t ext = word & rec_ext_mask(rg);
+  const uint32_t rounds = act ? rec_overflow_records(word >> rg.count_shift, 4u, rg.count_is_records) : 0u;
   for (uint32_t r = 0; wave_any(r < rounds); ++r)
   {
     const bool more = r < rounds;

@@ -330,7 +330,11 @@ __global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, 
           prelim[i] |= 0x80000000u;
     }
   }
-  // pass 2: compact survivors to the front, ascending point id (selection sort; runs are short)
+  // pass 2: compact survivors to the front, ordered by their distance to the voxel box (ties: ascending point id): the
+  // candidates a record holds INLINE are then the ones nearest to the voxel — the likely winners — and the nearest of the
+  // overflow candidates is the first of them, which is what the record's skip bound is taken from (mc_write_records). The
+  // order changes no result (a query takes the minimum over all candidates). Selection sort; runs are short — a run of
+  // more than 32 survivors keeps the ascending-id order (its bound is then the minimum over all overflow candidates anyway).
   uint32_t n = 0;
   for (uint32_t i = s; i < e; ++i)
   {
@@ -342,18 +346,34 @@ __global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, 
       ++n;
     }
   }
+  constexpr uint32_t SORT_MAX = 32;
+  double key[SORT_MAX];
+  if (n <= SORT_MAX)
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      double dmin2, dmax2;
+      box_dist2(c, pts[prelim[s + i] & 0x7fffffffu], vc[0], vc[1], vc[2], dmin2, dmax2);
+      key[i] = dmin2;
+    }
   for (uint32_t i = 0; i + 1 < n; ++i)
   {
     uint32_t m = i;
     for (uint32_t j = i + 1; j < n; ++j)
     {
       const uint32_t a = prelim[s + j] & 0x7fffffffu, bb = prelim[s + m] & 0x7fffffffu;
-      if (a < bb)
+      const bool before = n <= SORT_MAX ? (key[j] < key[m] || (key[j] == key[m] && a < bb)) : a < bb;
+      if (before)
         m = j;
     }
     const uint32_t tmp = prelim[s + i];
     prelim[s + i] = prelim[s + m];
     prelim[s + m] = tmp;
+    if (n <= SORT_MAX)
+    {
+      const double tk = key[i];
+      key[i] = key[m];
+      key[m] = tk;
+    }
   }
   kept_count[v] = n;
 }
@@ -382,8 +402,15 @@ __global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* _
 //              reference in the word it loaded, no cross-lane traffic. Needs every count <= 63 and fewer than 2^26
 //              overflow records; the compiler falls back to the plain form otherwise.
 //   plain    : w of part 0 = candidate count, w of part 1 = first overflow record (count > cap)
+//   bounded  : like packed, with a skip bound between count and reference — w = (overflow records << 28) | (bound << 22) |
+//              first overflow record; the count field holds the NUMBER OF OVERFLOW RECORDS ceil((count - 4) / 4), all a query
+//              needs (unused slots hold the sentinel), so 4 bits cover 64 candidates. bound = floor(63 x dmin / r) (rounded down with margin), dmin = the distance from the voxel box V+ to
+//              the NEAREST of the voxel's overflow candidates: no query inside the voxel is closer than dmin to any of them, so
+//              a lane whose best inline d2 is <= (bound x r / 63)^2 skips its overflow records — the minimum cannot change
+//              (exactness: RecGrid::bound_step). Needs every count <= 63 and fewer than 2^22 overflow records; 64-byte records.
 constexpr float REC_SENTINEL = 1.0e18f;
 constexpr uint32_t REC_EXT_BITS = 26u, REC_EXT_MASK = (1u << REC_EXT_BITS) - 1u, REC_COUNT_MAX = 63u;
+constexpr uint32_t REC2_EXT_BITS = 22u, REC2_COUNT_SHIFT = 28u, REC2_BOUND_MAX = 63u;
 
 struct RecGrid
 {
@@ -397,22 +424,46 @@ struct RecGrid
   uint32_t rec_bytes32, ovf_bytes32;  // size of rec / ovf in bytes when below 4 GB (buffer loads), else 0
   int rec_parts;                      // 16-byte parts (= inline candidates) per voxel record: 4 (64 bytes) or 8 (128 bytes)
   uint32_t ti_empty;                  // index of the table's extra last entry, always -1 (lanes without a voxel read it)
-  int packed;                         // w words in the packed form (above)
+  int packed;                         // w words in a packed form (above): count field = w >> count_shift, reference = w & ext mask
+  uint32_t count_shift, ext_bits;     // 26 / 26 (packed), 28 / 22 (bounded)
+  int count_is_records;               // bounded form: the count field is the number of overflow records, not of candidates
+  uint32_t over_thr;                  // a packed word above this has overflow records: (4 << 26) | low bits, resp. 2^28 - 1
+  // bounded form only (0 = no bound): a lane's overflow records cannot improve on a best inline d2 <= (bound * bound_step)^2.
+  // bound_step = float(r / 63); the compiler rounds the stored level down with a relative margin of 2e-4, orders of magnitude
+  // above the float rounding of this product and of the kernel's d2 (2e-7), so (bound * bound_step)^2 stays below the d2 the
+  // kernel would compute for every overflow candidate at every query inside the voxel: skipping is exact.
+  float bound_step;
 };
+
+__host__ __device__ inline uint32_t rec_ext_mask(const RecGrid& g)
+{
+  return (1u << g.ext_bits) - 1u;
+}
+// overflow records a voxel with this count field references (cap = inline candidates per record)
+__host__ __device__ inline uint32_t rec_overflow_records(uint32_t field, uint32_t cap, int count_is_records)
+{
+  return count_is_records ? field : (field > cap ? (field - cap + 3u) / 4u : 0u);
+}
+// squared skip bound of a packed word (0 when the index carries no bounds: never skip)
+__device__ inline float rec_bound2(const RecGrid& g, uint32_t w)
+{
+  const float bd = static_cast<float>((w >> REC2_EXT_BITS) & REC2_BOUND_MAX) * g.bound_step;
+  return bd * bd;
+}
 
 // Grid-stride: every wavefront keeps its three tallies in scalar registers and a work-group issues three global atomics in
 // total (one atomic per wavefront and counter used to serialise 125 000 wavefronts on one cache line: 1.3 ms of a 15 ms build).
 __global__ __launch_bounds__(256) void mc_count_overflow(const uint32_t* __restrict__ kept_count, uint32_t* __restrict__ n_ovf,
                                                          long long n_vox, unsigned long long* __restrict__ hist3, uint32_t cap)
 {
-  __shared__ unsigned long long s_h[4];
-  if (threadIdx.x < 4)
+  __shared__ unsigned long long s_h[5];
+  if (threadIdx.x < 5)
     s_h[threadIdx.x] = 0ull;
   __syncthreads();
-  unsigned long long h_any = 0, h_4 = 0, h_8 = 0, h_max = 0;  // wave-uniform
+  unsigned long long h_any = 0, h_4 = 0, h_8 = 0, h_max = 0, h_15 = 0;  // wave-uniform
   // hist3[0] = voxels with at least one candidate, [1] = voxels with more than four, [2] = with more than eight (the index
   // picks its voxel edge and its record size from their ratios: host_map_compilers.h), [3] = with more than REC_COUNT_MAX
-  // (any of those: no packed w words)
+  // (any of those: no packed w words), [4] = unused
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   for (long long base = static_cast<long long>(blockIdx.x) * blockDim.x; base < n_vox; base += stride)
   {
@@ -431,24 +482,50 @@ __global__ __launch_bounds__(256) void mc_count_overflow(const uint32_t* __restr
     atomicAdd(&s_h[1], h_4);
     atomicAdd(&s_h[2], h_8);
     atomicAdd(&s_h[3], h_max);
+    atomicAdd(&s_h[4], h_15);
   }
   __syncthreads();
-  if (hist3 && threadIdx.x < 4 && s_h[threadIdx.x])
+  if (hist3 && threadIdx.x < 5 && s_h[threadIdx.x])
     atomicAdd(&hist3[threadIdx.x], s_h[threadIdx.x]);
 }
 
 // cap = inline candidates per voxel record (4: 64-byte records, 8: 128-byte records); part j = {candidate j: x, y, z; w},
 // w words in the packed or the plain form (RecGrid); candidates cap.. go to four-candidate overflow records
+// fmt: 0 = plain w words, 1 = packed, 2 = bounded (needs cp, brick_xyz and r for the bound)
 __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
                                  const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ kept_count,
                                  const uint32_t* __restrict__ ovf_start, float* __restrict__ rec,
-                                 float* __restrict__ ovf, long long n_vox, uint32_t cap, int packed)
+                                 float* __restrict__ ovf, long long n_vox, uint32_t cap, int fmt, CompileParams cp,
+                                 const int* __restrict__ brick_xyz, double r)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vox)
     return;
   const uint32_t c = kept_count[v], src = pstart[v];
-  const uint32_t packed_w = (c << REC_EXT_BITS) | (c > cap ? ovf_start[v] : 0u);
+  uint32_t packed_w = (c << REC_EXT_BITS) | (c > cap ? ovf_start[v] : 0u);
+  if (fmt == 2)
+  {
+    uint32_t level = 0;
+    if (c > cap)
+    {
+      // distance from V+ to the nearest overflow candidate (the first one when the run is sorted by it; the minimum over
+      // all of them costs nothing more and holds for unsorted long runs too), as a level of r / 63, rounded DOWN
+      const int b = static_cast<int>(v >> 9), l = static_cast<int>(v & 511);
+      const int vx = brick_xyz[3 * b + 0] * 8 + (l & 7), vy = brick_xyz[3 * b + 1] * 8 + ((l >> 3) & 7),
+                vz = brick_xyz[3 * b + 2] * 8 + (l >> 6);
+      double nearest2 = 1.0e300;
+      for (uint32_t k = cap; k < c; ++k)
+      {
+        double dmin2, dmax2;
+        box_dist2(cp, pts[prelim[src + k] & 0x7fffffffu], vx, vy, vz, dmin2, dmax2);
+        nearest2 = dmin2 < nearest2 ? dmin2 : nearest2;
+      }
+      const double lv = floor(static_cast<double>(REC2_BOUND_MAX) * sqrt(nearest2) / r * (1.0 - 2.0e-4));
+      level = lv <= 0.0 ? 0u : (lv >= static_cast<double>(REC2_BOUND_MAX) ? REC2_BOUND_MAX : static_cast<uint32_t>(lv));
+    }
+    const uint32_t n_rec = c > cap ? (c - cap + 3u) / 4u : 0u;
+    packed_w = (n_rec << REC2_COUNT_SHIFT) | (level << REC2_EXT_BITS) | (c > cap ? ovf_start[v] : 0u);
+  }
   // unused candidate slots hold REC_SENTINEL: a point so far away that its d2 (~3e36, finite) never wins a minimum and
   // never passes the radius test, so a query may take the minimum over all inline slots without looking at the count
   float4* dst = reinterpret_cast<float4*>(rec) + static_cast<size_t>(cap) * v;
@@ -463,7 +540,7 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
       o.y = p.y;
       o.z = p.z;
     }
-    if (packed)
+    if (fmt != 0)
     {
       if (k < 4)
         o.w = __uint_as_float(packed_w);
@@ -574,7 +651,8 @@ __global__ void mc_compact_points(const float4* __restrict__ pts, const uint32_t
 // voxels of EXISTING bricks referenced become orphans: counted into *orphaned.
 __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int* __restrict__ sub_main, uint32_t ovf_base,
                                    uint32_t n_bricks_old, long long n_sub_vox, float4* __restrict__ rec,
-                                   unsigned long long* __restrict__ orphaned, uint32_t cap, int packed)
+                                   unsigned long long* __restrict__ orphaned, uint32_t cap, int packed, uint32_t count_shift,
+                                   int count_is_records)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_sub_vox)
@@ -586,17 +664,18 @@ __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int
   if (brick < n_bricks_old)
   {
     const uint32_t w0 = __float_as_uint(rec[dst].w);
-    const uint32_t old_count = packed ? w0 >> REC_EXT_BITS : w0;
-    if (old_count > cap)
-      atomicAdd(orphaned, static_cast<unsigned long long>((old_count - cap + 3u) / 4u));
+    const uint32_t old_records = rec_overflow_records(packed ? w0 >> count_shift : w0, cap, count_is_records);
+    if (old_records)
+      atomicAdd(orphaned, static_cast<unsigned long long>(old_records));
   }
   float4 r0 = sub_rec[src];
   float4 r1 = sub_rec[src + 1];
   if (packed)
   {
-    // the caller made sure ovf_base + (the sub-compile's overflow records) stays below 2^26: the sum cannot carry into the count
+    // the caller made sure ovf_base + (the sub-compile's overflow records) stays below 2^ext_bits: the sum cannot carry into
+    // the bound / the count
     const uint32_t w = __float_as_uint(r0.w);
-    const uint32_t moved = (w >> REC_EXT_BITS) > cap ? w + ovf_base : w;
+    const uint32_t moved = rec_overflow_records(w >> count_shift, cap, count_is_records) ? w + ovf_base : w;
     r0.w = __uint_as_float(moved);
     r1.w = __uint_as_float(moved);
     rec[dst + 0] = r0;
@@ -622,8 +701,8 @@ __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int
 // A map update appends the overflow records of the bricks it re-compiles and orphans the ones those bricks referenced before;
 // mapcloud_update replaces the previous update every time (src/mcl_3dl.cpp:141-153), so the orphans pile up at the rate of
 // the live update's records. Counting pass: overflow records each voxel references, from its own record's w word.
-__global__ void mc_ovf_counts(const float4* __restrict__ rec, long long n_vox, uint32_t cap, int packed,
-                              uint32_t* __restrict__ n_ovf /*[n_vox + 1]*/)
+__global__ void mc_ovf_counts(const float4* __restrict__ rec, long long n_vox, uint32_t cap, int packed, uint32_t count_shift,
+                              int count_is_records, uint32_t* __restrict__ n_ovf /*[n_vox + 1]*/)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v > n_vox)
@@ -632,32 +711,32 @@ __global__ void mc_ovf_counts(const float4* __restrict__ rec, long long n_vox, u
   if (v < n_vox)
   {
     const uint32_t w0 = __float_as_uint(rec[static_cast<size_t>(v) * cap].w);
-    const uint32_t count = packed ? w0 >> REC_EXT_BITS : w0;
-    n = count > cap ? (count - cap + 3u) / 4u : 0u;
+    n = rec_overflow_records(packed ? w0 >> count_shift : w0, cap, count_is_records);
   }
   n_ovf[v] = n;
 }
 
 // moves every voxel's overflow records to new_start[v] .. of a fresh array and rewrites the reference in its record
-__global__ void mc_ovf_move(float4* __restrict__ rec, long long n_vox, uint32_t cap, int packed,
-                            const uint32_t* __restrict__ new_start, const float4* __restrict__ old_ovf,
-                            float4* __restrict__ new_ovf)
+__global__ void mc_ovf_move(float4* __restrict__ rec, long long n_vox, uint32_t cap, int packed, uint32_t count_shift,
+                            uint32_t ext_bits, int count_is_records, const uint32_t* __restrict__ new_start,
+                            const float4* __restrict__ old_ovf, float4* __restrict__ new_ovf)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vox)
     return;
   float4* r = rec + static_cast<size_t>(v) * cap;
   const uint32_t w0 = __float_as_uint(r[0].w);
-  const uint32_t count = packed ? w0 >> REC_EXT_BITS : w0;
-  if (count <= cap)
+  const uint32_t n = rec_overflow_records(packed ? w0 >> count_shift : w0, cap, count_is_records);
+  if (n == 0)
     return;
-  const uint32_t old_ext = packed ? (w0 & REC_EXT_MASK) : __float_as_uint(r[1].w);
-  const uint32_t n = (count - cap + 3u) / 4u, dst = new_start[v];
+  const uint32_t ext_mask = (1u << ext_bits) - 1u;
+  const uint32_t old_ext = packed ? (w0 & ext_mask) : __float_as_uint(r[1].w);
+  const uint32_t dst = new_start[v];
   for (uint32_t j = 0; j < 4u * n; ++j)
     new_ovf[4 * static_cast<size_t>(dst) + j] = old_ovf[4 * static_cast<size_t>(old_ext) + j];
   if (packed)
   {
-    const float w = __uint_as_float((count << REC_EXT_BITS) | dst);
+    const float w = __uint_as_float((w0 & ~ext_mask) | dst);  // count (and bound) kept
     for (uint32_t k = 0; k < 4u; ++k)
       r[k].w = w;
   }

@@ -1,0 +1,67 @@
+"""The skip bound of the voxel records (mcl_3dl_amd/csrc/map_compiler.h, "bounded" w words): every record whose voxel holds more
+than four candidates also says how near its overflow candidates can come to ANY query inside the voxel; an evaluation whose best
+inline distance is within that bound skips the overflow records. The minimum over the candidates cannot change, so likelihoods
+and match ratios must equal — bit for bit — what the same map gives without bounds (cand_bound = 0: packed words), with plain
+words, and with the canonical 27-cell scan (lik_index = 0), on every kernel family. Maps: a cloud of voxel-filter centroids
+(a quarter of the voxels overflow) and a map with eleven points per lattice site (half of the voxels overflow, counts up to 15+)."""
+import numpy as np
+import pytest
+
+from mcl_3dl_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def crowded_scene(seed=21):
+    """Eleven map points around every lattice site (a raw, not down-sampled map)."""
+    sc = make_scene(n=61, n_p=600, n_s=3000, n_b=0, seed=seed)
+    rng = np.random.default_rng(seed)
+    pts = np.concatenate([sc.map_xyz + rng.normal(0, 0.012, sc.map_xyz.shape).astype(np.float32) for _ in range(11)], 0)
+    return sc, np.ascontiguousarray(pts.astype(np.float32))
+
+
+def run(engine, sc, map_xyz, dw, n_p, n_s, stamp, **opts):
+    try:
+        for k, v in opts.items():
+            engine.set_option(k, v)
+        engine.set_map(map_xyz, None, stamp=stamp, dist_weight=dw)
+        engine.set_likelihood_params()
+        lik, ratio, _ = engine.measure_batch(sc.poses[:n_p], sc.scan_lik[:n_s])
+        return lik, ratio, engine.index_stats(), int(engine.get_option("cand_bound_active"))
+    finally:
+        for k in opts:
+            engine.set_option(k, {"cand_bound": 1, "cand_packed": 1, "lik_index": 2, "lik_defer": 1, "lik_coop": 1}[k])
+
+
+@pytest.mark.parametrize("dw", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
+@pytest.mark.parametrize("n_p,n_s", [(512, 3000), (64, 500), (300, 8), (40, 1200)])
+def test_bounded_records_on_a_map_of_centroids(engine, dw, n_p, n_s):
+    sc = make_scene(n=91, n_p=600, n_s=3000, n_b=0, seed=33, map_jitter=0.045)
+    a_lik, a_ratio, st, active = run(engine, sc, sc.map_xyz, dw, n_p, n_s, 8800)
+    assert active == 1 and st["packed_words"] == 1 and st["voxels_with_overflow"] > 0
+    b_lik, b_ratio, _, off = run(engine, sc, sc.map_xyz, dw, n_p, n_s, 8801, cand_bound=0)
+    assert off == 0
+    np.testing.assert_array_equal(a_lik, b_lik)
+    np.testing.assert_array_equal(a_ratio, b_ratio)
+    c_lik, c_ratio, _, _ = run(engine, sc, sc.map_xyz, dw, n_p, n_s, 8802, lik_index=0)
+    np.testing.assert_array_equal(a_ratio, c_ratio)
+    if n_s >= 1024 and n_p >= 4:
+        np.testing.assert_array_equal(a_lik, c_lik)       # tiled kernel on both: same fp64 association
+    else:
+        np.testing.assert_allclose(a_lik, c_lik, rtol=2e-7)
+    assert np.count_nonzero(a_lik) > n_p // 2
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(lik_defer=0), dict(lik_coop=0)])
+def test_bounded_records_on_a_crowded_map(engine, variant):
+    sc, crowded = crowded_scene()
+    dw = (1.0, 1.0, 1.0)
+    a_lik, a_ratio, st, active = run(engine, sc, crowded, dw, 600, 3000, 8810, **variant)
+    b_lik, b_ratio, _, _ = run(engine, sc, crowded, dw, 600, 3000, 8811, cand_bound=0, **variant)
+    np.testing.assert_array_equal(a_lik, b_lik)
+    np.testing.assert_array_equal(a_ratio, b_ratio)
+    c_lik, c_ratio, _, _ = run(engine, sc, crowded, dw, 600, 3000, 8812, cand_packed=0, **variant)
+    np.testing.assert_array_equal(a_lik, c_lik)
+    np.testing.assert_array_equal(a_ratio, c_ratio)
+    print("crowded map: bounded form %s, %d of %d voxels overflow" % ("ON" if active else "off (a count above 15)",
+                                                                      st["voxels_with_overflow"], st["voxels_with_candidates"]))
