@@ -443,21 +443,24 @@ def route_a(sc, dist_weight, n_b, reps):
             return {"error": (proc.stdout + proc.stderr)[-300:]}
         ms = float(m.group(1))
         bd = re.search(r"route_a_breakdown_us pose_gather_upload (\S+) cloud_pack (\S+) measure_batch (\S+) "
-                       r"batched_calls_per_update (\S+)", proc.stdout)
+                       r"batched_calls_per_update (\S+) waiting (\S+)", proc.stdout)
         breakdown = None
         if bd:
-            inside = float(bd.group(1)) + float(bd.group(2)) + float(bd.group(3))
+            inside = float(bd.group(1)) + float(bd.group(2)) + float(bd.group(3)) + float(bd.group(5))
             breakdown = {"pose_gather_upload_us": float(bd.group(1)), "cloud_pack_us": float(bd.group(2)),
-                         "measure_batch_us": float(bd.group(3)), "batched_calls_per_update": float(bd.group(4)),
+                         "measure_batch_begin_us": float(bd.group(3)), "waiting_for_slices_us": float(bd.group(5)),
+                         "batched_calls_per_update": float(bd.group(4)),
                          "reference_pf_loop_us": ms * 1e3 - inside,
-                         "note": "measure_batch = scan upload + ordering + kernels of BOTH models + D2H + the one "
-                                 "synchronisation; reference_pf_loop = the rest: pf.h's particle copy, 2 N virtual calls, "
-                                 "weight product, normalisation and entropy on the CPU"}
+                         "note": "measure_batch_begin = staging the scans + enqueueing the kernels of BOTH models in particle "
+                                 "slices; waiting = blocked until the slice a particle belongs to has arrived (the GPU works "
+                                 "on the later slices while the loop runs); reference_pf_loop = the rest: the node's measure "
+                                 "lambda (src/mcl_3dl.cpp:399-426, a std::map per particle), 2 N virtual calls, weight "
+                                 "product, normalisation and entropy on the CPU — the reference's own code"}
         return {"ms_per_update": ms, "breakdown": breakdown, "evals_per_s": len(sc.poses) * len(sc.scan_lik) / (ms * 1e-3), "reps": reps,
                 "what": "pf_->measure(measure_func) through the drop-in LidarMeasurementModel{Likelihood,Beam} classes "
-                        "(per-particle virtuals, host pose/cloud packing, ONE measure_batch for both models — launched by the "
-                        "first measure() of the update —, poses uploaded once per update, weights normalised by the "
-                        "reference's pf.h on the CPU)"}
+                        "(per-particle virtuals, host pose/cloud packing, ONE batch for both models — launched by the "
+                        "first measure() of the update and delivered in particle slices while the loop runs —, weights "
+                        "normalised by the reference's pf.h on the CPU)"}
 
 
 def in_process_group_run(workload, n_cfg, extra_cfg, dist_weight, devices, steps, warmup, collective=None):

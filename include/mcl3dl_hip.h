@@ -102,6 +102,24 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7 or N
                              size_t n_o, float* out_lik /*n_p*/, float* out_match_ratio /*n_p*/,
                              float* out_beam /*n_p*/);
 
+/* measure_batch delivered in particle order while the GPU is still working — for a caller that consumes the results one
+ * particle at a time on the host, which is what the reference's pf::measure does with the lambda of src/mcl_3dl.cpp:399-426
+ * (include/mcl_3dl/pf.h:255-260: ~80 ns of host work per particle, 0.34 ms at 4096 particles — longer than the kernels).
+ *   _begin  same arguments as measure_batch + slice_particles (0 = option "batch_slice", itself 0 = automatic: four slices,
+ *           none below 512 particles; batches under 1024 particles are not sliced). Enqueues everything and returns; the
+ *           INPUT arrays may be reused at once (they were copied or are page-locked memory the kernels read in place — the
+ *           latter must stay untouched until _end), the OUTPUT arrays belong to the batch until _end.
+ *   _wait   returns once out_*[particle] are valid; *n_ready (optional) = number of leading particles whose results are
+ *           valid, so that a loop calls _wait once per slice, not once per particle.
+ *   _end    all results delivered (also implied by any other call on the context that synchronises its stream).
+ * Results are those of measure_batch bit for bit (a particle's result does not depend on which particles share its launch). */
+int mcl3dl_hip_measure_batch_begin(mcl3dl_hip_ctx* ctx, const float* pose /*n_p*7 or NULL*/, size_t n_p,
+                                   const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                                   const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                                   float* out_lik, float* out_match_ratio, float* out_beam, size_t slice_particles);
+int mcl3dl_hip_measure_batch_wait(mcl3dl_hip_ctx* ctx, size_t particle, size_t* n_ready);
+int mcl3dl_hip_measure_batch_end(mcl3dl_hip_ctx* ctx);
+
 /* Replaces: pf::ParticleFilter::measure (include/mcl_3dl/pf.h:252-279) given the per-particle factors of the
  * measure lambda (src/mcl_3dl.cpp:402-425): weight *= ((1*beam)*lik)*extra ; sum ; if sum > 0 normalise and
  * entropy = -sum(w ln w) over w > 0, else weights restored and *restored = 1 (entropy untouched -> NaN here).
@@ -386,6 +404,14 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose /*n_p*
                                    const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
                                    const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
                                    float* out_lik, float* out_match_ratio, float* out_beam);
+/* mcl3dl_hip_measure_batch_begin / _wait / _end for a group: one device delivers slice by slice; a sharded group evaluates
+ * the whole batch inside _begin and _wait reports every particle ready. */
+int mcl3dl_hip_group_measure_batch_begin(mcl3dl_hip_group* g, const float* pose /*n_p*7 or NULL*/, size_t n_p,
+                                         const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
+                                         const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
+                                         float* out_lik, float* out_match_ratio, float* out_beam, size_t slice_particles);
+int mcl3dl_hip_group_measure_batch_wait(mcl3dl_hip_group* g, size_t particle, size_t* n_ready);
+int mcl3dl_hip_group_measure_batch_end(mcl3dl_hip_group* g);
 int mcl3dl_hip_group_measure_update(mcl3dl_hip_group* g, const float* pose, const float* extra, float* weight_inout,
                                     size_t n_p, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
                                     const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o,
@@ -522,6 +548,8 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "poll_sync"         1 (default) = a zero-copy host-buffer update learns of its completion from a word in page-locked
  *                       memory that a one-thread kernel behind it writes (polled by the caller's thread), 0 =
  *                       hipStreamSynchronize (6 us slower on MI355X / ROCm 7)
+ *   "batch_slice"       particles per slice of mcl3dl_hip_measure_batch_begin when its slice_particles argument is 0
+ *                       (0 = automatic: four slices, none below 512); read-only "batch_slices_run" counts the slices run
  *   "pf_tail"           1 = pf::measure of up to 8192 particles on one GPU in two launches without hand-offs between
  *                       work-groups (the un-normalised weights come out of lik_finalize / a small kernel; every work-group
  *                       of pf_norm_kernel recomputes the reduction and normalises its own 256 weights); 0 (default) =

@@ -32,6 +32,9 @@ SIGNATURES = {
     "mcl3dl_hip_set_beam_params": (_i, [_p, _f, _f, _f, _f, _f, _f, _f, _u32, _f, _u32, _i]),
     "mcl3dl_hip_upload_poses": (_i, [_p, _p, _sz]),
     "mcl3dl_hip_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
+    "mcl3dl_hip_measure_batch_begin": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _sz]),
+    "mcl3dl_hip_measure_batch_wait": (_i, [_p, _sz, _p]),
+    "mcl3dl_hip_measure_batch_end": (_i, [_p]),
     "mcl3dl_hip_pf_measure": (_i, [_p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mcl3dl_hip_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mcl3dl_hip_host_alloc": (_i, [_p, _sz, C.POINTER(_p)]),
@@ -91,6 +94,9 @@ SIGNATURES = {
     "mcl3dl_hip_group_set_option": (_i, [_p, C.c_char_p, _d]),
     "mcl3dl_hip_group_upload_poses": (_i, [_p, _p, _sz]),
     "mcl3dl_hip_group_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
+    "mcl3dl_hip_group_measure_batch_begin": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _sz]),
+    "mcl3dl_hip_group_measure_batch_wait": (_i, [_p, _sz, _p]),
+    "mcl3dl_hip_group_measure_batch_end": (_i, [_p]),
     "mcl3dl_hip_group_measure_update": (_i, [_p, _p, _p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _p, _p, _p,
                                             _p]),
     "mcl3dl_hip_group_collective_stats": (_i, [_p, C.POINTER(_u64), C.POINTER(_u64)]),
@@ -231,6 +237,31 @@ class Group:
         poses = _np_f32(poses, 7)
         self._check(self.lib.mcl3dl_hip_group_upload_poses(self.h, _ptr(poses), len(poses)))
         self._n_uploaded = len(poses)
+
+    def measure_batch_begin(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None, slice_particles=0,
+                            out=None):
+        """mcl3dl_hip_measure_batch_begin: returns the (lik, ratio, beam) arrays the batch fills in particle order
+        (`out` = three caller-owned float32 arrays, e.g. host_array()s); measure_batch_wait(i) says how far they are valid."""
+        sl, sb, so, og = Engine._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        if poses is None:
+            n_p = self._n_uploaded
+        else:
+            poses = _np_f32(poses, 7)
+            n_p = len(poses)
+        lik, ratio, beam = out if out is not None else (np.zeros(n_p, np.float32) for _ in range(3))
+        self._batch_keep = (poses, sl, sb, so, og, lik, ratio, beam)
+        self._check(self.lib.mcl3dl_hip_group_measure_batch_begin(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
+                    len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam), int(slice_particles)))
+        return lik, ratio, beam
+
+    def measure_batch_wait(self, particle):
+        n = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_group_measure_batch_wait(self.h, int(particle), C.byref(n)))
+        return n.value
+
+    def measure_batch_end(self):
+        self._check(self.lib.mcl3dl_hip_group_measure_batch_end(self.h))
+        self._batch_keep = None
 
     def measure_batch(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
         sl, sb, so, og = Engine._scans(scan_lik, scan_beam, scan_beam_origin, origins)
@@ -409,6 +440,31 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_measure_batch(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
                                                       len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam)))
         return lik, ratio, beam
+
+    def measure_batch_begin(self, poses, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None, slice_particles=0,
+                            out=None):
+        """mcl3dl_hip_measure_batch_begin: returns the (lik, ratio, beam) arrays the batch fills in particle order
+        (`out` = three caller-owned float32 arrays, e.g. host_array()s); measure_batch_wait(i) says how far they are valid."""
+        sl, sb, so, og = self._scans(scan_lik, scan_beam, scan_beam_origin, origins)
+        if poses is None:
+            n_p = self._n_uploaded
+        else:
+            poses = _np_f32(poses, 7)
+            n_p = len(poses)
+        lik, ratio, beam = out if out is not None else (np.zeros(n_p, np.float32) for _ in range(3))
+        self._batch_keep = (poses, sl, sb, so, og, lik, ratio, beam)
+        self._check(self.lib.mcl3dl_hip_measure_batch_begin(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
+                    len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam), int(slice_particles)))
+        return lik, ratio, beam
+
+    def measure_batch_wait(self, particle):
+        n = C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_measure_batch_wait(self.h, int(particle), C.byref(n)))
+        return n.value
+
+    def measure_batch_end(self):
+        self._check(self.lib.mcl3dl_hip_measure_batch_end(self.h))
+        self._batch_keep = None
 
     def pf_measure(self, weights, lik, beam=None, extra=None, match_ratio=None):
         w = _np_f32(weights).copy()

@@ -132,6 +132,7 @@ protected:
                 const Slot& slot) const
   {
     Engine& e = Engine::shared();
+    e.endBatch();  // (a batch of the other model still in flight writes into its result vectors)
     syncMap(e, kdtree);
     e.push_params[kind_]();
     const double t0 = Engine::nowUs();
@@ -183,11 +184,24 @@ protected:
         e.profile.batch_us += Engine::nowUs() - t;
       }
     } stop{ e, t2 };
-    e.check(mcl3dl_hip_group_measure_batch(
+    // results arrive in particle order while the later particles are still on the GPU: the reference's per-particle loop
+    // (pf.h:255-260 with the lambda of src/mcl_3dl.cpp:399-426, ~80 ns of host work per particle) starts on the first slice
+    e.check(mcl3dl_hip_group_measure_batch_begin(
         e.group(), nullptr, slot.count, lik ? lik->xyz.data() : nullptr, lik ? lik->xyz.size() / 3 : 0,
         beam ? beam->xyz.data() : nullptr, beam ? beam->label.data() : nullptr, beam ? beam->xyz.size() / 3 : 0,
         beam ? org.data() : nullptr, beam ? origins.size() : 0, lik ? e.results[Engine::LIKELIHOOD].likelihood.data() : nullptr,
-        lik ? e.results[Engine::LIKELIHOOD].quality.data() : nullptr, beam ? e.results[Engine::BEAM].likelihood.data() : nullptr));
+        lik ? e.results[Engine::LIKELIHOOD].quality.data() : nullptr, beam ? e.results[Engine::BEAM].likelihood.data() : nullptr,
+        0));
+    e.batch_open = true;
+    e.batch_ready = 0;
+  }
+
+  // blocks until the results of particle `index` have arrived (one comparison once its slice is in)
+  static void awaitResult(const std::size_t index)
+  {
+    Engine& e = Engine::shared();
+    if (e.batch_open && index >= e.batch_ready)
+      e.waitBatch(index);
   }
 
   std::size_t points_default_ = 0, points_global_ = 0, points_now_ = 0;

@@ -71,6 +71,34 @@ public:
   // process-wide context used by the drop-in model classes (the node builds one likelihood and one beam model that
   // share the map: src/mcl_3dl.cpp:1315-1318)
   static Engine& shared();
+  // the same engine if shared() has built it already, otherwise nullptr (never creates one)
+  static Engine*& live()
+  {
+    static Engine* e = nullptr;
+    return e;
+  }
+
+  // ---- the batch in flight (mcl3dl_hip_group_measure_batch_begin): results arrive in particle order while the GPU works on
+  // the later particles; batch_ready = number of leading particles whose results are in `results`
+  bool batch_open = false;
+  std::size_t batch_ready = 0;
+  void waitBatch(const std::size_t index)
+  {
+    std::size_t n = 0;
+    const double t0 = nowUs();
+    check(mcl3dl_hip_group_measure_batch_wait(group_, index, &n));
+    profile.wait_us += nowUs() - t0;
+    batch_ready = n;
+  }
+  void endBatch()
+  {
+    if (!batch_open)
+      return;
+    batch_open = false;
+    const double t0 = nowUs();
+    check(mcl3dl_hip_group_measure_batch_end(group_));
+    profile.wait_us += nowUs() - t0;
+  }
 
   // ---- map bookkeeping shared by both models: upload when the cloud or its stamp changes ------------------------
   const void* map_cloud = nullptr;
@@ -113,7 +141,7 @@ public:
   // by whoever wants a breakdown: tests/cpp/adapter_demo.cpp prints it next to the total)
   struct Profile
   {
-    double pack_us = 0, poses_us = 0, batch_us = 0;
+    double pack_us = 0, poses_us = 0, batch_us = 0, wait_us = 0;
     std::uint64_t launches = 0;
   } profile;
   static double nowUs()
@@ -156,6 +184,17 @@ public:
   ~BatchScope()
   {
     currentBatch() = saved_;
+    // nothing of the batch stays in flight once pf::measure returns (also when the measure lambda threw half-way)
+    if (Engine* e = Engine::live())
+    {
+      try
+      {
+        e->endBatch();
+      }
+      catch (const std::exception&)
+      {
+      }
+    }
   }
 
 private:

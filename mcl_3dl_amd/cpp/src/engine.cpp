@@ -1,6 +1,7 @@
 // The process-wide engine shared by the drop-in LiDAR models: one map, one device group.
 //   MCL3DL_HIP_DEVICES=0,1,2,3   GPUs the particles are sharded over (default: MCL3DL_HIP_DEVICE, or device 0)
 //   MCL3DL_HIP_COLLECTIVE=host   combine the per-device sums on the host instead of an RCCL all-reduce
+//   MCL3DL_HIP_BATCH_SLICE=n      particles per slice of the batch behind pf::measure (option "batch_slice"; default: automatic)
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -38,6 +39,14 @@ Engine& Engine::shared()
                          }
                          return devices;
                        }());
+  static const bool configured = []
+  {
+    if (const char* slice = std::getenv("MCL3DL_HIP_BATCH_SLICE"))
+      engine.check(mcl3dl_hip_group_set_option(engine.group(), "batch_slice", std::atof(slice)));
+    return true;
+  }();
+  (void)configured;
+  live() = &engine;
   return engine;
 }
 }  // namespace hip

@@ -54,6 +54,7 @@ LidarMeasurementResult LidarMeasurementModelBeam::measure(ChunkedKdtree<PointTyp
   const Slot slot = lookup(s, pc.get());
   if (slot.refresh)
     evaluate(*kdtree, *pc, origins, s, slot);
+  awaitResult(slot.index);
   return LidarMeasurementResult(results().likelihood[slot.index], 1.0);
 }
 

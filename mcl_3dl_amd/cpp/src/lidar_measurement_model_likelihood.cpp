@@ -38,6 +38,7 @@ LidarMeasurementResult LidarMeasurementModelLikelihood::measure(ChunkedKdtree<Po
   const Slot slot = lookup(s, pc.get());
   if (slot.refresh)
     evaluate(*kdtree, *pc, origins, s, slot);
+  awaitResult(slot.index);
   const hip::Engine::Results& r = results();
   return LidarMeasurementResult(r.likelihood[slot.index], r.quality[slot.index]);
 }

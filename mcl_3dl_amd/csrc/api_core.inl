@@ -731,7 +731,7 @@ namespace
 int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,
                           const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
                           size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
-                          float* out_beam, float* st4, bool with_pf = true);
+                          float* out_beam, float* st4, bool with_pf = true, size_t slice = 0);
 }  // namespace
 
 int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
@@ -777,6 +777,71 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p,
     TRY(d2h(ctx, out_beam, ctx->beam.p, sizeof(float) * n_p));
   TRY(sync_stream(ctx));
   return 0;
+}
+
+// ---- the same batch, delivered in particle slices ------------------------------------------------------------------------
+int mcl3dl_hip_measure_batch_begin(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
+                                   const float* scan_beam_xyz, const uint32_t* scan_beam_origin, size_t n_b,
+                                   const float* origins, size_t n_o, float* out_lik, float* out_match_ratio, float* out_beam,
+                                   size_t slice_particles)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(progress_end(ctx));
+  ctx->prog = mcl3dl_hip_ctx::BatchProgress();
+  ctx->prog.n_p = n_p;
+  if (n_p == 0)
+    return 0;
+  if (!pose && ctx->n_pose_uploaded != n_p)
+    return ctx->fail(-3, "null pose array (and mcl3dl_hip_upload_poses holds %zu poses, not %zu)", ctx->n_pose_uploaded,
+                     n_p);
+  size_t slice = slice_particles ? slice_particles : static_cast<size_t>(ctx->batch_slice);
+  if (slice == 0)
+    slice = n_p >= 1024 ? std::max<size_t>(512, ((n_p + 3) / 4 + 63) & ~static_cast<size_t>(63)) : n_p;  // four slices
+  slice = (slice + 15) & ~static_cast<size_t>(15);
+  if (slice < n_p)
+  {
+    const int staged = measure_update_staged(ctx, pose, nullptr, nullptr, n_p, scan_lik_xyz, n_s, scan_beam_xyz,
+                                             scan_beam_origin, n_b, origins, n_o, out_lik, out_match_ratio, out_beam, nullptr,
+                                             false, slice);
+    if (staged < 0)
+      return staged;
+    if (staged != 0)
+    {
+      ctx->prog.n_p = n_p;  // (staged == 1: the path delivered everything at once)
+      return 0;
+    }
+  }
+  // not eligible for slices: the whole batch now
+  const int rc = mcl3dl_hip_measure_batch(ctx, pose, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o,
+                                          out_lik, out_match_ratio, out_beam);
+  ctx->prog = mcl3dl_hip_ctx::BatchProgress();
+  ctx->prog.n_p = n_p;
+  return rc;
+}
+
+int mcl3dl_hip_measure_batch_wait(mcl3dl_hip_ctx* ctx, size_t particle, size_t* n_ready)
+{
+  if (!ctx)
+    return -1;
+  if (particle >= ctx->prog.n_p)
+  {
+    // (not ctx->fail(): a wrong index does not abandon the batch in flight)
+    char buf[160];
+    snprintf(buf, sizeof(buf), "particle %zu is not part of the batch (%zu particles)", particle, ctx->prog.n_p);
+    ctx->err = buf;
+    return -3;
+  }
+  return progress_wait(ctx, particle, n_ready);
+}
+
+int mcl3dl_hip_measure_batch_end(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx)
+    return -1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return progress_end(ctx);
 }
 
 int mcl3dl_hip_pf_measure(mcl3dl_hip_ctx* ctx, float* weight_inout, const float* lik, const float* beam,
@@ -835,7 +900,7 @@ namespace
 int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,
                           const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
                           size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
-                          float* out_beam, float* st4, bool with_pf)
+                          float* out_beam, float* st4, bool with_pf, size_t slice)
 {
   if (!ctx->update_stage || n_s > 0x0fffffffu || n_b > 0x0fffffffu || n_o > 4096 || n_p > 0x7fffffffu / 8)
     return 0;
@@ -982,11 +1047,49 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   {
     // the two models only: their per-particle results go home through a copy kernel into page-locked memory (or one D2H copy)
     const bool lik_wanted = out_lik || out_match_ratio;
-    TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? d_lik : nullptr, lik_wanted ? d_ratio : nullptr,
-                       out_beam ? d_beam : nullptr, false, nullptr));
     float* const user[3] = { out_lik, out_match_ratio, out_beam };
     const float* const dev[3] = { d_lik, d_ratio, d_beam };
     char* blk3 = zero_copy ? static_cast<char*>(stage_alloc(ctx, 3 * rpart)) : nullptr;
+    if (blk3 && slice > 0 && slice < n_p && ctx->poll_sync && ensure_done_flag(ctx))
+    {
+      // progressive delivery (mcl3dl_hip_measure_batch_begin): the particles are evaluated slice by slice, each slice's
+      // results leave for page-locked memory as soon as its kernels are through and a completion word follows them, so the
+      // caller's per-particle loop (the reference's pf::measure, pf.h:255-260) runs while the later slices are still on the GPU
+      mcl3dl_hip_ctx::BatchProgress& pg = ctx->prog;
+      pg = mcl3dl_hip_ctx::BatchProgress();
+      pg.n_p = n_p;
+      pg.slice = slice;
+      pg.n_slices = (n_p + slice - 1) / slice;
+      pg.seq0 = ctx->done_seq;
+      PfEmit e{};
+      float** slot[3] = { &e.lik, &e.ratio, &e.beam };
+      for (int k = 0; k < 3; ++k)
+        if (user[k])
+        {
+          *slot[k] = ctx->is_pinned(user[k], fb) ? user[k] : reinterpret_cast<float*>(blk3 + k * rpart);
+          pg.user[k] = user[k];
+          pg.host[k] = *slot[k];
+        }
+      for (size_t lo = 0; lo < n_p; lo += slice)
+      {
+        const size_t n = std::min(slice, n_p - lo);
+        TRY(launch_measure(ctx, ctx->pose.as<float>() + 7 * lo, n, lik_wanted ? d_lik + lo : nullptr,
+                           lik_wanted ? d_ratio + lo : nullptr, out_beam ? d_beam + lo : nullptr, false, nullptr));
+        PfEmit es{};
+        es.lik = e.lik ? e.lik + lo : nullptr;
+        es.ratio = e.ratio ? e.ratio + lo : nullptr;
+        es.beam = e.beam ? e.beam + lo : nullptr;
+        hipLaunchKernelGGL(emit3_kernel, dim3(pf_blocks(n)), dim3(PF_BLOCK), 0, ctx->stream, es, d_lik + lo, d_ratio + lo,
+                           d_beam + lo, static_cast<int>(n));
+        hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->done_flag, ++ctx->done_seq);
+        HIP_TRY(hipGetLastError());
+        ++ctx->batch_slices_run;
+      }
+      pg.active = true;
+      return 2;
+    }
+    TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? d_lik : nullptr, lik_wanted ? d_ratio : nullptr,
+                       out_beam ? d_beam : nullptr, false, nullptr));
     if (blk3)
     {
       PfEmit e{};

@@ -295,6 +295,66 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
   return 0;
 }
 
+// Progressive form: a single device hands its results over slice by slice (api_core.inl); a sharded group evaluates the
+// whole batch in _begin (every shard at once is already the parallel form) and _wait reports all of it ready.
+int mcl3dl_hip_group_measure_batch_begin(mcl3dl_hip_group* g, const float* pose, size_t n_p, const float* scan_lik_xyz,
+                                         size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
+                                         size_t n_b, const float* origins, size_t n_o, float* out_lik,
+                                         float* out_match_ratio, float* out_beam, size_t slice_particles)
+{
+  if (!g)
+    return -1;
+  g->prog_n_p = 0;
+  g->prog_direct = false;
+  if (!pose && n_p && g->n_pose_uploaded != n_p)
+    return g->fail(-3, "null pose array (and mcl3dl_hip_group_upload_poses holds %zu poses, not %zu)", g->n_pose_uploaded,
+                   n_p);
+  if (g->n() == 1 && g->direct_single)
+  {
+    const int rc = mcl3dl_hip_measure_batch_begin(g->ctx[0], pose, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b,
+                                                  origins, n_o, out_lik, out_match_ratio, out_beam, slice_particles);
+    if (rc)
+      return g->fail_rank(rc, 0);
+    g->prog_n_p = n_p;
+    g->prog_direct = true;
+    return 0;
+  }
+  const int rc = mcl3dl_hip_group_measure_batch(g, pose, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins,
+                                                n_o, out_lik, out_match_ratio, out_beam);
+  if (rc == 0)
+    g->prog_n_p = n_p;
+  return rc;
+}
+
+int mcl3dl_hip_group_measure_batch_wait(mcl3dl_hip_group* g, size_t particle, size_t* n_ready)
+{
+  if (!g)
+    return -1;
+  if (particle >= g->prog_n_p)
+    return g->fail(-3, "particle %zu is not part of the batch (%zu particles)", particle, g->prog_n_p);
+  if (g->prog_direct)
+  {
+    const int rc = mcl3dl_hip_measure_batch_wait(g->ctx[0], particle, n_ready);
+    return rc ? g->fail_rank(rc, 0) : 0;
+  }
+  if (n_ready)
+    *n_ready = g->prog_n_p;
+  return 0;
+}
+
+int mcl3dl_hip_group_measure_batch_end(mcl3dl_hip_group* g)
+{
+  if (!g)
+    return -1;
+  if (g->prog_direct)
+  {
+    const int rc = mcl3dl_hip_measure_batch_end(g->ctx[0]);
+    if (rc)
+      return g->fail_rank(rc, 0);
+  }
+  return 0;
+}
+
 namespace
 {
 // One update over the group's shards. resident = false: mcl3dl_hip_group_measure_update (poses and prior weights come from the

@@ -136,6 +136,18 @@ struct mcl3dl_hip_ctx
   int poll_sync = 1;
   volatile unsigned* done_flag = nullptr;
   unsigned done_seq = 0;
+  // a measure_batch delivered in particle slices (mcl3dl_hip_measure_batch_begin / _wait / _end): slice k is in the host
+  // arrays once the completion word has reached seq0 + k + 1
+  struct BatchProgress
+  {
+    bool active = false;
+    size_t n_p = 0, slice = 0, n_slices = 0, delivered = 0;  // delivered = slices already handed to the caller's arrays
+    unsigned seq0 = 0;
+    float* user[3] = { nullptr, nullptr, nullptr };
+    const float* host[3] = { nullptr, nullptr, nullptr };  // page-locked source of each (== user when that is page-locked)
+  } prog;
+  int batch_slice = 0;  // option "batch_slice": particles per slice of a progressive batch (0 = automatic)
+  uint64_t batch_slices_run = 0;
   DevBuf stage_in_dev, tail_ticket;
   // page-locked host memory handed out by mcl3dl_hip_host_alloc: arrays inside it are read / written in place
   struct PinnedBlock
@@ -316,6 +328,7 @@ struct mcl3dl_hip_ctx
     va_end(ap);
     err = buf;
     stage_out.clear();  // results of a failed call are not delivered (their destinations may be gone)
+    prog.active = false;
     return code;
   }
 };
@@ -563,7 +576,7 @@ __global__ void done_flag_kernel(volatile unsigned* flag, unsigned seq)
 // Completion of everything enqueued on ctx->stream so far, observed through page-locked memory: a one-thread kernel behind
 // it writes a sequence number, the host spins on it (bounded: ~2 s, then hipStreamSynchronize decides). What the kernels in
 // front wrote into page-locked memory left the device before the flag did (uncached stores, one ordered path to the host).
-int wait_done_flag(mcl3dl_hip_ctx* ctx)
+bool ensure_done_flag(mcl3dl_hip_ctx* ctx)
 {
   if (!ctx->done_flag)
   {
@@ -571,17 +584,19 @@ int wait_done_flag(mcl3dl_hip_ctx* ctx)
     if (!ctx->done_flag || !ctx->update_zero_copy)
     {
       ctx->poll_sync = 0;
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      return 0;
+      return false;
     }
     *ctx->done_flag = 0u;
   }
-  const unsigned seq = ++ctx->done_seq;
-  hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->done_flag, seq);
-  HIP_TRY(hipGetLastError());
+  return true;
+}
+
+// spins until the completion word has reached `seq` (sequence numbers only grow, the stream is in order)
+int spin_done_flag(mcl3dl_hip_ctx* ctx, unsigned seq)
+{
   for (long long spin = 0; spin < 2000000000LL; ++spin)
   {
-    if (*ctx->done_flag == seq)
+    if (static_cast<int>(*ctx->done_flag - seq) >= 0)
     {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return 0;
@@ -592,10 +607,59 @@ int wait_done_flag(mcl3dl_hip_ctx* ctx)
   return 0;
 }
 
+int wait_done_flag(mcl3dl_hip_ctx* ctx)
+{
+  if (!ensure_done_flag(ctx))
+  {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  const unsigned seq = ++ctx->done_seq;
+  hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->done_flag, seq);
+  HIP_TRY(hipGetLastError());
+  return spin_done_flag(ctx, seq);
+}
+
+// Progressive batch: waits until the slice holding `particle` is on the host, hands every slice that has arrived to the
+// caller's arrays and returns the number of particles whose results are there.
+int progress_wait(mcl3dl_hip_ctx* ctx, size_t particle, size_t* n_ready)
+{
+  mcl3dl_hip_ctx::BatchProgress& pg = ctx->prog;
+  if (!pg.active)
+  {
+    if (n_ready)
+      *n_ready = pg.n_p;
+    return 0;
+  }
+  const size_t k = std::min(particle / pg.slice, pg.n_slices - 1);
+  if (k >= pg.delivered)
+    TRY(spin_done_flag(ctx, pg.seq0 + static_cast<unsigned>(k) + 1u));
+  const unsigned now = *ctx->done_flag;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const size_t arrived = std::min<size_t>(pg.n_slices, static_cast<size_t>(std::max(0, static_cast<int>(now - pg.seq0))));
+  if (arrived > pg.delivered)
+  {
+    const size_t lo = pg.delivered * pg.slice, hi = std::min(pg.n_p, arrived * pg.slice);
+    for (int a = 0; a < 3; ++a)
+      if (pg.user[a] && pg.host[a] != pg.user[a])
+        memcpy(pg.user[a] + lo, pg.host[a] + lo, sizeof(float) * (hi - lo));
+    pg.delivered = arrived;
+  }
+  if (n_ready)
+    *n_ready = std::min(pg.n_p, pg.delivered * pg.slice);
+  return 0;
+}
+
 // hipStreamSynchronize (or, polled = true and the option on, the polled completion flag) + hand the staged results to the
 // caller's arrays + recycle the staging memory.
 int sync_stream(mcl3dl_hip_ctx* ctx, bool polled = false)
 {
+  if (ctx->prog.active)
+  {
+    // a progressive batch is still in flight: its remaining slices are delivered before the staging memory is recycled
+    TRY(progress_wait(ctx, ctx->prog.n_p - 1, nullptr));
+    ctx->prog.active = false;
+  }
   if (polled && ctx->poll_sync)
     TRY(wait_done_flag(ctx));
   else
@@ -606,6 +670,21 @@ int sync_stream(mcl3dl_hip_ctx* ctx, bool polled = false)
   ctx->stage_cur = 0;
   ctx->stage_off = 0;
   ctx->stage_pending = 0;
+  return 0;
+}
+
+// End of a progressive batch: everything delivered, staging memory recycled. The batch's last completion word is the last
+// thing on the stream unless another call enqueued copies behind it, in which case the stream is synchronised the usual way.
+int progress_end(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx->prog.active)
+    return 0;
+  if (!ctx->stage_out.empty() || ctx->stage_pending != 0)
+    return sync_stream(ctx, true);
+  TRY(progress_wait(ctx, ctx->prog.n_p - 1, nullptr));
+  ctx->prog.active = false;
+  ctx->stage_cur = 0;
+  ctx->stage_off = 0;
   return 0;
 }
 

@@ -200,6 +200,9 @@ struct mcl3dl_hip_group
   std::vector<std::vector<double>> host_packed;
   // poses kept on the devices by group_upload_poses
   size_t n_pose_uploaded = 0;
+  // the batch mcl3dl_hip_group_measure_batch_begin started
+  size_t prog_n_p = 0;
+  bool prog_direct = false;
   // particles resident on the devices (api_group_state.inl): 13-float states + weights, sharded by shard_bounds
   size_t n_resident = 0;
   std::vector<float> h_weight, h_state;  // host gather buffers of the resampling steps

@@ -241,9 +241,11 @@ int main(int argc, char** argv)
     printf("route_a_ms_per_update %.6f\n", total_ms / reps);
     // of which inside the engine-side adapter (the rest is the reference's pf.h loop: particle copy, 2 N virtual calls,
     // weight product, normalisation, entropy)
-    printf("route_a_breakdown_us pose_gather_upload %.1f cloud_pack %.1f measure_batch %.1f batched_calls_per_update %.2f\n",
+    // (measure_batch = the call that enqueues the batch; waiting = blocked on a slice that had not arrived yet)
+    printf("route_a_breakdown_us pose_gather_upload %.1f cloud_pack %.1f measure_batch %.1f batched_calls_per_update %.2f "
+           "waiting %.1f\n",
            eng.profile.poses_us / reps, eng.profile.pack_us / reps, eng.profile.batch_us / reps,
-           static_cast<double>(eng.profile.launches) / reps);
+           static_cast<double>(eng.profile.launches) / reps, eng.profile.wait_us / reps);
     size_t i = 0;
     for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
       if (it->probability_ != posterior[i])

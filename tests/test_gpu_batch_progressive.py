@@ -1,0 +1,166 @@
+"""mcl3dl_hip_measure_batch_begin / _wait / _end (include/mcl3dl_hip.h): the batch of the two LiDAR models delivered in particle
+order while the GPU works on the later particles — what lets the reference's per-particle loop (include/mcl_3dl/pf.h:255-260
+with the lambda of src/mcl_3dl.cpp:399-426) start on the first slice. The results are those of mcl3dl_hip_measure_batch bit
+for bit (a particle's likelihood, match ratio and beam score do not depend on which particles share its launch), whatever
+the slice, whether the output arrays are pageable or page-locked, and whatever else is called on the context meanwhile."""
+import numpy as np
+import pytest
+
+from mcl_3dl_amd.capi import EngineError, Group
+from mcl_3dl_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return make_scene(n=61, n_p=4096, n_s=4096, n_b=256, seed=777)
+
+
+@pytest.fixture(scope="module")
+def configured(engine, scene):
+    sc = scene
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=9101, dist_weight=(1.0, 1.0, 5.0))
+    engine.set_likelihood_params()
+    engine.set_beam_params(num_points=256)
+    return engine
+
+
+def whole(engine, sc, n_p, n_s, n_b):
+    return engine.measure_batch(sc.poses[:n_p], sc.scan_lik[:n_s], sc.scan_beam[:n_b] if n_b else None,
+                                sc.scan_beam_label[:n_b] if n_b else None, sc.origins)
+
+
+def begin(engine, sc, n_p, n_s, n_b, slice_particles, out=None):
+    return engine.measure_batch_begin(sc.poses[:n_p], sc.scan_lik[:n_s], sc.scan_beam[:n_b] if n_b else None,
+                                      sc.scan_beam_label[:n_b] if n_b else None, sc.origins, slice_particles=slice_particles,
+                                      out=out)
+
+
+@pytest.mark.parametrize("n_p,n_s,n_b,slice_particles", [(4096, 4096, 256, 0), (4096, 4096, 0, 1024), (3000, 2048, 64, 512),
+                                                         (1025, 1000, 32, 256), (2048, 96, 3, 100), (4096, 4096, 256, 4096),
+                                                         (700, 300, 16, 0), (1, 500, 8, 0), (4096, 0, 128, 1000)])
+def test_slices_arrive_in_particle_order_with_the_results_of_the_whole_batch(configured, scene, n_p, n_s, n_b, slice_particles):
+    engine, sc = configured, scene
+    ref = whole(engine, sc, n_p, n_s, n_b)
+    run0 = engine.get_option("batch_slices_run")
+    lik, ratio, beam = begin(engine, sc, n_p, n_s, n_b, slice_particles)
+    ready, waits = 0, 0
+    for i in range(n_p):
+        if i >= ready:
+            now = engine.measure_batch_wait(i)
+            assert now > i and now >= ready and now <= n_p
+            ready, waits = now, waits + 1
+            # everything up to `ready` is final already
+            np.testing.assert_array_equal(lik[:ready], ref[0][:ready])
+            np.testing.assert_array_equal(ratio[:ready], ref[1][:ready])
+            np.testing.assert_array_equal(beam[:ready], ref[2][:ready])
+    engine.measure_batch_end()
+    for a, b in zip((lik, ratio, beam), ref):
+        np.testing.assert_array_equal(a, b)
+    ran = engine.get_option("batch_slices_run") - run0
+    eff = slice_particles if slice_particles else (max(512, -(-((n_p + 3) // 4) // 64) * 64) if n_p >= 1024 else n_p)
+    eff = -(-eff // 16) * 16
+    expected = -(-n_p // eff) if eff < n_p else 0
+    assert ran == expected, (ran, expected)
+    assert waits <= max(expected, 1)
+
+
+def test_page_locked_outputs_are_written_in_place(configured, scene):
+    engine, sc = configured, scene
+    n_p = 4096
+    ref = whole(engine, sc, n_p, 4096, 256)
+    out = tuple(engine.host_array(n_p) for _ in range(3))
+    try:
+        for a in out:
+            a[:] = -1.0
+        begin(engine, sc, n_p, 4096, 256, 1024, out=out)
+        assert engine.measure_batch_wait(0) >= 1024
+        np.testing.assert_array_equal(out[0][:1024], ref[0][:1024])
+        assert engine.measure_batch_wait(n_p - 1) == n_p
+        engine.measure_batch_end()
+        for a, b in zip(out, ref):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        for a in out:
+            engine.host_free(a)
+
+
+def test_end_without_wait_and_calls_in_between(configured, scene):
+    engine, sc = configured, scene
+    ref = whole(engine, sc, 4096, 4096, 256)
+    # _end alone delivers everything
+    got = begin(engine, sc, 4096, 4096, 256, 512)
+    engine.measure_batch_end()
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    # a synchronising call in the middle finishes the batch first; _wait then reports it complete
+    got = begin(engine, sc, 4096, 4096, 256, 512)
+    other = whole(engine, sc, 100, 300, 0)
+    assert engine.measure_batch_wait(5) == 4096
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    engine.measure_batch_end()
+    np.testing.assert_array_equal(other[0], whole(engine, sc, 100, 300, 0)[0])
+    # a second _begin ends the first
+    first = begin(engine, sc, 4096, 4096, 256, 512)
+    second = begin(engine, sc, 2048, 4096, 0, 512)
+    for a, b in zip(first, ref):
+        np.testing.assert_array_equal(a, b)
+    engine.measure_batch_end()
+    np.testing.assert_array_equal(second[0], ref[0][:2048])
+    # _end with no batch open is a no-op
+    engine.measure_batch_end()
+
+
+def test_a_wrong_index_is_refused_without_abandoning_the_batch(configured, scene):
+    engine, sc = configured, scene
+    ref = whole(engine, sc, 2048, 2048, 0)
+    got = begin(engine, sc, 2048, 2048, 0, 512)
+    with pytest.raises(EngineError, match="not part of the batch"):
+        engine.measure_batch_wait(2048)
+    assert engine.measure_batch_wait(2047) == 2048
+    engine.measure_batch_end()
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_uploaded_poses_and_the_update_after_a_batch(configured, scene):
+    """pose = NULL uses the uploaded set (what the drop-in classes do); a measure_update after the batch sees a clean context."""
+    engine, sc = configured, scene
+    n_p = 2048
+    ref = whole(engine, sc, n_p, 4096, 256)
+    engine.upload_poses(sc.poses[:n_p])
+    got = engine.measure_batch_begin(None, sc.scan_lik[:4096], sc.scan_beam[:256], sc.scan_beam_label[:256], sc.origins,
+                                     slice_particles=512)
+    engine.measure_batch_end()
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    w0 = np.full(n_p, 1.0 / n_p, np.float32)
+    a = engine.measure_update(sc.poses[:n_p], w0, sc.scan_lik[:4096], sc.scan_beam[:256], sc.scan_beam_label[:256], sc.origins)
+    np.testing.assert_array_equal(a["lik"], ref[0])
+    np.testing.assert_array_equal(a["beam"], ref[2])
+
+
+@pytest.mark.parametrize("devices,collective", [((0,), None), ((0, 0), "host")])
+def test_group_form(scene, devices, collective):
+    """One device: slices; a sharded group (two contexts on one GPU, host combine): the whole batch inside _begin."""
+    sc = scene
+    g = Group(devices, collective=collective)
+    try:
+        g.set_map(sc.map_xyz, sc.map_label, stamp=9102, dist_weight=(1.0, 1.0, 5.0))
+        g.set_likelihood_params()
+        g.set_beam_params(num_points=256)
+        ref = g.measure_batch(sc.poses[:3000], sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+        got = g.measure_batch_begin(sc.poses[:3000], sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
+                                    slice_particles=1000)
+        n = g.measure_batch_wait(0)
+        assert n == 3000 if len(devices) > 1 else n >= 1008
+        assert g.measure_batch_wait(2999) == 3000
+        with pytest.raises(EngineError, match="not part of the batch"):
+            g.measure_batch_wait(3000)
+        g.measure_batch_end()
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        g.close()
