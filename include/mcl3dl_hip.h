@@ -548,6 +548,8 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "poll_sync"         1 (default) = a zero-copy host-buffer update learns of its completion from a word in page-locked
  *                       memory that a one-thread kernel behind it writes (polled by the caller's thread), 0 =
  *                       hipStreamSynchronize (6 us slower on MI355X / ROCm 7)
+ *   "cand_prune_coop"   1 (default) = the map compiler's pruning pass runs 16 lanes per voxel (candidates in LDS), 0 = one
+ *                       thread per voxel; identical records, 4-5x shorter for the few hundred bricks of a map update
  *   "batch_slice"       particles per slice of mcl3dl_hip_measure_batch_begin when its slice_particles argument is 0
  *                       (0 = automatic: four slices, none below 512); read-only "batch_slices_run" counts the slices run
  *   "pf_tail"           1 = pf::measure of up to 8192 particles on one GPU in two launches without hand-offs between

@@ -118,6 +118,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_sync = value != 0.0;
     return 0;
   }
+  if (key == "cand_prune_coop")
+  {
+    ctx->cand_prune_coop = value != 0.0;
+    return 0;
+  }
   if (key == "batch_slice")
   {
     if (value < 0.0 || value > 1.0e9)
@@ -363,6 +368,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "update_particle") *value = ctx->update_particle;
   else if (key == "poll_sync") *value = ctx->poll_sync;
   else if (key == "batch_slice") *value = ctx->batch_slice;
+  else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
   else if (key == "batch_slices_run") *value = static_cast<double>(ctx->batch_slices_run);
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "update_small_conformant") *value = ctx->update_small_conformant;

@@ -452,7 +452,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   // total preliminary candidates must fit the 32-bit run delimiters
   unsigned long long total = 0;
   HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(sum_blocks(n_vox)), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
                      n_vox, static_cast<unsigned long long*>(d_total.p));
   TRY(d2h(ctx, &total, d_total.p, sizeof(total)));
   TRY(sync_stream(ctx));
@@ -467,12 +467,32 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
                        static_cast<const uint32_t*>(d_d2.p), static_cast<uint32_t*>(d_count.p),
                        static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p), n_threads);
   // prune; d_count becomes the kept count per voxel
-  hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, bxyz,
-                     static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
-                     static_cast<uint32_t*>(d_count.p), n_vox);
+  if (ctx->cand_prune_coop)
+  {
+    // runs of up to 32: sixteen lanes per voxel; 33 .. 256: one wavefront per voxel, from a list the first kernel writes; the
+    // rest: one thread per voxel
+    constexpr int LANES = 16;
+    TempBuf d_long;
+    TRY(scratch_alloc(ctx, d_long, sizeof(uint32_t) * (static_cast<size_t>(n_vox) + 1)));
+    uint32_t* long_count = static_cast<uint32_t*>(d_long.p);
+    HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL((mc_prune_coop<LANES>), dim3(static_cast<unsigned>((n_vox + 256 / LANES - 1) / (256 / LANES))), dim3(256),
+                       0, ctx->stream, cp, pts, bxyz, static_cast<const uint32_t*>(d_pstart.p),
+                       static_cast<uint32_t*>(d_prelim.p), static_cast<uint32_t*>(d_count.p), n_vox, long_count + 1, long_count);
+    hipLaunchKernelGGL(mc_prune_long, dim3(static_cast<unsigned>(std::min<long long>((n_vox + 3) / 4, 2048))), dim3(256), 0,
+                       ctx->stream, cp, pts, bxyz, static_cast<const uint32_t*>(d_pstart.p),
+                       static_cast<uint32_t*>(d_prelim.p), static_cast<uint32_t*>(d_count.p), long_count + 1, long_count);
+    hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, bxyz,
+                       static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
+                       static_cast<uint32_t*>(d_count.p), n_vox, static_cast<uint32_t>(PRUNE_LONG_MAX));
+  }
+  else
+    hipLaunchKernelGGL(mc_prune_boxed, dim3(blocks_v), dim3(256), 0, ctx->stream, cp, pts, bxyz,
+                       static_cast<const uint32_t*>(d_pstart.p), static_cast<uint32_t*>(d_prelim.p),
+                       static_cast<uint32_t*>(d_count.p), n_vox, 0u);
   unsigned long long kept = 0;
   HIP_TRY(hipMemsetAsync(d_total.p, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(sum_u32_to_u64, dim3(1024), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
+  hipLaunchKernelGGL(sum_u32_to_u64, dim3(sum_blocks(n_vox)), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_count.p),
                      n_vox, static_cast<unsigned long long*>(d_total.p));
   TRY(d2h(ctx, &kept, d_total.p, sizeof(kept)));
   TRY(sync_stream(ctx));

@@ -208,13 +208,11 @@ __global__ void mc_brick_coords(const int* __restrict__ table, int nbx, int nby,
   brick_xyz[3 * b + 2] = static_cast<int>(i / plane);
 }
 
-__global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, const int* __restrict__ brick_xyz,
-                               const uint32_t* __restrict__ pstart, uint32_t* __restrict__ prelim,
-                               uint32_t* __restrict__ kept_count, long long n_vox)
+// one voxel, one thread
+__device__ inline void prune_voxel_serial(const CompileParams& c, const float4* __restrict__ pts,
+                                          const int* __restrict__ brick_xyz, const uint32_t* __restrict__ pstart,
+                                          uint32_t* __restrict__ prelim, uint32_t* __restrict__ kept_count, long long v)
 {
-  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (v >= n_vox)
-    return;
   const uint32_t s = pstart[v], e = pstart[v + 1];
   if (s == e)
   {
@@ -376,6 +374,290 @@ __global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, 
     }
   }
   kept_count[v] = n;
+}
+
+// longer_than = 0: every voxel; > 0: only the voxels whose run is longer (the rest is mc_prune_coop's)
+__global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, const int* __restrict__ brick_xyz,
+                               const uint32_t* __restrict__ pstart, uint32_t* __restrict__ prelim,
+                               uint32_t* __restrict__ kept_count, long long n_vox, uint32_t longer_than)
+{
+  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v < n_vox && (longer_than == 0u || pstart[v + 1] - pstart[v] > longer_than))
+    prune_voxel_serial(c, pts, brick_xyz, pstart, prelim, kept_count, v);
+}
+
+// The same pruning with L lanes per voxel (runs of up to 32 preliminary candidates — the normal case; longer runs are left to a
+// mc_prune_boxed launch behind this one, whose scratch arrays this kernel then does not carry): the candidates sit in LDS, every lane tests its own candidates against all rivals, the
+// survivors are ranked by (distance to the voxel box, point id) instead of selection-sorted. Same fp64 expressions pair by
+// pair, same decisions, the same unique order — so the same records; what changes is the critical path: one thread per voxel
+// walks ~k^2 fp64 tests with its arrays in scratch memory (0.75 - 1 ms for the 172 k voxels of a map update, more than the rest
+// of the update together: profiles/r04n_map_update_kernel_stats.csv), sixteen lanes share them.
+constexpr int PRUNE_COOP_MAX = 32;
+constexpr int PRUNE_LONG_MAX = 256;  // runs of 33 .. 256: one wavefront per voxel (mc_prune_long); longer: one thread
+
+template <int L>
+__global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const float4* __restrict__ pts,
+                                                     const int* __restrict__ brick_xyz, const uint32_t* __restrict__ pstart,
+                                                     uint32_t* __restrict__ prelim, uint32_t* __restrict__ kept_count,
+                                                     long long n_vox, uint32_t* __restrict__ long_list,
+                                                     uint32_t* __restrict__ long_count)
+{
+  constexpr int G = 256 / L;  // voxels per work-group
+  __shared__ double s_px[G][PRUNE_COOP_MAX], s_py[G][PRUNE_COOP_MAX], s_pz[G][PRUNE_COOP_MAX], s_pp[G][PRUNE_COOP_MAX];
+  __shared__ double s_key[G][PRUNE_COOP_MAX];
+  __shared__ uint32_t s_id[G][PRUNE_COOP_MAX];
+  const int grp = static_cast<int>(threadIdx.x) / L, g = static_cast<int>(threadIdx.x) % L;
+  const long long v = static_cast<long long>(blockIdx.x) * G + grp;
+  const bool valid = v < n_vox;
+  uint32_t s = 0, e = 0;
+  if (valid)
+  {
+    s = pstart[v];
+    e = pstart[v + 1];
+  }
+  const uint32_t k = e - s;
+  const bool coop = valid && k > 0 && k <= static_cast<uint32_t>(PRUNE_COOP_MAX);
+  if (valid && g == 0 && k == 0)
+    kept_count[v] = 0;
+  if (valid && g == 0 && k > static_cast<uint32_t>(PRUNE_COOP_MAX) && k <= static_cast<uint32_t>(PRUNE_LONG_MAX))
+    long_list[atomicAdd(long_count, 1u)] = static_cast<uint32_t>(v);  // mc_prune_long's work (any order)
+  int vc[3] = { 0, 0, 0 };
+  double ctr[3] = { 0, 0, 0 };
+  const double half = 0.5 * c.e + c.grow;
+  if (coop)
+  {
+    const int b = static_cast<int>(v >> 9);
+    const int l = static_cast<int>(v & 511);
+    vc[0] = brick_xyz[3 * b + 0] * 8 + (l & 7);
+    vc[1] = brick_xyz[3 * b + 1] * 8 + ((l >> 3) & 7);
+    vc[2] = brick_xyz[3 * b + 2] * 8 + (l >> 6);
+    const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
+    for (int a = 0; a < 3; ++a)
+      ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
+    for (uint32_t i = g; i < k; i += L)
+    {
+      const uint32_t id = prelim[s + i] & 0x7fffffffu;
+      const float4 p = pts[id];
+      const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
+      s_id[grp][i] = id;
+      s_px[grp][i] = px;
+      s_py[grp][i] = py;
+      s_pz[grp][i] = pz;
+      s_pp[grp][i] = px * px + py * py + pz * pz;
+      double dmin2, dmax2;
+      box_dist2(c, p, vc[0], vc[1], vc[2], dmin2, dmax2);
+      s_key[grp][i] = dmin2;
+    }
+  }
+  __syncthreads();
+  const auto group_or = [](uint32_t m)
+  {
+#pragma unroll
+    for (int d = 1; d < L; d <<= 1)
+      m |= __shfl_xor(m, d, L);
+    return m;
+  };
+  // pass 1: dominated by ONE rival everywhere in V+ (any entry of the run is a rival)
+  uint32_t dom = 0u;
+  if (coop)
+    for (uint32_t i = g; i < k; i += L)
+    {
+      const double px = s_px[grp][i], py = s_py[grp][i], pz = s_pz[grp][i], pp = s_pp[grp][i];
+      bool dominated = false;
+      for (uint32_t j = 0; j < k && !dominated; ++j)
+      {
+        if (j == i)
+          continue;
+        const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
+        const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
+        const double gmin = pp - (qx * qx + qy * qy + qz * qz) - half * (fabs(cx) + fabs(cy) + fabs(cz));
+        dominated = gmin > c.margin;
+      }
+      dom |= dominated ? 1u << i : 0u;
+    }
+  dom = group_or(dom);
+  // pass 1b: crowded voxels — every sub-box of V+ has its own dominator (decided against the unrefined survivor set)
+  uint32_t drop = 0u;
+  if (coop && c.refine > 1 && k - static_cast<uint32_t>(__popc(dom)) > static_cast<uint32_t>(c.refine_above))
+  {
+    const int R = c.refine;
+    const double h = half / R;
+    for (uint32_t i = g; i < k; i += L)
+    {
+      if (dom & (1u << i))
+        continue;
+      const double px = s_px[grp][i], py = s_py[grp][i], pz = s_pz[grp][i], pp = s_pp[grp][i];
+      bool needed = false;
+      for (int cell = 0; cell < R * R * R && !needed; ++cell)
+      {
+        const double ox = -half + (2 * (cell % R) + 1) * h, oy = -half + (2 * ((cell / R) % R) + 1) * h,
+                     oz = -half + (2 * (cell / (R * R)) + 1) * h;
+        bool dominated_here = false;
+        for (uint32_t j = 0; j < k && !dominated_here; ++j)
+        {
+          if (j == i)
+            continue;
+          const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
+          const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
+          const double gmin = pp - (qx * qx + qy * qy + qz * qz) + (ox * cx + oy * cy + oz * cz) -
+                              h * (fabs(cx) + fabs(cy) + fabs(cz));
+          dominated_here = gmin > c.margin;
+        }
+        needed = !dominated_here;
+      }
+      drop |= needed ? 0u : 1u << i;
+    }
+  }
+  dom |= group_or(drop);
+  // pass 2: the survivors in the order of (distance to the voxel box, point id); the dropped entries behind them, flagged
+  if (coop)
+  {
+    const uint32_t n = k - static_cast<uint32_t>(__popc(dom));
+    for (uint32_t i = g; i < k; i += L)
+    {
+      const uint32_t id = s_id[grp][i];
+      uint32_t rank = 0;
+      if (dom & (1u << i))
+        rank = n + static_cast<uint32_t>(__popc(dom & ((1u << i) - 1u)));
+      else
+      {
+        const double key = s_key[grp][i];
+        for (uint32_t j = 0; j < k; ++j)
+        {
+          if (dom & (1u << j))
+            continue;
+          const double kj = s_key[grp][j];
+          rank += (kj < key || (kj == key && s_id[grp][j] < id)) ? 1u : 0u;
+        }
+      }
+      prelim[s + rank] = (dom & (1u << i)) ? (id | 0x80000000u) : id;
+    }
+    if (g == 0)
+      kept_count[v] = n;
+  }
+}
+
+// Runs of PRUNE_COOP_MAX + 1 .. PRUNE_LONG_MAX preliminary candidates (voxels between two close surfaces, raw maps): one
+// wavefront per voxel, taken from the list mc_prune_coop wrote. prune_voxel_serial's long-run rule, stated for 64 lanes: the
+// rivals are the PRUNE_K entries nearest to the voxel centre — the 32 smallest by (squared distance, position in the run),
+// which is what the serial insertion keeps —, every entry is tested against them, no sub-box refinement, survivors ordered by
+// (distance to the voxel box, id) when at most 32 survive and by id otherwise.
+__global__ __launch_bounds__(256) void mc_prune_long(CompileParams c, const float4* __restrict__ pts,
+                                                     const int* __restrict__ brick_xyz, const uint32_t* __restrict__ pstart,
+                                                     uint32_t* __restrict__ prelim, uint32_t* __restrict__ kept_count,
+                                                     const uint32_t* __restrict__ long_list,
+                                                     const uint32_t* __restrict__ long_count)
+{
+  constexpr int L = 64, G = 4, K = 32, M = PRUNE_LONG_MAX;
+  __shared__ double s_px[G][M], s_py[G][M], s_pz[G][M], s_pp[G][M], s_key[G][M];
+  __shared__ uint32_t s_id[G][M], s_near[G][K], s_alive[G][M];
+  const int grp = static_cast<int>(threadIdx.x) / L, g = static_cast<int>(threadIdx.x) % L;
+  const uint32_t n_work = *long_count;
+  // (every wavefront of a work-group makes the same number of trips: the barriers below are work-group barriers)
+  for (uint32_t w0 = blockIdx.x * G; w0 < n_work; w0 += gridDim.x * G)
+  {
+    const uint32_t w = w0 + static_cast<uint32_t>(grp);
+    const bool valid = w < n_work;
+    const long long v = valid ? static_cast<long long>(long_list[w]) : 0;
+    const uint32_t s = valid ? pstart[v] : 0u, e = valid ? pstart[v + 1] : 0u;
+    const uint32_t k = e - s;
+    int vc[3] = { 0, 0, 0 };
+    double ctr[3] = { 0, 0, 0 };
+    const double half = 0.5 * c.e + c.grow;
+    if (valid)
+    {
+      const int b = static_cast<int>(v >> 9);
+      const int l = static_cast<int>(v & 511);
+      vc[0] = brick_xyz[3 * b + 0] * 8 + (l & 7);
+      vc[1] = brick_xyz[3 * b + 1] * 8 + ((l >> 3) & 7);
+      vc[2] = brick_xyz[3 * b + 2] * 8 + (l >> 6);
+      const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
+      for (int a = 0; a < 3; ++a)
+        ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
+      for (uint32_t i = g; i < k; i += L)
+      {
+        const uint32_t id = prelim[s + i] & 0x7fffffffu;
+        const float4 p = pts[id];
+        const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
+        s_id[grp][i] = id;
+        s_px[grp][i] = px;
+        s_py[grp][i] = py;
+        s_pz[grp][i] = pz;
+        s_pp[grp][i] = px * px + py * py + pz * pz;
+        double dmin2, dmax2;
+        box_dist2(c, p, vc[0], vc[1], vc[2], dmin2, dmax2);
+        s_key[grp][i] = dmin2;
+      }
+    }
+    __syncthreads();
+    // the K rivals: rank by (pp, position)
+    if (valid)
+      for (uint32_t i = g; i < k; i += L)
+      {
+        const double pp = s_pp[grp][i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < k; ++j)
+        {
+          const double pj = s_pp[grp][j];
+          rank += (pj < pp || (pj == pp && j < i)) ? 1u : 0u;
+        }
+        if (rank < static_cast<uint32_t>(K))
+          s_near[grp][rank] = i;
+      }
+    __syncthreads();
+    if (valid)
+      for (uint32_t i = g; i < k; i += L)
+      {
+        const double px = s_px[grp][i], py = s_py[grp][i], pz = s_pz[grp][i], pp = s_pp[grp][i];
+        bool dominated = false;
+        for (int jj = 0; jj < K && !dominated; ++jj)
+        {
+          const uint32_t j = s_near[grp][jj];
+          if (j == i)
+            continue;
+          const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
+          const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
+          const double gmin = pp - (qx * qx + qy * qy + qz * qz) - half * (fabs(cx) + fabs(cy) + fabs(cz));
+          dominated = gmin > c.margin;
+        }
+        s_alive[grp][i] = dominated ? 0u : 1u;
+      }
+    __syncthreads();
+    if (valid)
+    {
+      uint32_t n = 0;
+      for (uint32_t j = 0; j < k; ++j)
+        n += s_alive[grp][j];
+      const bool by_key = n <= 32u;
+      for (uint32_t i = g; i < k; i += L)
+      {
+        const uint32_t id = s_id[grp][i];
+        uint32_t rank = 0;
+        if (s_alive[grp][i])
+        {
+          const double key = s_key[grp][i];
+          for (uint32_t j = 0; j < k; ++j)
+          {
+            if (!s_alive[grp][j])
+              continue;
+            const double kj = s_key[grp][j];
+            const uint32_t idj = s_id[grp][j];
+            rank += (by_key ? (kj < key || (kj == key && idj < id)) : idj < id) ? 1u : 0u;
+          }
+        }
+        else
+        {
+          rank = n;
+          for (uint32_t j = 0; j < i; ++j)
+            rank += s_alive[grp][j] ? 0u : 1u;
+        }
+        prelim[s + rank] = s_alive[grp][i] ? id : (id | 0x80000000u);
+      }
+      if (g == 0)
+        kept_count[v] = n;
+    }
+    __syncthreads();  // the next trip overwrites the staged run
+  }
 }
 
 // K7: write the final candidate runs
@@ -787,6 +1069,8 @@ __global__ void scan_add_offsets(uint32_t* __restrict__ out, const uint32_t* __r
 
 __global__ void sum_u32_to_u64(const uint32_t* __restrict__ in, long long n, unsigned long long* __restrict__ total)
 {
+  // one atomic per work-group (one per wavefront made 4096 of them on one address: 50 us for any n — twice per map update)
+  __shared__ unsigned long long part[4];
   unsigned long long s = 0;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x)
@@ -795,6 +1079,20 @@ __global__ void sum_u32_to_u64(const uint32_t* __restrict__ in, long long n, uns
   for (int off = 32; off > 0; off >>= 1)
     s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0)
-    atomicAdd(total, s);
+    part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long b = part[0] + part[1] + part[2] + part[3];
+    if (b)
+      atomicAdd(total, b);
+  }
+}
+
+// work-groups for sum_u32_to_u64 over n values: ~4096 values each, at most 1024
+inline unsigned sum_blocks(long long n)
+{
+  const long long b = (n + 4095) / 4096;
+  return static_cast<unsigned>(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 }  // namespace mcl3dl

@@ -3,7 +3,7 @@ than four candidates also says how near its overflow candidates can come to ANY 
 inline distance is within that bound skips the overflow records. The minimum over the candidates cannot change, so likelihoods
 and match ratios must equal — bit for bit — what the same map gives without bounds (cand_bound = 0: packed words), with plain
 words, and with the canonical 27-cell scan (lik_index = 0), on every kernel family. Maps: a cloud of voxel-filter centroids
-(a quarter of the voxels overflow) and a map with eleven points per lattice site (half of the voxels overflow, counts up to 15+)."""
+(a quarter of the voxels overflow) and a map with eleven points per lattice site (half of the voxels overflow, counts up to 63)."""
 import numpy as np
 import pytest
 
@@ -12,11 +12,11 @@ from mcl_3dl_amd.synthetic import make_scene
 pytestmark = pytest.mark.gpu
 
 
-def crowded_scene(seed=21):
+def crowded_scene(seed=21, per_site=11, n=61):
     """Eleven map points around every lattice site (a raw, not down-sampled map)."""
-    sc = make_scene(n=61, n_p=600, n_s=3000, n_b=0, seed=seed)
+    sc = make_scene(n=n, n_p=600, n_s=3000, n_b=0, seed=seed)
     rng = np.random.default_rng(seed)
-    pts = np.concatenate([sc.map_xyz + rng.normal(0, 0.012, sc.map_xyz.shape).astype(np.float32) for _ in range(11)], 0)
+    pts = np.concatenate([sc.map_xyz + rng.normal(0, 0.012, sc.map_xyz.shape).astype(np.float32) for _ in range(per_site)], 0)
     return sc, np.ascontiguousarray(pts.astype(np.float32))
 
 
@@ -30,7 +30,8 @@ def run(engine, sc, map_xyz, dw, n_p, n_s, stamp, **opts):
         return lik, ratio, engine.index_stats(), int(engine.get_option("cand_bound_active"))
     finally:
         for k in opts:
-            engine.set_option(k, {"cand_bound": 1, "cand_packed": 1, "lik_index": 2, "lik_defer": 1, "lik_coop": 1}[k])
+            engine.set_option(k, {"cand_bound": 1, "cand_packed": 1, "lik_index": 2, "lik_defer": 1, "lik_coop": 1,
+                                  "cand_prune_coop": 1}[k])
 
 
 @pytest.mark.parametrize("dw", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
@@ -65,3 +66,26 @@ def test_bounded_records_on_a_crowded_map(engine, variant):
     np.testing.assert_array_equal(a_ratio, c_ratio)
     print("crowded map: bounded form %s, %d of %d voxels overflow" % ("ON" if active else "off (a count above 15)",
                                                                       st["voxels_with_overflow"], st["voxels_with_candidates"]))
+
+
+@pytest.mark.parametrize("which", ["centroids", "crowded", "lattice", "very crowded"])
+def test_pruning_with_sixteen_lanes_per_voxel_compiles_the_same_index(engine, which):
+    """mc_prune_coop (runs of up to 32 preliminary candidates: sixteen lanes per voxel, candidates in LDS, survivors ranked) and
+    mc_prune_long (33 .. 256: a wavefront per voxel, the 32 nearest rivals by rank) against mc_prune_boxed (one thread per
+    voxel, insertion and selection sorts): same candidate sets, same overflow, same likelihoods. "crowded" has runs of ~100,
+    "very crowded" (70 points per lattice site) runs beyond 256, which stay with the one-thread kernel."""
+    if which == "crowded":
+        sc, map_xyz = crowded_scene(seed=5)
+    elif which == "very crowded":
+        sc, map_xyz = crowded_scene(seed=6, per_site=70, n=31)
+    else:
+        sc = make_scene(n=91, n_p=600, n_s=3000, n_b=0, seed=34, map_jitter=0.045 if which == "centroids" else 0.0)
+        map_xyz = sc.map_xyz
+    dw = (1.0, 1.0, 2.0)
+    a_lik, a_ratio, a_st, _ = run(engine, sc, map_xyz, dw, 600, 3000, 8830)
+    b_lik, b_ratio, b_st, _ = run(engine, sc, map_xyz, dw, 600, 3000, 8831, cand_prune_coop=0)
+    for key in ("bricks", "preliminary", "candidates", "voxels_with_candidates", "voxels_with_overflow", "overflow_records",
+                "voxels_over8"):
+        assert a_st[key] == b_st[key], key
+    np.testing.assert_array_equal(a_lik, b_lik)
+    np.testing.assert_array_equal(a_ratio, b_ratio)
