@@ -548,6 +548,11 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "poll_sync"         1 (default) = a zero-copy host-buffer update learns of its completion from a word in page-locked
  *                       memory that a one-thread kernel behind it writes (polled by the caller's thread), 0 =
  *                       hipStreamSynchronize (6 us slower on MI355X / ROCm 7)
+ *   "dda_overlay"       1 (default) = the points of a map update are an overlay of the DDA grid (sorted by voxel, looked up
+ *                       behind a voxel's base points): mcl3dl_hip_map_update replaces the overlay instead of marking the
+ *                       grid for a rebuild, as long as the update stays inside the base map's bounds; 0 = one array over
+ *                       base + update, rebuilt after every update. Read-only: "dda_overlay_updates" (updates applied that
+ *                       way), "dda_overlay_points". Same beam results either way.
  *   "cand_prune_coop"   1 (default) = the map compiler's pruning pass runs 16 lanes per voxel (candidates in LDS), 0 = one
  *                       thread per voxel; identical records, 4-5x shorter for the few hundred bricks of a map update
  *   "batch_slice"       particles per slice of mcl3dl_hip_measure_batch_begin when its slice_particles argument is 0

@@ -233,7 +233,27 @@ int install_map_update(mcl3dl_hip_ctx* ctx, size_t n_in, const float* leaf3, uin
   ++ctx->generation;
   ctx->n_base = n_base;
   ctx->stamp = stamp;
-  ctx->lik_dirty = ctx->dda_dirty = true;  // cell grid and DDA grid are rebuilt on next use (they are linear-time builds)
+  ctx->lik_dirty = true;  // the cell grid (matched / unmatched, lik_index 0) is rebuilt on next use: a linear-time build
+  // the DDA grid keeps its arrays when the update stays inside the bounds it was laid out for: the update's points replace the
+  // previous overlay (host_grid_builders.h:dda_overlay_apply). Otherwise it is rebuilt on next use.
+  bool dda_kept = false;
+  if (!ctx->dda_dirty && ctx->dda_overlay && ctx->dda_overlay_ok)
+  {
+    const DdaGrid& d = ctx->dg;
+    const float* u = ctx->map_xyz.data() + 3 * n_base;
+    bool inside = true;
+    for (size_t i = 0; i < n_out && inside; ++i)
+      inside = u[3 * i] >= d.min_x && u[3 * i] <= d.max_x && u[3 * i + 1] >= d.min_y && u[3 * i + 1] <= d.max_y &&
+               u[3 * i + 2] >= d.min_z && u[3 * i + 2] <= d.max_z;  // (a NaN fails every comparison)
+    if (inside)
+    {
+      TRY(dda_overlay_apply(ctx, ctx->sp_full.as<float4>(), n_out, n_base));
+      ++ctx->dda_overlay_updates;
+      dda_kept = true;
+    }
+  }
+  if (!dda_kept)
+    ctx->dda_dirty = true;
   TRY(update_cand_grid(ctx, n_base, old_update, stats5));
   if (n_map)
     *n_map = n_base + n_out;

@@ -118,6 +118,12 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_sync = value != 0.0;
     return 0;
   }
+  if (key == "dda_overlay")
+  {
+    ctx->dda_overlay = value != 0.0;
+    ctx->dda_dirty = true;
+    return 0;
+  }
   if (key == "cand_prune_coop")
   {
     ctx->cand_prune_coop = value != 0.0;
@@ -369,6 +375,9 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "poll_sync") *value = ctx->poll_sync;
   else if (key == "batch_slice") *value = ctx->batch_slice;
   else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
+  else if (key == "dda_overlay") *value = ctx->dda_overlay;
+  else if (key == "dda_overlay_updates") *value = static_cast<double>(ctx->dda_overlay_updates);
+  else if (key == "dda_overlay_points") *value = ctx->dda_dirty ? 0.0 : static_cast<double>(ctx->dg.ov_n);
   else if (key == "batch_slices_run") *value = static_cast<double>(ctx->batch_slices_run);
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "update_small_conformant") *value = ctx->update_small_conformant;

@@ -68,7 +68,9 @@ __device__ inline void to_index(const DdaGrid& g, const Vec3f p, int& ix, int& i
 }
 
 // The walk from a begin point that lies within the map and whose voxel (bx, by, bz) = toIndex(begin) is known.
-template <bool STATS, bool TRACE = false>
+// OVERLAY = false: compiled without the lookup of a map update's points (DdaGrid::ov_*) — for launches that know there is none
+// (six VGPRs and a wavefront of occupancy less in the beam kernel).
+template <bool STATS, bool TRACE = false, bool OVERLAY = true>
 __device__ inline int cast_ray_from(const DdaGrid& g, const BeamParams& bp, Vec3f b, int bx, int by, int bz, Vec3f e_org,
                                     int* hit, unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
 {
@@ -212,18 +214,53 @@ __device__ inline int cast_ray_from(const DdaGrid& g, const BeamParams& bp, Vec3
         break;
       }
     }
+    bool in_overlay = false;
+    if (OVERLAY && collided < 0 && g.ov_n > 0)
+    {
+      // the update's points of this voxel, behind the base map's (they are later in pc_map2): binary search for the run
+      int lo = 0, hi = g.ov_n;
+      while (lo < hi)
+      {
+        const int mid = (lo + hi) >> 1;
+        if (g.ov_key[mid] < static_cast<uint32_t>(v))
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      for (int k = lo; k < g.ov_n && g.ov_key[k] == static_cast<uint32_t>(v); ++k)
+      {
+        const float4 t = g.ov_pts[k];
+        if (STATS)
+          ++st_tested;
+        const Vec3f rel = { t.x - b.x, t.y - b.y, t.z - b.z };
+        const double foot = static_cast<double>(fabsf(vdot(rel, dir)));
+        const double a = g.ray_angle_half * foot;
+        const double a2 = a * a;
+        const double thr = a2 < g.min_dist_thr_sq ? g.min_dist_thr_sq : a2;
+        const double dist_sq = static_cast<double>(vdot(rel, rel)) - foot * foot;
+        if (dist_sq < thr)
+        {
+          collided = k;
+          cp = t;
+          in_overlay = true;
+          break;
+        }
+      }
+    }
     if (collided < 0)
       continue;
+    const int hit_index = (OVERLAY && in_overlay) ? static_cast<int>(g.ov_base + g.ov_idx[collided]) :
+                                                    static_cast<int>(g.pt_index[collided]);
     if (TRACE)
     {
       tr->collided = 1;
-      *hit = static_cast<int>(g.pt_index[collided]);
+      *hit = hit_index;
       return 0;
     }
     // getBeamStatus, beam.cpp:164-187
     if (__float_as_uint(cp.w) > bp.filter_label_max)
       continue;
-    *hit = static_cast<int>(g.pt_index[collided]);
+    *hit = hit_index;
     if (1.0f > bp.sin_total_ref)  // DDA always reports sin_angle_ = 1.0 (raycast_using_dda.h:152)
     {
       const double ddx = static_cast<double>(e_org.x - cp.x), ddy = static_cast<double>(e_org.y - cp.y),
@@ -237,7 +274,7 @@ __device__ inline int cast_ray_from(const DdaGrid& g, const BeamParams& bp, Vec3
 }
 
 // Casts one ray from an arbitrary begin point (explicit rays: getBeamStatus for the debug markers, the waypoint trace).
-template <bool STATS, bool TRACE = false>
+template <bool STATS, bool TRACE = false, bool OVERLAY = true>
 __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, Vec3f e_org, int* hit,
                                unsigned& st_steps, unsigned& st_occ, unsigned& st_tested, RayTrace* tr = nullptr)
 {
@@ -246,7 +283,7 @@ __device__ inline int cast_ray(const DdaGrid& g, const BeamParams& bp, Vec3f b, 
     return 2;
   int bx, by, bz;
   to_index(g, b, bx, by, bz);
-  return cast_ray_from<STATS, TRACE>(g, bp, b, bx, by, bz, e_org, hit, st_steps, st_occ, st_tested, tr);
+  return cast_ray_from<STATS, TRACE, OVERLAY>(g, bp, b, bx, by, bz, e_org, hit, st_steps, st_occ, st_tested, tr);
 }
 
 // Everything about a ray that depends only on (particle, origin): all N_b rays of a particle share it, so a small
@@ -292,7 +329,7 @@ __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, con
 // One lane per (particle, beam point).  scan_beam.w = origin index (PointXYZIL::label of the scan point).
 // prepared != nullptr: the per-(particle, origin) table of beam_origin_kernel ([n_p][n_o]); nullptr: every ray computes
 // its own begin point (small launches, where one more kernel launch costs more than it saves).
-template <bool STATS>
+template <bool STATS, bool OVERLAY = true>
 __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
                                                    int n_b, const float4* __restrict__ origins, long long n_rays,
                                                    DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pos
                              Vec3f{ bo.pos.x, bo.pos.y, bo.pos.z });  // beam.cpp:139 (transform)
       status = 2;
       if (bo.begin.w != 0.0f)
-        status = cast_ray_from<STATS>(g, bp, Vec3f{ bo.begin.x, bo.begin.y, bo.begin.z }, bo.voxel.x, bo.voxel.y, bo.voxel.z,
+        status = cast_ray_from<STATS, false, OVERLAY>(g, bp, Vec3f{ bo.begin.x, bo.begin.y, bo.begin.z }, bo.voxel.x, bo.voxel.y, bo.voxel.z,
                                       end, &hit, st_steps, st_occ, st_tested);
     }
     else
@@ -337,7 +374,7 @@ __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pos
       const Vec3f end = vadd(qrot(rot, Vec3f{ v.x, v.y, v.z }), pos);  // beam.cpp:139 (transform)
       const float4 og = origins[__float_as_uint(v.w)];
       const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
-      status = cast_ray<STATS>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
+      status = cast_ray<STATS, false, OVERLAY>(g, bp, begin, end, &hit, st_steps, st_occ, st_tested);
     }
     penalised = (status == 0) || (!bp.short_only && (status == 2));  // beam.cpp:146
   }

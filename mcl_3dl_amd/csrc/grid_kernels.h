@@ -108,4 +108,64 @@ __global__ void dda_gather_kernel(const float4* __restrict__ map, const uint32_t
   index[k] = i;
 }
 
+// ---- the DDA overlay of a map update (DdaGrid::ov_*) ---------------------------------------------------------------------
+// voxel keys of the update's points (all inside the grid: the host checked them against the grid's bounds)
+__global__ void dda_overlay_key_kernel(const float4* __restrict__ upd, int n, DdaGeom g, uint32_t* __restrict__ key,
+                                       uint32_t* __restrict__ val)
+{
+  const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n)
+    return;
+  const float4 p = upd[i];
+  const int c0 = static_cast<int>(static_cast<double>(p.x - g.mnx) / g.grid);
+  const int c1 = static_cast<int>(static_cast<double>(p.y - g.mny) / g.grid);
+  const int c2 = static_cast<int>(static_cast<double>(p.z - g.mnz) / g.grid);
+  key[i] = static_cast<uint32_t>(c0 + c1 * g.nx + c2 * (g.nx * g.ny));
+  val[i] = static_cast<uint32_t>(i);
+}
+
+__device__ inline void dda_brick_bit(const DdaGeom& g, uint32_t v, size_t& brick, unsigned long long& bit)
+{
+  const int plane = g.nx * g.ny;
+  const int c2 = static_cast<int>(v) / plane, rem = static_cast<int>(v) - c2 * plane;
+  const int c1 = rem / g.nx, c0 = rem - c1 * g.nx;
+  brick = (static_cast<size_t>(c2 >> 2) * g.bny + (c1 >> 2)) * g.bnx + (c0 >> 2);
+  bit = 1ull << (((c2 & 3) << 4) | ((c1 & 3) << 2) | (c0 & 3));
+}
+
+// the previous overlay goes: a voxel that holds no base point is empty again
+__global__ void dda_overlay_clear_kernel(const uint32_t* __restrict__ old_key, int n, DdaGeom g,
+                                         const uint32_t* __restrict__ vox_start, unsigned long long* __restrict__ bricks)
+{
+  const int k = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n)
+    return;
+  const uint32_t v = old_key[k];
+  if (vox_start[v + 1] != vox_start[v])
+    return;
+  size_t brick;
+  unsigned long long bit;
+  dda_brick_bit(g, v, brick, bit);
+  atomicAnd(&bricks[brick], ~bit);
+}
+
+// the sorted overlay arrays + the occupancy bits of the new update
+__global__ void dda_overlay_set_kernel(const float4* __restrict__ upd, const uint32_t* __restrict__ skey,
+                                       const uint32_t* __restrict__ sval, int n, DdaGeom g, uint32_t* __restrict__ ov_key,
+                                       float4* __restrict__ ov_pts, uint32_t* __restrict__ ov_idx,
+                                       unsigned long long* __restrict__ bricks)
+{
+  const int k = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n)
+    return;
+  const uint32_t v = skey[k], i = sval[k];
+  ov_key[k] = v;
+  ov_pts[k] = upd[i];
+  ov_idx[k] = i;
+  size_t brick;
+  unsigned long long bit;
+  dda_brick_bit(g, v, brick, bit);
+  atomicOr(&bricks[brick], bit);
+}
+
 }  // namespace mcl3dl

@@ -194,6 +194,13 @@ struct mcl3dl_hip_ctx
   // records, voxel edge / match_dist_min actually used
   double cand_stats[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   DevBuf dda_bits, dda_start, dda_pts, dda_index;
+  // the map update as an overlay of the DDA grid (DdaGrid::ov_*): option "dda_overlay"; dda_overlay_ok = the arrays above
+  // hold the base map only and the grid's bounds are the base map's, so an update inside them needs no rebuild
+  DevBuf dda_ov_key, dda_ov_pts, dda_ov_idx;
+  int dda_overlay = 1;
+  bool dda_overlay_ok = false;
+  uint64_t dda_overlay_updates = 0;
+  DdaGeom dda_geom{};
   // the map as a device cloud (host_grid_builders.h); 1 = build the cell grid / the DDA grid on the host instead
   DevBuf map_dev;
   bool map_dev_valid = false;

@@ -113,10 +113,48 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
 }
 
 // ---- DDA occupancy + voxel index (RaycastUsingDDA::updatePointCloud / setExists, raycast_using_dda.h:162-190,230-235) ----
+// The map update as an overlay (DdaGrid::ov_*): the previous overlay's bits are withdrawn (a voxel without base points is
+// empty again), the new points are keyed, sorted by voxel (stable: update order inside a voxel) and their bits set. A few
+// small launches over the update's points — the base arrays are not touched, nothing is read back. upd = the update's
+// points on the device {x, y, z, label bits}, all inside the grid's bounds (the caller checked).
+int dda_overlay_apply(mcl3dl_hip_ctx* ctx, const float4* upd, size_t n_upd, size_t n_base)
+{
+  DdaGrid& d = ctx->dg;
+  const DdaGeom g = ctx->dda_geom;
+  if (d.ov_n > 0)
+    hipLaunchKernelGGL(dda_overlay_clear_kernel, dim3(blocks_for(d.ov_n)), dim3(256), 0, ctx->stream, d.ov_key, d.ov_n, g,
+                       d.vox_start, ctx->dda_bits.as<unsigned long long>());
+  d.ov_n = 0;
+  d.ov_base = static_cast<uint32_t>(n_base);
+  if (n_upd == 0)
+    return 0;
+  if (n_upd > 0x7fffffffu)
+    return ctx->fail(-3, "map update too large");
+  const int n = static_cast<int>(n_upd);
+  TRY(ensure(ctx, ctx->dda_ov_key, sizeof(uint32_t) * n_upd));  // (a reallocation waits for the stream: the clear kernel is through)
+  TRY(ensure(ctx, ctx->dda_ov_pts, sizeof(float4) * n_upd));
+  TRY(ensure(ctx, ctx->dda_ov_idx, sizeof(uint32_t) * n_upd));
+  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n_upd + 1)));
+  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n_upd + 1)));
+  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n_upd + 1)));
+  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n_upd + 1)));
+  hipLaunchKernelGGL(dda_overlay_key_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, upd, n, g,
+                     ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>());
+  TRY(sort_pairs(ctx, n, sort_bits(g.total)));
+  hipLaunchKernelGGL(dda_overlay_set_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, upd, ctx->cl_key[1].as<uint32_t>(),
+                     ctx->cl_val[1].as<uint32_t>(), n, g, ctx->dda_ov_key.as<uint32_t>(), ctx->dda_ov_pts.as<float4>(),
+                     ctx->dda_ov_idx.as<uint32_t>(), ctx->dda_bits.as<unsigned long long>());
+  HIP_TRY(hipGetLastError());
+  d.ov_key = ctx->dda_ov_key.as<uint32_t>();
+  d.ov_pts = ctx->dda_ov_pts.as<float4>();
+  d.ov_idx = ctx->dda_ov_idx.as<uint32_t>();
+  d.ov_n = n;
+  return 0;
+}
+
 int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
 {
   const size_t n = ctx->map_xyz.size() / 3;
-  const long long nn = static_cast<long long>(n);
   const double grid = static_cast<double>(ctx->dda_grid_size);
   if (!(grid > 0))
     return ctx->fail(-3, "dda_grid_size must be positive");
@@ -129,9 +167,24 @@ int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
   HIP_TRY(hipEventRecord(tm.ev0, ctx->stream));
   float mm[6];
   unsigned long long n_finite = 0;
-  TRY(cloud_minmax(ctx, ctx->map_dev.as<float4>(), nn, mm, &n_finite));  // pcl::getMinMax3D
+  TRY(cloud_minmax(ctx, ctx->map_dev.as<float4>(), static_cast<long long>(n), mm, &n_finite));  // pcl::getMinMax3D
   if (n_finite != n)
     return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n) - n_finite);
+  // A map update that stays inside the base map's bounds (the usual one: it is what the robot sees) does not change the
+  // grid's geometry: the arrays are then built from the base map alone and the update rides on top as an overlay, which the
+  // next update replaces without a rebuild.
+  const size_t n_base = (ctx->n_base && ctx->n_base <= n) ? ctx->n_base : n;
+  const size_t n_upd = n - n_base;
+  bool overlay = false;
+  if (n_upd > 0 && ctx->dda_overlay)
+  {
+    float mb[6];
+    unsigned long long nf = 0;
+    TRY(cloud_minmax(ctx, ctx->map_dev.as<float4>(), static_cast<long long>(n_base), mb, &nf));
+    overlay = memcmp(mb, mm, sizeof(mm)) == 0;
+  }
+  const size_t n_csr = overlay ? n_base : n;
+  const long long nn = static_cast<long long>(n_csr);
   const float* mn = mm;
   const float* mx = mm + 3;
   int dim[3];
@@ -148,8 +201,8 @@ int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
   const size_t n_bricks = static_cast<size_t>(bdim[0]) * bdim[1] * bdim[2];
   TRY(ensure(ctx, ctx->dda_bits, sizeof(unsigned long long) * n_bricks));
   TRY(ensure(ctx, ctx->dda_start, sizeof(uint32_t) * (total + 1)));
-  TRY(ensure(ctx, ctx->dda_pts, sizeof(float4) * n));
-  TRY(ensure(ctx, ctx->dda_index, sizeof(uint32_t) * n));
+  TRY(ensure(ctx, ctx->dda_pts, sizeof(float4) * n_csr));
+  TRY(ensure(ctx, ctx->dda_index, sizeof(uint32_t) * n_csr));
   TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
   TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
   TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
@@ -169,13 +222,6 @@ int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
   TRY(device_exclusive_scan(ctx, ctx->dda_start.as<uint32_t>(), static_cast<long long>(total) + 1));
   int err = 0;
   TRY(d2h(ctx, &err, ctx->cl_err.p, sizeof(int)));
-  HIP_TRY(hipEventRecord(tm.ev1, ctx->stream));
-  TRY(sync_stream(ctx));
-  if (err)
-    return ctx->fail(-3, "a map point falls outside its own DDA grid");
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
-  ctx->grid_build_ms[1] = ms;
   DdaGrid& d = ctx->dg;
   d.bricks = ctx->dda_bits.as<unsigned long long>();
   d.bnx = bdim[0];
@@ -194,6 +240,19 @@ int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
   d.nx = dim[0];
   d.ny = dim[1];
   d.nz = dim[2];
+  d.ov_n = 0;  // (a fresh bit array: nothing of an earlier overlay to withdraw)
+  d.ov_base = static_cast<uint32_t>(n_base);
+  ctx->dda_geom = g;
+  if (overlay)
+    TRY(dda_overlay_apply(ctx, ctx->map_dev.as<float4>() + n_base, n_upd, n_base));
+  HIP_TRY(hipEventRecord(tm.ev1, ctx->stream));
+  TRY(sync_stream(ctx));
+  if (err)
+    return ctx->fail(-3, "a map point falls outside its own DDA grid");
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
+  ctx->grid_build_ms[1] = ms;
+  ctx->dda_overlay_ok = ctx->dda_overlay && (n_upd == 0 || overlay);
   dda_ray_constants(ctx, d);
   ctx->footprint[2] = sizeof(unsigned long long) * n_bricks;
   ctx->footprint[3] = sizeof(uint32_t) * (total + 1);

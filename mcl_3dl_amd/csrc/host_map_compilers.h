@@ -190,6 +190,8 @@ int build_dda_grid_host(mcl3dl_hip_ctx* ctx)
   g.nx = dim[0];
   g.ny = dim[1];
   g.nz = dim[2];
+  g.ov_n = 0;  // the host builder puts every point into the one array: a map update then rebuilds
+  ctx->dda_overlay_ok = false;
   dda_ray_constants(ctx, g);
   ctx->footprint[2] = sizeof(unsigned long long) * bits.size();
   ctx->footprint[3] = sizeof(uint32_t) * (total + 1);

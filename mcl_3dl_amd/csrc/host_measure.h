@@ -375,7 +375,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                              ctx->beam_origin.as<BeamOrigin>(), ctx->penalty.as<unsigned>());
           prepared = ctx->beam_origin.as<BeamOrigin>();
         }
-        hipLaunchKernelGGL((beam_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
+        // (a map update rides on the DDA grid as an overlay: the kernel that looks it up is chosen only then)
+        const auto kernel = ctx->dg.ov_n > 0 ? beam_kernel<false, true> : beam_kernel<false, false>;
+        hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
                            ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
                            ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr), prepared,
                            static_cast<int>(ctx->n_o));
@@ -626,6 +628,8 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
       return 0;
   }
   TRY(ensure_structures(ctx, ns > 0, ctx->n_b > 0));
+  if (ctx->n_b > 0 && ctx->dg.ov_n > 0)
+    return 0;  // a map update rides on the DDA grid: the one-launch kernel is compiled without the overlay lookup
   if (ctx->n_b > 0)
     TRY(ensure_pow_table(ctx));
   const int nvb = static_cast<int>((n_p + PF_BLOCK - 1) / PF_BLOCK);

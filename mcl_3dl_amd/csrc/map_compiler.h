@@ -391,7 +391,7 @@ __global__ void mc_prune_boxed(CompileParams c, const float4* __restrict__ pts, 
 // survivors are ranked by (distance to the voxel box, point id) instead of selection-sorted. Same fp64 expressions pair by
 // pair, same decisions, the same unique order — so the same records; what changes is the critical path: one thread per voxel
 // walks ~k^2 fp64 tests with its arrays in scratch memory (0.75 - 1 ms for the 172 k voxels of a map update, more than the rest
-// of the update together: profiles/r04n_map_update_kernel_stats.csv), sixteen lanes share them.
+// of the update together; what the pass costs now: profiles/r04o_map_update_C2_kernel_stats.csv), sixteen lanes share them.
 constexpr int PRUNE_COOP_MAX = 32;
 constexpr int PRUNE_LONG_MAX = 256;  // runs of 33 .. 256: one wavefront per voxel (mc_prune_long); longer: one thread
 

@@ -44,6 +44,14 @@ struct DdaGrid
   const uint32_t* vox_start;  // [total + 1] CSR into pts (voxel order, insertion order inside a voxel)
   const float4* pts;          // x,y,z (unscaled map coordinates), w = label bits
   const uint32_t* pt_index;   // original map index of pts[k]
+  // the map update (pc_map2 = pc_map + pc_update, src/mcl_3dl.cpp:150): its points are NOT in the arrays above but in a small
+  // overlay sorted by voxel — a new update replaces the overlay and flips a few occupancy bits, the base arrays stay as built.
+  // A voxel's points are its base run followed by its overlay run: map order, like one array over the merged cloud.
+  const uint32_t* ov_key;  // [ov_n] voxel index of overlay point k, ascending (update order inside a voxel)
+  const float4* ov_pts;    // [ov_n]
+  const uint32_t* ov_idx;  // [ov_n] position in the update; map index = ov_base + ov_idx[k]
+  int ov_n;                // 0: no overlay
+  uint32_t ov_base;
   float min_x, min_y, min_z;
   float max_x, max_y, max_z;
   int nx, ny, nz;

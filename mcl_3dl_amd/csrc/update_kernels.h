@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
         const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));  // beam.cpp:145: s.pos_ + s.rot_ * origin
         int hit;
         unsigned s0 = 0, s1 = 0, s2 = 0;
-        const int status = cast_ray<false>(a.dg, a.bp, begin, end, &hit, s0, s1, s2);
+        const int status = cast_ray<false, false, false>(a.dg, a.bp, begin, end, &hit, s0, s1, s2);
         penalised = (status == 0) || (!a.bp.short_only && (status == 2));  // beam.cpp:146
       }
       const unsigned long long m = __ballot(penalised);

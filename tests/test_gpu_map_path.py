@@ -170,6 +170,72 @@ def test_a_stream_of_replacing_updates_reclaims_its_orphaned_overflow_records():
         fresh.close()
 
 
+def test_map_updates_ride_on_the_dda_grid_as_an_overlay():
+    """The DDA grid keeps its arrays over a stream of map updates (DdaGrid::ov_*: the update's points sorted by voxel, looked up
+    behind a voxel's base points; the occupancy bits of the previous update withdrawn, the new ones set): beam scores, per-ray
+    status and the collided point's map index equal a fresh engine's on the merged map — for updates that replace each other,
+    one that leaves the base map's bounds (rebuild), the one after it (overlay again), an empty one, and with the overlay
+    switched off. Labels above filter_label_max make collided update points transparent like base points."""
+    sc = make_scene(n=61, n_p=128, n_s=200, n_b=256, seed=24, sigma_xyz=(0.4, 0.4, 0.1))
+    rng = np.random.default_rng(28)
+    inc, fresh, plain = capi.Engine(0), capi.Engine(0), capi.Engine(0)
+    try:
+        plain.set_option("dda_overlay", 0)
+        for e in (inc, fresh, plain):
+            e.set_likelihood_params()
+            e.set_beam_params(num_points=256, filter_label_max=1)
+        for e in (inc, plain):
+            e.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=DW)
+            e.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)   # builds the DDA grid on the base map
+        true_pos = sc.true_pose[:3]
+        lo, hi = sc.map_xyz.min(0), sc.map_xyz.max(0)
+        begin = (true_pos + rng.normal(0, 0.3, (3000, 3))).astype(np.float32)
+        end = (true_pos + rng.normal(0, 4.0, (3000, 3))).astype(np.float32)
+        updates = [furniture(rng, 1500, true_pos + np.array([1.2 * np.cos(k), 1.2 * np.sin(k), 0.1 * k])) for k in range(5)]
+        updates.append((rng.uniform(0, 1, (400, 3)) + hi + 2.0).astype(np.float32))      # outside the base bounds: a rebuild
+        updates.append(furniture(rng, 1500, true_pos + np.array([-1.0, 0.5, 0.0])))      # inside again
+        updates.append(np.zeros((0, 3), np.float32))                                     # withdrawn
+        updates.append(furniture(rng, 800, true_pos + np.array([0.3, -1.1, 0.2])))
+        applied = 0
+        for step, upd in enumerate(updates):
+            lab = rng.integers(0, 3, len(upd)).astype(np.uint32)
+            before = inc.get_option("dda_overlay_updates")
+            inc.map_update(upd, lab, leaf=(0.1, 0.1, 0.1), stamp=10 + step)
+            plain.map_update(upd, lab, leaf=(0.1, 0.1, 0.1), stamp=10 + step)
+            applied += inc.get_option("dda_overlay_updates") - before
+            m_xyz, m_lab = inc.map_download()
+            inside = len(upd) == 0 or bool(np.all((m_xyz[len(sc.map_xyz):] >= lo) & (m_xyz[len(sc.map_xyz):] <= hi)))
+            fresh.set_map(m_xyz, m_lab, stamp=100 + step, dist_weight=DW)
+            want = fresh.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+            w_st, w_hit = fresh.beam_status(begin, end)
+            for e in (inc, plain):
+                got = e.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+                np.testing.assert_array_equal(got[2], want[2], err_msg="update %d" % step)
+                np.testing.assert_array_equal(got[0], want[0], err_msg="update %d" % step)
+                st, hit = e.beam_status(begin, end)
+                np.testing.assert_array_equal(st, w_st, err_msg="update %d" % step)
+                np.testing.assert_array_equal(hit, w_hit, err_msg="update %d" % step)
+            if step == 0:
+                # the reference's own sizes (one-launch update: compiled without the overlay lookup, so it must step aside)
+                w0 = np.full(64, 1.0 / 64, np.float32)
+                a = inc.measure_update(sc.poses[:64], w0, sc.scan_lik[:96], sc.scan_beam[:3], sc.scan_beam_label[:3], sc.origins)
+                b = fresh.measure_update(sc.poses[:64], w0, sc.scan_lik[:96], sc.scan_beam[:3], sc.scan_beam_label[:3], sc.origins)
+                for k in ("weights", "beam", "lik"):
+                    np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+            # the engine with the overlay holds the update's points there whenever they are inside the base map's bounds
+            assert inc.get_option("dda_overlay_points") == (len(m_xyz) - len(sc.map_xyz) if inside else 0), step
+            if len(upd) and inside:
+                assert np.any(w_hit >= len(sc.map_xyz))   # rays do collide with the update's points
+        # every update but the one outside the bounds and the one right after it (its grid had been laid out for the far
+        # points) was applied without a rebuild
+        assert applied == len(updates) - 2, applied
+        assert plain.get_option("dda_overlay_updates") == 0
+    finally:
+        inc.close()
+        fresh.close()
+        plain.close()
+
+
 def test_update_outside_the_grid_falls_back_to_a_rebuild():
     sc = make_scene(n=61, n_p=16, n_s=300, seed=1)
     a, b = capi.Engine(0), capi.Engine(0)
