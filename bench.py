@@ -1292,22 +1292,39 @@ def main():
             # the node replaces its update cloud every few seconds (src/mcl_3dl.cpp:141-153): the steady state is an update
             # that REPLACES the previous one — the same surface moved by a centimetre each time (the first call also pays for
             # the scratch blocks every later one recycles)
-            walls, outcomes = [], []
+            walls, outcomes, after, steady = [], [], [], []
+
+            def small_measure():
+                # 64 particles against the whole scan, both models: whatever the update left to rebuild is paid here
+                t9 = time.perf_counter()
+                eng.measure_batch(sc.poses[:64], sc.scan_lik, sc.scan_beam if n_b else None,
+                                  sc.scan_beam_label if n_b else None, sc.origins)
+                return (time.perf_counter() - t9) * 1e3
+
+            small_measure()
             for rep in range(6):
                 upd_k = (near + (0.13 + 0.01 * rep) * inward).astype(np.float32)
                 t8 = time.perf_counter()
                 n_map, ust = eng.map_update(upd_k, None, leaf=(0.1, 0.1, 0.1), stamp=177 + rep)
                 walls.append((time.perf_counter() - t8) * 1e3)
                 outcomes.append(int(ust["outcome"]))
+                after.append(small_measure())
+                steady.append(small_measure())
             wall_ms = float(np.median(walls))
             out["map_update"] = dict(ust, update_points=int(n_map - len(sc.map_xyz)), map_points=int(len(sc.map_xyz)),
                                      wall_ms=wall_ms, wall_ms_first=first_ms, wall_ms_each=walls, outcomes=outcomes,
                                      overflow_compactions=int(eng.get_option("cand_ovf_compactions")),
+                                     first_measure_after_update_ms=float(np.median(after)),
+                                     same_measure_steady_ms=float(np.median(steady)),
+                                     dda_overlay_updates=int(eng.get_option("dda_overlay_updates")),
                                      full_build_ms=full_ms,
                                      what="mcl3dl_hip_map_update: VoxelGrid of the update + incremental index update "
                                           "(device_ms = the index part), median wall time of six updates that each replace the "
                                           "previous one; wall_ms_first = the first update (allocates the scratch blocks the "
-                                          "others recycle); includes the host copy of the map; outcome 0 = incremental")
+                                          "others recycle); includes the host copy of the map; outcome 0 = incremental; "
+                                          "first_measure_after_update_ms = a 64-particle measure_batch of both models right "
+                                          "behind each update (it pays for whatever the update left to rebuild: nothing, when "
+                                          "the DDA grid took the update as an overlay) next to the same call once more")
             eng.map_update(None, None, stamp=78)  # withdraw it again
         if world == 1 and not args.no_extras and args.jitter_check > 0 and args.workload in ("C2", "C3") and not args.map_jitter:
             # standing robustness figure: the same workload on a map whose points are voxel-filter centroids, not a lattice
