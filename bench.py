@@ -1085,7 +1085,7 @@ def main():
                                                      "(one timed group, run alone: overlap_models = 0)"}
             # the beam kernel's own counter-derived fractions (same pricing as `roofline`), against the kernel's share of the
             # timed group: its rocprofv3 share of beam_kernel in the group is > 95 % at these sizes
-            bpmc, bsrc, bnote = pmc_counters("void mcl3dl::beam_kernel<false>", pmc_tag)
+            bpmc, bsrc, bnote = pmc_counters("void mcl3dl::beam_kernel<false", pmc_tag)
             if bnote:
                 out["beam"]["counters_note"] = bnote
             beam_waves = 4 * ((n_p * n_b + 255) // 256)

@@ -148,6 +148,6 @@ def test_counters_are_tied_to_the_sources_they_profiled(tmp_path, monkeypatch):
         w.writerow(["__source__", "git_head", "abc123", 0])
         for n in bench.PMC_SOURCES["beam"]:
             w.writerow(["__source__", n, bench.source_sha(n), 0])
-        w.writerow(["void mcl3dl::beam_kernel<false>(args)", "SQ_WAVES", "32768", 5])
-    vals, src, note = bench.pmc_counters("void mcl3dl::beam_kernel<false>", "C3")
+        w.writerow(["void mcl3dl::beam_kernel<false, false>(args)", "SQ_WAVES", "32768", 5])
+    vals, src, note = bench.pmc_counters("void mcl3dl::beam_kernel<false", "C3")
     assert vals == {"SQ_WAVES": 32768.0} and note is None
