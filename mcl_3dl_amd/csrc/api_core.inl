@@ -1070,6 +1070,18 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
           pg.user[k] = user[k];
           pg.host[k] = *slot[k];
         }
+      // both models of a slice on ONE stream: the second stream's fork / join events cost ~35 us of host time per launch
+      // (host_measure.h), which the caller's thread would pay once per slice before it can start on the results
+      struct OverlapOff
+      {
+        mcl3dl_hip_ctx* c;
+        int saved;
+        ~OverlapOff()
+        {
+          c->overlap_models = saved;
+        }
+      } overlap_off{ ctx, ctx->overlap_models };
+      ctx->overlap_models = 0;
       for (size_t lo = 0; lo < n_p; lo += slice)
       {
         const size_t n = std::min(slice, n_p - lo);
