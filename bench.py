@@ -1347,6 +1347,36 @@ def main():
             out["map_jitter"] = {"jitter_m": args.jitter_check, "likelihood_ms": jm / max(jn, 1),
                                  "vs_lattice": (jm / max(jn, 1)) / lik_avg_ms if lik_avg_ms else None,
                                  "index": eng.index_stats()}
+        if world == 1 and not args.no_extras and args.workload in ("C2", "C3") and not args.map_jitter and args.dist_weight_z == 1.0:
+            # standing figure at the metric the reference SHIPS (dist_weight_z = 5, src/parameters.cpp:108-110; the demo's 2.0,
+            # config/test_localization.yaml:5): the rescaled z axis stretches the index (3.7 x the records at z x 5). Parity at
+            # these weights and sizes: tests/test_gpu_dist_weight_fullsize.py
+            shipped = {}
+            for wz in (5.0, 2.0):
+                eng.set_map(sc.map_xyz, sc.map_label, stamp=40 + int(wz), dist_weight=(1.0, 1.0, wz))
+                eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+                dw_pose = torch.from_numpy(sc.poses).to(dev).contiguous()
+                t_warm = time.perf_counter()
+                while time.perf_counter() - t_warm < 0.2:
+                    for _ in range(20):
+                        eng.measure_device(dw_pose, n_p, d_lik, d_ratio, None)
+                    eng.synchronize()
+                eng.set_option("timing_mask", 1)
+                eng.set_kernel_timing(True)
+                eng.reset_kernel_time()
+                for _ in range(args.steps):
+                    eng.measure_device(dw_pose, n_p, d_lik, d_ratio, None)
+                wm, wn = eng.kernel_time(capi.KERNEL_LIKELIHOOD)
+                eng.set_kernel_timing(False)
+                st = eng.index_stats()
+                shipped["z%g" % wz] = {"dist_weight": [1.0, 1.0, wz], "likelihood_ms": wm / max(wn, 1),
+                                       "vs_unit_weight": (wm / max(wn, 1)) / lik_avg_ms if lik_avg_ms else None,
+                                       "evals_per_s": n_p * n_s / (wm / max(wn, 1) * 1e-3) if wm else None,
+                                       "records_bytes": eng.memory_footprint()["cand_start"], "build_ms": st["build_ms"],
+                                       "voxels_with_overflow": st["voxels_with_overflow"]}
+            out["dist_weight_shipped"] = shipped
+            eng.set_map(sc.map_xyz, sc.map_label, stamp=49, dist_weight=dist_weight)
+            eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
         if world == 1 and not args.no_extras:
             out.update(cloud_path_extras(eng, sc, n_s, n_b, with_cpu=not args.no_cpu_baseline))
         # the in-process route (the one the reference's single process would use) on the same GPUs, next to the

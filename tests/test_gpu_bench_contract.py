@@ -114,6 +114,10 @@ def test_headline_workload_gates():
     mu = d["map_update"]
     assert mu["wall_ms"] < 2.0 and all(o == 0 for o in mu["outcomes"]), mu
     assert mu["first_measure_after_update_ms"] < 2.0 * mu["same_measure_steady_ms"] + 0.1, mu
+    # the metric the reference ships (dist_weight_z = 5; the demo's 2): 3.7 x the records, about the same kernel time
+    for key in ("z5", "z2"):
+        w = d["dist_weight_shipped"][key]
+        assert 0 < w["vs_unit_weight"] < 1.25 and w["records_bytes"] > 5e8, w
     if "route_a" in d:   # (the adapter demo is built where the reference's headers are; it travels as a file)
         assert d["route_a"]["ms_per_update"] < 0.60, d["route_a"]
     assert d["result_check"]["max_rel_err_vs_cpu"] < 1e-5
