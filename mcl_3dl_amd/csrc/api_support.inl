@@ -118,6 +118,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_sync = value != 0.0;
     return 0;
   }
+  if (key == "strict_rows")
+  {
+    ctx->strict_rows = value != 0.0;
+    return 0;
+  }
   if (key == "dda_overlay")
   {
     ctx->dda_overlay = value != 0.0;
@@ -376,6 +381,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "batch_slice") *value = ctx->batch_slice;
   else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
   else if (key == "dda_overlay") *value = ctx->dda_overlay;
+  else if (key == "strict_rows") *value = ctx->strict_rows;
   else if (key == "dda_overlay_updates") *value = static_cast<double>(ctx->dda_overlay_updates);
   else if (key == "dda_overlay_points") *value = ctx->dda_dirty ? 0.0 : static_cast<double>(ctx->dg.ov_n);
   else if (key == "batch_slices_run") *value = static_cast<double>(ctx->batch_slices_run);

@@ -101,6 +101,7 @@ struct mcl3dl_hip_ctx
   int strict_order = 2;
   int strict_auto_min = 32768;
   int strict_skew = 1;  // 1 = the particle groups' term regions staggered across HBM channels (lik_strict_sum_kernel), 0 = back to back (A/B)
+  int strict_rows = 1;  // 1 = float-order replay with the chunk row-major in LDS and a look-ahead adder, 0 = transposed chunk (A/B)
   int strict_gpw = 0;  // 0 = particle groups per work-group of the float-order adder chosen per launch, 1 / 2 = at most that many (A/B)
   double strict_auto_max_bytes = 0.0;  // > 0: the automatic replay is also skipped when its buffer would exceed this many bytes
   uint64_t strict_auto_skipped = 0;  // launches of the automatic mode that summed in fp64 because the replay buffer did not fit

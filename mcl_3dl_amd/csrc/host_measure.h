@@ -244,22 +244,33 @@ void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, i
   gpw = std::min(gpw, MAX_GPW);
   if (ctx->strict_gpw)
     gpw = std::min(gpw, ctx->strict_gpw);
+  const int skew = ctx->strict_skew ? STRICT_SKEW4 : 0;
+  // strict_rows = 1 (default): the chunk stays row-major in LDS and the adder reads sixteen rows ahead (lik_strict_sum_rows_kernel);
+  // 0 = the transposed form of round 3 (A/B, same bits)
+#define LAUNCH_STRICT(CHUNK, GPW, GRID)                                                                                  \
+  do                                                                                                                     \
+  {                                                                                                                      \
+    if (ctx->strict_rows)                                                                                                \
+      hipLaunchKernelGGL((lik_strict_sum_rows_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, ctx->stream, strict_terms, ns, \
+                         np, n_groups, d_lik, skew);                                                                     \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, ctx->stream, strict_terms, ns, np, \
+                         n_groups, d_lik, skew);                                                                         \
+  } while (0)
   if constexpr (MAX_GPW >= 4)
     if (gpw == 4)
     {
-      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 16384, 4>), dim3((n_groups + 3) / 4), dim3(1024), 0, ctx->stream, strict_terms, ns,
-                         np, n_groups, d_lik, ctx->strict_skew ? STRICT_SKEW4 : 0);
+      LAUNCH_STRICT(16384, 4, (n_groups + 3) / 4);
       return;
     }
   if constexpr (MAX_GPW >= 2)
     if (gpw >= 2)
     {
-      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 32768, 2>), dim3((n_groups + 1) / 2), dim3(1024), 0, ctx->stream, strict_terms, ns,
-                         np, n_groups, d_lik, ctx->strict_skew ? STRICT_SKEW4 : 0);
+      LAUNCH_STRICT(32768, 2, (n_groups + 1) / 2);
       return;
     }
-  hipLaunchKernelGGL((lik_strict_sum_kernel<GG, 65536, 1>), dim3(n_groups), dim3(1024), 0, ctx->stream, strict_terms, ns, np, n_groups,
-                     d_lik, ctx->strict_skew ? STRICT_SKEW4 : 0);
+  LAUNCH_STRICT(65536, 1, n_groups);
+#undef LAUNCH_STRICT
 }
 
 // What launch_measure leaves to launch_pf_tail when the caller asks for it (`want`): the sum over the tiled kernel's per-tile

@@ -1248,6 +1248,128 @@ __global__ __launch_bounds__(1024) void lik_strict_sum_kernel(const float* __res
     out_lik[p] = score;
 }
 
+// The same replay with the chunk kept in LDS as it comes from memory ([group][row][G], round 4): the loaders park their float4s
+// with one ds_write_b128 each, no transposition (the transposed form above needs four scattered ds_write_b32 per float4 — with
+// their bank conflicts the parking of a chunk took as long as the adder needed for it), and the adder lane (group, particle)
+// reads ONE float per row, sixteen rows ahead of the add that consumes them: the chain then waits for the adds alone, not for
+// an LDS round trip every sixteen terms (~11 -> ~6 cycles per term). Group regions sit G floats apart from a multiple of the
+// bank count so that the GPW groups' rows do not collide. Same terms, same order, same float: bit-identical.
+template <int G, int CHUNK, int GPW>
+__global__ __launch_bounds__(1024) void lik_strict_sum_rows_kernel(const float* __restrict__ terms, int n_s, int n_p,
+                                                                   int n_groups, float* __restrict__ out_lik, int skew4)
+{
+  constexpr int Q = G / 4;               // float4s per row
+  constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk and group
+  constexpr int GSTRIDE = ROWS * G + G;  // floats between the groups' regions of one buffer
+  constexpr int LOADERS = 960;
+  constexpr int ELEMS = GPW * ROWS * Q;  // float4s per chunk
+  constexpr int PER = (ELEMS + LOADERS - 1) / LOADERS;
+  constexpr int AHEAD = 16;
+  static_assert(GPW * G <= 64, "one adder wavefront");
+  static_assert(ROWS % AHEAD == 0, "whole batches of rows");
+  __shared__ __attribute__((aligned(16))) float buf[2][GPW * GSTRIDE];
+  const int group0 = blockIdx.x * GPW, t = threadIdx.x;
+  const float4* base = reinterpret_cast<const float4*>(terms);
+  const int n_chunks = (n_s + ROWS - 1) / ROWS;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // rows past n_s and groups past the last one arrive as zeros (x + 0.0f == x): every chunk is parked whole
+  const auto fetch = [&](int c, float4 (&reg)[PER])
+  {
+    const int lt = t - 64;
+    const int first = c * ROWS, n_rows = min(ROWS, n_s - first);
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+    {
+      const int e = lt + LOADERS * j;
+      const int gl = e / (ROWS * Q), rem = e - gl * (ROWS * Q), r = rem / Q;
+      const bool live = c < n_chunks && e < ELEMS && r < n_rows && group0 + gl < n_groups;
+      reg[j] = live ? base[static_cast<size_t>(group0 + gl) * (static_cast<size_t>(n_s) * Q + skew4) + static_cast<size_t>(first) * Q + rem] : z4;
+    }
+  };
+  const auto park = [&](int c, const float4 (&reg)[PER])
+  {
+    const int lt = t - 64;
+    float* dst = buf[c & 1];
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+    {
+      const int e = lt + LOADERS * j;
+      const int gl = e / (ROWS * Q), rem = e - gl * (ROWS * Q);
+      if (e < ELEMS)
+      {
+        float* d = dst + gl * GSTRIDE + rem * 4;  // (16-byte aligned: one ds_write_b128)
+        d[0] = reg[j].x;
+        d[1] = reg[j].y;
+        d[2] = reg[j].z;
+        d[3] = reg[j].w;
+      }
+    }
+  };
+  float4 ra[PER], rb[PER];  // chunks in flight: even ones in ra, odd ones in rb
+  const bool loader = t >= 64;
+  if (loader && n_chunks > 0)
+  {
+    fetch(0, ra);
+    park(0, ra);
+    fetch(1, rb);
+    fetch(2, ra);
+  }
+  __syncthreads();
+  float score = 0.0f;
+  // one trip of the pipeline: the loaders park chunk c + 1 out of `reg` and refill it with chunk c + 3, the adder wavefront
+  // runs chunk c. Called for even c with rb and for odd c with ra, so that each register array is named statically.
+  const auto trip = [&](int c, float4 (&reg)[PER])
+  {
+    if (loader)
+    {
+      if (c + 1 < n_chunks)
+      {
+        park(c + 1, reg);
+        fetch(c + 3, reg);
+      }
+    }
+    else if (t < GPW * G)
+    {
+      const float* cur = buf[c & 1] + (t / G) * GSTRIDE + (t % G);
+      float nx[AHEAD];
+#pragma unroll
+      for (int j = 0; j < AHEAD; ++j)
+        nx[j] = cur[j * G];
+#pragma unroll
+      for (int r = 0; r < ROWS; r += AHEAD)
+      {
+        float now[AHEAD];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j)
+          now[j] = nx[j];
+        if (r + AHEAD < ROWS)
+        {
+#pragma unroll
+          for (int j = 0; j < AHEAD; ++j)
+            nx[j] = cur[(r + AHEAD + j) * G];
+        }
+        // (the scheduler otherwise sinks these reads to just ahead of their own adds, and the chain waits for an LDS round trip
+        // every sixteen terms as before)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j)
+          score += now[j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c < n_chunks; c += 2)
+  {
+    trip(c, rb);
+    if (c + 1 < n_chunks)
+      trip(c + 1, ra);
+  }
+  const int p = (group0 + t / G) * G + (t % G);
+  if (t < GPW * G && group0 + t / G < n_groups && p < n_p)
+    out_lik[p] = score;
+}
+
 // "strict_order": pf::measure's `sum += p.probability_` (pf.h:255-260) as a float, sequentially, by one lane; the result
 // replaces the fp64 tree sum in packed[0] so that pf_apply_kernel divides by exactly the reference's float.
 __global__ __launch_bounds__(256) void pf_strict_sum_kernel(const float* __restrict__ w_new, int n,
