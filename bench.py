@@ -565,17 +565,20 @@ def cloud_path_extras(eng, sc, n_s, n_b, with_cpu):
                                         "draw included)"}}
     pose = np.asarray(sc.true_pose, np.float32)
     eng.scan_begin(raw, None, leaf=leaf, clip_lik=clip_lik, clip_beam=clip_beam)
-    eng.match_split(pose)
+    m, u = eng.match_split(pose)
+    out_m, out_u = np.zeros((max(n_full, 1), 3), np.float32), np.zeros((max(n_full, 1), 3), np.float32)
     calls = []
     with no_gc():
         for _ in range(10):
             t0 = time.perf_counter()
-            m, u = eng.match_split(pose)
+            n_m, n_u = eng.match_split_into(pose, out_m, out_u)
             calls.append((time.perf_counter() - t0) * 1e3)
+    assert n_m == len(m) and n_u == len(u) and np.array_equal(out_m[:n_m], m) and np.array_equal(out_u[:n_u], u)
     res["match_split"] = {"ms": float(np.median(calls)), "ms_max": float(np.max(calls)), "points": int(n_full),
-                          "matched": int(len(m)), "unmatched": int(len(u)),
-                          "what": "mcl3dl_hip_match_split of the down-sampled cloud left on the device (src/mcl_3dl.cpp:761-805): "
-                                  "classification, two compactions, D2H of both clouds"}
+                          "matched": int(n_m), "unmatched": int(n_u),
+                          "what": "mcl3dl_hip_match_split of the down-sampled cloud left on the device (src/mcl_3dl.cpp:761-805) "
+                                  "into the caller's (pageable) arrays: classification, both compactions by one kernel that "
+                                  "writes into page-locked memory, one polled completion"}
     # the two linear-time map structures (cell-sorted exact-NN grid, DDA occupancy + voxel index): device builders
     # (default) next to the sequential host form they replaced
     q1 = np.asarray(sc.true_pose[:3], np.float32).reshape(1, 3)

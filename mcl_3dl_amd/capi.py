@@ -791,6 +791,18 @@ class Engine:
                                                     cap, C.byref(nm), _ptr(u), cap, C.byref(nu)))
         return m[:nm.value].copy(), u[:nu.value].copy()
 
+    def match_split_into(self, pose7, out_matched, out_unmatched, xyz=None, unmatch_dist=0.5, match_dist=0.1):
+        """mcl3dl_hip_match_split into the caller's own float32 (n, 3) arrays (e.g. host_array()s: written in place by the
+        kernel), nothing allocated here; either may be None (count only). Returns (n_matched, n_unmatched)."""
+        pose = _np_f32(pose7)
+        pts = None if xyz is None else _np_f32(xyz, 3)
+        nm, nu = C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.mcl3dl_hip_match_split(
+            self.h, _ptr(pose), _ptr(pts), 0 if pts is None else len(pts), unmatch_dist, match_dist, _ptr(out_matched),
+            0 if out_matched is None else len(out_matched), C.byref(nm), _ptr(out_unmatched),
+            0 if out_unmatched is None else len(out_unmatched), C.byref(nu)))
+        return nm.value, nu.value
+
     # ---- device entry points (torch CUDA tensors or raw device addresses) ---------------------------------------
     def upload_scan(self, scan_lik, scan_beam=None, scan_beam_origin=None, origins=None):
         sl, sb, so, og = self._scans(scan_lik, scan_beam, scan_beam_origin, origins)

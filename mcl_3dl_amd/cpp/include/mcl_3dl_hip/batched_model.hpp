@@ -24,8 +24,13 @@ public:
     if (registered_)
     {
       Engine& e = Engine::shared();
-      e.push_params[kind_] = nullptr;
-      e.filtered[kind_] = Engine::FilteredScan();
+      if (e.owner[kind_] == this)  // (a newer model of the same kind keeps its registration)
+      {
+        e.push_params[kind_] = nullptr;
+        e.filtered[kind_] = Engine::FilteredScan();
+        e.results[kind_] = Engine::Results();
+        e.owner[kind_] = nullptr;
+      }
     }
   }
 
@@ -45,6 +50,7 @@ public:
     const Cloud::Ptr sampled = sampler.sample(clipped, points_now_);
     if (registered_ && sampled)
     {
+      claim();
       Engine& e = Engine::shared();
       Engine::FilteredScan& f = e.filtered[kind_];
       const double t0 = Engine::nowUs();
@@ -74,10 +80,23 @@ protected:
     clip_.far_sq = clip_far * clip_far;
     clip_.z_min = clip_z_min;
     clip_.z_max = clip_z_max;
-    Engine& e = Engine::shared();
-    e.push_params[kind_] = std::move(push);
-    e.results[kind_] = Engine::Results();
+    push_ = std::move(push);
     registered_ = true;
+    claim();
+  }
+
+  // The engine's slots of this kind belong to one model instance at a time. Two live models of one kind (a node never builds
+  // them, a test may) take turns: whoever is used claims the slots and drops the other's cached results.
+  void claim() const
+  {
+    Engine& e = Engine::shared();
+    if (e.owner[kind_] == this)
+      return;
+    e.endBatch();
+    e.owner[kind_] = this;
+    e.push_params[kind_] = push_;
+    e.results[kind_] = Engine::Results();
+    e.filtered[kind_] = Engine::FilteredScan();
   }
 
   // Where `s` sits in the published batch and whether the cached results of this model answer it. The cache is tested
@@ -91,6 +110,8 @@ protected:
   };
   Slot lookup(const State6DOF& s, const void* cloud) const
   {
+    if (Engine::shared().owner[kind_] != this)
+      claim();
     Slot slot;
     const BatchDescriptor& b = currentBatch();
     const char* first = static_cast<const char*>(b.first_state);
@@ -134,6 +155,8 @@ protected:
     Engine& e = Engine::shared();
     e.endBatch();  // (a batch of the other model still in flight writes into its result vectors)
     syncMap(e, kdtree);
+    if (!e.push_params[kind_])
+      throw std::runtime_error("mcl3dl_hip: LiDAR model used before its parameters were configured");
     e.push_params[kind_]();
     const double t0 = Engine::nowUs();
     refreshPoses(e, s, slot);
@@ -206,6 +229,7 @@ protected:
 
   std::size_t points_default_ = 0, points_global_ = 0, points_now_ = 0;
   Clip clip_;
+  std::function<void()> push_;
   Engine::Kind kind_ = Engine::LIKELIHOOD;
   bool registered_ = false;
   mutable Cloud::ConstPtr last_filtered_;

@@ -136,6 +136,10 @@ public:
   FilteredScan filtered[2];
   Results results[2];
   std::function<void()> push_params[2];  // each model's parameters -> the engine (set by the model, cleared when it dies)
+  // which model instance the slots of a kind (push_params, filtered, results) belong to: the one that configured itself last.
+  // Another live instance of the same kind takes them over again on its next use (and the result cache of the kind is
+  // invalidated on every change of owner); a dying instance clears them only while they are still its own.
+  const void* owner[2] = { nullptr, nullptr };
   std::vector<float> origin_scratch;
   // ---- where an update through the per-particle virtuals spends its host time (microseconds, accumulated; read and reset
   // by whoever wants a breakdown: tests/cpp/adapter_demo.cpp prints it next to the total)

@@ -622,10 +622,64 @@ __global__ void match_split_kernel(const float4* __restrict__ pts, long long n, 
     qy = t.y * prm.wy;
     qz = t.z * prm.wz;
   }
+  // The nearest map point within unmatch_output_dist: first the 27 cells around the query's own — a point outside that block
+  // is at least one cell edge away, so a neighbour found nearer than that (with a margin for the float cell assignment) is the
+  // global nearest and the (2 reach + 1)^3 cells of the whole radius (343 for 0.5 m over 0.2 m cells) are not visited; most
+  // points of a scan lie on the map. The minimum — all the classification reads — is the same either way.
   int idx = -1;
-  const float d2 = cell_grid_nearest(g, qx, qy, qz, reach, r2_unmatch, idx);
+  float d2 = r2_unmatch;
+  bool done = false;
+  if (reach > 1)
+  {
+    const float cell = 1.0f / g.inv_cell;
+    const float sure = cell * 0.9999f;
+    d2 = cell_grid_nearest(g, qx, qy, qz, 1, r2_unmatch, idx);
+    done = idx >= 0 && d2 <= sure * sure;
+    if (!done)
+    {
+      idx = -1;
+      d2 = r2_unmatch;
+    }
+  }
+  if (!done)
+    d2 = cell_grid_nearest(g, qx, qy, qz, reach, r2_unmatch, idx);
   out_xyz4[i] = make_float4(t.x, t.y, t.z, v.w);
   flag_unmatch[i] = idx < 0 ? 1u : 0u;
   flag_match[i] = (idx >= 0 && static_cast<double>(d2) < match_dist_sq) ? 1u : 0u;
+}
+
+// Both order-preserving compactions of match_split in one launch, written as xyz triples where the caller reads them
+// (page-locked host memory): pos_a / pos_b = exclusive scans of the two flag arrays (n + 1 entries), out_* may be null
+// (counts only), writes beyond cap_* are dropped (the host reports the overflow from the counts).
+__global__ void match_emit_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ pos_a,
+                                  const uint32_t* __restrict__ pos_b, long long n, unsigned long long cap_a,
+                                  unsigned long long cap_b, float* __restrict__ out_a, float* __restrict__ out_b,
+                                  uint32_t* __restrict__ counts2)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i == 0)
+  {
+    counts2[0] = pos_a[n];
+    counts2[1] = pos_b[n];
+  }
+  if (i >= n)
+    return;
+  const uint32_t a = pos_a[i], b = pos_b[i];
+  const bool in_a = pos_a[i + 1] != a && out_a && a < cap_a, in_b = pos_b[i + 1] != b && out_b && b < cap_b;
+  if (!in_a && !in_b)
+    return;
+  const float4 p = pts[i];
+  if (in_a)
+  {
+    out_a[3ull * a + 0] = p.x;
+    out_a[3ull * a + 1] = p.y;
+    out_a[3ull * a + 2] = p.z;
+  }
+  if (in_b)
+  {
+    out_b[3ull * b + 0] = p.x;
+    out_b[3ull * b + 1] = p.y;
+    out_b[3ull * b + 2] = p.z;
+  }
 }
 }  // namespace mcl3dl

@@ -263,6 +263,28 @@ int main(int argc, char** argv)
   const int status = n_b ? static_cast<int>(beam->getBeamStatus(
                                kdtree_, s0.pos_, s0.pos_ + mcl_3dl::Vec3(3.0, 0.5, -0.2), cr)) : -1;
 
+  // two live models of one kind (a node never builds them): whoever is used owns the engine's slots of the kind,
+  // and a dying model clears them only while they are its own
+  {
+    mcl_3dl::LidarMeasurementModelBase::Ptr second(new mcl_3dl::LidarMeasurementModelLikelihood(lik_params));
+    second->setGlobalLocalizationStatus(n_p, n_p);
+    const auto r2 = second->measure(kdtree_, pc_locals["likelihood"], origins, s0);
+    const auto r1 = lidar_measurements_["likelihood"]->measure(kdtree_, pc_locals["likelihood"], origins, s0);
+    second.reset();  // the first model used last: it owns the slots, the dying one must not clear them
+    const auto r3 = lidar_measurements_["likelihood"]->measure(kdtree_, pc_locals["likelihood"], origins, s0);
+    mcl_3dl::LidarMeasurementModelBase::Ptr third(new mcl_3dl::LidarMeasurementModelLikelihood(lik_params));
+    third->setGlobalLocalizationStatus(n_p, n_p);
+    third.reset();   // registered last, never used again: its death leaves the kind unowned, the first model claims it back
+    const auto r4 = lidar_measurements_["likelihood"]->measure(kdtree_, pc_locals["likelihood"], origins, s0);
+    for (const auto& r : { r1, r2, r3, r4 })
+      if (r.likelihood != single.likelihood || r.quality != single.quality)
+      {
+        fprintf(stderr, "two live likelihood models: %.9g / %.9g instead of %.9g / %.9g\n", r.likelihood, r.quality,
+                single.likelihood, single.quality);
+        return 4;
+      }
+  }
+
   FILE* g = fopen(argv[2], "wb");
   std::vector<float> w(n_p);
   {

@@ -288,6 +288,45 @@ def test_matched_unmatched_split(engine):
     np.testing.assert_array_equal(u2, moved2[cls2 == 2])
 
 
+def test_matched_unmatched_split_variants(engine):
+    """The one-kernel form (both compactions written into page-locked memory, polled completion) against the general form
+    (update_zero_copy = 0: scans, count read-backs, compactions, D2H copies); the caller's own page-locked arrays written in
+    place; counts without clouds; an output array that is too small."""
+    sc = make_scene(n=61, n_p=8, n_s=6000, n_b=0, seed=31, sigma_xyz=(0.3, 0.3, 0.1))
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=7301, dist_weight=DW)
+    engine.set_likelihood_params()
+    rng = np.random.default_rng(3)
+    cloud = np.concatenate([sc.scan_lik, rng.uniform(-3, 3, (2500, 3)).astype(np.float32)], 0)   # some far from every map point
+    pose = np.asarray(sc.true_pose, np.float32)
+    m, u = engine.match_split(pose, cloud, unmatch_dist=0.5, match_dist=0.1)
+    assert len(m) > 100 and len(u) > 100
+    try:
+        engine.set_option("update_zero_copy", 0)
+        m0, u0 = engine.match_split(pose, cloud, unmatch_dist=0.5, match_dist=0.1)
+    finally:
+        engine.set_option("update_zero_copy", 1)
+    np.testing.assert_array_equal(m, m0)
+    np.testing.assert_array_equal(u, u0)
+    hm, hu = engine.host_array((len(cloud), 3)), engine.host_array((len(cloud), 3))
+    try:
+        hm[:] = -7.0
+        n_m, n_u = engine.match_split_into(pose, hm, hu, xyz=cloud)
+        assert (n_m, n_u) == (len(m), len(u))
+        np.testing.assert_array_equal(hm[:n_m], m)
+        np.testing.assert_array_equal(hu[:n_u], u)
+        assert np.all(hm[n_m:] == -7.0)
+    finally:
+        engine.host_free(hm)
+        engine.host_free(hu)
+    assert engine.match_split_into(pose, None, None, xyz=cloud) == (len(m), len(u))
+    small = np.zeros((len(m) - 1, 3), np.float32)
+    with pytest.raises(capi.EngineError, match="output capacity"):
+        engine.match_split_into(pose, small, np.zeros((len(cloud), 3), np.float32), xyz=cloud)
+    # the context is fine afterwards
+    m1, u1 = engine.match_split(pose, cloud, unmatch_dist=0.5, match_dist=0.1)
+    np.testing.assert_array_equal(m1, m)
+
+
 def test_device_built_grids_equal_the_host_built_ones():
     """The cell-sorted exact-NN grid and the DDA occupancy / voxel index are counting sorts of the map: built on the device
     (default) and by the sequential host form (option grid_build_host) they must answer every query identically — radius
