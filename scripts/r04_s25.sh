@@ -1,0 +1,15 @@
+#!/bin/bash
+O=gpurun_out/r04w
+mkdir -p $O
+for w in C2 C3 C1 C4 C5; do
+  S=""; if [ $w = C4 ] || [ $w = C5 ]; then S="--steps 5 --warmup 2"; fi
+  timeout 900 python bench.py --workload $w $S > $O/bench_$w.out 2> $O/bench_$w.err; tail -1 $O/bench_$w.out > $O/bench_$w.json
+done
+python - <<'PY'
+import json
+for w in ("C2","C3","C1","C4","C5"):
+    try:
+        d=json.load(open("gpurun_out/r04w/bench_%s.json"%w)); r=d["roofline"]
+        print(w,"ms %.4f"%d["ms_per_step"],"8d %.4f"%d["update_8d"]["ms_per_update"],"roof",r["bound"],r["frac"],r.get("counters_source"),"jit",(d.get("map_jitter") or {}).get("vs_lattice"),"mu",(d.get("map_update") or {}).get("wall_ms"),"ra",(d.get("route_a") or {}).get("ms_per_update"),"ms",(d.get("match_split") or {}).get("ms"))
+    except Exception as e: print(w,"failed",e)
+PY
