@@ -246,8 +246,9 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
                                             origins, n_o, out_lik, out_match_ratio, out_beam);
     return rc ? g->fail_rank(rc, 0) : 0;
   }
+  const bool device_order = g->ctx[0]->scan_order_device > 0 && n_s + n_b >= static_cast<size_t>(g->ctx[0]->scan_order_device);
   std::string err;
-  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
+  if (!device_order && order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
     return g->fail(-3, "%s", err.c_str());
   if (pose)
     g->n_pose_uploaded = 0;
@@ -260,7 +261,10 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
         size_t lo, hi;
         shard_bounds(n_p, N, r, &lo, &hi);
         const size_t n = hi - lo;
-        TRY(push_scan(ctx, g->scan, false));
+        if (device_order)
+          TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
+        else
+          TRY(push_scan(ctx, g->scan, false));
         if (n == 0)
           return sync_stream(ctx);
         if (pose)
@@ -387,8 +391,12 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
   const bool no_collective = g->n() == 1 && g->direct_single;
   if (!no_collective)
     TRY(group_comms(g));
+  // Large scans are ordered by every device for itself (upload_scan_impl: raw points up, keys / stable radix sort / gather
+  // there — the same order as the host's, bit for bit): N redundant sorts of ~0.05 ms that run side by side, instead of
+  // 0.15 ms of one host core at 16 k points ahead of any GPU work. Small scans are ordered once on the host and pushed.
+  const bool device_order = g->ctx[0]->scan_order_device > 0 && n_s + n_b >= static_cast<size_t>(g->ctx[0]->scan_order_device);
   std::string err;
-  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
+  if (!device_order && order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
     return g->fail(-3, "%s", err.c_str());
   const int N = g->n();
   const size_t n_pack = 2 + 2 * static_cast<size_t>(N);
@@ -405,6 +413,37 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
     if (n)
     {
       float* d_w = resident ? ctx->gs_weight.as<float>() : ctx->weightb.as<float>();
+      // the normalising kernel writes the shard's results straight into page-locked memory (the caller's arrays where they
+      // are page-locked, a staging block otherwise) and the rank learns of its completion from a polled word — instead of up
+      // to five D2H copies and a hipStreamSynchronize per rank
+      const size_t rpart = (fb + 63) & ~static_cast<size_t>(63);
+      char* blk = (ctx->update_zero_copy && ctx->poll_sync && 64 + 4 * rpart <= STAGE_MAX_COPY) ?
+                      static_cast<char*>(stage_alloc(ctx, 64 + 4 * rpart)) : nullptr;
+      if (blk)
+      {
+        PfEmit e{};
+        e.stats4 = reinterpret_cast<float*>(blk);
+        ctx->stage_out.push_back({ &stats[4 * r], e.stats4, sizeof(float) * 4 });
+        float* const user[4] = { weight_inout, out_lik, out_match_ratio, out_beam };
+        float** const slot[4] = { &e.w, &e.lik, &e.ratio, &e.beam };
+        for (int k = 0; k < 4; ++k)
+          if (user[k])
+          {
+            float* u = user[k] + lo;
+            *slot[k] = ctx->is_pinned(u, fb) ? u : reinterpret_cast<float*>(blk + 64 + k * rpart);
+            if (*slot[k] != u)
+              ctx->stage_out.push_back({ u, *slot[k], fb });
+          }
+        HIP_TRY(hipSetDevice(ctx->device));
+        EventPair ep{};
+        TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+        hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n)), dim3(PF_BLOCK), 0, ctx->stream, d_w, ctx->wnew.as<float>(),
+                           static_cast<int>(n), N, ctx->packed.as<double>(), ctx->stats4.as<float>(), e, ctx->lik.as<float>(),
+                           ctx->ratio.as<float>(), ctx->beam.as<float>());
+        TRY(timing_end(ctx, ep));
+        HIP_TRY(hipGetLastError());
+        return sync_stream(ctx, true);
+      }
       TRY(mcl3dl_hip_pf_apply_device(ctx, d_w, n, N, ctx->packed.as<double>(), ctx->stats4.as<float>()));
       if (weight_inout)
         TRY(d2h(ctx, weight_inout + lo, d_w, fb));
@@ -433,7 +472,10 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
         // everything up to the collective; nothing in here waits for another rank
         const auto phase_a = [&]() -> int
         {
-          TRY(push_scan(ctx, g->scan, false));
+          if (device_order)
+            TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
+          else
+            TRY(push_scan(ctx, g->scan, false));
           TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
           if (!resident)
             ctx->n_pose_uploaded = 0;
