@@ -337,7 +337,8 @@ struct mcl3dl_hip_ctx
     va_end(ap);
     err = buf;
     stage_out.clear();  // results of a failed call are not delivered (their destinations may be gone)
-    prog.active = false;
+    // (a progressive batch in flight is NOT abandoned by another call's failure: its output arrays belong to it until
+    // mcl3dl_hip_measure_batch_end by contract, and _wait must never report results it has not delivered)
     return code;
   }
 };
@@ -642,7 +643,14 @@ int progress_wait(mcl3dl_hip_ctx* ctx, size_t particle, size_t* n_ready)
   }
   const size_t k = std::min(particle / pg.slice, pg.n_slices - 1);
   if (k >= pg.delivered)
-    TRY(spin_done_flag(ctx, pg.seq0 + static_cast<unsigned>(k) + 1u));
+  {
+    const int rc = spin_done_flag(ctx, pg.seq0 + static_cast<unsigned>(k) + 1u);
+    if (rc != 0)
+    {
+      pg = mcl3dl_hip_ctx::BatchProgress();  // the stream failed: there is no batch any more (later _wait calls are refused)
+      return rc;
+    }
+  }
   const unsigned now = *ctx->done_flag;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   const size_t arrived = std::min<size_t>(pg.n_slices, static_cast<size_t>(std::max(0, static_cast<int>(now - pg.seq0))));

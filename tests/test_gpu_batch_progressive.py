@@ -119,6 +119,9 @@ def test_a_wrong_index_is_refused_without_abandoning_the_batch(configured, scene
     got = begin(engine, sc, 2048, 2048, 0, 512)
     with pytest.raises(EngineError, match="not part of the batch"):
         engine.measure_batch_wait(2048)
+    # another call that fails its argument check does not abandon the batch either
+    with pytest.raises(EngineError, match="bad arguments"):
+        engine.match_split(sc.true_pose, sc.scan_lik[:10], unmatch_dist=0.0)
     assert engine.measure_batch_wait(2047) == 2048
     engine.measure_batch_end()
     np.testing.assert_array_equal(got[0], ref[0])
