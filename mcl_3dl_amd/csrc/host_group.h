@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enum values only: every RCCL call goes through the dlopen'ed pointers below
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -59,6 +61,10 @@ struct RcclApi
 };
 
 // One worker thread per device; run_all() hands every worker the same closure (argument = rank) and waits for all.
+// Hand-over and completion are SPUN on for a short while before anybody sleeps on a condition variable: updates follow
+// each other within a fraction of a millisecond while a filter runs, and a futex wake-up costs 20 - 50 us per hop — two hops
+// per update, a tenth of a C2 update. A worker that has seen no task for SPIN_US goes to sleep (an idle filter burns nothing);
+// the caller spins while the ranks work (that is its only job) and sleeps only behind a long update.
 class WorkerPool
 {
 public:
@@ -72,7 +78,7 @@ public:
   {
     {
       std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
+      stop_.store(true, std::memory_order_release);
     }
     cv_task_.notify_all();
     for (std::thread& t : threads_)
@@ -89,12 +95,31 @@ public:
         *failed_rank = 0;
       return rc;
     }
-    std::unique_lock<std::mutex> lk(m_);
     task_ = &f;
-    pending_ = static_cast<int>(threads_.size());
-    ++gen_;
-    cv_task_.notify_all();
-    cv_done_.wait(lk, [this] { return pending_ == 0; });
+    pending_.store(static_cast<int>(threads_.size()), std::memory_order_relaxed);
+    gen_.fetch_add(1);  // publishes task_ and pending_ (sequentially consistent: paired with the sleeper's count-then-look)
+    if (sleepers_.load() > 0)
+    {
+      std::lock_guard<std::mutex> lk(m_);  // (a worker between its last look at gen_ and its wait holds m_)
+      cv_task_.notify_all();
+    }
+    // completion: spin, then sleep
+    const auto t0 = std::chrono::steady_clock::now();
+    bool done = false;
+    for (long spin = 0; !(done = pending_.load(std::memory_order_acquire) == 0); ++spin)
+    {
+      __builtin_ia32_pause();
+      if ((spin & 1023) == 1023 &&
+          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0)
+        break;
+    }
+    if (!done)
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      waiter_.store(true);  // (sequentially consistent, like the worker's decrement-then-look: one of the two sees the other)
+      cv_done_.wait(lk, [this] { return pending_.load() == 0; });
+      waiter_.store(false);
+    }
     task_ = nullptr;
     for (size_t r = 0; r < rc_.size(); ++r)
       if (rc_[r] != 0)
@@ -107,26 +132,43 @@ public:
   }
 
 private:
+  static constexpr double SPIN_US = 300.0;
   void loop(int r)
   {
     uint64_t seen = 0;
     for (;;)
     {
-      const std::function<int(int)>* f = nullptr;
+      // the next task: spin for a while, then sleep
+      const auto t0 = std::chrono::steady_clock::now();
+      bool have = false;
+      for (long spin = 0; !stop_.load(std::memory_order_acquire); ++spin)
+      {
+        if (gen_.load(std::memory_order_acquire) != seen)
+        {
+          have = true;
+          break;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 255) == 255 &&
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > SPIN_US)
+          break;
+      }
+      if (!have)
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_task_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_)
-          return;
-        seen = gen_;
-        f = task_;
+        sleepers_.fetch_add(1);
+        cv_task_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
+        sleepers_.fetch_sub(1);
       }
-      const int rc = (*f)(r);
+      if (stop_.load(std::memory_order_acquire))
+        return;
+      seen = gen_.load(std::memory_order_acquire);
+      const std::function<int(int)>* f = task_;
+      rc_[r] = (*f)(r);
+      if (pending_.fetch_sub(1) == 1 && waiter_.load())
       {
         std::lock_guard<std::mutex> lk(m_);
-        rc_[r] = rc;
-        if (--pending_ == 0)
-          cv_done_.notify_one();
+        cv_done_.notify_one();
       }
     }
   }
@@ -134,9 +176,9 @@ private:
   std::mutex m_;
   std::condition_variable cv_task_, cv_done_;
   const std::function<int(int)>* task_ = nullptr;
-  uint64_t gen_ = 0;
-  int pending_ = 0;
-  bool stop_ = false;
+  std::atomic<uint64_t> gen_{ 0 };
+  std::atomic<int> pending_{ 0 }, sleepers_{ 0 };
+  std::atomic<bool> stop_{ false }, waiter_{ false };
   std::vector<int> rc_;
 };
 
