@@ -728,10 +728,18 @@ int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
 
 namespace
 {
+// slice = STAGE_FRONT_ONLY: only the front half of measure_update_staged — inputs taken over and scans ordered by the staging
+// launch(es) — and return 3 (0: not eligible, nothing done). What a rank of a device group runs ahead of its kernels.
+constexpr size_t STAGE_FRONT_ONLY = ~static_cast<size_t>(0);
 int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* extra, float* weight_inout, size_t n_p,
                           const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
                           size_t n_b, const float* origins, size_t n_o, float* out_lik, float* out_match_ratio,
                           float* out_beam, float* st4, bool with_pf = true, size_t slice = 0);
+// where the staging launch left the weights it took over
+inline float* staged_weights(mcl3dl_hip_ctx* ctx)
+{
+  return reinterpret_cast<float*>(ctx->upd_block.as<char>() + 64);
+}
 }  // namespace
 
 int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p, const float* scan_lik_xyz, size_t n_s,
@@ -1043,6 +1051,8 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   ctx->sp_n_samp[1] = n_b;
   if (pose)
     ctx->n_pose_uploaded = n_p;
+  if (slice == STAGE_FRONT_ONLY)
+    return 3;  // the caller (a device group's rank) goes on from here: poses in ctx->pose, weights at staged_weights(ctx)
   if (!with_pf)
   {
     // the two models only: their per-particle results go home through a copy kernel into page-locked memory (or one D2H copy)

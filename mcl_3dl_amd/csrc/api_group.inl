@@ -395,13 +395,16 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
   // there — the same order as the host's, bit for bit): N redundant sorts of ~0.05 ms that run side by side, instead of
   // 0.15 ms of one host core at 16 k points ahead of any GPU work. Small scans are ordered once on the host and pushed.
   const bool device_order = g->ctx[0]->scan_order_device > 0 && n_s + n_b >= static_cast<size_t>(g->ctx[0]->scan_order_device);
-  std::string err;
-  if (!device_order && order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
-    return g->fail(-3, "%s", err.c_str());
+  // (a rank whose staging launch is not eligible and whose scan is small pushes a copy ordered ONCE on the host, by whichever
+  // rank needs it first)
+  std::string host_order_error;
+  std::once_flag host_order_once;
+  bool host_ordered = false;
   const int N = g->n();
   const size_t n_pack = 2 + 2 * static_cast<size_t>(N);
   const bool host_combine = g->collective == 1 && !no_collective;
   std::vector<float> stats(4 * static_cast<size_t>(N), 0.f);
+  std::vector<float*> rank_weights(static_cast<size_t>(N), nullptr);  // where each rank's prior weights are on its device
   if (!resident)
     g->n_pose_uploaded = 0;
 
@@ -412,7 +415,7 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
     TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
     if (n)
     {
-      float* d_w = resident ? ctx->gs_weight.as<float>() : ctx->weightb.as<float>();
+      float* d_w = rank_weights[r];
       // the normalising kernel writes the shard's results straight into page-locked memory (the caller's arrays where they
       // are page-locked, a staging block otherwise) and the rank learns of its completion from a polled word — instead of up
       // to five D2H copies and a hipStreamSynchronize per rank
@@ -472,22 +475,50 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
         // everything up to the collective; nothing in here waits for another rank
         const auto phase_a = [&]() -> int
         {
-          if (device_order)
-            TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
-          else
-            TRY(push_scan(ctx, g->scan, false));
+          HIP_TRY(hipSetDevice(ctx->device));
+          if (resident && n && (ctx->gs_n != n || ctx->n_pose_uploaded != n))
+            return ctx->fail(-5, "this device holds %zu resident particles, its shard has %zu", ctx->gs_n, n);
+          // ONE launch takes the rank's inputs over — the raw scans (every rank orders them for itself, side by side), its
+          // pose / weight / odometry-factor shard — out of page-locked memory (stage_kernels.h); where that form is not
+          // eligible: uploads + the ordering launches, or the scans ordered once on the host and pushed
+          bool staged = false;
+          if (n)
+          {
+            const int st = measure_update_staged(ctx, resident ? nullptr : pose + 7 * lo, extra ? extra + lo : nullptr,
+                                                 resident ? nullptr : weight_inout + lo, n, scan_lik_xyz, n_s, scan_beam_xyz,
+                                                 scan_beam_origin, n_b, origins, n_o, nullptr, nullptr, nullptr, nullptr, true,
+                                                 STAGE_FRONT_ONLY);
+            if (st < 0)
+              return st;
+            staged = st == 3;
+          }
+          if (!staged)
+          {
+            if (device_order)
+              TRY(upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, false));
+            else
+            {
+              std::call_once(host_order_once,
+                             [&]
+                             {
+                               host_ordered = order_scan(host_order_error, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b,
+                                                         origins, n_o, g->scan) == 0;
+                             });
+              if (!host_ordered)
+                return ctx->fail(-3, "%s", host_order_error.c_str());
+              TRY(push_scan(ctx, g->scan, false));
+            }
+          }
           TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
-          if (!resident)
+          if (!resident && !staged)
             ctx->n_pose_uploaded = 0;
           if (n)
           {
-            if (resident && (ctx->gs_n != n || ctx->n_pose_uploaded != n))
-              return ctx->fail(-5, "this device holds %zu resident particles, its shard has %zu", ctx->gs_n, n);
             TRY(ensure(ctx, ctx->lik, fb));
             TRY(ensure(ctx, ctx->ratio, fb));
             TRY(ensure(ctx, ctx->beam, fb));
             TRY(ensure(ctx, ctx->extra, fb));
-            if (!resident)
+            if (!resident && !staged)
             {
               TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
               TRY(ensure(ctx, ctx->weightb, fb));
@@ -495,8 +526,9 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
               ctx->n_pose_uploaded = n;
               TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
             }
-            float* d_w = resident ? ctx->gs_weight.as<float>() : ctx->weightb.as<float>();
-            if (extra)
+            float* d_w = resident ? ctx->gs_weight.as<float>() : (staged ? staged_weights(ctx) : ctx->weightb.as<float>());
+            rank_weights[r] = d_w;
+            if (extra && !staged)
               TRY(h2d(ctx, ctx->extra.p, extra + lo, fb));
             TRY(launch_measure(ctx, ctx->pose.as<float>(), n, ctx->lik.as<float>(), ctx->ratio.as<float>(),
                                ctx->beam.as<float>(), false, nullptr));
