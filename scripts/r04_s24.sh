@@ -1,6 +1,6 @@
 #!/bin/bash
-# final tree of round 4 (commit 99930be8b890): PMC sessions, GPU suite, smoke, every bench line
-export GIT_HEAD=99930be8b890
+# final tree of round 4 (commit e447685ecda5): PMC sessions, GPU suite, smoke, every bench line
+export GIT_HEAD=e447685ecda5
 O=gpurun_out/r04v
 mkdir -p $O
 for t in "C2 --workload C2" "C2j --workload C2 --map-jitter 0.045" "C3 --workload C3" "C5 --workload C5"; do
