@@ -70,7 +70,8 @@ def test_single_gpu_line():
     assert r["hbm_target"]["target"] == 0.40 and r["hbm_target"]["status"].startswith("not applicable")
     assert r["algorithmic_bytes_per_launch"] > 0 and d["update_8d"]["value"] > 1e7
     # the two fixed names of the headline: device-resident (= value, the bench contract) and SURVEY.md 8d's region
-    assert d["value_device_resident"] == d["value"] and 0 < d["value_8d"] == d["update_8d"]["value"] <= d["value"]
+    # (no order between the two at C1: three Python-driven steps of ~20 us on a cold clock against twenty steps timed from C)
+    assert d["value_device_resident"] == d["value"] and 0 < d["value_8d"] == d["update_8d"]["value"]
     # the rows either side of the path stay far ahead of the reference's CPU code (round 2 shipped a line where a Python
     # garbage-collector pause inside the timed loop read as a 16x regression)
     sp = d["scan_preparation"]
