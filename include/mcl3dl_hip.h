@@ -553,9 +553,6 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       grid for a rebuild, as long as the update stays inside the base map's bounds; 0 = one array over
  *                       base + update, rebuilt after every update. Read-only: "dda_overlay_updates" (updates applied that
  *                       way), "dda_overlay_points". Same beam results either way.
- *   "cand_bound_groups" 1 (default) = on a crowded map (more than a twentieth of the occupied voxels keep overflow records) the
- *                       bounded voxel records carry one skip bound per QUARTER of the voxel (x half, y half) and an evaluation
- *                       reads the one of the quarter its query lies in; 0 = one bound per voxel. Same results.
  *   "cand_prune_coop"   1 (default) = the map compiler's pruning pass runs 16 lanes per voxel (candidates in LDS), 0 = one
  *                       thread per voxel; identical records, 4-5x shorter for the few hundred bricks of a map update
  *   "batch_slice"       particles per slice of mcl3dl_hip_measure_batch_begin when its slice_particles argument is 0

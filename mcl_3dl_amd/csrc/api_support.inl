@@ -118,12 +118,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_sync = value != 0.0;
     return 0;
   }
-  if (key == "cand_bound_groups")
-  {
-    ctx->cand_bound_groups = value != 0.0;
-    ctx->cand_dirty = true;
-    return 0;
-  }
   if (key == "strict_rows")
   {
     ctx->strict_rows = value != 0.0;
@@ -388,8 +382,6 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
   else if (key == "dda_overlay") *value = ctx->dda_overlay;
   else if (key == "strict_rows") *value = ctx->strict_rows;
-  else if (key == "cand_bound_groups") *value = ctx->cand_bound_groups;
-  else if (key == "cand_bound_groups_active") *value = (!ctx->cand_dirty && ctx->rg.bound_groups) ? 1.0 : 0.0;
   else if (key == "dda_overlay_updates") *value = static_cast<double>(ctx->dda_overlay_updates);
   else if (key == "dda_overlay_points") *value = ctx->dda_dirty ? 0.0 : static_cast<double>(ctx->dg.ov_n);
   else if (key == "batch_slices_run") *value = static_cast<double>(ctx->batch_slices_run);

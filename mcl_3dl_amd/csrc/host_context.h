@@ -147,7 +147,6 @@ struct mcl3dl_hip_ctx
     float* user[3] = { nullptr, nullptr, nullptr };
     const float* host[3] = { nullptr, nullptr, nullptr };  // page-locked source of each (== user when that is page-locked)
   } prog;
-  int cand_bound_groups = 1;  // option "cand_bound_groups": one skip bound per quarter of a voxel on crowded maps (0 = one per voxel)
   int cand_prune_coop = 1;  // option "cand_prune_coop": 16 lanes per voxel in the map compiler's pruning pass (0 = one thread)
   int batch_slice = 0;  // option "batch_slice": particles per slice of a progressive batch (0 = automatic)
   uint64_t batch_slices_run = 0;

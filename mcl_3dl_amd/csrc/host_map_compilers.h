@@ -402,7 +402,6 @@ void set_word_format(RecGrid& g, int fmt, float r)
   g.count_is_records = fmt == 2 ? 1 : 0;
   g.over_thr = fmt == 2 ? (1u << REC2_COUNT_SHIFT) - 1u : ((4u << REC_EXT_BITS) | REC_EXT_MASK);
   g.bound_step = fmt == 2 ? r / static_cast<float>(REC2_BOUND_MAX) : 0.0f;
-  g.bound_groups = 0;
 }
 
 int word_format(const RecGrid& g)
@@ -417,7 +416,6 @@ struct CompileOutput
   unsigned long long hist3[5] = { 0, 0, 0, 0, 0 };
   uint32_t n_ovf = 0;
   int packed = 0;  // form of the w words written: 0 plain, 1 packed, 2 bounded (map_compiler.h)
-  int bound_groups = 0;  // bounded form with one bound per quarter of the voxel (RecGrid::bound_groups)
   // CSR form (lik_index 1): kept counts per voxel stay in d_count, runs in d_pstart / d_prelim
   TempBuf d_count, d_pstart, d_prelim, d_ovf_data;
 };
@@ -427,7 +425,7 @@ struct CompileOutput
 // nothing (a map update into an index of that form): returns 1 without writing records when that is impossible.
 int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* pts, const int* table, const int* bxyz,
                    uint32_t n_bricks, bool records, float* rec_out, CompileOutput* out, uint32_t cap = 4,
-                   int want_packed = -1, uint32_t ovf_base = 0, int want_groups = -1)
+                   int want_packed = -1, uint32_t ovf_base = 0)
 {
   const size_t n = static_cast<size_t>(cp.n_points);
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
@@ -528,12 +526,6 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
     out->packed = want_packed;
   else
     out->packed = (can_bound && ctx->cand_packed && ctx->cand_bound) ? 2 : (can_pack && ctx->cand_packed) ? 1 : 0;
-  // one bound per quarter of the voxel where it pays: on a crowded map (more than a twentieth of the occupied voxels keep
-  // overflow records — a map of voxel-filter centroids: a quarter) the quarter a query lies in costs the kernel seven
-  // instructions per evaluation and saves a third of the overflow rounds; a lattice-like map (C2: 0.6 %) keeps one bound.
-  // A map update follows the index it compiles into (want_groups).
-  out->bound_groups = out->packed != 2 ? 0 :
-                      want_groups >= 0 ? want_groups : (ctx->cand_bound_groups && out->hist3[1] * 20 > out->hist3[0]) ? 1 : 0;
   TRY(scratch_alloc(ctx, out->d_ovf_data, 64ull * (n_ovf ? n_ovf : 1)));
   {
     // unused candidate slots of an overflow record hold the sentinel, like those of a voxel record
@@ -548,7 +540,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
                      static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
                      static_cast<const uint32_t*>(d_count.p), static_cast<const uint32_t*>(d_ovf.p), rec_out,
                      static_cast<float*>(out->d_ovf_data.p), n_vox, cap, out->packed, cp, bxyz,
-                     static_cast<double>(ctx->match_dist_min), out->bound_groups);
+                     static_cast<double>(ctx->match_dist_min));
   HIP_TRY(hipGetLastError());
   out->n_ovf = n_ovf;
   return 0;
@@ -649,7 +641,6 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     g.rec_bytes32 = bytes32(rec_bytes * static_cast<unsigned long long>(n_vox));
     g.rec_parts = static_cast<int>(cap);
     set_word_format(g, co.packed, ctx->match_dist_min);
-    g.bound_groups = co.bound_groups;
     ctx->cand_parts = cap;
     g.ovf_bytes32 = bytes32(64ull * (n_ovf ? n_ovf : 1));
     g.ti_empty = static_cast<uint32_t>(n_table);
@@ -950,7 +941,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   {
     const int rc = compile_bricks(ctx, cp, static_cast<const float4*>(d_rel.p), static_cast<const int*>(d_sub_table.p),
                                   static_cast<const int*>(d_sub_bxyz.p), n_dirty, true, static_cast<float*>(d_subrec.p), &co,
-                                  cap, word_format(ctx->rg), ctx->cand_n_ovf, ctx->rg.bound_groups);
+                                  cap, word_format(ctx->rg), ctx->cand_n_ovf);
     if (rc == 1)
     {
       // the update does not fit the index's w words (a voxel with more candidates than the count field holds, or more

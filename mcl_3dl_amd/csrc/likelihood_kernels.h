@@ -188,27 +188,6 @@ __device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz
          static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
 }
 
-// rec_locate + the quarter of the voxel the query lies in (x half = bit 0, y half = bit 1): which of the four bounds of a
-// bounded record with RecGrid::bound_groups applies. The voxel index comes out of floor(2 u) >> 1 — 2 u is exact in float, so
-// this is floor(u), the same voxel as rec_locate's — and the half is floor(2 u) & 1.
-__device__ inline bool rec_locate_q(const RecGrid& g, float qx, float qy, float qz, uint32_t& ti, uint32_t& sub, uint32_t& quarter)
-{
-  const int hx = floor_to_int(((qx - g.ox) * g.inv_e) * 2.0f);
-  const int hy = floor_to_int(((qy - g.oy) * g.inv_e) * 2.0f);
-  const int vx = hx >> 1, vy = hy >> 1;
-  const int vz = floor_to_int((qz - g.oz) * g.inv_e);
-  quarter = (static_cast<uint32_t>(hx) & 1u) | ((static_cast<uint32_t>(hy) & 1u) << 1);
-  if (g.mul24_ok)
-    ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
-         __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);
-  else
-    ti = (static_cast<uint32_t>(vz >> 3) * static_cast<uint32_t>(g.nby) + static_cast<uint32_t>(vy >> 3)) *
-             static_cast<uint32_t>(g.nbx) + static_cast<uint32_t>(vx >> 3);
-  sub = ((((static_cast<uint32_t>(vz) & 7u) << 3) | (static_cast<uint32_t>(vy) & 7u)) << 3) | (static_cast<uint32_t>(vx) & 7u);
-  return static_cast<unsigned>(vx) < static_cast<unsigned>(g.nvx) && static_cast<unsigned>(vy) < static_cast<unsigned>(g.nvy) &&
-         static_cast<unsigned>(vz) < static_cast<unsigned>(g.nvz);
-}
-
 // min d2 over the candidates a voxel's overflow records hold (candidates cap .. count - 1; four per 64-byte record, laid
 // out like the first half of a voxel record: part j = {x, y, z, -})
 // (n_records whole records: their unused slots hold the sentinel, which never wins)
@@ -229,8 +208,8 @@ template <bool STATS>
 __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, float qz, unsigned& n_tested)
 {
   float best = 3.0e38f;
-  uint32_t ti, sub, quarter = 0u;
-  if (!(g.bound_groups ? rec_locate_q(g, qx, qy, qz, ti, sub, quarter) : rec_locate(g, qx, qy, qz, ti, sub)))
+  uint32_t ti, sub;
+  if (!rec_locate(g, qx, qy, qz, ti, sub))
     return best;
   const int b = g.brick_table[ti];
   if (b < 0)
@@ -238,8 +217,7 @@ __device__ inline float nearest_d2_rec(const RecGrid& g, float qx, float qy, flo
   const uint32_t cap = static_cast<uint32_t>(g.rec_parts);
   const float4* r = g.rec + static_cast<size_t>(cap) * ((static_cast<uint32_t>(b) << 9) | sub);
   const float4 r0 = r[0], r1 = r[1];
-  // (the word of the part that carries the bound of the query's quarter; count and reference are the same in all four)
-  const uint32_t w0 = __float_as_uint(g.bound_groups ? r[quarter].w : r0.w);
+  const uint32_t w0 = __float_as_uint(r0.w);
   const uint32_t field = g.packed ? w0 >> g.count_shift : w0;
   const uint32_t n_records = rec_overflow_records(field, cap, g.count_is_records);
   if (!g.count_is_records && field == 0)
@@ -337,12 +315,8 @@ constexpr unsigned long long QUAD_LANE0_MASK = 0x1111111111111111ull;
 // returns to every lane the minimum over the four candidates of ITS record. w[e] = the w word of the part this lane read
 // of record e (part 0's w = count, part 1's w = first overflow record). Every lane of the wavefront must be active (DPP
 // reads 0 from an inactive lane); a lane without a record passes any valid index and ignores the answer.
-// sel (0..3, 0 = none): the lane's own record is read with its parts rotated — lane j reads part j ^ sel_e of record e — so
-// that w[j], the word the lane sees of its OWN record, is that of part j ^ sel. Records whose parts carry different words
-// (RecGrid::bound_groups) are addressed with sel = j ^ (the part wanted); the four lanes still cover the four candidates of
-// every record, and a load instruction still touches one cache line per record.
 __device__ inline float quad_round(const float4* recs, uint32_t bytes32, uint32_t rec_index, float qx, float qy, float qz,
-                                   int j, uint32_t (&w)[4], uint32_t sel = 0u)
+                                   int j, uint32_t (&w)[4])
 {
   float4 R0, R1, R2, R3;
   if (bytes32)
@@ -352,22 +326,21 @@ __device__ inline float quad_round(const float4* recs, uint32_t bytes32, uint32_
     // `bytes32` (the record index of a lane without a voxel is arbitrary) reads zeros instead of faulting.
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(recs), 0, static_cast<int>(bytes32), 0x00020000);
-    // (bits 4-5 of `mine` are sel, so the xor with the lane's part offset is the rotation — and a plain add when sel = 0)
-    const uint32_t mine = (rec_index << 6) | (sel << 4), part = static_cast<uint32_t>(j) << 4;
-    R0 = buffer_load_f4(rs, quad_u<QUAD_BCAST0>(mine) ^ part);
-    R1 = buffer_load_f4(rs, quad_u<QUAD_BCAST1>(mine) ^ part);
-    R2 = buffer_load_f4(rs, quad_u<QUAD_BCAST2>(mine) ^ part);
-    R3 = buffer_load_f4(rs, quad_u<QUAD_BCAST3>(mine) ^ part);
+    const uint32_t mine = rec_index << 6, part = static_cast<uint32_t>(j) << 4;
+    R0 = buffer_load_f4(rs, quad_u<QUAD_BCAST0>(mine) + part);
+    R1 = buffer_load_f4(rs, quad_u<QUAD_BCAST1>(mine) + part);
+    R2 = buffer_load_f4(rs, quad_u<QUAD_BCAST2>(mine) + part);
+    R3 = buffer_load_f4(rs, quad_u<QUAD_BCAST3>(mine) + part);
   }
   else
   {
-    const uint32_t mine = (rec_index << 2) | sel, part = static_cast<uint32_t>(j);
-    R0 = recs[static_cast<size_t>(quad_u<QUAD_BCAST0>(mine) ^ part)];
-    R1 = recs[static_cast<size_t>(quad_u<QUAD_BCAST1>(mine) ^ part)];
-    R2 = recs[static_cast<size_t>(quad_u<QUAD_BCAST2>(mine) ^ part)];
-    R3 = recs[static_cast<size_t>(quad_u<QUAD_BCAST3>(mine) ^ part)];
+    const float4* part = recs + j;
+    R0 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST0>(rec_index))];
+    R1 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST1>(rec_index))];
+    R2 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST2>(rec_index))];
+    R3 = part[4 * static_cast<size_t>(quad_u<QUAD_BCAST3>(rec_index))];
   }
-  // candidate j ^ sel_e of evaluation e against the query of lane e
+  // candidate j of evaluation e against the query of lane e
   const float d0 = d2_simple(quad_f<QUAD_BCAST0>(qx), quad_f<QUAD_BCAST0>(qy), quad_f<QUAD_BCAST0>(qz), R0.x, R0.y, R0.z);
   const float d1 = d2_simple(quad_f<QUAD_BCAST1>(qx), quad_f<QUAD_BCAST1>(qy), quad_f<QUAD_BCAST1>(qz), R1.x, R1.y, R1.z);
   const float d2 = d2_simple(quad_f<QUAD_BCAST2>(qx), quad_f<QUAD_BCAST2>(qy), quad_f<QUAD_BCAST2>(qz), R2.x, R2.y, R2.z);
@@ -453,8 +426,7 @@ __device__ inline uint32_t own_word(const uint32_t (&w)[4], int j)
 // vrec = the lane's own record index (0 for a lane without one: it reads record 0 and ignores the answer); returns
 // min d2 over ALL candidates of the lane's voxel: the inline four, then — while any lane of the wavefront still has
 // candidates left — one overflow record per round, fetched and reduced the same cooperative way.
-__device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, float qz, uint32_t vrec, bool valid, int lane,
-                                        uint32_t sel = 0u)
+__device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, float qz, uint32_t vrec, bool valid, int lane)
 {
   const int j = lane & 3;
   uint32_t w[4];
@@ -462,7 +434,7 @@ __device__ inline float rec_min_d2_quad(const RecGrid& g, float qx, float qy, fl
   // inline candidates in the other half of the same 128-byte line
   const bool wide = g.rec_parts == 8;
   float best = wide ? quad_round_wide(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w) :
-                      quad_round(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w, sel);
+                      quad_round(g.rec, g.rec_bytes32, vrec, qx, qy, qz, j, w);
   const uint32_t cap = wide ? 8u : 4u;
   if (g.packed)
   {
@@ -533,9 +505,8 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
   const Vec3f tp = vadd(qrot_trim(rot, Vec3f{ v.x, v.y, v.z }), pos);
   // rescale by dist_weight; without one the weights are 1.0f and x * 1.0f == x bit for bit: no select needed
   const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
-  uint32_t ti, sub, quarter = 0u;
-  const bool inside = (rg.bound_groups ? rec_locate_q(rg, qx, qy, qz, ti, sub, quarter) : rec_locate(rg, qx, qy, qz, ti, sub)) &&
-                      have_point;
+  uint32_t ti, sub;
+  const bool inside = rec_locate(rg, qx, qy, qz, ti, sub) && have_point;
   // a lane without a voxel reads the table's extra last entry, which is always -1: `valid` is then ONE compare, and its
   // ballot comes straight from that compare
   const int b = rg.brick_table[inside ? ti : rg.ti_empty];
@@ -546,8 +517,7 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
     // with buffer loads (array below 4 GB) the record index of an invalid lane may be anything: no select
     const uint32_t rec = (static_cast<uint32_t>(b) << 9) | sub;
     const uint32_t vrec = rg.rec_bytes32 ? rec : (valid ? rec : 0u);
-    const float d2 = rec_min_d2_quad(rg, qx, qy, qz, vrec, valid, lane,
-                                     rg.bound_groups ? ((static_cast<uint32_t>(lane) & 3u) ^ quarter) : 0u);
+    const float d2 = rec_min_d2_quad(rg, qx, qy, qz, vrec, valid, lane);
     if (valid && d2 < prm.r2)
     {
       const float s = sqrt_in_radius(d2);
@@ -782,9 +752,8 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
 {
   const Vec3f tp = vadd(qrot_trim(rot, Vec3f{ v.x, v.y, v.z }), pos);
   const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
-  uint32_t ti, sub, quarter = 0u;
-  const bool inside = (rg.bound_groups ? rec_locate_q(rg, qx, qy, qz, ti, sub, quarter) : rec_locate(rg, qx, qy, qz, ti, sub)) &&
-                      have_point;
+  uint32_t ti, sub;
+  const bool inside = rec_locate(rg, qx, qy, qz, ti, sub) && have_point;
   const int b = rg.brick_table[inside ? ti : rg.ti_empty];
   const bool valid = b >= 0;
   float dist = -1.0f;
@@ -796,9 +765,7 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
     const uint32_t rec = (static_cast<uint32_t>(b) << 9) | sub;
     const uint32_t vrec = rg.rec_bytes32 ? rec : (valid ? rec : 0u);
     uint32_t w[4];
-    // (records with one bound per quarter of the voxel: the lane reads the part of its own record that carries its quarter's)
-    best = quad_round(rg.rec, rg.rec_bytes32, vrec, qx, qy, qz, lane & 3, w,
-                      rg.bound_groups ? ((static_cast<uint32_t>(lane) & 3u) ^ quarter) : 0u);
+    best = quad_round(rg.rec, rg.rec_bytes32, vrec, qx, qy, qz, lane & 3, w);
     mine = own_word(w, lane & 3);
     over = valid && mine > rg.over_thr;
     // bounded records (RecGrid::bound_step): no overflow candidate is nearer than the voxel's skip bound to ANY query inside

@@ -87,32 +87,6 @@ __device__ inline void box_dist2(const CompileParams& c, const float4 p, int vx,
   }
 }
 
-// squared min distance from point p to quarter t of the grown voxel box (x half = bit 0, y half = bit 1, whole z; grown by
-// c.grow like the voxel itself: a query the kernel's float arithmetic puts into quarter t lies inside this box)
-__device__ inline double quarter_dist2(const CompileParams& c, const float4 p, int vx, int vy, int vz, int t)
-{
-  const double pc[3] = { static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z) };
-  const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
-  const int v[3] = { vx, vy, vz };
-  const int half[3] = { t & 1, (t >> 1) & 1, -1 };
-  double d2 = 0.0;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-  {
-    double lo = o[a] + v[a] * c.e, hi = o[a] + (v[a] + 1) * c.e;
-    if (half[a] == 0)
-      hi = o[a] + (v[a] + 0.5) * c.e;
-    else if (half[a] == 1)
-      lo = o[a] + (v[a] + 0.5) * c.e;
-    lo -= c.grow;
-    hi += c.grow;
-    const double below = lo - pc[a], above = pc[a] - hi;
-    const double out = below > 0 ? below : (above > 0 ? above : 0.0);
-    d2 += out * out;
-  }
-  return d2;
-}
-
 // decode thread -> (point, voxel offset); returns false if outside the grid
 __device__ inline bool visit(const CompileParams& c, const float4* __restrict__ pts, long long t, int& pi, int& vx,
                              int& vy, int& vz)
@@ -741,11 +715,6 @@ struct RecGrid
   // above the float rounding of this product and of the kernel's d2 (2e-7), so (bound * bound_step)^2 stays below the d2 the
   // kernel would compute for every overflow candidate at every query inside the voxel: skipping is exact.
   float bound_step;
-  // bounded form, crowded maps: the four parts of a record carry FOUR bounds — part t's word holds the bound of the quarter of
-  // the voxel (x half = bit 0, y half = bit 1 of t; whole z) a query lies in — and a lane picks the part it sees of its own
-  // record by its query's quarter (likelihood_kernels.h: rec_locate_q + the xor in quad_round). A quarter is closer to fewer
-  // overflow candidates than the whole voxel: its bound is larger and more evaluations skip their overflow records.
-  int bound_groups;
 };
 
 __host__ __device__ inline uint32_t rec_ext_mask(const RecGrid& g)
@@ -809,14 +778,13 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
                                  const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ kept_count,
                                  const uint32_t* __restrict__ ovf_start, float* __restrict__ rec,
                                  float* __restrict__ ovf, long long n_vox, uint32_t cap, int fmt, CompileParams cp,
-                                 const int* __restrict__ brick_xyz, double r, int bound_groups)
+                                 const int* __restrict__ brick_xyz, double r)
 {
   const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vox)
     return;
   const uint32_t c = kept_count[v], src = pstart[v];
   uint32_t packed_w = (c << REC_EXT_BITS) | (c > cap ? ovf_start[v] : 0u);
-  uint32_t quarter_w[4] = { 0u, 0u, 0u, 0u };  // bound_groups: the level bits of parts 0..3
   if (fmt == 2)
   {
     uint32_t level = 0;
@@ -834,41 +802,12 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
         box_dist2(cp, pts[prelim[src + k] & 0x7fffffffu], vx, vy, vz, dmin2, dmax2);
         nearest2 = dmin2 < nearest2 ? dmin2 : nearest2;
       }
-      const auto to_level = [&](double d2) -> uint32_t
-      {
-        const double lv = floor(static_cast<double>(REC2_BOUND_MAX) * sqrt(d2) / r * (1.0 - 2.0e-4));
-        return lv <= 0.0 ? 0u : (lv >= static_cast<double>(REC2_BOUND_MAX) ? REC2_BOUND_MAX : static_cast<uint32_t>(lv));
-      };
-      level = to_level(nearest2);
-      if (bound_groups)
-        for (int t = 0; t < 4; ++t)
-        {
-          double q2 = 1.0e300;
-          for (uint32_t k = cap; k < c; ++k)
-          {
-            const double d2 = quarter_dist2(cp, pts[prelim[src + k] & 0x7fffffffu], vx, vy, vz, t);
-            q2 = d2 < q2 ? d2 : q2;
-          }
-          quarter_w[t] = to_level(q2) << REC2_EXT_BITS;
-        }
+      const double lv = floor(static_cast<double>(REC2_BOUND_MAX) * sqrt(nearest2) / r * (1.0 - 2.0e-4));
+      level = lv <= 0.0 ? 0u : (lv >= static_cast<double>(REC2_BOUND_MAX) ? REC2_BOUND_MAX : static_cast<uint32_t>(lv));
     }
     const uint32_t n_rec = c > cap ? (c - cap + 3u) / 4u : 0u;
-    packed_w = (n_rec << REC2_COUNT_SHIFT) | (c > cap ? ovf_start[v] : 0u);
-    if (bound_groups && c > cap)
-    {
-      for (int t = 0; t < 4; ++t)
-        quarter_w[t] |= packed_w;
-    }
-    else
-    {
-      packed_w |= level << REC2_EXT_BITS;
-      for (int t = 0; t < 4; ++t)
-        quarter_w[t] = packed_w;
-    }
+    packed_w = (n_rec << REC2_COUNT_SHIFT) | (level << REC2_EXT_BITS) | (c > cap ? ovf_start[v] : 0u);
   }
-  else
-    for (int t = 0; t < 4; ++t)
-      quarter_w[t] = packed_w;
   // unused candidate slots hold REC_SENTINEL: a point so far away that its d2 (~3e36, finite) never wins a minimum and
   // never passes the radius test, so a query may take the minimum over all inline slots without looking at the count
   float4* dst = reinterpret_cast<float4*>(rec) + static_cast<size_t>(cap) * v;
@@ -886,7 +825,7 @@ __global__ void mc_write_records(const float4* __restrict__ pts, const uint32_t*
     if (fmt != 0)
     {
       if (k < 4)
-        o.w = __uint_as_float(quarter_w[k]);
+        o.w = __uint_as_float(packed_w);
     }
     else
     {
@@ -1017,18 +956,17 @@ __global__ void mc_install_records(const float4* __restrict__ sub_rec, const int
   {
     // the caller made sure ovf_base + (the sub-compile's overflow records) stays below 2^ext_bits: the sum cannot carry into
     // the bound / the count
-    // (every part's word is moved for itself: the parts of a bounded record may carry different bounds)
     const uint32_t w = __float_as_uint(r0.w);
-    const uint32_t add = rec_overflow_records(w >> count_shift, cap, count_is_records) ? ovf_base : 0u;
-    r0.w = __uint_as_float(w + add);
-    r1.w = __uint_as_float(__float_as_uint(r1.w) + add);
+    const uint32_t moved = rec_overflow_records(w >> count_shift, cap, count_is_records) ? w + ovf_base : w;
+    r0.w = __uint_as_float(moved);
+    r1.w = __uint_as_float(moved);
     rec[dst + 0] = r0;
     rec[dst + 1] = r1;
     for (uint32_t k = 2; k < cap; ++k)
     {
       float4 rk = sub_rec[src + k];
       if (k < 4)
-        rk.w = __uint_as_float(__float_as_uint(rk.w) + add);
+        rk.w = __uint_as_float(moved);
       rec[dst + k] = rk;
     }
     return;
@@ -1080,8 +1018,9 @@ __global__ void mc_ovf_move(float4* __restrict__ rec, long long n_vox, uint32_t 
     new_ovf[4 * static_cast<size_t>(dst) + j] = old_ovf[4 * static_cast<size_t>(old_ext) + j];
   if (packed)
   {
-    for (uint32_t k = 0; k < 4u; ++k)  // count and (each part's own) bound kept
-      r[k].w = __uint_as_float((__float_as_uint(r[k].w) & ~ext_mask) | dst);
+    const float w = __uint_as_float((w0 & ~ext_mask) | dst);  // count (and bound) kept
+    for (uint32_t k = 0; k < 4u; ++k)
+      r[k].w = w;
   }
   else
     r[1].w = __uint_as_float(dst);

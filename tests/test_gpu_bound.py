@@ -31,7 +31,7 @@ def run(engine, sc, map_xyz, dw, n_p, n_s, stamp, **opts):
     finally:
         for k in opts:
             engine.set_option(k, {"cand_bound": 1, "cand_packed": 1, "lik_index": 2, "lik_defer": 1, "lik_coop": 1,
-                                  "cand_prune_coop": 1, "cand_bound_groups": 1}[k])
+                                  "cand_prune_coop": 1}[k])
 
 
 @pytest.mark.parametrize("dw", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
@@ -89,36 +89,3 @@ def test_pruning_with_sixteen_lanes_per_voxel_compiles_the_same_index(engine, wh
         assert a_st[key] == b_st[key], key
     np.testing.assert_array_equal(a_lik, b_lik)
     np.testing.assert_array_equal(a_ratio, b_ratio)
-
-
-@pytest.mark.parametrize("which,dw", [("centroids", (1.0, 1.0, 1.0)), ("centroids", (1.0, 1.0, 5.0)), ("crowded", (1.0, 1.0, 1.0)),
-                                      ("lattice", (1.0, 1.0, 1.0))])
-@pytest.mark.parametrize("variant", [dict(), dict(lik_defer=0), dict(lik_coop=0)])
-def test_one_bound_per_quarter_of_the_voxel(engine, which, dw, variant):
-    """Crowded maps: the four parts of a record carry the bounds of the four quarters of the voxel and a lane reads the part of
-    its own record that carries its query's (parts rotated by an xor in the cooperative fetch). Same minima, so the same bits as
-    one bound per voxel and as no bounds — on every kernel family; a lattice keeps one bound (nothing to gain there)."""
-    if which == "crowded":
-        sc, map_xyz = crowded_scene(seed=8)
-    else:
-        sc = make_scene(n=91, n_p=600, n_s=3000, n_b=0, seed=35, map_jitter=0.045 if which == "centroids" else 0.0)
-        map_xyz = sc.map_xyz
-    for n_p, n_s in ((600, 3000), (48, 700)):
-        a_lik, a_ratio, a_st, bounded = run(engine, sc, map_xyz, dw, n_p, n_s, 8840, **variant)
-        active = int(engine.get_option("cand_bound_groups_active"))
-        # quarters need the bounded words and a crowded map: the raw map of `crowded` holds voxels with more candidates than
-        # those words count, without the queue the index picks 128-byte records, and with the z axis stretched five-fold fewer
-        # than a twentieth of the voxels overflow
-        assert not active or bounded
-        assert not (which == "lattice" and active)
-        if which == "centroids" and dw == (1.0, 1.0, 1.0) and "lik_defer" not in variant:
-            assert active == 1
-        b_lik, b_ratio, b_st, _ = run(engine, sc, map_xyz, dw, n_p, n_s, 8841, cand_bound_groups=0, **variant)
-        assert int(engine.get_option("cand_bound_groups_active")) == 0
-        c_lik, c_ratio, _, _ = run(engine, sc, map_xyz, dw, n_p, n_s, 8842, cand_bound=0, **variant)
-        for key in ("candidates", "voxels_with_overflow", "overflow_records"):
-            assert a_st[key] == b_st[key], key
-        np.testing.assert_array_equal(a_lik, b_lik)
-        np.testing.assert_array_equal(a_ratio, b_ratio)
-        np.testing.assert_array_equal(a_lik, c_lik)
-        np.testing.assert_array_equal(a_ratio, c_ratio)
