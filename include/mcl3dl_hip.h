@@ -545,9 +545,10 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       ordering as separate copies and launches (the path larger scans always take; same results)
  *   "update_zero_copy"  1 (default) = that launch reads the arrays in page-locked host memory and the update's last
  *                       kernel writes the results there; 0 = one H2D copy in front, one D2H copy behind
- *   "poll_sync"         1 (default) = a zero-copy host-buffer update learns of its completion from a word in page-locked
- *                       memory that a one-thread kernel behind it writes (polled by the caller's thread), 0 =
- *                       hipStreamSynchronize (6 us slower on MI355X / ROCm 7)
+ *   "poll_sync"         how a call learns that its work on the context's stream is through: 2 (default) = always from a word
+ *                       in page-locked memory that a one-thread kernel behind the work writes (polled by the caller's
+ *                       thread; 6 us less than hipStreamSynchronize per synchronisation on MI355X / ROCm 7), 1 = only the
+ *                       zero-copy host-buffer update and its relatives, 0 = hipStreamSynchronize everywhere
  *   "dda_overlay"       1 (default) = the points of a map update are an overlay of the DDA grid (sorted by voxel, looked up
  *                       behind a voxel's base points): mcl3dl_hip_map_update replaces the overlay instead of marking the
  *                       grid for a rebuild, as long as the update stays inside the base map's bounds; 0 = one array over

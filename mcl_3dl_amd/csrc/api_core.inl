@@ -920,6 +920,12 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
         return ctx->fail(-3, "beam point %zu names origin %u but only %zu origins were given", i, scan_beam_origin[i], n_o);
   if (!origins)
     n_o = 0;
+  // Whatever has to be (re)built lazily — the index after a map change, the DDA grid, the penalty table — is built NOW: a
+  // build synchronises the stream, recycles the staging memory and (polled) uses up completion sequence numbers, none of which
+  // may happen between the allocations below and the kernels that read and write them.
+  TRY(ensure_structures(ctx, n_s > 0, n_b > 0));
+  if (n_b > 0)
+    TRY(ensure_pow_table(ctx, n_b));
   const size_t fb = sizeof(float) * n_p;
   // ---- the input block: { poses | weights | odometry factor | likelihood xyz | beam xyz | beam origin ids | origins }
   struct Part

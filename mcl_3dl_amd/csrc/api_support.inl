@@ -115,7 +115,9 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   }
   if (key == "poll_sync")
   {
-    ctx->poll_sync = value != 0.0;
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return ctx->fail(-3, "poll_sync must be 0, 1 or 2");
+    ctx->poll_sync = static_cast<int>(value);
     return 0;
   }
   if (key == "strict_rows")

@@ -133,8 +133,10 @@ struct mcl3dl_hip_ctx
   int update_particle = 0;
   // host-buffer updates end by POLLING a word in page-locked memory that a one-thread kernel behind the update's last kernel
   // writes, instead of hipStreamSynchronize: 6.3 against 12.2 us for launch + completion of one kernel on this part
-  // (profiles/r04e_launch_cost.txt). 0 = hipStreamSynchronize.
-  int poll_sync = 1;
+  // (profiles/r04e_launch_cost.txt). 2 (default) = every synchronisation of the context's stream is that word (scan
+  // preparation -5..10 %, the post-update reductions -10 %, a whole filter iteration -8 %: profiles/r04ad_poll_all.txt),
+  // 1 = only the host-buffer update and its relatives, 0 = hipStreamSynchronize everywhere.
+  int poll_sync = 2;
   volatile unsigned* done_flag = nullptr;
   unsigned done_seq = 0;
   // a measure_batch delivered in particle slices (mcl3dl_hip_measure_batch_begin / _wait / _end): slice k is in the host
@@ -677,7 +679,10 @@ int sync_stream(mcl3dl_hip_ctx* ctx, bool polled = false)
     TRY(progress_wait(ctx, ctx->prog.n_p - 1, nullptr));
     ctx->prog.active = false;
   }
-  if (polled && ctx->poll_sync)
+  // poll_sync = 2: EVERY synchronisation of the context's stream is the polled word (the copies and kernels in front of the
+  // one-thread kernel are stream-ordered ahead of it, so what they wrote — staged D2H copies included — is there when the
+  // word arrives); 1: only where the caller asked for it (the host-buffer update and its relatives)
+  if ((polled || ctx->poll_sync >= 2) && ctx->poll_sync)
     TRY(wait_done_flag(ctx));
   else
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -755,6 +760,7 @@ int timing_collect(mcl3dl_hip_ctx* ctx)
   for (const EventPair& ep : ctx->pending)
   {
     float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(ep.stop));  // (past already; after a polled wait the runtime has not looked yet)
     HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
     ctx->kernel_ms[ep.kernel] += ms;
     ctx->kernel_launches[ep.kernel] += 1;

@@ -95,6 +95,7 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
   HIP_TRY(hipEventRecord(tm.ev1, ctx->stream));
   TRY(sync_stream(ctx));
   float ms = 0.f;
+  HIP_TRY(hipEventSynchronize(tm.ev1));  // (the stream may have been waited for through the polled word: the event is past, the runtime has to look)
   HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
   ctx->grid_build_ms[0] = ms;
   ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
@@ -250,6 +251,7 @@ int build_dda_grid_device(mcl3dl_hip_ctx* ctx)
   if (err)
     return ctx->fail(-3, "a map point falls outside its own DDA grid");
   float ms = 0.f;
+  HIP_TRY(hipEventSynchronize(tm.ev1));  // (the stream may have been waited for through the polled word: the event is past, the runtime has to look)
   HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
   ctx->grid_build_ms[1] = ms;
   ctx->dda_overlay_ok = ctx->dda_overlay && (n_upd == 0 || overlay);

@@ -621,6 +621,7 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     HIP_TRY(hipEventRecord(ev1, ctx->stream));
     TRY(sync_stream(ctx));
     float ms2 = 0.f;
+    HIP_TRY(hipEventSynchronize(ev1));
     HIP_TRY(hipEventElapsedTime(&ms2, ev0, ev1));
     RecGrid& g = ctx->rg;
     g.brick_table = table;
@@ -674,6 +675,7 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   HIP_TRY(hipEventRecord(ev1, ctx->stream));
   TRY(sync_stream(ctx));
   float ms = 0.f;
+  HIP_TRY(hipEventSynchronize(ev1));
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   CandGrid& g = ctx->cg;
   g.brick_table = table;
@@ -975,6 +977,7 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   HIP_TRY(hipEventRecord(ev1, ctx->stream));
   TRY(sync_stream(ctx));
   float ms = 0.f;
+  HIP_TRY(hipEventSynchronize(ev1));
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   ctx->cand_n_bricks = n_bricks;
   ctx->cand_n_ovf = ovf_base + co.n_ovf;

@@ -88,11 +88,13 @@ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z)
 // table[k] = score_beam after k penalised rays: `score_beam *= beam_likelihood_` repeated k times (beam.cpp:148), float. Built
 // for at least 1024 counts so that alternating scan sizes (the adapter launches the two models separately) do not rebuild it
 // every update.
-int ensure_pow_table(mcl3dl_hip_ctx* ctx)
+// n_b_coming: the beam scan size of an update whose scan is not in the context yet (0: the current one)
+int ensure_pow_table(mcl3dl_hip_ctx* ctx, size_t n_b_coming = 0)
 {
-  if (!(ctx->pow_table_dirty || ctx->n_b > ctx->pow_table_len))
+  const size_t n_b = std::max(ctx->n_b, n_b_coming);
+  if (!(ctx->pow_table_dirty || n_b > ctx->pow_table_len))
     return 0;
-  const size_t len = std::max<size_t>(ctx->n_b, 1024);
+  const size_t len = std::max<size_t>(n_b, 1024);
   std::vector<float> table(len + 1);
   table[0] = 1.0f;
   for (size_t k = 1; k <= len; ++k)

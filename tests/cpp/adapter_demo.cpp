@@ -246,13 +246,15 @@ int main(int argc, char** argv)
            "waiting %.1f\n",
            eng.profile.poses_us / reps, eng.profile.pack_us / reps, eng.profile.batch_us / reps,
            static_cast<double>(eng.profile.launches) / reps, eng.profile.wait_us / reps);
-    size_t i = 0;
+    size_t i = 0, n_diff = 0, first = 0;
     for (auto it = pf_->begin(); it != pf_->end(); ++it, ++i)
-      if (it->probability_ != posterior[i])
-      {
-        fprintf(stderr, "repetition changed the posterior of particle %zu\n", i);
-        return 3;
-      }
+      if (it->probability_ != posterior[i] && n_diff++ == 0)
+        first = i;
+    if (n_diff)
+    {
+      fprintf(stderr, "repetition changed the posterior of %zu particle(s), first %zu\n", n_diff, first);
+      return 3;
+    }
   }
 
   // a call outside pf::measure (the debug-marker path, src/mcl_3dl.cpp:471-478): batch of one
