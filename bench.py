@@ -133,7 +133,8 @@ def parse():
     ap.add_argument("--strict-order", type=int, default=-1,
                     help="-1 = the library's default (2: the likelihood terms are replayed in the reference's float order "
                          "from 32 768 scan points up), 0 = fp64 sums always, 1 = reference float summation order for "
-                         "likelihoods AND weights (bit-identical; slower)")
+                         "likelihoods AND weights (bit-identical; slower), 3 = the float recurrence inside the likelihood "
+                         "kernel in the engine's scan order (bit-identical to the reference on the scan in that order)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the all-reduce even with one rank (exercises the RCCL path)")
     ap.add_argument("--also-other-scaling", action="store_true",
@@ -334,9 +335,11 @@ def valu_costs():
     return dict(VALU_COST_FALLBACK), "bench.py VALU_COST_FALLBACK (no micro-benchmark run committed)"
 
 
-def cpu_baseline(sc, dist_weight, n_particles, beam_points):
+def cpu_baseline(sc, dist_weight, n_particles, beam_points, scan_order=None):
     """The reference's own measure() loop on this box's host cores (oracle/_ref when built, the C port otherwise),
-    single thread = the reference's execution model (src/mcl_3dl.cpp:1466), on a bounded sample of the same workload."""
+    single thread = the reference's execution model (src/mcl_3dl.cpp:1466), on a bounded sample of the same workload.
+    scan_order (strict_order = 3): the reference is given the scan in the engine's order (mcl3dl_hip_scan_order), the
+    order the timed kernel summed it in."""
     from oracle import pyoracle
     kind = "ref" if pyoracle.available("ref") else "port"
     o = pyoracle.Oracle(kind)
@@ -347,7 +350,8 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
         # ~12 s of single-thread work at the ~4.4e6 evals/s this path runs at on one core
         n_particles = max(64, int(12.0 * 4.4e6 / max(len(sc.scan_lik), 1)))
     n = min(n_particles, len(sc.poses))
-    lik, q, sec = o.likelihood_measure(sc.poses[:n], sc.scan_lik, threads=1, return_time=True)
+    scan = sc.scan_lik if scan_order is None else np.ascontiguousarray(sc.scan_lik[scan_order])
+    lik, q, sec = o.likelihood_measure(sc.poses[:n], scan, threads=1, return_time=True)
     evals = n * len(sc.scan_lik)
     out = {"value": evals / sec, "unit": "particle·point evals/s", "cores": 1,
            "kind": "reference" if kind == "ref" else "port",
@@ -356,7 +360,7 @@ def cpu_baseline(sc, dist_weight, n_particles, beam_points):
            "note": "nearest-neighbour index behind pcl::KdTreeFLANN is this repo's stand-in (PCL/FLANN not installed)"}
     threads = o.max_threads()
     if threads > 1:
-        _, _, sec_mt = o.likelihood_measure(sc.poses[:n], sc.scan_lik, threads=threads, return_time=True)
+        _, _, sec_mt = o.likelihood_measure(sc.poses[:n], scan, threads=threads, return_time=True)
         out["all_cores"] = {"value": evals / sec_mt, "cores": threads}
     return out, lik, q
 
@@ -1045,7 +1049,10 @@ def main():
                                 "particles sharded x%d, map+scan replicated, 1 all-reduce/update" % world if use_dist else
                                 "one GPU, mcl3dl_hip_update_device (measure + pf::measure in one call, no collective)"),
                 "update_hz": 1e3 / ms_per_step,
-                "accumulate": ("likelihood terms and weights added as floats in the reference's order (bit-identical results)"
+                "accumulate": ("likelihood terms added as floats INSIDE the likelihood kernel, in the engine's scan order "
+                               "(strict_order = 3: bit-identical to the reference on the scan in that order), weights in an fp64 tree"
+                               if strict_mode == 3 else
+                               "likelihood terms and weights added as floats in the reference's order (bit-identical results)"
                                if strict_mode == 1 else
                                "likelihood terms replayed as floats in the reference's order (this scan has >= %d points), "
                                "weights in an fp64 tree" % int(eng.get_option("strict_auto_min")) if strict_lik else
@@ -1226,12 +1233,11 @@ def main():
                            "ranks) at the same sizes")
             out["resample"]["prefix"] = pre
         if world == 1 and not args.no_extras:
-            # the fused device-resident call (measure + pf::measure in one C call) replaying its captured hipGraph, next
-            # to the same call enqueuing kernel by kernel: what launch overhead is worth at this size. Not `value`.
+            # the fused device-resident call (measure + pf::measure in one C call), host wall per call back to back. Not `value`.
+            # (its hipGraph-replay form measured slower for two rounds and was removed in round 5)
             fused = {}
             rewarm()
-            for use_graph in (0, 1):
-                eng.set_option("use_graph", use_graph)
+            for use_graph in (0,):
                 for _ in range(3):
                     d_w.copy_(d_w0)
                     eng.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam if n_b else None)
@@ -1244,7 +1250,6 @@ def main():
                 fused["graph" if use_graph else "eager"] = (time.perf_counter() - t5) / args.steps * 1e3
             # one whole filter iteration with everything resident on the device: measurement update -> expectation + max
             # (the node publishes the pose from it) -> resampling of the 13-float states; noise = identity
-            eng.set_option("use_graph", 0)
             rewarm()
             t7 = time.perf_counter()
             for _ in range(args.steps):
@@ -1257,11 +1262,16 @@ def main():
             torch.cuda.synchronize(dev)
             out["filter_iteration"] = {"ms": (time.perf_counter() - t7) / args.steps * 1e3,
                                        "what": "update + expectationBiased/max + resample, device-resident, one GPU"}
-            out["fused_update"] = {"ms_per_update_graph": fused["graph"], "ms_per_update_eager": fused["eager"],
-                                   "graph": eng.graph_stats(),
-                                   "what": "mcl3dl_hip_update_device, device-resident, hipGraph replay vs plain launches"}
+            out["fused_update"] = {"ms_per_update_eager": fused["eager"],
+                                   "what": "mcl3dl_hip_update_device, device-resident, plain launches"}
         if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_lik, cpu_q = cpu_baseline(sc, dist_weight, args.cpu_particles, n_b)
+            order = None
+            if strict_mode == 3:
+                eng.upload_scan(sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+                order = eng.scan_order(len(sc.scan_lik))
+                out["result_check"]["sum_order"] = ("engine (mcl3dl_hip_scan_order): the CPU reference below was given the scan "
+                                                    "in that order, the order the timed kernel summed it in")
+            cb, cpu_lik, cpu_q = cpu_baseline(sc, dist_weight, args.cpu_particles, n_b, scan_order=order)
             out["cpu_baseline"] = cb
             # parity spot check of the very numbers that were timed
             n = len(cpu_lik)

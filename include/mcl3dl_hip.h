@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCL3DL_HIP_ABI_VERSION 2
+#define MCL3DL_HIP_ABI_VERSION 3
 
 typedef struct mcl3dl_hip_ctx mcl3dl_hip_ctx;
 
@@ -175,6 +175,17 @@ int mcl3dl_hip_dda_trace(mcl3dl_hip_ctx* ctx, const float* begin3, const float* 
 /* Upload (and spatially order) the two filtered scans `pc_locals` of one update (src/mcl_3dl.cpp:377-383). */
 int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
                            const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o);
+/* The order in which the engine holds the likelihood scan it was last given (by mcl3dl_hip_upload_scan, _scan_finish or any
+ * host-buffer call): position k holds the caller's point order[k] — a stable sort by the Morton key of 0.25 m cells, which is
+ * what gives a wavefront neighbouring points. It matters to a caller in one case: with the option "strict_order" = 3 a
+ * particle's likelihood is the reference's float recurrence `score_like += dist * match_weight`
+ * (src/lidar_measurement_model_likelihood.cpp:124-134) over the scan IN THIS ORDER, i.e. bit for bit what
+ * LidarMeasurementModelLikelihood::measure returns for the cloud { scan[order[0]], scan[order[1]], ... } — computed inside
+ * the likelihood kernel, without the N_s x N_p term array and the replay pass that the caller's own order costs
+ * ("strict_order" = 1 / 2). The order of a sampled cloud carries no information (PointCloudUniformSampler draws it,
+ * include/mcl_3dl/point_cloud_random_samplers/point_cloud_uniform_sampler.h:56-74), but it does select which float
+ * roundings happen: two orders of the same points differ by ~1e-6..1e-5 relative, like any two float summation orders. */
+int mcl3dl_hip_scan_order(mcl3dl_hip_ctx* ctx, uint32_t* order /*n_s*/, size_t n_s /* must equal the installed scan's size */);
 /* measure_batch on device-resident poses against the uploaded scans; outputs are device arrays (may be NULL). */
 int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose /*n_p*7*/, size_t n_p, float* d_lik,
                               float* d_match_ratio, float* d_beam);
@@ -264,18 +275,11 @@ int mcl3dl_hip_resample_apply_slice_device(mcl3dl_hip_ctx* ctx, const float* d_s
 /* One device-resident update in one call (single GPU): measure_device + pf_partial_device + pf_apply_device, i.e. the
  * statement pf_->measure(measure_func) of src/mcl_3dl.cpp:398-426 on device arrays. d_extra, d_lik, d_match_ratio,
  * d_beam may be NULL (no odometry factor / results kept internally); d_stats4 as in pf_apply_device.
- * Small updates are launch-bound, so the enqueued sequence is captured into a hipGraph the second time the same
- * With option "use_graph" = 1 the enqueued sequence is captured into a hipGraph the second time the same argument set
- * arrives and replayed from then on. Anything that changes what would be enqueued (parameters, options, map, stream,
- * scan sizes, a reallocated buffer, other pointers) starts over; a new scan of the same size does not. Results are
- * identical to the three separate calls. The option is OFF by default: on ROCm 7.2 / MI355X replaying the 6-10 node
- * graph measured slower than launching the kernels directly (C1: 26.5 vs 23.2 us per update, C3: 0.517 vs 0.482 ms,
- * DESIGN.md section 6). */
+ * Results are identical to the three separate calls. (Until ABI 2 an option "use_graph" replayed the sequence from a
+ * captured hipGraph; on ROCm 7.2 / MI355X a replay cost a fixed 10-16 us against 3.3-3.8 us per plain launch and measured
+ * slower at every size, so the option and its two introspection calls are gone in ABI 3.) */
 int mcl3dl_hip_update_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight_inout,
                              const float* d_extra, float* d_lik, float* d_match_ratio, float* d_beam, float* d_stats4);
-int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* replays);
-/* Why the last capture attempt fell back to kernel-by-kernel launches ("" if none did). */
-const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx);
 
 /* ---- "next" row: scan preparation on the GPU ------------------------------------------------------
  * Replaces, for one measurement update: the pcl::VoxelGrid down-sampling of the accumulated cloud
@@ -503,7 +507,6 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       fence-free form the gfx950 guide gives); 1 = acq_rel increments at agent scope, the form the
  *                       HIP / LLVM memory model defines (one L2 write-back per arrival: slower). Same results; a one-line
  *                       mitigation should the default ever misbehave on a future part (tests/test_gpu_soak.py runs both)
- *   "use_graph"         1 = mcl3dl_hip_update_device replays a captured hipGraph; 0 (default) = enqueue kernel by kernel
  *   "timing_mask"       bit k set (default: all) = kernel group k is timed while kernel timing is on
  *   "overlap_models"    1 (default) = the beam kernels run on a second stream concurrently with the likelihood kernels
  *                       (forked from / joined into the context's stream with events); 0 = one after the other
@@ -522,7 +525,15 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       launch whose buffer would take more than half of the free device memory (or more than
  *                       "strict_auto_max_bytes" when that is set, or whose allocation fails) sums in fp64 instead — the
  *                       update never fails over it; read-only "strict_auto_skipped" counts such launches. Mode 1 fails
- *                       loudly when its buffer cannot be had.
+ *                       loudly when its buffer cannot be had. 3 = the float recurrence runs INSIDE the likelihood kernel,
+ *                       at every scan size, over the scan in the ENGINE's order (mcl3dl_hip_scan_order): bit-identical to
+ *                       the reference's measure() on the scan permuted that way; no term buffer, no replay pass (the
+ *                       work-group of a scan tile hands each particle's running sum on to the next tile's). Weights are
+ *                       summed as in mode 2. Suits callers whose scan order means nothing to them (a sampled cloud).
+ *   "poll_spin_us"      how long a completion wait spins on its page-locked word before it starts napping between looks
+ *                       (default 2000: every update up to a few thousand particles completes inside the spin); the naps
+ *                       grow with the time already waited (1/32 of it, 1 ms at most) and hipStreamQuery is consulted every
+ *                       5 ms, so a long update does not hold a core and a faulted queue comes back as an error
  *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
  *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
  *                       results either way.

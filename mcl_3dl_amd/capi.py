@@ -31,6 +31,7 @@ SIGNATURES = {
     "mcl3dl_hip_set_likelihood_params": (_i, [_p, _f, _f, _f]),
     "mcl3dl_hip_set_beam_params": (_i, [_p, _f, _f, _f, _f, _f, _f, _f, _u32, _f, _u32, _i]),
     "mcl3dl_hip_upload_poses": (_i, [_p, _p, _sz]),
+    "mcl3dl_hip_scan_order": (_i, [_p, _p, _sz]),
     "mcl3dl_hip_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_measure_batch_begin": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _sz]),
     "mcl3dl_hip_measure_batch_wait": (_i, [_p, _sz, _p]),
@@ -57,8 +58,6 @@ SIGNATURES = {
     "mcl3dl_hip_covariance_partial_device": (_i, [_p, _p, _p, _sz, _p, _sz, _p, _p]),
     "mcl3dl_hip_covariance_finish": (_i, [_p, _p]),
     "mcl3dl_hip_update_device": (_i, [_p, _p, _sz, _p, _p, _p, _p, _p, _p]),
-    "mcl3dl_hip_graph_note": (C.c_char_p, [_p]),
-    "mcl3dl_hip_graph_stats": (_i, [_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mcl3dl_hip_resample_begin_device": (_i, [_p, _p, _sz, _sz, C.POINTER(_f)]),
     "mcl3dl_hip_resample_apply_slice_device": (_i, [_p, _p, _p, _sz, _sz, _sz, _p]),
     "mcl3dl_hip_upload_scan": (_i, [_p, _p, _sz, _p, _p, _sz, _p, _sz]),
@@ -809,6 +808,12 @@ class Engine:
         self._check(self.lib.mcl3dl_hip_upload_scan(self.h, _ptr(sl), len(sl), _ptr(sb), _ptr(so), len(sb), _ptr(og),
                                                     len(og)))
 
+    def scan_order(self, n_s):
+        """order[k] = index (in the caller's array) of the point the engine holds at position k of the likelihood scan."""
+        order = np.zeros(n_s, np.uint32)
+        self._check(self.lib.mcl3dl_hip_scan_order(self.h, _ptr(order), n_s))
+        return order
+
     def measure_device(self, d_pose, n_p, d_lik, d_ratio, d_beam):
         self._check(self.lib.mcl3dl_hip_measure_device(self.h, _ptr(d_pose), n_p, _ptr(d_lik), _ptr(d_ratio),
                                                        _ptr(d_beam)))
@@ -817,12 +822,6 @@ class Engine:
         """measure_device + pf_partial_device + pf_apply_device in one call (hipGraph replay from the third call on)."""
         self._check(self.lib.mcl3dl_hip_update_device(self.h, _ptr(d_pose), n_p, _ptr(d_weight), _ptr(d_extra),
                                                       _ptr(d_lik), _ptr(d_ratio), _ptr(d_beam), _ptr(d_stats4)))
-
-    def graph_stats(self):
-        cap, rep = C.c_uint64(0), C.c_uint64(0)
-        self._check(self.lib.mcl3dl_hip_graph_stats(self.h, C.byref(cap), C.byref(rep)))
-        return dict(captures=int(cap.value), replays=int(rep.value),
-                    note=self.lib.mcl3dl_hip_graph_note(self.h).decode())
 
     def pf_partial_device(self, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_packed, rank=0, world=1):
         """d_packed: 2 + 2*world float64 on the device, ready for all_reduce(SUM) (see mcl_3dl_amd/distributed.py)."""

@@ -376,7 +376,7 @@ int mcl3dl_hip_match_split(mcl3dl_hip_ctx* ctx, const float* pose7, const float*
   // caller's own arrays when they come from mcl3dl_hip_host_alloc, a staging block otherwise — and ONE polled completion
   // (round 3: two rounds of scan + count read-back + compaction + unpack kernel + D2H copy, four synchronisations: 0.35 ms
   // for 35 k points; the kernels are ~20 us of it)
-  if (ctx->update_zero_copy && ctx->poll_sync)
+  if (ctx->zero_copy() && ctx->poll_mode())
   {
     const size_t want[2] = { outs[0] ? std::min(caps[0], n) : 0, outs[1] ? std::min(caps[1], n) : 0 };
     const bool own[2] = { want[0] && ctx->is_pinned(outs[0], 12 * want[0]), want[1] && ctx->is_pinned(outs[1], 12 * want[1]) };

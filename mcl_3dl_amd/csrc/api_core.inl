@@ -96,10 +96,6 @@ void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
   }
   for (hipEvent_t e : ctx->free_events)
     (void)hipEventDestroy(e);
-  if (ctx->graph_exec)
-    (void)hipGraphExecDestroy(ctx->graph_exec);
-  if (ctx->graph)
-    (void)hipGraphDestroy(ctx->graph);
   for (const mcl3dl_hip_ctx::ScratchBlk& b : ctx->scratch)
     (void)hipFree(b.p);
   for (const mcl3dl_hip_ctx::StageChunk& ch : ctx->stage)
@@ -446,6 +442,23 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
   return upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, true);
 }
 
+int mcl3dl_hip_scan_order(mcl3dl_hip_ctx* ctx, uint32_t* order, size_t n_s)
+{
+  if (!ctx)
+    return -1;
+  if (!ctx->has_scan)
+    return ctx->fail(-5, "no scan installed");
+  if (n_s != ctx->n_s)
+    return ctx->fail(-3, "the likelihood scan holds %zu points, not %zu", ctx->n_s, n_s);
+  if (n_s == 0)
+    return 0;
+  if (!order)
+    return ctx->fail(-3, "null order array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  TRY(d2h(ctx, order, ctx->scan_perm.p, sizeof(uint32_t) * n_s));
+  return sync_stream(ctx);
+}
+
 int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_match_ratio,
                               float* d_beam)
 {
@@ -580,15 +593,6 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   return 0;
 }
 
-void drop_graph(mcl3dl_hip_ctx* ctx)
-{
-  if (ctx->graph_exec)
-    (void)hipGraphExecDestroy(ctx->graph_exec);
-  if (ctx->graph)
-    (void)hipGraphDestroy(ctx->graph);
-  ctx->graph_exec = nullptr;
-  ctx->graph = nullptr;
-}
 }  // namespace
 
 int mcl3dl_hip_update_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight_inout,
@@ -620,91 +624,11 @@ int mcl3dl_hip_update_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_
     d_beam = ctx->beam.as<float>();
   }
   TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
-  mcl3dl_hip_ctx::UpdateKey key{};
-  key.p[0] = d_pose;
-  key.p[1] = d_weight_inout;
-  key.p[2] = d_extra;
-  key.p[3] = d_lik;
-  key.p[4] = d_match_ratio;
-  key.p[5] = d_beam;
-  key.p[6] = d_stats4;
-  key.p[7] = ctx->stream;
-  key.n_p = n_p;
-  key.generation = ctx->generation;
-  const bool graphs = ctx->use_graph && !ctx->timing;
-  if (graphs && ctx->graph_exec && ctx->graph_key == key)
-  {
-    HIP_TRY(hipGraphLaunch(ctx->graph_exec, ctx->stream));
-    ++ctx->graph_replays;
-    return 0;
-  }
-  // First sighting of these arguments: run eagerly (this is also what builds the map structures and sizes every work
-  // buffer). Second sighting: nothing is left to build or allocate, so the same calls can be captured.
-  // (the structure checks mirror ensure_structures / launch_measure: whatever this update needs must already exist)
-  const bool need_lik = ctx->n_s > 0, need_dda = ctx->n_b > 0;
-  const bool built = ctx->has_map && !(need_lik && ctx->lik_index == 0 && ctx->lik_dirty) &&
-                     !(need_lik && ctx->lik_index >= 1 && ctx->cand_dirty) &&
-                     !(need_dda && (ctx->dda_dirty || ctx->pow_table_dirty));
-  const bool capture = graphs && built && ctx->have_seen && ctx->seen_key == key &&
-                       !(ctx->have_failed && ctx->failed_key == key);
-  if (!capture)
-  {
-    TRY(enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4));
-    // enqueue_update may itself have moved the generation on (first-use allocations): remember the state it left
-    key.generation = ctx->generation;
-    ctx->seen_key = key;
-    ctx->have_seen = true;
-    return 0;
-  }
-  drop_graph(ctx);
-  HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  const int rc = enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
-  hipGraph_t g = nullptr;
-  const hipError_t e_end = hipStreamEndCapture(ctx->stream, &g);
-  bool ok = rc == 0 && e_end == hipSuccess && g != nullptr && ctx->generation == key.generation;
-  if (ok)
-  {
-    ctx->graph = g;
-    ok = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
-  }
-  else if (g)
-    (void)hipGraphDestroy(g);
-  if (!ok)
-  {
-    // not capturable in this state (e.g. a buffer had to grow): forget it and run the plain sequence
-    const hipError_t e_last = hipGetLastError();
-    char why[256];
-    snprintf(why, sizeof(why), "update graph not captured: rc=%d end=%s last=%s graph=%p generation %llu -> %llu", rc,
-             hipGetErrorString(e_end), hipGetErrorString(e_last), static_cast<void*>(g),
-             static_cast<unsigned long long>(key.generation), static_cast<unsigned long long>(ctx->generation));
-    ctx->graph_note = why;
-    drop_graph(ctx);
-    ctx->failed_key = key;
-    ctx->have_failed = true;
-    return enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
-  }
-  ctx->graph_key = key;
-  ++ctx->graph_captures;
-  HIP_TRY(hipGraphLaunch(ctx->graph_exec, ctx->stream));
-  ++ctx->graph_replays;
-  return 0;
+  // (round 5: the captured-hipGraph form of this call is gone — replaying the 3-4 kernel update cost a fixed 10-16 us on
+  // ROCm 7.2 against 3.3-3.8 us per plain launch and measured slower at every size for two rounds: DESIGN.md section 3.3)
+  return enqueue_update(ctx, d_pose, n_p, d_weight_inout, d_extra, d_lik, d_match_ratio, d_beam, d_stats4);
 }
 
-const char* mcl3dl_hip_graph_note(const mcl3dl_hip_ctx* ctx)
-{
-  return ctx ? ctx->graph_note.c_str() : "";
-}
-
-int mcl3dl_hip_graph_stats(mcl3dl_hip_ctx* ctx, uint64_t* captures, uint64_t* replays)
-{
-  if (!ctx)
-    return -1;
-  if (captures)
-    *captures = ctx->graph_captures;
-  if (replays)
-    *replays = ctx->graph_replays;
-  return 0;
-}
 
 int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
 {
@@ -713,7 +637,7 @@ int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
   if (!pose || n_p == 0 || n_p > 0x7fffffffu)
     return ctx->fail(-3, "bad pose array");
   HIP_TRY(hipSetDevice(ctx->device));
-  ctx->n_pose_uploaded = 0;
+  ctx->poses_set(0);
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
   bool staged = false;
   TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p, &staged));
@@ -722,7 +646,7 @@ int mcl3dl_hip_upload_poses(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p)
   // uploads — is waited for here
   if (!staged || ctx->stage_pending > (8u << 20))
     TRY(sync_stream(ctx));
-  ctx->n_pose_uploaded = n_p;
+  ctx->poses_set(n_p);
   return 0;
 }
 
@@ -768,10 +692,10 @@ int mcl3dl_hip_measure_batch(mcl3dl_hip_ctx* ctx, const float* pose, size_t n_p,
   TRY(ensure(ctx, ctx->beam, sizeof(float) * n_p));
   if (pose)
   {
-    ctx->n_pose_uploaded = 0;
+    ctx->poses_set(0);
     TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n_p));
     TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
-    ctx->n_pose_uploaded = n_p;
+    ctx->poses_set(n_p);
   }
   const bool lik_wanted = out_lik || out_match_ratio;
   TRY(launch_measure(ctx, ctx->pose.as<float>(), n_p, lik_wanted ? ctx->lik.as<float>() : nullptr,
@@ -797,8 +721,9 @@ int mcl3dl_hip_measure_batch_begin(mcl3dl_hip_ctx* ctx, const float* pose, size_
     return -1;
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(progress_end(ctx));
+  // prog.n_p stays 0 until the batch has been accepted: after a failed _begin, _wait refuses every index (-3) instead of
+  // reporting n_p results nobody delivered
   ctx->prog = mcl3dl_hip_ctx::BatchProgress();
-  ctx->prog.n_p = n_p;
   if (n_p == 0)
     return 0;
   if (!pose && ctx->n_pose_uploaded != n_p)
@@ -814,7 +739,13 @@ int mcl3dl_hip_measure_batch_begin(mcl3dl_hip_ctx* ctx, const float* pose, size_
                                              scan_beam_origin, n_b, origins, n_o, out_lik, out_match_ratio, out_beam, nullptr,
                                              false, slice);
     if (staged < 0)
+    {
+      // (slices already enqueued write page-locked staging memory or the caller's page-locked arrays: drained before the
+      // caller gets control back, then forgotten)
+      (void)hipStreamSynchronize(ctx->stream);
+      ctx->prog = mcl3dl_hip_ctx::BatchProgress();
       return staged;
+    }
     if (staged != 0)
     {
       ctx->prog.n_p = n_p;  // (staged == 1: the path delivered everything at once)
@@ -825,7 +756,8 @@ int mcl3dl_hip_measure_batch_begin(mcl3dl_hip_ctx* ctx, const float* pose, size_
   const int rc = mcl3dl_hip_measure_batch(ctx, pose, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o,
                                           out_lik, out_match_ratio, out_beam);
   ctx->prog = mcl3dl_hip_ctx::BatchProgress();
-  ctx->prog.n_p = n_p;
+  if (rc == 0)
+    ctx->prog.n_p = n_p;
   return rc;
 }
 
@@ -941,7 +873,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
                    { scan_beam_xyz, sizeof(float) * 3 * n_b, nullptr },
                    { scan_beam_origin, scan_beam_origin ? sizeof(uint32_t) * n_b : 0, nullptr },
                    { origins, sizeof(float) * 3 * n_o, nullptr } };
-  const bool zero_copy = ctx->update_zero_copy != 0;
+  const bool zero_copy = ctx->zero_copy();
   const auto up = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
   size_t staged_bytes = 0, off[7];
   for (int k = 0; k < 7; ++k)
@@ -1056,7 +988,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   ctx->sp_n_samp[0] = n_s;
   ctx->sp_n_samp[1] = n_b;
   if (pose)
-    ctx->n_pose_uploaded = n_p;
+    ctx->poses_set(n_p);
   if (slice == STAGE_FRONT_ONLY)
     return 3;  // the caller (a device group's rank) goes on from here: poses in ctx->pose, weights at staged_weights(ctx)
   if (!with_pf)
@@ -1066,7 +998,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
     float* const user[3] = { out_lik, out_match_ratio, out_beam };
     const float* const dev[3] = { d_lik, d_ratio, d_beam };
     char* blk3 = zero_copy ? static_cast<char*>(stage_alloc(ctx, 3 * rpart)) : nullptr;
-    if (blk3 && slice > 0 && slice < n_p && ctx->poll_sync && ensure_done_flag(ctx))
+    if (blk3 && slice > 0 && slice < n_p && ctx->poll_mode() && ensure_done_flag(ctx))
     {
       // progressive delivery (mcl3dl_hip_measure_batch_begin): the particles are evaluated slice by slice, each slice's
       // results leave for page-locked memory as soon as its kernels are through and a completion word follows them, so the
@@ -1234,9 +1166,9 @@ int mcl3dl_hip_measure_update(mcl3dl_hip_ctx* ctx, const float* pose, const floa
   float* d_lik = reinterpret_cast<float*>(blk + 64 + part);
   float* d_ratio = reinterpret_cast<float*>(blk + 64 + 2 * part);
   float* d_beam = reinterpret_cast<float*>(blk + 64 + 3 * part);
-  ctx->n_pose_uploaded = 0;
+  ctx->poses_set(0);
   TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n_p));
-  ctx->n_pose_uploaded = n_p;
+  ctx->poses_set(n_p);
   TRY(h2d(ctx, d_w, weight_inout, fb));
   if (extra)
     TRY(h2d(ctx, ctx->extra.p, extra, fb));

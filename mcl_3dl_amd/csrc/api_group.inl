@@ -216,7 +216,7 @@ int mcl3dl_hip_group_upload_poses(mcl3dl_hip_group* g, const float* pose, size_t
         mcl3dl_hip_ctx* ctx = g->ctx[r];
         size_t lo, hi;
         shard_bounds(n_p, N, r, &lo, &hi);
-        ctx->n_pose_uploaded = 0;
+        ctx->poses_set(0);
         if (hi == lo)
           return 0;
         return mcl3dl_hip_upload_poses(ctx, pose + 7 * lo, hi - lo);
@@ -269,10 +269,10 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
           return sync_stream(ctx);
         if (pose)
         {
-          ctx->n_pose_uploaded = 0;
+          ctx->poses_set(0);
           TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
           TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
-          ctx->n_pose_uploaded = n;
+          ctx->poses_set(n);
         }
         else if (ctx->n_pose_uploaded != n)
           return ctx->fail(-3, "uploaded pose shard holds %zu poses, not %zu", ctx->n_pose_uploaded, n);
@@ -361,6 +361,8 @@ int mcl3dl_hip_group_measure_batch_end(mcl3dl_hip_group* g)
 
 namespace
 {
+int resident_poses(mcl3dl_hip_ctx* ctx);  // api_group_state.inl
+
 // One update over the group's shards. resident = false: mcl3dl_hip_group_measure_update (poses and prior weights come from the
 // host, the weights go back). resident = true: the particles mcl3dl_hip_group_upload_state / _resample_apply left on the
 // devices (pose = first 7 floats of each 13-float state, kept as ctx->pose; weights in ctx->gs_weight, updated in place);
@@ -420,7 +422,7 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
       // are page-locked, a staging block otherwise) and the rank learns of its completion from a polled word — instead of up
       // to five D2H copies and a hipStreamSynchronize per rank
       const size_t rpart = (fb + 63) & ~static_cast<size_t>(63);
-      char* blk = (ctx->update_zero_copy && ctx->poll_sync && 64 + 4 * rpart <= STAGE_MAX_COPY) ?
+      char* blk = (ctx->zero_copy() && ctx->poll_mode() && 64 + 4 * rpart <= STAGE_MAX_COPY) ?
                       static_cast<char*>(stage_alloc(ctx, 64 + 4 * rpart)) : nullptr;
       if (blk)
       {
@@ -476,8 +478,14 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
         const auto phase_a = [&]() -> int
         {
           HIP_TRY(hipSetDevice(ctx->device));
-          if (resident && n && (ctx->gs_n != n || ctx->n_pose_uploaded != n))
-            return ctx->fail(-5, "this device holds %zu resident particles, its shard has %zu", ctx->gs_n, n);
+          if (resident && n)
+          {
+            if (ctx->gs_n != n)
+              return ctx->fail(-5, "this device holds %zu resident particles, its shard has %zu", ctx->gs_n, n);
+            // ctx->pose is shared with the non-resident calls (uploads, mcl3dl_hip_group_measure_update, moments of explicit
+            // states): whoever wrote it last, the poses evaluated here are those of the resident states
+            TRY(resident_poses(ctx));
+          }
           // ONE launch takes the rank's inputs over — the raw scans (every rank orders them for itself, side by side), its
           // pose / weight / odometry-factor shard — out of page-locked memory (stage_kernels.h); where that form is not
           // eligible: uploads + the ordering launches, or the scans ordered once on the host and pushed
@@ -511,7 +519,7 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
           }
           TRY(ensure(ctx, ctx->packed, sizeof(double) * n_pack));
           if (!resident && !staged)
-            ctx->n_pose_uploaded = 0;
+            ctx->poses_set(0);
           if (n)
           {
             TRY(ensure(ctx, ctx->lik, fb));
@@ -523,7 +531,7 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
               TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
               TRY(ensure(ctx, ctx->weightb, fb));
               TRY(h2d(ctx, ctx->pose.p, pose + 7 * lo, sizeof(float) * 7 * n));
-              ctx->n_pose_uploaded = n;
+              ctx->poses_set(n);
               TRY(h2d(ctx, ctx->weightb.p, weight_inout + lo, fb));
             }
             float* d_w = resident ? ctx->gs_weight.as<float>() : (staged ? staged_weights(ctx) : ctx->weightb.as<float>());

@@ -39,7 +39,7 @@ __global__ void unpad_states_kernel(const float* __restrict__ padded, size_t max
 
 int rebuild_pose(mcl3dl_hip_ctx* ctx, size_t n)
 {
-  ctx->n_pose_uploaded = 0;
+  ctx->poses_set(0);
   if (n == 0)
     return 0;
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
@@ -47,7 +47,17 @@ int rebuild_pose(mcl3dl_hip_ctx* ctx, size_t n)
   hipLaunchKernelGGL(state13_to_pose7_kernel, dim3((ni + 255) / 256), dim3(256), 0, ctx->stream,
                      ctx->gs_state[ctx->gs_cur].as<float>(), ni, ctx->pose.as<float>());
   HIP_TRY(hipGetLastError());
-  ctx->n_pose_uploaded = n;
+  ctx->poses_set(n);
+  ctx->pose_resident = true;
+  return 0;
+}
+
+// the resident calls read the poses from ctx->pose: re-derived from the resident states whenever another call (an upload, a
+// non-resident update, a moments call with its own states) has written that buffer since
+int resident_poses(mcl3dl_hip_ctx* ctx)
+{
+  if (ctx->gs_n && (!ctx->pose_resident || ctx->n_pose_uploaded != ctx->gs_n))
+    return rebuild_pose(ctx, ctx->gs_n);
   return 0;
 }
 }  // namespace
@@ -179,6 +189,7 @@ int mcl3dl_hip_group_expectation(mcl3dl_hip_group* g, const float* bias, float* 
           TRY(h2d(ctx, ctx->extra.p, bias + lo, sizeof(float) * n));
           d_bias = ctx->extra.as<float>();
         }
+        TRY(resident_poses(ctx));
         TRY(mcl3dl_hip_moments_partial_device(ctx, ctx->pose.as<float>(), ctx->gs_weight.as<float>(), d_bias, n,
                                               ctx->gs_rec.as<double>()));
         TRY(d2h(ctx, rec, ctx->gs_rec.p, sizeof(double) * 16));
@@ -216,6 +227,7 @@ int mcl3dl_hip_group_covariance(mcl3dl_hip_group* g, const float* mean7, float* 
           return 0;
         HIP_TRY(hipSetDevice(ctx->device));
         TRY(ensure(ctx, ctx->gs_rec, sizeof(double) * 32));
+        TRY(resident_poses(ctx));
         TRY(mcl3dl_hip_covariance_partial_device(ctx, ctx->pose.as<float>(), ctx->gs_weight.as<float>(), n, nullptr, 0, mean7,
                                                  ctx->gs_rec.as<double>()));
         TRY(d2h(ctx, &g->h_parts[22 * static_cast<size_t>(r)], ctx->gs_rec.p, sizeof(double) * 22));

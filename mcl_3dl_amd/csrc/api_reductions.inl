@@ -225,7 +225,7 @@ int mcl3dl_hip_expectation(mcl3dl_hip_ctx* ctx, const float* pose, const float* 
   if (n == 0 || !pose || !weight)
     return ctx->fail(-3, "bad arguments to expectation");
   HIP_TRY(hipSetDevice(ctx->device));
-  ctx->n_pose_uploaded = 0;  // the pose buffer is about to hold these states, not an uploaded particle set
+  ctx->poses_set(0);  // the pose buffer is about to hold these states, not an uploaded particle set
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
   TRY(ensure(ctx, ctx->weightb, sizeof(float) * n));
   TRY(ensure(ctx, ctx->extra, sizeof(float) * n));
@@ -250,7 +250,7 @@ int mcl3dl_hip_covariance(mcl3dl_hip_ctx* ctx, const float* pose, const float* w
       if (subset[i] >= n)
         return ctx->fail(-3, "subset index %u out of range", subset[i]);
   HIP_TRY(hipSetDevice(ctx->device));
-  ctx->n_pose_uploaded = 0;  // the pose buffer is about to hold these states, not an uploaded particle set
+  ctx->poses_set(0);  // the pose buffer is about to hold these states, not an uploaded particle set
   TRY(ensure(ctx, ctx->pose, sizeof(float) * 7 * n));
   TRY(ensure(ctx, ctx->weightb, sizeof(float) * n));
   TRY(h2d(ctx, ctx->pose.p, pose, sizeof(float) * 7 * n));

@@ -74,8 +74,8 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   }
   if (key == "strict_order")
   {
-    if (!(value == 0.0 || value == 1.0 || value == 2.0))
-      return ctx->fail(-3, "strict_order must be 0 (never), 1 (always, weights too) or 2 (large scans only)");
+    if (!(value == 0.0 || value == 1.0 || value == 2.0 || value == 3.0))
+      return ctx->fail(-3, "strict_order must be 0 (never), 1 (always, weights too), 2 (large scans only) or 3 (always, in the engine's scan order)");
     if (static_cast<int>(value) != ctx->strict_order)
       ++ctx->generation;  // a captured update graph holds the other kernel selection
     ctx->strict_order = static_cast<int>(value);
@@ -118,6 +118,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     if (value != 0.0 && value != 1.0 && value != 2.0)
       return ctx->fail(-3, "poll_sync must be 0, 1 or 2");
     ctx->poll_sync = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "poll_spin_us")
+  {
+    if (!(value >= 0.0 && value <= 1e9))
+      return ctx->fail(-3, "poll_spin_us must be >= 0");
+    ctx->poll_spin_us = value;
     return 0;
   }
   if (key == "strict_rows")
@@ -191,11 +198,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   if (key == "timing_mask")
   {
     ctx->timing_mask = static_cast<unsigned>(value);
-    return 0;
-  }
-  if (key == "use_graph")
-  {
-    ctx->use_graph = value != 0.0;
     return 0;
   }
   if (key == "overlap_models")
@@ -380,6 +382,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "pf_tail") *value = ctx->pf_tail;
   else if (key == "update_particle") *value = ctx->update_particle;
   else if (key == "poll_sync") *value = ctx->poll_sync;
+  else if (key == "poll_spin_us") *value = ctx->poll_spin_us;
   else if (key == "batch_slice") *value = ctx->batch_slice;
   else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
   else if (key == "dda_overlay") *value = ctx->dda_overlay;
@@ -390,7 +393,6 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "update_small_max") *value = ctx->update_small_max;
   else if (key == "update_small_conformant") *value = ctx->update_small_conformant;
   else if (key == "timing_mask") *value = ctx->timing_mask;
-  else if (key == "use_graph") *value = ctx->use_graph;
   else if (key == "overlap_models") *value = ctx->overlap_models;
   else if (key == "lik_small") *value = ctx->lik_small;
   else if (key == "lik_tiled") *value = ctx->lik_tiled;

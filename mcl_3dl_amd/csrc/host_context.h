@@ -137,8 +137,29 @@ struct mcl3dl_hip_ctx
   // preparation -5..10 %, the post-update reductions -10 %, a whole filter iteration -8 %: profiles/r04ad_poll_all.txt),
   // 1 = only the host-buffer update and its relatives, 0 = hipStreamSynchronize everywhere.
   int poll_sync = 2;
+  // what the PLATFORM can do, set by pinned_alloc alone: page-locked memory visible to the device at the host's address. The
+  // two options above are what the caller asked for; what runs is option && capability (an option could
+  // switch a mode back on that the platform had ruled out, and update_zero_copy = 0 used to switch the polled word off for good)
+  bool zero_copy_supported = true;
+  bool zero_copy() const
+  {
+    return update_zero_copy != 0 && zero_copy_supported;
+  }
+  int poll_mode() const
+  {
+    return zero_copy_supported ? poll_sync : 0;
+  }
+  // completion waits: the polled word is spun on for at most poll_spin_us microseconds (covers every update up to a few
+  // thousand particles), then polled between naps that grow with the time already waited (a 25 ms update of 65 536 particles
+  // costs its caller ~2 ms of CPU, not 25), with hipStreamQuery looked at every few milliseconds so that a faulted queue
+  // comes back as an error instead of an endless wait
+  double poll_spin_us = 2000.0;
   volatile unsigned* done_flag = nullptr;
   unsigned done_seq = 0;
+  // strict_order = 3 (likelihood_kernels.h: LikChain): hand-off words, their tag counter, the page-locked error word
+  DevBuf chain_carry, chain_lik;
+  uint32_t chain_tag = 1;
+  volatile unsigned* chain_err = nullptr;
   // a measure_batch delivered in particle slices (mcl3dl_hip_measure_batch_begin / _wait / _end): slice k is in the host
   // arrays once the completion word has reached seq0 + k + 1
   struct BatchProgress
@@ -227,6 +248,15 @@ struct mcl3dl_hip_ctx
 
   // work buffers
   size_t n_pose_uploaded = 0;  // poses `pose` holds from mcl3dl_hip_upload_poses / the last host-buffer call
+  // `pose` holds the 7-float poses derived from this rank's RESIDENT states (api_group_state.inl:rebuild_pose). Every other
+  // writer of `pose` goes through poses_set(), which withdraws the mark: the resident calls then re-derive the poses from
+  // gs_state instead of evaluating somebody else's
+  bool pose_resident = false;
+  void poses_set(size_t n)
+  {
+    n_pose_uploaded = n;
+    pose_resident = false;
+  }
   size_t stage_pending = 0;       // bytes staged for H2D copies since the last sync_stream
   DevBuf upd_block;  // measure_update: { stats4 | weights | lik | ratio | beam } in one allocation, so that the results go home in ONE copy
   DevBuf pose, lik, ratio, beam, weightb, wnew, extra, penalty, block_partials, partial4, stats4, ray_stats,
@@ -270,28 +300,10 @@ struct mcl3dl_hip_ctx
   bool rs_sorted = false;  // std::sort had ties to order: rs_order is not the identity
   int resample_prefix_device = 0;  // 1 = resample_begin_device runs the float prefix recurrence on the device (one lane)
 
-  // mcl3dl_hip_update_device: the launch sequence of one device-resident update, captured into a hipGraph the second
-  // time the same arguments arrive and replayed afterwards (small updates are launch-bound: 8-10 launches of a few
-  // microseconds each). `generation` counts everything that can change what gets enqueued — parameters, options, map,
-  // stream, scan sizes, any device buffer that had to be reallocated.
+  // counts everything that can change what an update enqueues (parameters, options, map, stream, scan sizes, reallocated
+  // buffers); kept as a cheap change stamp for diagnostics
   uint64_t generation = 0;
-  int use_graph = 0;
-  struct UpdateKey
-  {
-    const void* p[8];
-    size_t n_p;
-    uint64_t generation;
-    bool operator==(const UpdateKey& o) const
-    {
-      return memcmp(p, o.p, sizeof(p)) == 0 && n_p == o.n_p && generation == o.generation;
-    }
-  };
-  UpdateKey graph_key{}, seen_key{}, failed_key{};
-  bool have_seen = false, have_failed = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  uint64_t graph_replays = 0, graph_captures = 0;
-  std::string graph_note;  // why the last capture attempt fell back to plain launches (diagnostics)
+  std::string index_note;  // why the map compiler fell back to a coarser / plainer index form (diagnostics)
 
   // Pinned staging for the host-buffer entry points: small copies go through page-locked memory so that
   // hipMemcpyAsync really is asynchronous (a pageable copy costs a driver-side staging round trip each); results are
@@ -479,7 +491,7 @@ void* pinned_alloc(mcl3dl_hip_ctx* ctx, size_t bytes)
   if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != p)
   {
     (void)hipGetLastError();
-    ctx->update_zero_copy = 0;
+    ctx->zero_copy_supported = false;
   }
   return p;
 }
@@ -590,33 +602,89 @@ __global__ void done_flag_kernel(volatile unsigned* flag, unsigned seq)
 // front wrote into page-locked memory left the device before the flag did (uncached stores, one ordered path to the host).
 bool ensure_done_flag(mcl3dl_hip_ctx* ctx)
 {
+  if (!ctx->zero_copy_supported)
+    return false;
   if (!ctx->done_flag)
   {
-    ctx->done_flag = static_cast<volatile unsigned*>(pinned_alloc(ctx, 64));
-    if (!ctx->done_flag || !ctx->update_zero_copy)
-    {
-      ctx->poll_sync = 0;
-      return false;
-    }
-    *ctx->done_flag = 0u;
+    volatile unsigned* f = static_cast<volatile unsigned*>(pinned_alloc(ctx, 64));
+    if (!f || !ctx->zero_copy_supported)
+      return false;  // (a block the device cannot write in place stays unused; it is released with the process)
+    *f = 0u;
+    ctx->done_flag = f;
   }
   return true;
 }
 
-// spins until the completion word has reached `seq` (sequence numbers only grow, the stream is in order)
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
+}
+
+inline double mono_us()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e6 * static_cast<double>(ts.tv_sec) + 1e-3 * static_cast<double>(ts.tv_nsec);
+}
+
+// Waits until the completion word has reached `seq` (sequence numbers only grow, the stream is in order). Bounded by wall
+// time, not by iterations: a pure spin for poll_spin_us, then naps of 1/32 of the time already waited (at most 1 ms) between
+// looks at the word — and a hipStreamQuery every ~5 ms: an error (a faulted queue) is returned within milliseconds, and a
+// stream that has drained without the word having arrived (it cannot: the word's kernel is on it) ends the wait as well.
 int spin_done_flag(mcl3dl_hip_ctx* ctx, unsigned seq)
 {
-  for (long long spin = 0; spin < 2000000000LL; ++spin)
+  const auto arrived = [&]() { return static_cast<int>(*ctx->done_flag - seq) >= 0; };
+  for (int spin = 0; spin < 256; ++spin)
   {
-    if (static_cast<int>(*ctx->done_flag - seq) >= 0)
+    if (arrived())
     {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return 0;
     }
-    __builtin_ia32_pause();
+    cpu_relax();
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return 0;
+  const double t0 = mono_us();
+  double next_query = 5000.0;
+  for (;;)
+  {
+    for (int spin = 0; spin < 64; ++spin)
+    {
+      if (arrived())
+      {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return 0;
+      }
+      cpu_relax();
+    }
+    const double waited = mono_us() - t0;
+    if (waited < ctx->poll_spin_us)
+      continue;
+    if (waited >= next_query)
+    {
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipErrorNotReady)
+      {
+        if (q != hipSuccess)
+          return ctx->fail(-2, "the stream failed while its completion was awaited: %s", hipGetErrorString(q));
+        // drained: everything in front of the word's kernel — and the kernel — has run
+        if (arrived())
+        {
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          return 0;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return 0;
+      }
+      next_query = waited + 5000.0;
+    }
+    const double nap_us = std::min(1000.0, waited / 32.0);
+    timespec ts{ 0, static_cast<long>(nap_us * 1e3) };
+    nanosleep(&ts, nullptr);
+  }
 }
 
 int wait_done_flag(mcl3dl_hip_ctx* ctx)
@@ -682,10 +750,15 @@ int sync_stream(mcl3dl_hip_ctx* ctx, bool polled = false)
   // poll_sync = 2: EVERY synchronisation of the context's stream is the polled word (the copies and kernels in front of the
   // one-thread kernel are stream-ordered ahead of it, so what they wrote — staged D2H copies included — is there when the
   // word arrives); 1: only where the caller asked for it (the host-buffer update and its relatives)
-  if ((polled || ctx->poll_sync >= 2) && ctx->poll_sync)
+  if ((polled || ctx->poll_mode() >= 2) && ctx->poll_mode())
     TRY(wait_done_flag(ctx));
   else
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->chain_err && *ctx->chain_err)
+  {
+    *ctx->chain_err = 0u;
+    return ctx->fail(-2, "strict_order = 3: a hand-off of the in-kernel float sum did not arrive (likelihoods of this update are invalid)");
+  }
   for (const mcl3dl_hip_ctx::StagedResult& r : ctx->stage_out)
     memcpy(r.user, r.staged, r.bytes);
   ctx->stage_out.clear();

@@ -743,7 +743,7 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
         ctx->cand_dirty = true;  // its buffers may have been re-allocated under the first index
         TRY(build_cand_grid_at(ctx, 0.5, forced ? forced : 4u));
         ctx->cand_stats[3] += first_ms;
-        ctx->graph_note = "finer candidate index not built (" + why + "): voxel edge r / 2 kept";
+        ctx->index_note = "finer candidate index not built (" + why + "): voxel edge r / 2 kept";
       }
     }
   }

@@ -117,6 +117,8 @@ struct LikPlan
   int group_size = 16, W = 1, n_tiles = 0, n_groups = 0;
   long long blocks = 0;
   float* strict_terms = nullptr;
+  bool chain = false;  // the float sum in the scan array's order inside the tiled kernel (likelihood_kernels.h: LikChain)
+  uint32_t chain_tag0 = 0;
 };
 
 // does an update over ns scan points replay the likelihood terms in the reference's float order?
@@ -135,6 +137,37 @@ bool lik_defer_active(const mcl3dl_hip_ctx* ctx)
 bool lik_strict(const mcl3dl_hip_ctx* ctx, int ns)
 {
   return ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min);
+}
+
+// strict_order = 3: the reference's float recurrence over the scan in the ENGINE's order (mcl3dl_hip_scan_order), inside the
+// tiled kernel — no term array, no replay (needs the page-locked error word of the hand-off: ensure_chain)
+bool lik_chain(const mcl3dl_hip_ctx* ctx)
+{
+  return ctx->strict_order == 3;
+}
+
+// hand-off words + error word of the in-kernel chain for n_p particles and n_tiles tiles; *tag0 = tag of tile 0
+int ensure_chain(mcl3dl_hip_ctx* ctx, size_t n_p, int n_tiles, uint32_t* tag0)
+{
+  if (!ctx->chain_err)
+  {
+    ctx->chain_err = static_cast<volatile unsigned*>(pinned_alloc(ctx, 64));
+    if (!ctx->chain_err || !ctx->zero_copy_supported)
+      return ctx->fail(-2, "strict_order = 3 needs page-locked memory the device can write in place");
+    *ctx->chain_err = 0u;
+  }
+  const size_t need = sizeof(unsigned long long) * 2 * n_p;
+  const bool fresh = need > ctx->chain_carry.cap;
+  TRY(ensure(ctx, ctx->chain_carry, need));
+  // tags only grow; a fresh buffer (or a wrap of the 32-bit tag) starts from cleared words and tag 1
+  if (fresh || ctx->chain_tag > 0xffffffffu - static_cast<uint32_t>(n_tiles) - 2u)
+  {
+    HIP_TRY(hipMemsetAsync(ctx->chain_carry.p, 0, ctx->chain_carry.cap, ctx->stream));
+    ctx->chain_tag = 1u;
+  }
+  *tag0 = ctx->chain_tag;
+  ctx->chain_tag += static_cast<uint32_t>(n_tiles) + 1u;
+  return 0;
 }
 
 // rows of G floats per particle group: what the float-order replay of ns points x n_p particles stores
@@ -166,8 +199,11 @@ int plan_group_size(const mcl3dl_hip_ctx* ctx, int np, int ns)
 int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
 {
   const int np = static_cast<int>(n_p);
-  bool strict = lik_strict(ctx, ns);
-  const int group_size = plan_group_size(ctx, np, ns);
+  const bool chain = lik_chain(ctx);
+  bool strict = lik_strict(ctx, ns) && !chain;
+  int group_size = plan_group_size(ctx, np, ns);
+  if (chain && group_size > 16)
+    group_size = 16;
   if (strict && ctx->strict_order == 2)
   {
     // The AUTOMATIC replay (scans of at least strict_auto_min points) costs ns x n_p floats of device memory — 0.5 GB at
@@ -203,7 +239,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
   // to fill the GPU with (tile, group) pairs (4096 x 1000: 30.6 us tiled against 34.9 us; 64 x 1000 and 4096 x 512: no gain)
   pl->tiled = (ctx->lik_tiled && np >= 4 &&
                (ns >= ctx->lik_tiled_min || (np >= 256 && 4 * static_cast<long long>(ns) >= 3ll * ctx->lik_tiled_min))) ||
-              strict;
+              strict || chain;
   pl->group_size = group_size;
   pl->small = !pl->tiled && ns <= 32 && np >= 256 && ctx->lik_small;
   if (pl->small)
@@ -223,6 +259,15 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
     // per XCD: the interleaved tiles of the largest multiple of eight, then an eighth of the remaining (tile, group) pairs
     const long long full_tiles = pl->n_tiles & ~7, rem_items = static_cast<long long>(pl->n_tiles - full_tiles) * pl->n_groups;
     pl->blocks = 8 * ((full_tiles / 8) * pl->n_groups + (rem_items + 7) / 8);
+    if (chain)
+    {
+      // rows of eight tiles, no shared-out remainder (likelihood_tiled_kernel<..., CHAIN>)
+      pl->blocks = 8ll * ((pl->n_tiles + 7) / 8) * pl->n_groups;
+      if (pl->blocks > 0x7fffffffLL)
+        return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
+      pl->chain = true;
+      return ensure_chain(ctx, n_p, pl->n_tiles, &pl->chain_tag0);
+    }
     if (pl->blocks > 0x7fffffffLL)
       return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
     TRY(ensure(ctx, ctx->lik_partial_sum, sizeof(double) * static_cast<size_t>(pl->n_tiles) * n_p));
@@ -480,6 +525,52 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                      ctx->scan_perm.as<uint32_t>(), strict_terms, ctx->strict_skew ? STRICT_SKEW4 : 0)
           const bool coop = coop_arg != 0;
           const bool defer = coop && lik_defer_active(ctx);
+          if (plan.chain)
+          {
+            float* lik_out = d_lik;
+            if (!lik_out)  // (only the match ratio was asked for: the sum still has somewhere to go)
+            {
+              TRY(ensure(ctx, ctx->chain_lik, sizeof(float) * n_p));
+              lik_out = ctx->chain_lik.as<float>();
+            }
+            const LikChain lc{ ctx->chain_carry.as<unsigned long long>(), plan.chain_tag0, lik_out, d_ratio,
+                               beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr), ctx->chain_err };
+#define LAUNCH_CHAIN(GG, MODE, CC, DD)                                                                                  \
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, 8, CC, DD, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
+                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
+                     static_cast<double*>(nullptr), static_cast<unsigned*>(nullptr),                                   \
+                     static_cast<const uint32_t*>(nullptr), static_cast<float*>(nullptr), 0, lc)
+#define LAUNCH_CHAIN_G(GG)              \
+  do                                    \
+  {                                     \
+    if (coop && defer)                  \
+      LAUNCH_CHAIN(GG, 2, true, true);  \
+    else if (coop)                      \
+      LAUNCH_CHAIN(GG, 2, true, false); \
+    else if (ctx->lik_index == 2)       \
+      LAUNCH_CHAIN(GG, 2, false, false);\
+    else if (ctx->lik_index == 1)       \
+      LAUNCH_CHAIN(GG, 1, false, false);\
+    else                                \
+      LAUNCH_CHAIN(GG, 0, false, false);\
+  } while (0)
+            switch (G)
+            {
+              case 4:
+                LAUNCH_CHAIN_G(4);
+                break;
+              case 8:
+                LAUNCH_CHAIN_G(8);
+                break;
+              default:
+                LAUNCH_CHAIN_G(16);
+                break;
+            }
+#undef LAUNCH_CHAIN_G
+#undef LAUNCH_CHAIN
+          }
+          else
+          {
 #define LAUNCH_TILED_G(GG, WW)         \
   do                                   \
   {                                    \
@@ -537,6 +628,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                 launch_strict_sum<16>(ctx, strict_terms, ns, np, n_groups, d_lik);
                 break;
             }
+          }
           }
         }
         else
@@ -620,7 +712,7 @@ bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
 int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                         float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho = nullptr)
 {
-  if (!ctx->update_small || n_p == 0 || ctx->n_b > 256 || ctx->strict_order == 1 || !ctx->has_scan || !d_lik || !d_ratio ||
+  if (!ctx->update_small || n_p == 0 || ctx->n_b > 256 || ctx->strict_order == 1 || ctx->strict_order == 3 || !ctx->has_scan || !d_lik || !d_ratio ||
       !d_beam)
     return 0;
   const bool tickets = n_p <= static_cast<size_t>(ctx->update_small_max);

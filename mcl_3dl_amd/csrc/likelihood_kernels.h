@@ -728,6 +728,42 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
   }
 }
 
+// ---- the reference's float sum inside the tiled kernel (CHAIN) ---------------------------------------------------------
+// score_like += dist * match_weight is a float recurrence over the scan in the order the cloud holds its points
+// (likelihood.cpp:124-134). When that order IS the order of the device scan array — a scan that came out of the engine's
+// own preparation, or any scan under the option strict_order = 3, whose order mcl3dl_hip_scan_order reports — a tile's 256
+// terms are consecutive links of every particle's chain, so the chain can run where the terms are, in LDS: the work-group of
+// (tile j, particle group g) takes each particle's running sum and match count over from (tile j - 1, g), adds its 256
+// terms in array order — G lanes of its first wavefront, one particle each, four terms per 16-byte LDS read — and hands
+// them on; the last tile writes likelihood and match ratio. No term ever leaves the CU: no N_s x N_p array, no replay
+// kernel, no partials and no finalize launch. Unmatched points hold +0 (x + 0.0f == x for the non-negative sums here), so
+// the float is the reference's bit for bit.
+// Hand-off: per particle two naturally aligned 8-byte words {value, tag} — {running float sum, tag}, {match count, tag} —
+// each written by ONE agent-scope store and polled by ONE agent-scope load (MI355X_MICROARCH.md "handoff-1to1": data-tagged
+// granules need no fence and no separate flag). tag = tag0 + tile, tag0 advancing by the tile count with every launch, so
+// the words are never cleared and a stale word of an earlier launch never matches. The consumer (tile j) has a higher
+// block index than its producer (tile j - 1: same row of tiles -> block - 1, previous row -> block - 8 n_groups + 7) and
+// blocks are dispatched in index order, so the producer is always resident or done when the consumer polls; the poll is
+// bounded all the same — a lane that gives up raises *err (page-locked: the host checks it after every synchronisation)
+// instead of hanging the GPU.
+// Cost model (measured, profiles/r05*): a hop is ~1.2 us of dependent adds + ~1.5-3 us of hand-off. The eight tiles of a
+// row run side by side on the eight XCDs, so XCD x settles x hops behind XCD 0 (once per launch), and a row must last
+// eight hops for the chain to keep up: rows of >= 512 particle groups (8192 particles) never wait.
+struct LikChain
+{
+  unsigned long long* carry;  // [n_p][2] words {sum, tag}, {count, tag}
+  uint32_t tag0;              // tag of tile 0 in this launch
+  float* out_lik;             // [n_p] written by the last tile
+  float* out_ratio;           // [n_p] (may be null)
+  float* also_fill;           // [n_p] set to 1 on the way (may be null): the beam score of an update without beam points
+  volatile unsigned* err;     // raised when a hand-off did not arrive within the poll bound
+};
+
+__device__ inline unsigned long long chain_pack(uint32_t value, uint32_t tag)
+{
+  return (static_cast<unsigned long long>(tag) << 32) | value;
+}
+
 // ---- deferred overflow rounds (tiled kernel, packed 64-byte records) ------------------------------------------------
 // On a map of voxel-filter centroids a quarter of the voxels hold more than four candidates. A wavefront runs an overflow
 // round as soon as ONE of its 64 evaluations needs it — practically always — with a quarter of its lanes doing useful work
@@ -736,6 +772,7 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
 // a per-wavefront LDS queue; whenever 64 are queued the wavefront runs ONE dense overflow round for them — each lane
 // rebuilds its query from the queued lane's scan point (ds_bpermute) and the particle's pose (LDS), exactly the arithmetic
 // of the first pass, so the minimum, the term and therefore every result are the same bits as without the queue.
+constexpr int CHAIN_POLL_MAX = 1 << 20;  // polls of a hand-off word before the lane gives up (~1 s)
 constexpr int DEFER_QCAP = 96;   // entries per wavefront: a push never finds more than 63 queued, and flushes first if it would not fit
 
 struct DeferQueue
@@ -784,8 +821,8 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
 
 // One dense overflow round for entries [base, base + n) of this wavefront's queue, n <= 64 (all lanes arrive; lane l takes
 // entry base + l). s_term / s_cnt rows are the tiled kernel's: the parked best is replaced by the term, a match is counted.
-template <int G>
-__device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, const float (&s_pose)[G][8], float (&s_term)[G][256],
+template <int G, int LD>
+__device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, const float (&s_pose)[G][8], float (&s_term)[G][LD],
                                    unsigned (&s_cnt)[G][4], const DeferQueue& q, int wave, int lane, uint32_t base, uint32_t n,
                                    const float4 v)
 {
@@ -843,19 +880,23 @@ __device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, cons
 // terms, bit for bit. MINW = wavefronts per SIMD the register allocation must leave room for (G = 32 holds 33 KB of LDS:
 // 4 at most).
 // DEFER (COOP only; packed 64-byte records): overflow rounds queued per wavefront and run densely (above).
-template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false>
+template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false, bool CHAIN = false>
 __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
                                                                int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
                                                                LikParams prm, double* __restrict__ partial_sum,
                                                                unsigned* __restrict__ partial_cnt,
                                                                const uint32_t* __restrict__ scan_perm,
-                                                               float* __restrict__ strict_terms, int strict_skew4 = 0)
+                                                               float* __restrict__ strict_terms, int strict_skew4 = 0,
+                                                               LikChain ch = LikChain{})
 {
   // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
   // [particle group][original scan index][G] so that lik_strict_sum_kernel can add them in the reference's own order.
+  // (CHAIN: rows padded to 260 floats — the chain's lanes read DIFFERENT rows at the same column, 16 bytes at a time: with a
+  // row length of 256 they would all hit the same LDS banks)
+  constexpr int TERM_LD = CHAIN ? 260 : 256;
   __shared__ float s_pose[G][8];        // px,py,pz, qx,qy,qz,qw (normalised), valid
-  __shared__ float s_term[G][256];
+  __shared__ __attribute__((aligned(16))) float s_term[G][TERM_LD];
   __shared__ unsigned s_cnt[G][4];
   // Work-groups are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8). The tiles of the largest
   // multiple of eight are INTERLEAVED: XCD x walks tiles x, x + 8, ... one after the other over all particle groups —
@@ -869,7 +910,17 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   const uint32_t full_tiles = static_cast<uint32_t>(n_tiles) & ~7u;
   const uint32_t per_xcd_full = (full_tiles >> 3) * ng;
   int tile, group;
-  if (seq < per_xcd_full)
+  if constexpr (CHAIN)
+  {
+    // rows of eight tiles, XCD x takes tile 8 row + x over all particle groups; a last partial row leaves XCDs idle (the
+    // shared-out remainder below would break "the producer's block index is lower")
+    const uint32_t row = seq / ng;
+    tile = static_cast<int>(row * 8u + xcd);
+    group = static_cast<int>(seq - row * ng);
+    if (tile >= n_tiles)
+      return;
+  }
+  else if (seq < per_xcd_full)
   {
     const uint32_t row = seq / ng;
     tile = static_cast<int>(row * 8u + xcd);
@@ -936,7 +987,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
         {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          defer_drain<G>(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, 0u, qn, v);
+          defer_drain(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, 0u, qn, v);
           qn = 0;
         }
         if (over)
@@ -952,7 +1003,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
           // the LAST 64 entries: what stays queued keeps its place
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          defer_drain<G>(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, qn - 64u, 64u, v);
+          defer_drain(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, qn - 64u, 64u, v);
           qn -= 64u;
         }
       }
@@ -961,7 +1012,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
     {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      defer_drain<G>(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, 0u, qn, v);
+      defer_drain(rg, prm, s_pose, s_term, s_cnt, s_q, wave, lane, 0u, qn, v);
     }
   }
   else if constexpr (COOP && MODE == 2)
@@ -1013,6 +1064,67 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
       s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
   }
   __syncthreads();
+  if constexpr (CHAIN)
+  {
+    if (wave != 0 || lane >= n_valid)
+      return;
+    const int k = lane;
+    const size_t p = static_cast<size_t>(group) * G + k;
+    unsigned long long* cw = ch.carry + 2 * p;
+    float s = 0.0f;
+    uint32_t cnt = 0;
+    if (tile > 0)
+    {
+      const uint32_t want = ch.tag0 + static_cast<uint32_t>(tile) - 1u;
+      unsigned long long a = 0, b = 0;
+      int polls = 0;
+      bool got = false;
+      // (every lane polls its own two words; lanes that have theirs idle through the others' iterations)
+      while (!got)
+      {
+        a = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(cw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = static_cast<uint32_t>(a >> 32) == want && static_cast<uint32_t>(b >> 32) == want;
+        if (!got)
+        {
+          if (++polls > CHAIN_POLL_MAX)
+          {
+            *ch.err = 1u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      s = __uint_as_float(static_cast<uint32_t>(a));
+      cnt = static_cast<uint32_t>(b);
+    }
+    const float4* row = reinterpret_cast<const float4*>(&s_term[k][0]);
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j)
+    {
+      const float4 t4 = row[j];
+      s = s + t4.x;
+      s = s + t4.y;
+      s = s + t4.z;
+      s = s + t4.w;
+    }
+    cnt += s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+    if (tile == n_tiles - 1)
+    {
+      ch.out_lik[p] = s;
+      if (ch.out_ratio)
+        ch.out_ratio[p] = static_cast<float>(cnt) / static_cast<float>(n_s);
+      if (ch.also_fill)
+        ch.also_fill[p] = 1.0f;
+    }
+    else
+    {
+      const uint32_t tag = ch.tag0 + static_cast<uint32_t>(tile);
+      __hip_atomic_store(cw, chain_pack(__float_as_uint(s), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cw + 1, chain_pack(cnt, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (strict_terms)
   {
     // rows of G floats, [group][original scan index][G]: G / 4 lanes write one row as float4s (one 16..128-byte run)

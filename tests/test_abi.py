@@ -36,7 +36,7 @@ def test_binding_covers_every_declared_symbol():
     from mcl_3dl_amd import capi
     assert sorted(capi.SIGNATURES) == declared_symbols()
     lib = capi.load_library()
-    assert lib.mcl3dl_hip_abi_version() == 2
+    assert lib.mcl3dl_hip_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -83,4 +83,4 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     abi, rc = (int(x) for x in out.stdout.split())
-    assert abi == 2 and rc <= 0
+    assert abi == 3 and rc <= 0

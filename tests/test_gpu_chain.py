@@ -1,0 +1,164 @@
+"""strict_order = 3: the reference's float recurrence `score_like += dist * match_weight`
+(src/lidar_measurement_model_likelihood.cpp:124-134) runs INSIDE the tiled likelihood kernel, over the scan in the ENGINE's
+order (mcl3dl_hip_scan_order) — no N_s x N_p term array, no replay pass. The contract these tests hold it to:
+
+    engine likelihood (strict_order = 3)  ==  reference measure() on the cloud { scan[order[0]], scan[order[1]], ... }
+
+bit for bit (assert_array_equal), at every scan size and particle count, for every index / kernel family, with overflow
+records (map of centroids), through the device call, the host-buffer update and the progressive batch.
+"""
+import numpy as np
+import pytest
+
+from mcl_3dl_amd.synthetic import make_scene
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_oracle(kind, sc, dist_weight, beam_kw=None):
+    o = pyoracle.Oracle(kind)
+    o.set_map(sc.map_xyz, sc.map_label, dist_weight=dist_weight)
+    o.set_likelihood_params(pyoracle.LikelihoodParams())
+    o.set_beam_params(pyoracle.BeamParams(**(beam_kw or {})))
+    return o
+
+
+def setup_engine(eng, sc, dist_weight, stamp, beam_kw=None):
+    eng.set_map(sc.map_xyz, sc.map_label, stamp=stamp, dist_weight=dist_weight)
+    eng.set_likelihood_params()
+    eng.set_beam_params(**(beam_kw or {}))
+
+
+class chain_mode:
+    def __init__(self, eng, **opts):
+        self.eng, self.opts = eng, dict(opts, strict_order=3)
+        self.saved = {}
+
+    def __enter__(self):
+        for k, v in self.opts.items():
+            self.saved[k] = self.eng.get_option(k)
+            self.eng.set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            self.eng.set_option(k, v)
+
+
+def check_order(order, n_s):
+    assert order.shape == (n_s,)
+    assert np.array_equal(np.sort(order), np.arange(n_s, dtype=np.uint32)), "scan_order is not a permutation"
+
+
+# (particles, points): one tile, a ragged last tile, fewer than eight tiles, partial last row of tiles, ragged particle groups
+SHAPES = [(5, 1), (64, 255), (64, 1000), (33, 2049), (300, 2500), (1000, 4100), (257, 6000)]
+
+
+@pytest.mark.parametrize("n_p,n_s", SHAPES)
+@pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
+def test_chain_is_the_reference_on_the_scan_in_engine_order(engine, oracle_kind, n_p, n_s, dist_weight):
+    sc = make_scene(n=91, n_p=n_p, n_s=n_s, seed=100 + n_s)
+    setup_engine(engine, sc, dist_weight, stamp=300 + n_s)
+    with chain_mode(engine):
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        order = engine.scan_order(n_s)
+    check_order(order, n_s)
+    o = make_oracle(oracle_kind, sc, dist_weight)
+    want_lik, want_q = o.likelihood_measure(sc.poses, sc.scan_lik[order])
+    assert np.any(want_lik > 0)
+    np.testing.assert_array_equal(lik, want_lik)
+    np.testing.assert_array_equal(ratio, want_q)
+    # and the default mode (fp64 sums, caller's order) stays within its tolerance of the same points
+    lik0, ratio0, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    np.testing.assert_allclose(lik0, want_lik, rtol=3e-5)
+    np.testing.assert_array_equal(ratio0, want_q)
+
+
+@pytest.mark.parametrize("opts", [dict(lik_group=4), dict(lik_group=8), dict(lik_group=16), dict(lik_coop=0),
+                                  dict(lik_index=1), dict(lik_index=0), dict(lik_defer=0), dict(cand_packed=0)])
+def test_every_kernel_family_chains_the_same_bits(engine, oracle_kind, opts):
+    sc = make_scene(n=91, n_p=150, n_s=3000, seed=7)
+    dw = (1.0, 1.0, 5.0)
+    setup_engine(engine, sc, dw, stamp=340)
+    with chain_mode(engine, **opts):
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        order = engine.scan_order(len(sc.scan_lik))
+    o = make_oracle(oracle_kind, sc, dw)
+    want_lik, want_q = o.likelihood_measure(sc.poses, sc.scan_lik[order])
+    np.testing.assert_array_equal(lik, want_lik)
+    np.testing.assert_array_equal(ratio, want_q)
+
+
+def test_chain_on_a_map_of_centroids(engine, oracle_kind):
+    """Overflow records (deferred rounds parked in the term slots) in front of the chain."""
+    sc = make_scene(n=91, n_p=200, n_s=4096, seed=11, map_jitter=0.045)
+    dw = (1.0, 1.0, 1.0)
+    setup_engine(engine, sc, dw, stamp=350)
+    with chain_mode(engine):
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        order = engine.scan_order(len(sc.scan_lik))
+    o = make_oracle(oracle_kind, sc, dw)
+    want_lik, want_q = o.likelihood_measure(sc.poses, sc.scan_lik[order])
+    np.testing.assert_array_equal(lik, want_lik)
+    np.testing.assert_array_equal(ratio, want_q)
+
+
+def test_chain_through_the_host_buffer_update_and_the_progressive_batch(engine, oracle_kind):
+    sc = make_scene(n=91, n_p=1500, n_s=2600, n_b=40, seed=5)
+    dw = (1.0, 1.0, 5.0)
+    kw = dict(num_points=40)
+    setup_engine(engine, sc, dw, stamp=360, beam_kw=kw)
+    rng = np.random.default_rng(9)
+    w0 = rng.uniform(0.5, 1.5, len(sc.poses)).astype(np.float32)
+    w0 /= w0.sum()
+    with chain_mode(engine):
+        got = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+        order = engine.scan_order(len(sc.scan_lik))
+        lik_b, ratio_b, beam_b = engine.measure_batch_begin(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label,
+                                                            sc.origins, slice_particles=400)
+        assert engine.measure_batch_wait(0) >= 400
+        engine.measure_batch_end()
+        order_b = engine.scan_order(len(sc.scan_lik))
+        # twice in a row: the hand-off words of the first launch must not satisfy the second
+        lik_c, _, _ = engine.measure_batch(sc.poses[::-1].copy(), sc.scan_lik)
+    np.testing.assert_array_equal(order, order_b)
+    o = make_oracle(oracle_kind, sc, dw, beam_kw=kw)
+    want = o.measure_update(sc.poses, w0, sc.scan_lik[order], sc.scan_beam, sc.scan_beam_label, sc.origins)
+    np.testing.assert_array_equal(got["lik"], want["lik"])
+    np.testing.assert_array_equal(got["quality"], want["quality"])
+    np.testing.assert_array_equal(got["beam"], want["beam"])
+    np.testing.assert_allclose(got["weights"], want["weights"], rtol=1e-5)  # (weights: fp64 tree here, float recurrence there)
+    np.testing.assert_array_equal(lik_b, want["lik"])
+    np.testing.assert_array_equal(ratio_b, want["quality"])
+    np.testing.assert_array_equal(beam_b, want["beam"])
+    np.testing.assert_array_equal(lik_c[::-1], want["lik"])
+
+
+def test_chain_at_the_headline_size(engine, oracle_kind):
+    """C2: 4096 particles x 16 384 points (64 tiles, 256 particle groups: the size at which a row of tiles lasts about as
+    long as its eight hand-offs). Every particle evaluated on the GPU, a sample of them by the reference."""
+    sc = make_scene(n=408, n_p=4096, n_s=16384, seed=12345)
+    dw = (1.0, 1.0, 1.0)
+    setup_engine(engine, sc, dw, stamp=370)
+    with chain_mode(engine):
+        lik, ratio, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        lik2, ratio2, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        order = engine.scan_order(len(sc.scan_lik))
+    np.testing.assert_array_equal(lik, lik2)
+    sample = np.r_[0:8, 2040:2056, 4088:4096]
+    o = make_oracle(oracle_kind, sc, dw)
+    want_lik, want_q = o.likelihood_measure(sc.poses[sample], sc.scan_lik[order])
+    np.testing.assert_array_equal(lik[sample], want_lik)
+    np.testing.assert_array_equal(ratio[sample], want_q)
+    lik0, _, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    np.testing.assert_allclose(lik0, lik, rtol=2e-5)
+
+
+def test_scan_order_errors(engine):
+    sc = make_scene(n=91, n_p=8, n_s=100, seed=3)
+    setup_engine(engine, sc, (1.0, 1.0, 1.0), stamp=380)
+    engine.measure_batch(sc.poses, sc.scan_lik)
+    with pytest.raises(RuntimeError):
+        engine.scan_order(99)
+    check_order(engine.scan_order(100), 100)

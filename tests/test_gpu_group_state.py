@@ -159,3 +159,44 @@ def test_more_devices_than_particles_and_call_order(scene, start):
         assert new_st.shape == (3, 13) and np.isfinite(new_st).all()
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("devices,collective", [([0], None), ([0, 0, 0], "host")])
+def test_non_resident_calls_between_resident_ones_do_not_swap_the_poses(scene, start, devices, collective):
+    """update_resident / expectation / covariance read the poses from the context's pose buffer, which
+    mcl3dl_hip_group_upload_poses, group_measure_batch and the non-resident group_measure_update also write — with the same
+    particle count the resident calls used to evaluate the FOREIGN poses and report success. They now re-derive the poses
+    from the resident states whenever somebody else has written the buffer."""
+    sc = scene
+    st, w0, extra, bias = start
+    other = make_scene(n=91, n_p=N_P, n_s=1200, n_b=48, seed=78).poses   # same count, different poses
+    g = capi.Group(devices, collective=collective)
+    h = capi.Group(devices, collective=collective)
+    try:
+        for obj in (g, h):
+            configure(obj, sc)
+            obj.upload_state(st, w0)
+        args = (sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+        # h: resident calls only; g: the same calls with foreign-pose traffic in between each of them
+        want = h.update_resident(*args, extra=extra)
+        g.measure_update(other, w0.copy(), *args)
+        got = g.update_resident(*args, extra=extra)
+        for k in ("lik", "quality", "beam", "weights"):
+            np.testing.assert_array_equal(got[k], want[k])
+        want_m = h.expectation(bias)
+        g.upload_poses(other)
+        got_m = g.expectation(bias)
+        np.testing.assert_array_equal(got_m[0], want_m[0])
+        assert got_m[1:] == want_m[1:]
+        want_c = h.covariance(want_m[0])
+        g.measure_batch(other, sc.scan_lik)
+        got_c = g.covariance(want_m[0])
+        np.testing.assert_array_equal(got_c, want_c)
+        # ... and a second resident update still starts from the weights the first one left
+        want2 = h.update_resident(*args)
+        g.measure_update(other, w0.copy(), *args)
+        got2 = g.update_resident(*args)
+        np.testing.assert_array_equal(got2["weights"], want2["weights"])
+    finally:
+        g.close()
+        h.close()
