@@ -186,6 +186,12 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
  * include/mcl_3dl/point_cloud_random_samplers/point_cloud_uniform_sampler.h:56-74), but it does select which float
  * roundings happen: two orders of the same points differ by ~1e-6..1e-5 relative, like any two float summation orders. */
 int mcl3dl_hip_scan_order(mcl3dl_hip_ctx* ctx, uint32_t* order /*n_s*/, size_t n_s /* must equal the installed scan's size */);
+/* The same order computed on the host, without a context or a device (same keys, same stable sort): for a caller that wants
+ * to HOLD its sampled cloud in the engine's order — a cloud permuted by `order` is left as it is by the engine (the sort is
+ * stable and the keys depend only on the points and their bounding box), so "the caller's order" and "the engine's order"
+ * coincide and strict_order = 3 is bit-identical to the reference's measure() on the caller's own cloud. The drop-in model
+ * classes do exactly this in filter() when MCL3DL_HIP_ENGINE_ORDER=1. Returns 0, -3 on a null array. */
+int mcl3dl_hip_scan_order_host(const float* scan_lik_xyz /*n_s*3*/, size_t n_s, uint32_t* order /*n_s*/);
 /* measure_batch on device-resident poses against the uploaded scans; outputs are device arrays (may be NULL). */
 int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose /*n_p*7*/, size_t n_p, float* d_lik,
                               float* d_match_ratio, float* d_beam);

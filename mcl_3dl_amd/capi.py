@@ -32,6 +32,7 @@ SIGNATURES = {
     "mcl3dl_hip_set_beam_params": (_i, [_p, _f, _f, _f, _f, _f, _f, _f, _u32, _f, _u32, _i]),
     "mcl3dl_hip_upload_poses": (_i, [_p, _p, _sz]),
     "mcl3dl_hip_scan_order": (_i, [_p, _p, _sz]),
+    "mcl3dl_hip_scan_order_host": (_i, [_p, _sz, _p]),
     "mcl3dl_hip_measure_batch": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p]),
     "mcl3dl_hip_measure_batch_begin": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _sz, _p, _sz, _p, _p, _p, _sz]),
     "mcl3dl_hip_measure_batch_wait": (_i, [_p, _sz, _p]),
@@ -171,6 +172,16 @@ def _ptr(a):
     if isinstance(a, int):
         return C.c_void_p(a)
     return C.c_void_p(a.data_ptr())  # torch tensor (device memory)
+
+
+def scan_order_host(scan_lik):
+    """mcl3dl_hip_scan_order_host: the engine's order of a likelihood scan, computed on the host (no GPU needed)."""
+    lib = load_library()
+    sl = _np_f32(scan_lik, 3)
+    order = np.zeros(len(sl), np.uint32)
+    if lib.mcl3dl_hip_scan_order_host(_ptr(sl), len(sl), _ptr(order)) != 0:
+        raise ValueError("mcl3dl_hip_scan_order_host rejected the scan")
+    return order
 
 
 def group_shard(n_p, n_devices, rank):

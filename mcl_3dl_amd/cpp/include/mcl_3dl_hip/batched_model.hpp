@@ -55,6 +55,20 @@ public:
       Engine::FilteredScan& f = e.filtered[kind_];
       const double t0 = Engine::nowUs();
       packCloud(*sampled, f.xyz, &f.label);
+      if (e.engine_order && kind_ == Engine::LIKELIHOOD && !sampled->points.empty())
+      {
+        // The order of a sampled cloud is the order the sampler drew it in (point_cloud_uniform_sampler.h:66-71) and means
+        // nothing; the node holds the cloud in the ENGINE's order instead, so that the float recurrence of
+        // likelihood.cpp:124-134 over the node's cloud is the one the likelihood kernel runs (strict_order = 3).
+        std::vector<std::uint32_t> order(sampled->points.size());
+        if (mcl3dl_hip_scan_order_host(f.xyz.data(), order.size(), order.data()) != 0)
+          throw std::runtime_error("mcl3dl_hip: mcl3dl_hip_scan_order_host rejected the sampled cloud");
+        Cloud::VectorType pts(sampled->points.size());
+        for (std::size_t k = 0; k < order.size(); ++k)
+          pts[k] = sampled->points[order[k]];
+        sampled->points.swap(pts);
+        packCloud(*sampled, f.xyz, &f.label);
+      }
       e.profile.pack_us += Engine::nowUs() - t0;
       f.cloud = sampled.get();
       f.from_filter = true;

@@ -78,6 +78,9 @@ public:
     return e;
   }
 
+  // MCL3DL_HIP_ENGINE_ORDER=1 (src/engine.cpp): sampled likelihood clouds leave filter() in the engine's scan order
+  bool engine_order = false;
+
   // ---- the batch in flight (mcl3dl_hip_group_measure_batch_begin): results arrive in particle order while the GPU works on
   // the later particles; batch_ready = number of leading particles whose results are in `results`
   bool batch_open = false;

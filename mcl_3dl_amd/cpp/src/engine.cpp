@@ -2,6 +2,10 @@
 //   MCL3DL_HIP_DEVICES=0,1,2,3   GPUs the particles are sharded over (default: MCL3DL_HIP_DEVICE, or device 0)
 //   MCL3DL_HIP_COLLECTIVE=host   combine the per-device sums on the host instead of an RCCL all-reduce
 //   MCL3DL_HIP_BATCH_SLICE=n      particles per slice of the batch behind pf::measure (option "batch_slice"; default: automatic)
+//   MCL3DL_HIP_ENGINE_ORDER=1     the likelihood model's filter() returns its sampled cloud in the engine's scan order
+//                                 (mcl3dl_hip_scan_order_host) and the likelihoods are the reference's float recurrence over that
+//                                 cloud, computed inside the likelihood kernel (option "strict_order" = 3): bit-identical to
+//                                 what the reference's own class returns for the cloud the node holds, at ~1.05x the default time
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -43,6 +47,12 @@ Engine& Engine::shared()
   {
     if (const char* slice = std::getenv("MCL3DL_HIP_BATCH_SLICE"))
       engine.check(mcl3dl_hip_group_set_option(engine.group(), "batch_slice", std::atof(slice)));
+    if (const char* eo = std::getenv("MCL3DL_HIP_ENGINE_ORDER"))
+      if (std::atoi(eo) != 0)
+      {
+        engine.check(mcl3dl_hip_group_set_option(engine.group(), "strict_order", 3.0));
+        engine.engine_order = true;
+      }
     return true;
   }();
   (void)configured;

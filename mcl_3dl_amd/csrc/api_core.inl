@@ -442,6 +442,20 @@ int mcl3dl_hip_upload_scan(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size_
   return upload_scan_impl(ctx, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, true);
 }
 
+int mcl3dl_hip_scan_order_host(const float* scan_lik_xyz, size_t n_s, uint32_t* order)
+{
+  if (n_s == 0)
+    return 0;
+  if (!scan_lik_xyz || !order)
+    return -3;
+  std::string err;
+  OrderedScan o;
+  if (order_scan(err, scan_lik_xyz, n_s, nullptr, nullptr, 0, nullptr, 0, o) != 0)
+    return -3;
+  memcpy(order, o.perm.data(), sizeof(uint32_t) * n_s);
+  return 0;
+}
+
 int mcl3dl_hip_scan_order(mcl3dl_hip_ctx* ctx, uint32_t* order, size_t n_s)
 {
   if (!ctx)

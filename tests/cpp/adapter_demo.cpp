@@ -301,6 +301,12 @@ int main(int argc, char** argv)
   fwrite(out_beam.data(), 4, n_p, g);
   fwrite(out_quality.data(), 4, n_p, g);
   fwrite(tail, 4, 6, g);
+  // the likelihood cloud as the node holds it after filter() (MCL3DL_HIP_ENGINE_ORDER=1: in the engine's scan order)
+  for (const PointType& q : pc_locals["likelihood"]->points)
+  {
+    const float xyz[3] = { q.x, q.y, q.z };
+    fwrite(xyz, 4, 3, g);
+  }
   fclose(g);
   printf("adapter_demo: %zu particles, entropy %.6f, match ratio [%.4f, %.4f]\n", n_p, tail[0], tail[1], tail[2]);
   return 0;

@@ -51,7 +51,8 @@ def test_node_call_site_through_drop_in_classes(tmp_path, oracle_kind, dist_weig
     assert proc.returncode == 0, proc.stdout + proc.stderr
     raw = np.fromfile(result, dtype=np.float32)
     n = len(sc.poses)
-    w, lik, beam, quality, tail = raw[:n], raw[n:2 * n], raw[2 * n:3 * n], raw[3 * n:4 * n], raw[4 * n:]
+    w, lik, beam, quality, tail = raw[:n], raw[n:2 * n], raw[2 * n:3 * n], raw[3 * n:4 * n], raw[4 * n:4 * n + 6]
+    np.testing.assert_array_equal(raw[4 * n + 6:].reshape(-1, 3), sc.scan_lik)   # filter() leaves the sampler's order alone
 
     o = pyoracle.Oracle(oracle_kind)
     o.set_map(sc.map_xyz, sc.map_label, dist_weight=dist_weight)
@@ -69,6 +70,42 @@ def test_node_call_site_through_drop_in_classes(tmp_path, oracle_kind, dist_weig
     assert tail[3] == lik[0] and tail[4] == quality[0]
     st, _ = o.beam_status(sc.poses[:1, :3], sc.poses[:1, :3] + np.array([[3.0, 0.5, -0.2]], np.float32))
     assert int(tail[5]) == int(st[0])
+
+
+@pytest.mark.parametrize("n_p,n_s", [(96, 777), (2000, 5000)])
+def test_node_call_site_in_engine_order_is_bit_identical(tmp_path, oracle_kind, n_p, n_s):
+    """MCL3DL_HIP_ENGINE_ORDER=1: the likelihood model's filter() hands the node its sampled cloud in the engine's scan
+    order and the likelihood kernel runs the reference's float recurrence over it (strict_order = 3). The reference's own
+    classes, given the cloud the node holds, return the same floats bit for bit — the node's source untouched, no N_s x N_p
+    term array, no replay pass."""
+    from mcl_3dl_amd import capi
+    need_binary(DEMO)
+    dist_weight = (1.0, 1.0, 5.0)
+    sc = make_scene(n=91, n_p=n_p, n_s=n_s, n_b=40, seed=22, label_wall=2)
+    sigma, flmax = 0.6, 1
+    scene, result = str(tmp_path / "scene.bin"), str(tmp_path / "result.bin")
+    write_scene(scene, sc, dist_weight, 40, True, flmax, sigma)
+    proc = subprocess.run([DEMO, scene, result], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, MCL3DL_HIP_ENGINE_ORDER="1"))
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    raw = np.fromfile(result, dtype=np.float32)
+    n = len(sc.poses)
+    w, lik, beam, quality, tail = raw[:n], raw[n:2 * n], raw[2 * n:3 * n], raw[3 * n:4 * n], raw[4 * n:4 * n + 6]
+    held = raw[4 * n + 6:].reshape(-1, 3)
+    order = capi.scan_order_host(sc.scan_lik)
+    assert np.array_equal(np.sort(order), np.arange(n_s, dtype=np.uint32)) and not np.array_equal(order, np.arange(n_s))
+    np.testing.assert_array_equal(held, sc.scan_lik[order])
+    np.testing.assert_array_equal(capi.scan_order_host(held), np.arange(n_s, dtype=np.uint32))  # an ordered cloud stays put
+    o = pyoracle.Oracle(oracle_kind)
+    o.set_map(sc.map_xyz, sc.map_label, dist_weight=dist_weight)
+    o.set_likelihood_params(pyoracle.LikelihoodParams())
+    o.set_beam_params(pyoracle.BeamParams(num_points=40, filter_label_max=flmax))
+    want = o.measure_update(sc.poses, sc.weights, held, sc.scan_beam, sc.scan_beam_label, sc.origins, sc.odom_err, sigma)
+    np.testing.assert_array_equal(lik, want["lik"])
+    np.testing.assert_array_equal(beam, want["beam"])
+    np.testing.assert_array_equal(quality, want["quality"])
+    np.testing.assert_array_equal(w, want["weights"])     # pf.h normalises on the host in this route: the reference's own code
+    assert tail[3] == lik[0] and tail[4] == quality[0]
 
 
 def test_rest_of_the_plugin_surface(tmp_path):
