@@ -1059,10 +1059,13 @@ def main():
                                "fp64 tree (terms bit-identical to the reference's float terms)"),
                 "lik_coop": lik_coop,
             },
-            "value_definition": "value = value_device_resident: inputs (map structures, ordered scan, poses, prior weights) in HBM "
-                                "before the timed region, as the bench contract defines `value` (the PCIe-inclusive rate is "
-                                "never `value`); value_8d = SURVEY.md section 8d's region (scan upload + pose / weight H2D + "
-                                "kernels + weight D2H from / to host buffers), timed in the same run",
+            "value_definition": "value = value_device_resident at every N: inputs (map structures, ordered scan, poses, prior "
+                                "weights) in HBM before the timed region — the bench contract's wording ('inputs already resident in "
+                                "HBM when the timed region starts ... the PCIe-inclusive rate is never `value`'), and the one "
+                                "region that is the same code path at N = 1 and N > 1, so that the driver's scaling efficiency "
+                                "compares like with like. The METRIC's own region (SURVEY.md section 8d: scan upload + pose / weight "
+                                "H2D + kernels + weight D2H from / to host buffers) is `headline.value_8d` below, timed in the same "
+                                "run from C; it is the lower of the two and the one DESIGN.md quotes as the update rate",
             "value_device_resident": value,
             "value_8d": None,
             "roofline": roofline,
@@ -1158,6 +1161,20 @@ def main():
                 if a is not None:
                     eng.host_free(a)
             out["value_8d"] = n_p * n_s / (host_ms * 1e-3)
+            fp = out["index"]["footprint_bytes"]
+            index_bytes = int(fp["cand_table"] + fp["cand_start"] + fp["cand_points"])
+            map_bytes = 16 * int(len(sc.map_xyz))
+            out["headline"] = {
+                "value_8d": out["value_8d"], "ms_per_update_8d": host_ms, "update_hz_8d": 1e3 / host_ms,
+                "value_device_resident": value, "ms_per_step_device_resident": ms_per_step,
+                "region_8d": "SURVEY.md section 8d: host buffers in (scan, poses, prior weights), host buffers out (weights, "
+                             "likelihoods), PCIe and scan ordering included — mcl3dl_hip_measure_update timed from C",
+                "likelihood_sum": out["config"]["accumulate"],
+                "index_bytes": index_bytes, "map_bytes": map_bytes, "index_bytes_per_map_byte": index_bytes / max(map_bytes, 1),
+            }
+            roofline["frac_of_update"] = {"device_resident": lik_avg_ms / ms_per_step if lik_n else None,
+                                          "update_8d": lik_avg_ms / host_ms if lik_n else None,
+                                          "what": "dominant kernel's average launch time / time of one whole update"}
             out["update_8d"] = {"ms_per_update": host_ms, "value": n_p * n_s / (host_ms * 1e-3),
                                 "unit": "particle·point evals/s", "update_hz": 1e3 / host_ms, "steps": args.steps,
                                 "median_ms": float(np.median(per)), "min_ms": float(per.min()),

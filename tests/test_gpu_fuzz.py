@@ -138,6 +138,16 @@ def test_random_configuration(engine, oracle_kind, seed):
                                                 c["scan_beam_label"] if has_beam else None, c["origins"])
         np.testing.assert_array_equal(lik, want_lik)
         np.testing.assert_array_equal(ratio, want_q)
+        # strict_order = 3: the same recurrence inside the likelihood kernel, over the scan in the engine's order — bit-identical
+        # to the reference on the scan permuted that way (round 5: no term array, no replay pass)
+        if len(c["scan_lik"]):
+            engine.set_option("strict_order", 3)
+            lik3, ratio3, _ = engine.measure_batch(c["poses"], c["scan_lik"])
+            order = engine.scan_order(len(c["scan_lik"]))
+            want3, want_q3 = o.likelihood_measure(c["poses"], np.ascontiguousarray(c["scan_lik"][order]))
+            np.testing.assert_array_equal(lik3, want3)
+            np.testing.assert_array_equal(ratio3, want_q3)
+            np.testing.assert_array_equal(want_q3, want_q)
         # default: the same float terms summed in fp64. What is left is the rounding of the REFERENCE's own float
         # running sum (bounded by n_s * 2^-24 relative, ~sqrt(n_s) * 2^-24 typical): inside north_star's 1e-5 for the
         # scan sizes of BASELINE.json's configs (tests/test_gpu_parity.py, test_gpu_fullsize.py), up to ~2e-5 on the
