@@ -120,6 +120,14 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_sync = static_cast<int>(value);
     return 0;
   }
+  if (key == "test_late_structures")
+  {
+    const char* hooks = getenv("MCL3DL_HIP_TEST_HOOKS");
+    if (!hooks || std::string(hooks) != "1")
+      return ctx->fail(-3, "test_late_structures is a test hook: set MCL3DL_HIP_TEST_HOOKS=1 in the environment to enable it");
+    ctx->test_late_structures = value != 0.0;
+    return 0;
+  }
   if (key == "poll_spin_us")
   {
     if (!(value >= 0.0 && value <= 1e9))

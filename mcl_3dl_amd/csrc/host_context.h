@@ -154,6 +154,7 @@ struct mcl3dl_hip_ctx
   // costs its caller ~2 ms of CPU, not 25), with hipStreamQuery looked at every few milliseconds so that a faulted queue
   // comes back as an error instead of an endless wait
   double poll_spin_us = 2000.0;
+  bool test_late_structures = false;  // fault injection for the API-sequence fuzz (option of the same name, test hooks only)
   volatile unsigned* done_flag = nullptr;
   unsigned done_seq = 0;
   // strict_order = 3 (likelihood_kernels.h: LikChain): hand-off words, their tag counter, the page-locked error word

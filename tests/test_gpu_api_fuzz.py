@@ -67,9 +67,14 @@ class Model:
         self.oracle_state = None
 
 
+INJECT = os.environ.get("MCL3DL_FUZZ_INJECT", "")   # a test-hook option switched on for every sequence (fault injection)
+
+
 def reset_options(obj):
     for k, v in DEFAULTS.items():
         obj.set_option(k, v)
+    if INJECT:
+        obj.set_option(INJECT, 1)
 
 
 def oracle_for(m, kind, cache):
@@ -405,3 +410,18 @@ def test_random_call_sequences_against_the_reference(engine, group2, fresh_engin
         except Exception:
             print("\nsequence seed %d failed after:\n  " % (9000 + seed) + "\n  ".join(log))
             raise
+
+
+def test_the_fuzz_finds_the_round_4_staging_hazard_again():
+    """'the r04ad hazard reproduces on the pre-fix commit'. The fix (three lines: build lazily-built
+    structures BEFORE the staged update allocates its staging memory, api_core.inl:measure_update_staged) and the mode that
+    exposed it (poll_sync = 2) arrived in one commit, so the pre-fix state is re-created by a test hook that takes those three
+    lines out again — and the same fuzz, run in a child process with the hook on, must FAIL."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MCL3DL_HIP_TEST_HOOKS="1", MCL3DL_FUZZ_INJECT="test_late_structures", MCL3DL_FUZZ_SEQUENCES="120")
+    proc = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "random_call_sequences",
+                           "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env,
+                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = proc.stdout[-3000:]
+    assert proc.returncode != 0 and "sequence seed" in proc.stdout, "the injected hazard went unnoticed:\n" + tail
