@@ -536,6 +536,17 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       the reference's measure() on the scan permuted that way; no term buffer, no replay pass (the
  *                       work-group of a scan tile hands each particle's running sum on to the next tile's). Weights are
  *                       summed as in mode 2. Suits callers whose scan order means nothing to them (a sampled cloud).
+ *   "index_budget_bytes"  upper bound of the candidate-voxel records (the bulk of the likelihood index: one 64-byte record per
+ *                       voxel of every 8 x 8 x 8-voxel brick within reach of a map point): -1 (default) = a quarter of the
+ *                       device's memory, 0 = none. The index is laid out, in this order, with cubes of edge r / 2 (fastest),
+ *                       with BOXES whose edges follow the dist_weight axis by axis (option "cand_aniso" below: the shipped
+ *                       z x 5 then costs the memory of the unit-weight map — a quarter — at 1.04-1.14 x the kernel time),
+ *                       with coarser voxels (up to 1.5 r), and fails with the number of bytes it would need when even those
+ *                       do not fit. Results are the same bits whatever the voxel shape. Read-only: "index_record_bytes",
+ *                       "index_budget_in_use", "cand_aniso_active", "cand_edge_ratio_x/_y/_z" (voxel edge / match_dist_min)
+ *   "cand_aniso"        voxel shape of the candidate index under a dist_weight: 0 = cubes always, 1 = boxes always (edge of
+ *                       axis a = base edge x min(w_a / w_min, "cand_aniso_max" = 8)), 2 (default) = boxes when the cubes
+ *                       exceed the budget
  *   "poll_spin_us"      how long a completion wait spins on its page-locked word before it starts napping between looks
  *                       (default 2000: every update up to a few thousand particles completes inside the spin); the naps
  *                       grow with the time already waited (1/32 of it, 1 ms at most) and hipStreamQuery is consulted every

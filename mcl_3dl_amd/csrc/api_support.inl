@@ -72,6 +72,33 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->cand_voxel_ratio = value;
     return 0;
   }
+  if (key == "cand_aniso")
+  {
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return ctx->fail(-3, "cand_aniso must be 0 (cubes), 1 (boxes that follow the dist_weight) or 2 (boxes when cubes exceed the budget)");
+    if (static_cast<int>(value) != ctx->cand_aniso)
+      ctx->cand_dirty = true;
+    ctx->cand_aniso = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "cand_aniso_max")
+  {
+    if (!(value >= 1.0 && value <= 64.0))
+      return ctx->fail(-3, "cand_aniso_max must be in [1, 64]");
+    if (value != ctx->cand_aniso_max)
+      ctx->cand_dirty = true;
+    ctx->cand_aniso_max = value;
+    return 0;
+  }
+  if (key == "index_budget_bytes")
+  {
+    if (!(value >= 0.0 || value == -1.0))
+      return ctx->fail(-3, "index_budget_bytes must be >= 0 (0 = no budget) or -1 (a quarter of the device's memory)");
+    if (value != ctx->index_budget_opt)
+      ctx->cand_dirty = true;
+    ctx->index_budget_opt = value;
+    return 0;
+  }
   if (key == "strict_order")
   {
     if (!(value == 0.0 || value == 1.0 || value == 2.0 || value == 3.0))
@@ -369,6 +396,16 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   if (key == "lik_index") *value = ctx->lik_index;
   else if (key == "cand_voxel_ratio") *value = ctx->cand_voxel_ratio;
   else if (key == "cand_phase") *value = ctx->cand_phase;
+  else if (key == "cand_aniso") *value = ctx->cand_aniso;
+  else if (key == "cand_aniso_max") *value = ctx->cand_aniso_max;
+  else if (key == "index_budget_bytes") *value = ctx->index_budget_opt;
+  else if (key == "index_budget_in_use") *value = ctx->index_budget_bytes;
+  else if (key == "cand_aniso_active") *value = ctx->cand_aniso_active ? 1.0 : 0.0;
+  else if (key == "cand_edge_ratio_x") *value = ctx->cand_edge_ratio[0];
+  else if (key == "cand_edge_ratio_y") *value = ctx->cand_edge_ratio[1];
+  else if (key == "cand_edge_ratio_z") *value = ctx->cand_edge_ratio[2];
+  else if (key == "index_record_bytes") *value = static_cast<double>(ctx->footprint[6]);
+  else if (key == "index_note") *value = ctx->index_note.empty() ? 0.0 : 1.0;
   else if (key == "cand_record_parts") *value = ctx->cand_record_parts;
   else if (key == "cand_record_parts_in_use") *value = ctx->cand_parts;
   else if (key == "cand_voxels_over8") *value = ctx->cand_over8;

@@ -192,6 +192,13 @@ struct mcl3dl_hip_ctx
   }
   double cand_voxel_ratio = 0.0;  // voxel edge / match_dist_min; 0 = chosen per map (host_map_compilers.h:build_cand_grid)
   double cand_phase = 0.5;        // grid origin shifted by this fraction of a voxel (see build_cand_grid)
+  int cand_aniso = 2;             // option: voxel edges follow the dist_weight axis by axis (host_map_compilers.h:cand_axis_stretch): 0 never, 1 always, 2 when cubes exceed the budget
+  bool cand_aniso_active = false; // ... what the index in place was built with
+  double cand_aniso_max = 8.0;    // ... up to this factor over the base edge
+  double index_budget_opt = -1.0;   // option index_budget_bytes: upper bound of the candidate records; -1 = a quarter of the device's memory, 0 = none
+  double index_budget_bytes = 0.0;  // ... resolved at build time
+  double cand_need_bytes = 0.0;     // record bytes the last priced voxel edge needs
+  double cand_edge_ratio[3] = { 0.5, 0.5, 0.5 };  // voxel edge / match_dist_min of the index in place, per axis
   int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
   // sharper pruning of crowded voxels (map_compiler.h:mc_prune_boxed, pass 1b): voxels that keep more than
   // cand_refine_above candidates have them tested per sub-box of a cand_refine^3 subdivision (1 = off)

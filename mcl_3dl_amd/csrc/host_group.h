@@ -108,7 +108,7 @@ public:
     bool done = false;
     for (long spin = 0; !(done = pending_.load(std::memory_order_acquire) == 0); ++spin)
     {
-      __builtin_ia32_pause();
+      cpu_relax();
       if ((spin & 1023) == 1023 &&
           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0)
         break;
@@ -148,7 +148,7 @@ private:
           have = true;
           break;
         }
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spin & 255) == 255 &&
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > SPIN_US)
           break;

@@ -313,23 +313,63 @@ int device_exclusive_scan_ws(mcl3dl_hip_ctx* ctx, uint32_t* data, long long n, u
 }
 
 // Geometry of the candidate-voxel grid for a point set with the given bounds (rescaled coordinates).
-int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const float mn[3], const float mx[3], CompileParams* out,
-                  long long* n_table_out)
+// How much longer than the base edge a voxel is along each axis: 1 without a dist_weight; with one (option "cand_aniso",
+// default on) the axis weight relative to the smallest weight, capped — src/mcl_3dl.cpp:1270 stretches the map along an axis
+// (the shipped default: z x 5, src/parameters.cpp:108-110), which thins the map's points out along it in the metric the query
+// ball lives in, so a voxel stretched the same way holds the candidates an unstretched map's cube would, and there are that
+// many fewer voxels (walls at z x 5: a fifth; the +-r shell around a floor: 2-3 layers instead of 4-5).
+void cand_axis_stretch(const mcl3dl_hip_ctx* ctx, double stretch[3])
+{
+  stretch[0] = stretch[1] = stretch[2] = 1.0;
+  if (!ctx->cand_aniso_active || !ctx->has_weight)
+    return;
+  double wmin = 0.0;
+  for (int a = 0; a < 3; ++a)
+  {
+    const double w = std::fabs(static_cast<double>(ctx->weight[a]));
+    if (w > 0.0 && (wmin == 0.0 || w < wmin))
+      wmin = w;
+  }
+  if (!(wmin > 0.0))
+    return;
+  for (int a = 0; a < 3; ++a)
+  {
+    const double w = std::fabs(static_cast<double>(ctx->weight[a]));
+    stretch[a] = std::min(std::max(w / wmin, 1.0), ctx->cand_aniso_max);
+  }
+}
+
+int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const double stretch[3], const float mn[3], const float mx[3],
+                  CompileParams* out, long long* n_table_out)
 {
   const double r = static_cast<double>(ctx->match_dist_min);
-  const float e_f = static_cast<float>(r * voxel_ratio);
-  if (!(e_f > 0.f) || !std::isfinite(e_f))
-    return ctx->fail(-3, "bad candidate voxel edge");
+  float e_f[3];
+  for (int a = 0; a < 3; ++a)
+  {
+    e_f[a] = static_cast<float>(r * voxel_ratio * stretch[a]);
+    if (!(e_f[a] > 0.f) || !std::isfinite(e_f[a]))
+      return ctx->fail(-3, "bad candidate voxel edge");
+  }
   CompileParams cp{};
-  cp.e = static_cast<double>(e_f);
-  cp.inv_e = 1.0f / e_f;
-  cp.grow = 1e-3 * cp.e;
+  cp.ex = static_cast<double>(e_f[0]);
+  cp.ey = static_cast<double>(e_f[1]);
+  cp.ez = static_cast<double>(e_f[2]);
+  cp.inv_ex = 1.0f / e_f[0];
+  cp.inv_ey = 1.0f / e_f[1];
+  cp.inv_ez = 1.0f / e_f[2];
+  const double ed[3] = { cp.ex, cp.ey, cp.ez };
+  cp.grow = 1e-3 * std::min(cp.ex, std::min(cp.ey, cp.ez));
   const double r_hi = r * (1.0 + 1e-5);
   cp.r2_hi = r_hi * r_hi;
   cp.margin = 1e-5 * r * r;
   cp.refine = ctx->cand_refine;
   cp.refine_above = ctx->cand_refine_above;
-  cp.reach = static_cast<int>(std::floor((r_hi + cp.grow) / cp.e)) + 1;
+  int reach[3];
+  for (int a = 0; a < 3; ++a)
+    reach[a] = static_cast<int>(std::floor((r_hi + cp.grow) / ed[a])) + 1;
+  cp.rx = reach[0];
+  cp.ry = reach[1];
+  cp.rz = reach[2];
   float o[3];
   int nv[3], nb[3];
   double n_table_d = 1;
@@ -338,8 +378,8 @@ int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const float mn[3], co
     // Phase: maps that come out of a voxel filter sit on a lattice; with the origin ON that lattice every voxel face
     // coincides with a Voronoi face of the map and each voxel keeps 3 candidates per axis instead of the 2 a generic
     // position needs. Half a voxel of phase puts lattice maps in the generic position; arbitrary maps do not care.
-    o[a] = mn[a] - static_cast<float>((cp.reach + 1 + ctx->cand_phase) * cp.e);
-    nv[a] = static_cast<int>(std::floor((static_cast<double>(mx[a]) - o[a]) / cp.e)) + cp.reach + 2;
+    o[a] = mn[a] - static_cast<float>((reach[a] + 1 + ctx->cand_phase) * ed[a]);
+    nv[a] = static_cast<int>(std::floor((static_cast<double>(mx[a]) - o[a]) / ed[a])) + reach[a] + 2;
     nb[a] = (nv[a] + 7) / 8;
     n_table_d *= nb[a];
   }
@@ -429,8 +469,7 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
 {
   const size_t n = static_cast<size_t>(cp.n_points);
   const long long n_vox = static_cast<long long>(n_bricks) * 512;
-  const int side = 2 * cp.reach + 1;
-  const long long n_threads = static_cast<long long>(n) * side * side * side;
+  const long long n_threads = static_cast<long long>(n) * (2 * cp.rx + 1) * (2 * cp.ry + 1) * (2 * cp.rz + 1);
   const unsigned blocks_t = static_cast<unsigned>((n_threads + 255) / 256);
   if ((n_threads + 255) / 256 > 0x7fffffffLL)
     return ctx->fail(-4, "candidate index: too many (point, voxel) pairs");
@@ -546,6 +585,10 @@ int compile_bricks(mcl3dl_hip_ctx* ctx, const CompileParams& cp, const float4* p
   return 0;
 }
 
+// returns 0, an error (< 0), or RC_OVER_BUDGET: the records would exceed option "index_budget_bytes" (ctx->cand_need_bytes says
+// by how much; nothing has been allocated or replaced: the previous index, if any, is still in place)
+constexpr int RC_OVER_BUDGET = 1;
+
 int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4)
 {
   const unsigned long long rec_bytes = 16ull * cap;  // per voxel
@@ -571,7 +614,9 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   const float* mx = mm + 3;
   CompileParams cp{};
   long long n_table = 0;
-  TRY(cand_geometry(ctx, voxel_ratio, mn, mx, &cp, &n_table));
+  double stretch[3];
+  cand_axis_stretch(ctx, stretch);
+  TRY(cand_geometry(ctx, voxel_ratio, stretch, mn, mx, &cp, &n_table));
   cp.n_points = static_cast<int>(n);
 
   TempBuf d_flag, d_scan, d_bxyz;
@@ -589,6 +634,9 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   TRY(sync_stream(ctx));
   if (n_bricks == 0 || n_bricks > (1u << 22))
     return ctx->fail(-4, "candidate index: %u bricks", n_bricks);
+  ctx->cand_need_bytes = static_cast<double>(rec_bytes) * 512.0 * n_bricks;
+  if (ctx->lik_index == 2 && ctx->index_budget_bytes > 0.0 && ctx->cand_need_bytes > ctx->index_budget_bytes)
+    return RC_OVER_BUDGET;
   // one entry more than the grid has bricks: entry n_table is always -1, the entry lanes without a voxel read (eval_coop)
   TRY(ensure(ctx, ctx->cand_table, sizeof(int) * (n_table + 1)));
   int* table = ctx->cand_table.as<int>();
@@ -630,7 +678,9 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     g.ox = cp.ox;
     g.oy = cp.oy;
     g.oz = cp.oz;
-    g.inv_e = cp.inv_e;
+    g.inv_ex = cp.inv_ex;
+    g.inv_ey = cp.inv_ey;
+    g.inv_ez = cp.inv_ez;
     g.nvx = cp.nvx;
     g.nvy = cp.nvy;
     g.nvz = cp.nvz;
@@ -656,7 +706,10 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     ctx->cand_stats[5] = static_cast<double>(co.hist3[1]);
     ctx->cand_over8 = static_cast<double>(co.hist3[2]);
     ctx->cand_stats[6] = n_ovf;
-    ctx->cand_stats[7] = cp.e / static_cast<double>(ctx->match_dist_min);
+    ctx->cand_stats[7] = cp.ex / static_cast<double>(ctx->match_dist_min);
+    ctx->cand_edge_ratio[0] = cp.ex / static_cast<double>(ctx->match_dist_min);
+    ctx->cand_edge_ratio[1] = cp.ey / static_cast<double>(ctx->match_dist_min);
+    ctx->cand_edge_ratio[2] = cp.ez / static_cast<double>(ctx->match_dist_min);
     ctx->cand_dirty = false;
     return 0;
   }
@@ -684,7 +737,9 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
   g.ox = cp.ox;
   g.oy = cp.oy;
   g.oz = cp.oz;
-  g.inv_e = cp.inv_e;
+  g.inv_ex = cp.inv_ex;
+  g.inv_ey = cp.inv_ey;
+  g.inv_ez = cp.inv_ez;
   g.nvx = cp.nvx;
   g.nvy = cp.nvy;
   g.nvz = cp.nvz;
@@ -706,14 +761,61 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
 // unless more than a quarter of the voxels with candidates hold more than the four a record has room for (maps of
 // voxel-filter centroids rather than lattice points: DESIGN.md section 6), then 0.36 r: the second fetch round per
 // evaluation costs more than the larger table (measured: jittered C2 0.49 -> 0.37 ms, lattice C2 +2 %).
+// One attempt under the footprint budget (option "index_budget_bytes", 0 = none): when the records of the wanted voxel edge
+// would exceed it, the edge is coarsened (records ~ 1 / edge^2 on a map of surfaces; the mark-and-count passes that price an
+// edge cost a millisecond and allocate nothing) until they fit — larger voxels hold more candidates, the tiled kernel's queued
+// overflow rounds take them, results stay the same bits — and when even the coarsest edge the record format can describe
+// (1.5 r: a voxel then reaches the 63 candidates the packed word counts) does not fit, the build fails with what it would need.
+int build_cand_grid_budgeted(mcl3dl_hip_ctx* ctx, double ratio, uint32_t cap, double* ratio_used = nullptr)
+{
+  // the budget: option index_budget_bytes; -1 (default) = a quarter of the device's memory, 0 = none
+  if (ctx->index_budget_opt < 0.0)
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      total_b = 0;
+    }
+    ctx->index_budget_bytes = 0.25 * static_cast<double>(total_b);
+  }
+  else
+    ctx->index_budget_bytes = ctx->index_budget_opt;
+  // cubes first (fastest: profiles/r05e_aniso_ab.txt); boxes that follow the dist_weight when the cubes do not fit the budget
+  // (option cand_aniso = 2, the default; 1 = always boxes, 0 = never); then coarser voxels
+  const bool can_stretch = ctx->has_weight && ctx->cand_aniso != 0;
+  ctx->cand_aniso_active = ctx->cand_aniso == 1 && can_stretch;
+  for (int attempt = 0; attempt < 8; ++attempt)
+  {
+    const int rc = build_cand_grid_at(ctx, ratio, cap);
+    if (rc != RC_OVER_BUDGET)
+    {
+      if (rc == 0 && ratio_used)
+        *ratio_used = ratio;
+      return rc;
+    }
+    if (can_stretch && !ctx->cand_aniso_active)
+    {
+      ctx->cand_aniso_active = true;
+      continue;
+    }
+    if (ratio >= 1.5)
+      break;
+    ratio = std::min(1.5, ratio * std::sqrt(ctx->cand_need_bytes / ctx->index_budget_bytes) * 1.08);
+  }
+  return ctx->fail(-4, "the candidate index needs %.3g bytes of records at its coarsest voxel edge (1.5 x match_dist_min), the "
+                       "budget (option index_budget_bytes) is %.3g", ctx->cand_need_bytes, ctx->index_budget_bytes);
+}
+
 int build_cand_grid(mcl3dl_hip_ctx* ctx)
 {
   const uint32_t forced = ctx->cand_record_parts == 8 ? 8u : ctx->cand_record_parts == 4 ? 4u : 0u;
   if (ctx->cand_voxel_ratio > 0.0)
-    return build_cand_grid_at(ctx, ctx->cand_voxel_ratio, forced ? forced : 4u);
-  TRY(build_cand_grid_at(ctx, 0.5, forced ? forced : 4u));
+    return build_cand_grid_budgeted(ctx, ctx->cand_voxel_ratio, forced ? forced : 4u);
+  double base = 0.5;
+  TRY(build_cand_grid_budgeted(ctx, 0.5, forced ? forced : 4u, &base));
   const double crowded = forced == 8 ? ctx->cand_over8 : ctx->cand_stats[5];  // voxels whose candidates do not fit the record
-  if (ctx->lik_index == 2 && ctx->cand_stats[4] > 0 && crowded / ctx->cand_stats[4] > 0.25)
+  if (base == 0.5 && ctx->lik_index == 2 && ctx->cand_stats[4] > 0 && crowded / ctx->cand_stats[4] > 0.25)
   {
     // a crowded map (voxel-filter centroids rather than a lattice): smaller voxels, and — unless the record size is forced
     // or the tiled kernel queues its overflow rounds (below) — 128-byte records with eight inline candidates when they stay
@@ -729,19 +831,24 @@ int build_cand_grid(mcl3dl_hip_ctx* ctx)
     // 0.326 ms against 0.340 with 128-byte records at 0.36 r on that map, 0.316 at 0.30 r (profiles/r03u_defer_ab.txt)
     const uint32_t cap = forced ? forced : (defer ? 4u : est_bytes < 16.0e9 ? 8u : 4u);
     // the finer index is an optimisation of a valid one: only attempt it where it fits (brick limit of the dense table,
-    // memory), and if it fails all the same, put the r / 2 index back — a map the coarser default handles must keep working
+    // memory, the footprint budget), and if it fails all the same, put the r / 2 index back — a map the coarser default
+    // handles must keep working
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const double need = (cap == 8 ? 128.0 : 64.0) * 512.0 * est_bricks * 1.5;
-    if (est_bricks < 0.9 * static_cast<double>(1u << 22) && need < 0.8 * static_cast<double>(free_b))
+    const bool in_budget = ctx->index_budget_bytes <= 0.0 || need / 1.5 * 1.1 < ctx->index_budget_bytes;
+    if (est_bricks < 0.9 * static_cast<double>(1u << 22) && need < 0.8 * static_cast<double>(free_b) && in_budget)
     {
-      if (build_cand_grid_at(ctx, fine, cap) == 0)
+      const int rc = build_cand_grid_at(ctx, fine, cap);
+      if (rc == 0)
         ctx->cand_stats[3] += first_ms;
+      else if (rc == RC_OVER_BUDGET)
+        ctx->index_note = "finer candidate index not built (over index_budget_bytes): voxel edge r / 2 kept";
       else
       {
         const std::string why = ctx->err;
         ctx->cand_dirty = true;  // its buffers may have been re-allocated under the first index
-        TRY(build_cand_grid_at(ctx, 0.5, forced ? forced : 4u));
+        TRY(build_cand_grid_budgeted(ctx, 0.5, forced ? forced : 4u));
         ctx->cand_stats[3] += first_ms;
         ctx->index_note = "finer candidate index not built (" + why + "): voxel edge r / 2 kept";
       }
@@ -837,11 +944,12 @@ int update_cand_grid(mcl3dl_hip_ctx* ctx, size_t n_base, const std::vector<float
   // every added point, with its reach, must lie inside the grid the index was laid out for
   for (const float4& p : fresh)
   {
-    const int v[3] = { static_cast<int>(floorf((p.x - cp.ox) * cp.inv_e)), static_cast<int>(floorf((p.y - cp.oy) * cp.inv_e)),
-                       static_cast<int>(floorf((p.z - cp.oz) * cp.inv_e)) };
+    const int v[3] = { static_cast<int>(floorf((p.x - cp.ox) * cp.inv_ex)), static_cast<int>(floorf((p.y - cp.oy) * cp.inv_ey)),
+                       static_cast<int>(floorf((p.z - cp.oz) * cp.inv_ez)) };
     const int nv[3] = { cp.nvx, cp.nvy, cp.nvz };
+    const int reach[3] = { cp.rx, cp.ry, cp.rz };
     for (int a = 0; a < 3; ++a)
-      if (v[a] - cp.reach - 1 < 0 || v[a] + cp.reach + 1 >= nv[a])
+      if (v[a] - reach[a] - 1 < 0 || v[a] + reach[a] + 1 >= nv[a])
       {
         if (stats5)
           stats5[5] = 4;

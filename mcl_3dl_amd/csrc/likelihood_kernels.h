@@ -60,9 +60,9 @@ __device__ inline float nearest_d2(const LikGrid& g, float qx, float qy, float q
 template <bool STATS>
 __device__ inline float nearest_d2_cand(const CandGrid& g, float qx, float qy, float qz, unsigned& n_tested)
 {
-  const float fx = floorf((qx - g.ox) * g.inv_e);
-  const float fy = floorf((qy - g.oy) * g.inv_e);
-  const float fz = floorf((qz - g.oz) * g.inv_e);
+  const float fx = floorf((qx - g.ox) * g.inv_ex);
+  const float fy = floorf((qy - g.oy) * g.inv_ey);
+  const float fz = floorf((qz - g.oz) * g.inv_ez);
   float best = 3.0e38f;
   if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
         fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
@@ -174,9 +174,9 @@ __device__ inline int floor_to_int(float x)
 // bricks: build_cand_grid) with 24-bit multiplies where build_cand_grid found every factor below 2^24.
 __device__ inline bool rec_locate(const RecGrid& g, float qx, float qy, float qz, uint32_t& ti, uint32_t& sub)
 {
-  const int vx = floor_to_int((qx - g.ox) * g.inv_e);
-  const int vy = floor_to_int((qy - g.oy) * g.inv_e);
-  const int vz = floor_to_int((qz - g.oz) * g.inv_e);
+  const int vx = floor_to_int((qx - g.ox) * g.inv_ex);
+  const int vy = floor_to_int((qy - g.oy) * g.inv_ey);
+  const int vz = floor_to_int((qz - g.oz) * g.inv_ez);
   if (g.mul24_ok)
     ti = __umul24(static_cast<uint32_t>(vz >> 3), static_cast<uint32_t>(g.nbx * g.nby)) +
          __umul24(static_cast<uint32_t>(vy >> 3), static_cast<uint32_t>(g.nbx)) + static_cast<uint32_t>(vx >> 3);

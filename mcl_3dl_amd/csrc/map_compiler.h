@@ -29,21 +29,23 @@ struct CandGrid
   const uint32_t* vox_start;   // [n_bricks*512 + 1] run delimiters into cand
   const float4* cand;          // rescaled x,y,z ; w = original map index (bits)
   float ox, oy, oz;            // origin of voxel (0,0,0), rescaled coordinates
-  float inv_e;                 // 1 / voxel edge
+  float inv_ex, inv_ey, inv_ez;  // 1 / voxel edge, per axis (round 5: voxels are boxes — an axis the metric stretches gets a longer edge)
   int nvx, nvy, nvz;           // voxel-grid extent
   int nbx, nby, nbz;           // brick-grid extent (= ceil(nv / 8))
 };
 
 struct CompileParams
 {
-  float ox, oy, oz, inv_e;
-  double e;       // voxel edge
+  float ox, oy, oz, inv_ex, inv_ey, inv_ez;
+  double ex, ey, ez;  // voxel edges (rescaled coordinates). Every step of the candidate proof is per axis (boxes V, V+), so a
+                      // voxel may be a box: dist_weight stretches the map along an axis and thins its points out there in the
+                      // metric — an edge stretched likewise keeps the candidates per voxel and divides the voxel count
   double grow;    // V+ = V grown by this on every side
   double r2_hi;   // (r*(1+1e-5))^2
   double margin;  // domination margin m
   int refine;        // crowded voxels: domination tested per sub-box of a refine^3 subdivision (1 = whole voxel only)
   int refine_above;  // ... when more than this many candidates survive the whole-voxel test
-  int reach;      // voxels to visit around a point's own voxel
+  int rx, ry, rz;  // voxels to visit around a point's own voxel, per axis
   int nvx, nvy, nvz, nbx, nby, nbz;
   int n_points;
 };
@@ -51,8 +53,8 @@ struct CompileParams
 __device__ inline int3 voxel_of(const CompileParams& c, const float4 p)
 {
   // the same float expression the query kernel evaluates
-  return make_int3(static_cast<int>(floorf((p.x - c.ox) * c.inv_e)), static_cast<int>(floorf((p.y - c.oy) * c.inv_e)),
-                   static_cast<int>(floorf((p.z - c.oz) * c.inv_e)));
+  return make_int3(static_cast<int>(floorf((p.x - c.ox) * c.inv_ex)), static_cast<int>(floorf((p.y - c.oy) * c.inv_ey)),
+                   static_cast<int>(floorf((p.z - c.oz) * c.inv_ez)));
 }
 
 __device__ inline long long brick_index(const CompileParams& c, int vx, int vy, int vz)
@@ -72,12 +74,13 @@ __device__ inline void box_dist2(const CompileParams& c, const float4 p, int vx,
   const double pc[3] = { static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z) };
   const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
   const int v[3] = { vx, vy, vz };
+  const double ed[3] = { c.ex, c.ey, c.ez };
   dmin2 = 0.0;
   dmax2 = 0.0;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
   {
-    const double lo = o[a] + v[a] * c.e - c.grow, hi = o[a] + (v[a] + 1) * c.e + c.grow;
+    const double lo = o[a] + v[a] * ed[a] - c.grow, hi = o[a] + (v[a] + 1) * ed[a] + c.grow;
     const double below = lo - pc[a], above = pc[a] - hi;
     const double out = below > 0 ? below : (above > 0 ? above : 0.0);
     dmin2 += out * out;
@@ -91,16 +94,16 @@ __device__ inline void box_dist2(const CompileParams& c, const float4 p, int vx,
 __device__ inline bool visit(const CompileParams& c, const float4* __restrict__ pts, long long t, int& pi, int& vx,
                              int& vy, int& vz)
 {
-  const int side = 2 * c.reach + 1;
-  const int per = side * side * side;
+  const int sx = 2 * c.rx + 1, sy = 2 * c.ry + 1, sz = 2 * c.rz + 1;
+  const int per = sx * sy * sz;
   pi = static_cast<int>(t / per);
   if (pi >= c.n_points)
     return false;
   const int o = static_cast<int>(t - static_cast<long long>(pi) * per);
   const int3 pv = voxel_of(c, pts[pi]);
-  vx = pv.x + (o % side) - c.reach;
-  vy = pv.y + ((o / side) % side) - c.reach;
-  vz = pv.z + (o / (side * side)) - c.reach;
+  vx = pv.x + (o % sx) - c.rx;
+  vy = pv.y + ((o / sx) % sy) - c.ry;
+  vz = pv.z + (o / (sx * sy)) - c.rz;
   return vx >= 0 && vy >= 0 && vz >= 0 && vx < c.nvx && vy < c.nvy && vz < c.nvz;
 }
 
@@ -111,9 +114,9 @@ __global__ void mc_mark_bricks(CompileParams c, const float4* __restrict__ pts, 
   if (pi >= c.n_points)
     return;
   const int3 v = voxel_of(c, pts[pi]);
-  const int x0 = max(v.x - c.reach, 0) >> 3, x1 = min(v.x + c.reach, c.nvx - 1) >> 3;
-  const int y0 = max(v.y - c.reach, 0) >> 3, y1 = min(v.y + c.reach, c.nvy - 1) >> 3;
-  const int z0 = max(v.z - c.reach, 0) >> 3, z1 = min(v.z + c.reach, c.nvz - 1) >> 3;
+  const int x0 = max(v.x - c.rx, 0) >> 3, x1 = min(v.x + c.rx, c.nvx - 1) >> 3;
+  const int y0 = max(v.y - c.ry, 0) >> 3, y1 = min(v.y + c.ry, c.nvy - 1) >> 3;
+  const int z0 = max(v.z - c.rz, 0) >> 3, z1 = min(v.z + c.rz, c.nvz - 1) >> 3;
   for (int z = z0; z <= z1; ++z)
     for (int y = y0; y <= y1; ++y)
       for (int x = x0; x <= x1; ++x)
@@ -224,10 +227,11 @@ __device__ inline void prune_voxel_serial(const CompileParams& c, const float4* 
   const int vc[3] = { brick_xyz[3 * b + 0] * 8 + (l & 7), brick_xyz[3 * b + 1] * 8 + ((l >> 3) & 7),
                       brick_xyz[3 * b + 2] * 8 + (l >> 6) };
   const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
-  double ctr[3], half;
-  half = 0.5 * c.e + c.grow;
+  double ctr[3];
+  const double ed[3] = { c.ex, c.ey, c.ez };
+  const double hx = 0.5 * c.ex + c.grow, hy = 0.5 * c.ey + c.grow, hz = 0.5 * c.ez + c.grow;
   for (int a = 0; a < 3; ++a)
-    ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
+    ctr[a] = o[a] + (vc[a] + 0.5) * ed[a];
   // pass 1: mark dominated candidates (bit 31 of the stored id). Every pair is compared while the list is short (the
   // normal case: ~10 entries); a long list (huge match_dist_min relative to the map spacing) is compared against its
   // PRUNE_K entries nearest to the voxel centre only — the likely dominators — which keeps the work linear in the list
@@ -274,7 +278,7 @@ __device__ inline void prune_voxel_serial(const CompileParams& c, const float4* 
       const double qx = q.x - ctr[0], qy = q.y - ctr[1], qz = q.z - ctr[2];
       // g(x) = |x-p|^2 - |x-q|^2 = 2 x.(q-p) + |p|^2 - |q|^2 ; its minimum over the box [-half, half]^3
       const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
-      const double gmin = pp - (qx * qx + qy * qy + qz * qz) - half * (fabs(cx) + fabs(cy) + fabs(cz));
+      const double gmin = pp - (qx * qx + qy * qy + qz * qz) - (hx * fabs(cx) + hy * fabs(cy) + hz * fabs(cz));
       dominated = gmin > c.margin;
     }
     if (dominated)
@@ -292,7 +296,7 @@ __device__ inline void prune_voxel_serial(const CompileParams& c, const float4* 
     if (alive > static_cast<uint32_t>(c.refine_above))
     {
       const int R = c.refine;
-      const double h = half / R;
+      const double hsx = hx / R, hsy = hy / R, hsz = hz / R;
       uint32_t drop_mask = 0u;  // decided against the UNrefined survivor set, applied afterwards (k_all <= 32)
       for (uint32_t i = s; i < e; ++i)
       {
@@ -304,8 +308,8 @@ __device__ inline void prune_voxel_serial(const CompileParams& c, const float4* 
         bool needed = false;
         for (int cell = 0; cell < R * R * R && !needed; ++cell)
         {
-          const double ox = -half + (2 * (cell % R) + 1) * h, oy = -half + (2 * ((cell / R) % R) + 1) * h,
-                       oz = -half + (2 * (cell / (R * R)) + 1) * h;
+          const double ox = -hx + (2 * (cell % R) + 1) * hsx, oy = -hy + (2 * ((cell / R) % R) + 1) * hsy,
+                       oz = -hz + (2 * (cell / (R * R)) + 1) * hsz;
           bool dominated_here = false;
           for (uint32_t j = s; j < e && !dominated_here; ++j)
           {
@@ -315,7 +319,7 @@ __device__ inline void prune_voxel_serial(const CompileParams& c, const float4* 
             const double qx = q.x - ctr[0], qy = q.y - ctr[1], qz = q.z - ctr[2];
             const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
             const double gmin = pp - (qx * qx + qy * qy + qz * qz) + (ox * cx + oy * cy + oz * cz) -
-                                h * (fabs(cx) + fabs(cy) + fabs(cz));
+                                (hsx * fabs(cx) + hsy * fabs(cy) + hsz * fabs(cz));
             dominated_here = gmin > c.margin;
           }
           needed = !dominated_here;
@@ -423,7 +427,8 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
     long_list[atomicAdd(long_count, 1u)] = static_cast<uint32_t>(v);  // mc_prune_long's work (any order)
   int vc[3] = { 0, 0, 0 };
   double ctr[3] = { 0, 0, 0 };
-  const double half = 0.5 * c.e + c.grow;
+  const double ed[3] = { c.ex, c.ey, c.ez };
+  const double hx = 0.5 * c.ex + c.grow, hy = 0.5 * c.ey + c.grow, hz = 0.5 * c.ez + c.grow;
   if (coop)
   {
     const int b = static_cast<int>(v >> 9);
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
     vc[2] = brick_xyz[3 * b + 2] * 8 + (l >> 6);
     const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
     for (int a = 0; a < 3; ++a)
-      ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
+      ctr[a] = o[a] + (vc[a] + 0.5) * ed[a];
     for (uint32_t i = g; i < k; i += L)
     {
       const uint32_t id = prelim[s + i] & 0x7fffffffu;
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
           continue;
         const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
         const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
-        const double gmin = pp - (qx * qx + qy * qy + qz * qz) - half * (fabs(cx) + fabs(cy) + fabs(cz));
+        const double gmin = pp - (qx * qx + qy * qy + qz * qz) - (hx * fabs(cx) + hy * fabs(cy) + hz * fabs(cz));
         dominated = gmin > c.margin;
       }
       dom |= dominated ? 1u << i : 0u;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
   if (coop && c.refine > 1 && k - static_cast<uint32_t>(__popc(dom)) > static_cast<uint32_t>(c.refine_above))
   {
     const int R = c.refine;
-    const double h = half / R;
+    const double hsx = hx / R, hsy = hy / R, hsz = hz / R;
     for (uint32_t i = g; i < k; i += L)
     {
       if (dom & (1u << i))
@@ -490,8 +495,8 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
       bool needed = false;
       for (int cell = 0; cell < R * R * R && !needed; ++cell)
       {
-        const double ox = -half + (2 * (cell % R) + 1) * h, oy = -half + (2 * ((cell / R) % R) + 1) * h,
-                     oz = -half + (2 * (cell / (R * R)) + 1) * h;
+        const double ox = -hx + (2 * (cell % R) + 1) * hsx, oy = -hy + (2 * ((cell / R) % R) + 1) * hsy,
+                     oz = -hz + (2 * (cell / (R * R)) + 1) * hsz;
         bool dominated_here = false;
         for (uint32_t j = 0; j < k && !dominated_here; ++j)
         {
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
           const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
           const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
           const double gmin = pp - (qx * qx + qy * qy + qz * qz) + (ox * cx + oy * cy + oz * cz) -
-                              h * (fabs(cx) + fabs(cy) + fabs(cz));
+                              (hsx * fabs(cx) + hsy * fabs(cy) + hsz * fabs(cz));
           dominated_here = gmin > c.margin;
         }
         needed = !dominated_here;
@@ -563,7 +568,8 @@ __global__ __launch_bounds__(256) void mc_prune_long(CompileParams c, const floa
     const uint32_t k = e - s;
     int vc[3] = { 0, 0, 0 };
     double ctr[3] = { 0, 0, 0 };
-    const double half = 0.5 * c.e + c.grow;
+    const double ed[3] = { c.ex, c.ey, c.ez };
+    const double hx = 0.5 * c.ex + c.grow, hy = 0.5 * c.ey + c.grow, hz = 0.5 * c.ez + c.grow;
     if (valid)
     {
       const int b = static_cast<int>(v >> 9);
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(256) void mc_prune_long(CompileParams c, const floa
       vc[2] = brick_xyz[3 * b + 2] * 8 + (l >> 6);
       const double o[3] = { static_cast<double>(c.ox), static_cast<double>(c.oy), static_cast<double>(c.oz) };
       for (int a = 0; a < 3; ++a)
-        ctr[a] = o[a] + (vc[a] + 0.5) * c.e;
+        ctr[a] = o[a] + (vc[a] + 0.5) * ed[a];
       for (uint32_t i = g; i < k; i += L)
       {
         const uint32_t id = prelim[s + i] & 0x7fffffffu;
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(256) void mc_prune_long(CompileParams c, const floa
             continue;
           const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
           const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
-          const double gmin = pp - (qx * qx + qy * qy + qz * qz) - half * (fabs(cx) + fabs(cy) + fabs(cz));
+          const double gmin = pp - (qx * qx + qy * qy + qz * qz) - (hx * fabs(cx) + hy * fabs(cy) + hz * fabs(cz));
           dominated = gmin > c.margin;
         }
         s_alive[grp][i] = dominated ? 0u : 1u;
@@ -699,7 +705,7 @@ struct RecGrid
   const int32_t* brick_table;
   const float4* rec;  // [n_bricks*512][rec_parts]
   const float4* ovf;  // [n_overflow][4]
-  float ox, oy, oz, inv_e;
+  float ox, oy, oz, inv_ex, inv_ey, inv_ez;
   int nvx, nvy, nvz, nbx, nby, nbz;
   int mul24_ok;  // nbx * nby and every brick coordinate < 2^24: the table index can use 24-bit multiplies
   int off32_ok;  // the record array is smaller than 4 GB: byte offsets fit 32 bits
@@ -905,9 +911,9 @@ __global__ void mc_relevant_points(CompileParams c, const float4* __restrict__ p
     return;
   }
   const int3 v = voxel_of(c, pts[pi]);
-  const int x0 = max(v.x - c.reach, 0) >> 3, x1 = min(v.x + c.reach, c.nvx - 1) >> 3;
-  const int y0 = max(v.y - c.reach, 0) >> 3, y1 = min(v.y + c.reach, c.nvy - 1) >> 3;
-  const int z0 = max(v.z - c.reach, 0) >> 3, z1 = min(v.z + c.reach, c.nvz - 1) >> 3;
+  const int x0 = max(v.x - c.rx, 0) >> 3, x1 = min(v.x + c.rx, c.nvx - 1) >> 3;
+  const int y0 = max(v.y - c.ry, 0) >> 3, y1 = min(v.y + c.ry, c.nvy - 1) >> 3;
+  const int z0 = max(v.z - c.rz, 0) >> 3, z1 = min(v.z + c.rz, c.nvz - 1) >> 3;
   uint32_t f = 0;
   for (int z = z0; z <= z1; ++z)
     for (int y = y0; y <= y1; ++y)

@@ -137,3 +137,48 @@ def test_automatic_strict_order_never_fails_an_update_over_memory(engine):
     np.testing.assert_array_equal(ratio_s, ratio_l)
     np.testing.assert_allclose(loose, strict, rtol=1e-5)
     assert not np.array_equal(loose, strict)   # (the float recurrence and the fp64 tree do differ somewhere over 300 particles)
+
+
+def test_a_long_update_does_not_hold_a_core(engine):
+    """the polled completion word used to be spun on for the whole kernel (one core pegged for the 26 ms
+    of a C5 update). The wait now spins for poll_spin_us (default 2 ms: every update up to a few thousand particles), then naps
+    between looks (1/32 of the time already waited). Measured here: CPU time / wall time of the caller over updates of ~15 ms."""
+    import resource
+    import time
+
+    import torch
+    sc = make_scene(n=91, n_p=64, n_s=2048, seed=77)
+    n_p = 400000
+    rng = np.random.default_rng(1)
+    poses = np.repeat(sc.poses, (n_p + 63) // 64, axis=0)[:n_p].copy()
+    poses[:, :3] += rng.normal(0, 0.05, (n_p, 3)).astype(np.float32)
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=99100, dist_weight=(1.0, 1.0, 1.0))
+    engine.set_likelihood_params()
+    engine.upload_scan(sc.scan_lik)
+    dev = torch.device("cuda", 0)
+    d_pose = torch.from_numpy(poses).to(dev)
+    d_lik, d_q = torch.zeros(n_p, device=dev), torch.zeros(n_p, device=dev)
+    torch.cuda.synchronize()
+
+    def run(reps):
+        r0, t0 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+        for _ in range(reps):
+            engine.measure_device(d_pose, n_p, d_lik, d_q, None)
+            engine.synchronize()
+        r1, t1 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+        return (r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime), t1 - t0
+
+    run(2)
+    cpu, wall = run(8)
+    per_update_ms = wall / 8 * 1e3
+    assert per_update_ms > 6.0, "the update is too short (%.2f ms) to say anything about the napping phase" % per_update_ms
+    assert cpu / wall < 0.5, "caller used %.0f %% of a core over %.1f ms updates" % (100 * cpu / wall, per_update_ms)
+    # a pure spin for comparison (poll_spin_us far beyond the update): the same updates, (nearly) a whole core
+    try:
+        engine.set_option("poll_spin_us", 1e6)
+        cpu_spin, wall_spin = run(4)
+    finally:
+        engine.set_option("poll_spin_us", 2000)
+    assert cpu_spin / wall_spin > 0.8
+    # and the nap costs the caller little latency: the napping wait is within 5 % + 0.1 ms of the spinning one
+    assert wall / 8 < 1.05 * wall_spin / 4 + 1e-4
