@@ -259,9 +259,12 @@ class Group:
             poses = _np_f32(poses, 7)
             n_p = len(poses)
         lik, ratio, beam = out if out is not None else (np.zeros(n_p, np.float32) for _ in range(3))
-        self._batch_keep = (poses, sl, sb, so, og, lik, ratio, beam)
+        # (a batch still open is ended by this very call and delivers into ITS arrays: they stay alive until it returns)
+        previous = getattr(self, "_batch_keep", None)
+        self._batch_keep = (poses, sl, sb, so, og, lik, ratio, beam, previous)
         self._check(self.lib.mcl3dl_hip_group_measure_batch_begin(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
                     len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam), int(slice_particles)))
+        self._batch_keep = self._batch_keep[:8]
         return lik, ratio, beam
 
     def measure_batch_wait(self, particle):
@@ -462,9 +465,12 @@ class Engine:
             poses = _np_f32(poses, 7)
             n_p = len(poses)
         lik, ratio, beam = out if out is not None else (np.zeros(n_p, np.float32) for _ in range(3))
-        self._batch_keep = (poses, sl, sb, so, og, lik, ratio, beam)
+        # (a batch still open is ended by this very call and delivers into ITS arrays: they stay alive until it returns)
+        previous = getattr(self, "_batch_keep", None)
+        self._batch_keep = (poses, sl, sb, so, og, lik, ratio, beam, previous)
         self._check(self.lib.mcl3dl_hip_measure_batch_begin(self.h, _ptr(poses), n_p, _ptr(sl), len(sl), _ptr(sb), _ptr(so),
                     len(sb), _ptr(og), len(og), _ptr(lik), _ptr(ratio), _ptr(beam), int(slice_particles)))
+        self._batch_keep = self._batch_keep[:8]
         return lik, ratio, beam
 
     def measure_batch_wait(self, particle):

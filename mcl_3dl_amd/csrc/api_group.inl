@@ -299,8 +299,12 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
   return 0;
 }
 
-// Progressive form: a single device hands its results over slice by slice (api_core.inl); a sharded group evaluates the
-// whole batch in _begin (every shard at once is already the parallel form) and _wait reports all of it ready.
+// Progressive form. One device: the context's own slices (api_core.inl). N devices (round 5): every
+// rank takes its shard of the batch as a progressive batch of its own — poses, scans and kernels enqueued by its worker
+// thread, nothing waited for — and the shards' results land in the caller's arrays shard by shard, slice by slice, through
+// each rank's page-locked emission + polled completion word. _wait(particle) is answered by the rank that owns the particle
+// (after the ranks in front of it: the reference's loop consumes the particles in order, pf.h:255-260), from the caller's
+// thread; the other ranks keep computing. Results are those of mcl3dl_hip_group_measure_batch bit for bit.
 int mcl3dl_hip_group_measure_batch_begin(mcl3dl_hip_group* g, const float* pose, size_t n_p, const float* scan_lik_xyz,
                                          size_t n_s, const float* scan_beam_xyz, const uint32_t* scan_beam_origin,
                                          size_t n_b, const float* origins, size_t n_o, float* out_lik,
@@ -308,8 +312,10 @@ int mcl3dl_hip_group_measure_batch_begin(mcl3dl_hip_group* g, const float* pose,
 {
   if (!g)
     return -1;
+  TRY(mcl3dl_hip_group_measure_batch_end(g));  // (a batch still open is ended first, like the context form does)
   g->prog_n_p = 0;
   g->prog_direct = false;
+  g->prog_sharded = false;
   if (!pose && n_p && g->n_pose_uploaded != n_p)
     return g->fail(-3, "null pose array (and mcl3dl_hip_group_upload_poses holds %zu poses, not %zu)", g->n_pose_uploaded,
                    n_p);
@@ -323,11 +329,45 @@ int mcl3dl_hip_group_measure_batch_begin(mcl3dl_hip_group* g, const float* pose,
     g->prog_direct = true;
     return 0;
   }
-  const int rc = mcl3dl_hip_group_measure_batch(g, pose, n_p, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins,
-                                                n_o, out_lik, out_match_ratio, out_beam);
-  if (rc == 0)
-    g->prog_n_p = n_p;
-  return rc;
+  if (n_p == 0)
+    return 0;
+  const int N = g->n();
+  if (pose)
+    g->n_pose_uploaded = 0;
+  int bad = 0;
+  const int rc = g->pool.run_all(
+      [&](int r) -> int
+      {
+        mcl3dl_hip_ctx* ctx = g->ctx[r];
+        size_t lo, hi;
+        shard_bounds(n_p, N, r, &lo, &hi);
+        const size_t n = hi - lo;
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (n == 0)
+          return 0;
+        // (the context form slices a shard of >= 1024 particles in four by default; shorter shards, and shards whose shape the
+        // staged path does not take, are evaluated whole before this returns — they are short)
+        return mcl3dl_hip_measure_batch_begin(ctx, pose ? pose + 7 * lo : nullptr, n, scan_lik_xyz, n_s, scan_beam_xyz,
+                                              scan_beam_origin, n_b, origins, n_o, out_lik ? out_lik + lo : nullptr,
+                                              out_match_ratio ? out_match_ratio + lo : nullptr,
+                                              out_beam ? out_beam + lo : nullptr, slice_particles);
+      },
+      &bad);
+  g->prog_done.assign(static_cast<size_t>(N), false);
+  if (rc)
+  {
+    for (int r = 0; r < N; ++r)  // the other ranks' batches are drained before the caller gets control back
+    {
+      (void)hipSetDevice(g->ctx[r]->device);
+      (void)mcl3dl_hip_measure_batch_end(g->ctx[r]);
+    }
+    return g->fail_rank(rc, bad);
+  }
+  if (pose)
+    g->n_pose_uploaded = n_p;
+  g->prog_n_p = n_p;
+  g->prog_sharded = true;
+  return 0;
 }
 
 int mcl3dl_hip_group_measure_batch_wait(mcl3dl_hip_group* g, size_t particle, size_t* n_ready)
@@ -341,9 +381,45 @@ int mcl3dl_hip_group_measure_batch_wait(mcl3dl_hip_group* g, size_t particle, si
     const int rc = mcl3dl_hip_measure_batch_wait(g->ctx[0], particle, n_ready);
     return rc ? g->fail_rank(rc, 0) : 0;
   }
-  if (n_ready)
-    *n_ready = g->prog_n_p;
-  return 0;
+  if (!g->prog_sharded)
+  {
+    if (n_ready)
+      *n_ready = g->prog_n_p;
+    return 0;
+  }
+  const int N = g->n();
+  for (int r = 0; r < N; ++r)
+  {
+    size_t lo, hi;
+    shard_bounds(g->prog_n_p, N, r, &lo, &hi);
+    if (hi == lo)
+      continue;
+    mcl3dl_hip_ctx* ctx = g->ctx[r];
+    if (particle >= hi)
+    {
+      // a rank in front of the owner: all of it must have arrived for the particles up to `particle` to be a leading run
+      if (!g->prog_done[static_cast<size_t>(r)])
+      {
+        (void)hipSetDevice(ctx->device);
+        const int rc = mcl3dl_hip_measure_batch_wait(ctx, hi - lo - 1, nullptr);
+        if (rc)
+          return g->fail_rank(rc, r);
+        g->prog_done[static_cast<size_t>(r)] = true;
+      }
+      continue;
+    }
+    (void)hipSetDevice(ctx->device);
+    size_t n = 0;
+    const int rc = mcl3dl_hip_measure_batch_wait(ctx, particle - lo, &n);
+    if (rc)
+      return g->fail_rank(rc, r);
+    if (n >= hi - lo)
+      g->prog_done[static_cast<size_t>(r)] = true;
+    if (n_ready)
+      *n_ready = lo + n;
+    return 0;
+  }
+  return g->fail(-3, "particle %zu belongs to no shard", particle);
 }
 
 int mcl3dl_hip_group_measure_batch_end(mcl3dl_hip_group* g)
@@ -352,9 +428,27 @@ int mcl3dl_hip_group_measure_batch_end(mcl3dl_hip_group* g)
     return -1;
   if (g->prog_direct)
   {
+    g->prog_direct = false;
     const int rc = mcl3dl_hip_measure_batch_end(g->ctx[0]);
     if (rc)
       return g->fail_rank(rc, 0);
+  }
+  if (g->prog_sharded)
+  {
+    g->prog_sharded = false;
+    int first_rc = 0, first_r = 0;
+    for (int r = 0; r < g->n(); ++r)
+    {
+      (void)hipSetDevice(g->ctx[r]->device);
+      const int rc = mcl3dl_hip_measure_batch_end(g->ctx[r]);
+      if (rc && !first_rc)
+      {
+        first_rc = rc;
+        first_r = r;
+      }
+    }
+    if (first_rc)
+      return g->fail_rank(first_rc, first_r);
   }
   return 0;
 }

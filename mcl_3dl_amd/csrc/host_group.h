@@ -245,6 +245,8 @@ struct mcl3dl_hip_group
   // the batch mcl3dl_hip_group_measure_batch_begin started
   size_t prog_n_p = 0;
   bool prog_direct = false;
+  bool prog_sharded = false;          // every rank holds a progressive batch of its own over its shard (api_group.inl)
+  std::vector<bool> prog_done;        // ... ranks whose whole shard has been handed to the caller's arrays
   // particles resident on the devices (api_group_state.inl): 13-float states + weights, sharded by shard_bounds
   size_t n_resident = 0;
   std::vector<float> h_weight, h_state;  // host gather buffers of the resampling steps

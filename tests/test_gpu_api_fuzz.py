@@ -64,7 +64,7 @@ class Model:
         self.lik = dict(match_dist_min=0.2, match_dist_flat=0.05, match_weight=5.0)
         self.beam = dict(num_points=3, hit_range=0.3, add_penalty_short_only_mode=True, filter_label_max=0xFFFFFFFF)
         self.opt = dict(DEFAULTS)
-        self.oracle_state = None
+        self.map_version = 0   # bumped whenever map_xyz is replaced (id() of a fresh array can repeat a freed one's)
 
 
 INJECT = os.environ.get("MCL3DL_FUZZ_INJECT", "")   # a test-hook option switched on for every sequence (fault injection)
@@ -78,7 +78,7 @@ def reset_options(obj):
 
 
 def oracle_for(m, kind, cache):
-    key = (m.map_id, id(m.map_xyz), m.dw, tuple(sorted(m.lik.items())), tuple(sorted(m.beam.items())))
+    key = (m.map_id, m.map_version, m.dw, tuple(sorted(m.lik.items())), tuple(sorted(m.beam.items())))
     if cache.get("key") != key:
         o = cache.get("o") or pyoracle.Oracle(kind)
         o.set_map(m.map_xyz, m.map_label, dist_weight=m.dw)
@@ -150,6 +150,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         sc = world[m.map_id]
         m.dw = [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0), (1.0, 1.0, 2.0)][int(rng.integers(0, 3))]
         m.map_xyz, m.map_label = sc.map_xyz, sc.map_label
+        m.map_version += 1
         eng.set_map(sc.map_xyz, sc.map_label, stamp=int(rng.integers(1, 1 << 30)), dist_weight=m.dw)
         log.append("set_map %d dw=%s" % (m.map_id, m.dw))
 
@@ -164,6 +165,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         lab = rng.integers(0, 4, n_new).astype(np.uint32)
         n_map, st = eng.map_update(pts, lab, leaf=(0.2, 0.2, 0.2), stamp=int(rng.integers(1, 1 << 30)))
         m.map_xyz, m.map_label = eng.map_download()
+        m.map_version += 1
         assert len(m.map_xyz) == n_map
         log.append("map_update %d pts (%s) -> %d, outcome %d" % (n_new, "inside" if inside else "beyond", n_map, st["outcome"]))
         # an updated engine == a fresh engine on the merged map, bit for bit, over the whole pool of poses and points
@@ -342,9 +344,9 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
     def do_group():
         nonlocal grp_map
         sc = world[m.map_id]
-        if grp_map != (m.map_id, id(m.map_xyz), m.dw):
+        if grp_map != (m.map_id, m.map_version, m.dw):
             grp.set_map(m.map_xyz, m.map_label, stamp=int(rng.integers(1, 1 << 30)), dist_weight=m.dw)
-            grp_map = (m.map_id, id(m.map_xyz), m.dw)
+            grp_map = (m.map_id, m.map_version, m.dw)
         grp.set_likelihood_params(**m.lik)
         grp.set_beam_params(**m.beam)
         for k in ("poll_sync", "strict_order", "update_stage", "update_zero_copy", "lik_coop"):

@@ -145,25 +145,50 @@ def test_uploaded_poses_and_the_update_after_a_batch(configured, scene):
     np.testing.assert_array_equal(a["beam"], ref[2])
 
 
-@pytest.mark.parametrize("devices,collective", [((0,), None), ((0, 0), "host")])
+@pytest.mark.parametrize("devices,collective", [((0,), None), ((0, 0), "host"), ((0, 0, 0), "host")])
 def test_group_form(scene, devices, collective):
-    """One device: slices; a sharded group (two contexts on one GPU, host combine): the whole batch inside _begin."""
+    """One device: the context's slices. A sharded group (round 5): every rank runs its shard as a progressive batch of its
+    own, the shards' slices arrive in the caller's arrays while the other ranks still compute, _wait is answered by the owner
+    of the particle. Results are those of measure_batch bit for bit."""
+    import time
     sc = scene
     g = Group(devices, collective=collective)
+    N = len(devices)
     try:
         g.set_map(sc.map_xyz, sc.map_label, stamp=9102, dist_weight=(1.0, 1.0, 5.0))
         g.set_likelihood_params()
         g.set_beam_params(num_points=256)
-        ref = g.measure_batch(sc.poses[:3000], sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
-        got = g.measure_batch_begin(sc.poses[:3000], sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins,
-                                    slice_particles=1000)
+        n_p = 3000 * N if N > 1 else 3000
+        poses = np.ascontiguousarray(np.tile(sc.poses, (n_p // len(sc.poses) + 1, 1))[:n_p])
+        poses[:, :3] += np.random.default_rng(1).normal(0, 0.02, (n_p, 3)).astype(np.float32)
+        ref = g.measure_batch(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
+        t0 = time.perf_counter()
+        got = g.measure_batch_begin(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, slice_particles=1000)
+        t_begin = time.perf_counter()
         n = g.measure_batch_wait(0)
-        assert n == 3000 if len(devices) > 1 else n >= 1008
-        assert g.measure_batch_wait(2999) == 3000
+        t_first = time.perf_counter()
+        assert 1000 <= n < n_p                      # the first slice of the first shard, not the batch
+        np.testing.assert_array_equal(got[0][:n], ref[0][:n])
+        if N > 1:
+            # a particle of the LAST shard: everything in front of it has arrived by then
+            m = g.measure_batch_wait(n_p - 2999)
+            assert m > n_p - 2999
+            np.testing.assert_array_equal(got[0][:m], ref[0][:m])
+            np.testing.assert_array_equal(got[2][:m], ref[2][:m])
+        assert g.measure_batch_wait(n_p - 1) == n_p
+        t_last = time.perf_counter()
         with pytest.raises(EngineError, match="not part of the batch"):
-            g.measure_batch_wait(3000)
+            g.measure_batch_wait(n_p)
         g.measure_batch_end()
         for a, b in zip(got, ref):
             np.testing.assert_array_equal(a, b)
+        # the first _wait returned before the last results arrived (timestamps; the batch is ~N x 3 slices long)
+        assert (t_first - t0) < 0.8 * (t_last - t0), (t_begin - t0, t_first - t0, t_last - t0)
+        # a new _begin ends an open batch; fewer particles than devices
+        g.measure_batch_begin(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, slice_particles=1000)
+        few = g.measure_batch_begin(poses[:2], sc.scan_lik[:500])
+        assert g.measure_batch_wait(1) == 2
+        g.measure_batch_end()
+        np.testing.assert_array_equal(few[0], g.measure_batch(poses[:2], sc.scan_lik[:500])[0])
     finally:
         g.close()
