@@ -536,6 +536,10 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       the reference's measure() on the scan permuted that way; no term buffer, no replay pass (the
  *                       work-group of a scan tile hands each particle's running sum on to the next tile's). Weights are
  *                       summed as in mode 2. Suits callers whose scan order means nothing to them (a sampled cloud).
+ *   "strict_chunk"      0 (default) = a caller-order replay ("strict_order" 1 / 2) keeps the terms of the whole scan (n_s x n_p floats);
+ *                       a point count >= 1024 = scans of at least two such chunks are ordered chunk by chunk of the caller's order
+ *                       and replayed chunk by chunk with two term buffers (C5: 4.3 GB instead of 17 GB, 27.9 instead of 25.6 ms:
+ *                       the low-memory form). Same bits. Read-only "scan_chunk_in_use".
  *   "index_budget_bytes"  upper bound of the candidate-voxel records (the bulk of the likelihood index: one 64-byte record per
  *                       voxel of every 8 x 8 x 8-voxel brick within reach of a map point): -1 (default) = a quarter of the
  *                       device's memory, 0 = none. The index is laid out, in this order, with cubes of edge r / 2 (fastest),

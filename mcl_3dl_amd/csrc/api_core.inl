@@ -83,6 +83,18 @@ int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
 
 void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
 {
+  if (ctx)
+  {
+    for (int k = 0; k < 2; ++k)
+    {
+      if (ctx->ev_tiled[k])
+        (void)hipEventDestroy(ctx->ev_tiled[k]);
+      if (ctx->ev_replay[k])
+        (void)hipEventDestroy(ctx->ev_replay[k]);
+    }
+    if (ctx->replay_stream)
+      (void)hipStreamDestroy(ctx->replay_stream);
+  }
   if (!ctx)
     return;
   (void)hipSetDevice(ctx->device);
@@ -470,7 +482,11 @@ int mcl3dl_hip_scan_order(mcl3dl_hip_ctx* ctx, uint32_t* order, size_t n_s)
     return ctx->fail(-3, "null order array");
   HIP_TRY(hipSetDevice(ctx->device));
   TRY(d2h(ctx, order, ctx->scan_perm.p, sizeof(uint32_t) * n_s));
-  return sync_stream(ctx);
+  TRY(sync_stream(ctx));
+  if (ctx->scan_chunk)  // (ordered in chunks of the caller's order: the device holds indices relative to each chunk)
+    for (size_t k = 0; k < n_s; ++k)
+      order[k] += static_cast<uint32_t>((k / ctx->scan_chunk) * ctx->scan_chunk);
+  return 0;
 }
 
 int mcl3dl_hip_measure_device(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_match_ratio,

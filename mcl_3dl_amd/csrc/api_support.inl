@@ -202,6 +202,13 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->update_small_max = static_cast<int>(value);
     return 0;
   }
+  if (key == "strict_chunk")
+  {
+    if (!(value == 0.0 || (value >= 1024.0 && value <= 1e9)))
+      return ctx->fail(-3, "strict_chunk must be 0 (replay the scan in one piece) or a point count >= 1024");
+    ctx->strict_chunk = static_cast<int>(value);
+    return 0;
+  }
   if (key == "strict_auto_min")
   {
     if (!(value >= 1.0 && value <= 2147483647.0))
@@ -413,6 +420,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "cand_ovf_leaked") *value = ctx->cand_ovf_leaked;
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
+  else if (key == "strict_chunk") *value = ctx->strict_chunk;
+  else if (key == "scan_chunk_in_use") *value = static_cast<double>(ctx->scan_chunk);
   else if (key == "strict_gpw") *value = ctx->strict_gpw;
   else if (key == "strict_skew") *value = ctx->strict_skew;
   else if (key == "strict_auto_max_bytes") *value = ctx->strict_auto_max_bytes;

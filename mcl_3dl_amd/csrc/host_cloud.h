@@ -463,11 +463,20 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
     const long long ns = static_cast<long long>(n_s);
     if (!have_minmax)
       TRY(cloud_minmax(ctx, ctx->sp_samp[0].as<float4>(), ns, nullptr, nullptr));
-    RsKeyGen kg{};
-    kg.pts = ctx->sp_samp[0].as<float4>();
-    kg.min3 = ctx->cl_minmax.as<float>();
-    const RsFinal fin{ ctx->sp_samp[0].as<float4>(), ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>(), 1 };
-    TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, ns, MCL3DL_MORTON_BITS, &fin));
+    // a scan whose terms will be replayed in the caller's order (strict_order 1, or 2 from strict_auto_min points) and that is
+    // at least two chunks long: ordered chunk by chunk of the caller's order (same keys, same bounding box for every chunk)
+    const size_t chunk = (ctx->strict_chunk >= 1024 && (ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min)) &&
+                          n_s >= 2 * static_cast<size_t>(ctx->strict_chunk)) ? static_cast<size_t>(ctx->strict_chunk) & ~static_cast<size_t>(255) : 0;
+    for (size_t first = 0; first < n_s; first += chunk ? chunk : n_s)
+    {
+      const size_t n = chunk ? std::min(chunk, n_s - first) : n_s;
+      RsKeyGen kg{};
+      kg.pts = ctx->sp_samp[0].as<float4>() + first;
+      kg.min3 = ctx->cl_minmax.as<float>();
+      const RsFinal fin{ ctx->sp_samp[0].as<float4>() + first, ctx->scan_lik.as<float4>() + first, ctx->scan_perm.as<uint32_t>() + first, 1 };
+      TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, static_cast<long long>(n), MCL3DL_MORTON_BITS, &fin));
+    }
+    ctx->scan_chunk = chunk;
   }
   if (n_o && origins)  // (origins == nullptr: the caller's kernel has put them into ctx->origins already)
   {

@@ -107,6 +107,17 @@ struct mcl3dl_hip_ctx
   uint64_t strict_auto_skipped = 0;  // launches of the automatic mode that summed in fp64 because the replay buffer did not fit
   DevBuf scan_block;  // { perm | lik scan | beam scan | origins } of the current update in ONE allocation (ensure_scan_block)
   DevBuf scan_perm, strict_terms;
+  // Option strict_chunk > 0: a scan whose terms will be replayed in the caller's order is ORDERED in chunks of that order
+  // (strict_chunk points each, Morton order inside a chunk; scan_perm then holds indices relative to the chunk): chunk c + 1 is
+  // evaluated while chunk c is replayed on a stream of its own, and the term buffer holds two chunks instead of the whole scan
+  // (host_measure.h). Measured and OFF by default (profiles/r05g_chunked_replay.txt): the term buffer of C5 shrinks from 17 GB to
+  // 4.3 GB, but the update takes 27.9 instead of 25.6 ms — the replay's 1024-thread, 128 KB work-groups find no room next to
+  // the tiled kernel's (eight 19 KB work-groups per CU), so the two do not overlap and the shorter launches cost their tails.
+  // scan_chunk = chunk size the scan in place was ordered with (0 = one piece).
+  size_t scan_chunk = 0;
+  int strict_chunk = 0;
+  hipStream_t replay_stream = nullptr;
+  hipEvent_t ev_tiled[2] = { nullptr, nullptr }, ev_replay[2] = { nullptr, nullptr };
   // the whole update as one launch (update_kernels.h) up to update_small_max particles when the per-particle likelihood
   // kernel would run anyway: same bits, two to four launches fewer. Measured (profiles/r03*_update_small.txt): ahead of the
   // separate kernels up to ~500 particles (64 x 96 + 3: 26.9 -> 22.4 us, 64 x 1000: 13.7 -> 10.3), behind from 1024 on —
@@ -459,6 +470,7 @@ int ensure_scan_block(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, size_t n_o, s
   const size_t part[4] = { up(sizeof(uint32_t) * n_s), up(sizeof(float4) * n_s), up(sizeof(float4) * n_b), up(sizeof(float4) * n_o) };
   const size_t total = part[0] + part[1] + part[2] + part[3];
   TRY(ensure(ctx, ctx->scan_block, total));
+  ctx->scan_chunk = 0;  // (device_order_scans sets it again when it orders the scan in chunks)
   DevBuf* view[4] = { &ctx->scan_perm, &ctx->scan_lik, &ctx->scan_beam, &ctx->origins };
   size_t off = 0;
   bool moved = false;

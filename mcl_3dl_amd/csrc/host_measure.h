@@ -117,6 +117,7 @@ struct LikPlan
   int group_size = 16, W = 1, n_tiles = 0, n_groups = 0;
   long long blocks = 0;
   float* strict_terms = nullptr;
+  size_t chunk = 0;    // > 0: the scan is ordered in chunks of the caller's order and replayed chunk by chunk (two term buffers)
   bool chain = false;  // the float sum in the scan array's order inside the tiled kernel (likelihood_kernels.h: LikChain)
   uint32_t chain_tag0 = 0;
 };
@@ -177,6 +178,28 @@ size_t strict_terms_bytes(size_t n_p, int ns, int group_size)
   return ((n_p + G - 1) / G) * (sizeof(float) * static_cast<size_t>(ns) * G + sizeof(float4) * STRICT_SKEW4);
 }
 
+// device memory of the float-order replay: the whole scan's terms, or two chunks' when the scan was ordered in chunks
+size_t strict_plan_bytes(const mcl3dl_hip_ctx* ctx, size_t n_p, int ns, int group_size)
+{
+  if (ctx->scan_chunk && static_cast<size_t>(ns) > ctx->scan_chunk)
+    return 2 * strict_terms_bytes(n_p, static_cast<int>(ctx->scan_chunk), group_size);
+  return strict_terms_bytes(n_p, ns, group_size);
+}
+
+int ensure_replay_stream(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx->replay_stream)
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->replay_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k)
+  {
+    if (!ctx->ev_tiled[k])
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_tiled[k], hipEventDisableTiming));
+    if (!ctx->ev_replay[k])
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_replay[k], hipEventDisableTiming));
+  }
+  return 0;
+}
+
 int plan_group_size(const mcl3dl_hip_ctx* ctx, int np, int ns)
 {
   // particles per work-group of the tiled kernel: the largest of 16 / 8 / 4 that still gives the 256 CUs x 8
@@ -211,7 +234,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
     // float at such sizes), so it must never make an update fail: when the buffer would take more than half of the free
     // device memory, or its allocation fails, this launch sums in fp64 like smaller scans do. (strict_order = 1 — asked for
     // explicitly — still fails loudly.)
-    const size_t need = strict_terms_bytes(n_p, ns, group_size);
+    const size_t need = strict_plan_bytes(ctx, n_p, ns, group_size);
     if (ctx->strict_auto_max_bytes > 0.0 && static_cast<double>(need) > ctx->strict_auto_max_bytes)
     {
       strict = false;
@@ -274,8 +297,11 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
     TRY(ensure(ctx, ctx->lik_partial_cnt, sizeof(unsigned) * static_cast<size_t>(pl->n_tiles) * n_p));
     if (strict)
     {
-      TRY(ensure(ctx, ctx->strict_terms, strict_terms_bytes(n_p, ns, group_size)));
+      TRY(ensure(ctx, ctx->strict_terms, strict_plan_bytes(ctx, n_p, ns, group_size)));
       pl->strict_terms = ctx->strict_terms.as<float>();
+      pl->chunk = (ctx->scan_chunk && static_cast<size_t>(ns) > ctx->scan_chunk) ? ctx->scan_chunk : 0;
+      if (pl->chunk)
+        TRY(ensure_replay_stream(ctx));
     }
   }
   return 0;
@@ -284,8 +310,11 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
 // lik_strict_sum_kernel with as many particle groups per work-group as keep the launch in ONE round of work-groups, up to a
 // full adder wavefront (64 lanes / GG particles per group)
 template <int GG>
-void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, int np, int n_groups, float* d_lik)
+void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, int np, int n_groups, float* d_lik,
+                       hipStream_t on = nullptr, int accumulate = 0)
 {
+  if (!on)
+    on = ctx->stream;
   constexpr int MAX_GPW = 64 / GG >= 4 ? 4 : (64 / GG >= 2 ? 2 : 1);
   int gpw = n_groups <= ctx->n_cus ? 1 : (n_groups <= 2 * ctx->n_cus ? 2 : 4);
   gpw = std::min(gpw, MAX_GPW);
@@ -298,11 +327,11 @@ void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, i
   do                                                                                                                     \
   {                                                                                                                      \
     if (ctx->strict_rows)                                                                                                \
-      hipLaunchKernelGGL((lik_strict_sum_rows_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, ctx->stream, strict_terms, ns, \
-                         np, n_groups, d_lik, skew);                                                                     \
+      hipLaunchKernelGGL((lik_strict_sum_rows_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, on, strict_terms, ns, \
+                         np, n_groups, d_lik, skew, accumulate);                                                         \
     else                                                                                                                 \
-      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, ctx->stream, strict_terms, ns, np, \
-                         n_groups, d_lik, skew);                                                                         \
+      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, on, strict_terms, ns, np, \
+                         n_groups, d_lik, skew, accumulate);                                                             \
   } while (0)
   if constexpr (MAX_GPW >= 4)
     if (gpw == 4)
@@ -519,10 +548,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const int n_tiles = plan.n_tiles, n_groups = plan.n_groups;
           const long long blocks = plan.blocks;
 #define LAUNCH_TILED(GG, MODE, WW, CC, DD)                                                                             \
-  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC, DD>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
-                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
-                     ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(),                          \
-                     ctx->scan_perm.as<uint32_t>(), strict_terms, ctx->strict_skew ? STRICT_SKEW4 : 0)
+  hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC, DD>), dim3(static_cast<unsigned>(t_blocks)), dim3(256), 0, \
+                     ctx->stream, d_pose, np, t_scan, t_ns, t_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp, t_psum, t_pcnt, \
+                     t_perm, t_terms, ctx->strict_skew ? STRICT_SKEW4 : 0)
           const bool coop = coop_arg != 0;
           const bool defer = coop && lik_defer_active(ctx);
           if (plan.chain)
@@ -585,50 +613,107 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     else                               \
       LAUNCH_TILED(GG, 0, WW, false, false); \
   } while (0)
-          switch (G)
+          // one launch of the tiled kernel over t_ns points starting at t_scan (the whole scan, or one chunk of it)
+          const auto launch_tiled = [&](const float4* t_scan, int t_ns, int t_tiles, double* t_psum, unsigned* t_pcnt,
+                                        const uint32_t* t_perm, float* t_terms)
           {
-            case 4:
-              LAUNCH_TILED_G(4, 8);
-              break;
-            case 8:
-              LAUNCH_TILED_G(8, 8);
-              break;
-            case 32:
-              LAUNCH_TILED_G(32, 4);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
-              break;
-            default:
-              LAUNCH_TILED_G(16, 8);
-              break;
+            const long long full = t_tiles & ~7, rem = static_cast<long long>(t_tiles - full) * n_groups;
+            const long long t_blocks = 8 * ((full / 8) * n_groups + (rem + 7) / 8);  // (plan_lik's count, for this many tiles)
+            switch (G)
+            {
+              case 4:
+                LAUNCH_TILED_G(4, 8);
+                break;
+              case 8:
+                LAUNCH_TILED_G(8, 8);
+                break;
+              case 32:
+                LAUNCH_TILED_G(32, 4);  // 33 KB of LDS per work-group: 4 wavefronts per SIMD at most
+                break;
+              default:
+                LAUNCH_TILED_G(16, 8);
+                break;
+            }
+          };
+          const auto launch_replay = [&](const float* terms, int r_ns, hipStream_t on, int accumulate)
+          {
+            switch (G)
+            {
+              case 4:
+                launch_strict_sum<4>(ctx, terms, r_ns, np, n_groups, d_lik, on, accumulate);
+                break;
+              case 8:
+                launch_strict_sum<8>(ctx, terms, r_ns, np, n_groups, d_lik, on, accumulate);
+                break;
+              case 32:
+                launch_strict_sum<32>(ctx, terms, r_ns, np, n_groups, d_lik, on, accumulate);
+                break;
+              default:
+                launch_strict_sum<16>(ctx, terms, r_ns, np, n_groups, d_lik, on, accumulate);
+                break;
+            }
+          };
+          double* const psum = ctx->lik_partial_sum.as<double>();
+          unsigned* const pcnt = ctx->lik_partial_cnt.as<unsigned>();
+          if (strict_terms && plan.chunk && d_lik)
+          {
+            // The scan was ordered in chunks of the caller's order (host_cloud.h:device_order_scans). Chunk c is evaluated on the
+            // context's stream into term buffer c % 2 while chunk c - 1 is replayed — the reference's float recurrence continued
+            // from the sums chunk c - 2 ... left in d_lik — on a stream of its own: the replay streams its terms at memory speed,
+            // the evaluation is bound by VALU issue, and the two share the GPU well; the buffer holds two chunks, not the scan.
+            const size_t chunk = plan.chunk;
+            const int n_chunks = static_cast<int>((static_cast<size_t>(ns) + chunk - 1) / chunk);
+            float* const buf[2] = { strict_terms,
+                                    strict_terms + strict_terms_bytes(n_p, static_cast<int>(chunk), G) / sizeof(float) };
+            struct ReplayGuard
+            {
+              mcl3dl_hip_ctx* c;
+              ~ReplayGuard()
+              {
+                (void)hipStreamSynchronize(c->replay_stream);
+              }
+            };
+            bool failed = false;
+            for (int c = 0; c < n_chunks && !failed; ++c)
+            {
+              const size_t first = static_cast<size_t>(c) * chunk;
+              const int c_ns = static_cast<int>(std::min(chunk, static_cast<size_t>(ns) - first));
+              const int c_tiles = (c_ns + 255) / 256, tile0 = static_cast<int>(first / 256);
+              if (c >= 2)
+                failed = failed || hipStreamWaitEvent(ctx->stream, ctx->ev_replay[c & 1], 0) != hipSuccess;  // its buffer is free again
+              launch_tiled(scan + first, c_ns, c_tiles, psum + static_cast<size_t>(tile0) * n_p, pcnt + static_cast<size_t>(tile0) * n_p,
+                           ctx->scan_perm.as<uint32_t>() + first, buf[c & 1]);
+              failed = failed || hipEventRecord(ctx->ev_tiled[c & 1], ctx->stream) != hipSuccess ||
+                       hipStreamWaitEvent(ctx->replay_stream, ctx->ev_tiled[c & 1], 0) != hipSuccess;
+              launch_replay(buf[c & 1], c_ns, ctx->replay_stream, c > 0 ? 1 : 0);
+              failed = failed || hipEventRecord(ctx->ev_replay[c & 1], ctx->replay_stream) != hipSuccess;
+            }
+            // match ratios (and nothing else: the likelihoods are the replay's) from the per-tile counts
+            hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, psum, pcnt, n_tiles, np, ns,
+                               static_cast<float*>(nullptr), d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
+            if (failed || hipStreamWaitEvent(ctx->stream, ctx->ev_replay[(n_chunks - 1) & 1], 0) != hipSuccess)
+            {
+              ReplayGuard drain{ ctx };
+              return ctx->fail(-2, "stream / event call failed in the chunked float-order replay: %s", hipGetErrorString(hipGetLastError()));
+            }
           }
-#undef LAUNCH_TILED_G
-#undef LAUNCH_TILED
+          else
+          {
+          // (a chunk-ordered scan whose likelihoods nobody asked for: its permutation is chunk-relative, no terms are kept)
+          launch_tiled(scan, ns, n_tiles, psum, pcnt, ctx->scan_perm.as<uint32_t>(), plan.chunk ? nullptr : strict_terms);
           if (tail && tail->want && !strict_terms && d_lik && d_ratio)
           {
             tail->lik_partials = true;  // launch_pf_tail adds the tiles up (lik_finalize_kernel with the weights folded in)
             tail->n_tiles = n_tiles;
           }
           else
-            hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream,
-                               ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), n_tiles, np, ns,
+            hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, psum, pcnt, n_tiles, np, ns,
                                d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
-          if (strict_terms && d_lik)
-          {
-            switch (G)
-            {
-              case 4:
-                launch_strict_sum<4>(ctx, strict_terms, ns, np, n_groups, d_lik);
-                break;
-              case 8:
-                launch_strict_sum<8>(ctx, strict_terms, ns, np, n_groups, d_lik);
-                break;
-              case 32:
-                launch_strict_sum<32>(ctx, strict_terms, ns, np, n_groups, d_lik);
-                break;
-              default:
-                launch_strict_sum<16>(ctx, strict_terms, ns, np, n_groups, d_lik);
-                break;
-            }
+          if (strict_terms && d_lik && !plan.chunk)
+            launch_replay(strict_terms, ns, ctx->stream, 0);
           }
+#undef LAUNCH_TILED_G
+#undef LAUNCH_TILED
           }
         }
         else

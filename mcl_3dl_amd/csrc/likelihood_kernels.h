@@ -1253,7 +1253,7 @@ constexpr int STRICT_SKEW4 = 272;
 
 template <int G, int CHUNK, int GPW>
 __global__ __launch_bounds__(1024) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p, int n_groups,
-                                                              float* __restrict__ out_lik, int skew4)
+                                                              float* __restrict__ out_lik, int skew4, int accumulate = 0)
 {
   constexpr int Q = G / 4;               // float4s per row
   constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk and group
@@ -1315,6 +1315,13 @@ __global__ __launch_bounds__(1024) void lik_strict_sum_kernel(const float* __res
   }
   __syncthreads();
   float score = 0.0f;
+  if (accumulate)
+  {
+    // (a scan replayed in chunks of its original order: this launch continues the sums the previous chunk's launch left)
+    const int p0 = (group0 + t / G) * G + (t % G);
+    if (t < GPW * G && group0 + t / G < n_groups && p0 < n_p)
+      score = out_lik[p0];
+  }
   for (int c = 0; c < n_chunks; ++c)
   {
     if (loader)
@@ -1368,7 +1375,7 @@ __global__ __launch_bounds__(1024) void lik_strict_sum_kernel(const float* __res
 // bank count so that the GPW groups' rows do not collide. Same terms, same order, same float: bit-identical.
 template <int G, int CHUNK, int GPW>
 __global__ __launch_bounds__(1024) void lik_strict_sum_rows_kernel(const float* __restrict__ terms, int n_s, int n_p,
-                                                                   int n_groups, float* __restrict__ out_lik, int skew4)
+                                                                   int n_groups, float* __restrict__ out_lik, int skew4, int accumulate = 0)
 {
   constexpr int Q = G / 4;               // float4s per row
   constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk and group
@@ -1428,6 +1435,13 @@ __global__ __launch_bounds__(1024) void lik_strict_sum_rows_kernel(const float* 
   }
   __syncthreads();
   float score = 0.0f;
+  if (accumulate)
+  {
+    // (a scan replayed in chunks of its original order: this launch continues the sums the previous chunk's launch left)
+    const int p0 = (group0 + t / G) * G + (t % G);
+    if (t < GPW * G && group0 + t / G < n_groups && p0 < n_p)
+      score = out_lik[p0];
+  }
   // one trip of the pipeline: the loaders park chunk c + 1 out of `reg` and refill it with chunk c + 3, the adder wavefront
   // runs chunk c. Called for even c with rb and for odd c with ra, so that each register array is named statically.
   const auto trip = [&](int c, float4 (&reg)[PER])
