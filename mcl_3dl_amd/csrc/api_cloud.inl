@@ -208,6 +208,7 @@ int install_base_map(mcl3dl_hip_ctx* ctx, size_t n_in, const float* leaf3, uint6
     ctx->weight[a] = dist_weight ? dist_weight[a] : 1.0f;
   ctx->has_map = true;
   ctx->lik_dirty = ctx->cand_dirty = ctx->dda_dirty = true;
+  ctx->lik_base_dirty = true;
   ctx->n_base = n_out;
   ctx->sp_ready = false;  // sp_full was borrowed
   if (n_map)

@@ -179,6 +179,7 @@ int mcl3dl_hip_set_map(mcl3dl_hip_ctx* ctx, const float* xyz, const uint32_t* la
   ctx->has_map = true;
   ctx->n_base = n_m;
   ctx->lik_dirty = true;
+  ctx->lik_base_dirty = true;
   ctx->cand_dirty = true;
   ctx->dda_dirty = true;
   return 0;
@@ -193,7 +194,7 @@ int mcl3dl_hip_set_likelihood_params(mcl3dl_hip_ctx* ctx, float match_dist_min, 
   if (!(match_dist_min > 0.f))
     return ctx->fail(-3, "match_dist_min must be > 0");
   if (match_dist_min != ctx->match_dist_min)
-    ctx->lik_dirty = ctx->cand_dirty = true;  // cell / voxel edges follow the search radius
+    ctx->lik_dirty = ctx->cand_dirty = ctx->lik_base_dirty = true;  // cell / voxel edges follow the search radius
   ctx->match_dist_min = match_dist_min;
   ctx->match_dist_flat = match_dist_flat;
   ctx->match_weight = match_weight;

@@ -355,7 +355,7 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     if (v != ctx->grid_build_host)
     {
       ctx->grid_build_host = v;
-      ctx->lik_dirty = ctx->dda_dirty = true;
+      ctx->lik_dirty = ctx->dda_dirty = ctx->lik_base_dirty = true;
       ++ctx->generation;
     }
     return 0;
@@ -422,6 +422,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
   else if (key == "strict_chunk") *value = ctx->strict_chunk;
   else if (key == "scan_chunk_in_use") *value = static_cast<double>(ctx->scan_chunk);
+  else if (key == "lik_grid_merges") *value = static_cast<double>(ctx->lik_grid_merges);
+  else if (key == "lik_grid_rebuilds") *value = static_cast<double>(ctx->lik_grid_rebuilds);
   else if (key == "strict_gpw") *value = ctx->strict_gpw;
   else if (key == "strict_skew") *value = ctx->strict_skew;
   else if (key == "strict_auto_max_bytes") *value = ctx->strict_auto_max_bytes;

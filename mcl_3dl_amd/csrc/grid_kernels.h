@@ -51,6 +51,72 @@ __global__ void lik_cell_key_kernel(const float4* __restrict__ sp, long long n, 
   atomicAdd(&count[k], 1u);
 }
 
+// ---- the cell grid after a map update: merge of the BASE map's grid with the update's points (round 5) -------------------
+// pc_map2 = pc_map + pc_update (src/mcl_3dl.cpp:150): the update's points have the highest map indices, so inside a cell they
+// follow the base points — the merged, cell-sorted array is the base array with every cell's run shifted by the number of
+// update points in the cells before it, and the update's points (sorted by cell, stable) appended to their cells' runs.
+// ukey = the update's cell keys, ascending (n_u of them). No histogram, no sort of the map: one binary search per cell / point.
+__device__ inline uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v)
+{
+  uint32_t lo = 0, hi = n;
+  while (lo < hi)
+  {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__device__ inline uint32_t lik_cell_of(const float4 p, const CellGeom& g)
+{
+  int cx = static_cast<int>(floorf((p.x - g.ox) * g.inv));
+  int cy = static_cast<int>(floorf((p.y - g.oy) * g.inv));
+  int cz = static_cast<int>(floorf((p.z - g.oz) * g.inv));
+  cx = min(max(cx, 0), g.nx - 1);
+  cy = min(max(cy, 0), g.ny - 1);
+  cz = min(max(cz, 0), g.nz - 1);
+  return static_cast<uint32_t>((static_cast<size_t>(cz) * g.ny + cy) * g.nx + cx);
+}
+
+__global__ void lik_update_key_kernel(const float4* __restrict__ sp_upd, int n_u, CellGeom g, uint32_t* __restrict__ key,
+                                      uint32_t* __restrict__ val)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_u)
+    return;
+  key[i] = lik_cell_of(sp_upd[i], g);
+  val[i] = static_cast<uint32_t>(i);
+}
+
+__global__ void lik_merge_cells_kernel(const uint32_t* __restrict__ base_start, long long n_cell_plus_1,
+                                       const uint32_t* __restrict__ ukey, uint32_t n_u, uint32_t* __restrict__ out_start)
+{
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c < n_cell_plus_1)
+    out_start[c] = base_start[c] + lower_bound_u32(ukey, n_u, static_cast<uint32_t>(c));
+}
+
+__global__ void lik_merge_points_kernel(const float4* __restrict__ base_pts, long long n_base,
+                                        const uint32_t* __restrict__ base_start, CellGeom g,
+                                        const float4* __restrict__ sp_upd, const uint32_t* __restrict__ ukey,
+                                        const uint32_t* __restrict__ uval, uint32_t n_u, float4* __restrict__ out_pts)
+{
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < n_base)
+  {
+    const float4 p = base_pts[t];
+    out_pts[t + lower_bound_u32(ukey, n_u, lik_cell_of(p, g))] = p;
+  }
+  else if (t < n_base + n_u)
+  {
+    const uint32_t j = static_cast<uint32_t>(t - n_base);
+    out_pts[static_cast<size_t>(base_start[ukey[j] + 1u]) + j] = sp_upd[uval[j]];
+  }
+}
+
 __global__ void grid_gather_kernel(const float4* __restrict__ src, const uint32_t* __restrict__ val, long long n,
                                    float4* __restrict__ dst)
 {

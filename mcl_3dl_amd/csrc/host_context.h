@@ -83,6 +83,13 @@ struct mcl3dl_hip_ctx
 
   bool lik_dirty = true, dda_dirty = true, cand_dirty = true;
   DevBuf lik_pts, lik_cells;
+  // the cell grid of the BASE map alone (host_grid_builders.h): after a map update the grid in use (lik_pts / lik_cells) is the
+  // merge of this one with the update's points — no sort of the map, no histogram (round 5)
+  DevBuf lik_base_pts, lik_base_cells;
+  bool lik_base_dirty = true;
+  size_t lik_base_n = 0;
+  float lik_base_lo[3] = { 0, 0, 0 }, lik_base_hi[3] = { 0, 0, 0 };  // rescaled bounds the base grid's geometry was laid out for
+  uint64_t lik_grid_merges = 0, lik_grid_rebuilds = 0;
   LikGrid lg{};
   // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
   int lik_index = 2;

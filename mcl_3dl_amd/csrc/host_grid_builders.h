@@ -41,9 +41,15 @@ struct BuildTimer
 };
 
 // ---- exact-NN grid (replaces ChunkedKdtree::setInputCloud + pcl::KdTreeFLANN::setInputCloud, see host_map_compilers.h) ----
+// The grid in use = the grid of the BASE map (built here: keys, histogram, stable sort, gather, scan — linear, but a sort of
+// the whole map) merged with the current map update's points (three small kernels, no sort of the map: grid_kernels.h).
+// The base grid is laid out for the bounds of base + update of the moment; a later update that stays inside those bounds
+// only merges (0.36 -> ~0.07 ms at 1 M points), one that leaves them rebuilds the base for the new bounds.
 int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
 {
   const size_t n = ctx->map_xyz.size() / 3;
+  const size_t n_base = (ctx->n_base && ctx->n_base <= n) ? ctx->n_base : n;
+  const size_t n_upd = n - n_base;
   const long long nn = static_cast<long long>(n);
   const float cell = ctx->match_dist_min * 1.01f;
   if (!(cell > 0.f) || !std::isfinite(cell))
@@ -60,53 +66,108 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
   TRY(scratch_alloc(ctx, sp, sizeof(float4) * n));
   hipLaunchKernelGGL(grid_rescale_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn,
                      ctx->weight[0], ctx->weight[1], ctx->weight[2], ctx->has_weight ? 1 : 0, static_cast<float4*>(sp.p));
-  float mm[6];
-  unsigned long long n_finite = 0;
-  TRY(cloud_minmax(ctx, static_cast<const float4*>(sp.p), nn, mm, &n_finite));
-  if (n_finite != n)
-    return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n) - n_finite);
-  float o[3];
-  int dim[3];
-  double total = 1;
-  for (int a = 0; a < 3; ++a)
+  // can the base grid in place take this update? (same base map, same cell edge, update inside the bounds it was laid out for)
+  bool keep_base = !ctx->lik_base_dirty && ctx->lik_base_n == n_base && ctx->lg.inv_cell == inv && ctx->lik_base_pts.p;
+  if (keep_base && n_upd)
   {
-    o[a] = mm[a] - 2.0f * cell;
-    dim[a] = static_cast<int>(floorf((mm[3 + a] - o[a]) * inv)) + 3;
-    total *= dim[a];
+    float mm_u[6];
+    unsigned long long fin_u = 0;
+    TRY(cloud_minmax(ctx, static_cast<const float4*>(sp.p) + n_base, static_cast<long long>(n_upd), mm_u, &fin_u));
+    if (fin_u != n_upd)
+      return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n_upd) - fin_u);
+    for (int a = 0; a < 3; ++a)
+      keep_base = keep_base && mm_u[a] >= ctx->lik_base_lo[a] && mm_u[3 + a] <= ctx->lik_base_hi[a];
   }
-  if (total > 3.0e9)
-    return ctx->fail(-4, "likelihood grid would need %.3g cells (map extent too large for the dense index)", total);
-  const size_t ncell = static_cast<size_t>(dim[0]) * dim[1] * dim[2];
-  TRY(ensure(ctx, ctx->lik_pts, sizeof(float4) * n));
-  TRY(ensure(ctx, ctx->lik_cells, sizeof(uint32_t) * (ncell + 1)));
-  TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
-  TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n + 1)));
-  HIP_TRY(hipMemsetAsync(ctx->lik_cells.p, 0, sizeof(uint32_t) * (ncell + 1), ctx->stream));
-  const CellGeom g{ o[0], o[1], o[2], inv, dim[0], dim[1], dim[2] };
-  hipLaunchKernelGGL(lik_cell_key_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
-                     nn, g, ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->lik_cells.as<uint32_t>());
-  TRY(sort_pairs(ctx, nn, sort_bits(ncell)));
-  hipLaunchKernelGGL(grid_gather_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
-                     ctx->cl_val[1].as<uint32_t>(), nn, ctx->lik_pts.as<float4>());
-  HIP_TRY(hipGetLastError());
-  TRY(device_exclusive_scan(ctx, ctx->lik_cells.as<uint32_t>(), static_cast<long long>(ncell) + 1));
+  if (!keep_base)
+  {
+    float mm[6];
+    unsigned long long n_finite = 0;
+    TRY(cloud_minmax(ctx, static_cast<const float4*>(sp.p), nn, mm, &n_finite));
+    if (n_finite != n)
+      return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n) - n_finite);
+    float o[3];
+    int dim[3];
+    double total = 1;
+    for (int a = 0; a < 3; ++a)
+    {
+      o[a] = mm[a] - 2.0f * cell;
+      dim[a] = static_cast<int>(floorf((mm[3 + a] - o[a]) * inv)) + 3;
+      total *= dim[a];
+    }
+    if (total > 3.0e9)
+      return ctx->fail(-4, "likelihood grid would need %.3g cells (map extent too large for the dense index)", total);
+    const size_t ncell = static_cast<size_t>(dim[0]) * dim[1] * dim[2];
+    const long long nb = static_cast<long long>(n_base);
+    TRY(ensure(ctx, ctx->lik_base_pts, sizeof(float4) * n_base));
+    TRY(ensure(ctx, ctx->lik_base_cells, sizeof(uint32_t) * (ncell + 1)));
+    TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n + 1)));
+    TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n + 1)));
+    TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n + 1)));
+    TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n + 1)));
+    HIP_TRY(hipMemsetAsync(ctx->lik_base_cells.p, 0, sizeof(uint32_t) * (ncell + 1), ctx->stream));
+    const CellGeom g{ o[0], o[1], o[2], inv, dim[0], dim[1], dim[2] };
+    hipLaunchKernelGGL(lik_cell_key_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
+                       nb, g, ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>(), ctx->lik_base_cells.as<uint32_t>());
+    TRY(sort_pairs(ctx, nb, sort_bits(ncell)));
+    hipLaunchKernelGGL(grid_gather_kernel, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, static_cast<const float4*>(sp.p),
+                       ctx->cl_val[1].as<uint32_t>(), nb, ctx->lik_base_pts.as<float4>());
+    HIP_TRY(hipGetLastError());
+    TRY(device_exclusive_scan(ctx, ctx->lik_base_cells.as<uint32_t>(), static_cast<long long>(ncell) + 1));
+    ctx->lg.ox = o[0];
+    ctx->lg.oy = o[1];
+    ctx->lg.oz = o[2];
+    ctx->lg.inv_cell = inv;
+    ctx->lg.nx = dim[0];
+    ctx->lg.ny = dim[1];
+    ctx->lg.nz = dim[2];
+    for (int a = 0; a < 3; ++a)
+    {
+      ctx->lik_base_lo[a] = mm[a];
+      ctx->lik_base_hi[a] = mm[3 + a];
+    }
+    ctx->lik_base_n = n_base;
+    ctx->lik_base_dirty = false;
+    ++ctx->lik_grid_rebuilds;
+  }
+  const size_t ncell = static_cast<size_t>(ctx->lg.nx) * ctx->lg.ny * ctx->lg.nz;
+  if (n_upd == 0)
+  {
+    ctx->lg.cell_start = ctx->lik_base_cells.as<uint32_t>();
+    ctx->lg.pts = ctx->lik_base_pts.as<float4>();
+  }
+  else
+  {
+    const CellGeom g{ ctx->lg.ox, ctx->lg.oy, ctx->lg.oz, inv, ctx->lg.nx, ctx->lg.ny, ctx->lg.nz };
+    const int nu = static_cast<int>(n_upd);
+    TRY(ensure(ctx, ctx->lik_pts, sizeof(float4) * n));
+    TRY(ensure(ctx, ctx->lik_cells, sizeof(uint32_t) * (ncell + 1)));
+    TRY(ensure(ctx, ctx->cl_key[0], sizeof(uint32_t) * (n_upd + 1)));
+    TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n_upd + 1)));
+    TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n_upd + 1)));
+    TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n_upd + 1)));
+    const float4* sp_upd = static_cast<const float4*>(sp.p) + n_base;
+    hipLaunchKernelGGL(lik_update_key_kernel, dim3(blocks_for(nu)), dim3(256), 0, ctx->stream, sp_upd, nu, g,
+                       ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>());
+    TRY(sort_pairs(ctx, nu, sort_bits(ncell)));
+    hipLaunchKernelGGL(lik_merge_cells_kernel, dim3(blocks_for(static_cast<long long>(ncell) + 1)), dim3(256), 0, ctx->stream,
+                       ctx->lik_base_cells.as<uint32_t>(), static_cast<long long>(ncell) + 1, ctx->cl_key[1].as<uint32_t>(),
+                       static_cast<uint32_t>(n_upd), ctx->lik_cells.as<uint32_t>());
+    hipLaunchKernelGGL(lik_merge_points_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream,
+                       ctx->lik_base_pts.as<float4>(), static_cast<long long>(n_base), ctx->lik_base_cells.as<uint32_t>(), g,
+                       sp_upd, ctx->cl_key[1].as<uint32_t>(), ctx->cl_val[1].as<uint32_t>(), static_cast<uint32_t>(n_upd),
+                       ctx->lik_pts.as<float4>());
+    HIP_TRY(hipGetLastError());
+    ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
+    ctx->lg.pts = ctx->lik_pts.as<float4>();
+    if (keep_base)
+      ++ctx->lik_grid_merges;
+  }
   HIP_TRY(hipEventRecord(tm.ev1, ctx->stream));
   TRY(sync_stream(ctx));
   float ms = 0.f;
   HIP_TRY(hipEventSynchronize(tm.ev1));  // (the stream may have been waited for through the polled word: the event is past, the runtime has to look)
   HIP_TRY(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
   ctx->grid_build_ms[0] = ms;
-  ctx->lg.cell_start = ctx->lik_cells.as<uint32_t>();
-  ctx->lg.pts = ctx->lik_pts.as<float4>();
-  ctx->lg.ox = o[0];
-  ctx->lg.oy = o[1];
-  ctx->lg.oz = o[2];
-  ctx->lg.inv_cell = inv;
-  ctx->lg.nx = dim[0];
-  ctx->lg.ny = dim[1];
-  ctx->lg.nz = dim[2];
   ctx->footprint[0] = sizeof(float4) * n;
   ctx->footprint[1] = sizeof(uint32_t) * (ncell + 1);
   ctx->lik_dirty = false;

@@ -4,7 +4,8 @@ ORDER of calls. Here every sequence draws >= 30 calls from
 
     set_map / map_update (inside and outside the base map's bounds) / set_likelihood_params / set_beam_params /
     set_option (poll_sync 0/1/2, strict_order 0/1/2/3, update_stage, update_zero_copy, update_small, pf_fused, pf_tail,
-    lik_coop, lik_defer, overlap_models, batch_slice, scan_order_device, lik_tiled_min, poll_spin_us) /
+    lik_coop, lik_defer, overlap_models, batch_slice, scan_order_device, lik_tiled_min, poll_spin_us, lik_index 0/1/2 — the
+    cell grid that a map update merges instead of rebuilding —, cand_aniso) /
     measure_batch / measure_batch_begin.._wait.._end with calls in between and batches abandoned until a later _end /
     measure_update on pageable and on page-locked arrays / scan_begin + scan_finish + measure_device /
     resample_begin + _plan / expectation / the same update through a device group of two contexts
@@ -36,11 +37,11 @@ RTOL_FP64 = 3e-5   # the fp64 mode against the reference's sequential float sum 
 
 DEFAULTS = dict(poll_sync=2, strict_order=2, update_stage=1, update_zero_copy=1, update_small=1, pf_fused=1, pf_tail=0,
                 lik_coop=1, lik_defer=1, overlap_models=1, batch_slice=0, scan_order_device=4096, lik_tiled_min=1024,
-                poll_spin_us=2000)
+                poll_spin_us=2000, lik_index=2, cand_aniso=2)
 CHOICES = dict(poll_sync=(0, 1, 2), strict_order=(0, 1, 2, 3), update_stage=(0, 1), update_zero_copy=(0, 1),
                update_small=(0, 1), pf_fused=(0, 1), pf_tail=(0, 1), lik_coop=(0, 1), lik_defer=(0, 1, 2),
                overlap_models=(0, 1), batch_slice=(0, 64, 128), scan_order_device=(0, 512, 4096),
-               lik_tiled_min=(256, 1024), poll_spin_us=(0, 50, 2000))
+               lik_tiled_min=(256, 1024), poll_spin_us=(0, 50, 2000), lik_index=(2, 2, 1, 0), cand_aniso=(2, 1, 0))
 
 
 @pytest.fixture(scope="module")

@@ -362,3 +362,53 @@ def test_device_built_grids_equal_the_host_built_ones():
     for a, b in zip(out[0], out[1]):
         np.testing.assert_array_equal(a, b)
     assert (out[0][3] >= 0).sum() > 1000 and len(np.unique(out[0][5])) >= 2 and out[0][6].max() >= len(sc.map_xyz)
+
+
+def test_the_cell_grid_takes_a_map_update_by_merging(engine):
+    """Round 5: the cell-sorted grid behind matched / unmatched, radius_search and lik_index = 0 used to
+    be rebuilt whole (keys, histogram, sort of the map, gather, scan) on the first use after every map update. Now the BASE map's
+    grid is kept and the update's points are merged into a copy of it — pc_map2 = pc_map + pc_update puts them behind the base
+    points of their cell (src/mcl_3dl.cpp:150) — unless the update leaves the bounds the grid was laid out for. Equal, query by
+    query, to a fresh engine on the merged map."""
+    from mcl_3dl_amd import capi
+    sc = make_scene(n=91, n_p=64, n_s=1500, seed=8)
+    rng = np.random.default_rng(12)
+    half = 91 * 0.1 / 2
+    fresh = capi.Engine(0)
+    dw = (1.0, 1.0, 5.0)
+    try:
+        engine.set_map(sc.map_xyz, sc.map_label, stamp=4400, dist_weight=dw)
+        engine.set_likelihood_params()
+        queries = (sc.scan_lik[:1200] @ np.eye(3, dtype=np.float32) + sc.true_pose[:3]).astype(np.float32)
+        engine.radius_search(queries, 0.3)                           # builds the base grid
+        r0, m0 = engine.get_option("lik_grid_rebuilds"), engine.get_option("lik_grid_merges")
+        for k, inside in enumerate([True, True, False, True, True]):
+            span = half - 0.5 if inside else half + 2.0
+            pts = rng.uniform(-span, span, (int(rng.integers(1, 400)), 3)).astype(np.float32)
+            pts[:, 2] = rng.uniform(-half + 0.1, -half + 2.0, len(pts))
+            engine.map_update(pts, rng.integers(0, 3, len(pts)).astype(np.uint32), leaf=(0.2, 0.2, 0.2), stamp=4401 + k)
+            mx, ml = engine.map_download()
+            fresh.set_map(mx, ml, stamp=4500 + k, dist_weight=dw)
+            fresh.set_likelihood_params()
+            q = np.concatenate([queries, (mx[-len(pts):] + rng.normal(0, 0.05, (len(pts), 3))).astype(np.float32)])
+            for radius in (0.2, 0.5):
+                a, b = engine.radius_search(q, radius), fresh.radius_search(q, radius)
+                np.testing.assert_array_equal(a[0], b[0])
+                np.testing.assert_array_equal(a[1], b[1])
+            ms_a = engine.match_split(sc.true_pose, sc.scan_lik)
+            ms_b = fresh.match_split(sc.true_pose, sc.scan_lik)
+            for x, y in zip(ms_a, ms_b):
+                np.testing.assert_array_equal(x, y)
+            try:
+                engine.set_option("lik_index", 0)
+                fresh.set_option("lik_index", 0)
+                np.testing.assert_array_equal(engine.measure_batch(sc.poses, sc.scan_lik)[1],
+                                              fresh.measure_batch(sc.poses, sc.scan_lik)[1])
+            finally:
+                engine.set_option("lik_index", 2)
+                fresh.set_option("lik_index", 2)
+        r1, m1 = engine.get_option("lik_grid_rebuilds"), engine.get_option("lik_grid_merges")
+        # five updates: the one that left the bounds rebuilt the base (for the wider bounds), the others merged
+        assert r1 - r0 == 1 and m1 - m0 == 4, (r0, r1, m0, m1)
+    finally:
+        fresh.close()
