@@ -948,20 +948,28 @@ def main():
         value = evals_per_step * args.steps / elapsed
         lik_avg_ms = lik_ms / max(lik_n, 1)
         stats = main_sh.d_stats.cpu().numpy()
-        tiled = bool(args.lik_tiled and n_p >= 4 and (n_s >= tiled_min or (n_p >= 256 and 4 * n_s >= 3 * tiled_min))) or strict_lik
+        tiled = (bool(args.lik_tiled and n_p >= 4 and (n_s >= tiled_min or (n_p >= 256 and 4 * n_s >= 3 * tiled_min))) or strict_lik
+                 or strict_mode == 3)
         group = _tiled_group(n_s, n_p, args.lik_group)
+        if strict_mode == 3:
+            group = min(group, 16)
         small = (not tiled) and n_s <= 32 and n_p >= 256 and args.lik_small
         if tiled:
             coop = bool(lik_coop and args.lik_index == 2)
             defer = bool(coop and int(eng.get_option("lik_defer_active")))
-            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %s, %s>" % (group, args.lik_index, 4 if group == 32 else 8,
-                                                                           "true" if coop else "false",
-                                                                           "true" if defer else "false")
+            kernel_name = "likelihood_tiled_kernel<%d, %d, %d, %s, %s, %s>" % (group, args.lik_index, 4 if group == 32 else 8,
+                                                                               "true" if coop else "false",
+                                                                               "true" if defer else "false",
+                                                                               "true" if strict_mode == 3 else "false")
         elif small:
             kernel_name = "likelihood_small_kernel<"
         else:
             wide = args.lik_index == 2 and n_s > 512 and n_p <= int(eng.get_option("lik_wide_max_particles"))
             kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 1024 if wide else 256, args.lik_index)
+            if one_launch:
+                # the whole update as ONE launch (update_kernels.h): that kernel is what was timed, and what the counters are of
+                kernel_name = "update_small_kernel<%d, %d, true>" % (64 if n_s <= 128 else 1024 if wide else 256,
+                                                                     args.lik_index)
         # counters of the same map kind: profiles/*_C2j_* = C2 with displaced map points (--map-jitter)
         pmc_tag = args.workload + ("j" if args.map_jitter else "")
         pmc, pmc_src, pmc_refused = pmc_counters("void mcl3dl::" + kernel_name, pmc_tag)
@@ -1187,6 +1195,35 @@ def main():
                                         "ordering + pose/weight H2D + kernels + weight/likelihood D2H, PCIe included (SURVEY.md "
                                         "section 8d's timed region); pageable caller arrays (ms_per_update) and arrays from "
                                         "mcl3dl_hip_host_alloc (ms_per_update_page_locked_arrays)"}
+            if not args.no_extras and args.workload in ("C1", "C2", "C3") and strict_mode in (0, 2):
+                # The same region for a caller that HOLDS its scan in the engine's order (mcl3dl_hip_scan_order_host; the drop-in
+                # classes with MCL3DL_HIP_ENGINE_ORDER=1): no ordering launches (scan_presorted) and the reference's float
+                # recurrence inside the likelihood kernel (strict_order = 3) — likelihoods bit-identical to the reference on the
+                # caller's own array — next to the caller-order replay (strict_order = 1). Checked against the CPU reference below.
+                held = np.ascontiguousarray(h_lik[capi.scan_order_host(h_lik)])
+                eo = {}
+                e_lik, e_ratio, e_beam = (np.zeros(n_p, np.float32) for _ in range(3))
+                try:
+                    for tag, scan_arr, so, pre in (("caller_order_replay", h_lik, 1, 0), ("engine_order_in_kernel", h_lik, 3, 0),
+                                                   ("held_in_engine_order_presorted_fp64", held, 0, 1),
+                                                   ("held_in_engine_order_presorted_in_kernel", held, 3, 1)):
+                        eng.set_option("strict_order", so)
+                        eng.set_option("scan_presorted", pre)
+                        with no_gc():
+                            ms_e, _ = eng.time_measure_update(h_pose, h_w0, h_w0.copy(), scan_arr, h_beam, h_lab, h_org, e_lik, e_ratio,
+                                                              e_beam, args.steps, warm_ms=100.0)
+                        eo[tag + "_ms"] = ms_e
+                finally:
+                    eng.set_option("strict_order", strict_mode)
+                    eng.set_option("scan_presorted", 0)
+                eo["default_ms"] = host_ms
+                eo["held_scan_likelihoods"] = e_lik.copy()   # (popped again below: compared with the CPU reference on `held`)
+                eo["held_scan"] = held
+                eo["what"] = ("mcl3dl_hip_measure_update on host buffers timed from C, as update_8d: the float sums replayed in the "
+                              "caller's order behind the kernel (strict_order 1), run inside the kernel in the engine's order (3), "
+                              "and for a caller that holds its scan in that order (option scan_presorted: no ordering launches) — "
+                              "the last one is bit-identical to the reference on the caller's own array")
+                out["engine_order"] = eo
             eng.set_stream(stream.cuda_stream)
         if not args.no_extras:
             # the reductions that follow the update in the node (expectationBiased + max + covariance) on the
@@ -1301,8 +1338,21 @@ def main():
                                                 "reference's own rounding (random walk: ~5e-6 at 16 384 points, ~1e-5 at "
                                                 "65 536); --strict-order 1 reproduces the reference's float bit for bit")
             out["result_check"]["cpu_sample_particles"] = n
+            eo = out.get("engine_order")
+            if eo and "held_scan" in eo:
+                from oracle import pyoracle as _po
+                o2 = _po.Oracle("ref" if _po.available("ref") else "port")
+                o2.set_map(sc.map_xyz, sc.map_label, dist_weight=dist_weight)
+                o2.set_likelihood_params(_po.LikelihoodParams())
+                m = min(n, 64)
+                ref_lik, _q = o2.likelihood_measure(sc.poses[:m], eo["held_scan"])
+                eo["bit_identical_to_cpu_reference_on_the_held_scan"] = bool(np.array_equal(eo["held_scan_likelihoods"][:m], ref_lik))
+                eo["checked_particles"] = m
         else:
             out["cpu_baseline"] = None
+        if "engine_order" in out:
+            out["engine_order"].pop("held_scan", None)
+            out["engine_order"].pop("held_scan_likelihoods", None)
         if world == 1 and not args.no_extras:
             ra = route_a(sc, dist_weight, n_b, args.route_a_reps if args.workload in ("C1", "C2", "C3") else 0)
             if ra:
@@ -1322,7 +1372,18 @@ def main():
             # the node replaces its update cloud every few seconds (src/mcl_3dl.cpp:141-153): the steady state is an update
             # that REPLACES the previous one — the same surface moved by a centimetre each time (the first call also pays for
             # the scratch blocks every later one recycles)
-            walls, outcomes, after, steady = [], [], [], []
+            walls, outcomes, after, steady, split_after, split_steady = [], [], [], [], [], []
+            split_cloud = np.ascontiguousarray(sc.scan_lik)
+            m_out, u_out = (eng.host_array((len(split_cloud), 3)) for _ in range(2))
+
+            def small_split():
+                # matched / unmatched of the scan (src/mcl_3dl.cpp:761-805): the consumer of the cell grid, which a map update
+                # now merges into instead of rebuilding (host_grid_builders.h)
+                t9 = time.perf_counter()
+                eng.match_split_into(sc.true_pose, m_out, u_out, xyz=split_cloud)
+                return (time.perf_counter() - t9) * 1e3
+
+            small_split()
 
             def small_measure():
                 # 64 particles against the whole scan, both models: whatever the update left to rebuild is paid here
@@ -1340,12 +1401,18 @@ def main():
                 outcomes.append(int(ust["outcome"]))
                 after.append(small_measure())
                 steady.append(small_measure())
+                split_after.append(small_split())
+                split_steady.append(small_split())
             wall_ms = float(np.median(walls))
             out["map_update"] = dict(ust, update_points=int(n_map - len(sc.map_xyz)), map_points=int(len(sc.map_xyz)),
                                      wall_ms=wall_ms, wall_ms_first=first_ms, wall_ms_each=walls, outcomes=outcomes,
                                      overflow_compactions=int(eng.get_option("cand_ovf_compactions")),
                                      first_measure_after_update_ms=float(np.median(after)),
                                      same_measure_steady_ms=float(np.median(steady)),
+                                     first_match_split_after_update_ms=float(np.median(split_after)),
+                                     same_match_split_steady_ms=float(np.median(split_steady)),
+                                     cell_grid_merges=int(eng.get_option("lik_grid_merges")),
+                                     cell_grid_rebuilds=int(eng.get_option("lik_grid_rebuilds")),
                                      dda_overlay_updates=int(eng.get_option("dda_overlay_updates")),
                                      full_build_ms=full_ms,
                                      what="mcl3dl_hip_map_update: VoxelGrid of the update + incremental index update "
@@ -1356,6 +1423,8 @@ def main():
                                           "behind each update (it pays for whatever the update left to rebuild: nothing, when "
                                           "the DDA grid took the update as an overlay) next to the same call once more")
             eng.map_update(None, None, stamp=78)  # withdraw it again
+            eng.host_free(m_out)
+            eng.host_free(u_out)
         if world == 1 and not args.no_extras and args.jitter_check > 0 and args.workload in ("C2", "C3") and not args.map_jitter:
             # standing robustness figure: the same workload on a map whose points are voxel-filter centroids, not a lattice
             scj = make_config(args.workload, n_p=n_cfg, seed=12345, map_jitter=args.jitter_check, **extra_cfg)

@@ -536,6 +536,11 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       the reference's measure() on the scan permuted that way; no term buffer, no replay pass (the
  *                       work-group of a scan tile hands each particle's running sum on to the next tile's). Weights are
  *                       summed as in mode 2. Suits callers whose scan order means nothing to them (a sampled cloud).
+ *   "scan_presorted"    1 = the caller holds its likelihood scans in the engine's order already (mcl3dl_hip_scan_order_host): every
+ *                       scan is installed as it is — no ordering launches (four of the ten launches of a host-buffer update at
+ *                       16 384 points), the permutation is the identity, and with "strict_order" = 3 (or 1) the float sums follow
+ *                       the caller's own order. A scan that is NOT in that order is still evaluated correctly, in the order it
+ *                       has; only the likelihood kernel loses the locality the order exists for. 0 (default) = ordered here.
  *   "strict_chunk"      0 (default) = a caller-order replay ("strict_order" 1 / 2) keeps the terms of the whole scan (n_s x n_p floats);
  *                       a point count >= 1024 = scans of at least two such chunks are ordered chunk by chunk of the caller's order
  *                       and replayed chunk by chunk with two term buffers (C5: 4.3 GB instead of 17 GB, 27.9 instead of 25.6 ms:

@@ -51,6 +51,7 @@ Engine& Engine::shared()
       if (std::atoi(eo) != 0)
       {
         engine.check(mcl3dl_hip_group_set_option(engine.group(), "strict_order", 3.0));
+        engine.check(mcl3dl_hip_group_set_option(engine.group(), "scan_presorted", 1.0));  // filter() has ordered the cloud
         engine.engine_order = true;
       }
     return true;

@@ -245,7 +245,8 @@ int mcl3dl_hip_set_beam_params(mcl3dl_hip_ctx* ctx, float map_grid_x, float map_
 // Host-side ordering of one update's scans (no device work): shared by the single-context upload and by a device group,
 // which orders once and pushes the same arrays to every GPU. Returns 0, or -3 with `err` filled.
 static int order_scan(std::string& err, const float* scan_lik_xyz, size_t n_s, const float* scan_beam_xyz,
-                      const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o, OrderedScan& o)
+                      const uint32_t* scan_beam_origin, size_t n_b, const float* origins, size_t n_o, OrderedScan& o,
+                      bool presorted = false)
 {
   if ((n_s && !scan_lik_xyz) || (n_b && (!scan_beam_xyz || !origins || n_o == 0)))
   {
@@ -261,7 +262,16 @@ static int order_scan(std::string& err, const float* scan_lik_xyz, size_t n_s, c
   std::vector<float4>& lik = o.lik;
   lik.resize(n_s);
   o.perm.resize(n_s);
-  if (n_s)
+  if (n_s && presorted)
+  {
+    // option scan_presorted: the caller's order IS the engine's order
+    for (size_t i = 0; i < n_s; ++i)
+    {
+      lik[i] = make_float4(scan_lik_xyz[3 * i], scan_lik_xyz[3 * i + 1], scan_lik_xyz[3 * i + 2], 0.f);
+      o.perm[i] = static_cast<uint32_t>(i);
+    }
+  }
+  else if (n_s)
   {
     // min / max over the finite points (like the device's cloud_minmax)
     float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
@@ -444,7 +454,7 @@ static int upload_scan_impl(mcl3dl_hip_ctx* ctx, const float* scan_lik_xyz, size
     return 0;
   }
   std::string err;
-  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, ctx->h_scan) != 0)
+  if (order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, ctx->h_scan, ctx->scan_presorted != 0) != 0)
     return ctx->fail(-3, "%s", err.c_str());
   return push_scan(ctx, ctx->h_scan, sync_at_end);
 }
@@ -964,6 +974,7 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   float* d_ratio = reinterpret_cast<float*>(blk + 64 + 2 * rpart);
   float* d_beam = reinterpret_cast<float*>(blk + 64 + 3 * rpart);
   StageArgs a{};
+  a.presorted = ctx->scan_presorted;
   a.in_pose = static_cast<const float*>(part[0].dev);
   a.in_w = static_cast<const float*>(part[1].dev);
   a.in_extra = static_cast<const float*>(part[2].dev);

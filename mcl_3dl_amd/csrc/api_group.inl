@@ -248,7 +248,8 @@ int mcl3dl_hip_group_measure_batch(mcl3dl_hip_group* g, const float* pose, size_
   }
   const bool device_order = g->ctx[0]->scan_order_device > 0 && n_s + n_b >= static_cast<size_t>(g->ctx[0]->scan_order_device);
   std::string err;
-  if (!device_order && order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan) != 0)
+  if (!device_order &&
+      order_scan(err, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b, origins, n_o, g->scan, g->ctx[0]->scan_presorted != 0) != 0)
     return g->fail(-3, "%s", err.c_str());
   if (pose)
     g->n_pose_uploaded = 0;
@@ -604,7 +605,7 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
                              [&]
                              {
                                host_ordered = order_scan(host_order_error, scan_lik_xyz, n_s, scan_beam_xyz, scan_beam_origin, n_b,
-                                                         origins, n_o, g->scan) == 0;
+                                                         origins, n_o, g->scan, g->ctx[0]->scan_presorted != 0) == 0;
                              });
               if (!host_ordered)
                 return ctx->fail(-3, "%s", host_order_error.c_str());

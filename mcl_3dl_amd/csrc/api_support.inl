@@ -202,6 +202,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->update_small_max = static_cast<int>(value);
     return 0;
   }
+  if (key == "scan_presorted")
+  {
+    ctx->scan_presorted = value != 0.0 ? 1 : 0;
+    return 0;
+  }
   if (key == "strict_chunk")
   {
     if (!(value == 0.0 || (value >= 1024.0 && value <= 1e9)))
@@ -421,6 +426,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "strict_order") *value = ctx->strict_order;
   else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
   else if (key == "strict_chunk") *value = ctx->strict_chunk;
+  else if (key == "scan_presorted") *value = ctx->scan_presorted;
   else if (key == "scan_chunk_in_use") *value = static_cast<double>(ctx->scan_chunk);
   else if (key == "lik_grid_merges") *value = static_cast<double>(ctx->lik_grid_merges);
   else if (key == "lik_grid_rebuilds") *value = static_cast<double>(ctx->lik_grid_rebuilds);

@@ -448,6 +448,18 @@ int scan_begin_common(mcl3dl_hip_ctx* ctx, size_t n, const float* leaf3, const f
 // produce the same order and with it bit-identical results. Keys are made inside the sort's first pass and the points are
 // written by its last one. have_minmax: ctx->cl_minmax holds the min corner of sp_samp[0] already. Raises error flag 2
 // (*d_err, device memory) for a bad origin id.
+__global__ void scan_install_kernel(const float4* __restrict__ src, long long n, float4* __restrict__ dst,
+                                    uint32_t* __restrict__ perm)
+{
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  float4 q = src[i];
+  q.w = 0.f;
+  dst[i] = q;
+  perm[i] = static_cast<uint32_t>(i);
+}
+
 int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float* origins, size_t n_o, bool have_minmax,
                        int* d_err)
 {
@@ -467,6 +479,14 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
     // at least two chunks long: ordered chunk by chunk of the caller's order (same keys, same bounding box for every chunk)
     const size_t chunk = (ctx->strict_chunk >= 1024 && (ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min)) &&
                           n_s >= 2 * static_cast<size_t>(ctx->strict_chunk)) ? static_cast<size_t>(ctx->strict_chunk) & ~static_cast<size_t>(255) : 0;
+    if (ctx->scan_presorted)
+    {
+      // option scan_presorted: the caller holds its scans in the engine's order (mcl3dl_hip_scan_order_host) — installed as
+      // they are, permutation = identity, no ordering launches
+      hipLaunchKernelGGL(scan_install_kernel, dim3(blocks_for(ns)), dim3(256), 0, ctx->stream, ctx->sp_samp[0].as<float4>(), ns,
+                         ctx->scan_lik.as<float4>(), ctx->scan_perm.as<uint32_t>());
+    }
+    else
     for (size_t first = 0; first < n_s; first += chunk ? chunk : n_s)
     {
       const size_t n = chunk ? std::min(chunk, n_s - first) : n_s;
@@ -476,7 +496,7 @@ int device_order_scans(mcl3dl_hip_ctx* ctx, size_t n_s, size_t n_b, const float*
       const RsFinal fin{ ctx->sp_samp[0].as<float4>() + first, ctx->scan_lik.as<float4>() + first, ctx->scan_perm.as<uint32_t>() + first, 1 };
       TRY(radix_sort<RS_KEY_MORTON>(ctx, kg, static_cast<long long>(n), MCL3DL_MORTON_BITS, &fin));
     }
-    ctx->scan_chunk = chunk;
+    ctx->scan_chunk = ctx->scan_presorted ? 0 : chunk;
   }
   if (n_o && origins)  // (origins == nullptr: the caller's kernel has put them into ctx->origins already)
   {

@@ -123,6 +123,7 @@ struct mcl3dl_hip_ctx
   // scan_chunk = chunk size the scan in place was ordered with (0 = one piece).
   size_t scan_chunk = 0;
   int strict_chunk = 0;
+  int scan_presorted = 0;  // option: likelihood scans arrive in the engine's order already — no ordering pass (see include/mcl3dl_hip.h)
   hipStream_t replay_stream = nullptr;
   hipEvent_t ev_tiled[2] = { nullptr, nullptr }, ev_replay[2] = { nullptr, nullptr };
   // the whole update as one launch (update_kernels.h) up to update_small_max particles when the per-particle likelihood

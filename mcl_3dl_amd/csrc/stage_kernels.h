@@ -58,6 +58,7 @@ struct StageArgs
   int n_o;
   float4* d_origins;
   int* d_err;                   // set to 2 when a beam point names an origin that does not exist
+  int presorted;                // option scan_presorted: the likelihood scan is installed in the caller's order as it is
 };
 
 template <int ROUNDS>
@@ -80,7 +81,7 @@ __device__ __forceinline__ void stage_order(const float* __restrict__ in_xyz, co
                                             float4* __restrict__ raw, float4* __restrict__ out, uint32_t* __restrict__ perm,
                                             float* __restrict__ mm6_out, unsigned long long* __restrict__ cnt_out,
                                             const float4* __restrict__ origins, uint32_t n_o, int* __restrict__ err,
-                                            StageLds<ROUNDS>& s)
+                                            StageLds<ROUNDS>& s, bool presorted = false)
 {
   static_assert(KEYMODE == RS_KEY_MORTON || KEYMODE == RS_KEY_RANGE, "scan keys only");
   const int rounds = (n + RS_THREADS - 1) / RS_THREADS;
@@ -139,6 +140,22 @@ __device__ __forceinline__ void stage_order(const float* __restrict__ in_xyz, co
     }
   }
   __syncthreads();  // raw[] (written by this work-group) and s.mm6 are visible to every thread of it
+  if (KEYMODE == RS_KEY_MORTON && presorted)
+  {
+    // the caller holds its scan in the engine's order already (mcl3dl_hip_scan_order_host): installed as it is
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+      if ((valid >> r) & 1u)
+      {
+        const int idx = (w * rounds + r) * 64 + lane;
+        float4 q = raw[idx];
+        q.w = 0.f;
+        out[idx] = q;
+        if (perm)
+          perm[idx] = static_cast<uint32_t>(idx);
+      }
+    return;
+  }
   // ---- keys
   float mmr[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
   if (KEYMODE == RS_KEY_MORTON)
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(RS_THREADS) void scan_stage_kernel(StageArgs a)
   {
     if (a.n_s > 0)
       stage_order<ROUNDS, RS_KEY_MORTON>(a.in_lik_xyz, nullptr, a.n_s, a.raw_lik, a.out_lik, a.out_perm, a.mm6, a.mm_cnt,
-                                         nullptr, 0u, nullptr, s);
+                                         nullptr, 0u, nullptr, s, a.presorted != 0);
     return;
   }
   if (blockIdx.x == 1)

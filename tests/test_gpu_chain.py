@@ -162,3 +162,35 @@ def test_scan_order_errors(engine):
     with pytest.raises(RuntimeError):
         engine.scan_order(99)
     check_order(engine.scan_order(100), 100)
+
+
+@pytest.mark.parametrize("n_p,n_s", [(40, 300), (64, 1000), (300, 5000), (700, 16384)])
+def test_presorted_scans_are_installed_as_they_are(engine, oracle_kind, n_p, n_s):
+    """Option scan_presorted: a caller that holds its scan in the engine's order (mcl3dl_hip_scan_order_host) skips the ordering
+    launches; strict_order = 3 then sums in the CALLER's order — bit-identical to the reference on the caller's own array. A
+    scan that is not in that order is evaluated in the order it has, at every size (same bits as the reference again)."""
+    from mcl_3dl_amd import capi
+    sc = make_scene(n=91, n_p=n_p, n_s=n_s, seed=200 + n_s)
+    dw = (1.0, 1.0, 5.0)
+    setup_engine(engine, sc, dw, stamp=390 + n_s)
+    o = make_oracle(oracle_kind, sc, dw)
+    held = np.ascontiguousarray(sc.scan_lik[capi.scan_order_host(sc.scan_lik)])
+    with chain_mode(engine, scan_presorted=1):
+        lik_held, q_held, _ = engine.measure_batch(sc.poses, held)
+        np.testing.assert_array_equal(engine.scan_order(n_s), np.arange(n_s, dtype=np.uint32))
+        lik_raw, q_raw, _ = engine.measure_batch(sc.poses, sc.scan_lik)          # NOT ordered: summed as it is
+        np.testing.assert_array_equal(engine.scan_order(n_s), np.arange(n_s, dtype=np.uint32))
+        w0 = np.full(n_p, 1.0 / n_p, np.float32)
+        upd = engine.measure_update(sc.poses, w0, held)
+    want_held, want_q = o.likelihood_measure(sc.poses, held)
+    want_raw, _ = o.likelihood_measure(sc.poses, sc.scan_lik)
+    np.testing.assert_array_equal(lik_held, want_held)
+    np.testing.assert_array_equal(q_held, want_q)
+    np.testing.assert_array_equal(lik_raw, want_raw)
+    np.testing.assert_array_equal(q_raw, want_q)
+    np.testing.assert_array_equal(upd["lik"], want_held)
+    # and without the option the engine orders the held scan itself — to the same order
+    with chain_mode(engine):
+        lik2, _, _ = engine.measure_batch(sc.poses, held)
+        np.testing.assert_array_equal(engine.scan_order(n_s), np.arange(n_s, dtype=np.uint32))
+    np.testing.assert_array_equal(lik2, want_held)
