@@ -91,6 +91,8 @@ __global__ void lik_update_key_kernel(const float4* __restrict__ sp_upd, int n_u
   val[i] = static_cast<uint32_t>(i);
 }
 
+// (measured and not kept: one search per run of eight consecutive cells / points followed by a linear walk of the keys —
+// 0.138 ms instead of 0.112 at C2: the strided runs cost more in uncoalesced accesses than the searches they save)
 __global__ void lik_merge_cells_kernel(const uint32_t* __restrict__ base_start, long long n_cell_plus_1,
                                        const uint32_t* __restrict__ ukey, uint32_t n_u, uint32_t* __restrict__ out_start)
 {

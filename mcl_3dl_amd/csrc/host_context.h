@@ -90,6 +90,7 @@ struct mcl3dl_hip_ctx
   size_t lik_base_n = 0;
   float lik_base_lo[3] = { 0, 0, 0 }, lik_base_hi[3] = { 0, 0, 0 };  // rescaled bounds the base grid's geometry was laid out for
   uint64_t lik_grid_merges = 0, lik_grid_rebuilds = 0;
+  std::vector<float4> lik_upd_host;  // the update's rescaled points (host staging of the merge)
   LikGrid lg{};
   // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
   int lik_index = 2;

@@ -60,26 +60,39 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
   BuildTimer tm;
   HIP_TRY(hipEventCreate(&tm.ev0));
   HIP_TRY(hipEventCreate(&tm.ev1));
-  TRY(ensure_map_dev(ctx));
   HIP_TRY(hipEventRecord(tm.ev0, ctx->stream));
-  TempBuf sp;
-  TRY(scratch_alloc(ctx, sp, sizeof(float4) * n));
-  hipLaunchKernelGGL(grid_rescale_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn,
-                     ctx->weight[0], ctx->weight[1], ctx->weight[2], ctx->has_weight ? 1 : 0, static_cast<float4*>(sp.p));
-  // can the base grid in place take this update? (same base map, same cell edge, update inside the bounds it was laid out for)
+  // can the base grid in place take this update? (same base map, same cell edge, update inside the bounds it was laid out for).
+  // The update's points — a few thousand — are rescaled on the host (the same float product the device forms) and go up alone:
+  // the whole map is neither uploaded nor touched by a kernel unless the base has to be rebuilt.
   bool keep_base = !ctx->lik_base_dirty && ctx->lik_base_n == n_base && ctx->lg.inv_cell == inv && ctx->lik_base_pts.p;
-  if (keep_base && n_upd)
+  std::vector<float4>& upd_host = ctx->lik_upd_host;
+  upd_host.resize(n_upd);
+  for (size_t k = 0; k < n_upd; ++k)
   {
-    float mm_u[6];
-    unsigned long long fin_u = 0;
-    TRY(cloud_minmax(ctx, static_cast<const float4*>(sp.p) + n_base, static_cast<long long>(n_upd), mm_u, &fin_u));
-    if (fin_u != n_upd)
-      return ctx->fail(-3, "%llu map point(s) are not finite", static_cast<unsigned long long>(n_upd) - fin_u);
+    const size_t i = n_base + k;
+    float v[3];
     for (int a = 0; a < 3; ++a)
-      keep_base = keep_base && mm_u[a] >= ctx->lik_base_lo[a] && mm_u[3 + a] <= ctx->lik_base_hi[a];
+    {
+      v[a] = ctx->has_weight ? ctx->map_xyz[3 * i + a] * ctx->weight[a] : ctx->map_xyz[3 * i + a];
+      if (!std::isfinite(v[a]))
+        return ctx->fail(-3, "map point %zu is not finite", i);
+      keep_base = keep_base && v[a] >= ctx->lik_base_lo[a] && v[a] <= ctx->lik_base_hi[a];
+    }
+    upd_host[k] = make_float4(v[0], v[1], v[2], bits_to_float(static_cast<uint32_t>(i)));
+  }
+  TempBuf sp;       // rescaled points of the whole map (only when the base is rebuilt)
+  TempBuf sp_u;     // rescaled points of the update
+  if (n_upd)
+  {
+    TRY(scratch_alloc(ctx, sp_u, sizeof(float4) * n_upd));
+    TRY(h2d(ctx, sp_u.p, upd_host.data(), sizeof(float4) * n_upd));
   }
   if (!keep_base)
   {
+    TRY(ensure_map_dev(ctx));
+    TRY(scratch_alloc(ctx, sp, sizeof(float4) * n));
+    hipLaunchKernelGGL(grid_rescale_kernel, dim3(blocks_for(nn)), dim3(256), 0, ctx->stream, ctx->map_dev.as<float4>(), nn,
+                       ctx->weight[0], ctx->weight[1], ctx->weight[2], ctx->has_weight ? 1 : 0, static_cast<float4*>(sp.p));
     float mm[6];
     unsigned long long n_finite = 0;
     TRY(cloud_minmax(ctx, static_cast<const float4*>(sp.p), nn, mm, &n_finite));
@@ -145,7 +158,7 @@ int build_lik_grid_device(mcl3dl_hip_ctx* ctx)
     TRY(ensure(ctx, ctx->cl_key[1], sizeof(uint32_t) * (n_upd + 1)));
     TRY(ensure(ctx, ctx->cl_val[0], sizeof(uint32_t) * (n_upd + 1)));
     TRY(ensure(ctx, ctx->cl_val[1], sizeof(uint32_t) * (n_upd + 1)));
-    const float4* sp_upd = static_cast<const float4*>(sp.p) + n_base;
+    const float4* sp_upd = static_cast<const float4*>(sp_u.p);
     hipLaunchKernelGGL(lik_update_key_kernel, dim3(blocks_for(nu)), dim3(256), 0, ctx->stream, sp_upd, nu, g,
                        ctx->cl_key[0].as<uint32_t>(), ctx->cl_val[0].as<uint32_t>());
     TRY(sort_pairs(ctx, nu, sort_bits(ncell)));

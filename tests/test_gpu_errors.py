@@ -142,12 +142,12 @@ def test_automatic_strict_order_never_fails_an_update_over_memory(engine):
 def test_a_long_update_does_not_hold_a_core(engine):
     """the polled completion word used to be spun on for the whole kernel (one core pegged for the 26 ms
     of a C5 update). The wait now spins for poll_spin_us (default 2 ms: every update up to a few thousand particles), then naps
-    between looks (1/32 of the time already waited). Measured here: CPU time / wall time of the caller over updates of ~15 ms."""
+    between looks (1/32 of the time already waited). Measured here: CPU time / wall time of the caller over updates of 10-20 ms."""
     import resource
     import time
 
     import torch
-    sc = make_scene(n=91, n_p=64, n_s=2048, seed=77)
+    sc = make_scene(n=91, n_p=64, n_s=8192, seed=77)
     n_p = 400000
     rng = np.random.default_rng(1)
     poses = np.repeat(sc.poses, (n_p + 63) // 64, axis=0)[:n_p].copy()
