@@ -971,7 +971,8 @@ def main():
                 kernel_name = "update_small_kernel<%d, %d, true>" % (64 if n_s <= 128 else 1024 if wide else 256,
                                                                      args.lik_index)
         # counters of the same map kind: profiles/*_C2j_* = C2 with displaced map points (--map-jitter)
-        pmc_tag = args.workload + ("j" if args.map_jitter else "")
+        # (... and *_C2c_* / *_C5c_* = the same workload with the float sums inside the kernel, strict_order = 3)
+        pmc_tag = args.workload + ("j" if args.map_jitter else "") + ("c" if strict_mode == 3 else "")
         pmc, pmc_src, pmc_refused = pmc_counters("void mcl3dl::" + kernel_name, pmc_tag)
         # the committed counters are per launch of ONE shape: use them only for a launch of that many wavefronts
         if tiled:
