@@ -49,11 +49,11 @@ __device__ inline uint32_t spread10(uint32_t v)
 // MCL3DL_MORTON_BITS most significant bits the cloud's extent can set are kept (mm6 = the cloud's {min x, y, z, max x, y, z},
 // device memory). The order only decides which evaluations share a work-group. 16 bits = two radix passes (four launches
 // behind the key-making one) instead of the three a 22-bit key costs or the four of the full 30-bit key: cells of 1 m for a
-// cloud up to 32 m across (2 m up to 64 m, ...). Measured at C2 (scripts/r04_s2.sh, r04_s4.sh: profiles/r04b_time8d_C2_m16.json,
+// cloud up to 32 m across (2 m up to 64 m, ...). Measured at C2 (round-4 sessions s2 / s4, drivers in the git history: profiles/r04b_time8d_C2_m16.json,
 // r04d_time8d_C2_m16.json against the 22-bit build in the same session): likelihood kernel +0.5 % (0.2305 -> 0.2326 ms
 // device-resident step), host-buffer update -2.5 % (0.2918 -> 0.2843 ms: two launches fewer in front of the likelihood
 // kernel, where every dependent launch costs 3-4 us); with 8 bits (one pass) the kernel loses 13 %. Round 3 measured 16 / 22 /
-// 30 bits at C2 / C5 / the map of centroids within 1 % of each other (scripts/r03_s22.sh). api_core.inl:order_scan makes the
+// 30 bits at C2 / C5 / the map of centroids within 1 % of each other (round-3 session s22, git history). api_core.inl:order_scan makes the
 // same key on the host.
 #ifndef MCL3DL_MORTON_BITS
 #define MCL3DL_MORTON_BITS 16   // (A/B builds: 22 / 8 — csrc/Makefile:variants-morton)

@@ -437,7 +437,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (!beam_prepared)  // (beam_origin_kernel zeroes the counters itself)
       {
         // a kernel, not hipMemsetAsync: a memset node at the head of a single-stream captured update faulted on its third
-        // replay (ROCm 7.2; 700 particles x 3 rays, 128 x 48 — scripts/r03_dbg.py), the same zeroing as a kernel node does not
+        // replay (ROCm 7.2; 700 particles x 3 rays, 128 x 48), the same zeroing as a kernel node does not
         hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, bs, reinterpret_cast<float*>(ctx->penalty.p), 0.0f,
                            static_cast<float*>(nullptr), 0.0f, np);
       }
