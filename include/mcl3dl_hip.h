@@ -559,7 +559,14 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "poll_spin_us"      how long a completion wait spins on its page-locked word before it starts napping between looks
  *                       (default 2000: every update up to a few thousand particles completes inside the spin); the naps
  *                       grow with the time already waited (1/32 of it, 1 ms at most) and hipStreamQuery is consulted every
- *                       5 ms, so a long update does not hold a core and a faulted queue comes back as an error
+ *                       "poll_query_us" (default 5000), so a long update does not hold a core and a faulted queue comes
+ *                       back as an error
+ *   "update_fold_done"  0 (default): the polled completion word is written by a one-thread kernel of its own behind the update;
+ *                       1: where the host-buffer update ends in a one-work-group kernel (the fused pf::measure up to
+ *                       "pf_fused_max" particles, the apply behind a float-order replay as ONE block up to 16 384) that
+ *                       kernel writes the word behind its results. Same bits; measured 0 - 14 us SLOWER (the system-scope
+ *                       release sits on the update's critical path, and the one-block apply is slower than sixteen):
+ *                       profiles/r05j_fold_ab.txt
  *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
  *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
  *                       results either way.

@@ -573,7 +573,20 @@ namespace
 int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
                       const float* d_ratio, size_t n_p, float* d_stats4, const PfEmit* ho = nullptr)
 {
-  const PfEmit emit = ho ? *ho : PfEmit{};
+  PfEmit emit = ho ? *ho : PfEmit{};
+  // the completion word folded into the last kernel (one work-group: pf_fused_kernel, or pf_apply_kernel as one block up to
+  // 16 384 particles): asked for by the host-buffer update, whose next step is the polled wait
+  const bool fold = ho && ctx->fold_done && ctx->poll_mode() && n_p <= 16384 && ensure_done_flag(ctx);
+  if (fold)
+  {
+    emit.done = ctx->done_flag;
+    emit.done_seq = ctx->done_seq + 1u;
+  }
+  const auto folded = [&]()
+  {
+    if (fold)
+      ctx->done_folded = ++ctx->done_seq;
+  };
   if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->strict_order != 1 && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
@@ -583,6 +596,7 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
                        static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit);
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
+    folded();
     return 0;
   }
   if (pf_tail_eligible(ctx, n_p))
@@ -602,10 +616,11 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
     return mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4);
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-  hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
+  hipLaunchKernelGGL(pf_apply_kernel, dim3(fold ? 1 : pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
                      static_cast<int>(n_p), 1, ctx->partial4.as<double>(), d_stats4, emit, d_lik, d_ratio, d_beam);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
+  folded();
   return 0;
 }
 
@@ -1143,8 +1158,29 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
         *res[k].slot = (k > 0 && ctx->is_pinned(res[k].user, res[k].bytes)) ? res[k].user
                                                                             : reinterpret_cast<float*>(out_blk + res[k].offset);
   bool host_written = false;
-  TRY(enqueue_update(ctx, ctx->pose.as<float>(), n_p, d_w, extra ? ctx->extra.as<float>() : nullptr, d_lik, d_ratio, d_beam,
-                     d_stats, out_blk ? &ho : nullptr, &host_written));
+  {
+    // the update's last kernel may write the completion word itself (pf_measure_single): the polled wait below is the very
+    // next thing this stream sees. The request is withdrawn on every way out of enqueue_update.
+    struct FoldScope
+    {
+      mcl3dl_hip_ctx* c;
+      ~FoldScope()
+      {
+        c->fold_done = false;
+      }
+    } fold_scope{ ctx };
+    ctx->fold_done = out_blk != nullptr && ctx->fold_done_opt;
+    ctx->done_folded = 0;
+    const int rc_u = enqueue_update(ctx, ctx->pose.as<float>(), n_p, d_w, extra ? ctx->extra.as<float>() : nullptr, d_lik, d_ratio,
+                                    d_beam, d_stats, out_blk ? &ho : nullptr, &host_written);
+    if (rc_u != 0)
+    {
+      ctx->done_folded = 0;  // (whatever was enqueued, the next wait launches its own completion word behind it)
+      return rc_u;
+    }
+  }
+  if (!host_written)
+    ctx->done_folded = 0;
   if (host_written)
   {
     for (int k = 0; k < 5; ++k)

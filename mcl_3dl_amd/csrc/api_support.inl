@@ -162,6 +162,18 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_spin_us = value;
     return 0;
   }
+  if (key == "update_fold_done")
+  {
+    ctx->fold_done_opt = value != 0.0;
+    return 0;
+  }
+  if (key == "poll_query_us")
+  {
+    if (!(value >= 100.0 && value <= 1e9))
+      return ctx->fail(-3, "poll_query_us must be >= 100");
+    ctx->poll_query_us = value;
+    return 0;
+  }
   if (key == "strict_rows")
   {
     ctx->strict_rows = value != 0.0;
@@ -445,6 +457,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "update_particle") *value = ctx->update_particle;
   else if (key == "poll_sync") *value = ctx->poll_sync;
   else if (key == "poll_spin_us") *value = ctx->poll_spin_us;
+  else if (key == "poll_query_us") *value = ctx->poll_query_us;
+  else if (key == "update_fold_done") *value = ctx->fold_done_opt ? 1.0 : 0.0;
   else if (key == "batch_slice") *value = ctx->batch_slice;
   else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
   else if (key == "dda_overlay") *value = ctx->dda_overlay;

@@ -174,9 +174,15 @@ struct mcl3dl_hip_ctx
   // costs its caller ~2 ms of CPU, not 25), with hipStreamQuery looked at every few milliseconds so that a faulted queue
   // comes back as an error instead of an endless wait
   double poll_spin_us = 2000.0;
+  double poll_query_us = 5000.0;  // interval of the hipStreamQuery health checks while napping (option "poll_query_us")
   bool test_late_structures = false;  // fault injection for the API-sequence fuzz (option of the same name, test hooks only)
   volatile unsigned* done_flag = nullptr;
   unsigned done_seq = 0;
+  // the host-buffer update asks its last kernel to write the completion word itself (fold_done = true while it enqueues);
+  // done_folded = the sequence number such a kernel was given: the wait that follows launches no kernel of its own
+  bool fold_done = false;
+  bool fold_done_opt = false;  // option "update_fold_done" (measured slower than a kernel of its own: profiles/r05j_fold_ab.txt)
+  unsigned done_folded = 0;
   // strict_order = 3 (likelihood_kernels.h: LikChain): hand-off words, their tag counter, the page-locked error word
   DevBuf chain_carry, chain_lik;
   uint32_t chain_tag = 1;
@@ -677,7 +683,7 @@ int spin_done_flag(mcl3dl_hip_ctx* ctx, unsigned seq)
     cpu_relax();
   }
   const double t0 = mono_us();
-  double next_query = 5000.0;
+  double next_query = ctx->poll_query_us;
   for (;;)
   {
     for (int spin = 0; spin < 64; ++spin)
@@ -708,7 +714,7 @@ int spin_done_flag(mcl3dl_hip_ctx* ctx, unsigned seq)
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return 0;
       }
-      next_query = waited + 5000.0;
+      next_query = waited + ctx->poll_query_us;
     }
     const double nap_us = std::min(1000.0, waited / 32.0);
     timespec ts{ 0, static_cast<long>(nap_us * 1e3) };
@@ -723,6 +729,13 @@ int wait_done_flag(mcl3dl_hip_ctx* ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
   }
+  if (ctx->done_folded != 0 && ctx->done_folded == ctx->done_seq)
+  {
+    // the last kernel on the stream writes the word behind its results (pf_kernels.h: pf_emit_done)
+    ctx->done_folded = 0;
+    return spin_done_flag(ctx, ctx->done_seq);
+  }
+  ctx->done_folded = 0;
   const unsigned seq = ++ctx->done_seq;
   hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->done_flag, seq);
   HIP_TRY(hipGetLastError());

@@ -24,7 +24,22 @@ struct PfEmit
   float* lik;
   float* ratio;
   float* beam;
+  // round 5: the completion word of the host-buffer update (host_context.h: done_flag) written by THIS kernel behind its
+  // results instead of by a one-thread kernel of its own — only where the kernel is ONE work-group (pf_fused_kernel, and
+  // pf_apply_kernel launched as one block): every thread fences its stores to the host, the work-group meets, thread 0 writes
+  volatile unsigned* done;
+  unsigned done_seq;
 };
+
+__device__ inline void pf_emit_done(const PfEmit& emit)
+{
+  if (!emit.done)   // (a kernel argument: uniform)
+    return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *emit.done = emit.done_seq;
+}
 
 // w_new = w * (((1 * beam) * lik) * extra); per-block partials {sum w, sum w ln w, max ratio, -min ratio}.
 __global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __restrict__ w, const float* __restrict__ lik,
@@ -175,6 +190,7 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
         emit.stats4[k] = st[k];
     }
   }
+  pf_emit_done(emit);  // (only ever set on a one-block launch)
 }
 
 // pf_partial_kernel -> pf_reduce_kernel -> pf_apply_kernel for ONE GPU and at most PF_FUSED_MAX particles, as a single
@@ -316,6 +332,7 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
         emit.stats4[k] = st[k];
     }
   }
+  pf_emit_done(emit);
 }
 
 // ---------------------------------------------------------------------------------------------------------

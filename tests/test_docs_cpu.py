@@ -44,5 +44,12 @@ def test_cited_files_exist():
 
 
 def test_the_patterns_find_something():
+    # (DESIGN.md = the current design, ~25 KB; HISTORY.md = rounds 1-4 measurement by measurement: it cites session drivers that
+    # live in the git history only and is therefore not in DOCS — every profiles/ file it names is still checked here)
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
-    assert len(PAT.findall(text)) > 30 and len(BARE.findall(text)) > 20
+    assert len(PAT.findall(text)) > 30
+    hist = open(os.path.join(ROOT, "HISTORY.md")).read()
+    import glob
+    assert len(BARE.findall(hist)) > 20
+    missing = [c for c in BARE.findall(hist) for p in expand(c) if not glob.glob(os.path.join(ROOT, "profiles", p))]
+    assert not missing, missing

@@ -142,7 +142,10 @@ def test_automatic_strict_order_never_fails_an_update_over_memory(engine):
 def test_a_long_update_does_not_hold_a_core(engine):
     """the polled completion word used to be spun on for the whole kernel (one core pegged for the 26 ms
     of a C5 update). The wait now spins for poll_spin_us (default 2 ms: every update up to a few thousand particles), then naps
-    between looks (1/32 of the time already waited). Measured here: CPU time / wall time of the caller over updates of 10-20 ms."""
+    between looks (1/32 of the time already waited). Measured here: CPU time / wall time of the CALLING THREAD (RUSAGE_THREAD)
+    over updates of 10-20 ms — the process-wide figure also counts whatever helper threads earlier tests of the session left
+    behind (RCCL proxies, the HIP runtime's handlers): measured alone the two agree (19 % of a core at 11 ms; a pure spin and
+    hipStreamSynchronize both hold 100 %: scripts/r05_dbg_cpushare.py, profiles/r05i_cpushare.txt)."""
     import resource
     import time
 
@@ -161,18 +164,18 @@ def test_a_long_update_does_not_hold_a_core(engine):
     torch.cuda.synchronize()
 
     def run(reps):
-        r0, t0 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+        r0, t0 = resource.getrusage(resource.RUSAGE_THREAD), time.perf_counter()
         for _ in range(reps):
             engine.measure_device(d_pose, n_p, d_lik, d_q, None)
             engine.synchronize()
-        r1, t1 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+        r1, t1 = resource.getrusage(resource.RUSAGE_THREAD), time.perf_counter()
         return (r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime), t1 - t0
 
     run(2)
     cpu, wall = run(8)
     per_update_ms = wall / 8 * 1e3
     assert per_update_ms > 6.0, "the update is too short (%.2f ms) to say anything about the napping phase" % per_update_ms
-    assert cpu / wall < 0.5, "caller used %.0f %% of a core over %.1f ms updates" % (100 * cpu / wall, per_update_ms)
+    assert cpu / wall < 0.4, "caller used %.0f %% of a core over %.1f ms updates" % (100 * cpu / wall, per_update_ms)
     # a pure spin for comparison (poll_spin_us far beyond the update): the same updates, (nearly) a whole core
     try:
         engine.set_option("poll_spin_us", 1e6)

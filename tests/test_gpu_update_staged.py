@@ -198,3 +198,26 @@ def test_device_resident_update_with_and_without_the_tail(engine, scene):
         for x, y in zip(got[0], got[1]):
             np.testing.assert_array_equal(x, y)
         assert abs(float(got[1][0].astype(np.float64).sum()) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("n_p,strict", [(64, 0), (1024, 0), (1025, 0), (3000, 1), (3000, 3)])
+def test_completion_word_folded_into_the_last_kernel(engine, scene, n_p, strict):
+    """Option update_fold_done (off by default: measured slower, profiles/r05j_fold_ab.txt): the fused pf::measure / the one-block
+    apply writes the polled completion word itself. Same bits as with the one-thread kernel behind the update, call after call,
+    and a wait that follows a call of another kind (no folded word) still launches its own."""
+    sc, n_s, n_b = scene, 3000, 256
+    configure(engine, sc, n_b, stamp=7300 + n_p + strict)
+    poses, w0 = sc.poses[:n_p], np.full(n_p, 1.0 / n_p, np.float32)
+    args = (poses, w0, sc.scan_lik[:n_s], sc.scan_beam[:n_b], sc.scan_beam_label[:n_b], sc.origins)
+    saved = engine.get_option("strict_order")
+    try:
+        engine.set_option("strict_order", strict)
+        want = engine.measure_update(*args)
+        engine.set_option("update_fold_done", 1)
+        for _ in range(3):
+            same(engine.measure_update(*args), want)
+            lik, _, _ = engine.measure_batch(poses, sc.scan_lik[:n_s])   # (its wait: a word of its own)
+            np.testing.assert_array_equal(lik, want["lik"])
+    finally:
+        engine.set_option("update_fold_done", 0)
+        engine.set_option("strict_order", saved)
