@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 5, session 14: the GPU suite twice on the final tree (flakiness), smoke, the default bench line
+O=gpurun_out/r05s14; mkdir -p $O
+for i in 1 2; do
+  timeout 1200 python -m pytest tests -m gpu -q -rf 2>&1 | grep -vE "RCCL|HIP version|ROCm version|Hostname|Librccl" | tail -60 > $O/pytest_gpu_$i.log
+  grep -E "passed|failed" $O/pytest_gpu_$i.log | tail -1
+done
+timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 $O/smoke.log)"
+timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench_C2.json; python -c "
+import json; d=json.load(open('$O/bench_C2.json')); print(d['value'], d['ms_per_step'], d['headline']['ms_per_update_8d'], d['roofline']['frac'], d['result_check']['max_rel_err_vs_cpu'])"
