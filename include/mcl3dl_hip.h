@@ -584,6 +584,12 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "sort_full_pass"    1 = arrays of 2049 .. 32 768 elements (a 16 384-point scan) are radix-sorted with ONE launch per
  *                       8-bit pass — every work-group counts every work-group's digits itself —, 0 (default; measured
  *                       faster) = a counting launch and a scatter launch per pass. Same order either way.
+ *   "sort_one_launch"   1 = arrays of 2049 .. 32 768 elements with keys of at most 16 bits (the scan ordering of a 16 384-point
+ *                       likelihood scan) are sorted by ONE launch whose work-groups each hold the whole key distribution in
+ *                       LDS; 0 (default) = the launches per 8-bit pass above. Same stable order. Measured: the 15 360 LDS
+ *                       atomics every work-group needs run at one lane per clock (7.7 us) — equal to the passes at 16 384
+ *                       elements (0.2755 / 0.2742 ms per host-buffer update), faster at 4096, slower at 32 768:
+ *                       profiles/r05p_sort16_one_launch.txt
  *   "update_stage"      1 (default) = mcl3dl_hip_measure_update hands scans (<= 16 384 points per model), poses and prior
  *                       weights to the device with ONE launch that also orders the scans (stage_kernels.h), 0 = upload +
  *                       ordering as separate copies and launches (the path larger scans always take; same results)

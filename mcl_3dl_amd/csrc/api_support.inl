@@ -305,6 +305,11 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->sort_full_pass = value != 0.0;
     return 0;
   }
+  if (key == "sort_one_launch")
+  {
+    ctx->sort_one_launch = value != 0.0;
+    return 0;
+  }
   if (key == "pf_fused_max")
   {
     if (!(value >= 1.0 && value <= static_cast<double>(PF_FUSED_MAX)))
@@ -491,6 +496,7 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "dda_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[1];
   else if (key == "pf_fused") *value = ctx->pf_fused;
   else if (key == "sort_full_pass") *value = ctx->sort_full_pass;
+  else if (key == "sort_one_launch") *value = ctx->sort_one_launch;
   else if (key == "pf_fused_max") *value = ctx->pf_fused_max;
   else if (key == "scan_order_device") *value = ctx->scan_order_device;
   else

@@ -101,6 +101,19 @@ int radix_sort(mcl3dl_hip_ctx* ctx, const RsKeyGen& kg, long long n, int end_bit
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  // keys of at most 16 bits, up to 32 768 of them: ONE launch (sort_kernels.h:rs_sort16_kernel; every work-group reads ALL keys,
+  // so not when the result would land in the arrays the caller's keys are read from)
+  if (end_bit <= 16 && n <= RS16_MAX && ctx->sort_one_launch &&
+      !(KEYMODE == RS_KEY_ARRAY && (g.keys == key[1] || g.vals == val[1])))
+  {
+    const unsigned nb = static_cast<unsigned>((n + RS_THREADS - 1) / RS_THREADS);
+    if (fin)
+      hipLaunchKernelGGL((rs_sort16_kernel<KEYMODE, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, g, f, key[1], val[1], ni, mask);
+    else
+      hipLaunchKernelGGL((rs_sort16_kernel<KEYMODE, false>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, g, f, key[1], val[1], ni, mask);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   // (not when pass 0 would write the array set the caller's keys are read from: every work-group reads ALL keys in that pass)
   const int first_dst = (n_pass & 1) ? 1 : 0;
   const bool aliased = KEYMODE == RS_KEY_ARRAY && (g.keys == key[first_dst] || g.vals == val[first_dst]);

@@ -312,6 +312,8 @@ struct mcl3dl_hip_ctx
   // (rs_pass_full_kernel). Measured and off: n LDS atomics per work-group on <= 256 addresses serialise — a 16 384-point scan took
   // 55 us to stage against 43 us with the count + scatter launches (profiles/r04d_time8d_C2.json)
   int sort_full_pass = 0;
+  int sort_one_launch = 0;  // keys of <= 16 bits, 2049 .. 32 768 elements: rs_sort16_kernel (option "sort_one_launch"; measured
+                            // equal to the passes at 16 384 elements, slower at 32 768: profiles/r05p_sort16_one_launch.txt)
   int scan_order_device = 4096;  // scans of at least this many points (both models together) are ordered on the device; 0 = never
   size_t n_base = 0;  // points of the base map; anything behind them in map_xyz is the current map update
   DevBuf ms_xyz, ms_out, ms_flag[2];
