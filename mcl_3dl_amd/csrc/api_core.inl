@@ -1027,9 +1027,10 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
   else
   {
     // larger scans: one launch brings the arrays over (+ the min / max the Morton keys need), the chip-wide sort orders them
-    const unsigned nb_lik = n_s ? minmax_blocks(static_cast<long long>(n_s)) : 0u;
-    const unsigned nb_beam = n_b ? static_cast<unsigned>(std::min<size_t>((n_b + 1023) / 1024, 64)) : (n_o ? 1u : 0u);
-    const unsigned nb_copy = static_cast<unsigned>(std::min<size_t>(std::max<size_t>((n_copy + 1023) / 1024, 1), 64));
+    // (256 points per work-group and round; the copies 16 bytes per thread: stage_kernels.h)
+    const unsigned nb_lik = n_s ? static_cast<unsigned>(std::min<size_t>((n_s + 255) / 256, 256)) : 0u;
+    const unsigned nb_beam = n_b ? static_cast<unsigned>(std::min<size_t>((n_b + 255) / 256, 64)) : (n_o ? 1u : 0u);
+    const unsigned nb_copy = static_cast<unsigned>(std::min<size_t>(std::max<size_t>((7 * n_p + 1023) / 1024, 1), 64));
     MinMaxOut mm{};
     if (nb_lik)
       TRY(minmax_out(ctx, nb_lik, &mm));

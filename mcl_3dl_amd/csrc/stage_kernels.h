@@ -260,19 +260,74 @@ __global__ __launch_bounds__(RS_THREADS) void scan_stage_kernel(StageArgs a)
 // ordered by the multi-work-group sort of sort_kernels.h (host_cloud.h:device_order_scans) — this kernel only brings the
 // caller's arrays over: work-groups [0, nb_lik) the likelihood scan as float4 + its min / max (last work-group to arrive
 // folds the partials: cloud_kernels.h:block_minmax_finish), [nb_lik, nb_lik + nb_beam) the beam scan (+ origins), the rest
-// the poses / weights / odometry factor. 256 threads per work-group.
+// the poses / weights / odometry factor. 256 threads per work-group, 256 points resp. 1024 floats per work-group and round:
+// one PCIe round trip for a 16 384-point scan and 4096 particles, every byte fetched once.
+// 256 consecutive points of a packed xyz array (host-visible memory) -> this thread's point. Read as float4s through LDS where
+// the array is 16-byte aligned: three 4-byte loads at stride 12 fetch every 64-byte segment of UNCACHED host memory three times —
+// a 16 384-point scan crossed PCIe as 590 KB instead of 196 (stage_pack 14 us, profiles/r05o_timeline_8d_C2.txt).
+// Every thread of the work-group calls it (two barriers inside).
+__device__ inline float4 stage_load_xyz256(const float* __restrict__ in, int first_point, int n_points, float* s_xyz /*[768]*/)
+{
+  const int t = threadIdx.x;
+  const int n_here = min(256, n_points - first_point);
+  const float* src = in + 3ll * first_point;
+  const int n_f = 3 * n_here;
+  if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0)
+  {
+    const int n4 = n_f >> 2;
+    if (t < n4)
+      reinterpret_cast<float4*>(s_xyz)[t] = reinterpret_cast<const float4*>(src)[t];
+    if (t < (n_f & 3))
+      s_xyz[4 * n4 + t] = src[4 * n4 + t];
+  }
+  else
+    for (int k = t; k < n_f; k += 256)
+      s_xyz[k] = src[k];
+  __syncthreads();
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < n_here)
+    p = make_float4(s_xyz[3 * t], s_xyz[3 * t + 1], s_xyz[3 * t + 2], 0.f);
+  __syncthreads();
+  return p;
+}
+
+// a flat array of n floats copied by work-groups [0, n_blocks) of 256 threads, 16 bytes per thread and load where both ends
+// are 16-byte aligned
+__device__ inline void stage_copy_floats(const float* __restrict__ in, float* __restrict__ out, long long n, unsigned bid,
+                                         unsigned n_blocks)
+{
+  const long long stride = static_cast<long long>(n_blocks) * 256;
+  const long long me = static_cast<long long>(bid) * 256 + threadIdx.x;
+  if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0)
+  {
+    const long long n4 = n >> 2;
+    for (long long i = me; i < n4; i += stride)
+      reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(in)[i];
+    if (me < (n & 3))
+      out[4 * n4 + me] = in[4 * n4 + me];
+    return;
+  }
+  for (long long i = me; i < n; i += stride)
+    out[i] = in[i];
+}
+
 __global__ __launch_bounds__(256) void stage_pack_kernel(StageArgs a, MinMaxOut mm, unsigned nb_lik, unsigned nb_beam)
 {
+  __shared__ __attribute__((aligned(16))) float s_xyz[768];
   const unsigned b = blockIdx.x;
   if (b < nb_lik)
   {
     float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
     unsigned cnt = 0;
-    for (int i = static_cast<int>(b) * 256 + threadIdx.x; i < a.n_s; i += static_cast<int>(nb_lik) * 256)
+    for (int first = static_cast<int>(b) * 256; first < a.n_s; first += static_cast<int>(nb_lik) * 256)
     {
-      const float4 p = make_float4(a.in_lik_xyz[3 * i], a.in_lik_xyz[3 * i + 1], a.in_lik_xyz[3 * i + 2], 0.f);
-      a.raw_lik[i] = p;
-      minmax_accumulate(p, mn, mx, cnt);
+      const float4 p = stage_load_xyz256(a.in_lik_xyz, first, a.n_s, s_xyz);
+      const int i = first + static_cast<int>(threadIdx.x);
+      if (i < a.n_s)
+      {
+        a.raw_lik[i] = p;
+        minmax_accumulate(p, mn, mx, cnt);
+      }
     }
     block_minmax_finish(mn, mx, cnt, mm, b, nb_lik);
     return;
@@ -283,23 +338,26 @@ __global__ __launch_bounds__(256) void stage_pack_kernel(StageArgs a, MinMaxOut 
     if (bb == 0)
       for (int i = threadIdx.x; i < a.n_o; i += 256)
         a.d_origins[i] = make_float4(a.in_origins[3 * i], a.in_origins[3 * i + 1], a.in_origins[3 * i + 2], 0.f);
-    for (int i = static_cast<int>(bb) * 256 + threadIdx.x; i < a.n_b; i += static_cast<int>(nb_beam) * 256)
-      a.raw_beam[i] = make_float4(a.in_beam_xyz[3 * i], a.in_beam_xyz[3 * i + 1], a.in_beam_xyz[3 * i + 2],
-                                  __uint_as_float(a.in_beam_origin ? a.in_beam_origin[i] : 0u));
+    for (int first = static_cast<int>(bb) * 256; first < a.n_b; first += static_cast<int>(nb_beam) * 256)
+    {
+      float4 p = stage_load_xyz256(a.in_beam_xyz, first, a.n_b, s_xyz);
+      const int i = first + static_cast<int>(threadIdx.x);
+      if (i < a.n_b)
+      {
+        p.w = __uint_as_float(a.in_beam_origin ? a.in_beam_origin[i] : 0u);
+        a.raw_beam[i] = p;
+      }
+    }
     return;
   }
-  const long long n_pose = a.in_pose ? 7ll * a.n_p : 0, n_w = a.in_w ? a.n_p : 0, n_e = a.in_extra ? a.n_p : 0;
-  const long long total = n_pose + n_w + n_e;
-  const long long stride = static_cast<long long>(gridDim.x - nb_lik - nb_beam) * 256;
-  for (long long i = static_cast<long long>(b - nb_lik - nb_beam) * 256 + threadIdx.x; i < total; i += stride)
-  {
-    if (i < n_pose)
-      a.d_pose[i] = a.in_pose[i];
-    else if (i < n_pose + n_w)
-      a.d_w[i - n_pose] = a.in_w[i - n_pose];
-    else
-      a.d_extra[i - n_pose - n_w] = a.in_extra[i - n_pose - n_w];
-  }
+  // poses (7 floats per particle), prior weights, odometry factor: three flat arrays, every copy work-group takes its share of each
+  const unsigned bc = b - nb_lik - nb_beam, nbc = gridDim.x - nb_lik - nb_beam;
+  if (a.in_pose)
+    stage_copy_floats(a.in_pose, a.d_pose, 7ll * a.n_p, bc, nbc);
+  if (a.in_w)
+    stage_copy_floats(a.in_w, a.d_w, a.n_p, bc, nbc);
+  if (a.in_extra)
+    stage_copy_floats(a.in_extra, a.d_extra, a.n_p, bc, nbc);
 }
 
 }  // namespace mcl3dl
