@@ -561,6 +561,11 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       grow with the time already waited (1/32 of it, 1 ms at most) and hipStreamQuery is consulted every
  *                       "poll_query_us" (default 5000), so a long update does not hold a core and a faulted queue comes
  *                       back as an error
+ *   "chain_ppl"         strict_order = 3: scan tiles per work-group of the in-kernel float sum. 0 (default) = four (a quarter of
+ *                       the hand-offs between work-groups: likelihood_chain_multi.h) up to "chain_multi_max" = 1536 particles on
+ *                       scans of at least 16 tiles, default kernel family only; 1 = always one; 4 = four wherever the family
+ *                       allows. Same bits. 1024 particles x 16 384 points: 0.139 -> 0.122 ms (fp64 sums 0.072); slower from
+ *                       2048 particles (profiles/r05r_chain_multi.txt)
  *   "update_fold_done"  0 (default): the polled completion word is written by a one-thread kernel of its own behind the update;
  *                       1: where the host-buffer update ends in a one-work-group kernel (the fused pf::measure up to
  *                       "pf_fused_max" particles, the apply behind a float-order replay as ONE block up to 16 384) that

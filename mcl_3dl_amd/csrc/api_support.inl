@@ -162,6 +162,20 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->poll_spin_us = value;
     return 0;
   }
+  if (key == "chain_ppl")
+  {
+    if (value != 0.0 && value != 1.0 && value != 4.0)
+      return ctx->fail(-3, "chain_ppl must be 0 (by size), 1 or 4");
+    ctx->chain_ppl = static_cast<int>(value);
+    return 0;
+  }
+  if (key == "chain_multi_max")
+  {
+    if (!(value >= 0.0 && value <= 1e9))
+      return ctx->fail(-3, "chain_multi_max must be >= 0");
+    ctx->chain_multi_max = static_cast<int>(value);
+    return 0;
+  }
   if (key == "update_fold_done")
   {
     ctx->fold_done_opt = value != 0.0;
@@ -464,6 +478,8 @@ int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
   else if (key == "poll_spin_us") *value = ctx->poll_spin_us;
   else if (key == "poll_query_us") *value = ctx->poll_query_us;
   else if (key == "update_fold_done") *value = ctx->fold_done_opt ? 1.0 : 0.0;
+  else if (key == "chain_ppl") *value = ctx->chain_ppl;
+  else if (key == "chain_multi_max") *value = ctx->chain_multi_max;
   else if (key == "batch_slice") *value = ctx->batch_slice;
   else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
   else if (key == "dda_overlay") *value = ctx->dda_overlay;

@@ -311,6 +311,8 @@ struct mcl3dl_hip_ctx
   // arrays of 2049 .. 32 768 elements: 1 = one launch per radix pass, every work-group counting every work-group's digits itself
   // (rs_pass_full_kernel). Measured and off: n LDS atomics per work-group on <= 256 addresses serialise — a 16 384-point scan took
   // 55 us to stage against 43 us with the count + scatter launches (profiles/r04d_time8d_C2.json)
+  int chain_ppl = 0;          // strict_order = 3: tiles per work-group (0 = by size, 1, 4: likelihood_chain_multi.h)
+  int chain_multi_max = 1536; // ... the four-tile form up to this many particles (profiles/r05r_chain_multi.txt: slower from 2048)
   int sort_full_pass = 0;
   int sort_one_launch = 0;  // keys of <= 16 bits, 2049 .. 32 768 elements: rs_sort16_kernel (option "sort_one_launch"; measured
                             // equal to the passes at 16 384 elements, slower at 32 768: profiles/r05p_sort16_one_launch.txt)

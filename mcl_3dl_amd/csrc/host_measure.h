@@ -120,6 +120,8 @@ struct LikPlan
   size_t chunk = 0;    // > 0: the scan is ordered in chunks of the caller's order and replayed chunk by chunk (two term buffers)
   bool chain = false;  // the float sum in the scan array's order inside the tiled kernel (likelihood_kernels.h: LikChain)
   uint32_t chain_tag0 = 0;
+  int chain_ppl = 1;   // > 1: likelihood_chain_multi_kernel, that many tiles per work-group (n_super super-tiles)
+  int n_super = 0;
 };
 
 // does an update over ns scan points replay the likelihood terms in the reference's float order?
@@ -284,6 +286,21 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
     pl->blocks = 8 * ((full_tiles / 8) * pl->n_groups + (rem_items + 7) / 8);
     if (chain)
     {
+      // few particles on a long scan (default kernel family only): four tiles per work-group, a quarter of the hand-offs
+      // (likelihood_chain_multi.h). chain_ppl: 0 = by size, 1 = never, 4 = whenever the family allows.
+      const bool family = ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f && lik_defer_active(ctx) && ctx->lik_group == 0;
+      if (family && (ctx->chain_ppl == 4 || (ctx->chain_ppl == 0 && pl->n_tiles >= 16 && np <= ctx->chain_multi_max)))
+      {
+        pl->chain_ppl = 4;
+        pl->group_size = 4;
+        pl->n_groups = (np + 3) / 4;
+        pl->n_super = (pl->n_tiles + 3) / 4;
+        pl->blocks = 8ll * ((pl->n_super + 7) / 8) * pl->n_groups;
+        if (pl->blocks > 0x7fffffffLL)
+          return ctx->fail(-3, "too many work-groups for the tiled likelihood kernel");
+        pl->chain = true;
+        return ensure_chain(ctx, n_p, pl->n_super, &pl->chain_tag0);
+      }
       // rows of eight tiles, no shared-out remainder (likelihood_tiled_kernel<..., CHAIN>)
       pl->blocks = 8ll * ((pl->n_tiles + 7) / 8) * pl->n_groups;
       if (pl->blocks > 0x7fffffffLL)
@@ -563,6 +580,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             }
             const LikChain lc{ ctx->chain_carry.as<unsigned long long>(), plan.chain_tag0, lik_out, d_ratio,
                                beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr), ctx->chain_err };
+            if (plan.chain_ppl == 4)
+            {
+              hipLaunchKernelGGL((likelihood_chain_multi_kernel<4, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
+                                 d_pose, np, scan, ns, n_tiles, plan.n_super, n_groups, ctx->rg, lp, lc);
+            }
+            else
+            {
 #define LAUNCH_CHAIN(GG, MODE, CC, DD)                                                                                  \
   hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, 8, CC, DD, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
                      ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
@@ -596,6 +620,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             }
 #undef LAUNCH_CHAIN_G
 #undef LAUNCH_CHAIN
+            }
           }
           else
           {

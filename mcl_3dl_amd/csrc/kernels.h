@@ -2,6 +2,7 @@
 //
 //   likelihood_kernels.h  likelihood-field model: per-particle / small-scan / tile-major (XCD-aware) kernels over the
 //                         candidate-voxel index (map_compiler.h) or the cell-sorted map; strict-order sums; radius search
+//   likelihood_chain_multi.h  strict_order = 3 for few particles on long scans: several tiles per work-group, a quarter of the hand-offs
 //   beam_kernels.h        beam model: one lane per ray, DDA walk through 4x4x4 occupancy bricks, point tests, penalty count
 //   pf_kernels.h          pf::measure (weights, deterministic fp64 reductions, normalisation, entropy) and the "next" rows
 //                         (expectation / max / covariance, resampling)
@@ -20,6 +21,7 @@
 #pragma once
 #include "map_structs.h"
 #include "likelihood_kernels.h"
+#include "likelihood_chain_multi.h"
 #include "beam_kernels.h"
 #include "pf_kernels.h"
 #include "update_kernels.h"

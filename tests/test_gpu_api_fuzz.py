@@ -37,12 +37,14 @@ RTOL_FP64 = 3e-5   # the fp64 mode against the reference's sequential float sum 
 
 DEFAULTS = dict(poll_sync=2, strict_order=2, update_stage=1, update_zero_copy=1, update_small=1, pf_fused=1, pf_tail=0,
                 lik_coop=1, lik_defer=1, overlap_models=1, batch_slice=0, scan_order_device=4096, lik_tiled_min=1024,
-                poll_spin_us=2000, lik_index=2, cand_aniso=2, sort_one_launch=0, update_fold_done=0, poll_query_us=5000)
+                poll_spin_us=2000, lik_index=2, cand_aniso=2, sort_one_launch=0, update_fold_done=0, poll_query_us=5000,
+                chain_ppl=0)
 CHOICES = dict(poll_sync=(0, 1, 2), strict_order=(0, 1, 2, 3), update_stage=(0, 1), update_zero_copy=(0, 1),
                update_small=(0, 1), pf_fused=(0, 1), pf_tail=(0, 1), lik_coop=(0, 1), lik_defer=(0, 1, 2),
                overlap_models=(0, 1), batch_slice=(0, 64, 128), scan_order_device=(0, 512, 4096),
                lik_tiled_min=(256, 1024), poll_spin_us=(0, 50, 2000), lik_index=(2, 2, 1, 0), cand_aniso=(2, 1, 0),
-               sort_one_launch=(0, 1), update_fold_done=(0, 1), poll_query_us=(5000, 200))
+               sort_one_launch=(0, 1), update_fold_done=(0, 1), poll_query_us=(5000, 200),
+               chain_ppl=(0, 1, 4))
 
 
 @pytest.fixture(scope="module")

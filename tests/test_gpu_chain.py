@@ -194,3 +194,35 @@ def test_presorted_scans_are_installed_as_they_are(engine, oracle_kind, n_p, n_s
         lik2, _, _ = engine.measure_batch(sc.poses, held)
         np.testing.assert_array_equal(engine.scan_order(n_s), np.arange(n_s, dtype=np.uint32))
     np.testing.assert_array_equal(lik2, want_held)
+
+
+@pytest.mark.parametrize("n_p,n_s,jitter", [(5, 1, 0.0), (64, 255, 0.0), (64, 1000, 0.0), (33, 2049, 0.0), (300, 2500, 0.0),
+                                            (1000, 4100, 0.0), (257, 6000, 0.0), (1024, 16384, 0.0), (3000, 9000, 0.0),
+                                            (200, 4096, 0.045), (777, 12345, 0.045)])
+def test_four_tiles_per_work_group_chain_the_same_bits(engine, oracle_kind, n_p, n_s, jitter):
+    """likelihood_chain_multi.h (option chain_ppl: 0 = by size — four tiles per work-group up to 1536 particles from 16 tiles
+    on —, 1 = never, 4 = always): a quarter of the hand-offs, the same adds in the same order. Against the one-tile form, the
+    reference on the scan in engine order (a sample of the particles at the larger sizes), twice in a row (tags), and with
+    the ragged ends: one tile, a last super-tile of one to three tiles, a last row of fewer than eight super-tiles."""
+    sc = make_scene(n=91, n_p=n_p, n_s=n_s, seed=4000 + n_s, **({"map_jitter": jitter} if jitter else {}))
+    dw = (1.0, 1.0, 5.0) if n_s % 2 else (1.0, 1.0, 1.0)
+    setup_engine(engine, sc, dw, stamp=420 + n_s)
+    with chain_mode(engine, chain_ppl=1):
+        lik1, q1, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        order = engine.scan_order(n_s)
+    with chain_mode(engine, chain_ppl=4):
+        lik4, q4, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        lik4b, _, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+        np.testing.assert_array_equal(engine.scan_order(n_s), order)
+        w0 = np.full(n_p, 1.0 / n_p, np.float32)
+        upd = engine.measure_update(sc.poses, w0, sc.scan_lik)
+    with chain_mode(engine, chain_ppl=0):
+        lik0, q0, _ = engine.measure_batch(sc.poses, sc.scan_lik)
+    for got_lik, got_q in ((lik4, q4), (lik4b, q4), (lik0, q0), (upd["lik"], upd["quality"])):
+        np.testing.assert_array_equal(got_lik, lik1)
+        np.testing.assert_array_equal(got_q, q1)
+    sample = np.arange(n_p) if n_p * n_s <= 2_000_000 else np.unique(np.r_[0:6, n_p // 2 - 3:n_p // 2 + 3, n_p - 6:n_p])
+    o = make_oracle(oracle_kind, sc, dw)
+    want_lik, want_q = o.likelihood_measure(sc.poses[sample], sc.scan_lik[order])
+    np.testing.assert_array_equal(lik4[sample], want_lik)
+    np.testing.assert_array_equal(q4[sample], want_q)
