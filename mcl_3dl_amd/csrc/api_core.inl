@@ -83,24 +83,26 @@ int mcl3dl_hip_create(mcl3dl_hip_ctx** out, int device_id)
 
 void mcl3dl_hip_destroy(mcl3dl_hip_ctx* ctx)
 {
-  if (ctx)
-  {
-    for (int k = 0; k < 2; ++k)
-    {
-      if (ctx->ev_tiled[k])
-        (void)hipEventDestroy(ctx->ev_tiled[k]);
-      if (ctx->ev_replay[k])
-        (void)hipEventDestroy(ctx->ev_replay[k]);
-    }
-    if (ctx->replay_stream)
-      (void)hipStreamDestroy(ctx->replay_stream);
-  }
   if (!ctx)
     return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->aux_stream)
     (void)hipStreamSynchronize(ctx->aux_stream);
+  // (on THIS context's device and behind its own synchronisation: in a device group the current device can be another
+  // rank's, and replay kernels may still read the term buffers freed below — ADVICE round 5)
+  if (ctx->replay_stream)
+  {
+    (void)hipStreamSynchronize(ctx->replay_stream);
+    (void)hipStreamDestroy(ctx->replay_stream);
+  }
+  for (int k = 0; k < 2; ++k)
+  {
+    if (ctx->ev_tiled[k])
+      (void)hipEventDestroy(ctx->ev_tiled[k]);
+    if (ctx->ev_replay[k])
+      (void)hipEventDestroy(ctx->ev_replay[k]);
+  }
   for (const EventPair& ep : ctx->pending)
   {
     (void)hipEventDestroy(ep.start);
@@ -537,7 +539,7 @@ int mcl3dl_hip_pf_partial_device(mcl3dl_hip_ctx* ctx, const float* d_weight, con
                      d_match_ratio, static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
   hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank,
                      world, d_packed);
-  if (ctx->strict_order == 1 && world == 1)
+  if (world == 1 && pf_float_order(ctx, n_p))
     hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->wnew.as<float>(),
                        static_cast<int>(n_p), d_packed);
   TRY(timing_end(ctx, ep));
@@ -587,19 +589,20 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
     if (fold)
       ctx->done_folded = ++ctx->done_seq;
   };
-  if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->strict_order != 1 && ctx->pf_fused)
+  const bool float_w = pf_float_order(ctx, n_p);
+  if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
     EventPair ep{};
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(pf_fused_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
-                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit);
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit, float_w ? 1 : 0);
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     folded();
     return 0;
   }
-  if (pf_tail_eligible(ctx, n_p))
+  if (pf_tail_eligible(ctx, n_p) && !float_w)
   {
     // two launches, no hand-off: the weights, then every work-group reduces all of them and normalises its own (pf_norm_kernel)
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));

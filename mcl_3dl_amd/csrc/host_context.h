@@ -107,7 +107,19 @@ struct mcl3dl_hip_ctx
   // 2 (default) = replay the likelihood terms in that order for scans of at least strict_auto_min points, where the
   // reference's own float rounding (a random walk of n_s roundings) reaches the 1e-5 tolerance of north_star; 0 = never
   int strict_order = 2;
-  int strict_auto_min = 32768;
+  // strict_order 2: exact caller-order float sums for scans of at most strict_exact_max points and of at least strict_auto_min.
+  // strict_auto_min comes from a bound, not from a measurement: the reference's float recurrence over n positive terms
+  // differs from the exact sum by a random walk of n roundings, each within half an ulp of the running sum — relative
+  // standard deviation <= 2^-24 sqrt(n) / 3 (ulp(s_i) <= 2^-23 s_i, s_i ~ (i / n) S) — while the fp64 tree is the exact sum
+  // rounded once. Three standard deviations stay inside north_star's 1e-5 up to n = (1e-5 x 2^24)^2 = 28 147 points; from
+  // there on the default replays the reference's own order. (A bound on the WORST case, n x 2^-24, would put that limit at
+  // 168 points: sums of equal terms can drift systematically — which is what strict_exact_max and strict_order 1 are for.)
+  int strict_auto_min = 28147;
+  int strict_exact_max = 4096;
+  int strict_rows_max_particles = 2048;  // exact sums by the per-particle kernels' LDS rows below this many particles, by the tiled kernel + replay from it
+  // the likelihoods the last launch_measure / one-launch update enqueued are the reference's floats bit for bit (caller-order
+  // rows, replay, in-kernel chain): pf::measure on one GPU then adds the weights in the reference's float order as well
+  bool lik_exact = false;
   int strict_skew = 1;  // 1 = the particle groups' term regions staggered across HBM channels (lik_strict_sum_kernel), 0 = back to back (A/B)
   int strict_rows = 1;  // 1 = float-order replay with the chunk row-major in LDS and a look-ahead adder, 0 = transposed chunk (A/B)
   int strict_gpw = 0;  // 0 = particle groups per work-group of the float-order adder chosen per launch, 1 / 2 = at most that many (A/B)
@@ -746,6 +758,22 @@ int wait_done_flag(mcl3dl_hip_ctx* ctx)
   return spin_done_flag(ctx, seq);
 }
 
+// strict_order = 3: the page-locked error word of the in-kernel hand-offs, looked at (and cleared) after EVERY completed wait —
+// sync_stream, but also the slices of a progressive batch, which never pass through sync_stream. Whatever
+// was staged for the failed work is dropped, so that no later synchronisation copies stale results into the caller's arrays.
+int chain_check(mcl3dl_hip_ctx* ctx)
+{
+  if (!ctx->chain_err || !*ctx->chain_err)
+    return 0;
+  *ctx->chain_err = 0u;
+  ctx->stage_out.clear();
+  ctx->stage_cur = 0;
+  ctx->stage_off = 0;
+  ctx->stage_pending = 0;
+  ctx->prog = mcl3dl_hip_ctx::BatchProgress();
+  return ctx->fail(-2, "strict_order = 3: a hand-off of the in-kernel float sum did not arrive (likelihoods of this update are invalid)");
+}
+
 // Progressive batch: waits until the slice holding `particle` is on the host, hands every slice that has arrived to the
 // caller's arrays and returns the number of particles whose results are there.
 int progress_wait(mcl3dl_hip_ctx* ctx, size_t particle, size_t* n_ready)
@@ -767,6 +795,7 @@ int progress_wait(mcl3dl_hip_ctx* ctx, size_t particle, size_t* n_ready)
       return rc;
     }
   }
+  TRY(chain_check(ctx));  // (a slice whose hand-off timed out is not delivered: the batch is gone, rc -2)
   const unsigned now = *ctx->done_flag;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   const size_t arrived = std::min<size_t>(pg.n_slices, static_cast<size_t>(std::max(0, static_cast<int>(now - pg.seq0))));
@@ -800,11 +829,7 @@ int sync_stream(mcl3dl_hip_ctx* ctx, bool polled = false)
     TRY(wait_done_flag(ctx));
   else
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ctx->chain_err && *ctx->chain_err)
-  {
-    *ctx->chain_err = 0u;
-    return ctx->fail(-2, "strict_order = 3: a hand-off of the in-kernel float sum did not arrive (likelihoods of this update are invalid)");
-  }
+  TRY(chain_check(ctx));
   for (const mcl3dl_hip_ctx::StagedResult& r : ctx->stage_out)
     memcpy(r.user, r.staged, r.bytes);
   ctx->stage_out.clear();

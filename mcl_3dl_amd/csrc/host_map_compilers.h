@@ -785,13 +785,26 @@ int build_cand_grid_budgeted(mcl3dl_hip_ctx* ctx, double ratio, uint32_t cap, do
   // (option cand_aniso = 2, the default; 1 = always boxes, 0 = never); then coarser voxels
   const bool can_stretch = ctx->has_weight && ctx->cand_aniso != 0;
   ctx->cand_aniso_active = ctx->cand_aniso == 1 && can_stretch;
-  for (int attempt = 0; attempt < 8; ++attempt)
+  const double asked = ratio;
+  const bool asked_aniso = ctx->cand_aniso_active;
+  // (every step either switches to boxes — once — or coarsens the edge by at least 8 %, so the loop reaches 1.5 r within 20
+  // steps from any edge the options allow; it ends only at 1.5 r: the message below then tells the truth)
+  for (int attempt = 0; attempt < 64; ++attempt)
   {
     const int rc = build_cand_grid_at(ctx, ratio, cap);
     if (rc != RC_OVER_BUDGET)
     {
       if (rc == 0 && ratio_used)
         *ratio_used = ratio;
+      // whatever differs from what was asked for is said (diagnostics: mcl3dl_hip_index_note), not only visible in
+      // cand_edge_ratio_* 
+      if (rc == 0 && (ratio != asked || ctx->cand_aniso_active != asked_aniso))
+      {
+        char note[256];
+        snprintf(note, sizeof(note), "index budget %.3g bytes: %s voxels of %.3g x match_dist_min instead of cubes of %.3g x",
+                 ctx->index_budget_bytes, ctx->cand_aniso_active ? "dist_weight-stretched" : "cubic", ratio, asked);
+        ctx->index_note = note;
+      }
       return rc;
     }
     if (can_stretch && !ctx->cand_aniso_active)
@@ -801,10 +814,11 @@ int build_cand_grid_budgeted(mcl3dl_hip_ctx* ctx, double ratio, uint32_t cap, do
     }
     if (ratio >= 1.5)
       break;
-    ratio = std::min(1.5, ratio * std::sqrt(ctx->cand_need_bytes / ctx->index_budget_bytes) * 1.08);
+    ratio = std::min(1.5, ratio * std::max(1.08, std::sqrt(ctx->cand_need_bytes / ctx->index_budget_bytes) * 1.08));
   }
-  return ctx->fail(-4, "the candidate index needs %.3g bytes of records at its coarsest voxel edge (1.5 x match_dist_min), the "
-                       "budget (option index_budget_bytes) is %.3g", ctx->cand_need_bytes, ctx->index_budget_bytes);
+  return ctx->fail(-4, "the candidate index needs %.3g bytes of records at a voxel edge of %.3g x match_dist_min (the coarsest "
+                       "the record format describes is 1.5 x), the budget (option index_budget_bytes) is %.3g",
+                   ctx->cand_need_bytes, ratio, ctx->index_budget_bytes);
 }
 
 int build_cand_grid(mcl3dl_hip_ctx* ctx)

@@ -122,7 +122,57 @@ struct LikPlan
   uint32_t chain_tag0 = 0;
   int chain_ppl = 1;   // > 1: likelihood_chain_multi_kernel, that many tiles per work-group (n_super super-tiles)
   int n_super = 0;
+  bool rows = false;   // per-particle / small-scan kernel with the terms parked in LDS at their ORIGINAL scan indices and added up
+                       // as the reference adds them (float, sequentially, caller's order): bit-identical likelihoods
 };
+
+// Scans up to this many points fit the caller-order term row of the per-particle kernels (48 KB of the 64 KB of LDS a
+// work-group gets without asking for more).
+constexpr int LIK_ROW_MAX = 12288;
+
+// Which likelihood kernel family a launch of np particles x ns points takes, and how its terms are added (no allocation:
+// plan_lik and the one-launch update both ask).
+//   exact   the sum must be the reference's float, in the caller's order: strict_order 1 always; the default (2) for every
+//           scan of at most strict_exact_max points (4096: the reference's operating range and far beyond — the fuzz's gate is
+//           assert_array_equal there) and from strict_auto_min points up, where the reference's own float rounding is no longer
+//           safely inside north_star's 1e-5 (host_context.h); in between, and with strict_order 0, the fixed-order fp64 tree
+//   rows    ... by the per-particle kernels themselves: every term parked in LDS at its ORIGINAL scan index, one wavefront
+//           runs the recurrence (lik_particle / likelihood_small_kernel) — no term array, no second launch
+//   replay  ... by the tiled kernel + the N_s x N_p term array + lik_strict_sum_rows_kernel
+// Measured (profiles/r06d_rows_vs_replay.txt): below ~2000 particles the rows are the cheaper exact form at every scan size
+// that fits them (64 x 4096: 21 against 38 us; 1024 x 4096: 48 against 58), above it the replay (4096 x 4096: 116 against 126).
+struct LikMode
+{
+  bool tiled = false, rows = false, replay = false;
+};
+
+LikMode lik_mode(const mcl3dl_hip_ctx* ctx, int np, int ns)
+{
+  LikMode m;
+  const bool by_size = ctx->lik_tiled && np >= 4 &&
+                       (ns >= ctx->lik_tiled_min || (np >= 256 && 4 * static_cast<long long>(ns) >= 3ll * ctx->lik_tiled_min));
+  if (ctx->strict_order == 3)
+  {
+    m.tiled = true;  // the in-kernel chain, in the engine's scan order
+    return m;
+  }
+  const bool exact = ctx->strict_order == 1 ||
+                     (ctx->strict_order == 2 && (ns <= ctx->strict_exact_max || ns >= ctx->strict_auto_min));
+  // (a scan ordered in chunks of the caller's order — option strict_chunk — carries chunk-relative indices: the replay's business)
+  const bool rows_fit = ns <= LIK_ROW_MAX && ctx->scan_chunk == 0;
+  if (!exact)
+  {
+    m.tiled = by_size;
+    // where a per-particle kernel runs anyway the rows cost a few per cent: exact there too (unless told not to: strict_order 0)
+    m.rows = !by_size && ctx->strict_order == 2 && rows_fit;
+    return m;
+  }
+  if (rows_fit && (!by_size || np < ctx->strict_rows_max_particles))
+    m.rows = true;
+  else
+    m.tiled = m.replay = true;
+  return m;
+}
 
 // does an update over ns scan points replay the likelihood terms in the reference's float order?
 // the tiled kernel with its overflow rounds deferred (likelihood_kernels.h): needs packed 64-byte records; mode 2 = only
@@ -137,11 +187,6 @@ bool lik_defer_active(const mcl3dl_hip_ctx* ctx)
   return with_cand > 0 && over4 / with_cand > ctx->lik_defer_min_frac;
 }
 
-bool lik_strict(const mcl3dl_hip_ctx* ctx, int ns)
-{
-  return ctx->strict_order == 1 || (ctx->strict_order == 2 && ns >= ctx->strict_auto_min);
-}
-
 // strict_order = 3: the reference's float recurrence over the scan in the ENGINE's order (mcl3dl_hip_scan_order), inside the
 // tiled kernel — no term array, no replay (needs the page-locked error word of the hand-off: ensure_chain)
 bool lik_chain(const mcl3dl_hip_ctx* ctx)
@@ -154,10 +199,14 @@ int ensure_chain(mcl3dl_hip_ctx* ctx, size_t n_p, int n_tiles, uint32_t* tag0)
 {
   if (!ctx->chain_err)
   {
-    ctx->chain_err = static_cast<volatile unsigned*>(pinned_alloc(ctx, 64));
-    if (!ctx->chain_err || !ctx->zero_copy_supported)
+    // (the word is kept only once the platform has shown that the device can write it in place: a context on a platform
+    // without such memory fails HERE on every call instead of launching kernels that write through a pointer the device
+    // cannot reach — ADVICE round 5)
+    volatile unsigned* w = ctx->zero_copy_supported ? static_cast<volatile unsigned*>(pinned_alloc(ctx, 64)) : nullptr;
+    if (!w || !ctx->zero_copy_supported)
       return ctx->fail(-2, "strict_order = 3 needs page-locked memory the device can write in place");
-    *ctx->chain_err = 0u;
+    *w = 0u;
+    ctx->chain_err = w;
   }
   const size_t need = sizeof(unsigned long long) * 2 * n_p;
   const bool fresh = need > ctx->chain_carry.cap;
@@ -225,7 +274,9 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
 {
   const int np = static_cast<int>(n_p);
   const bool chain = lik_chain(ctx);
-  bool strict = lik_strict(ctx, ns) && !chain;
+  const LikMode mode = lik_mode(ctx, np, ns);
+  pl->tiled = mode.tiled;
+  bool strict = mode.replay;
   int group_size = plan_group_size(ctx, np, ns);
   if (chain && group_size > 16)
     group_size = 16;
@@ -262,9 +313,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
   }
   // tiled from lik_tiled_min points up (default 1024), and already from three quarters of that when there are enough particles
   // to fill the GPU with (tile, group) pairs (4096 x 1000: 30.6 us tiled against 34.9 us; 64 x 1000 and 4096 x 512: no gain)
-  pl->tiled = (ctx->lik_tiled && np >= 4 &&
-               (ns >= ctx->lik_tiled_min || (np >= 256 && 4 * static_cast<long long>(ns) >= 3ll * ctx->lik_tiled_min))) ||
-              strict || chain;
+  pl->rows = mode.rows;
   pl->group_size = group_size;
   pl->small = !pl->tiled && ns <= 32 && np >= 256 && ctx->lik_small;
   if (pl->small)
@@ -405,6 +454,10 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   LikPlan plan;
   if (want_lik && !stats && ctx->n_s > 0)
     TRY(plan_lik(ctx, n_p, static_cast<int>(ctx->n_s), &plan));
+  // are the likelihoods of this launch the reference's floats bit for bit (caller-order rows, the float-order replay, the
+  // in-kernel chain, or no terms at all)? pf::measure then adds the weights as the reference does, too (pf_float_order)
+  if (want_lik && !stats)
+    ctx->lik_exact = ctx->n_s == 0 || plan.rows || plan.chain || plan.strict_terms != nullptr;
   if (stats && ctx->n_s > 0)
     TRY(ensure(ctx, ctx->tested, sizeof(double) * n_p));
   // ---- beam model (enqueued first: on its own stream when both models run, see mcl3dl_hip_ctx::aux_stream)
@@ -527,13 +580,17 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         const int coop_arg = (ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f) ? 1 : 0;
         const int group_size = plan.group_size;
         float* strict_terms = plan.strict_terms;
+        // caller-order float sums inside the per-particle kernels: the permutation (device index -> caller's index) and the
+        // LDS row of chain_row_floats(ns) floats
+        const uint32_t* row_perm = plan.rows ? ctx->scan_perm.as<uint32_t>() : nullptr;
+        const size_t row_bytes = plan.rows ? sizeof(float) * static_cast<size_t>(chain_row_floats(ns)) : 0;
         if (small)
         {
           const int W = plan.W;
           const long long blocks = plan.blocks;
 #define LAUNCH_SMALL(WW, MODE)                                                                                         \
   hipLaunchKernelGGL((likelihood_small_kernel<WW, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
-                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, coop_arg)
+                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, coop_arg, row_perm)
 #define LAUNCH_SMALL_W(MODE)       \
   switch (W)                       \
   {                                \
@@ -744,8 +801,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         else
         {
 #define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
-  hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), 0, ctx->stream, d_pose, scan, ns, \
-                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg)
+  hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), row_bytes, ctx->stream, d_pose, scan, ns, \
+                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg, row_perm)
         if (ctx->lik_index == 2)
         {
           if (ns <= 128)
@@ -807,6 +864,19 @@ int pf_blocks(size_t n)
 }
 
 
+// Does pf::measure on ONE GPU add the un-normalised weights as the reference does (pf.h:255-260: float, sequentially, particle
+// order) instead of the fp64 tree? strict_order 1: always. The default (2): whenever the likelihoods in front of it are the
+// reference's bits (ctx->lik_exact) — the whole update is then bit-identical — as long as pf::measure is ONE work-group
+// (pf_fused_kernel: up to pf_fused_max = 1024 particles; the one-launch update does the same up to update_small_max). Beyond
+// that the recurrence needs a launch of its own (pf_strict_sum_kernel: +10 us at 4096 particles, a third of a 4096 x 96
+// update, profiles/r06d_rows_vs_replay.txt) for weights that agree to ~1e-7 anyway: strict_order 1 only.
+bool pf_float_order(const mcl3dl_hip_ctx* ctx, size_t n_p)
+{
+  return ctx->strict_order == 1 ||
+         (ctx->strict_order == 2 && ctx->lik_exact && ctx->pf_fused &&
+          n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)));
+}
+
 // is pf::measure of n_p particles on this GPU finished by pf_norm_kernel (weights formed by the kernel in front of it)?
 bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
 {
@@ -822,10 +892,11 @@ bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
 int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                         float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho = nullptr)
 {
-  if (!ctx->update_small || n_p == 0 || ctx->n_b > 256 || ctx->strict_order == 1 || ctx->strict_order == 3 || !ctx->has_scan || !d_lik || !d_ratio ||
-      !d_beam)
+  if (!ctx->update_small || n_p == 0 || ctx->n_b > 256 || ctx->strict_order == 3 || !ctx->has_scan || !d_lik || !d_ratio || !d_beam)
     return 0;
   const bool tickets = n_p <= static_cast<size_t>(ctx->update_small_max);
+  if (!tickets && ctx->strict_order == 1)
+    return 0;  // (the per-particle half leaves pf::measure to pf_norm_kernel's fp64 tree)
   // (above update_small_max only with a handful of beam points — the reference's default is 3: a work-group per particle
   // walks its rays with mostly idle wavefronts, the flat beam kernel packs the rays of all particles)
   if (!tickets && !(pf_tail_eligible(ctx, n_p) && ctx->update_particle && ctx->n_b <= 32))
@@ -835,9 +906,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   {
     // (decided without plan_lik's buffer allocations: the tiled form needs per-tile partials this path never touches)
     const int np = static_cast<int>(n_p);
-    const bool tiled = (ctx->lik_tiled && np >= 4 &&
-                        (ns >= ctx->lik_tiled_min || (np >= 256 && 4ll * ns >= 3ll * ctx->lik_tiled_min))) ||
-                       lik_strict(ctx, ns);
+    const bool tiled = lik_mode(ctx, np, ns).tiled;
     const bool small = !tiled && ns <= 32 && np >= 256 && ctx->lik_small;
     if (tiled || small)
       return 0;
@@ -890,6 +959,15 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.stats4 = d_stats4;
   a.conformant = ctx->update_small_conformant;
   a.emit = (ho && tickets) ? *ho : PfEmit{};  // (the particle-only form leaves the host copies to pf_norm_kernel)
+  // the reference's float recurrences, in its own order: the likelihood terms over the caller's scan (lik_particle's row) and —
+  // where this launch also finishes pf::measure — the weights over the particles (pf.h:255-260)
+  const bool rows = ns > 0 && lik_mode(ctx, static_cast<int>(n_p), ns).rows;
+  const bool float_w = tickets && (ctx->strict_order == 1 || (ctx->strict_order == 2 && (rows || ns == 0)));
+  a.perm = rows ? ctx->scan_perm.as<uint32_t>() : nullptr;
+  a.float_order_w = float_w ? 1 : 0;
+  ctx->lik_exact = rows || ns == 0;
+  const size_t row_floats = std::max<size_t>(rows ? chain_row_floats(ns) : 0, float_w ? chain_row_floats(static_cast<int>(n_p)) : 0);
+  const size_t row_bytes = sizeof(float) * row_floats;
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_UPDATE, &ep));
   const unsigned grid = static_cast<unsigned>(n_p);
@@ -897,9 +975,9 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   do                                                                                                                \
   {                                                                                                                 \
     if (tickets)                                                                                                    \
-      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a);     \
+      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, true>), dim3(grid), dim3(BLOCK), row_bytes, ctx->stream, a);     \
     else                                                                                                            \
-      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, a);    \
+      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, false>), dim3(grid), dim3(BLOCK), row_bytes, ctx->stream, a);    \
   } while (0)
   // the work-group size the separate likelihood kernel would get (launch_measure), so that the lanes add in the same order
   const bool narrow = ns <= 128 && ctx->n_b <= 128;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "float_chain.h"
 #include "map_structs.h"
 #pragma clang fp contract(off)
 
@@ -531,18 +532,32 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
   return fmaxf(dist, 0.0f) * prm.match_weight;
 }
 
-// One particle's likelihood-field score by one work-group of BLOCK threads: lanes stride the (Morton-ordered) scan, fp64
-// per-lane accumulators, wavefront __shfl reduction, then across the work-group's wavefronts through LDS in wavefront order.
-// Thread 0 returns the sum of the float terms (fp64), the match count and (STATS) the candidates tested; shared by
-// likelihood_kernel and the one-launch update (update_kernels.h), which therefore produce the same bits.
+// One particle's likelihood-field score by one work-group of BLOCK threads: lanes stride the (Morton-ordered) scan.
+// s_row != nullptr (the default wherever the scan fits: launch_measure): every float term goes to LDS at its ORIGINAL scan
+// index (perm: device index -> index in the caller's array) and the first wavefront runs the reference's own recurrence over
+// them — score_like += dist * match_weight, float, sequentially, in the order the caller's cloud holds its points
+// (likelihood.cpp:120-134; float_chain.h: the whole wavefront works on it) — so the likelihood is the reference's float bit
+// for bit. Unmatched points hold +0 (x + 0.0f == x). s_row: 16-byte aligned, chain_row_floats(n_s) floats.
+// s_row == nullptr: fp64 per-lane accumulators, wavefront __shfl reduction, then across the wavefronts in order — the same
+// terms in a fixed-order fp64 tree (within the reference's own rounding of its float, ~n_s * 6e-8 at worst).
+// Thread 0 returns the sum, the match count and (STATS) the candidates tested; shared by likelihood_kernel and the one-launch
+// update (update_kernels.h), which therefore produce the same bits.
 template <int BLOCK, int MODE, bool STATS>
 __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, const float4* __restrict__ scan, int n_s,
                                              const LikGrid& g, const CandGrid& cg, const RecGrid& rg, const LikParams& prm,
-                                             int coop, double& sum_out, unsigned& num_out, unsigned& tested_out)
+                                             int coop, double& sum_out, unsigned& num_out, unsigned& tested_out,
+                                             const uint32_t* __restrict__ perm = nullptr, float* s_row = nullptr)
 {
   double acc = 0.0;   // sum of float terms, each exactly representable: fp64 sum is exact to ~1e-16
   unsigned num = 0;   // matched points
   unsigned tested = 0;
+  const bool rows = !STATS && s_row != nullptr;
+  if (rows)
+  {
+    // the zeros behind the last term (seq_sum_wave: chain_row_floats)
+    if (static_cast<int>(threadIdx.x) < chain_row_floats(n_s) - n_s)
+      s_row[n_s + threadIdx.x] = 0.0f;
+  }
   if (MODE == 2 && !STATS && coop)
   {
     // cooperative record fetch (rec_min_d2_quad): consecutive lanes hold consecutive (Morton-ordered) scan points; every
@@ -552,9 +567,16 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
       const int i = base + static_cast<int>(threadIdx.x);
       const bool have = i < n_s;
       const float4 v = have ? scan[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t slot = (rows && have) ? perm[i] : 0u;
       bool matched;
       const float term = eval_coop(rg, prm, pos, rot, v, have, static_cast<int>(threadIdx.x & 63), matched);
-      acc += static_cast<double>(term);
+      if (rows)
+      {
+        if (have)
+          s_row[slot] = term;
+      }
+      else
+        acc += static_cast<double>(term);
       num += matched ? 1u : 0u;
     }
   }
@@ -575,22 +597,28 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
     const float d2 = MODE == 0 ? nearest_d2<STATS>(g, qx, qy, qz, tested) :
                      MODE == 1 ? nearest_d2_cand<STATS>(cg, qx, qy, qz, tested) :
                                  nearest_d2_rec<STATS>(rg, qx, qy, qz, tested);
+    float term = 0.0f;
     if (d2 < prm.r2)  // radiusSearch found a neighbour (strict <)
     {
       const float s = sqrtf(d2);
       const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);  // :128
       if (!(dist < 0.0f))                                                                           // :129
       {
-        acc += static_cast<double>(dist * prm.match_weight);  // :132 (float product, then accumulated)
+        term = dist * prm.match_weight;  // :132 (float product, then accumulated)
+        if (!rows)
+          acc += static_cast<double>(term);
         ++num;
       }
     }
+    if (rows)
+      s_row[perm[i]] = term;
   }
   // wavefront __shfl reduction, then across the work-group's waves through LDS
   __shared__ double s_acc[BLOCK / 64];
   __shared__ unsigned s_num[BLOCK / 64];
   __shared__ unsigned s_tested[BLOCK / 64];
-  acc = wave_sum(acc);
+  if (!rows)
+    acc = wave_sum(acc);
   num = wave_sum(num);
   if (STATS)
     tested = wave_sum(tested);
@@ -603,6 +631,9 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
       s_tested[wave] = tested;
   }
   __syncthreads();
+  float chain = 0.0f;
+  if (rows && wave == 0)
+    chain = seq_sum_wave(s_row, n_s, lane);
   if (threadIdx.x == 0)
   {
     double a = 0.0;
@@ -615,7 +646,7 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
       if (STATS)
         tt += s_tested[w];
     }
-    sum_out = a;
+    sum_out = rows ? static_cast<double>(chain) : a;  // (float -> double -> float is the identity: the callers narrow it back)
     num_out = n;
     tested_out = tt;
   }
@@ -623,13 +654,17 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
 
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
 // MODE 1: candidate-voxel index
+// (the caller-order term row of lik_particle / the one-launch update: dynamic LDS, sized by the launch)
+extern __shared__ __attribute__((aligned(16))) float dyn_row[];
+
 template <int BLOCK, int MODE, bool STATS>
 __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
                                                            const float4* __restrict__ scan, int n_s, LikGrid g,
                                                            CandGrid cg, RecGrid rg, LikParams prm,
                                                            float* __restrict__ out_lik,
                                                            float* __restrict__ out_ratio,
-                                                           double* __restrict__ out_tested, int coop)
+                                                           double* __restrict__ out_tested, int coop,
+                                                           const uint32_t* __restrict__ perm = nullptr)
 {
   const int p = blockIdx.x;
   const float* ps = pose7 + 7 * static_cast<size_t>(p);
@@ -637,7 +672,7 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
   const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
   double a = 0.0;
   unsigned n = 0, tt = 0;
-  lik_particle<BLOCK, MODE, STATS>(pos, rot, scan, n_s, g, cg, rg, prm, coop, a, n, tt);
+  lik_particle<BLOCK, MODE, STATS>(pos, rot, scan, n_s, g, cg, rg, prm, coop, a, n, tt, perm, perm ? dyn_row : nullptr);
   if (threadIdx.x == 0)
   {
     if (out_lik)
@@ -659,17 +694,20 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
 // up to a power of two; lane = (particle, point). Poses differ between the lanes of a wave, so each lane normalises its
 // own quaternion; the W terms of a particle are reduced with width-W shuffles (fp64, fixed order).
 // ---------------------------------------------------------------------------------------------------------
+// perm != nullptr (the default): the W lanes of a particle park their float terms in LDS at their ORIGINAL scan indices and
+// the particle's first lane adds them up as the reference does (likelihood.cpp:120-134: float, sequentially, caller's order;
+// at most 32 adds) — bit-identical likelihoods. perm == nullptr: the fp64 width-W shuffle tree.
 template <int W, int MODE>
 __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, LikGrid g,
                                                                CandGrid cg, RecGrid rg, LikParams prm,
                                                                float* __restrict__ out_lik, float* __restrict__ out_ratio,
-                                                               int coop)
+                                                               int coop, const uint32_t* __restrict__ perm = nullptr)
 {
   const long long gt = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   const long long p = gt / W;
   const int i = static_cast<int>(gt % W);
-  double acc = 0.0;
+  float term = 0.0f;
   unsigned num = 0;
   if (MODE == 2 && coop)
   {
@@ -680,8 +718,7 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
     const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });
     const float4 v = scan[i < n_s ? i : 0];
     bool matched;
-    const float term = eval_coop(rg, prm, pos, rot, v, have, static_cast<int>(threadIdx.x & 63), matched);
-    acc = static_cast<double>(term);
+    term = eval_coop(rg, prm, pos, rot, v, have, static_cast<int>(threadIdx.x & 63), matched);
     num = matched ? 1u : 0u;
   }
   else if (p < n_p && i < n_s)
@@ -708,21 +745,40 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
       const float dist = prm.match_dist_min - (s > prm.match_dist_flat ? s : prm.match_dist_flat);
       if (!(dist < 0.0f))
       {
-        acc = static_cast<double>(dist * prm.match_weight);
+        term = dist * prm.match_weight;
         num = 1;
       }
     }
   }
+  float lik;
+  if (perm)
+  {
+    __shared__ float s_small[256];
+    const int row = static_cast<int>(threadIdx.x) - i;  // first lane of this particle
+    if (i < n_s)
+      s_small[row + static_cast<int>(perm[i])] = term;
+    __syncthreads();
+    float s = 0.0f;
+    if (i == 0)
+      for (int j = 0; j < n_s; ++j)
+        s = s + s_small[row + j];
+    lik = s;
+  }
+  else
+  {
+    double acc = static_cast<double>(term);
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1)
+      acc += __shfl_down(acc, off, W);
+    lik = static_cast<float>(acc);
+  }
 #pragma unroll
   for (int off = W / 2; off > 0; off >>= 1)
-  {
-    acc += __shfl_down(acc, off, W);
     num += __shfl_down(num, off, W);
-  }
   if (i == 0 && p < n_p)
   {
     if (out_lik)
-      out_lik[p] = static_cast<float>(acc);
+      out_lik[p] = lik;
     if (out_ratio)
       out_ratio[p] = static_cast<float>(num) / static_cast<float>(n_s);
   }
@@ -1496,38 +1552,25 @@ __global__ __launch_bounds__(1024) void lik_strict_sum_rows_kernel(const float* 
     out_lik[p] = score;
 }
 
-// "strict_order": pf::measure's `sum += p.probability_` (pf.h:255-260) as a float, sequentially, by one lane; the result
-// replaces the fp64 tree sum in packed[0] so that pf_apply_kernel divides by exactly the reference's float.
+// pf::measure's `sum += p.probability_` (pf.h:255-260) as the reference runs it — a float recurrence in particle order — behind
+// pf_partial / pf_reduce: the result replaces the fp64 tree sum in packed[0] so that pf_apply_kernel divides by exactly the
+// reference's float. One work-group: 256 lanes stage 4096 weights at a time in LDS (coalesced), the first wavefront runs
+// the recurrence over them (float_chain.h: 256 terms a pass instead of one), carrying the sum from chunk to chunk.
 __global__ __launch_bounds__(256) void pf_strict_sum_kernel(const float* __restrict__ w_new, int n,
                                                             double* __restrict__ packed)
 {
-  // one work-group: 256 lanes stage 4096 weights at a time in LDS (coalesced), lane 0 runs the dependent add chain
-  __shared__ float buf[4096];
+  __shared__ __attribute__((aligned(16))) float buf[4096 + 4];
   if (blockIdx.x != 0)
     return;
   float sum = 0.0f;
   for (int base = 0; base < n; base += 4096)
   {
-    const int m = min(4096, n - base);
-    for (int j = threadIdx.x; j < m; j += 256)
-      buf[j] = w_new[base + j];
+    const int m = min(4096, n - base), m4 = chain_row_floats(m);
+    for (int j = threadIdx.x; j < m4; j += 256)
+      buf[j] = j < m ? w_new[base + j] : 0.0f;
     __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      int i = 0;
-      for (; i + 16 <= m; i += 16)
-      {
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          v[j] = buf[i + j];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          sum += v[j];
-      }
-      for (; i < m; ++i)
-        sum += buf[i];
-    }
+    if (threadIdx.x < 64)
+      sum = seq_sum_wave(buf, m, static_cast<int>(threadIdx.x), sum);
     __syncthreads();
   }
   if (threadIdx.x == 0)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "float_chain.h"
 
 #pragma clang fp contract(off)
 
@@ -208,8 +209,11 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
                                                         const float* __restrict__ beam, const float* __restrict__ extra,
                                                         const float* __restrict__ ratio, int n, float* __restrict__ w_new,
                                                         double* __restrict__ packed, float* __restrict__ stats4,
-                                                        PfEmit emit = PfEmit{})
+                                                        PfEmit emit = PfEmit{}, int float_order = 0)
 {
+  // float_order: pf::measure's `sum += p.probability_` (pf.h:255-260) as the reference runs it — float, sequentially, in
+  // particle order (float_chain.h) — instead of the fp64 tree: the weights are divided by exactly the reference's float
+  __shared__ __attribute__((aligned(16))) float s_w[PF_FUSED_MAX + 4];
   __shared__ double sh[4][16];          // per wavefront of the group
   __shared__ double part[4][16];        // per virtual block (n <= 4096 -> at most 16 of them)
   __shared__ double tot[4];
@@ -230,6 +234,8 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
         l = l * extra[i];
       const float wn = w[i] * l;
       w_new[i] = wn;
+      if (float_order)
+        s_w[i] = wn;
       s += static_cast<double>(wn);
       if (wn > 0.0f)
         t += static_cast<double>(wn) * log(static_cast<double>(wn));
@@ -284,6 +290,15 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
     b = wave_sum(b);
     c = wave_max(c);
     d = wave_max(d);
+    if (float_order)
+    {
+      // (s_w[0 .. n) was written before the loop's last barrier; the padding of the last float4 here, by this wavefront)
+      if (lane < chain_row_floats(n) - n)
+        s_w[n + lane] = 0.0f;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      a = static_cast<double>(seq_sum_wave(s_w, n, lane));
+    }
     if (lane == 0)
     {
       tot[0] = a;

@@ -62,6 +62,9 @@ struct UpdateSmallArgs
   float* stats4;
   PfEmit emit;          // page-locked host copies of the results (pf_kernels.h), each may be null
   int conformant;       // 1: every arrival is an acq_rel read-modify-write at agent scope (see last_arrival)
+  const uint32_t* perm; // device scan index -> index in the caller's array: the likelihood terms are added in THAT order, as
+                        // floats (lik_particle's row in dynamic LDS); null = fixed-order fp64 tree
+  int float_order_w;    // 1: pf::measure's `sum += p.probability_` (pf.h:255-260) as the float recurrence over the particles
 };
 
 __device__ __forceinline__ void store_agent(float* p, float v)
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
   {
     double sum = 0.0;
     unsigned num = 0, unused = 0;
-    lik_particle<BLOCK, MODE, false>(pos, rot, a.scan_lik, a.n_s, a.g, a.cg, a.rg, a.prm, a.coop, sum, num, unused);
+    lik_particle<BLOCK, MODE, false>(pos, rot, a.scan_lik, a.n_s, a.g, a.cg, a.rg, a.prm, a.coop, sum, num, unused, a.perm,
+                                     a.perm ? dyn_row : nullptr);
     lik = static_cast<float>(sum);
     ratio = static_cast<float>(num) / static_cast<float>(a.n_s);  // :136
   }
@@ -323,6 +327,26 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
     }
   }
   __syncthreads();
+  if (a.float_order_w)
+  {
+    // the reference's own sum (pf.h:255-260): float, sequentially, in particle order — the un-normalised weights staged in
+    // the dynamic LDS row (free again: every particle's likelihood is done), the first wavefront runs the recurrence
+    // (float_chain.h). The weights are then divided by exactly the reference's float.
+    const int n4 = chain_row_floats(a.n_p);
+    for (int i = threadIdx.x; i < n4; i += BLOCK)
+      dyn_row[i] = i < a.n_p ? load_agent(a.w_new + i) : 0.0f;
+    __syncthreads();
+    if (wave == 0)
+    {
+      const float sum_w = seq_sum_wave(dyn_row, a.n_p, lane);
+      if (lane == 0)
+      {
+        tot[0] = static_cast<double>(sum_w);
+        a.packed[0] = static_cast<double>(sum_w);
+      }
+    }
+    __syncthreads();
+  }
   // pf_apply_kernel
   const double S = tot[0];
   const float sum_f = static_cast<float>(S);
