@@ -485,147 +485,78 @@ int mcl3dl_hip_workload_stats(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n
  * [7] candidate points (with lik_index 2: [6] = the 64-byte voxel records, [7] = their overflow records). Structures that
  * were never needed are 0. */
 int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
-/* Tuning knobs (no reference counterpart; results are identical for every setting):
- *   "lik_index"         2 (default) = candidate-voxel index, one 64-byte record per voxel; 1 = candidate-voxel index,
- *                       CSR runs; 0 = 27-cell scan of the cell-sorted map
- *   "cand_voxel_ratio"  candidate voxel edge / match_dist_min; 0 (default) = chosen per map: 0.5, or 0.36 when more than a
- *                       quarter of the voxels hold more candidates than a record has room for
- *   "cand_phase"        candidate grid origin phase in voxels, [0,1) (default 0.5)
- *   "cand_record_parts" inline candidates per voxel record: 4 (64-byte records), 8 (128-byte records: one 128-byte line
- *                       per lookup, all eight loads issued together), 0 (default) = 4 — or, only when "lik_defer" is 0, 8
- *                       together with the smaller voxel edge on a crowded map when the records stay below 16 GB.
- *                       Read-only: "cand_record_parts_in_use", "cand_voxels_over8"
- *   "lik_defer"         1 (default) = the tiled kernel queues the evaluations whose voxel holds more than four candidates
- *                       per wavefront and runs their overflow rounds densely (needs "cand_packed" records of 4 parts; same
- *                       bits, -5 % on a lattice, -7..-15 % on maps of voxel-filter centroids); 0 = overflow rounds at once;
- *                       2 = the queue only where more than "lik_defer_min_frac" (0.03) of the voxels overflow.
- *                       Read-only: "lik_defer_active"
- *   "cand_packed"       1 (default) = every part of a voxel record carries (candidate count << 26) | first overflow record
- *                       when the map allows it (every count <= 63, fewer than 2^26 overflow records), else — and with 0 —
- *                       count and reference in parts 0 and 1. Read-only: "cand_packed_active"
- *   "lik_tiled"         1 (default) = tile-major, XCD-aware likelihood kernel for scans >= "lik_tiled_min" points and >= 4
- *                       particles; 0 = one work-group per particle always (only the fp64 summation order differs)
- *   "lik_tiled_min"     default 1024; with >= 256 particles the tiled kernel already takes over at three quarters of it
- *   "update_small"      1 (default) = up to "update_small_max" particles (default 512) an update whose scans the per-particle
- *                       kernels serve (<= ~768 likelihood points, <= 256 beam points) runs as ONE launch: likelihood + beam
- *                       + pf::measure, the stages handed over by arrival tickets (update_kernels.h); 0 = separate kernels
- *   "update_small_conformant"  0 (default) = the tickets are relaxed increments behind drained agent-scope stores (the
- *                       fence-free form the gfx950 guide gives); 1 = acq_rel increments at agent scope, the form the
- *                       HIP / LLVM memory model defines (one L2 write-back per arrival: slower). Same results; a one-line
- *                       mitigation should the default ever misbehave on a future part (tests/test_gpu_soak.py runs both)
- *   "timing_mask"       bit k set (default: all) = kernel group k is timed while kernel timing is on
- *   "overlap_models"    1 (default) = the beam kernels run on a second stream concurrently with the likelihood kernels
- *                       (forked from / joined into the context's stream with events); 0 = one after the other
- *   "lik_small"         1 (default) = scans of <= 32 points with >= 256 particles (global localisation) share each
- *                       wavefront between 64 / W particles; 0 = always one work-group per particle
- *   "lik_group"         particles per work-group of the tiled kernel: 0 (default) = the largest of 16 / 8 / 4 that
- *                       still yields >= 2048 work-groups, or 4, 8, 16, 32 to force one
- *   "strict_order"      0 = fp64 tree sums always; 1 = add the likelihood terms per particle and the weights over the
- *                       particles as floats in the reference's own sequential order (likelihood.cpp:120-134,
- *                       pf.h:255-260): likelihoods and normalised weights then equal the reference's bit for bit
- *                       (single GPU; costs an n_s x n_p float buffer and two serial passes); 2 (default) = the likelihood
- *                       terms are replayed in that order for scans of at least "strict_auto_min" points (default 32 768)
- *                       — from there on the reference's own float rounding, a random walk of n_s roundings, reaches the
- *                       1e-5 relative tolerance the fp64 sum is held to — and summed in fp64 below. The automatic replay
- *                       needs n_s x n_p floats of device memory (0.5 GB at 32 768 x 4096, 26 GB at 65 536 x 100 000): a
- *                       launch whose buffer would take more than half of the free device memory (or more than
- *                       "strict_auto_max_bytes" when that is set, or whose allocation fails) sums in fp64 instead — the
- *                       update never fails over it; read-only "strict_auto_skipped" counts such launches. Mode 1 fails
- *                       loudly when its buffer cannot be had. 3 = the float recurrence runs INSIDE the likelihood kernel,
- *                       at every scan size, over the scan in the ENGINE's order (mcl3dl_hip_scan_order): bit-identical to
- *                       the reference's measure() on the scan permuted that way; no term buffer, no replay pass (the
- *                       work-group of a scan tile hands each particle's running sum on to the next tile's). Weights are
- *                       summed as in mode 2. Suits callers whose scan order means nothing to them (a sampled cloud).
- *   "scan_presorted"    1 = the caller holds its likelihood scans in the engine's order already (mcl3dl_hip_scan_order_host): every
- *                       scan is installed as it is — no ordering launches (four of the ten launches of a host-buffer update at
- *                       16 384 points), the permutation is the identity, and with "strict_order" = 3 (or 1) the float sums follow
- *                       the caller's own order. A scan that is NOT in that order is still evaluated correctly, in the order it
- *                       has; only the likelihood kernel loses the locality the order exists for. 0 (default) = ordered here.
- *   "strict_chunk"      0 (default) = a caller-order replay ("strict_order" 1 / 2) keeps the terms of the whole scan (n_s x n_p floats);
- *                       a point count >= 1024 = scans of at least two such chunks are ordered chunk by chunk of the caller's order
- *                       and replayed chunk by chunk with two term buffers (C5: 4.3 GB instead of 17 GB, 27.9 instead of 25.6 ms:
- *                       the low-memory form). Same bits. Read-only "scan_chunk_in_use".
- *   "index_budget_bytes"  upper bound of the candidate-voxel records (the bulk of the likelihood index: one 64-byte record per
- *                       voxel of every 8 x 8 x 8-voxel brick within reach of a map point): -1 (default) = a quarter of the
- *                       device's memory, 0 = none. The index is laid out, in this order, with cubes of edge r / 2 (fastest),
- *                       with BOXES whose edges follow the dist_weight axis by axis (option "cand_aniso" below: the shipped
- *                       z x 5 then costs the memory of the unit-weight map — a quarter — at 1.04-1.14 x the kernel time),
- *                       with coarser voxels (up to 1.5 r), and fails with the number of bytes it would need when even those
- *                       do not fit. Results are the same bits whatever the voxel shape. Read-only: "index_record_bytes",
- *                       "index_budget_in_use", "cand_aniso_active", "cand_edge_ratio_x/_y/_z" (voxel edge / match_dist_min)
- *   "cand_aniso"        voxel shape of the candidate index under a dist_weight: 0 = cubes always, 1 = boxes always (edge of
- *                       axis a = base edge x min(w_a / w_min, "cand_aniso_max" = 8)), 2 (default) = boxes when the cubes
- *                       exceed the budget
- *   "poll_spin_us"      how long a completion wait spins on its page-locked word before it starts napping between looks
- *                       (default 2000: every update up to a few thousand particles completes inside the spin); the naps
- *                       grow with the time already waited (1/32 of it, 1 ms at most) and hipStreamQuery is consulted every
- *                       "poll_query_us" (default 5000), so a long update does not hold a core and a faulted queue comes
- *                       back as an error
- *   "chain_ppl"         strict_order = 3: scan tiles per work-group of the in-kernel float sum. 0 (default) = four (a quarter of
- *                       the hand-offs between work-groups: likelihood_chain_multi.h) up to "chain_multi_max" = 1536 particles on
- *                       scans of at least 16 tiles, default kernel family only; 1 = always one; 4 = four wherever the family
- *                       allows. Same bits. 1024 particles x 16 384 points: 0.139 -> 0.122 ms (fp64 sums 0.072); slower from
- *                       2048 particles (profiles/r05r_chain_multi.txt)
- *   "update_fold_done"  0 (default): the polled completion word is written by a one-thread kernel of its own behind the update;
- *                       1: where the host-buffer update ends in a one-work-group kernel (the fused pf::measure up to
- *                       "pf_fused_max" particles, the apply behind a float-order replay as ONE block up to 16 384) that
- *                       kernel writes the word behind its results. Same bits; measured 0 - 14 us SLOWER (the system-scope
- *                       release sits on the update's critical path, and the one-block apply is slower than sixteen):
- *                       profiles/r05j_fold_ab.txt
- *   "scan_order_device" scans of at least this many points (both models together; default 4096) are ordered on the
- *                       device when they are uploaded, smaller ones on the host; 0 = always on the host. Same order, same
- *                       results either way.
- *   "pf_fused"          1 (default) = pf::measure of the single-GPU entry points runs as ONE work-group up to
- *                       "pf_fused_max" particles (default 1024, at most 4096: measured faster than three launches up to
- *                       1024, slower at 4096); 0 = always partial + reduce + apply. Same bits either way.
- *   "lik_coop"          tiled kernel: 1 (default) = the four lanes of a quad fetch each 64-byte voxel record together
- *                       (16 cache-line accesses per load instruction instead of 64) and split its candidates between
- *                       them, with the VALU-trimmed transform / sqrt; 0 = every lane fetches its own record
- *   "lik_wide_max_particles"  default 64: up to this many particles a scan of more than 512 points is walked by 1024
- *                       threads per particle instead of 256 (a quarter of the dependent load chains per lane: the
- *                       reference's own 64 x 1000 case is latency-bound); 0 = never
- *   "beam_prepare"      1 (default) = launches of >= 32 768 rays take what depends only on (particle, origin) from a
- *                       small kernel instead of every ray recomputing it; 0 = never
- *   "sort_full_pass"    1 = arrays of 2049 .. 32 768 elements (a 16 384-point scan) are radix-sorted with ONE launch per
- *                       8-bit pass — every work-group counts every work-group's digits itself —, 0 (default; measured
- *                       faster) = a counting launch and a scatter launch per pass. Same order either way.
- *   "sort_one_launch"   1 = arrays of 2049 .. 32 768 elements with keys of at most 16 bits (the scan ordering of a 16 384-point
- *                       likelihood scan) are sorted by ONE launch whose work-groups each hold the whole key distribution in
- *                       LDS; 0 (default) = the launches per 8-bit pass above. Same stable order. Measured: the 15 360 LDS
- *                       atomics every work-group needs run at one lane per clock (7.7 us) — equal to the passes at 16 384
- *                       elements (0.2755 / 0.2742 ms per host-buffer update), faster at 4096, slower at 32 768:
- *                       profiles/r05p_sort16_one_launch.txt
- *   "update_stage"      1 (default) = mcl3dl_hip_measure_update hands scans (<= 16 384 points per model), poses and prior
- *                       weights to the device with ONE launch that also orders the scans (stage_kernels.h), 0 = upload +
- *                       ordering as separate copies and launches (the path larger scans always take; same results)
- *   "update_zero_copy"  1 (default) = that launch reads the arrays in page-locked host memory and the update's last
- *                       kernel writes the results there; 0 = one H2D copy in front, one D2H copy behind
- *   "poll_sync"         how a call learns that its work on the context's stream is through: 2 (default) = always from a word
- *                       in page-locked memory that a one-thread kernel behind the work writes (polled by the caller's
- *                       thread; 6 us less than hipStreamSynchronize per synchronisation on MI355X / ROCm 7), 1 = only the
- *                       zero-copy host-buffer update and its relatives, 0 = hipStreamSynchronize everywhere
- *   "dda_overlay"       1 (default) = the points of a map update are an overlay of the DDA grid (sorted by voxel, looked up
- *                       behind a voxel's base points): mcl3dl_hip_map_update replaces the overlay instead of marking the
- *                       grid for a rebuild, as long as the update stays inside the base map's bounds; 0 = one array over
- *                       base + update, rebuilt after every update. Read-only: "dda_overlay_updates" (updates applied that
- *                       way), "dda_overlay_points". Same beam results either way.
- *   "cand_prune_coop"   1 (default) = the map compiler's pruning pass runs 16 lanes per voxel (candidates in LDS), 0 = one
- *                       thread per voxel; identical records, 4-5x shorter for the few hundred bricks of a map update
- *   "batch_slice"       particles per slice of mcl3dl_hip_measure_batch_begin when its slice_particles argument is 0
- *                       (0 = automatic: four slices, none below 512); read-only "batch_slices_run" counts the slices run
- *   "pf_tail"           1 = pf::measure of up to 8192 particles on one GPU in two launches without hand-offs between
- *                       work-groups (the un-normalised weights come out of lik_finalize / a small kernel; every work-group
- *                       of pf_norm_kernel recomputes the reduction and normalises its own 256 weights); 0 (default) =
- *                       pf_partial + pf_reduce + pf_apply. Bit-identical either way; the three small launches measured
- *                       3-5 us faster behind a long likelihood kernel (they are enqueued while it runs).
- *   "update_particle"   1 = with pf_tail, between update_small_max and 8192 particles, updates the per-particle likelihood
- *                       kernel serves (scans below ~768 points, <= 32 beam points) run likelihood + beam + weight in ONE
- *                       launch (one work-group per particle) followed by pf_norm_kernel; 0 (default) = separate kernels
- *   "grid_build_host"   0 (default) = the cell-sorted exact-NN grid and the DDA occupancy / voxel index are built on the
- *                       device from a device copy of the map; 1 = sequential counting sorts on the host + upload (the
- *                       form the device builders are checked against). Read-only: "lik_grid_build_ms",
- *                       "dda_grid_build_ms" (device time of the last build), "lik_grid_build_wall_ms",
- *                       "dda_grid_build_wall_ms" (host wall time of the last build, either builder) */
+/* Options (no reference counterpart). Round 6 pruned the switchboard: what lost its A/B is gone (the two-launch pf::measure tail,
+ * the one-launch sorts, the completion word folded into the last kernel, the device-side resampling prefix, the CSR form of the
+ * candidate index, sharper pruning of crowded voxels, the replay's A/B knobs, the dense record grid) and the thresholds nobody
+ * needs to move are constants (HISTORY.md R6-7). The 39 keys left are ALL drawn, in combination, by tests/test_gpu_api_fuzz.py
+ * (tests/test_abi.py keeps that pool and this list in step). Except for "strict_order" and its thresholds — which select HOW the
+ * sums are rounded — results are the same bits for every setting. Every key can be read back with mcl3dl_hip_get_option.
+ *
+ * -- how the sums are added up
+ *   "strict_order"      2 (default) = the likelihood terms are added up as the reference adds them — float, sequentially, in the
+ *                       order the CALLER's cloud holds its points (likelihood.cpp:120-134) — for every scan of at most
+ *                       "strict_exact_max" points (4096: the reference's operating range and far beyond) and for every scan of
+ *                       at least "strict_auto_min" points (28 147: from there on three standard deviations of the reference's own
+ *                       rounding leave north_star's 1e-5; host_context.h derives it): likelihoods are then the reference's bit for
+ *                       bit; so are match ratios and beam scores always, and the normalised weights up to 1024 particles (pf::measure's
+ *                       float sum, pf.h:255-260). In between the same float terms are summed in a fixed-order fp64 tree (within
+ *                       the reference's rounding of its own float: 5e-6 at 16 384 points). Wherever one work-group owns a
+ *                       particle's whole scan (below ~1000 points, or few particles: up to 12 288 points) the exact sum costs no
+ *                       memory and no launch — the terms wait in LDS at their original indices and a wavefront runs the
+ *                       recurrence 512 terms a pass (float_chain.h); elsewhere it costs an n_s x n_p float buffer and a replay
+ *                       launch. When that buffer would take more than half of the free device memory (or "strict_auto_max_bytes",
+ *                       or its allocation fails) the launch sums in fp64 instead — an update never fails over it; read-only
+ *                       "strict_auto_skipped" counts such launches.
+ *                       0 = fp64 tree sums always (fastest; ~1e-6, at worst n_s x 6e-8, from the reference).
+ *                       1 = exact always, weights at every particle count too (single GPU); fails loudly when the buffer cannot be had.
+ *                       3 = the float recurrence INSIDE the tiled likelihood kernel, at every scan size, over the scan in the
+ *                       ENGINE's order (mcl3dl_hip_scan_order): bit-identical to the reference's measure() on the scan permuted
+ *                       that way; no term buffer, no replay pass. Suits callers whose scan order means nothing to them (a
+ *                       sampled cloud): the drop-in classes with MCL3DL_HIP_ENGINE_ORDER=1.
+ *   "strict_exact_max", "strict_auto_min", "strict_auto_max_bytes"   the thresholds above (0 = no cap for the last)
+ *   "strict_chunk"      0 (default) = a replay keeps the terms of the whole scan; a point count >= 1024 = scans of at least two such
+ *                       chunks are ordered chunk by chunk of the caller's order and replayed with two term buffers (C5: 4.3 GB
+ *                       instead of 17 GB, 27.9 instead of 25.6 ms). Same bits. Read-only "scan_chunk_in_use".
+ *   "scan_presorted"    1 = the caller holds its likelihood scans in the engine's order already (mcl3dl_hip_scan_order_host): no
+ *                       ordering launches, the permutation is the identity, and the exact modes follow the caller's own order.
+ *   "chain_ppl"         strict_order 3: scan tiles per work-group (0 = four for few particles on long scans, 1, 4). Same bits.
+ * -- which kernel runs (same bits)
+ *   "lik_index"         2 (default) = candidate-voxel records (map_compiler.h); 0 = 27-cell scan of the cell-sorted map
+ *   "lik_tiled", "lik_tiled_min", "lik_group"   tile-major XCD-aware kernel for scans >= lik_tiled_min (1024) points and >= 4 particles;
+ *                       particles per work-group 0 (= 16 / 8 / 4 by launch size), 4, 8, 16, 32
+ *   "lik_small"         1 = scans of <= 32 points with >= 256 particles share each wavefront between several particles
+ *   "lik_coop"          1 = quad-cooperative record fetch + VALU-trimmed evaluation in the tiled kernel
+ *   "lik_defer"         1 = overflow rounds queued per wavefront and run densely (packed 64-byte records); 0 = at once; 2 = only on
+ *                       maps where enough voxels overflow. Read-only "lik_defer_active"
+ *   "update_small", "update_small_max"   the whole update as ONE launch up to that many particles (512) where the per-particle
+ *                       kernels serve the scans; "update_small_conformant" = its arrival tickets as acq_rel RMWs (the memory
+ *                       model's form; slower; a mitigation switch, tests/test_gpu_soak.py runs both)
+ *   "pf_fused"          1 = pf::measure as ONE work-group up to 1024 particles; 0 = partial + reduce + apply
+ *   "overlap_models"    1 = beam kernels on a second stream beside the likelihood kernels (large launches)
+ *   "beam_prepare"      1 = launches of >= 32 768 rays take per-(particle, origin) constants from a small kernel
+ * -- the likelihood index (same bits)
+ *   "cand_voxel_ratio"  voxel edge / match_dist_min; 0 (default) = per map: 0.5, or 0.36 on maps of voxel-filter centroids
+ *   "cand_phase"        grid origin phase in voxels, [0, 1) (0.5)
+ *   "cand_record_parts" inline candidates per record: 0 (default) / 4 = 64-byte records, 8 = 128-byte records
+ *   "cand_packed", "cand_bound"   packed w words / skip bounds in the records when the map allows them
+ *   "cand_aniso"        0 = cubes, 1 = boxes that follow the dist_weight (edge of axis a = base edge x min(w_a / w_min,
+ *                       "cand_aniso_max" = 8)), 2 (default) = boxes when cubes exceed the budget
+ *   "index_budget_bytes"  upper bound of the records: -1 (default) = a quarter of the device's memory, 0 = none; cubes, then boxes,
+ *                       then coarser voxels (<= 1.5 r), then a clean error naming the bytes needed. Read-only "index_note" says
+ *                       when the index differs from what was asked for; "index_record_bytes", "cand_edge_ratio_x/_y/_z"
+ *   "cand_prune_coop"   1 = the compiler's pruning pass runs 16 lanes per voxel; 0 = one thread per voxel (the form it is checked against)
+ *   "grid_build_host"   1 = cell grid and DDA grid built by sequential counting sorts on the host (the form the device builders are
+ *                       checked against)
+ *   "dda_overlay"       1 = a map update rides on the DDA grid as an overlay instead of forcing a rebuild
+ * -- host side
+ *   "update_stage", "update_zero_copy"   host-buffer updates: scans / poses / weights taken over by ONE launch that also orders the
+ *                       scans; read in place from page-locked memory, results written there by the update's last kernel
+ *   "poll_sync", "poll_spin_us"   completion by a polled page-locked word (2 = every synchronisation, 1 = host-buffer updates, 0 =
+ *                       hipStreamSynchronize); spin that long (2000 us) before napping between looks
+ *   "scan_order_device" scans of at least this many points are ordered on the device (4096; 0 = always on the host)
+ *   "batch_slice"       particles per slice of mcl3dl_hip_measure_batch_begin when slice_particles is 0
+ *   "timing_mask"       bit k set = kernel group k is timed while kernel timing is on
+ *   "test_late_structures"  fault injection for the API-sequence fuzz only */
 int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value);
 int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value);
 /* Candidate-voxel index of the current map: [0] bricks, [1] preliminary candidates, [2] candidates kept,

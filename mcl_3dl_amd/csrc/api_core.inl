@@ -575,20 +575,7 @@ namespace
 int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
                       const float* d_ratio, size_t n_p, float* d_stats4, const PfEmit* ho = nullptr)
 {
-  PfEmit emit = ho ? *ho : PfEmit{};
-  // the completion word folded into the last kernel (one work-group: pf_fused_kernel, or pf_apply_kernel as one block up to
-  // 16 384 particles): asked for by the host-buffer update, whose next step is the polled wait
-  const bool fold = ho && ctx->fold_done && ctx->poll_mode() && n_p <= 16384 && ensure_done_flag(ctx);
-  if (fold)
-  {
-    emit.done = ctx->done_flag;
-    emit.done_seq = ctx->done_seq + 1u;
-  }
-  const auto folded = [&]()
-  {
-    if (fold)
-      ctx->done_folded = ++ctx->done_seq;
-  };
+  const PfEmit emit = ho ? *ho : PfEmit{};
   const bool float_w = pf_float_order(ctx, n_p);
   if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->pf_fused)
   {
@@ -599,31 +586,17 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
                        static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit, float_w ? 1 : 0);
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
-    folded();
     return 0;
-  }
-  if (pf_tail_eligible(ctx, n_p) && !float_w)
-  {
-    // two launches, no hand-off: the weights, then every work-group reduces all of them and normalises its own (pf_norm_kernel)
-    TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
-    EventPair ep{};
-    TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-    hipLaunchKernelGGL(pf_weights_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
-                       static_cast<int>(n_p), ctx->wnew.as<float>());
-    TRY(timing_end(ctx, ep));
-    HIP_TRY(hipGetLastError());
-    return launch_pf_norm(ctx, n_p, d_weight, d_lik, d_ratio, d_beam, d_stats4, ho);
   }
   TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
   if (!ho)
     return mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4);
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-  hipLaunchKernelGGL(pf_apply_kernel, dim3(fold ? 1 : pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
+  hipLaunchKernelGGL(pf_apply_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
                      static_cast<int>(n_p), 1, ctx->partial4.as<double>(), d_stats4, emit, d_lik, d_ratio, d_beam);
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
-  folded();
   return 0;
 }
 
@@ -636,18 +609,9 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   if (host_written)
     *host_written = ho != nullptr;  // every path below writes them
   const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho);
-  if (one == 2)  // the per-particle half ran: likelihood, beam score, un-normalised weights
-    return launch_pf_norm(ctx, n_p, d_weight, d_lik, d_ratio, d_beam, d_stats4, ho);
   if (one != 0)
     return one < 0 ? one : 0;
-  MeasureTail mt;
-  mt.want = pf_tail_eligible(ctx, n_p) && d_lik && d_ratio && d_beam;
-  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr, &mt));
-  if (mt.want)
-  {
-    TRY(launch_pf_tail(ctx, mt, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho));
-    return 0;
-  }
+  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
   TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4, ho));
   return 0;
 }
@@ -1162,29 +1126,8 @@ int measure_update_staged(mcl3dl_hip_ctx* ctx, const float* pose, const float* e
         *res[k].slot = (k > 0 && ctx->is_pinned(res[k].user, res[k].bytes)) ? res[k].user
                                                                             : reinterpret_cast<float*>(out_blk + res[k].offset);
   bool host_written = false;
-  {
-    // the update's last kernel may write the completion word itself (pf_measure_single): the polled wait below is the very
-    // next thing this stream sees. The request is withdrawn on every way out of enqueue_update.
-    struct FoldScope
-    {
-      mcl3dl_hip_ctx* c;
-      ~FoldScope()
-      {
-        c->fold_done = false;
-      }
-    } fold_scope{ ctx };
-    ctx->fold_done = out_blk != nullptr && ctx->fold_done_opt;
-    ctx->done_folded = 0;
-    const int rc_u = enqueue_update(ctx, ctx->pose.as<float>(), n_p, d_w, extra ? ctx->extra.as<float>() : nullptr, d_lik, d_ratio,
-                                    d_beam, d_stats, out_blk ? &ho : nullptr, &host_written);
-    if (rc_u != 0)
-    {
-      ctx->done_folded = 0;  // (whatever was enqueued, the next wait launches its own completion word behind it)
-      return rc_u;
-    }
-  }
-  if (!host_written)
-    ctx->done_folded = 0;
+  TRY(enqueue_update(ctx, ctx->pose.as<float>(), n_p, d_w, extra ? ctx->extra.as<float>() : nullptr, d_lik, d_ratio, d_beam,
+                     d_stats, out_blk ? &ho : nullptr, &host_written));
   if (host_written)
   {
     for (int k = 0; k < 5; ++k)

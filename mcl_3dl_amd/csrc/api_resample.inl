@@ -131,31 +131,8 @@ int mcl3dl_hip_resample_begin_device(mcl3dl_hip_ctx* ctx, const float* d_weight,
   HIP_TRY(hipSetDevice(ctx->device));
   if (n_out == 0 || n_out > 0x7fffffffu)
     return ctx->fail(-3, "bad arguments to resample_begin_device");
-  if (ctx->resample_prefix_device)
-  {
-    // the recurrence on the device (one lane): nothing but two floats come back — unless a weight is zero, then the tie
-    // order is libstdc++'s std::sort's and the host path below takes over
-    TRY(ensure(ctx, ctx->rs_d_keys, sizeof(float) * n));
-    TRY(ensure(ctx, ctx->stats4, sizeof(float) * 4));
-    hipLaunchKernelGGL(resample_prefix_kernel, dim3(1), dim3(256), 0, ctx->stream, d_weight, static_cast<int>(n),
-                       ctx->rs_d_keys.as<float>(), ctx->stats4.as<float>());
-    HIP_TRY(hipGetLastError());
-    float out2[2] = { 0.f, 0.f };
-    TRY(d2h(ctx, out2, ctx->stats4.p, sizeof(out2)));
-    TRY(sync_stream(ctx));
-    if (out2[1] == 0.0f)
-    {
-      ctx->rs_sorted = false;
-      ctx->rs_n = n;
-      ctx->rs_n_out = n_out;
-      ctx->rs_pstep = out2[0] / n_out;  // pf.h:202 / 410 (float / size_t)
-      ctx->rs_planned = false;
-      if (out_pstep)
-        *out_pstep = ctx->rs_pstep;
-      return 0;
-    }
-  }
-  // the prefix sums are a float recurrence in particle order (pf.h:193-197): 4 bytes per particle come to the host
+  // the prefix sums are a float recurrence in particle order (pf.h:193-197): 4 bytes per particle come to the host (0.3 ms at
+  // 262 144 particles; one device lane running the recurrence took 3.9 ms — that form and its option went in round 6)
   std::vector<float> w(n);
   TRY(d2h(ctx, w.data(), d_weight, sizeof(float) * n));
   TRY(sync_stream(ctx));

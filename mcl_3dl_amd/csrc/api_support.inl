@@ -56,8 +56,8 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   const std::string key(name);
   if (key == "lik_index")
   {
-    if (value != 0.0 && value != 1.0 && value != 2.0)
-      return ctx->fail(-3, "lik_index must be 0 (27-cell scan), 1 (candidate runs) or 2 (candidate records)");
+    if (value != 0.0 && value != 2.0)
+      return ctx->fail(-3, "lik_index must be 0 (27-cell scan) or 2 (candidate records)");
     if ((value == 0.0) != (ctx->lik_index == 0) || static_cast<int>(value) != ctx->lik_index)
       ctx->cand_dirty = true;
     ctx->lik_index = static_cast<int>(value);
@@ -108,18 +108,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->strict_order = static_cast<int>(value);
     return 0;
   }
-  if (key == "overlap_min_rays")
-  {
-    if (!(value >= 0.0 && value <= 9.0e18))
-      return ctx->fail(-3, "overlap_min_rays must be >= 0");
-    ctx->overlap_min_rays = static_cast<long long>(value);
-    return 0;
-  }
-  if (key == "resample_prefix_device")
-  {
-    ctx->resample_prefix_device = value != 0.0;
-    return 0;
-  }
   if (key == "update_small")
   {
     ctx->update_small = value != 0.0;
@@ -133,11 +121,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   if (key == "update_zero_copy")
   {
     ctx->update_zero_copy = value != 0.0;
-    return 0;
-  }
-  if (key == "pf_tail")
-  {
-    ctx->pf_tail = value != 0.0;
     return 0;
   }
   if (key == "poll_sync")
@@ -169,30 +152,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->chain_ppl = static_cast<int>(value);
     return 0;
   }
-  if (key == "chain_multi_max")
-  {
-    if (!(value >= 0.0 && value <= 1e9))
-      return ctx->fail(-3, "chain_multi_max must be >= 0");
-    ctx->chain_multi_max = static_cast<int>(value);
-    return 0;
-  }
-  if (key == "update_fold_done")
-  {
-    ctx->fold_done_opt = value != 0.0;
-    return 0;
-  }
-  if (key == "poll_query_us")
-  {
-    if (!(value >= 100.0 && value <= 1e9))
-      return ctx->fail(-3, "poll_query_us must be >= 100");
-    ctx->poll_query_us = value;
-    return 0;
-  }
-  if (key == "strict_rows")
-  {
-    ctx->strict_rows = value != 0.0;
-    return 0;
-  }
   if (key == "dda_overlay")
   {
     ctx->dda_overlay = value != 0.0;
@@ -209,11 +168,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     if (value < 0.0 || value > 1.0e9)
       return ctx->fail(-3, "batch_slice must be a particle count (0 = automatic)");
     ctx->batch_slice = static_cast<int>(value);
-    return 0;
-  }
-  if (key == "update_particle")
-  {
-    ctx->update_particle = value != 0.0;
     return 0;
   }
   if (key == "update_small_conformant")
@@ -249,16 +203,14 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->strict_auto_min = static_cast<int>(value);
     return 0;
   }
-  if (key == "strict_skew")
+  if (key == "strict_exact_max")
   {
-    ctx->strict_skew = value != 0.0;
-    return 0;
-  }
-  if (key == "strict_gpw")
-  {
-    if (value != 0.0 && value != 1.0 && value != 2.0)
-      return ctx->fail(-3, "strict_gpw must be 0 (chosen per launch), 1 or 2");
-    ctx->strict_gpw = static_cast<int>(value);
+    // strict_order 2: scans of at most this many points are added up in the caller's order, as floats (0 = none)
+    if (!(value >= 0.0 && value <= 2147483647.0))
+      return ctx->fail(-3, "strict_exact_max must be a point count >= 0");
+    if (static_cast<int>(value) != ctx->strict_exact_max)
+      ++ctx->generation;
+    ctx->strict_exact_max = static_cast<int>(value);
     return 0;
   }
   if (key == "strict_auto_max_bytes")
@@ -314,24 +266,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->pf_fused = value != 0.0;
     return 0;
   }
-  if (key == "sort_full_pass")
-  {
-    ctx->sort_full_pass = value != 0.0;
-    return 0;
-  }
-  if (key == "sort_one_launch")
-  {
-    ctx->sort_one_launch = value != 0.0;
-    return 0;
-  }
-  if (key == "pf_fused_max")
-  {
-    if (!(value >= 1.0 && value <= static_cast<double>(PF_FUSED_MAX)))
-      return ctx->fail(-3, "pf_fused_max must be 1..%d", PF_FUSED_MAX);
-    ctx->pf_fused_max = static_cast<int>(value);
-    ++ctx->generation;
-    return 0;
-  }
   if (key == "lik_coop")
   {
     ctx->lik_coop = value != 0.0;
@@ -349,14 +283,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->lik_defer = static_cast<int>(value);
     return 0;
   }
-  if (key == "lik_defer_min_frac")
-  {
-    if (!(value >= 0.0 && value <= 1.0))
-      return ctx->fail(-3, "lik_defer_min_frac must be in [0, 1]");
-    ctx->lik_defer_min_frac = value;
-    ++ctx->generation;
-    return 0;
-  }
   if (key == "cand_bound")
   {
     if ((value != 0.0) != (ctx->cand_bound != 0))
@@ -364,25 +290,16 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->cand_bound = value != 0.0 ? 1 : 0;
     return 0;
   }
+  if (key == "beam_prepare")
+  {
+    ctx->beam_prepare = value != 0.0;
+    return 0;
+  }
   if (key == "cand_packed")
   {
     if ((value != 0.0) != (ctx->cand_packed != 0))
       ctx->cand_dirty = true;
     ctx->cand_packed = value != 0.0 ? 1 : 0;
-    return 0;
-  }
-  if (key == "beam_prepare")
-  {
-    ctx->beam_prepare = value != 0.0;
-    ++ctx->generation;
-    return 0;
-  }
-  if (key == "lik_wide_max_particles")
-  {
-    if (!(value >= 0.0 && value <= 2e9))
-      return ctx->fail(-3, "lik_wide_max_particles must be >= 0");
-    ctx->lik_wide_max_particles = static_cast<int>(value);
-    ++ctx->generation;
     return 0;
   }
   if (key == "grid_build_host")
@@ -408,17 +325,6 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
     ctx->cand_record_parts = static_cast<int>(value);
     return 0;
   }
-  if (key == "cand_refine" || key == "cand_refine_above")
-  {
-    const bool which = key == "cand_refine";
-    if (!(value >= (which ? 1.0 : 0.0) && value <= (which ? 4.0 : 32.0)))
-      return ctx->fail(-3, "cand_refine must be in [1, 4], cand_refine_above in [0, 32]");
-    int& field = which ? ctx->cand_refine : ctx->cand_refine_above;
-    if (static_cast<int>(value) != field)
-      ctx->cand_dirty = true;
-    field = static_cast<int>(value);
-    return 0;
-  }
   if (key == "cand_phase")
   {
     if (!(value >= 0.0 && value < 1.0))
@@ -431,93 +337,94 @@ int mcl3dl_hip_set_option(mcl3dl_hip_ctx* ctx, const char* name, double value)
   return ctx->fail(-3, "unknown option '%s'", name);
 }
 
+// Every option that can be set can be read back, next to the read-only diagnostics (what the index in place was built with, the
+// counters of the map path, build times): ONE table, name -> getter.
+namespace
+{
+struct OptionGetter
+{
+  const char* name;
+  double (*get)(const mcl3dl_hip_ctx*);
+};
+const OptionGetter kOptionGetters[] = {
+    { "lik_index", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_index; } },
+    { "cand_voxel_ratio", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_voxel_ratio; } },
+    { "cand_phase", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_phase; } },
+    { "cand_aniso", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_aniso; } },
+    { "index_budget_bytes", [](const mcl3dl_hip_ctx* c) -> double { return c->index_budget_opt; } },
+    { "index_budget_in_use", [](const mcl3dl_hip_ctx* c) -> double { return c->index_budget_bytes; } },
+    { "cand_aniso_active", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_aniso_active ? 1.0 : 0.0; } },
+    { "cand_edge_ratio_x", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_edge_ratio[0]; } },
+    { "cand_edge_ratio_y", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_edge_ratio[1]; } },
+    { "cand_edge_ratio_z", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_edge_ratio[2]; } },
+    { "index_record_bytes", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->footprint[6]); } },
+    { "index_note", [](const mcl3dl_hip_ctx* c) -> double { return c->index_note.empty() ? 0.0 : 1.0; } },
+    { "cand_record_parts", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_record_parts; } },
+    { "cand_record_parts_in_use", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_parts; } },
+    { "cand_voxels_over8", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_over8; } },
+    { "cand_ovf_compactions", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->cand_ovf_compactions); } },
+    { "cand_ovf_leaked", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_ovf_leaked; } },
+    { "strict_order", [](const mcl3dl_hip_ctx* c) -> double { return c->strict_order; } },
+    { "strict_auto_min", [](const mcl3dl_hip_ctx* c) -> double { return c->strict_auto_min; } },
+    { "strict_exact_max", [](const mcl3dl_hip_ctx* c) -> double { return c->strict_exact_max; } },
+    { "lik_exact", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_exact ? 1.0 : 0.0; } },
+    { "strict_chunk", [](const mcl3dl_hip_ctx* c) -> double { return c->strict_chunk; } },
+    { "scan_presorted", [](const mcl3dl_hip_ctx* c) -> double { return c->scan_presorted; } },
+    { "scan_chunk_in_use", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->scan_chunk); } },
+    { "lik_grid_merges", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->lik_grid_merges); } },
+    { "lik_grid_rebuilds", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->lik_grid_rebuilds); } },
+    { "strict_auto_max_bytes", [](const mcl3dl_hip_ctx* c) -> double { return c->strict_auto_max_bytes; } },
+    { "strict_auto_skipped", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->strict_auto_skipped); } },
+    { "update_small", [](const mcl3dl_hip_ctx* c) -> double { return c->update_small; } },
+    { "update_stage", [](const mcl3dl_hip_ctx* c) -> double { return c->update_stage; } },
+    { "update_zero_copy", [](const mcl3dl_hip_ctx* c) -> double { return c->update_zero_copy; } },
+    { "poll_sync", [](const mcl3dl_hip_ctx* c) -> double { return c->poll_sync; } },
+    { "poll_spin_us", [](const mcl3dl_hip_ctx* c) -> double { return c->poll_spin_us; } },
+    { "chain_ppl", [](const mcl3dl_hip_ctx* c) -> double { return c->chain_ppl; } },
+    { "batch_slice", [](const mcl3dl_hip_ctx* c) -> double { return c->batch_slice; } },
+    { "cand_prune_coop", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_prune_coop; } },
+    { "dda_overlay", [](const mcl3dl_hip_ctx* c) -> double { return c->dda_overlay; } },
+    { "dda_overlay_updates", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->dda_overlay_updates); } },
+    { "dda_overlay_points", [](const mcl3dl_hip_ctx* c) -> double { return c->dda_dirty ? 0.0 : static_cast<double>(c->dg.ov_n); } },
+    { "batch_slices_run", [](const mcl3dl_hip_ctx* c) -> double { return static_cast<double>(c->batch_slices_run); } },
+    { "update_small_max", [](const mcl3dl_hip_ctx* c) -> double { return c->update_small_max; } },
+    { "update_small_conformant", [](const mcl3dl_hip_ctx* c) -> double { return c->update_small_conformant; } },
+    { "timing_mask", [](const mcl3dl_hip_ctx* c) -> double { return c->timing_mask; } },
+    { "overlap_models", [](const mcl3dl_hip_ctx* c) -> double { return c->overlap_models; } },
+    { "lik_small", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_small; } },
+    { "lik_tiled", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_tiled; } },
+    { "lik_group", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_group; } },
+    { "lik_tiled_min", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_tiled_min; } },
+    { "lik_coop", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_coop; } },
+    { "lik_defer", [](const mcl3dl_hip_ctx* c) -> double { return c->lik_defer; } },
+    { "lik_defer_active", [](const mcl3dl_hip_ctx* c) -> double { return lik_defer_active(c) ? 1.0 : 0.0; } },
+    { "beam_prepare", [](const mcl3dl_hip_ctx* c) -> double { return c->beam_prepare; } },
+    { "cand_aniso_max", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_aniso_max; } },
+    { "cand_packed", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_packed; } },
+    { "cand_packed_active", [](const mcl3dl_hip_ctx* c) -> double { return c->rg.packed; } },
+    { "cand_bound", [](const mcl3dl_hip_ctx* c) -> double { return c->cand_bound; } },
+    { "cand_bound_active", [](const mcl3dl_hip_ctx* c) -> double { return c->rg.bound_step > 0.0f ? 1.0 : 0.0; } },
+    { "grid_build_host", [](const mcl3dl_hip_ctx* c) -> double { return c->grid_build_host; } },
+    { "lik_grid_build_ms", [](const mcl3dl_hip_ctx* c) -> double { return c->grid_build_ms[0]; } },
+    { "dda_grid_build_ms", [](const mcl3dl_hip_ctx* c) -> double { return c->grid_build_ms[1]; } },
+    { "lik_grid_build_wall_ms", [](const mcl3dl_hip_ctx* c) -> double { return c->grid_build_wall_ms[0]; } },
+    { "dda_grid_build_wall_ms", [](const mcl3dl_hip_ctx* c) -> double { return c->grid_build_wall_ms[1]; } },
+    { "pf_fused", [](const mcl3dl_hip_ctx* c) -> double { return c->pf_fused; } },
+    { "scan_order_device", [](const mcl3dl_hip_ctx* c) -> double { return c->scan_order_device; } },
+};
+}  // namespace
+
 int mcl3dl_hip_get_option(mcl3dl_hip_ctx* ctx, const char* name, double* value)
 {
   if (!ctx || !name || !value)
     return -1;
-  const std::string key(name);
-  if (key == "lik_index") *value = ctx->lik_index;
-  else if (key == "cand_voxel_ratio") *value = ctx->cand_voxel_ratio;
-  else if (key == "cand_phase") *value = ctx->cand_phase;
-  else if (key == "cand_aniso") *value = ctx->cand_aniso;
-  else if (key == "cand_aniso_max") *value = ctx->cand_aniso_max;
-  else if (key == "index_budget_bytes") *value = ctx->index_budget_opt;
-  else if (key == "index_budget_in_use") *value = ctx->index_budget_bytes;
-  else if (key == "cand_aniso_active") *value = ctx->cand_aniso_active ? 1.0 : 0.0;
-  else if (key == "cand_edge_ratio_x") *value = ctx->cand_edge_ratio[0];
-  else if (key == "cand_edge_ratio_y") *value = ctx->cand_edge_ratio[1];
-  else if (key == "cand_edge_ratio_z") *value = ctx->cand_edge_ratio[2];
-  else if (key == "index_record_bytes") *value = static_cast<double>(ctx->footprint[6]);
-  else if (key == "index_note") *value = ctx->index_note.empty() ? 0.0 : 1.0;
-  else if (key == "cand_record_parts") *value = ctx->cand_record_parts;
-  else if (key == "cand_record_parts_in_use") *value = ctx->cand_parts;
-  else if (key == "cand_voxels_over8") *value = ctx->cand_over8;
-  else if (key == "cand_ovf_compactions") *value = static_cast<double>(ctx->cand_ovf_compactions);
-  else if (key == "cand_ovf_leaked") *value = ctx->cand_ovf_leaked;
-  else if (key == "strict_order") *value = ctx->strict_order;
-  else if (key == "strict_auto_min") *value = ctx->strict_auto_min;
-  else if (key == "strict_chunk") *value = ctx->strict_chunk;
-  else if (key == "scan_presorted") *value = ctx->scan_presorted;
-  else if (key == "scan_chunk_in_use") *value = static_cast<double>(ctx->scan_chunk);
-  else if (key == "lik_grid_merges") *value = static_cast<double>(ctx->lik_grid_merges);
-  else if (key == "lik_grid_rebuilds") *value = static_cast<double>(ctx->lik_grid_rebuilds);
-  else if (key == "strict_gpw") *value = ctx->strict_gpw;
-  else if (key == "strict_skew") *value = ctx->strict_skew;
-  else if (key == "strict_auto_max_bytes") *value = ctx->strict_auto_max_bytes;
-  else if (key == "strict_auto_skipped") *value = static_cast<double>(ctx->strict_auto_skipped);
-  else if (key == "overlap_min_rays") *value = static_cast<double>(ctx->overlap_min_rays);
-  else if (key == "resample_prefix_device") *value = ctx->resample_prefix_device;
-  else if (key == "cand_refine") *value = ctx->cand_refine;
-  else if (key == "cand_refine_above") *value = ctx->cand_refine_above;
-  else if (key == "update_small") *value = ctx->update_small;
-  else if (key == "update_stage") *value = ctx->update_stage;
-  else if (key == "update_zero_copy") *value = ctx->update_zero_copy;
-  else if (key == "pf_tail") *value = ctx->pf_tail;
-  else if (key == "update_particle") *value = ctx->update_particle;
-  else if (key == "poll_sync") *value = ctx->poll_sync;
-  else if (key == "poll_spin_us") *value = ctx->poll_spin_us;
-  else if (key == "poll_query_us") *value = ctx->poll_query_us;
-  else if (key == "update_fold_done") *value = ctx->fold_done_opt ? 1.0 : 0.0;
-  else if (key == "chain_ppl") *value = ctx->chain_ppl;
-  else if (key == "chain_multi_max") *value = ctx->chain_multi_max;
-  else if (key == "batch_slice") *value = ctx->batch_slice;
-  else if (key == "cand_prune_coop") *value = ctx->cand_prune_coop;
-  else if (key == "dda_overlay") *value = ctx->dda_overlay;
-  else if (key == "strict_rows") *value = ctx->strict_rows;
-  else if (key == "dda_overlay_updates") *value = static_cast<double>(ctx->dda_overlay_updates);
-  else if (key == "dda_overlay_points") *value = ctx->dda_dirty ? 0.0 : static_cast<double>(ctx->dg.ov_n);
-  else if (key == "batch_slices_run") *value = static_cast<double>(ctx->batch_slices_run);
-  else if (key == "update_small_max") *value = ctx->update_small_max;
-  else if (key == "update_small_conformant") *value = ctx->update_small_conformant;
-  else if (key == "timing_mask") *value = ctx->timing_mask;
-  else if (key == "overlap_models") *value = ctx->overlap_models;
-  else if (key == "lik_small") *value = ctx->lik_small;
-  else if (key == "lik_tiled") *value = ctx->lik_tiled;
-  else if (key == "lik_group") *value = ctx->lik_group;
-  else if (key == "lik_tiled_min") *value = ctx->lik_tiled_min;
-  else if (key == "lik_coop") *value = ctx->lik_coop;
-  else if (key == "lik_defer") *value = ctx->lik_defer;
-  else if (key == "lik_defer_min_frac") *value = ctx->lik_defer_min_frac;
-  else if (key == "lik_defer_active") *value = lik_defer_active(ctx) ? 1.0 : 0.0;
-  else if (key == "cand_packed") *value = ctx->cand_packed;
-  else if (key == "cand_packed_active") *value = ctx->rg.packed;
-  else if (key == "cand_bound") *value = ctx->cand_bound;
-  else if (key == "cand_bound_active") *value = ctx->rg.bound_step > 0.0f ? 1.0 : 0.0;
-  else if (key == "beam_prepare") *value = ctx->beam_prepare;
-  else if (key == "lik_wide_max_particles") *value = ctx->lik_wide_max_particles;
-  else if (key == "grid_build_host") *value = ctx->grid_build_host;
-  else if (key == "lik_grid_build_ms") *value = ctx->grid_build_ms[0];
-  else if (key == "dda_grid_build_ms") *value = ctx->grid_build_ms[1];
-  else if (key == "lik_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[0];
-  else if (key == "dda_grid_build_wall_ms") *value = ctx->grid_build_wall_ms[1];
-  else if (key == "pf_fused") *value = ctx->pf_fused;
-  else if (key == "sort_full_pass") *value = ctx->sort_full_pass;
-  else if (key == "sort_one_launch") *value = ctx->sort_one_launch;
-  else if (key == "pf_fused_max") *value = ctx->pf_fused_max;
-  else if (key == "scan_order_device") *value = ctx->scan_order_device;
-  else
-    return ctx->fail(-3, "unknown option '%s'", name);
-  return 0;
+  for (const OptionGetter& g : kOptionGetters)
+    if (strcmp(g.name, name) == 0)
+    {
+      *value = g.get(ctx);
+      return 0;
+    }
+  return ctx->fail(-3, "unknown option '%s'", name);
 }
 
 // ---- page-locked host memory for the caller's arrays ---------------------------------------------------------------------

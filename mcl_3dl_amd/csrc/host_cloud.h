@@ -101,47 +101,6 @@ int radix_sort(mcl3dl_hip_ctx* ctx, const RsKeyGen& kg, long long n, int end_bit
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  // keys of at most 16 bits, up to 32 768 of them: ONE launch (sort_kernels.h:rs_sort16_kernel; every work-group reads ALL keys,
-  // so not when the result would land in the arrays the caller's keys are read from)
-  if (end_bit <= 16 && n <= RS16_MAX && ctx->sort_one_launch &&
-      !(KEYMODE == RS_KEY_ARRAY && (g.keys == key[1] || g.vals == val[1])))
-  {
-    const unsigned nb = static_cast<unsigned>((n + RS_THREADS - 1) / RS_THREADS);
-    if (fin)
-      hipLaunchKernelGGL((rs_sort16_kernel<KEYMODE, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, g, f, key[1], val[1], ni, mask);
-    else
-      hipLaunchKernelGGL((rs_sort16_kernel<KEYMODE, false>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, g, f, key[1], val[1], ni, mask);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  // (not when pass 0 would write the array set the caller's keys are read from: every work-group reads ALL keys in that pass)
-  const int first_dst = (n_pass & 1) ? 1 : 0;
-  const bool aliased = KEYMODE == RS_KEY_ARRAY && (g.keys == key[first_dst] || g.vals == val[first_dst]);
-  if (n <= RS_FULL_MAX && ctx->sort_full_pass && !aliased)
-  {
-    // one launch per pass: every work-group counts every work-group's digits itself (sort_kernels.h:rs_pass_full_kernel)
-    const unsigned nb = static_cast<unsigned>((n + RS_THREADS - 1) / RS_THREADS);
-    int cur = (n_pass & 1) ? 0 : 1;  // the pairs ping-pong; the LAST pass writes set 1
-    for (int p = 0; p < n_pass; ++p)
-    {
-      const bool apply = fin && p + 1 == n_pass;
-#define RS_LAUNCH_FULL(FIRST, AP)                                                                                            \
-  hipLaunchKernelGGL((rs_pass_full_kernel<KEYMODE, FIRST, AP>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, g, key[cur], val[cur], \
-                     key[cur ^ 1], val[cur ^ 1], f, ni, p, n_pass, mask)
-      if (p == 0 && apply)
-        RS_LAUNCH_FULL(true, true);
-      else if (p == 0)
-        RS_LAUNCH_FULL(true, false);
-      else if (apply)
-        RS_LAUNCH_FULL(false, true);
-      else
-        RS_LAUNCH_FULL(false, false);
-#undef RS_LAUNCH_FULL
-      cur ^= 1;
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
   if (n <= RS_MAX_ELEMS)
   {
     // 1024 elements per work-group up to 65 536 (every CU of a quarter of the chip ranks one round), 4096 above

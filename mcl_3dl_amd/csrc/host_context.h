@@ -92,7 +92,8 @@ struct mcl3dl_hip_ctx
   uint64_t lik_grid_merges = 0, lik_grid_rebuilds = 0;
   std::vector<float4> lik_upd_host;  // the update's rescaled points (host staging of the merge)
   LikGrid lg{};
-  // candidate-voxel index (map_compiler.h): lik_index 1 = use it for measure(), 0 = 27-cell scan of the cell grid
+  // lik_index 2 = the candidate-voxel records (map_compiler.h) serve measure(), 0 = 27-cell scan of the cell grid (the canonical
+  // structure of SURVEY.md 8d, also what STATS counts on)
   int lik_index = 2;
   int lik_small = 1;       // 1 = several particles share a wavefront when the scan has <= 32 points
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
@@ -120,9 +121,6 @@ struct mcl3dl_hip_ctx
   // the likelihoods the last launch_measure / one-launch update enqueued are the reference's floats bit for bit (caller-order
   // rows, replay, in-kernel chain): pf::measure on one GPU then adds the weights in the reference's float order as well
   bool lik_exact = false;
-  int strict_skew = 1;  // 1 = the particle groups' term regions staggered across HBM channels (lik_strict_sum_kernel), 0 = back to back (A/B)
-  int strict_rows = 1;  // 1 = float-order replay with the chunk row-major in LDS and a look-ahead adder, 0 = transposed chunk (A/B)
-  int strict_gpw = 0;  // 0 = particle groups per work-group of the float-order adder chosen per launch, 1 / 2 = at most that many (A/B)
   double strict_auto_max_bytes = 0.0;  // > 0: the automatic replay is also skipped when its buffer would exceed this many bytes
   uint64_t strict_auto_skipped = 0;  // launches of the automatic mode that summed in fp64 because the replay buffer did not fit
   DevBuf scan_block;  // { perm | lik scan | beam scan | origins } of the current update in ONE allocation (ensure_scan_block)
@@ -150,19 +148,11 @@ struct mcl3dl_hip_ctx
   // host-buffer updates (mcl3dl_hip_measure_update): update_stage = 1: the caller's scans / poses / weights are taken over by
   // ONE launch (stage_kernels.h:scan_stage_kernel — ordering included) for scans up to ST_MAX_POINTS points per model;
   // update_zero_copy = 1: that kernel reads them where they lie in page-locked host memory and the last kernel of the update
-  // writes the results there (no DMA copy either way), 0 = one H2D copy of the staged block, one D2H copy of the results;
-  // pf_tail = 1: pf::measure of up to 8192 particles on one GPU finished by pf_norm_kernel (pf_kernels.h: every work-group
-  // recomputes the reduction, no hand-off), the weights formed by the kernel in front of it — two launches behind the tiled
-  // likelihood kernel instead of four, two in all (update_particle = 1: likelihood + beam + weight per work-group) where the
-  // per-particle likelihood kernel runs (4096 x 96 + 3: two launches instead of seven). 0 = the split kernels (default:
-  // behind a long likelihood kernel the three pf launches are already queued and cost ~1.6 us each on the device, less than
-  // the redundant 1024-thread reduction — C2 host-buffer update 0.2884 with, 0.2833 ms without: profiles/r04e_time8d_C2.json).
-  // (Round 4's first form — ONE launch with an arrival ticket per work-group — measured slower than the split kernels at every
-  // size: profiles/r04a_time8d_*.json.)
+  // writes the results there (no DMA copy either way), 0 = one H2D copy of the staged block, one D2H copy of the results.
+  // (Rounds 4-5 also carried a two-launch tail — pf_norm_kernel, every work-group recomputing the reduction — and a
+  // per-particle-only form of the one-launch update; both measured slower than the split kernels and are gone: HISTORY.md.)
   int update_stage = 1;
   int update_zero_copy = 1;
-  int pf_tail = 0;
-  int update_particle = 0;
   // host-buffer updates end by POLLING a word in page-locked memory that a one-thread kernel behind the update's last kernel
   // writes, instead of hipStreamSynchronize: 6.3 against 12.2 us for launch + completion of one kernel on this part
   // (profiles/r04e_launch_cost.txt). 2 (default) = every synchronisation of the context's stream is that word (scan
@@ -190,11 +180,6 @@ struct mcl3dl_hip_ctx
   bool test_late_structures = false;  // fault injection for the API-sequence fuzz (option of the same name, test hooks only)
   volatile unsigned* done_flag = nullptr;
   unsigned done_seq = 0;
-  // the host-buffer update asks its last kernel to write the completion word itself (fold_done = true while it enqueues);
-  // done_folded = the sequence number such a kernel was given: the wait that follows launches no kernel of its own
-  bool fold_done = false;
-  bool fold_done_opt = false;  // option "update_fold_done" (measured slower than a kernel of its own: profiles/r05j_fold_ab.txt)
-  unsigned done_folded = 0;
   // strict_order = 3 (likelihood_kernels.h: LikChain): hand-off words, their tag counter, the page-locked error word
   DevBuf chain_carry, chain_lik;
   uint32_t chain_tag = 1;
@@ -212,7 +197,7 @@ struct mcl3dl_hip_ctx
   int cand_prune_coop = 1;  // option "cand_prune_coop": 16 lanes per voxel in the map compiler's pruning pass (0 = one thread)
   int batch_slice = 0;  // option "batch_slice": particles per slice of a progressive batch (0 = automatic)
   uint64_t batch_slices_run = 0;
-  DevBuf stage_in_dev, tail_ticket;
+  DevBuf stage_in_dev;
   // page-locked host memory handed out by mcl3dl_hip_host_alloc: arrays inside it are read / written in place
   struct PinnedBlock
   {
@@ -238,10 +223,6 @@ struct mcl3dl_hip_ctx
   double cand_need_bytes = 0.0;     // record bytes the last priced voxel edge needs
   double cand_edge_ratio[3] = { 0.5, 0.5, 0.5 };  // voxel edge / match_dist_min of the index in place, per axis
   int cand_record_parts = 0;      // inline candidates per voxel record: 4 (64 bytes), 8 (128 bytes), 0 = chosen per map
-  // sharper pruning of crowded voxels (map_compiler.h:mc_prune_boxed, pass 1b): voxels that keep more than
-  // cand_refine_above candidates have them tested per sub-box of a cand_refine^3 subdivision (1 = off)
-  int cand_refine = 1;
-  int cand_refine_above = 4;
   uint32_t cand_parts = 4;        // what the current index was built with
   int n_cus = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int cand_packed = 1;            // option: packed w words in the voxel records when the map allows it (map_compiler.h)
@@ -258,7 +239,6 @@ struct mcl3dl_hip_ctx
   uint32_t cand_n_bricks = 0, cand_n_ovf = 0, cand_ovf_leaked = 0;
   uint64_t cand_ovf_compactions = 0;  // times the orphaned overflow records were reclaimed in place (compact_overflow)
   size_t cand_n_points = 0;
-  CandGrid cg{};
   RecGrid rg{};
   // bricks, preliminary candidates, candidates kept, build ms, voxels with candidates, voxels with overflow, overflow
   // records, voxel edge / match_dist_min actually used
@@ -320,14 +300,8 @@ struct mcl3dl_hip_ctx
   uint32_t sp_kept32[2] = { 0, 0 };                 // their counts, delivered by one synchronisation
   size_t sp_n_full = 0, sp_n_clip[2] = { 0, 0 }, sp_n_samp[2] = { 0, 0 };
   bool sp_ready = false;
-  // arrays of 2049 .. 32 768 elements: 1 = one launch per radix pass, every work-group counting every work-group's digits itself
-  // (rs_pass_full_kernel). Measured and off: n LDS atomics per work-group on <= 256 addresses serialise — a 16 384-point scan took
-  // 55 us to stage against 43 us with the count + scatter launches (profiles/r04d_time8d_C2.json)
   int chain_ppl = 0;          // strict_order = 3: tiles per work-group (0 = by size, 1, 4: likelihood_chain_multi.h)
   int chain_multi_max = 1536; // ... the four-tile form up to this many particles (profiles/r05r_chain_multi.txt: slower from 2048)
-  int sort_full_pass = 0;
-  int sort_one_launch = 0;  // keys of <= 16 bits, 2049 .. 32 768 elements: rs_sort16_kernel (option "sort_one_launch"; measured
-                            // equal to the passes at 16 384 elements, slower at 32 768: profiles/r05p_sort16_one_launch.txt)
   int scan_order_device = 4096;  // scans of at least this many points (both models together) are ordered on the device; 0 = never
   size_t n_base = 0;  // points of the base map; anything behind them in map_xyz is the current map update
   DevBuf ms_xyz, ms_out, ms_flag[2];
@@ -348,7 +322,6 @@ struct mcl3dl_hip_ctx
   DevBuf rs_d_keys, rs_d_pscan, rs_d_it, rs_d_source, rs_d_slot, rs_d_noise, rs_d_in, rs_d_out, rs_d_order, rs_d_flag,
       rs_d_ws, rs_d_dup8;
   bool rs_sorted = false;  // std::sort had ties to order: rs_order is not the identity
-  int resample_prefix_device = 0;  // 1 = resample_begin_device runs the float prefix recurrence on the device (one lane)
 
   // counts everything that can change what an update enqueues (parameters, options, map, stream, scan sizes, reallocated
   // buffers); kept as a cheap change stamp for diagnostics
@@ -745,13 +718,6 @@ int wait_done_flag(mcl3dl_hip_ctx* ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
   }
-  if (ctx->done_folded != 0 && ctx->done_folded == ctx->done_seq)
-  {
-    // the last kernel on the stream writes the word behind its results (pf_kernels.h: pf_emit_done)
-    ctx->done_folded = 0;
-    return spin_done_flag(ctx, ctx->done_seq);
-  }
-  ctx->done_folded = 0;
   const unsigned seq = ++ctx->done_seq;
   hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->done_flag, seq);
   HIP_TRY(hipGetLastError());

@@ -362,8 +362,6 @@ int cand_geometry(mcl3dl_hip_ctx* ctx, double voxel_ratio, const double stretch[
   const double r_hi = r * (1.0 + 1e-5);
   cp.r2_hi = r_hi * r_hi;
   cp.margin = 1e-5 * r * r;
-  cp.refine = ctx->cand_refine;
-  cp.refine_above = ctx->cand_refine_above;
   int reach[3];
   for (int a = 0; a < 3; ++a)
     reach[a] = static_cast<int>(std::floor((r_hi + cp.grow) / ed[a])) + 1;
@@ -713,48 +711,7 @@ int build_cand_grid_at(mcl3dl_hip_ctx* ctx, double voxel_ratio, uint32_t cap = 4
     ctx->cand_dirty = false;
     return 0;
   }
-  TempBuf &d_count = co.d_count, &d_pstart = co.d_pstart, &d_prelim = co.d_prelim;
-  const unsigned blocks_v = static_cast<unsigned>((n_vox + 1 + 255) / 256);
-  TRY(ensure(ctx, ctx->cand_start, sizeof(uint32_t) * (n_vox + 1)));
-  TRY(ensure(ctx, ctx->cand_pts, sizeof(float4) * (kept ? kept : 1)));
-  HIP_TRY(hipMemsetAsync(static_cast<uint32_t*>(d_count.p) + n_vox, 0, sizeof(uint32_t), ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->cand_start.p, d_count.p, sizeof(uint32_t) * (n_vox + 1), hipMemcpyDeviceToDevice,
-                         ctx->stream));
-  TRY(device_exclusive_scan(ctx, ctx->cand_start.as<uint32_t>(), n_vox + 1));
-  hipLaunchKernelGGL(mc_write_final, dim3(blocks_v), dim3(256), 0, ctx->stream, pts,
-                     static_cast<const uint32_t*>(d_pstart.p), static_cast<const uint32_t*>(d_prelim.p),
-                     ctx->cand_start.as<uint32_t>(), ctx->cand_pts.as<float4>(), n_vox);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev1, ctx->stream));
-  TRY(sync_stream(ctx));
-  float ms = 0.f;
-  HIP_TRY(hipEventSynchronize(ev1));
-  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  CandGrid& g = ctx->cg;
-  g.brick_table = table;
-  g.vox_start = ctx->cand_start.as<uint32_t>();
-  g.cand = ctx->cand_pts.as<float4>();
-  g.ox = cp.ox;
-  g.oy = cp.oy;
-  g.oz = cp.oz;
-  g.inv_ex = cp.inv_ex;
-  g.inv_ey = cp.inv_ey;
-  g.inv_ez = cp.inv_ez;
-  g.nvx = cp.nvx;
-  g.nvy = cp.nvy;
-  g.nvz = cp.nvz;
-  g.nbx = cp.nbx;
-  g.nby = cp.nby;
-  g.nbz = cp.nbz;
-  ctx->footprint[5] = sizeof(int) * n_table;
-  ctx->footprint[6] = sizeof(uint32_t) * (n_vox + 1);
-  ctx->footprint[7] = sizeof(float4) * kept;
-  ctx->cand_stats[0] = n_bricks;
-  ctx->cand_stats[1] = static_cast<double>(total);
-  ctx->cand_stats[2] = static_cast<double>(kept);
-  ctx->cand_stats[3] = ms;
-  ctx->cand_dirty = false;
-  return 0;
+  return ctx->fail(-3, "the candidate index is built for lik_index = 2 only");
 }
 
 // The voxel edge: option "cand_voxel_ratio" x match_dist_min, or — ratio 0, the default — chosen from the map itself: r / 2

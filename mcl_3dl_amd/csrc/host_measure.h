@@ -373,7 +373,7 @@ int plan_lik(mcl3dl_hip_ctx* ctx, size_t n_p, int ns, LikPlan* pl)
   return 0;
 }
 
-// lik_strict_sum_kernel with as many particle groups per work-group as keep the launch in ONE round of work-groups, up to a
+// lik_strict_sum_rows_kernel with as many particle groups per work-group as keep the launch in ONE round of work-groups, up to a
 // full adder wavefront (64 lanes / GG particles per group)
 template <int GG>
 void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, int np, int n_groups, float* d_lik,
@@ -384,21 +384,10 @@ void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, i
   constexpr int MAX_GPW = 64 / GG >= 4 ? 4 : (64 / GG >= 2 ? 2 : 1);
   int gpw = n_groups <= ctx->n_cus ? 1 : (n_groups <= 2 * ctx->n_cus ? 2 : 4);
   gpw = std::min(gpw, MAX_GPW);
-  if (ctx->strict_gpw)
-    gpw = std::min(gpw, ctx->strict_gpw);
-  const int skew = ctx->strict_skew ? STRICT_SKEW4 : 0;
-  // strict_rows = 1 (default): the chunk stays row-major in LDS and the adder reads sixteen rows ahead (lik_strict_sum_rows_kernel);
-  // 0 = the transposed form of round 3 (A/B, same bits)
-#define LAUNCH_STRICT(CHUNK, GPW, GRID)                                                                                  \
-  do                                                                                                                     \
-  {                                                                                                                      \
-    if (ctx->strict_rows)                                                                                                \
-      hipLaunchKernelGGL((lik_strict_sum_rows_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, on, strict_terms, ns, \
-                         np, n_groups, d_lik, skew, accumulate);                                                         \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((lik_strict_sum_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, on, strict_terms, ns, np, \
-                         n_groups, d_lik, skew, accumulate);                                                             \
-  } while (0)
+  const int skew = STRICT_SKEW4;
+#define LAUNCH_STRICT(CHUNK, GPW, GRID)                                                                               \
+  hipLaunchKernelGGL((lik_strict_sum_rows_kernel<GG, CHUNK, GPW>), dim3(GRID), dim3(1024), 0, on, strict_terms, ns, np, \
+                     n_groups, d_lik, skew, accumulate)
   if constexpr (MAX_GPW >= 4)
     if (gpw == 4)
     {
@@ -415,18 +404,8 @@ void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, i
 #undef LAUNCH_STRICT
 }
 
-// What launch_measure leaves to launch_pf_tail when the caller asks for it (`want`): the sum over the tiled kernel's per-tile
-// partials (lik_partials: d_lik / d_ratio are NOT written by launch_measure then) and the beam score of an update without
-// beam points (beam_fill: d_beam is not written).
-struct MeasureTail
-{
-  bool want = false;
-  bool lik_partials = false, beam_fill = false;
-  int n_tiles = 0;
-};
-
 int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
-                   bool stats, double* stats6, MeasureTail* tail = nullptr)
+                   bool stats, double* stats6)
 {
   if (!ctx->has_scan)
     return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
@@ -467,12 +446,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     {
       // (1, 0) for every particle; with the tiled likelihood kernel behind it the per-particle finalize writes the ones
       beam_ones_by_finalize = !stats && d_beam && want_lik && ctx->n_s > 0 && plan.tiled;
-      if (tail && tail->want && !stats && d_beam)
-      {
-        tail->beam_fill = true;
-        beam_ones_by_finalize = false;
-      }
-      else if (!stats && !beam_ones_by_finalize)
+      if (!stats && !beam_ones_by_finalize)
         hipLaunchKernelGGL(fill_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d_beam, 1.0f,
                            static_cast<float*>(nullptr), 0.0f, np);
     }
@@ -568,7 +542,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (stats)
       {
         hipLaunchKernelGGL((likelihood_kernel<256, 0, true>), dim3(np), dim3(256), 0, ctx->stream, d_pose,
-                           ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->cg, ctx->rg, lp, nullptr, nullptr,
+                           ctx->scan_lik.as<float4>(), ns, ctx->lg, ctx->rg, lp, nullptr, nullptr,
                            ctx->tested.as<double>(), 0);
       }
       else
@@ -590,7 +564,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const long long blocks = plan.blocks;
 #define LAUNCH_SMALL(WW, MODE)                                                                                         \
   hipLaunchKernelGGL((likelihood_small_kernel<WW, MODE>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,           \
-                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, coop_arg, row_perm)
+                     ctx->stream, d_pose, np, scan, ns, ctx->lg, ctx->rg, lp, d_lik, d_ratio, coop_arg, row_perm)
 #define LAUNCH_SMALL_W(MODE)       \
   switch (W)                       \
   {                                \
@@ -604,10 +578,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           if (ctx->lik_index == 2)
           {
             LAUNCH_SMALL_W(2)
-          }
-          else if (ctx->lik_index == 1)
-          {
-            LAUNCH_SMALL_W(1)
           }
           else
           {
@@ -623,8 +593,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const long long blocks = plan.blocks;
 #define LAUNCH_TILED(GG, MODE, WW, CC, DD)                                                                             \
   hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, WW, CC, DD>), dim3(static_cast<unsigned>(t_blocks)), dim3(256), 0, \
-                     ctx->stream, d_pose, np, t_scan, t_ns, t_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp, t_psum, t_pcnt, \
-                     t_perm, t_terms, ctx->strict_skew ? STRICT_SKEW4 : 0)
+                     ctx->stream, d_pose, np, t_scan, t_ns, t_tiles, n_groups, ctx->lg, ctx->rg, lp, t_psum, t_pcnt, \
+                     t_perm, t_terms, STRICT_SKEW4)
           const bool coop = coop_arg != 0;
           const bool defer = coop && lik_defer_active(ctx);
           if (plan.chain)
@@ -646,7 +616,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             {
 #define LAUNCH_CHAIN(GG, MODE, CC, DD)                                                                                  \
   hipLaunchKernelGGL((likelihood_tiled_kernel<GG, MODE, 8, CC, DD, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
-                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->cg, ctx->rg, lp,              \
+                     ctx->stream, d_pose, np, scan, ns, n_tiles, n_groups, ctx->lg, ctx->rg, lp,              \
                      static_cast<double*>(nullptr), static_cast<unsigned*>(nullptr),                                   \
                      static_cast<const uint32_t*>(nullptr), static_cast<float*>(nullptr), 0, lc)
 #define LAUNCH_CHAIN_G(GG)              \
@@ -658,8 +628,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       LAUNCH_CHAIN(GG, 2, true, false); \
     else if (ctx->lik_index == 2)       \
       LAUNCH_CHAIN(GG, 2, false, false);\
-    else if (ctx->lik_index == 1)       \
-      LAUNCH_CHAIN(GG, 1, false, false);\
     else                                \
       LAUNCH_CHAIN(GG, 0, false, false);\
   } while (0)
@@ -690,8 +658,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       LAUNCH_TILED(GG, 2, WW, true, false);  \
     else if (ctx->lik_index == 2)      \
       LAUNCH_TILED(GG, 2, WW, false, false); \
-    else if (ctx->lik_index == 1)      \
-      LAUNCH_TILED(GG, 1, WW, false, false); \
     else                               \
       LAUNCH_TILED(GG, 0, WW, false, false); \
   } while (0)
@@ -783,13 +749,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           {
           // (a chunk-ordered scan whose likelihoods nobody asked for: its permutation is chunk-relative, no terms are kept)
           launch_tiled(scan, ns, n_tiles, psum, pcnt, ctx->scan_perm.as<uint32_t>(), plan.chunk ? nullptr : strict_terms);
-          if (tail && tail->want && !strict_terms && d_lik && d_ratio)
-          {
-            tail->lik_partials = true;  // launch_pf_tail adds the tiles up (lik_finalize_kernel with the weights folded in)
-            tail->n_tiles = n_tiles;
-          }
-          else
-            hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, psum, pcnt, n_tiles, np, ns,
+          hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, psum, pcnt, n_tiles, np, ns,
                                d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
           if (strict_terms && d_lik && !plan.chunk)
             launch_replay(strict_terms, ns, ctx->stream, 0);
@@ -802,7 +762,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         {
 #define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
   hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), row_bytes, ctx->stream, d_pose, scan, ns, \
-                     ctx->lg, ctx->cg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg, row_perm)
+                     ctx->lg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg, row_perm)
         if (ctx->lik_index == 2)
         {
           if (ns <= 128)
@@ -811,13 +771,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             LAUNCH_LIK(1024, 2);  // few particles: 16 wavefronts share a scan — a quarter of the dependent load chains per lane
           else
             LAUNCH_LIK(256, 2);
-        }
-        else if (ctx->lik_index == 1)
-        {
-          if (ns <= 128)
-            LAUNCH_LIK(64, 1);
-          else
-            LAUNCH_LIK(256, 1);
         }
         else
         {
@@ -865,41 +818,26 @@ int pf_blocks(size_t n)
 
 
 // Does pf::measure on ONE GPU add the un-normalised weights as the reference does (pf.h:255-260: float, sequentially, particle
-// order) instead of the fp64 tree? strict_order 1: always. The default (2): whenever the likelihoods in front of it are the
-// reference's bits (ctx->lik_exact) — the whole update is then bit-identical — as long as pf::measure is ONE work-group
-// (pf_fused_kernel: up to pf_fused_max = 1024 particles; the one-launch update does the same up to update_small_max). Beyond
-// that the recurrence needs a launch of its own (pf_strict_sum_kernel: +10 us at 4096 particles, a third of a 4096 x 96
-// update, profiles/r06d_rows_vs_replay.txt) for weights that agree to ~1e-7 anyway: strict_order 1 only.
+// order; float_chain.h) instead of the fp64 tree? strict_order 1: always. The default (2): up to pf_fused_max = 1024 particles —
+// the reference's operating range; pf::measure is then the reference's arithmetic bit for bit given its inputs, inside the
+// fused kernel / the one-launch update at no extra launch. Beyond that the recurrence needs a launch of its own
+// (pf_strict_sum_kernel: +10 us at 4096 particles, a third of a 4096 x 96 update, profiles/r06d_rows_vs_replay.txt) for weights
+// that agree to ~1e-7 anyway. Independent of pf_fused, so that the fused and the split form give the same bits.
 bool pf_float_order(const mcl3dl_hip_ctx* ctx, size_t n_p)
 {
-  return ctx->strict_order == 1 ||
-         (ctx->strict_order == 2 && ctx->lik_exact && ctx->pf_fused &&
-          n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)));
-}
-
-// is pf::measure of n_p particles on this GPU finished by pf_norm_kernel (weights formed by the kernel in front of it)?
-bool pf_tail_eligible(const mcl3dl_hip_ctx* ctx, size_t n_p)
-{
-  return ctx->pf_tail && ctx->strict_order != 1 && n_p >= 1 && n_p <= static_cast<size_t>(PF_NORM_MAX);
+  return ctx->strict_order == 1 || (ctx->strict_order == 2 && n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)));
 }
 
 // The whole update — both models and pf::measure — as ONE launch (update_kernels.h) where the sizes are launch-bound:
 // returns 1 when it was enqueued, 0 when this update is not eligible (the caller then runs the separate kernels), < 0 on
 // error. Eligible: one GPU, per-particle likelihood kernel (not the tiled / small-scan forms), at most update_small_max
-// particles and 256 beam points, no float-order replay.
-// Returns 2 when only the per-particle half ran (more than update_small_max particles, pf_tail on): likelihood, beam score
-// and ctx->wnew are enqueued, the caller finishes with launch_pf_norm.
+// particles and 256 beam points.
 int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,
                         float* d_lik, float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho = nullptr)
 {
   if (!ctx->update_small || n_p == 0 || ctx->n_b > 256 || ctx->strict_order == 3 || !ctx->has_scan || !d_lik || !d_ratio || !d_beam)
     return 0;
-  const bool tickets = n_p <= static_cast<size_t>(ctx->update_small_max);
-  if (!tickets && ctx->strict_order == 1)
-    return 0;  // (the per-particle half leaves pf::measure to pf_norm_kernel's fp64 tree)
-  // (above update_small_max only with a handful of beam points — the reference's default is 3: a work-group per particle
-  // walks its rays with mostly idle wavefronts, the flat beam kernel packs the rays of all particles)
-  if (!tickets && !(pf_tail_eligible(ctx, n_p) && ctx->update_particle && ctx->n_b <= 32))
+  if (n_p > static_cast<size_t>(ctx->update_small_max))
     return 0;
   const int ns = static_cast<int>(ctx->n_s);
   if (ns > 0)
@@ -921,7 +859,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * static_cast<size_t>(nvb)));
   TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
   const size_t n_tickets = static_cast<size_t>(nvb) * 37 + static_cast<size_t>(ticket_tree_size(nvb)) + 1;
-  if (tickets && ctx->us_tickets.cap < sizeof(unsigned) * n_tickets)
+  if (ctx->us_tickets.cap < sizeof(unsigned) * n_tickets)
   {
     TRY(ensure(ctx, ctx->us_tickets, sizeof(unsigned) * n_tickets));
     // (a kernel, not hipMemsetAsync: see launch_measure — a memset node in a captured update faulted on replay)
@@ -936,7 +874,6 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.scan_lik = ctx->scan_lik.as<float4>();
   a.n_s = ns;
   a.g = ctx->lg;
-  a.cg = ctx->cg;
   a.rg = ctx->rg;
   a.prm = lik_params(ctx);
   a.coop = (ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f) ? 1 : 0;
@@ -958,11 +895,11 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   a.packed = ctx->partial4.as<double>();
   a.stats4 = d_stats4;
   a.conformant = ctx->update_small_conformant;
-  a.emit = (ho && tickets) ? *ho : PfEmit{};  // (the particle-only form leaves the host copies to pf_norm_kernel)
+  a.emit = ho ? *ho : PfEmit{};
   // the reference's float recurrences, in its own order: the likelihood terms over the caller's scan (lik_particle's row) and —
   // where this launch also finishes pf::measure — the weights over the particles (pf.h:255-260)
   const bool rows = ns > 0 && lik_mode(ctx, static_cast<int>(n_p), ns).rows;
-  const bool float_w = tickets && (ctx->strict_order == 1 || (ctx->strict_order == 2 && (rows || ns == 0)));
+  const bool float_w = pf_float_order(ctx, n_p);
   a.perm = rows ? ctx->scan_perm.as<uint32_t>() : nullptr;
   a.float_order_w = float_w ? 1 : 0;
   ctx->lik_exact = rows || ns == 0;
@@ -971,14 +908,8 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
   EventPair ep{};
   TRY(timing_begin(ctx, MCL3DL_KERNEL_UPDATE, &ep));
   const unsigned grid = static_cast<unsigned>(n_p);
-#define LAUNCH_US(BLOCK, MODE)                                                                                      \
-  do                                                                                                                \
-  {                                                                                                                 \
-    if (tickets)                                                                                                    \
-      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, true>), dim3(grid), dim3(BLOCK), row_bytes, ctx->stream, a);     \
-    else                                                                                                            \
-      hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE, false>), dim3(grid), dim3(BLOCK), row_bytes, ctx->stream, a);    \
-  } while (0)
+#define LAUNCH_US(BLOCK, MODE) \
+  hipLaunchKernelGGL((update_small_kernel<BLOCK, MODE>), dim3(grid), dim3(BLOCK), row_bytes, ctx->stream, a)
   // the work-group size the separate likelihood kernel would get (launch_measure), so that the lanes add in the same order
   const bool narrow = ns <= 128 && ctx->n_b <= 128;
   if (ctx->lik_index == 2)
@@ -989,13 +920,6 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
       LAUNCH_US(1024, 2);
     else
       LAUNCH_US(256, 2);
-  }
-  else if (ctx->lik_index == 1)
-  {
-    if (ns <= 128)
-      LAUNCH_US(64, 1);
-    else
-      LAUNCH_US(256, 1);
   }
   else
   {
@@ -1008,41 +932,7 @@ int launch_update_small(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, fl
 #undef LAUNCH_US
   TRY(timing_end(ctx, ep));
   HIP_TRY(hipGetLastError());
-  return tickets ? 1 : 2;
+  return 1;
 }
 
-// pf_norm_kernel over ctx->wnew (filled by lik_finalize_kernel / pf_weights_kernel / update_particle_kernel)
-int launch_pf_norm(mcl3dl_hip_ctx* ctx, size_t n_p, float* d_weight, const float* d_lik, const float* d_ratio,
-                   const float* d_beam, float* d_stats4, const PfEmit* ho)
-{
-  TRY(ensure(ctx, ctx->partial4, sizeof(double) * 4));
-  EventPair ep{};
-  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-  hipLaunchKernelGGL(pf_norm_kernel, dim3(pf_blocks(n_p)), dim3(1024), 0, ctx->stream, d_weight, ctx->wnew.as<float>(), d_ratio,
-                     static_cast<int>(n_p), ctx->partial4.as<double>(), d_stats4, ho ? *ho : PfEmit{}, d_lik, d_beam);
-  TRY(timing_end(ctx, ep));
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// The weights behind launch_measure(&mt): folded into lik_finalize_kernel where the tiled kernel left per-tile partials,
-// a launch of their own otherwise; then pf_norm_kernel.
-int launch_pf_tail(mcl3dl_hip_ctx* ctx, const MeasureTail& mt, size_t n_p, float* d_weight, const float* d_extra, float* d_lik,
-                   float* d_ratio, float* d_beam, float* d_stats4, const PfEmit* ho)
-{
-  const int np = static_cast<int>(n_p);
-  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
-  EventPair ep{};
-  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
-  if (mt.lik_partials)
-    hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, ctx->lik_partial_sum.as<double>(),
-                       ctx->lik_partial_cnt.as<unsigned>(), mt.n_tiles, np, static_cast<int>(ctx->n_s), d_lik, d_ratio,
-                       mt.beam_fill ? d_beam : static_cast<float*>(nullptr), d_weight, d_beam, d_extra, ctx->wnew.as<float>());
-  else
-    hipLaunchKernelGGL(pf_weights_kernel, dim3(pf_blocks(n_p)), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra,
-                       np, ctx->wnew.as<float>(), mt.beam_fill ? d_beam : static_cast<float*>(nullptr));
-  TRY(timing_end(ctx, ep));
-  HIP_TRY(hipGetLastError());
-  return launch_pf_norm(ctx, n_p, d_weight, d_lik, d_ratio, d_beam, d_stats4, ho);
-}
 }  // namespace

@@ -56,38 +56,6 @@ __device__ inline float nearest_d2(const LikGrid& g, float qx, float qy, float q
   return best;
 }
 
-// Same query against the candidate-voxel index (map_compiler.h): the voxel of q holds every map point that can be the
-// nearest neighbour within r of a query inside it, so min d2 over that run == min d2 over the whole map.
-template <bool STATS>
-__device__ inline float nearest_d2_cand(const CandGrid& g, float qx, float qy, float qz, unsigned& n_tested)
-{
-  const float fx = floorf((qx - g.ox) * g.inv_ex);
-  const float fy = floorf((qy - g.oy) * g.inv_ey);
-  const float fz = floorf((qz - g.oz) * g.inv_ez);
-  float best = 3.0e38f;
-  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= static_cast<float>(g.nvx - 1) &&
-        fy <= static_cast<float>(g.nvy - 1) && fz <= static_cast<float>(g.nvz - 1)))
-    return best;
-  const int vx = static_cast<int>(fx), vy = static_cast<int>(fy), vz = static_cast<int>(fz);
-  const int b = g.brick_table[(static_cast<size_t>(vz >> 3) * g.nby + (vy >> 3)) * g.nbx + (vx >> 3)];
-  if (b < 0)
-    return best;
-  const size_t v = static_cast<size_t>(b) * 512 + (((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7));
-  const uint32_t s = g.vox_start[v], e = g.vox_start[v + 1];
-  for (uint32_t k = s; k < e; ++k)
-  {
-    const float4 p = g.cand[k];
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-    float d2 = dx * dx;
-    d2 = d2 + dy * dy;
-    d2 = d2 + dz * dz;
-    best = d2 < best ? d2 : best;
-    if (STATS)
-      ++n_tested;
-  }
-  return best;
-}
-
 // flann::L2_Simple<float>: ((0 + dx*dx) + dy*dy) + dz*dz, float, no contraction
 __device__ inline float d2_simple(float qx, float qy, float qz, float px, float py, float pz)
 {
@@ -544,7 +512,7 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
 // update (update_kernels.h), which therefore produce the same bits.
 template <int BLOCK, int MODE, bool STATS>
 __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, const float4* __restrict__ scan, int n_s,
-                                             const LikGrid& g, const CandGrid& cg, const RecGrid& rg, const LikParams& prm,
+                                             const LikGrid& g, const RecGrid& rg, const LikParams& prm,
                                              int coop, double& sum_out, unsigned& num_out, unsigned& tested_out,
                                              const uint32_t* __restrict__ perm = nullptr, float* s_row = nullptr)
 {
@@ -595,7 +563,6 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
       qz = t.z * prm.wz;
     }
     const float d2 = MODE == 0 ? nearest_d2<STATS>(g, qx, qy, qz, tested) :
-                     MODE == 1 ? nearest_d2_cand<STATS>(cg, qx, qy, qz, tested) :
                                  nearest_d2_rec<STATS>(rg, qx, qy, qz, tested);
     float term = 0.0f;
     if (d2 < prm.r2)  // radiusSearch found a neighbour (strict <)
@@ -653,14 +620,15 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
 }
 
 // MODE 0: 27-cell scan of the cell-sorted map (canonical structure of SURVEY.md §8d; also the STATS/K-bar counter)
-// MODE 1: candidate-voxel index
+// MODE 2: candidate-voxel records (map_compiler.h). (MODE 1, candidate RUNS behind a CSR, lost every A/B from round 2 on and
+// went in round 6.)
 // (the caller-order term row of lik_particle / the one-launch update: dynamic LDS, sized by the launch)
 extern __shared__ __attribute__((aligned(16))) float dyn_row[];
 
 template <int BLOCK, int MODE, bool STATS>
 __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
                                                            const float4* __restrict__ scan, int n_s, LikGrid g,
-                                                           CandGrid cg, RecGrid rg, LikParams prm,
+                                                           RecGrid rg, LikParams prm,
                                                            float* __restrict__ out_lik,
                                                            float* __restrict__ out_ratio,
                                                            double* __restrict__ out_tested, int coop,
@@ -672,7 +640,7 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
   const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
   double a = 0.0;
   unsigned n = 0, tt = 0;
-  lik_particle<BLOCK, MODE, STATS>(pos, rot, scan, n_s, g, cg, rg, prm, coop, a, n, tt, perm, perm ? dyn_row : nullptr);
+  lik_particle<BLOCK, MODE, STATS>(pos, rot, scan, n_s, g, rg, prm, coop, a, n, tt, perm, perm ? dyn_row : nullptr);
   if (threadIdx.x == 0)
   {
     if (out_lik)
@@ -700,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
 template <int W, int MODE>
 __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, LikGrid g,
-                                                               CandGrid cg, RecGrid rg, LikParams prm,
+                                                               RecGrid rg, LikParams prm,
                                                                float* __restrict__ out_lik, float* __restrict__ out_ratio,
                                                                int coop, const uint32_t* __restrict__ perm = nullptr)
 {
@@ -737,7 +705,6 @@ __global__ __launch_bounds__(256) void likelihood_small_kernel(const float* __re
     }
     unsigned dummy = 0;
     const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
-                     MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
                                  nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
     if (d2 < prm.r2)
     {
@@ -939,7 +906,7 @@ __device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, cons
 template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false, bool CHAIN = false>
 __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
                                                                const float4* __restrict__ scan, int n_s, int n_tiles,
-                                                               int n_groups, LikGrid g, CandGrid cg, RecGrid rg,
+                                                               int n_groups, LikGrid g, RecGrid rg,
                                                                LikParams prm, double* __restrict__ partial_sum,
                                                                unsigned* __restrict__ partial_cnt,
                                                                const uint32_t* __restrict__ scan_perm,
@@ -947,7 +914,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
                                                                LikChain ch = LikChain{})
 {
   // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
-  // [particle group][original scan index][G] so that lik_strict_sum_kernel can add them in the reference's own order.
+  // [particle group][original scan index][G] so that lik_strict_sum_rows_kernel can add them in the reference's own order.
   // (CHAIN: rows padded to 260 floats — the chain's lanes read DIFFERENT rows at the same column, 16 bytes at a time: with a
   // row length of 256 they would all hit the same LDS banks)
   constexpr int TERM_LD = CHAIN ? 260 : 256;
@@ -1101,7 +1068,6 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
       const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
       unsigned dummy = 0;
       const float d2 = MODE == 0 ? nearest_d2<false>(g, qx, qy, qz, dummy) :
-                       MODE == 1 ? nearest_d2_cand<false>(cg, qx, qy, qz, dummy) :
                                    nearest_d2_rec<false>(rg, qx, qy, qz, dummy);
       if (d2 < prm.r2)
       {
@@ -1185,7 +1151,7 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   {
     // rows of G floats, [group][original scan index][G]: G / 4 lanes write one row as float4s (one 16..128-byte run)
     constexpr int Q = G / 4;
-    // (group regions are strict_skew4 float4s further apart than their n_s rows: see lik_strict_sum_kernel)
+    // (group regions are strict_skew4 float4s further apart than their n_s rows: see lik_strict_sum_rows_kernel)
     float4* rows = reinterpret_cast<float4*>(strict_terms) + static_cast<size_t>(group) * (static_cast<size_t>(n_s) * Q + strict_skew4);
 #pragma unroll
     for (int j = 0; j < Q; ++j)
@@ -1226,17 +1192,10 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
 // (independent loads, 1/8 of the dependent chain), then lane-slice 0 adds the 8 sub-sums in fixed order (deterministic).
 // also_fill (may be null): an array of n_p floats set to 1 on the way — the beam score of an update without beam points
 // (beam.cpp:130-133), which would otherwise cost a launch of its own.
-// w_new (may be null): the particle's un-normalised weight w * (((1 * beam) * lik) * extra) formed on the way (pf.h:258 with
-// the lambda's product, src/mcl_3dl.cpp:407-424) — pf_kernels.h:pf_norm_kernel then needs no pf_partial launch. beam_in is
-// read for it unless also_fill is set (the beam score of this update is 1); has_beam = pf_partial_kernel's `beam` non-null.
 __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restrict__ partial_sum,
                                                            const unsigned* __restrict__ partial_cnt, int n_tiles, int n_p,
                                                            int n_s, float* __restrict__ out_lik,
-                                                           float* __restrict__ out_ratio, float* __restrict__ also_fill,
-                                                           const float* __restrict__ w = nullptr,
-                                                           const float* __restrict__ beam_in = nullptr,
-                                                           const float* __restrict__ extra = nullptr,
-                                                           float* __restrict__ w_new = nullptr)
+                                                           float* __restrict__ out_ratio, float* __restrict__ also_fill)
 {
   __shared__ double s_a[8][32];
   __shared__ unsigned s_n[8][32];
@@ -1263,24 +1222,12 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
     a += s_a[k][pl];
     n += s_n[k][pl];
   }
-  const float lik = static_cast<float>(a);
   if (out_lik)
-    out_lik[p] = lik;
+    out_lik[p] = static_cast<float>(a);
   if (out_ratio)
     out_ratio[p] = static_cast<float>(n) / static_cast<float>(n_s);
   if (also_fill)
     also_fill[p] = 1.0f;
-  if (w_new)
-  {
-    const bool has_beam = also_fill != nullptr || beam_in != nullptr;
-    float l = 1.0f;
-    if (has_beam)
-      l *= also_fill ? 1.0f : beam_in[p];
-    l *= lik;
-    if (extra)
-      l = l * extra[p];
-    w_new[p] = w[p] * l;
-  }
 }
 
 // "strict_order": score_like += dist * match_weight in the reference's own order (likelihood.cpp:120-134): float adds,
@@ -1307,125 +1254,9 @@ __global__ __launch_bounds__(256) void lik_finalize_kernel(const double* __restr
 // CHUNK = bytes of terms per group and LDS buffer (2 x GPW x CHUNK <= 128 KB): 65536 / 32768 / 16384 for GPW 1 / 2 / 4.
 constexpr int STRICT_SKEW4 = 272;
 
-template <int G, int CHUNK, int GPW>
-__global__ __launch_bounds__(1024) void lik_strict_sum_kernel(const float* __restrict__ terms, int n_s, int n_p, int n_groups,
-                                                              float* __restrict__ out_lik, int skew4, int accumulate = 0)
-{
-  constexpr int Q = G / 4;               // float4s per row
-  constexpr int ROWS = CHUNK / (4 * G);  // rows per chunk and group
-  constexpr int LD = ROWS + 4;           // padded row length of the transposed buffer (keeps 16-byte alignment)
-  constexpr int LOADERS = 960;
-  constexpr int ELEMS = GPW * ROWS * Q;  // float4s per chunk
-  constexpr int PER = (ELEMS + LOADERS - 1) / LOADERS;
-  static_assert(GPW * G <= 64, "one adder wavefront");
-  __shared__ __attribute__((aligned(16))) float buf[2][GPW * G * LD];
-  const int group0 = blockIdx.x * GPW, t = threadIdx.x;
-  const float4* base = reinterpret_cast<const float4*>(terms);
-  const int n_chunks = (n_s + ROWS - 1) / ROWS;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // loaders: chunk c of the GPW groups into registers ...
-  const auto fetch = [&](int c, float4 (&reg)[PER])
-  {
-    const int lt = t - 64;
-    const int first = c * ROWS, n_rows = min(ROWS, n_s - first);
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-    {
-      const int e = lt + LOADERS * j;
-      const int gl = e / (ROWS * Q), rem = e - gl * (ROWS * Q), r = rem / Q;
-      const bool live = c < n_chunks && e < ELEMS && r < n_rows && group0 + gl < n_groups;
-      reg[j] = live ? base[static_cast<size_t>(group0 + gl) * (static_cast<size_t>(n_s) * Q + skew4) + static_cast<size_t>(first) * Q + rem] : z4;
-    }
-  };
-  // ... and from there into buf[c & 1], transposed ([group][particle][row]); rows past n_s (and groups past the last one) are
-  // zero-filled up to the next multiple of 4 rows
-  const auto park = [&](int c, const float4 (&reg)[PER])
-  {
-    const int lt = t - 64;
-    const int n_rows = min(ROWS, n_s - c * ROWS);
-    const int padded = (n_rows + 3) & ~3;
-    float* dst = buf[c & 1];
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-    {
-      const int e = lt + LOADERS * j;
-      const int gl = e / (ROWS * Q), rem = e - gl * (ROWS * Q), r = rem / Q, k4 = (rem % Q) * 4;
-      if (e < ELEMS && r < padded)
-      {
-        float* d = dst + (gl * G + k4) * LD + r;
-        d[0 * LD] = reg[j].x;
-        d[1 * LD] = reg[j].y;
-        d[2 * LD] = reg[j].z;
-        d[3 * LD] = reg[j].w;
-      }
-    }
-  };
-  float4 ra[PER], rb[PER];  // chunks in flight: even ones in ra, odd ones in rb
-  const bool loader = t >= 64;
-  if (loader && n_chunks > 0)
-  {
-    fetch(0, ra);
-    park(0, ra);
-    fetch(1, rb);
-    fetch(2, ra);
-  }
-  __syncthreads();
-  float score = 0.0f;
-  if (accumulate)
-  {
-    // (a scan replayed in chunks of its original order: this launch continues the sums the previous chunk's launch left)
-    const int p0 = (group0 + t / G) * G + (t % G);
-    if (t < GPW * G && group0 + t / G < n_groups && p0 < n_p)
-      score = out_lik[p0];
-  }
-  for (int c = 0; c < n_chunks; ++c)
-  {
-    if (loader)
-    {
-      // chunk c + 1 has been in flight since iteration c - 1 (its buffer was last read in iteration c - 1: behind the barrier)
-      if (c + 1 < n_chunks)
-      {
-        if ((c + 1) & 1)
-        {
-          park(c + 1, rb);
-          fetch(c + 3, rb);
-        }
-        else
-        {
-          park(c + 1, ra);
-          fetch(c + 3, ra);
-        }
-      }
-    }
-    else if (t < GPW * G)
-    {
-      const float4* cur = reinterpret_cast<const float4*>(buf[c & 1] + t * LD);
-      const int n4 = (min(ROWS, n_s - c * ROWS) + 3) >> 2;  // zero padding: x + 0.0f == x
-      int r = 0;
-      for (; r + 4 <= n4; r += 4)
-      {
-        const float4 a = cur[r], b = cur[r + 1], d = cur[r + 2], e = cur[r + 3];
-        score += a.x; score += a.y; score += a.z; score += a.w;
-        score += b.x; score += b.y; score += b.z; score += b.w;
-        score += d.x; score += d.y; score += d.z; score += d.w;
-        score += e.x; score += e.y; score += e.z; score += e.w;
-      }
-      for (; r < n4; ++r)
-      {
-        const float4 a = cur[r];
-        score += a.x; score += a.y; score += a.z; score += a.w;
-      }
-    }
-    __syncthreads();
-  }
-  const int p = (group0 + t / G) * G + (t % G);
-  if (t < GPW * G && group0 + t / G < n_groups && p < n_p)
-    out_lik[p] = score;
-}
-
-// The same replay with the chunk kept in LDS as it comes from memory ([group][row][G], round 4): the loaders park their float4s
-// with one ds_write_b128 each, no transposition (the transposed form above needs four scattered ds_write_b32 per float4 — with
-// their bank conflicts the parking of a chunk took as long as the adder needed for it), and the adder lane (group, particle)
+// The chunk is kept in LDS as it comes from memory ([group][row][G]): the loaders park their float4s with one ds_write_b128 each
+// (round 3's form transposed it — four scattered ds_write_b32 per float4, whose bank conflicts made the parking of a chunk take as
+// long as the adder needed for it; gone in round 6), and the adder lane (group, particle)
 // reads ONE float per row, sixteen rows ahead of the add that consumes them: the chain then waits for the adds alone, not for
 // an LDS round trip every sixteen terms (~11 -> ~6 cycles per term). Group regions sit G floats apart from a multiple of the
 // bank count so that the GPW groups' rows do not collide. Same terms, same order, same float: bit-identical.

@@ -23,17 +23,6 @@
 
 namespace mcl3dl
 {
-struct CandGrid
-{
-  const int32_t* brick_table;  // dense [nbx*nby*nbz]: brick id or -1
-  const uint32_t* vox_start;   // [n_bricks*512 + 1] run delimiters into cand
-  const float4* cand;          // rescaled x,y,z ; w = original map index (bits)
-  float ox, oy, oz;            // origin of voxel (0,0,0), rescaled coordinates
-  float inv_ex, inv_ey, inv_ez;  // 1 / voxel edge, per axis (round 5: voxels are boxes — an axis the metric stretches gets a longer edge)
-  int nvx, nvy, nvz;           // voxel-grid extent
-  int nbx, nby, nbz;           // brick-grid extent (= ceil(nv / 8))
-};
-
 struct CompileParams
 {
   float ox, oy, oz, inv_ex, inv_ey, inv_ez;
@@ -43,8 +32,6 @@ struct CompileParams
   double grow;    // V+ = V grown by this on every side
   double r2_hi;   // (r*(1+1e-5))^2
   double margin;  // domination margin m
-  int refine;        // crowded voxels: domination tested per sub-box of a refine^3 subdivision (1 = whole voxel only)
-  int refine_above;  // ... when more than this many candidates survive the whole-voxel test
   int rx, ry, rz;  // voxels to visit around a point's own voxel, per axis
   int nvx, nvy, nvz, nbx, nby, nbz;
   int n_points;
@@ -284,54 +271,8 @@ __device__ inline void prune_voxel_serial(const CompileParams& c, const float4* 
     if (dominated)
       prelim[i] |= 0x80000000u;
   }
-  // pass 1b (crowded voxels only: more survivors than a record holds inline): the pairwise test asks for ONE rival that beats
-  // p everywhere in V+; a point whose Voronoi cell misses the voxel is often beaten by DIFFERENT rivals in different parts
-  // of it. So cut V+ into refine^3 sub-boxes and drop p when every sub-box has its own dominator — still a proof that p is
-  // nowhere the nearest neighbour (any point, dominated or not, is a valid rival), just a sharper one.
-  if (c.refine > 1 && k_all <= PRUNE_K)
-  {
-    uint32_t alive = 0;
-    for (uint32_t i = s; i < e; ++i)
-      alive += (prelim[i] & 0x80000000u) ? 0u : 1u;
-    if (alive > static_cast<uint32_t>(c.refine_above))
-    {
-      const int R = c.refine;
-      const double hsx = hx / R, hsy = hy / R, hsz = hz / R;
-      uint32_t drop_mask = 0u;  // decided against the UNrefined survivor set, applied afterwards (k_all <= 32)
-      for (uint32_t i = s; i < e; ++i)
-      {
-        if (prelim[i] & 0x80000000u)
-          continue;
-        const float4 p = pts[prelim[i] & 0x7fffffffu];
-        const double px = p.x - ctr[0], py = p.y - ctr[1], pz = p.z - ctr[2];
-        const double pp = px * px + py * py + pz * pz;
-        bool needed = false;
-        for (int cell = 0; cell < R * R * R && !needed; ++cell)
-        {
-          const double ox = -hx + (2 * (cell % R) + 1) * hsx, oy = -hy + (2 * ((cell / R) % R) + 1) * hsy,
-                       oz = -hz + (2 * (cell / (R * R)) + 1) * hsz;
-          bool dominated_here = false;
-          for (uint32_t j = s; j < e && !dominated_here; ++j)
-          {
-            if (j == i)
-              continue;
-            const float4 q = pts[prelim[j] & 0x7fffffffu];
-            const double qx = q.x - ctr[0], qy = q.y - ctr[1], qz = q.z - ctr[2];
-            const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
-            const double gmin = pp - (qx * qx + qy * qy + qz * qz) + (ox * cx + oy * cy + oz * cz) -
-                                (hsx * fabs(cx) + hsy * fabs(cy) + hsz * fabs(cz));
-            dominated_here = gmin > c.margin;
-          }
-          needed = !dominated_here;
-        }
-        if (!needed)
-          drop_mask |= 1u << (i - s);
-      }
-      for (uint32_t i = s; i < e; ++i)
-        if (drop_mask & (1u << (i - s)))
-          prelim[i] |= 0x80000000u;
-    }
-  }
+  // (Rounds 4-5 carried a pass 1b for crowded voxels — every sub-box of a subdivision of V+ with its own dominator, a sharper
+  // proof: it moved the tiled kernel on maps of centroids by <= 1.2 %, profiles/r04ac_quarter_bounds_ab.txt, and went in round 6.)
   // pass 2: compact survivors to the front, ordered by their distance to the voxel box (ties: ascending point id): the
   // candidates a record holds INLINE are then the ones nearest to the voxel — the likely winners — and the nearest of the
   // overflow candidates is the first of them, which is what the record's skip bound is taken from (mc_write_records). The
@@ -481,39 +422,6 @@ __global__ __launch_bounds__(256) void mc_prune_coop(CompileParams c, const floa
       dom |= dominated ? 1u << i : 0u;
     }
   dom = group_or(dom);
-  // pass 1b: crowded voxels — every sub-box of V+ has its own dominator (decided against the unrefined survivor set)
-  uint32_t drop = 0u;
-  if (coop && c.refine > 1 && k - static_cast<uint32_t>(__popc(dom)) > static_cast<uint32_t>(c.refine_above))
-  {
-    const int R = c.refine;
-    const double hsx = hx / R, hsy = hy / R, hsz = hz / R;
-    for (uint32_t i = g; i < k; i += L)
-    {
-      if (dom & (1u << i))
-        continue;
-      const double px = s_px[grp][i], py = s_py[grp][i], pz = s_pz[grp][i], pp = s_pp[grp][i];
-      bool needed = false;
-      for (int cell = 0; cell < R * R * R && !needed; ++cell)
-      {
-        const double ox = -hx + (2 * (cell % R) + 1) * hsx, oy = -hy + (2 * ((cell / R) % R) + 1) * hsy,
-                     oz = -hz + (2 * (cell / (R * R)) + 1) * hsz;
-        bool dominated_here = false;
-        for (uint32_t j = 0; j < k && !dominated_here; ++j)
-        {
-          if (j == i)
-            continue;
-          const double qx = s_px[grp][j], qy = s_py[grp][j], qz = s_pz[grp][j];
-          const double cx = 2.0 * (qx - px), cy = 2.0 * (qy - py), cz = 2.0 * (qz - pz);
-          const double gmin = pp - (qx * qx + qy * qy + qz * qz) + (ox * cx + oy * cy + oz * cz) -
-                              (hsx * fabs(cx) + hsy * fabs(cy) + hsz * fabs(cz));
-          dominated_here = gmin > c.margin;
-        }
-        needed = !dominated_here;
-      }
-      drop |= needed ? 0u : 1u << i;
-    }
-  }
-  dom |= group_or(drop);
   // pass 2: the survivors in the order of (distance to the voxel box, point id); the dropped entries behind them, flagged
   if (coop)
   {
@@ -666,18 +574,6 @@ __global__ __launch_bounds__(256) void mc_prune_long(CompileParams c, const floa
   }
 }
 
-// K7: write the final candidate runs
-__global__ void mc_write_final(const float4* __restrict__ pts, const uint32_t* __restrict__ pstart,
-                               const uint32_t* __restrict__ prelim, const uint32_t* __restrict__ vstart,
-                               float4* __restrict__ cand, long long n_vox)
-{
-  const long long v = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (v >= n_vox)
-    return;
-  const uint32_t s = vstart[v], e = vstart[v + 1], src = pstart[v];
-  for (uint32_t k = 0; k < e - s; ++k)
-    cand[s + k] = pts[prelim[src + k] & 0x7fffffffu];
-}
 
 // ---- "fat" voxel records (query MODE 2) -------------------------------------------------------------------------
 // One 64-byte record per voxel of every allocated brick, so a query is ONE cache line after the brick table. Four 16-byte
@@ -721,6 +617,9 @@ struct RecGrid
   // above the float rounding of this product and of the kernel's d2 (2e-7), so (bound * bound_step)^2 stays below the d2 the
   // kernel would compute for every overflow candidate at every query inside the voxel: skipping is exact.
   float bound_step;
+  // (A dense form — every brick of the grid allocated in table order, brick id == table index, no table load in the kernels —
+  // was measured in round 6 and not kept: one load instruction less per evaluation, but 4.9 GB instead of 0.51 GB at C2, +8 % L2
+  // requests, +39 % L2 misses, 0.2362 against 0.2314 ms; twice as slow at 32 768 particles: profiles/r06g_tiled_levers_ab.txt.)
 };
 
 __host__ __device__ inline uint32_t rec_ext_mask(const RecGrid& g)

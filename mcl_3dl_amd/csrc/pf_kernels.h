@@ -25,22 +25,7 @@ struct PfEmit
   float* lik;
   float* ratio;
   float* beam;
-  // round 5: the completion word of the host-buffer update (host_context.h: done_flag) written by THIS kernel behind its
-  // results instead of by a one-thread kernel of its own — only where the kernel is ONE work-group (pf_fused_kernel, and
-  // pf_apply_kernel launched as one block): every thread fences its stores to the host, the work-group meets, thread 0 writes
-  volatile unsigned* done;
-  unsigned done_seq;
 };
-
-__device__ inline void pf_emit_done(const PfEmit& emit)
-{
-  if (!emit.done)   // (a kernel argument: uniform)
-    return;
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0)
-    *emit.done = emit.done_seq;
-}
 
 // w_new = w * (((1 * beam) * lik) * extra); per-block partials {sum w, sum w ln w, max ratio, -min ratio}.
 __global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __restrict__ w, const float* __restrict__ lik,
@@ -191,7 +176,6 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ 
         emit.stats4[k] = st[k];
     }
   }
-  pf_emit_done(emit);  // (only ever set on a one-block launch)
 }
 
 // pf_partial_kernel -> pf_reduce_kernel -> pf_apply_kernel for ONE GPU and at most PF_FUSED_MAX particles, as a single
@@ -347,20 +331,8 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
         emit.stats4[k] = st[k];
     }
   }
-  pf_emit_done(emit);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// pf::measure of ONE GPU and at most PF_NORM_MAX particles in two launches without any hand-off between work-groups:
-//   pf_weights_kernel   w_new = w * (((1 * beam) * lik) * extra)            (or folded into the kernel that produces lik:
-//                       lik_finalize_kernel on the tiled path, update_particle_kernel on the per-particle path)
-//   pf_norm_kernel      pf_blocks(n) work-groups of 1024 threads; EVERY work-group recomputes the whole reduction — the 256-
-//                       particle partials of pf_partial_kernel and the 64-lane reduce of pf_reduce_kernel, in their association
-//                       (the loop of pf_fused_kernel), from the <= 32 KB of w_new / ratio in L2 — and then normalises ITS 256
-//                       weights (pf_apply_kernel). No ticket, no fence, nobody waits: redundant arithmetic (n log()s per
-//                       work-group) instead of a launch boundary. Same bits as the split form.
-// Replaces pf_partial + pf_reduce + pf_apply (three launches, ~4 us each on an idle queue) where one GPU holds every particle.
-// ---------------------------------------------------------------------------------------------------------
 // per-particle results of the two models -> page-locked host memory (mcl3dl_hip_measure_batch without a D2H copy)
 __global__ __launch_bounds__(PF_BLOCK) void emit3_kernel(PfEmit emit, const float* __restrict__ lik, const float* __restrict__ ratio,
                                                          const float* __restrict__ beam, int n)
@@ -376,8 +348,6 @@ __global__ __launch_bounds__(PF_BLOCK) void emit3_kernel(PfEmit emit, const floa
   }
 }
 
-constexpr int PF_NORM_MAX_BLOCKS = 32;
-constexpr int PF_NORM_MAX = PF_NORM_MAX_BLOCKS * PF_BLOCK;
 
 __device__ __forceinline__ float pf_weight_product(float w, float lik, float beam, bool has_beam, const float* __restrict__ extra,
                                                    int i)
@@ -389,184 +359,6 @@ __device__ __forceinline__ float pf_weight_product(float w, float lik, float bea
   if (extra)
     l = l * extra[i];
   return w * l;  // pf.h:258
-}
-
-// fill_beam (may be null): the update has no beam points — the beam score 1 (beam.cpp:130-133) is written there on the way
-// and used for the product (`beam` is not read then)
-__global__ __launch_bounds__(PF_BLOCK) void pf_weights_kernel(const float* __restrict__ w, const float* __restrict__ lik,
-                                                              const float* beam, const float* __restrict__ extra, int n,
-                                                              float* __restrict__ w_new, float* fill_beam = nullptr)
-{
-  const int i = blockIdx.x * PF_BLOCK + threadIdx.x;
-  if (i >= n)
-    return;
-  if (fill_beam)
-    fill_beam[i] = 1.0f;
-  const bool has_beam = fill_beam != nullptr || beam != nullptr;
-  w_new[i] = pf_weight_product(w[i], lik[i], fill_beam ? 1.0f : (beam ? beam[i] : 1.0f), has_beam, extra, i);
-}
-
-// lik / beam: only read for `emit` (the device arrays its host copies come from); ratio: pf_partial_kernel's (may be null).
-// Latency, not work, is what this kernel costs (every load is a ~1 us round trip to data another kernel has just written):
-// all loads of a thread — its <= 8 weights / ratios of the reduction and what its own particle needs at the end — are issued
-// up front, and the work-group meets at three barriers in all.
-__global__ __launch_bounds__(1024) void pf_norm_kernel(float* __restrict__ w, const float* __restrict__ w_new,
-                                                       const float* __restrict__ ratio, int n, double* __restrict__ packed,
-                                                       float* __restrict__ stats4, PfEmit emit, const float* __restrict__ lik,
-                                                       const float* __restrict__ beam)
-{
-  constexpr int MAXIT = PF_NORM_MAX_BLOCKS / 4;
-  __shared__ double sh[4][MAXIT][16];   // per iteration, per wavefront of the group
-  __shared__ double part[4][PF_NORM_MAX_BLOCKS];
-  __shared__ double tot[4];
-  const int nb = (n + PF_BLOCK - 1) / PF_BLOCK;  // == gridDim.x == pf_blocks(n)
-  const int q = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mine = static_cast<int>(blockIdx.x);
-  const int n_it = (nb + 3) >> 2;
-  float wn_r[MAXIT], ra_r[MAXIT];
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-  {
-    const int i = (4 * it + q) * PF_BLOCK + tid;
-    const bool ok = it < n_it && 4 * it + q < nb && i < n;
-    wn_r[it] = ok ? w_new[i] : 0.0f;
-    ra_r[it] = (ok && ratio) ? ratio[i] : 0.0f;
-  }
-  // this thread's own particle (quarter mine & 3 of the group finishes work-group `mine`'s 256 weights)
-  const int own_i = mine * PF_BLOCK + tid;
-  const bool owner = q == (mine & 3) && own_i < n;
-  float w_old = 0.f, e_lik = 0.f, e_beam = 1.f;
-  if (owner)
-  {
-    w_old = w[own_i];
-    if (emit.lik)
-      e_lik = lik[own_i];
-    if (emit.beam && beam)
-      e_beam = beam[own_i];
-  }
-  float own = 0.0f, own_ratio = 0.0f;
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-  {
-    if (it < n_it)  // (uniform over the work-group)
-    {
-      const int vb = 4 * it + q;
-      const int i = vb * PF_BLOCK + tid;
-      double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;
-      if (vb < nb && i < n)
-      {
-        const float wn = wn_r[it];
-        if (vb == mine)
-        {
-          own = wn;
-          own_ratio = ra_r[it];
-        }
-        s += static_cast<double>(wn);
-        if (wn > 0.0f)
-          t += static_cast<double>(wn) * log(static_cast<double>(wn));
-        if (ratio)
-        {
-          const double r = static_cast<double>(ra_r[it]);
-          rmax = r > rmax ? r : rmax;
-          rneg = -r > rneg ? -r : rneg;
-        }
-      }
-      s = wave_sum(s);
-      t = wave_sum(t);
-      rmax = wave_max(rmax);
-      rneg = wave_max(rneg);
-      if (lane == 0)
-      {
-        sh[0][it][wave] = s;
-        sh[1][it][wave] = t;
-        sh[2][it][wave] = rmax;
-        sh[3][it][wave] = rneg;
-      }
-    }
-  }
-  __syncthreads();
-  if (static_cast<int>(threadIdx.x) < nb)
-  {
-    // pf_partial_kernel's thread 0 of virtual block vb: its four wavefronts in order
-    const int vb = threadIdx.x, it = vb >> 2, qq = vb & 3;
-    double a = 0, b = 0, c = sh[2][it][4 * qq], d = sh[3][it][4 * qq];
-    for (int k = 0; k < PF_BLOCK / 64; ++k)
-    {
-      a += sh[0][it][4 * qq + k];
-      b += sh[1][it][4 * qq + k];
-      c = sh[2][it][4 * qq + k] > c ? sh[2][it][4 * qq + k] : c;
-      d = sh[3][it][4 * qq + k] > d ? sh[3][it][4 * qq + k] : d;
-    }
-    part[0][vb] = a;
-    part[1][vb] = b;
-    part[2][vb] = c;
-    part[3][vb] = d;
-  }
-  __syncthreads();
-  if (wave == 0)
-  {
-    // pf_reduce_kernel
-    double a = 0, b = 0, c = 0.0, d = -1.0;
-    for (int k = lane; k < nb; k += 64)
-    {
-      a += part[0][k];
-      b += part[1][k];
-      c = part[2][k] > c ? part[2][k] : c;
-      d = part[3][k] > d ? part[3][k] : d;
-    }
-    a = wave_sum(a);
-    b = wave_sum(b);
-    c = wave_max(c);
-    d = wave_max(d);
-    if (lane == 0)
-    {
-      tot[0] = a;
-      tot[1] = b;
-      tot[2] = c;
-      tot[3] = d;
-      if (mine == 0)
-      {
-        packed[0] = a;
-        packed[1] = b;
-        packed[2] = c;
-        packed[3] = d;
-      }
-    }
-  }
-  __syncthreads();
-  // pf_apply_kernel
-  const double S = tot[0];
-  const float sum_f = static_cast<float>(S);
-  const bool alive = sum_f > 0.0f;
-  if (owner)
-  {
-    float wv = w_old;
-    if (alive)
-    {
-      wv = own / sum_f;
-      w[own_i] = wv;
-    }
-    if (emit.w)
-      emit.w[own_i] = wv;
-    if (emit.lik)
-      emit.lik[own_i] = e_lik;
-    if (emit.ratio)
-      emit.ratio[own_i] = own_ratio;
-    if (emit.beam)
-      emit.beam[own_i] = e_beam;
-  }
-  if (mine == 0 && threadIdx.x == 0 && (stats4 || emit.stats4))
-  {
-    const float st[4] = { alive ? static_cast<float>(log(S) - tot[1] / S) : __builtin_nanf(""), static_cast<float>(-tot[3]),
-                          static_cast<float>(tot[2]), alive ? 0.0f : 1.0f };
-    for (int k = 0; k < 4; ++k)
-    {
-      if (stats4)
-        stats4[k] = st[k];
-      if (emit.stats4)
-        emit.stats4[k] = st[k];
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -789,65 +581,6 @@ __global__ __launch_bounds__(64) void pf_covariance_reduce_kernel(const double* 
 // stay on the host in mcl3dl_hip.hip; the device does the n_out independent std::lower_bound searches and the
 // gather of the 13-dof states with State6DOF::operator+ / normalize() for the duplicated ones.
 // ---------------------------------------------------------------------------------------------------------
-// accum += p.probability_ ; p.accum_probability_ = accum (pf.h:193-197 / 401-405) on the device: a float recurrence in
-// particle order, so ONE lane runs it; the work-group's 256 threads stage 4096 weights at a time in LDS (coalesced) and
-// write the 4096 prefixes back. out2[0] = the total, out2[1] = 1 if any prefix failed to grow (a weight of zero: the
-// reference's std::sort then decides the order inside the tie group, which only the host path reproduces).
-__global__ __launch_bounds__(256) void resample_prefix_kernel(const float* __restrict__ w, int n, float* __restrict__ keys,
-                                                              float* __restrict__ out2)
-{
-  __shared__ float buf[4096];
-  if (blockIdx.x != 0)
-    return;
-  float accum = 0.0f;
-  int ties = 0;
-  for (int base = 0; base < n; base += 4096)
-  {
-    const int m = min(4096, n - base);
-    for (int j = threadIdx.x; j < m; j += 256)
-      buf[j] = w[base + j];
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      int i = 0;
-      for (; i + 16 <= m; i += 16)
-      {
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          v[j] = buf[i + j];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-        {
-          const float prev = accum;
-          accum += v[j];
-          ties |= (base + i + j > 0 && !(prev < accum)) ? 1 : 0;
-          v[j] = accum;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          buf[i + j] = v[j];
-      }
-      for (; i < m; ++i)
-      {
-        const float prev = accum;
-        accum += buf[i];
-        ties |= (base + i > 0 && !(prev < accum)) ? 1 : 0;
-        buf[i] = accum;
-      }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < m; j += 256)
-      keys[base + j] = buf[j];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-  {
-    out2[0] = accum;
-    out2[1] = ties ? 1.0f : 0.0f;
-  }
-}
-
 __global__ void resample_lower_bound_kernel(const float* __restrict__ keys, int n, const float* __restrict__ pscan,
                                             float pstep, float initial_p, int n_out, uint32_t* __restrict__ it_out,
                                             uint32_t* __restrict__ last_valid)

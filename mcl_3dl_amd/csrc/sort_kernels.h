@@ -20,8 +20,6 @@
 //     table of counts and scatters (rs_pass_kernel). No work-group ever waits for another one inside a launch. (Counting
 //     the NEXT pass's digits from inside the scatter — one device-scope atomic per element — was measured first: the atomics
 //     alone cost 7 us per pass, more than the extra launch.)
-//   * (option, off) 2048 < n <= 32 768 with keys of at most 16 bits: ONE launch, every work-group holds the whole key
-//     distribution in LDS (rs_sort16_kernel below; no gain: LDS atomics).
 //   * Larger arrays (whole maps) go to rocprim::radix_sort_pairs (host_cloud.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -381,296 +379,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_pass_kernel(const uint32_t* __r
     }
 }
 
-// ---- RS_ONE_LAUNCH_MAX < n <= RS_FULL_MAX: ONE launch per pass, no counting launches ------------------------------------
-// What a pass needs from the other work-groups is how many elements with each digit every one of them owns — a property of
-// the keys alone. For arrays this small every work-group can count that ITSELF: it reads all n keys (64 KB at 16 384; pass 0
-// derives them from the points) and histograms them per owning work-group into LDS (n LDS atomics, ~2 us) — less than the
-// ~5 us a separate counting launch costs between two dependent kernels. A 16 384-point scan is ordered by three launches
-// instead of seven (keygen + count, then count / scatter pairs). Same ranks, same stable order as rs_pass_kernel.
-constexpr int RS_FULL_MAX_BLOCKS = 32;
-constexpr int RS_FULL_MAX = RS_THREADS * RS_FULL_MAX_BLOCKS;
-
-template <int KEYMODE, bool FIRST, bool APPLY>
-__global__ __launch_bounds__(RS_THREADS) void rs_pass_full_kernel(RsKeyGen kg, const uint32_t* __restrict__ keys_src,
-                                                                  const uint32_t* __restrict__ vals_src,
-                                                                  uint32_t* __restrict__ keys_dst, uint32_t* __restrict__ vals_dst,
-                                                                  RsFinal fin, int n, int pass, int n_pass, uint32_t mask)
-{
-  __shared__ uint32_t cnt[RS_WAVES][256];
-  __shared__ uint32_t dbase[256];
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t tab[RS_FULL_MAX_BLOCKS][256];
-  __shared__ uint32_t s_part[4][256];
-  const int nb = gridDim.x, b = blockIdx.x;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int shift = 8 * pass;
-  for (int k = threadIdx.x; k < nb * 256; k += RS_THREADS)
-    (&tab[0][0])[k] = 0u;
-  __syncthreads();
-  // every work-group's digit counts, from all n keys (element idx belongs to work-group idx / RS_THREADS)
-  uint32_t key[1] = { 0xffffffffu }, val[1] = { 0u }, dst[1] = { 0u };
-  const int own = b * RS_THREADS + w * 64 + lane;
-  for (int idx = threadIdx.x; idx < n; idx += RS_THREADS)
-  {
-    const uint32_t k = FIRST ? rs_make_key<KEYMODE>(kg, static_cast<uint32_t>(idx)) : keys_src[idx];
-    atomicAdd(&tab[idx / RS_THREADS][((k & mask) >> shift) & 255u], 1u);
-    if (idx == own)
-      key[0] = k;
-  }
-  const bool have = own < n;
-  const uint32_t valid = have ? 1u : 0u;
-  if (have)
-    val[0] = FIRST ? ((KEYMODE == RS_KEY_ARRAY && kg.vals) ? kg.vals[own] : static_cast<uint32_t>(own)) : vals_src[own];
-  // (rs_rank_pass starts with a barrier: tab is complete behind it)
-  rs_rank_pass<1>(key, valid, 1, shift, mask, dst, cnt, dbase, wsum, [&](uint32_t total_d, uint32_t* ws) {
-    (void)total_d;  // == tab[b][d]
-    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
-    uint32_t all = 0, ahead = 0;
-    for (int bb = q; bb < nb; bb += 4)
-    {
-      const uint32_t x = tab[bb][d];
-      all += x;
-      ahead += bb < b ? x : 0u;
-    }
-    s_part[q][d] = all;
-    __syncthreads();
-    if (q == 0)
-      all = s_part[0][d] + s_part[1][d] + s_part[2][d] + s_part[3][d];
-    __syncthreads();
-    s_part[q][d] = ahead;
-    __syncthreads();
-    if (q == 0)
-      ahead = s_part[0][d] + s_part[1][d] + s_part[2][d] + s_part[3][d];
-    return rs_scan256(all, ws) + ahead;
-  });
-  if (APPLY && pass + 1 == n_pass)
-  {
-    rs_apply<1>(fin, val, dst, valid);
-    return;
-  }
-  if (have)
-  {
-    keys_dst[dst[0]] = key[0];
-    vals_dst[dst[0]] = val[0];
-  }
-}
-
-// ---- RS_ONE_LAUNCH_MAX < n <= RS16_MAX, keys of at most 16 bits (the Morton key of a likelihood scan): ONE launch -------
-// Two launches per 8-bit pass is four or five dependent launches for a 16 384-point scan — 25 us of the host-buffer update's
-// 39 us head, most of it the 4 - 5 us between dependent launches on an otherwise empty queue (profiles/r05o_timeline_8d_C2.txt).
-// With 16 key bits the whole distribution fits in LDS: 65 536 sixteen-bit counters = 128 KB of the CU's 160. Every work-group
-// (1024 consecutive elements each) counts ALL n keys itself and needs nothing from any other work-group:
-//   position of element i  =  [elements with a smaller key]  +  [elements j < i with the same key]
-//   * the elements of the work-groups AHEAD are counted first (LDS atomics, any order), so that when the work-group turns to its
-//     own 1024 elements the counter of a key holds the second term's share of all earlier work-groups; its own elements are
-//     then added wavefront by wavefront in index order (sixteen barriers), the lanes of one wavefront ordered by sixteen ballots
-//     (the lanes that share all sixteen key bits) + v_mbcnt — the second term is complete;
-//   * then the elements of the work-groups BEHIND, and an exclusive prefix over the 65 536 counters in place (every wavefront
-//     4096 counters, 64 words per round, carried from round to round; the sixteen wavefront totals are added at look-up).
-// Same stable order as the LSD passes. n <= 32 768 keeps every count and every prefix inside sixteen bits.
-// MEASURED (profiles/r05p_sort16_one_launch.txt, profiles/sort16_phases.hip): 15.6 us for 16 384 elements, 7.7 of them the
-// 15 360 LDS atomics of the two counting loops — LDS atomics retire one lane per clock — so the launch costs what the passes
-// cost in a live update (0.2755 against 0.2742 ms); kept as an option ("sort_one_launch"), off.
-constexpr int RS16_MAX = 32768;
-
-// lanes of this wavefront that hold the same BITS-bit key (0 for a lane without an element)
-template <int BITS>
-__device__ __forceinline__ unsigned long long rs_match_bits(uint32_t key, bool valid)
-{
-  unsigned long long m = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < BITS; ++b)
-  {
-    const bool bit = (key >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
-  }
-  return valid ? m : 0ull;
-}
-
-// what a key needs besides its point, fetched once per thread (the Morton key's corner and shift are the same for every point)
-template <int KEYMODE>
-struct Rs16KeyCtx
-{
-  float mn[3];
-  uint32_t drop;
-  __device__ __forceinline__ void init(const RsKeyGen& kg)
-  {
-    if (KEYMODE == RS_KEY_MORTON)
-    {
-      mn[0] = kg.min3[0];
-      mn[1] = kg.min3[1];
-      mn[2] = kg.min3[2];
-      drop = morton_key_drop(kg.min3);
-    }
-  }
-  __device__ __forceinline__ uint32_t key(const RsKeyGen& kg, uint32_t idx, const float4& p) const
-  {
-    if (KEYMODE == RS_KEY_ARRAY)
-      return kg.keys[idx];
-    if (KEYMODE == RS_KEY_MORTON)
-    {
-      const float c[3] = { p.x, p.y, p.z };
-      uint32_t q[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-      {
-        const float f = (c[a] - mn[a]) * 4.0f;   // (morton_scan_key, cloud_keys.h: the same expression)
-        q[a] = (f >= 0.f) ? (f < 1023.f ? static_cast<uint32_t>(f) : 1023u) : 0u;
-      }
-      return (spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2)) >> drop;
-    }
-    if (KEYMODE == RS_KEY_RANGE)
-      return range_scan_key(p, kg.origins, kg.n_o, kg.error);
-    return voxel_leaf_key(p, kg.vp);
-  }
-};
-
-// counter of key k: half (k & 1) of word (k >> 1); words are placed so that the 64 lanes of a wavefront, each walking its own
-// run of 32 consecutive words (the prefix below), hit 64 different banks
-__device__ __forceinline__ uint32_t rs16_word(uint32_t j)
-{
-  return j ^ ((j >> 6) & 31u);
-}
-
-template <int KEYMODE, bool APPLY>
-__global__ __launch_bounds__(RS_THREADS) void rs_sort16_kernel(RsKeyGen kg, RsFinal fin, uint32_t* __restrict__ keys_out,
-                                                               uint32_t* __restrict__ vals_out, int n, uint32_t mask)
-{
-  __shared__ __attribute__((aligned(16))) uint32_t bins[32768];
-  __shared__ uint32_t wtot[RS_WAVES];
-  constexpr int BATCH = 8;  // loads in flight per thread while counting the other work-groups' elements
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int own0 = static_cast<int>(blockIdx.x) * RS_THREADS;
-  const uint32_t m16 = mask & 0xffffu;
-  Rs16KeyCtx<KEYMODE> kc;
-  kc.init(kg);
-  uint4* b4 = reinterpret_cast<uint4*>(bins);
-  for (int k = t; k < 8192; k += RS_THREADS)
-    b4[k] = make_uint4(0u, 0u, 0u, 0u);
-  // this thread's own element
-  const int own = own0 + t;
-  const bool have = own < n;
-  uint32_t kraw = 0, val = 0;
-  if (have)
-  {
-    const float4 p = KEYMODE == RS_KEY_ARRAY ? make_float4(0.f, 0.f, 0.f, 0.f) : kg.pts[own];
-    kraw = kc.key(kg, static_cast<uint32_t>(own), p);
-    val = (KEYMODE == RS_KEY_ARRAY && kg.vals) ? kg.vals[own] : static_cast<uint32_t>(own);
-  }
-  const uint32_t k16 = kraw & m16;
-  const uint32_t sh = (k16 & 1u) * 16u;
-  const uint32_t own_word = rs16_word(k16 >> 1);
-  // counts the elements [first, last) (whole chunks of 1024), BATCH loads in flight per thread
-  const auto count_range = [&](int first, int last)
-  {
-    for (int base = first + t; base < last; base += BATCH * RS_THREADS)
-    {
-      float4 p[BATCH];
-      uint32_t ka[BATCH];
-#pragma unroll
-      for (int u = 0; u < BATCH; ++u)
-      {
-        const int idx = base + u * RS_THREADS;
-        if (idx < last)
-        {
-          if (KEYMODE == RS_KEY_ARRAY)
-            ka[u] = kg.keys[idx];
-          else
-            p[u] = kg.pts[idx];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < BATCH; ++u)
-      {
-        const int idx = base + u * RS_THREADS;
-        if (idx < last)
-        {
-          const uint32_t k = (KEYMODE == RS_KEY_ARRAY ? ka[u] : kc.key(kg, static_cast<uint32_t>(idx), p[u])) & m16;
-          atomicAdd(&bins[rs16_word(k >> 1)], 1u << ((k & 1u) * 16u));
-        }
-      }
-    }
-  };
-  __syncthreads();
-  // ---- the work-groups ahead
-  count_range(0, own0);
-  // ---- this work-group's own elements, in index order
-  const unsigned long long m = rs_match_bits<16>(k16, have);
-  const uint32_t below = rs_lanes_below(m), total = static_cast<uint32_t>(__popcll(m));
-  uint32_t tie = 0;
-  __syncthreads();
-  for (int ww = 0; ww < RS_WAVES; ++ww)
-  {
-    if (w == ww)
-    {
-      uint32_t base = 0;
-      if (have)
-        base = (bins[own_word] >> sh) & 0xffffu;
-      // every lane of a key group has ISSUED its read before the group's highest lane adds to the same word (LDS operations
-      // of one wavefront complete in order; the wave barrier keeps the compiler from moving either across the other)
-      __builtin_amdgcn_wave_barrier();
-      if (have && below + 1 == total)
-        atomicAdd(&bins[own_word], total << sh);
-      tie = base + below;
-    }
-    __syncthreads();
-  }
-  // ---- the work-groups behind
-  count_range(min(own0 + RS_THREADS, n), n);
-  __syncthreads();
-  // ---- exclusive prefix in place: lane l of wavefront w owns the words [2048 w + 32 l, + 32) (64 counters), values relative to
-  // the wavefront's first counter
-  {
-    const uint32_t first = 2048u * static_cast<uint32_t>(w) + 32u * static_cast<uint32_t>(lane);
-    uint32_t sum = 0;
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r)
-    {
-      const uint32_t x = bins[rs16_word(first + r)];
-      sum += (x & 0xffffu) + (x >> 16);
-    }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
-    {
-      const uint32_t o = __shfl_up(inc, off, 64);
-      if (lane >= off)
-        inc += o;
-    }
-    uint32_t run = inc - sum;
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r)
-    {
-      const uint32_t x = bins[rs16_word(first + r)];
-      const uint32_t lo = x & 0xffffu, hi = x >> 16;
-      bins[rs16_word(first + r)] = run | ((run + lo) << 16);
-      run += lo + hi;
-    }
-    if (lane == 63)
-      wtot[w] = inc;
-  }
-  __syncthreads();
-  if (!have)
-    return;
-  uint32_t pos = ((bins[own_word] >> sh) & 0xffffu) + tie;
-  for (uint32_t ww = 0; ww < (k16 >> 12); ++ww)
-    pos += wtot[ww];
-  if (APPLY)
-  {
-    float4 q = fin.src_pts[val];
-    if (fin.zero_w)
-      q.w = 0.f;
-    fin.out_pts[pos] = q;
-    if (fin.out_perm)
-      fin.out_perm[pos] = val;
-  }
-  else
-  {
-    keys_out[pos] = kraw;
-    vals_out[pos] = val;
-  }
-}
+// (Rounds 4-5 also carried a one-launch-per-pass form in which every work-group counted every work-group's digits itself, and
+// a one-launch sort of 16-bit keys with the whole key distribution in LDS: both correct, both bound by LDS atomics that retire
+// one lane a clock, neither faster than the launches above — profiles/r04d_time8d_C2.json, r05p_sort16_one_launch.txt. Gone in
+// round 6 with their options.)
 
 // ---- the two ends of a sort that goes to rocprim (more than RS_MAX_ELEMS elements) -------------------------
 template <int KEYMODE>

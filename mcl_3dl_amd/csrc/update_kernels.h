@@ -37,7 +37,6 @@ struct UpdateSmallArgs
   const float4* scan_lik;
   int n_s;
   LikGrid g;
-  CandGrid cg;
   RecGrid rg;
   LikParams prm;
   int coop;
@@ -153,10 +152,7 @@ __device__ __forceinline__ bool last_of_tree(unsigned* tree, int idx, int width,
   return true;
 }
 
-// TICKETS = false ("update_particle_kernel"): the per-particle half only — likelihood + beam score of particle p and its
-// un-normalised weight w_new[p] (pf.h:258) — for particle counts above update_small_max, where the arrival tickets serialise:
-// pf_kernels.h:pf_norm_kernel finishes pf::measure in a second launch (two launches instead of seven at 4096 x 96 + 3).
-template <int BLOCK, int MODE, bool TICKETS = true>
+template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
 {
   constexpr int NW = BLOCK / 64;
@@ -172,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
   {
     double sum = 0.0;
     unsigned num = 0, unused = 0;
-    lik_particle<BLOCK, MODE, false>(pos, rot, a.scan_lik, a.n_s, a.g, a.cg, a.rg, a.prm, a.coop, sum, num, unused, a.perm,
+    lik_particle<BLOCK, MODE, false>(pos, rot, a.scan_lik, a.n_s, a.g, a.rg, a.prm, a.coop, sum, num, unused, a.perm,
                                      a.perm ? dyn_row : nullptr);
     lik = static_cast<float>(sum);
     ratio = static_cast<float>(num) / static_cast<float>(a.n_s);  // :136
@@ -224,19 +220,7 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
       a.emit.ratio[p] = ratio;
     if (a.emit.beam)
       a.emit.beam[p] = beam;
-    if (!TICKETS)
-    {
-      float l = 1.0f;
-      if (a.use_beam)
-        l *= beam;
-      l *= lik;
-      if (a.extra)
-        l = l * a.extra[p];
-      a.w_new[p] = a.w[p] * l;  // pf.h:258
-    }
   }
-  if (!TICKETS)
-    return;
   // ---- pf::measure (pf.h:252-279). Stage 1: the last work-group of each 256-particle virtual block.
   const int nvb = (a.n_p + PF_BLOCK - 1) / PF_BLOCK;
   const int vb = p / PF_BLOCK;

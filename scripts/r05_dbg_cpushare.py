@@ -56,8 +56,6 @@ def run(tag, reps=8, **opts):
 
 for rep in range(2):
     run("polled word, query every 5 ms (default)")
-    run("polled word, no query", poll_query_us=1e9)
-    run("polled word, query every 20 ms", poll_query_us=20000)
     run("polled word, no spin phase", poll_spin_us=0)
     run("polled word, pure spin", poll_spin_us=1e6)
     run("hipStreamSynchronize", poll_sync=0)

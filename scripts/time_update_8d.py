@@ -57,7 +57,6 @@ def pinned():
 def run(tag, arrays, stage, zero_copy, tail):
     eng.set_option("update_stage", stage)
     eng.set_option("update_zero_copy", zero_copy)
-    eng.set_option("pf_tail", tail)
     a = arrays
     eng.set_kernel_timing(False)
     ms, per = eng.time_measure_update(a["poses"], a["w0"], a["w"], a["lik"], a["beam"], a["lab"], a["org"], a["o_lik"], a["o_ratio"],
@@ -97,7 +96,6 @@ d_w = d_w0.clone()
 d_lik, d_ratio, d_beam = (torch.zeros(n_p, device=dev) for _ in range(3))
 d_st = torch.zeros(4, device=dev)
 for tail in (0, 1):
-    eng.set_option("pf_tail", tail)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.3:
         for _ in range(10):

@@ -84,3 +84,27 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     assert out.returncode == 0, out.stderr
     abi, rc = (int(x) for x in out.stdout.split())
     assert abi == 3 and rc <= 0
+
+
+def test_every_option_is_in_the_api_fuzz_pool():
+    """no runtime switch without a test that draws it in combination with the others. Every key
+    mcl3dl_hip_set_option accepts (parsed from api_support.inl) is in tests/test_gpu_api_fuzz.py's CHOICES — the fault-injection
+    hook aside — and can be read back (the getter table)."""
+    import ast
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "mcl_3dl_amd", "csrc", "api_support.inl")).read()
+    a = src.index("int mcl3dl_hip_set_option(")
+    b = src.index("kOptionGetters[]")
+    settable = set(re.findall(r'key == "([a-z_0-9]+)"', src[a:b]))
+    readable = set(re.findall(r'\{ "([a-z_0-9]+)", \[\]', src[b:]))
+    fuzz = open(os.path.join(root, "tests", "test_gpu_api_fuzz.py")).read()
+    tree = ast.parse(fuzz)
+    pools = {}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") in ("DEFAULTS", "CHOICES"):
+            pools[node.targets[0].id] = {kw.arg for kw in node.value.keywords}
+    assert pools["DEFAULTS"] == pools["CHOICES"]
+    assert settable - {"test_late_structures"} == pools["CHOICES"], (sorted(settable - pools["CHOICES"]), sorted(pools["CHOICES"] - settable))
+    assert settable - {"test_late_structures"} <= readable, sorted(settable - readable)
+    assert len(settable) <= 40

@@ -3,9 +3,8 @@ round-4 hazard (a lazy structure build recycling staging memory under a live upd
 ORDER of calls. Here every sequence draws >= 30 calls from
 
     set_map / map_update (inside and outside the base map's bounds) / set_likelihood_params / set_beam_params /
-    set_option (poll_sync 0/1/2, strict_order 0/1/2/3, update_stage, update_zero_copy, update_small, pf_fused, pf_tail,
-    lik_coop, lik_defer, overlap_models, batch_slice, scan_order_device, lik_tiled_min, poll_spin_us, lik_index 0/1/2 — the
-    cell grid that a map update merges instead of rebuilding —, cand_aniso) /
+    set_option (EVERY key the library accepts — round 6: 38 of them, the fault-injection hook aside — with two to five values
+    each: summation modes and their thresholds, kernel selection, index forms, staging, polling, ...) /
     measure_batch / measure_batch_begin.._wait.._end with calls in between and batches abandoned until a later _end /
     measure_update on pageable and on page-locked arrays / scan_begin + scan_finish + measure_device /
     resample_begin + _plan / expectation / the same update through a device group of two contexts
@@ -35,16 +34,28 @@ CHUNK = 10
 ND0 = np.float32(1.0 / np.sqrt(2.0 * np.pi))
 RTOL_FP64 = 3e-5   # the fp64 mode against the reference's sequential float sum (tests/test_gpu_fuzz.py holds the same gate)
 
-DEFAULTS = dict(poll_sync=2, strict_order=2, update_stage=1, update_zero_copy=1, update_small=1, pf_fused=1, pf_tail=0,
+# EVERY key mcl3dl_hip_set_option accepts (tests/test_abi.py::test_every_option_is_in_the_api_fuzz_pool keeps this list and
+# api_support.inl in step) except the fault-injection hook test_late_structures, which MCL3DL_FUZZ_INJECT switches on
+DEFAULTS = dict(poll_sync=2, strict_order=2, update_stage=1, update_zero_copy=1, update_small=1, pf_fused=1,
                 lik_coop=1, lik_defer=1, overlap_models=1, batch_slice=0, scan_order_device=4096, lik_tiled_min=1024,
-                poll_spin_us=2000, lik_index=2, cand_aniso=2, sort_one_launch=0, update_fold_done=0, poll_query_us=5000,
-                chain_ppl=0)
-CHOICES = dict(poll_sync=(0, 1, 2), strict_order=(0, 1, 2, 3), update_stage=(0, 1), update_zero_copy=(0, 1),
-               update_small=(0, 1), pf_fused=(0, 1), pf_tail=(0, 1), lik_coop=(0, 1), lik_defer=(0, 1, 2),
+                poll_spin_us=2000, lik_index=2, cand_aniso=2, chain_ppl=0,
+                beam_prepare=1, cand_aniso_max=8, cand_bound=1, cand_packed=1, cand_phase=0.5, cand_prune_coop=1, cand_record_parts=0,
+                cand_voxel_ratio=0.0, dda_overlay=1, grid_build_host=0, index_budget_bytes=-1, lik_group=0, lik_small=1,
+                lik_tiled=1, scan_presorted=0, strict_auto_max_bytes=0, strict_auto_min=28147, strict_chunk=0,
+                strict_exact_max=4096, timing_mask=0xFFFFFFFF, update_small_conformant=0, update_small_max=512)
+CHOICES = dict(poll_sync=(0, 1, 2), strict_order=(0, 1, 2, 2, 3), update_stage=(0, 1), update_zero_copy=(0, 1),
+               update_small=(0, 1), pf_fused=(0, 1), lik_coop=(0, 1), lik_defer=(0, 1, 2),
                overlap_models=(0, 1), batch_slice=(0, 64, 128), scan_order_device=(0, 512, 4096),
-               lik_tiled_min=(256, 1024), poll_spin_us=(0, 50, 2000), lik_index=(2, 2, 1, 0), cand_aniso=(2, 1, 0),
-               sort_one_launch=(0, 1), update_fold_done=(0, 1), poll_query_us=(5000, 200),
-               chain_ppl=(0, 1, 4))
+               lik_tiled_min=(256, 1024), poll_spin_us=(0, 50, 2000), lik_index=(2, 2, 0), cand_aniso=(2, 1, 0),
+               chain_ppl=(0, 1, 4),
+               beam_prepare=(1, 0), cand_aniso_max=(8, 3), cand_bound=(1, 0), cand_packed=(1, 0), cand_phase=(0.5, 0.0, 0.3), cand_prune_coop=(1, 0),
+               cand_record_parts=(0, 4, 8), cand_voxel_ratio=(0.0, 0.5, 0.3), dda_overlay=(1, 0), grid_build_host=(0, 1),
+               index_budget_bytes=(-1, 0, 2e7), lik_group=(0, 4, 8, 16, 32), lik_small=(1, 0), lik_tiled=(1, 0),
+               scan_presorted=(0, 1), strict_auto_max_bytes=(0, 1 << 18), strict_auto_min=(28147, 1500), strict_chunk=(0, 1024),
+               strict_exact_max=(4096, 0, 800), timing_mask=(0xFFFFFFFF, 1, 0), update_small_conformant=(0, 1),
+               update_small_max=(512, 64))
+# the options that select HOW the likelihood terms are added up: an engine compared bit for bit with another one needs them all
+SUM_OPTIONS = ("strict_order", "strict_exact_max", "strict_auto_min", "strict_auto_max_bytes", "strict_chunk")
 
 
 @pytest.fixture(scope="module")
@@ -92,9 +103,18 @@ def oracle_for(m, kind, cache):
     return cache["o"]
 
 
-def check_lik(mode, got_lik, got_q, want_lik, want_q, what):
-    np.testing.assert_array_equal(got_q, want_q, err_msg=what + ": match ratio")
+def lik_is_exact(opt, n_s):
+    """strict_order 1 / 3: always; the default (2): every scan of at most strict_exact_max points (round 6) — above it the sum may
+    still be exact (per-particle rows), which the tolerance accepts as well."""
+    mode = opt["strict_order"] if isinstance(opt, dict) else opt
     if mode in (1, 3):
+        return True
+    return isinstance(opt, dict) and mode == 2 and n_s <= opt["strict_exact_max"] and opt["strict_chunk"] == 0
+
+
+def check_lik(opt, got_lik, got_q, want_lik, want_q, what, n_s=1 << 30):
+    np.testing.assert_array_equal(got_q, want_q, err_msg=what + ": match ratio")
+    if lik_is_exact(opt, n_s):
         np.testing.assert_array_equal(got_lik, want_lik, err_msg=what + ": likelihood (float order)")
     else:
         np.testing.assert_allclose(got_lik, want_lik, rtol=RTOL_FP64, err_msg=what + ": likelihood")
@@ -177,7 +197,8 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         fresh.set_map(m.map_xyz, m.map_label, stamp=int(rng.integers(1, 1 << 30)), dist_weight=m.dw)
         fresh.set_likelihood_params(**m.lik)
         fresh.set_beam_params(**m.beam)
-        fresh.set_option("strict_order", m.opt["strict_order"])    # (the one option that selects the summation)
+        for k in SUM_OPTIONS:   # (the options that select the summation)
+            fresh.set_option(k, m.opt[k])
         a = eng.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
         b = fresh.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
         np.testing.assert_array_equal(a[1], b[1], err_msg="updated engine vs fresh engine: match ratio")
@@ -214,18 +235,18 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
                                       org if len(beam) else None)
         sel = sample_of(len(poses))
         wl, wq, wb = want_models(poses[sel], scan, beam, lab, org, lik_order(eng, len(scan)))
-        check_lik(m.opt["strict_order"], lik[sel], q[sel], wl, wq, "measure_batch")
+        check_lik(m.opt, lik[sel], q[sel], wl, wq, "measure_batch", len(scan))
         np.testing.assert_array_equal(b[sel], wb, err_msg="measure_batch: beam")
 
     def end_pending():
         nonlocal pending
         if pending is None:
             return
-        (lik, q, b), (sel, wl, wq, wb), mode = pending
+        (lik, q, b), (sel, wl, wq, wb), (opt_then, n_s_then) = pending
         eng.measure_batch_end()
         pending = None
         log.append("  _end of the batch begun earlier")
-        check_lik(mode, lik[sel], q[sel], wl, wq, "progressive batch")
+        check_lik(opt_then, lik[sel], q[sel], wl, wq, "progressive batch", n_s_then)
         np.testing.assert_array_equal(b[sel], wb, err_msg="progressive batch: beam")
 
     def do_progressive():
@@ -247,7 +268,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         # what the batch must deliver is fixed by the state at _begin (everything is enqueued there): later map / parameter
         # calls must not change it
         sel = sample_of(len(poses))
-        pending = (arrays, (sel,) + want_models(poses[sel], scan, beam, lab, org, order), m.opt["strict_order"])
+        pending = (arrays, (sel,) + want_models(poses[sel], scan, beam, lab, org, order), (dict(m.opt), len(scan)))
         if rng.random() < 0.5:
             end_pending()     # otherwise: abandoned until a later call ends it
 
@@ -274,10 +295,11 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         order = lik_order(eng, len(scan))
         s = scan if order is None else np.ascontiguousarray(scan[order])
         want = o.measure_update(poses, w0, s, beam, lab, org)
-        check_lik(m.opt["strict_order"], got["lik"], got["quality"], want["lik"], want["quality"], "measure_update")
+        check_lik(m.opt, got["lik"], got["quality"], want["lik"], want["quality"], "measure_update", len(scan))
         np.testing.assert_array_equal(got["beam"], want["beam"], err_msg="measure_update: beam")
         assert bool(got["restored"]) == bool(want["restored"])
-        if m.opt["strict_order"] == 1:
+        # (the default adds the weights in the reference's float order too, up to 1024 particles: host_measure.h: pf_float_order)
+        if m.opt["strict_order"] == 1 or (m.opt["strict_order"] == 2 and lik_is_exact(m.opt, len(scan)) and n_p <= 1024):
             np.testing.assert_array_equal(got["weights"], want["weights"], err_msg="measure_update: weights (float order)")
         else:
             np.testing.assert_allclose(got["weights"], want["weights"], rtol=1e-4, atol=1e-12, err_msg="measure_update: weights")
@@ -312,7 +334,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         eng.synchronize()
         order = lik_order(eng, n_s)
         wl, wq, wb = want_models(poses, samp_l, samp_b, lab_b, sc.origins, order)
-        check_lik(m.opt["strict_order"], d_l.cpu().numpy(), d_q.cpu().numpy(), wl, wq, "scan_finish + measure_device")
+        check_lik(m.opt, d_l.cpu().numpy(), d_q.cpu().numpy(), wl, wq, "scan_finish + measure_device", n_s)
         np.testing.assert_array_equal(d_b.cpu().numpy(), wb, err_msg="scan_finish + measure_device: beam")
 
     def do_resample():
@@ -353,7 +375,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
             grp_map = (m.map_id, m.map_version, m.dw)
         grp.set_likelihood_params(**m.lik)
         grp.set_beam_params(**m.beam)
-        for k in ("poll_sync", "strict_order", "update_stage", "update_zero_copy", "lik_coop"):
+        for k in ("poll_sync", "update_stage", "update_zero_copy", "lik_coop") + SUM_OPTIONS:
             grp.set_option(k, m.opt[k])
         poses, scan, beam, lab, org = pick_inputs(whole=True)
         if len(poses) < 2:
@@ -369,7 +391,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
             order = capi.scan_order_host(scan)   # (every rank of the group orders the same scan the same way)
         s = scan if order is None else np.ascontiguousarray(scan[order])
         want = o.measure_update(poses, w0, s, beam, lab, org)
-        check_lik(m.opt["strict_order"], got["lik"], got["quality"], want["lik"], want["quality"], "group measure_update")
+        check_lik(m.opt, got["lik"], got["quality"], want["lik"], want["quality"], "group measure_update", len(scan))
         np.testing.assert_array_equal(got["beam"], want["beam"], err_msg="group: beam")
         np.testing.assert_allclose(got["weights"], want["weights"], rtol=1e-4, atol=1e-12, err_msg="group: weights")
 

@@ -141,7 +141,7 @@ def test_c5_likelihood_and_beam_slice(c5_launch, c5, c5_oracle, engine):
     print("C5: worst default-mode relative error at 65 536 points: %.3g" % err)
     # north_star: per-particle weights within 1e-5 relative of the CPU path. Every float term is bit-identical to the
     # reference's; summed in fp64 the gap to the reference's sequential float sum is the reference's own rounding, a random
-    # walk that reaches 1e-5 at 65 536 points (round 2: 1.02e-5 over 800 particles, gate relaxed to 2e-5). From 32 768 points
+    # walk that reaches 1e-5 at 65 536 points (round 2: 1.02e-5 over 800 particles, gate relaxed to 2e-5). From 28 147 points
     # on the default mode (strict_order = 2) therefore replays the terms in the reference's order: no gap at all.
     assert engine.get_option("strict_order") == 2 and len(sc.scan_lik) >= engine.get_option("strict_auto_min")
     np.testing.assert_allclose(lik[C5_SLICE], wl, rtol=1e-5)

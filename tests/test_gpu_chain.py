@@ -76,7 +76,7 @@ def test_chain_is_the_reference_on_the_scan_in_engine_order(engine, oracle_kind,
 
 
 @pytest.mark.parametrize("opts", [dict(lik_group=4), dict(lik_group=8), dict(lik_group=16), dict(lik_coop=0),
-                                  dict(lik_index=1), dict(lik_index=0), dict(lik_defer=0), dict(cand_packed=0)])
+                                  dict(lik_index=0), dict(lik_defer=0), dict(cand_packed=0)])
 def test_every_kernel_family_chains_the_same_bits(engine, oracle_kind, opts):
     sc = make_scene(n=91, n_p=150, n_s=3000, seed=7)
     dw = (1.0, 1.0, 5.0)

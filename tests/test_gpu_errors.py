@@ -121,18 +121,20 @@ def test_automatic_strict_order_never_fails_an_update_over_memory(engine):
     reference's own rounding of the strict result — instead of failing."""
     import numpy as np
     from mcl_3dl_amd.synthetic import make_scene
-    sc = make_scene(n=91, n_p=300, n_s=4000, seed=99)
+    # (13 000 points: beyond the LDS rows of the per-particle kernels, which need no buffer at all — round 6)
+    sc = make_scene(n=91, n_p=300, n_s=13000, seed=99)
     engine.set_map(sc.map_xyz, sc.map_label, stamp=7700, dist_weight=(1.0, 1.0, 1.0))
     engine.set_likelihood_params()
+    auto_min = engine.get_option("strict_auto_min")
     try:
-        engine.set_option("strict_auto_min", 3000)
+        engine.set_option("strict_auto_min", 12500)
         strict, ratio_s, _ = engine.measure_batch(sc.poses, sc.scan_lik)
         before = engine.get_option("strict_auto_skipped")
-        engine.set_option("strict_auto_max_bytes", 1 << 20)   # 4000 x 304 x 4 B = 4.9 MB does not fit
+        engine.set_option("strict_auto_max_bytes", 1 << 20)   # 13 000 x 304 x 4 B = 15.8 MB does not fit
         loose, ratio_l, _ = engine.measure_batch(sc.poses, sc.scan_lik)
         assert engine.get_option("strict_auto_skipped") == before + 1
     finally:
-        engine.set_option("strict_auto_min", 32768)
+        engine.set_option("strict_auto_min", auto_min)
         engine.set_option("strict_auto_max_bytes", 0)
     np.testing.assert_array_equal(ratio_s, ratio_l)
     np.testing.assert_allclose(loose, strict, rtol=1e-5)

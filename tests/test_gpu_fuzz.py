@@ -2,11 +2,13 @@
 dist_weight, likelihood and beam parameters (grids, tolerances, label filter, penalty mode), scan sizes, origins and
 poses (including un-normalised quaternions and particles far outside the map), then compares
 
-  * likelihood score      bit-identical with strict_order=1; rtol 1e-5 (north_star; 3e-5 on scans > 512 points, see
-                          below) in the default fp64-accumulation mode          * match ratio   exact
+  * likelihood score      bit-identical in the DEFAULT mode (round 6: every scan of at most 4096 points is added up in the
+                          caller's order, as floats — strict_order 2) and with strict_order 1 / 3; the opt-out fp64 tree
+                          (strict_order 0): rtol 1e-5 (north_star), 3e-5 on scans > 512 points (see below)
+  * match ratio           exact
   * beam score            exact                                 * beam status + collided map point   exact
-  * the fused update      weights bit-identical (strict) / rtol 3e-5 (default), entropy rtol 1e-5, match-ratio min/max
-                          and `restored` exact
+  * the fused update      weights bit-identical (default and strict_order 1) / rtol 3e-5 (strict_order 0), entropy rtol 1e-5,
+                          match-ratio min/max and `restored` exact
 
 The parity tests elsewhere use the reference's default parameters on cube maps; this file is the guard for every
 other combination the plugin surface accepts (parameters.h:64-132).
@@ -148,10 +150,18 @@ def test_random_configuration(engine, oracle_kind, seed):
             np.testing.assert_array_equal(lik3, want3)
             np.testing.assert_array_equal(ratio3, want_q3)
             np.testing.assert_array_equal(want_q3, want_q)
-        # default: the same float terms summed in fp64. What is left is the rounding of the REFERENCE's own float
-        # running sum (bounded by n_s * 2^-24 relative, ~sqrt(n_s) * 2^-24 typical): inside north_star's 1e-5 for the
-        # scan sizes of BASELINE.json's configs (tests/test_gpu_parity.py, test_gpu_fullsize.py), up to ~2e-5 on the
-        # longest random scans here
+        # the DEFAULT (strict_order 2): scans of at most strict_exact_max = 4096 points — all of this file's — are added up as
+        # the reference adds them, by the per-particle kernels' LDS rows (float_chain.h) or the replay: the reference's bits
+        engine.set_option("strict_order", 2)
+        assert len(c["scan_lik"]) <= engine.get_option("strict_exact_max")
+        lik, ratio, beam = engine.measure_batch(c["poses"], c["scan_lik"], c["scan_beam"] if has_beam else None,
+                                                c["scan_beam_label"] if has_beam else None, c["origins"])
+        np.testing.assert_array_equal(lik, want_lik)
+        np.testing.assert_array_equal(ratio, want_q)
+        # the opt-out (strict_order 0): the same float terms summed in fp64. What is left is the rounding of the REFERENCE's
+        # own float running sum (bounded by n_s * 2^-24 relative, ~sqrt(n_s) * 2^-24 typical): inside north_star's 1e-5 for
+        # the scan sizes of BASELINE.json's configs (tests/test_gpu_parity.py, test_gpu_fullsize.py), up to ~2e-5 on the
+        # longest random scans here (match_dist_flat = 0.9 r makes most terms EQUAL: their roundings do not cancel)
         engine.set_option("strict_order", 0)
         lik, ratio, beam = engine.measure_batch(c["poses"], c["scan_lik"], c["scan_beam"] if has_beam else None,
                                                 c["scan_beam_label"] if has_beam else None, c["origins"])
@@ -175,12 +185,12 @@ def test_random_configuration(engine, oracle_kind, seed):
         want = o.measure_update(c["poses"], w0, c["scan_lik"], c["scan_beam"], c["scan_beam_label"], c["origins"])
         # the node's odometry-error factor with a zero error vector: NormalLikelihood(sigma = 1)(0) (nd.h:41-58)
         extra = np.full(len(w0), np.float32(1.0 / np.sqrt(2.0 * np.pi)), np.float32)
-        for strict in (1, 0):
+        for strict in (1, 2, 0):
             engine.set_option("strict_order", strict)
             got = engine.measure_update(c["poses"], w0, c["scan_lik"], c["scan_beam"] if has_beam else None,
                                         c["scan_beam_label"] if has_beam else None, c["origins"], extra=extra)
             assert got["restored"] == want["restored"]
-            if strict:
+            if strict:  # (the default too: at most 300 particles here — pf::measure's float sum runs inside the update)
                 np.testing.assert_array_equal(got["weights"], want["weights"])
             else:
                 np.testing.assert_allclose(got["weights"], want["weights"], rtol=3e-5, atol=0)

@@ -32,7 +32,7 @@ def test_candidate_index_on_irregular_maps(engine, name, dist_weight):
     # one "particle" (identity pose) per 5000-query chunk, each query its own 1-point-per-lane scan
     try:
         results = {}
-        for mode, ratio, phase in ((0, 0.5, 0.5), (1, 0.5, 0.5), (2, 0.5, 0.5), (2, 0.25, 0.0), (2, 1.0, 0.3)):
+        for mode, ratio, phase in ((0, 0.5, 0.5), (2, 0.5, 0.5), (2, 0.25, 0.0), (2, 1.0, 0.3)):
             engine.set_option("lik_index", mode)
             engine.set_option("cand_voxel_ratio", ratio)
             engine.set_option("cand_phase", phase)

@@ -1,4 +1,5 @@
-"""pf::measure as ONE kernel (pf_fused_kernel, <= 4096 particles on one GPU) against the partial + reduce + apply form:
+"""pf::measure as ONE kernel (pf_fused_kernel, <= 1024 particles on one GPU; both forms then add the weights in the reference's float
+order — float_chain.h — so the comparison covers that recurrence too) against the partial + reduce + apply form:
 the same arithmetic in the same association, so weights, entropy, ratio bounds and the restore rule are bit-identical."""
 import numpy as np
 import pytest
@@ -19,13 +20,11 @@ def test_fused_equals_split(engine, n, with_factors):
     ratio = rng.uniform(0.0, 1.0, n).astype(np.float32) if with_factors else None
     out = {}
     try:
-        engine.set_option("pf_fused_max", 4096)  # the kernel's own limit (the default switches to the split form above 1024)
         for fused in (0, 1):
             engine.set_option("pf_fused", fused)
             out[fused] = engine.pf_measure(w0, lik, beam, extra, ratio)
     finally:
         engine.set_option("pf_fused", 1)
-        engine.set_option("pf_fused_max", 1024)
     a, b = out[0], out[1]
     np.testing.assert_array_equal(a["weights"], b["weights"])
     assert a["restored"] == b["restored"]

@@ -108,10 +108,9 @@ def test_device_resident_and_sliced_apply(engine, n, dead):
 
 
 @pytest.mark.parametrize("n,zeros", [(1, 0), (300, 0), (4096, 0), (4097, 0), (50000, 0), (262144, 0), (5000, 40), (4096, 4096 - 3)])
-def test_prefix_recurrence_on_the_device_gives_the_host_paths_plan(engine, n, zeros):
-    """Option resample_prefix_device: the float recurrence `accum += p.probability_` (pf.h:193-197) run by one lane on the
-    device instead of on the host. Same floats in the same order -> the same plan, bit for bit; a weight of zero (a tie for
-    std::sort, pf.h:200) sends the call back to the host path, which reproduces libstdc++'s order."""
+def test_device_resident_begin_runs_the_references_prefix_recurrence(engine, n, zeros):
+    """resample_begin_device: the float recurrence `accum += p.probability_` (pf.h:193-197) over weights that live on the device
+    (4 bytes per particle come to the host, where the recurrence runs): pstep is the reference's float."""
     import torch
     rng = np.random.default_rng(n + zeros)
     w = rng.uniform(0.1, 1.0, n).astype(np.float32)
@@ -119,20 +118,10 @@ def test_prefix_recurrence_on_the_device_gives_the_host_paths_plan(engine, n, ze
         w[rng.choice(n, zeros, replace=False)] = 0.0
     w /= w.sum(dtype=np.float64).astype(np.float32)
     d_w = torch.from_numpy(w).cuda()
-    out = {}
-    try:
-        for dev in (0, 1):
-            engine.set_option("resample_prefix_device", dev)
-            pstep = engine.resample_begin_device(d_w, n)
-            src, dup, nd = engine.resample_plan(0, 0.37 * pstep)
-            out[dev] = (pstep, src.copy(), dup.copy(), nd)
-    finally:
-        engine.set_option("resample_prefix_device", 0)
-    assert out[0][0] == out[1][0] and out[0][3] == out[1][3]
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    np.testing.assert_array_equal(out[0][2], out[1][2])
-    # and the host path is the reference's own recurrence (checked against real pf.h above): one more look at pstep
+    pstep = engine.resample_begin_device(d_w, n)
+    src, dup, nd = engine.resample_plan(0, 0.37 * pstep)
+    assert len(src) == n
     acc = np.float32(0)
     for x in w:
         acc = np.float32(acc + x)
-    assert out[1][0] == np.float32(acc / np.float32(n))
+    assert pstep == np.float32(acc / np.float32(n))

@@ -71,16 +71,10 @@ def test_only_bits_below_end_bit_order_the_pairs(engine):
 
 @pytest.mark.parametrize("n", [2049, 5000, 16384, 31000, 32767, 32768, 32769])
 @pytest.mark.parametrize("end_bit", [8, 17, 22, 24, 32])
-def test_one_launch_per_pass_without_counting_launches(engine, n, end_bit):
-    """2049 .. 32 768 pairs: every work-group counts every work-group's digits itself (rs_pass_full_kernel) — same stable order
-    as the count + scatter form (option sort_full_pass = 0), few distinct keys included."""
+def test_mid_sizes_and_few_distinct_keys(engine, n, end_bit):
+    """2049 .. 32 769 pairs through the count + scatter launches: stable order, few distinct keys included."""
     rng = np.random.default_rng(n * 3 + end_bit)
     keys = rng.integers(0, 2**32 - 1, n, dtype=np.uint64, endpoint=True).astype(np.uint32)
     few = rng.integers(0, 5, n, dtype=np.uint64).astype(np.uint32) * np.uint32(1 << (end_bit - 3))
-    try:
-        for full in (1, 0):
-            engine.set_option("sort_full_pass", full)
-            check(engine, keys, None, end_bit)
-            check(engine, few, rng.integers(0, 2**32 - 1, n, dtype=np.uint64).astype(np.uint32), end_bit)
-    finally:
-        engine.set_option("sort_full_pass", 0)
+    check(engine, keys, None, end_bit)
+    check(engine, few, rng.integers(0, 2**32 - 1, n, dtype=np.uint64).astype(np.uint32), end_bit)

@@ -66,7 +66,7 @@ def test_the_automatic_mode_chunks_from_twice_the_chunk_size_and_other_modes_tak
     engine.set_option("strict_chunk", 16384)
     o = oracle_for(oracle_kind, sc, dw)
     want_lik, want_q = o.likelihood_measure(sc.poses[:64], sc.scan_lik)
-    # default: strict_order 2 replays from 32 768 points, in chunks of 16 384
+    # default: strict_order 2 replays from strict_auto_min = 28 147 points, in chunks of 16 384
     lik, ratio, _ = engine.measure_batch(sc.poses[:64], sc.scan_lik)
     assert int(engine.get_option("scan_chunk_in_use")) == 16384
     np.testing.assert_array_equal(lik, want_lik)

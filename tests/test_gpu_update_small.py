@@ -59,7 +59,7 @@ def test_one_launch_equals_the_separate_kernels(engine, scene, n_p, n_s, n_b, ex
     assert np.count_nonzero(b["lik"]) > 0
 
 
-@pytest.mark.parametrize("lik_index", [0, 1])
+@pytest.mark.parametrize("lik_index", [0])
 @pytest.mark.parametrize("n_p,n_s,n_b", [(64, 96, 3), (300, 400, 20)])
 def test_other_indices(engine, scene, lik_index, n_p, n_s, n_b):
     a, b = run_both(engine, scene, n_p, n_s, n_b, True, lik_index=lik_index, stamp=8101)

@@ -41,19 +41,17 @@ def run_modes(engine, sc, n_p, n_s, n_b, extra, modes, origins=None, beam_label=
     lab = (sc.scan_beam_label[:n_b] if beam_label is None else beam_label) if n_b else None
     out = []
     try:
-        for stage, zero_copy, tail in modes:
+        for stage, zero_copy in modes:
             engine.set_option("update_stage", stage)
             engine.set_option("update_zero_copy", zero_copy)
-            engine.set_option("pf_tail", tail)
             out.append(engine.measure_update(poses, w0, lik, sc.scan_beam[:n_b] if n_b else None, lab, org, extra=ex))
     finally:
         engine.set_option("update_stage", 1)
         engine.set_option("update_zero_copy", 1)
-        engine.set_option("pf_tail", 1)
     return out
 
 
-ALL_MODES = [(0, 0, 0), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 0, 1)]
+ALL_MODES = [(0, 0), (1, 1), (1, 0)]
 
 
 @pytest.mark.parametrize("n_p,n_s,n_b", [(64, 96, 3), (64, 1000, 32), (700, 300, 0), (513, 2048, 40), (1024, 2049, 0),
@@ -72,12 +70,12 @@ def test_staged_update_equals_the_general_path(engine, scene, n_p, n_s, n_b, ext
 
 
 def test_full_c2_scan_with_all_particles(engine, scene):
-    """16 384 points (stage_pack_kernel + the chip-wide sort) x 9000 particles (above pf_tail's 8192)."""
+    """16 384 points (stage_pack_kernel + the chip-wide sort) x 9000 particles."""
     configure(engine, scene, 0, stamp=9200, dist_weight=(1.0, 1.0, 1.0))
-    res = run_modes(engine, scene, 9000, 16384, 0, True, [(0, 0, 0), (1, 1, 1), (1, 0, 1)])
+    res = run_modes(engine, scene, 9000, 16384, 0, True, [(0, 0), (1, 1), (1, 0)])
     same(res[0], res[1])
     same(res[0], res[2])
-    res = run_modes(engine, scene, 4096, 16384, 0, False, [(0, 0, 0), (1, 1, 1)])
+    res = run_modes(engine, scene, 4096, 16384, 0, False, [(0, 0), (1, 1)])
     same(res[0], res[1])
 
 
@@ -120,11 +118,9 @@ def test_restore_rule(engine, scene):
     try:
         for stage in (0, 1):
             engine.set_option("update_stage", stage)
-            engine.set_option("pf_tail", stage)
             outs.append(engine.measure_update(far, w0, sc.scan_lik[:600], None, None, sc.origins))
     finally:
         engine.set_option("update_stage", 1)
-        engine.set_option("pf_tail", 1)
     for o in outs:
         assert o["restored"]
         np.testing.assert_array_equal(o["weights"], w0)
@@ -136,7 +132,7 @@ def test_arrays_in_the_callers_page_locked_block(engine, scene):
     sc = scene
     n_p, n_s, n_b = 3000, 5000, 64
     configure(engine, sc, n_b, stamp=9400)
-    ref = run_modes(engine, sc, n_p, n_s, n_b, False, [(0, 0, 0)])[0]
+    ref = run_modes(engine, sc, n_p, n_s, n_b, False, [(0, 0)])[0]
     poses = engine.host_array((n_p, 7))
     w = engine.host_array(n_p)
     lik_xyz = engine.host_array((n_s, 3))
@@ -167,57 +163,3 @@ def test_arrays_in_the_callers_page_locked_block(engine, scene):
     np.testing.assert_array_equal(lik2, ref["lik"])
     for a in (poses, w, lik_xyz, beam_xyz, beam_lab, org, out_lik, out_ratio, out_beam):
         engine.host_free(a)
-
-
-def test_device_resident_update_with_and_without_the_tail(engine, scene):
-    """mcl3dl_hip_update_device: the two-launch tail (weights folded into lik_finalize / the per-particle kernel, pf_norm_kernel)
-    against lik_finalize + pf_partial + pf_reduce + pf_apply (and the single work-group form up to 1024 particles), tiled and
-    per-particle likelihood kernels in front of it."""
-    sc = scene
-    configure(engine, sc, 16, stamp=9500)
-    dev = torch.device("cuda", 0)
-    for n_p, n_s, n_b in [(600, 300, 16), (1000, 2048, 0), (4096, 2048, 16), (8192, 700, 3), (5000, 96, 0), (4096, 96, 3)]:
-        engine.upload_scan(sc.scan_lik[:n_s], sc.scan_beam[:n_b] if n_b else None, sc.scan_beam_label[:n_b] if n_b else None,
-                           sc.origins)
-        d_pose = torch.from_numpy(np.ascontiguousarray(sc.poses[:n_p])).to(dev)
-        got = []
-        try:
-            for tail in (0, 1):
-                engine.set_option("pf_tail", tail)
-                d_w = torch.full((n_p,), 1.0 / n_p, dtype=torch.float32, device=dev)
-                d_lik, d_ratio, d_beam = (torch.zeros(n_p, dtype=torch.float32, device=dev) for _ in range(3))
-                d_stats = torch.zeros(4, dtype=torch.float32, device=dev)
-                for _ in range(2):   # twice: the ticket is left zero for the next launch
-                    d_w.fill_(1.0 / n_p)
-                    torch.cuda.synchronize()   # (torch's stream is not the engine's)
-                    engine.update_device(d_pose, n_p, d_w, d_stats, d_lik=d_lik, d_ratio=d_ratio, d_beam=d_beam)
-                    engine.synchronize()
-                got.append([t.cpu().numpy() for t in (d_w, d_lik, d_ratio, d_beam, d_stats)])
-        finally:
-            engine.set_option("pf_tail", 1)
-        for x, y in zip(got[0], got[1]):
-            np.testing.assert_array_equal(x, y)
-        assert abs(float(got[1][0].astype(np.float64).sum()) - 1.0) < 1e-5
-
-
-@pytest.mark.parametrize("n_p,strict", [(64, 0), (1024, 0), (1025, 0), (3000, 1), (3000, 3)])
-def test_completion_word_folded_into_the_last_kernel(engine, scene, n_p, strict):
-    """Option update_fold_done (off by default: measured slower, profiles/r05j_fold_ab.txt): the fused pf::measure / the one-block
-    apply writes the polled completion word itself. Same bits as with the one-thread kernel behind the update, call after call,
-    and a wait that follows a call of another kind (no folded word) still launches its own."""
-    sc, n_s, n_b = scene, 3000, 256
-    configure(engine, sc, n_b, stamp=7300 + n_p + strict)
-    poses, w0 = sc.poses[:n_p], np.full(n_p, 1.0 / n_p, np.float32)
-    args = (poses, w0, sc.scan_lik[:n_s], sc.scan_beam[:n_b], sc.scan_beam_label[:n_b], sc.origins)
-    saved = engine.get_option("strict_order")
-    try:
-        engine.set_option("strict_order", strict)
-        want = engine.measure_update(*args)
-        engine.set_option("update_fold_done", 1)
-        for _ in range(3):
-            same(engine.measure_update(*args), want)
-            lik, _, _ = engine.measure_batch(poses, sc.scan_lik[:n_s])   # (its wait: a word of its own)
-            np.testing.assert_array_equal(lik, want["lik"])
-    finally:
-        engine.set_option("update_fold_done", 0)
-        engine.set_option("strict_order", saved)
