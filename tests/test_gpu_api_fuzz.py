@@ -55,7 +55,8 @@ CHOICES = dict(poll_sync=(0, 1, 2), strict_order=(0, 1, 2, 2, 3), update_stage=(
                strict_exact_max=(4096, 0, 800), timing_mask=(0xFFFFFFFF, 1, 0), update_small_conformant=(0, 1),
                update_small_max=(512, 64))
 # the options that select HOW the likelihood terms are added up: an engine compared bit for bit with another one needs them all
-SUM_OPTIONS = ("strict_order", "strict_exact_max", "strict_auto_min", "strict_auto_max_bytes", "strict_chunk")
+# (scan_presorted: with strict_order 3 the sum follows the device scan array's order — the caller's own when it is taken as it is)
+SUM_OPTIONS = ("strict_order", "strict_exact_max", "strict_auto_min", "strict_auto_max_bytes", "strict_chunk", "scan_presorted")
 
 
 @pytest.fixture(scope="module")
@@ -387,7 +388,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
                                  org if len(beam) else None, extra=np.full(n_p, ND0, np.float32))
         o = oracle_for(m, kind, cache)
         order = None
-        if m.opt["strict_order"] == 3 and len(scan):
+        if m.opt["strict_order"] == 3 and len(scan) and not m.opt["scan_presorted"]:
             order = capi.scan_order_host(scan)   # (every rank of the group orders the same scan the same way)
         s = scan if order is None else np.ascontiguousarray(scan[order])
         want = o.measure_update(poses, w0, s, beam, lab, org)

@@ -136,11 +136,13 @@ def test_a_voxel_with_more_than_63_candidates_keeps_the_plain_words(engine):
     try:
         engine.set_option("lik_index", 0)
         engine.set_option("lik_tiled_min", 256)
+        engine.set_option("strict_order", 0)   # (like run(): the tiled kernel's fp64 sums on both sides)
         engine.set_map(sc.map_xyz, sc.map_label, stamp=9101, dist_weight=(1.0, 1.0, 5.0))
         want = engine.measure_batch(sc.poses[:64], sc.scan_lik[:2048])
     finally:
         engine.set_option("lik_index", 2)
         engine.set_option("lik_tiled_min", 1024)
+        engine.set_option("strict_order", 2)
     np.testing.assert_array_equal(got[0], want[0])
     np.testing.assert_array_equal(got[1], want[1])
 

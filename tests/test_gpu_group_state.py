@@ -86,7 +86,7 @@ def test_filter_iterations_over_resident_shards(engine, scene, start, devices, c
                 np.testing.assert_array_equal(got["weights"], want["weights"])
                 assert got["entropy"] == want["entropy"]
             else:
-                np.testing.assert_allclose(got["weights"], want["weights"], rtol=2e-7)
+                np.testing.assert_allclose(got["weights"], want["weights"], rtol=1e-6)  # (one GPU adds up to 1024 weights as the reference does, float by float; shards add theirs in an fp64 all-reduce)
                 np.testing.assert_allclose(got["entropy"], want["entropy"], rtol=1e-6)
             # the weights stayed on the devices
             st_dev, w_dev = g.download_state()

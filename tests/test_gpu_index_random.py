@@ -55,12 +55,13 @@ def test_candidate_index_on_irregular_maps(engine, name, dist_weight):
     for key, val in results.items():
         np.testing.assert_array_equal(val, base, err_msg=str(key))
     assert base[:, 1].max() > 0.2  # the case exercises matches ...
-    # ... and the sums agree with the stand-alone radius search: sum over found of (r - d)
+    # ... and the sums ARE those of the stand-alone radius search: (r - d) over the found, added as the reference adds them —
+    # float, sequentially, in the order of the queries (round 6: the per-particle kernel's caller-order rows, the default)
     idx, sq = engine.radius_search(queries, 0.2)
     want = 0.0
     for c in range(0, len(queries), 5000):
         f = idx[c:c + 5000] >= 0
         d = np.sqrt(sq[c:c + 5000][f]).astype(np.float32)
         terms = (np.float32(0.2) - d).astype(np.float32)
-        np.testing.assert_allclose(base[c // 5000, 0], terms.astype(np.float64).sum(), rtol=2e-7)
+        assert base[c // 5000, 0] == np.cumsum(terms, dtype=np.float32)[-1] if len(terms) else base[c // 5000, 0] == 0.0
         assert base[c // 5000, 1] == np.float32(f.sum()) / np.float32(5000)

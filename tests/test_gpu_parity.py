@@ -397,7 +397,7 @@ def test_sharded_update_protocol_on_one_gpu(engine, oracle_kind, scene_c1):
         assert s[1] == np.float32(want["match_ratio_min"]) and s[2] == np.float32(want["match_ratio_max"])
         assert s[3] == 0.0
     whole = engine.measure_update(sc.poses, w0, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
-    np.testing.assert_allclose(got_w, whole["weights"], rtol=2e-7)
+    np.testing.assert_allclose(got_w, whole["weights"], rtol=1e-6)  # (the whole update adds its 64 weights as the reference does; the sharded protocol in fp64)
 
 
 @pytest.mark.parametrize("dist_weight", [(1.0, 1.0, 1.0), (1.0, 1.0, 5.0)])
