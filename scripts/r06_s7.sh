@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the option strict_pipeline it sets existed only in that session: the pipelined replay was measured and reverted, profiles/r06i_replay_pipeline_ab.txt)
 # round 6 session 7: the caller-order replay pipelined over particle batches, the replay of batch b - 1 by
 # the light (256-thread, 16 KB) form of the replay kernel beside the evaluation of batch b — against one replay behind everything
 O=gpurun_out/r06i; mkdir -p $O
