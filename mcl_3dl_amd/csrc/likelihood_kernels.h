@@ -387,9 +387,29 @@ __device__ inline float quad_round_wide(const float4* recs, uint32_t bytes32, ui
 }
 
 // w[e] = the w word of part j of record e, as quad_round returns them: w[j] is the word of this lane's own record
+// (two levels of selects on the bits of j — three v_cndmask; the chain of comparisons j == 0 ? ... : j == 1 ? ... compiled into a
+// dozen exec-mask instructions per evaluation)
 __device__ inline uint32_t own_word(const uint32_t (&w)[4], int j)
 {
-  return j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
+  const bool odd = (j & 1) != 0, high = (j & 2) != 0;
+  const uint32_t lo = odd ? w[1] : w[0], hi = odd ? w[3] : w[2];
+  return high ? hi : lo;
+}
+
+// likelihood.cpp:128-132 for one evaluation: dist = r - std::max(root, flat), and the term dist * match_weight — 0 * match_weight
+// for an evaluation without a match (dist < 0: the -1 of a lane without a neighbour, or a root beyond r - flat)
+__device__ inline float lik_dist(const LikParams& prm, float root)
+{
+  // root is a finite, non-negative float here: v_max_f32 (IEEE maxNum) returns what std::max(root, flat) returns for every flat,
+  // a NaN parameter included (both give root) — ONE instruction; fmaxf() costs two canonicalising v_max on top of its own, the
+  // compare-and-select form a v_mov of the uniform operand
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(root), "s"(prm.match_dist_flat));
+  return prm.match_dist_min - m;
+}
+__device__ inline float lik_term(const LikParams& prm, float dist, bool matched)
+{
+  return matched ? dist * prm.match_weight : 0.0f * prm.match_weight;
 }
 
 // vrec = the lane's own record index (0 for a lane without one: it reads record 0 and ignores the answer); returns
@@ -490,14 +510,12 @@ __device__ inline float eval_coop(const RecGrid& rg, const LikParams& prm, const
     if (valid && d2 < prm.r2)
     {
       const float s = sqrt_in_radius(d2);
-      // likelihood.cpp:128 `s > flat ? s : flat`: s is a finite non-negative root here, so v_max_f32 gives the same float
-      dist = prm.match_dist_min - fmaxf(s, prm.match_dist_flat);
+      dist = lik_dist(prm, s);
     }
   }
-  // likelihood.cpp:129 `if (dist < 0.0) continue;` — one compare decides both the count and the term; max(dist, 0) * w
-  // is dist * w for a match (dist >= 0) and 0 otherwise (the -1 of a lane without a neighbour)
+  // likelihood.cpp:129 `if (dist < 0.0) continue;` — one compare decides both the count and the term
   matched = !(dist < 0.0f);
-  return fmaxf(dist, 0.0f) * prm.match_weight;
+  return lik_term(prm, dist, matched);
 }
 
 // One particle's likelihood-field score by one work-group of BLOCK threads: lanes stride the (Morton-ordered) scan.
@@ -835,11 +853,11 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
     if (valid && !over && best < prm.r2)
     {
       const float s = sqrt_in_radius(best);
-      dist = prm.match_dist_min - fmaxf(s, prm.match_dist_flat);
+      dist = lik_dist(prm, s);
     }
   }
   matched = !(dist < 0.0f);
-  return fmaxf(dist, 0.0f) * prm.match_weight;
+  return lik_term(prm, dist, matched);
 }
 
 // One dense overflow round for entries [base, base + n) of this wavefront's queue, n <= 64 (all lanes arrive; lane l takes
@@ -875,11 +893,11 @@ __device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, cons
   if (act && best < prm.r2)
   {
     const float s = sqrt_in_radius(best);
-    dist = prm.match_dist_min - fmaxf(s, prm.match_dist_flat);
+    dist = lik_dist(prm, s);
   }
   if (act)
   {
-    s_term[k][t_src] = fmaxf(dist, 0.0f) * prm.match_weight;
+    s_term[k][t_src] = lik_term(prm, dist, !(dist < 0.0f));
     if (!(dist < 0.0f))
       atomicAdd(&s_cnt[k][wave], 1u);
   }
