@@ -998,7 +998,7 @@ def main():
         elif small:
             kernel_name = "likelihood_small_kernel<"
         else:
-            wide = args.lik_index == 2 and n_s > 512 and n_p <= 64
+            wide = args.lik_index == 2 and n_s > 512 and n_p <= 512
             kernel_name = "likelihood_kernel<%d, %d, false>" % (64 if n_s <= 128 else 1024 if wide else 256, args.lik_index)
             if one_launch:
                 # the whole update as ONE launch (update_kernels.h): that kernel is what was timed, and what the counters are of

@@ -99,7 +99,11 @@ struct mcl3dl_hip_ctx
   int lik_tiled = 1;       // 1 = tile-major XCD-aware kernel for large scans, 0 = one work-group per particle always
   int lik_tiled_min = 1024;  // scans of at least this many points take the tiled kernel
   int lik_group = 0;       // particles per work-group of the tiled kernel: 0 = chosen per launch, or 4 / 8 / 16 / 32
-  int lik_wide_max_particles = 64;  // up to this many particles a scan of > 512 points gets 1024 threads per particle (C1: 9.9 -> 7.5 us; no gain from 128 particles up)
+  // up to this many particles a scan of > 512 points gets 1024 threads per particle: 512 x 16 wavefronts are ONE round of the
+  // chip's 8192 wavefront slots (profiles/r06m_wide_threshold.txt: 64 x 4096 27 -> 16 us, 300 x 3000 27 -> 22, 512 x 4096 34 -> 29;
+  // 1024 particles and more: 1.2 x SLOWER). Round 2 had set 64 from scans of ~1000 points; since round 6 this kernel serves
+  // every default-mode scan up to 4096 points below 2048 particles (caller-order rows)
+  int lik_wide_max_particles = 512;
   int lik_coop = 1;        // tiled kernel: 1 = quad-cooperative record fetch + VALU-trimmed evaluation (same results)
   DevBuf lik_partial_sum, lik_partial_cnt;
   int pf_fused = 1;        // 1 = pf::measure as ONE kernel up to pf_fused_max particles on one GPU (same bits, two launches fewer)

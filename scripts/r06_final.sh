@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 5, the final sessions (one gpurun call per part: profiles are long). usage: r05_final.sh <part>
+# round 6, the final sessions (one gpurun call per part: profiles are long). usage: r05_final.sh <part>
 #   prof_a : kernel stats + PMC passes of C1, C2, C2 with in-kernel sums (C2c), C2 on the map of centroids (C2j), C3
 #   prof_b : ... of C4, C5, C5 with in-kernel sums (C5c)
 #   bench  : the bench line of every BASELINE configuration (+ C2 / C5 with strict_order 3, C2 with strict_order 1) and the suite
 part=${1:-bench}
-O=gpurun_out/r05z; mkdir -p $O
+O=gpurun_out/r06z; mkdir -p $O
 prof() { # tag, bench args
-  bash profiles/run_profiles.sh r05z_$1 $2 > $O/prof_$1.log 2>&1
-  cp gpurun_out/prof_r05z_$1/r05z_$1_kernel_stats.csv gpurun_out/prof_r05z_$1/r05z_$1_pmc_summary.csv $O/ 2>/dev/null
+  bash profiles/run_profiles.sh r06z_$1 $2 > $O/prof_$1.log 2>&1
+  cp gpurun_out/prof_r06z_$1/r06z_$1_kernel_stats.csv gpurun_out/prof_r06z_$1/r06z_$1_pmc_summary.csv $O/ 2>/dev/null
   echo "profile $1: $(tail -1 $O/prof_$1.log)"
 }
 line() { # name, bench args
