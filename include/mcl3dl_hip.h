@@ -517,6 +517,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *   "strict_chunk"      0 (default) = a replay keeps the terms of the whole scan; a point count >= 1024 = scans of at least two such
  *                       chunks are ordered chunk by chunk of the caller's order and replayed with two term buffers (C5: 4.3 GB
  *                       instead of 17 GB, 27.9 instead of 25.6 ms). Same bits. Read-only "scan_chunk_in_use".
+ *                       (Mode 3 launches of one DEVICE are serialised across contexts — an event per device —: the hand-off between
+ *                       tile work-groups relies on in-order dispatch inside one launch, and two such kernels side by side could starve
+ *                       each other's producers. The poll is bounded all the same: ~1 s, then error -2 for that update.)
  *   "scan_presorted"    1 = the caller holds its likelihood scans in the engine's order already (mcl3dl_hip_scan_order_host): no
  *                       ordering launches, the permutation is the identity, and the exact modes follow the caller's own order.
  *   "chain_ppl"         strict_order 3: scan tiles per work-group (0 = four for few particles on long scans, 1, 4). Same bits.

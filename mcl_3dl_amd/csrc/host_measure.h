@@ -222,6 +222,21 @@ int ensure_chain(mcl3dl_hip_ctx* ctx, size_t n_p, int n_tiles, uint32_t* tag0)
   return 0;
 }
 
+// strict_order = 3 launches of ONE device are serialised across contexts: the hand-off makes progress only while a
+// consumer's producer is resident or done, which dispatch in block-index order guarantees inside one launch — but two chain kernels
+// running side by side (two contexts, or two ranks of a device group on one GPU) could fill each other's XCDs with polling
+// consumers (bounded: ~1 s, then error -2). A process-wide event per device: a chain launch waits for the previous one's.
+struct ChainSerial
+{
+  std::mutex m;
+  hipEvent_t ev = nullptr;
+};
+inline ChainSerial& chain_serial(int device)
+{
+  static ChainSerial per_device[64];
+  return per_device[(device >= 0 && device < 64) ? device : 0];
+}
+
 // rows of G floats per particle group: what the float-order replay of ns points x n_p particles stores
 size_t strict_terms_bytes(size_t n_p, int ns, int group_size)
 {
@@ -599,6 +614,21 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           const bool defer = coop && lik_defer_active(ctx);
           if (plan.chain)
           {
+            ChainSerial& cs = chain_serial(ctx->device);
+            std::lock_guard<std::mutex> chain_lock(cs.m);
+            if (cs.ev)
+              HIP_TRY(hipStreamWaitEvent(ctx->stream, cs.ev, 0));
+            else
+              HIP_TRY(hipEventCreateWithFlags(&cs.ev, hipEventDisableTiming));
+            struct ChainDone  // (recorded behind the launch on every way out of this block)
+            {
+              hipEvent_t ev;
+              hipStream_t st;
+              ~ChainDone()
+              {
+                (void)hipEventRecord(ev, st);
+              }
+            } chain_done{ cs.ev, ctx->stream };
             float* lik_out = d_lik;
             if (!lik_out)  // (only the match ratio was asked for: the sum still has somewhere to go)
             {

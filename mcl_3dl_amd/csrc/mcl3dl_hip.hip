@@ -12,6 +12,7 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>

@@ -39,6 +39,21 @@ __global__ __launch_bounds__(64) void bench_kernel(const float* terms, int n, fl
   float s;
   if (MODE == 0)
     s = serial_chain(row, n);
+  else if (MODE == 2)
+  {
+    // the plain chain with ONE active lane (does a wave64 instruction whose upper half is inactive issue faster?)
+    s = 0.0f;
+    if (threadIdx.x == 0)
+      s = serial_chain(row, n);
+    s = __shfl(s, 0);
+  }
+  else if (MODE == 3)
+  {
+    s = 0.0f;
+    if (threadIdx.x < 32)
+      s = serial_chain(row, n);
+    s = __shfl(s, 0);
+  }
   else
     s = seq_sum_wave(row, n, threadIdx.x);
   const long long t1 = __builtin_readcyclecounter();
@@ -102,6 +117,21 @@ int main()
       printf("n %5d, %4d work-groups: serial %8.0f cycles (%.2f / term), launch %.1f us | wavefront %8.0f cycles (%.2f / term), launch %.1f us | x %.2f | same bits %d\n",
              n, blocks, cyc[0], cyc[0] / n, ms[0] * 1e3, cyc[1], cyc[1] / n, ms[1] * 1e3, cyc[0] / cyc[1], res[0] == res[1]);
     }
+  }
+  // one active lane / the lower half only
+  for (int n : { 256, 1000 })
+  {
+    std::vector<float> t(n, 0.4f);
+    hipMemcpy(d_terms, t.data(), n * 4, hipMemcpyHostToDevice);
+    const size_t lds = chain_row_floats(n) * 4;
+    long long c0, c2, c3;
+    hipLaunchKernelGGL(bench_kernel<0>, dim3(1), dim3(64), lds, 0, d_terms, n, d_out, d_cyc);
+    hipMemcpy(&c0, d_cyc, 8, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(bench_kernel<2>, dim3(1), dim3(64), lds, 0, d_terms, n, d_out, d_cyc);
+    hipMemcpy(&c2, d_cyc, 8, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(bench_kernel<3>, dim3(1), dim3(64), lds, 0, d_terms, n, d_out, d_cyc);
+    hipMemcpy(&c3, d_cyc, 8, hipMemcpyDeviceToHost);
+    printf("n %5d serial chain: all 64 lanes %lld cycles | lane 0 only %lld | lanes 0-31 %lld\n", n, c0, c2, c3);
   }
   return 0;
 }
