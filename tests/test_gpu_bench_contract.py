@@ -112,6 +112,15 @@ def test_headline_workload_gates():
     u = d["update_8d"]
     assert 0 < u["overhead_over_device_resident_ms"] < 0.075, u
     assert d["value_8d"] == u["value"] > 2.0e11
+    # round 6: the metric's own region at the top level beside `value`, and SURVEY 8d's own fraction
+    # spelled out — above 1, because the canonical 27-cell bytes are never read
+    assert d["ms_per_step_8d"] == u["ms_per_update"] > d["ms_per_step"] > 0
+    r = d["roofline"]
+    assert r["frac_algorithmic_hbm"] > 5.0 and "not read" in r["frac_algorithmic_hbm_note"]
+    # the committed counters belong to THIS tree's kernels (bench.py refuses a summary whose source hashes differ): a kernel
+    # edit without a new profiles/ session would leave the driver's line without a roofline
+    assert r["frac"] is not None and r["counters_source"].startswith("profiles/r06"), (r["counters_source"], r["counters_note"])
+    assert r["bound"] == "valu_issue" and 0.4 < r["frac"] < 0.8, r["frac"]
     mj = d["map_jitter"]
     assert mj["vs_lattice"] < 1.40, mj
     mu = d["map_update"]
