@@ -198,8 +198,10 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         fresh.set_map(m.map_xyz, m.map_label, stamp=int(rng.integers(1, 1 << 30)), dist_weight=m.dw)
         fresh.set_likelihood_params(**m.lik)
         fresh.set_beam_params(**m.beam)
-        for k in SUM_OPTIONS:   # (the options that select the summation)
-            fresh.set_option(k, m.opt[k])
+        # (every option of the moment: since round 6 kernel SELECTION decides the summation too — a per-particle kernel adds in the
+        # caller's order where the tiled kernel's default is the fp64 tree)
+        for k, v in m.opt.items():
+            fresh.set_option(k, v)
         a = eng.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
         b = fresh.measure_batch(sc.poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins)
         np.testing.assert_array_equal(a[1], b[1], err_msg="updated engine vs fresh engine: match ratio")
