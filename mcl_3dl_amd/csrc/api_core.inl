@@ -569,14 +569,47 @@ int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_
 // ---- host entry points -------------------------------------------------------------------------------------
 namespace
 {
+// is pf::measure of n_p particles on this GPU the split form with the fp64 sum of the weights? Then launch_measure may leave the
+// sum over the tiled kernel's per-tile partials to lik_pf_partial_kernel (LikTail).
+bool pf_takes_tiles(const mcl3dl_hip_ctx* ctx, size_t n_p)
+{
+  const bool fused = n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->pf_fused;
+  return !fused && !pf_float_order(ctx, n_p) && n_p <= static_cast<size_t>(1024) * PF_BLOCK;  // (one particle per thread of the grid)
+}
+
 // pf::measure on one GPU: the fused single-work-group kernel up to pf_fused_max particles (default 1024; the kernel takes up
-// to PF_FUSED_MAX = 4096 — same bits as the split form, two launches fewer), partial + reduce + apply beyond, or with strict_order (which replaces the sum between the two).
+// to PF_FUSED_MAX = 4096 — same bits as the split form), the split form beyond.
 // ho (optional): page-locked arrays the last kernel writes the results to as well (PfEmit).
-int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, const float* d_beam, const float* d_extra,
-                      const float* d_ratio, size_t n_p, float* d_stats4, const PfEmit* ho = nullptr)
+// The split form on one GPU with the fp64 sum of the weights is TWO launches since round 6 (five with lik_finalize_kernel in
+// front until then): lik_pf_partial_kernel / pf_partial_kernel, then pf_apply_kernel whose every work-group runs pf_reduce_kernel's
+// reduction itself. Same arithmetic in the same association as the launches apart (the multi-GPU protocol still runs them apart,
+// the all-reduce between them): the same bits. Measured on one box, C2: 0.2344 -> 0.2303 ms per update, C3 0.3448 -> 0.3409
+// (profiles/r06p_tail_ab.txt); the earlier forms of the idea that LOST are in profiles/r06o_pf_two_launch_ab.txt.
+int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float* d_beam, const float* d_extra,
+                      float* d_ratio, size_t n_p, float* d_stats4, const PfEmit* ho = nullptr, const LikTail* tail = nullptr)
 {
   const PfEmit emit = ho ? *ho : PfEmit{};
   const bool float_w = pf_float_order(ctx, n_p);
+  if (tail && tail->pending)
+  {
+    // launch_measure left the tiled kernel's per-tile partials where they are: lik_finalize_kernel's sum and pf_partial_kernel's
+    // product in one launch, one wavefront of pf_partial_kernel's blocks per work-group (pf_kernels.h)
+    const int n_waves = static_cast<int>((n_p + 63) / 64), nb = pf_blocks(n_p);
+    TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+    TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 16 * nb));  // (whole blocks of four wavefront partials)
+    const LikTiles lt{ ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), tail->n_tiles, static_cast<int>(ctx->n_s),
+                       d_lik, d_ratio, tail->beam_fill ? d_beam : static_cast<float*>(nullptr) };
+    EventPair ep{};
+    TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+    hipLaunchKernelGGL(lik_pf_partial_kernel, dim3(n_waves), dim3(256), 0, ctx->stream, lt, d_weight, d_beam, d_extra,
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
+    hipLaunchKernelGGL(pf_apply_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
+                       static_cast<int>(n_p), 1, static_cast<const double*>(nullptr), d_stats4, emit, d_lik, d_ratio, d_beam,
+                       ctx->block_partials.as<double>(), nb, n_waves, ctx->partial4.as<double>());
+    TRY(timing_end(ctx, ep));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
@@ -588,6 +621,23 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, const float* d_lik, 
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  if (!float_w)
+  {
+    const int nb = pf_blocks(n_p);
+    TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+    TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 4 * nb));
+    EventPair ep{};
+    TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+    hipLaunchKernelGGL(pf_partial_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
+    hipLaunchKernelGGL(pf_apply_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
+                       static_cast<int>(n_p), 1, static_cast<const double*>(nullptr), d_stats4, emit, d_lik, d_ratio, d_beam,
+                       ctx->block_partials.as<double>(), nb, 0, ctx->partial4.as<double>());
+    TRY(timing_end(ctx, ep));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  // the reference's float recurrence over the weights between the two (pf_strict_sum_kernel replaces the sum in `packed`)
   TRY(mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, 0, 1, ctx->partial4.as<double>()));
   if (!ho)
     return mcl3dl_hip_pf_apply_device(ctx, d_weight, n_p, 1, ctx->partial4.as<double>(), d_stats4);
@@ -611,8 +661,10 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   const int one = launch_update_small(ctx, d_pose, n_p, d_weight, d_extra, d_lik, d_ratio, d_beam, d_stats4, ho);
   if (one != 0)
     return one < 0 ? one : 0;
-  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr));
-  TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4, ho));
+  LikTail tail;
+  tail.want = pf_takes_tiles(ctx, n_p) && d_lik && d_ratio && d_beam;
+  TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr, &tail));
+  TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4, ho, &tail));
   return 0;
 }
 

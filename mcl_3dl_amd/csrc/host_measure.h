@@ -419,8 +419,18 @@ void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, i
 #undef LAUNCH_STRICT
 }
 
+// What launch_measure leaves to the kernel behind it when the caller asks for it (`want`: the split pf::measure follows on the
+// same stream): the sum over the tiled kernel's per-tile partials — d_lik / d_ratio (and d_beam's ones, `beam_fill`) are then NOT
+// written by launch_measure but by pf_partial_kernel (pf_kernels.h: LikTiles), one launch less per update.
+struct LikTail
+{
+  bool want = false;
+  bool pending = false, beam_fill = false;
+  int n_tiles = 0;
+};
+
 int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
-                   bool stats, double* stats6)
+                   bool stats, double* stats6, LikTail* tail = nullptr)
 {
   if (!ctx->has_scan)
     return ctx->fail(-5, "no scan uploaded: call mcl3dl_hip_upload_scan first");
@@ -779,6 +789,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           {
           // (a chunk-ordered scan whose likelihoods nobody asked for: its permutation is chunk-relative, no terms are kept)
           launch_tiled(scan, ns, n_tiles, psum, pcnt, ctx->scan_perm.as<uint32_t>(), plan.chunk ? nullptr : strict_terms);
+          if (tail && tail->want && !strict_terms && d_lik && d_ratio)
+          {
+            tail->pending = true;  // pf_partial_kernel adds the tiles up
+            tail->n_tiles = n_tiles;
+            tail->beam_fill = beam_ones_by_finalize;
+          }
+          else
           hipLaunchKernelGGL(lik_finalize_kernel, dim3((np + 31) / 32), dim3(256), 0, ctx->stream, psum, pcnt, n_tiles, np, ns,
                                d_lik, d_ratio, beam_ones_by_finalize ? d_beam : static_cast<float*>(nullptr));
           if (strict_terms && d_lik && !plan.chunk)

@@ -87,15 +87,152 @@ __global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __res
   }
 }
 
+// lik_finalize_kernel + pf_partial_kernel as ONE launch (round 6; one GPU, the tiled likelihood kernel in front, at most
+// 1024 x 256 particles — one per thread of pf_partial_kernel's grid). A work-group owns 64 consecutive particles (one wavefront
+// of pf_partial_kernel's 256-thread blocks) with lik_finalize_kernel's own parallelism: its four wavefronts add up the eight
+// tile slices of the per-tile partials (wavefront v: slices v and v + 4, every eighth tile in increasing order), the first one
+// combines them in order — lik_finalize_kernel's association — and goes on with pf_partial_kernel's product, fp64 terms and
+// wavefront reductions. What leaves is the WAVEFRONT partial {sum w, sum w ln w, max ratio, -min ratio} of the 64 particles;
+// pf_reduce_kernel (waves = 1) forms pf_partial_kernel's block partials from four of them in that kernel's order (0 + w0 + w1 +
+// w2 + w3; a missing wavefront counts {0, 0, 0, -1}, what a wavefront without particles reduces to). Same arithmetic in the same
+// association as the two launches: the same bits (tests/test_gpu_pf_fused.py).
+struct LikTiles
+{
+  const double* psum;    // [n_tiles][n]
+  const unsigned* pcnt;  // [n_tiles][n]
+  int n_tiles, n_s;
+  float* lik_out;        // [n]
+  float* ratio_out;      // [n]
+  float* beam_fill;      // [n] set to 1 (an update without beam points), or null
+};
+__global__ __launch_bounds__(256) void lik_pf_partial_kernel(LikTiles lt, const float* __restrict__ w,
+                                                             const float* __restrict__ beam, const float* __restrict__ extra,
+                                                             int n, float* __restrict__ w_new,
+                                                             double* __restrict__ wave_partials)
+{
+  __shared__ double s_a[8][64];
+  __shared__ unsigned s_n[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  double a0 = 0.0, a1 = 0.0;
+  unsigned n0 = 0, n1 = 0;
+  if (p < n)
+  {
+    const double* ps = lt.psum + p;
+    const unsigned* pc = lt.pcnt + p;
+    int tl = wave;
+    for (; tl + 4 < lt.n_tiles; tl += 8)  // slice `wave` and slice `wave + 4` side by side: two independent chains of loads
+    {
+      const double x0 = ps[static_cast<size_t>(tl) * n], x1 = ps[static_cast<size_t>(tl + 4) * n];
+      const unsigned c0 = pc[static_cast<size_t>(tl) * n], c1 = pc[static_cast<size_t>(tl + 4) * n];
+      a0 += x0;
+      a1 += x1;
+      n0 += c0;
+      n1 += c1;
+    }
+    if (tl < lt.n_tiles)
+    {
+      a0 += ps[static_cast<size_t>(tl) * n];
+      n0 += pc[static_cast<size_t>(tl) * n];
+    }
+  }
+  s_a[wave][lane] = a0;
+  s_a[wave + 4][lane] = a1;
+  s_n[wave][lane] = n0;
+  s_n[wave + 4][lane] = n1;
+  __syncthreads();
+  if (wave != 0)
+    return;
+  double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;
+  if (p < n)
+  {
+    double a = a0;
+    unsigned cnt = n0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+    {
+      a += s_a[k][lane];
+      cnt += s_n[k][lane];
+    }
+    const float lk = static_cast<float>(a);
+    const float r32 = static_cast<float>(cnt) / static_cast<float>(lt.n_s);
+    lt.lik_out[p] = lk;
+    lt.ratio_out[p] = r32;
+    if (lt.beam_fill)
+      lt.beam_fill[p] = 1.0f;
+    float l = 1.0f;
+    if (beam)  // (1 * 1 for an update without beam points: what pf_partial_kernel reads back from the array filled with ones)
+      l *= lt.beam_fill ? 1.0f : beam[p];
+    l *= lk;
+    if (extra)
+      l = l * extra[p];
+    const float wn = w[p] * l;  // pf.h:258
+    w_new[p] = wn;
+    s += static_cast<double>(wn);  // (0.0 + x, as pf_partial_kernel's loop forms it: the sign of a zero included)
+    if (wn > 0.0f)
+      t += static_cast<double>(wn) * log(static_cast<double>(wn));
+    const double r = static_cast<double>(r32);
+    rmax = r > rmax ? r : rmax;
+    rneg = -r > rneg ? -r : rneg;
+  }
+  s = wave_sum(s);
+  t = wave_sum(t);
+  rmax = wave_max(rmax);
+  rneg = wave_max(rneg);
+  if (lane == 0)
+  {
+    wave_partials[4 * blockIdx.x + 0] = s;
+    wave_partials[4 * blockIdx.x + 1] = t;
+    wave_partials[4 * blockIdx.x + 2] = rmax;
+    wave_partials[4 * blockIdx.x + 3] = rneg;
+  }
+}
+
 // Fixed-order reduction of the block partials (deterministic run to run). The result is written in the layout the
 // update's single all-reduce(SUM) needs (mcl_3dl_amd/distributed.py): [0] sum w, [1] sum w ln w, then per rank r the pair
 // [2+2r] max ratio, [3+2r] -min ratio — this rank fills its own pair and zeroes the others, so that after the SUM every
 // rank holds every rank's pair. world == 1 degenerates to the plain 4 doubles.
-__global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict__ block_partials, int n_blocks, int rank,
-                                                       int world, double* __restrict__ packed)
+// n_waves > 0: `block_partials` holds lik_pf_partial_kernel's n_waves WAVEFRONT partials instead (block k = wavefronts 4 k .. 4 k + 3,
+// added up here the way pf_partial_kernel's thread 0 does).
+__device__ inline void pf_reduce_lanes(const double* __restrict__ block_partials, int n_blocks, int n_waves, int lane, double& a,
+                                       double& b, double& c, double& d)
 {
-  double a = 0, b = 0, c = 0.0, d = -1.0;
-  for (int k = threadIdx.x; k < n_blocks; k += 64)
+  a = 0;
+  b = 0;
+  c = 0.0;
+  d = -1.0;
+  if (n_waves > 0)
+  {
+    for (int k = lane; k < n_blocks; k += 64)
+    {
+      const double* wp = block_partials + 16 * static_cast<size_t>(k);
+      const bool h1 = 4 * k + 1 < n_waves, h2 = 4 * k + 2 < n_waves, h3 = 4 * k + 3 < n_waves;
+      double ba = 0, bb = 0, bc = wp[2], bd = wp[3];
+      ba += wp[0];
+      bb += wp[1];
+      const double a1 = h1 ? wp[4] : 0.0, b1 = h1 ? wp[5] : 0.0, c1 = h1 ? wp[6] : 0.0, d1 = h1 ? wp[7] : -1.0;
+      const double a2 = h2 ? wp[8] : 0.0, b2 = h2 ? wp[9] : 0.0, c2 = h2 ? wp[10] : 0.0, d2 = h2 ? wp[11] : -1.0;
+      const double a3 = h3 ? wp[12] : 0.0, b3 = h3 ? wp[13] : 0.0, c3 = h3 ? wp[14] : 0.0, d3 = h3 ? wp[15] : -1.0;
+      ba += a1;
+      bb += b1;
+      bc = c1 > bc ? c1 : bc;
+      bd = d1 > bd ? d1 : bd;
+      ba += a2;
+      bb += b2;
+      bc = c2 > bc ? c2 : bc;
+      bd = d2 > bd ? d2 : bd;
+      ba += a3;
+      bb += b3;
+      bc = c3 > bc ? c3 : bc;
+      bd = d3 > bd ? d3 : bd;
+      a += ba;
+      b += bb;
+      c = bc > c ? bc : c;
+      d = bd > d ? bd : d;
+    }
+  }
+  else
+  for (int k = lane; k < n_blocks; k += 64)
   {
     a += block_partials[4 * k + 0];
     b += block_partials[4 * k + 1];
@@ -106,6 +243,13 @@ __global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict_
   b = wave_sum(b);
   c = wave_max(c);
   d = wave_max(d);
+}
+
+__global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict__ block_partials, int n_blocks, int rank,
+                                                       int world, double* __restrict__ packed, int n_waves = 0)
+{
+  double a, b, c, d;
+  pf_reduce_lanes(block_partials, n_blocks, n_waves, threadIdx.x, a, b, c, d);
   if (threadIdx.x == 0)
   {
     packed[0] = a;
@@ -121,13 +265,43 @@ __global__ __launch_bounds__(64) void pf_reduce_kernel(const double* __restrict_
 // Normalise (pf.h:262-272) or restore (pf.h:274-278); entropy = ln S - T/S == -sum (w/S) ln (w/S).
 // `packed` is the (all-reduced) vector described above.
 // emit (+ the device arrays its lik / ratio / beam copies come from): see PfEmit.
+// partials != null (one GPU, world == 1): EVERY work-group runs pf_reduce_kernel's reduction itself (first wavefront, the same
+// association) instead of reading `packed` behind a launch of its own; work-group 0 also leaves the four sums in packed_w.
 __global__ __launch_bounds__(PF_BLOCK) void pf_apply_kernel(float* __restrict__ w, const float* __restrict__ w_new,
-                                                            int n, int world, const double* __restrict__ packed,
+                                                            int n, int world, const double* __restrict__ packed_in,
                                                             float* __restrict__ stats4, PfEmit emit = PfEmit{},
                                                             const float* __restrict__ lik = nullptr,
                                                             const float* __restrict__ ratio = nullptr,
-                                                            const float* __restrict__ beam = nullptr)
+                                                            const float* __restrict__ beam = nullptr,
+                                                            const double* __restrict__ partials = nullptr, int n_blocks = 0,
+                                                            int n_waves = 0, double* __restrict__ packed_w = nullptr)
 {
+  __shared__ double s_tot[4];
+  const double* packed = packed_in;
+  if (partials)
+  {
+    if (threadIdx.x < 64)
+    {
+      double a, b, c, d;
+      pf_reduce_lanes(partials, n_blocks, n_waves, threadIdx.x, a, b, c, d);
+      if (threadIdx.x == 0)
+      {
+        s_tot[0] = a;
+        s_tot[1] = b;
+        s_tot[2] = c;
+        s_tot[3] = d;
+        if (blockIdx.x == 0 && packed_w)
+        {
+          packed_w[0] = a;
+          packed_w[1] = b;
+          packed_w[2] = c;
+          packed_w[3] = d;
+        }
+      }
+    }
+    __syncthreads();
+    packed = s_tot;
+  }
   const double S = packed[0];
   const float sum_f = static_cast<float>(S);
   const bool alive = sum_f > 0.0f;

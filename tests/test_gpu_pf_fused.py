@@ -48,3 +48,46 @@ def test_larger_filters_still_take_the_split_path(engine):
     lik = rng.uniform(0, 10, n).astype(np.float32)
     got = engine.pf_measure(w0, lik)
     np.testing.assert_allclose(got["weights"].sum(dtype=np.float64), 1.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_p,n_s,n_b", [(1025, 4352, 0), (4096, 4352, 0), (4100, 5000, 7), (4159, 4608, 0), (16387, 4352, 3)])
+def test_the_two_launch_tail_behind_the_tiled_kernel_equals_the_launches_apart(engine, n_p, n_s, n_b):
+    """Round 6: behind the tiled likelihood kernel (default mode, 4097 .. 28 146 points, more than 1024 particles) lik_finalize's
+    sum and pf_partial's product are ONE launch (lik_pf_partial_kernel: wavefront partials) and pf_reduce runs inside pf_apply.
+    Same arithmetic in the same association as the kernels apart — measure_batch, then pf_measure on its results; a one-device
+    group runs partial / reduce / apply as three launches with the collective's slot between them — so every output is the
+    same bits: likelihoods, ratios, beam scores, weights, entropy, ratio bounds."""
+    from mcl_3dl_amd import capi
+    from mcl_3dl_amd.synthetic import make_scene
+    sc = make_scene(n=91, n_p=n_p, n_s=n_s, n_b=max(n_b, 1), seed=900 + n_b)
+    beam = sc.scan_beam[:n_b] if n_b else None
+    lab = sc.scan_beam_label[:n_b] if n_b else None
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=6600 + n_b, dist_weight=(1.0, 1.0, 5.0))
+    engine.set_likelihood_params()
+    engine.set_beam_params(num_points=max(n_b, 1))
+    extra = np.random.default_rng(n_p).uniform(0.1, 0.4, n_p).astype(np.float32)
+    w0 = np.random.default_rng(n_s).uniform(0.0, 1.0, n_p).astype(np.float32)
+    w0[::7] = 0.0
+    one = engine.measure_update(sc.poses, w0, sc.scan_lik, beam, lab, sc.origins, extra=extra)
+    assert engine.get_option("lik_exact") == 0     # (the fp64 tree of the tiled kernel: the path this test is about)
+    lik, ratio, bscore = engine.measure_batch(sc.poses, sc.scan_lik, beam, lab, sc.origins)
+    apart = engine.pf_measure(w0, lik, bscore, extra, ratio)
+    np.testing.assert_array_equal(one["lik"], lik)
+    np.testing.assert_array_equal(one["quality"], ratio)
+    np.testing.assert_array_equal(one["beam"], bscore)
+    np.testing.assert_array_equal(one["weights"], apart["weights"])
+    assert one["entropy"] == apart["entropy"] and one["restored"] == apart["restored"] is False
+    assert one["match_ratio_min"] == apart["match_ratio_min"] and one["match_ratio_max"] == apart["match_ratio_max"]
+    g = capi.Group((0,))
+    try:
+        g.set_map(sc.map_xyz, sc.map_label, stamp=1, dist_weight=(1.0, 1.0, 5.0))
+        g.set_likelihood_params()
+        g.set_beam_params(num_points=max(n_b, 1))
+        g.set_option("direct_single", 0)   # the sharded protocol with one rank: partial / reduce / all-reduce / apply apart
+        grp = g.measure_update(sc.poses, w0, sc.scan_lik, beam, lab, sc.origins, extra=extra)
+    finally:
+        g.close()
+    for k in ("lik", "quality", "beam", "weights"):
+        np.testing.assert_array_equal(one[k], grp[k], err_msg=k)
+    assert one["entropy"] == grp["entropy"]
+    assert one["match_ratio_min"] == grp["match_ratio_min"] and one["match_ratio_max"] == grp["match_ratio_max"]
