@@ -597,8 +597,11 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
     const int n_waves = static_cast<int>((n_p + 63) / 64), nb = pf_blocks(n_p);
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
     TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 16 * nb));  // (whole blocks of four wavefront partials)
+    const bool counts = tail->beam_pending;  // the beam score from the penalty counts on the way (beam_finalize_kernel's step)
     const LikTiles lt{ ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), tail->n_tiles, static_cast<int>(ctx->n_s),
-                       d_lik, d_ratio, tail->beam_fill ? d_beam : static_cast<float*>(nullptr) };
+                       d_lik, d_ratio, tail->beam_fill ? d_beam : static_cast<float*>(nullptr),
+                       counts ? ctx->penalty.as<unsigned>() : static_cast<unsigned*>(nullptr),
+                       counts ? ctx->pow_table.as<float>() : static_cast<const float*>(nullptr), ctx->beam_likelihood_min, d_beam };
     EventPair ep{};
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(lik_pf_partial_kernel, dim3(n_waves), dim3(256), 0, ctx->stream, lt, d_weight, d_beam, d_extra,
@@ -606,10 +609,16 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
     hipLaunchKernelGGL(pf_apply_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
                        static_cast<int>(n_p), 1, static_cast<const double*>(nullptr), d_stats4, emit, d_lik, d_ratio, d_beam,
                        ctx->block_partials.as<double>(), nb, n_waves, ctx->partial4.as<double>());
+    if (counts)
+      ctx->penalty_clean_n = n_p;  // (lik_pf_partial_kernel zeroes every counter it reads)
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  if (tail && tail->beam_pending)  // (no kernel below takes the penalty counts: the beam model's last step as a launch after all)
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3((static_cast<unsigned>(n_p) + 255) / 256), dim3(256), 0, ctx->stream,
+                       ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
+                       static_cast<int>(n_p));
   if (n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->pf_fused)
   {
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));

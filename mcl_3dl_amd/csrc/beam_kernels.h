@@ -297,6 +297,26 @@ struct BeamOrigin
   float4 pos;    // particle position
 };
 
+// what depends only on (particle, origin): beam.cpp:139 / :145 and the begin voxel
+__device__ inline BeamOrigin make_beam_origin(const float* __restrict__ pose7, long long p, const float4 og, const DdaGrid& g)
+{
+  const float* ps = pose7 + 7 * p;
+  const Vec3f pos = { ps[0], ps[1], ps[2] };
+  const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
+  const Quat rot = qnormalized(raw);
+  const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));
+  BeamOrigin r;
+  r.rot = make_float4(rot.x, rot.y, rot.z, rot.w);
+  const bool within = point_within_map(g, begin);
+  r.begin = make_float4(begin.x, begin.y, begin.z, within ? 1.0f : 0.0f);
+  int bx = 0, by = 0, bz = 0;
+  if (within)
+    to_index(g, begin, bx, by, bz);
+  r.voxel = make_int4(bx, by, bz, 0);
+  r.pos = make_float4(pos.x, pos.y, pos.z, 0.f);
+  return r;
+}
+
 // Also zeroes the particle's penalty counter (the memset the beam kernel would otherwise wait for).
 __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, const float4* __restrict__ origins, int n_o,
                                    DdaGrid g, BeamOrigin* __restrict__ out, unsigned* __restrict__ penalty_count)
@@ -308,27 +328,14 @@ __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, con
   const int o = static_cast<int>(t - p * n_o);
   if (o == 0)
     penalty_count[p] = 0u;
-  const float* ps = pose7 + 7 * p;
-  const Vec3f pos = { ps[0], ps[1], ps[2] };
-  const Quat raw = { ps[3], ps[4], ps[5], ps[6] };
-  const Quat rot = qnormalized(raw);
-  const float4 og = origins[o];
-  const Vec3f begin = vadd(pos, qrot(raw, Vec3f{ og.x, og.y, og.z }));
-  BeamOrigin r;
-  r.rot = make_float4(rot.x, rot.y, rot.z, rot.w);
-  const bool within = point_within_map(g, begin);
-  r.begin = make_float4(begin.x, begin.y, begin.z, within ? 1.0f : 0.0f);
-  int bx = 0, by = 0, bz = 0;
-  if (within)
-    to_index(g, begin, bx, by, bz);
-  r.voxel = make_int4(bx, by, bz, 0);
-  r.pos = make_float4(pos.x, pos.y, pos.z, 0.f);
-  out[t] = r;
+  out[t] = make_beam_origin(pose7, p, origins[o], g);
 }
 
 // One lane per (particle, beam point).  scan_beam.w = origin index (PointXYZIL::label of the scan point).
 // prepared != nullptr: the per-(particle, origin) table of beam_origin_kernel ([n_p][n_o]); nullptr: every ray computes
-// its own begin point (small launches, where one more kernel launch costs more than it saves).
+// its own begin point (small launches, where one more kernel launch costs more than it saves). (Round 6 measured a third form —
+// every work-group prepares the entries of ITS particles in LDS, no launch, no trip through memory — level at C3 and 4.6 % slower
+// at the C5 shard: one or two lanes computing while four wavefronts wait cost more than a 64-byte load: profiles/r06q_beam_tail_ab.txt.)
 template <bool STATS, bool OVERLAY = true>
 __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
                                                    int n_b, const float4* __restrict__ origins, long long n_rays,

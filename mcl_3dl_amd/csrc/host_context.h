@@ -275,6 +275,7 @@ struct mcl3dl_hip_ctx
   bool has_scan = false;
   bool pow_table_dirty = true;
   size_t pow_table_len = 0;  // penalty counts 0..pow_table_len the device table covers
+  size_t penalty_clean_n = 0;  // the first so many penalty counters are known to be zero (the update's tail kernel zeroes what it reads)
 
   // work buffers
   size_t n_pose_uploaded = 0;  // poses `pose` holds from mcl3dl_hip_upload_poses / the last host-buffer call

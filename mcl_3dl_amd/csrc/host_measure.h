@@ -421,12 +421,15 @@ void launch_strict_sum(mcl3dl_hip_ctx* ctx, const float* strict_terms, int ns, i
 
 // What launch_measure leaves to the kernel behind it when the caller asks for it (`want`: the split pf::measure follows on the
 // same stream): the sum over the tiled kernel's per-tile partials — d_lik / d_ratio (and d_beam's ones, `beam_fill`) are then NOT
-// written by launch_measure but by pf_partial_kernel (pf_kernels.h: LikTiles), one launch less per update.
+// written by launch_measure but by lik_pf_partial_kernel (pf_kernels.h: LikTiles), one launch less per update.
 struct LikTail
 {
   bool want = false;
   bool pending = false, beam_fill = false;
   int n_tiles = 0;
+  // the beam model's last step (penalty count -> score, beam_finalize_kernel) left to that kernel as well: ctx->penalty holds the
+  // counts, d_beam is NOT written yet (pf_measure_single runs beam_finalize_kernel itself when its kernel cannot take the counts)
+  bool beam_pending = false;
 };
 
 int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
@@ -483,7 +486,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       const long long blocks = (n_rays + 255) / 256;
       if (blocks > 0x7fffffffLL)
         return ctx->fail(-3, "too many rays for one launch");
-      TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+      {
+        const size_t cap0 = ctx->penalty.cap;
+        TRY(ensure(ctx, ctx->penalty, sizeof(unsigned) * n_p));
+        if (ctx->penalty.cap != cap0)
+          ctx->penalty_clean_n = 0;  // (a new allocation: nothing is known about its content)
+      }
       const bool beam_prepared = !stats && ctx->beam_prepare && n_rays >= ctx->beam_prepare_min_rays &&
                                  static_cast<long long>(n_p) * static_cast<long long>(ctx->n_o) < 0x7fffffffLL;
       if (beam_prepared)
@@ -503,7 +511,10 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       EventPair ep{};
       if (!stats)
         TRY(timing_begin(ctx, MCL3DL_KERNEL_BEAM, &ep, bs));
-      if (!beam_prepared)  // (beam_origin_kernel zeroes the counters itself)
+      // (beam_origin_kernel zeroes the counters itself; the update's tail kernel leaves them zeroed behind itself)
+      const bool counters_clean = ctx->penalty_clean_n >= n_p;
+      ctx->penalty_clean_n = 0;  // ... and from here on they are in use
+      if (!beam_prepared && !counters_clean)
       {
         // a kernel, not hipMemsetAsync: a memset node at the head of a single-stream captured update faulted on its third
         // replay (ROCm 7.2; 700 particles x 3 rays, 128 x 48), the same zeroing as a kernel node does not
@@ -537,9 +548,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                            ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
                            ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr), prepared,
                            static_cast<int>(ctx->n_o));
-        hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,
-                           ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
-                           np);
+        if (tail && tail->want)
+          tail->beam_pending = true;
+        else
+          hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,
+                             ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
+                             np);
         TRY(timing_end(ctx, ep, bs));
       }
       if (overlap)
@@ -791,7 +805,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           launch_tiled(scan, ns, n_tiles, psum, pcnt, ctx->scan_perm.as<uint32_t>(), plan.chunk ? nullptr : strict_terms);
           if (tail && tail->want && !strict_terms && d_lik && d_ratio)
           {
-            tail->pending = true;  // pf_partial_kernel adds the tiles up
+            tail->pending = true;  // lik_pf_partial_kernel adds the tiles up
             tail->n_tiles = n_tiles;
             tail->beam_fill = beam_ones_by_finalize;
           }

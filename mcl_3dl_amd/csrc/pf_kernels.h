@@ -104,6 +104,11 @@ struct LikTiles
   float* lik_out;        // [n]
   float* ratio_out;      // [n]
   float* beam_fill;      // [n] set to 1 (an update without beam points), or null
+  // the beam model's last step as well (beam_kernels.h: beam_finalize_kernel — table[count], clamped from below): penalty != null
+  unsigned* penalty;     // [n] penalised rays per particle; zeroed behind the read (the next update's beam kernel counts from 0)
+  const float* pow_table;
+  float beam_likelihood_min;
+  float* beam_out;       // [n]
 };
 __global__ __launch_bounds__(256) void lik_pf_partial_kernel(LikTiles lt, const float* __restrict__ w,
                                                              const float* __restrict__ beam, const float* __restrict__ extra,
@@ -161,7 +166,16 @@ __global__ __launch_bounds__(256) void lik_pf_partial_kernel(LikTiles lt, const 
     if (lt.beam_fill)
       lt.beam_fill[p] = 1.0f;
     float l = 1.0f;
-    if (beam)  // (1 * 1 for an update without beam points: what pf_partial_kernel reads back from the array filled with ones)
+    if (lt.penalty)
+    {
+      float sb = lt.pow_table[lt.penalty[p]];
+      lt.penalty[p] = 0u;
+      if (sb < lt.beam_likelihood_min)
+        sb = lt.beam_likelihood_min;
+      lt.beam_out[p] = sb;
+      l *= sb;
+    }
+    else if (beam)  // (1 * 1 for an update without beam points: what pf_partial_kernel reads back from the array filled with ones)
       l *= lt.beam_fill ? 1.0f : beam[p];
     l *= lk;
     if (extra)

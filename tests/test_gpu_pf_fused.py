@@ -91,3 +91,36 @@ def test_the_two_launch_tail_behind_the_tiled_kernel_equals_the_launches_apart(e
         np.testing.assert_array_equal(one[k], grp[k], err_msg=k)
     assert one["entropy"] == grp["entropy"]
     assert one["match_ratio_min"] == grp["match_ratio_min"] and one["match_ratio_max"] == grp["match_ratio_max"]
+
+
+def test_beam_counters_stay_consistent_across_the_paths_that_share_them(engine):
+    """Round 6: with the update's tail kernel behind it the beam kernel prepares its per-(particle, origin) constants per work-group
+    in LDS and finds its penalty counters zeroed by the PREVIOUS update's tail kernel (no beam_origin / fill launch). The counters
+    are shared with every other path (measure_batch, other particle counts, the per-particle likelihood kernels whose updates run
+    beam_finalize on its own): whatever the order of calls, every beam score equals the one of a plain measure_batch."""
+    from mcl_3dl_amd.synthetic import make_scene
+    sc = make_scene(n=91, n_p=6000, n_s=4500, n_b=600, seed=77)
+    engine.set_map(sc.map_xyz, sc.map_label, stamp=6700, dist_weight=(1.0, 1.0, 1.0))
+    engine.set_likelihood_params()
+    engine.set_beam_params(num_points=600)
+    w0 = np.full(6000, np.float32(1.0 / 6000), np.float32)
+
+    def batch(n_p, n_s, n_b):
+        return engine.measure_batch(sc.poses[:n_p], sc.scan_lik[:n_s], sc.scan_beam[:n_b], sc.scan_beam_label[:n_b], sc.origins)
+
+    def update(n_p, n_s, n_b):
+        return engine.measure_update(sc.poses[:n_p], w0[:n_p], sc.scan_lik[:n_s], sc.scan_beam[:n_b], sc.scan_beam_label[:n_b],
+                                     sc.origins)
+
+    want = {}
+    for shape in [(4100, 4500, 600), (6000, 4500, 600), (4100, 300, 600), (2000, 4500, 64), (4100, 4500, 64)]:
+        want[shape] = batch(*shape)
+    order = [(4100, 4500, 600), (4100, 4500, 600), (6000, 4500, 600), (4100, 4500, 600), (4100, 300, 600), (4100, 4500, 600),
+             (2000, 4500, 64), (4100, 4500, 64), (4100, 4500, 600), (6000, 4500, 600)]
+    for k, shape in enumerate(order):
+        got = update(*shape)
+        np.testing.assert_array_equal(got["beam"], want[shape][2], err_msg="update %d %r" % (k, shape))
+        np.testing.assert_array_equal(got["lik"], want[shape][0], err_msg="update %d %r" % (k, shape))
+        if k % 3 == 1:   # a plain batch in between uses (and dirties) the same counters
+            b = batch(*shape)
+            np.testing.assert_array_equal(b[2], want[shape][2])
