@@ -569,6 +569,10 @@ int mcl3dl_hip_pf_apply_device(mcl3dl_hip_ctx* ctx, float* d_weight_inout, size_
 // ---- host entry points -------------------------------------------------------------------------------------
 namespace
 {
+bool pf_is_split(const mcl3dl_hip_ctx* ctx, size_t n_p)
+{
+  return !(n_p <= static_cast<size_t>(std::min(ctx->pf_fused_max, PF_FUSED_MAX)) && ctx->pf_fused);
+}
 // is pf::measure of n_p particles on this GPU the split form with the fp64 sum of the weights? Then launch_measure may leave the
 // sum over the tiled kernel's per-tile partials to lik_pf_partial_kernel (LikTail).
 bool pf_takes_tiles(const mcl3dl_hip_ctx* ctx, size_t n_p)
@@ -590,6 +594,10 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
 {
   const PfEmit emit = ho ? *ho : PfEmit{};
   const bool float_w = pf_float_order(ctx, n_p);
+  // the beam score from the penalty counts on the way (beam_finalize_kernel's step; the kernel zeroes every counter it reads)
+  const bool counts = tail && tail->beam_pending && (tail->pending || !float_w || !pf_is_split(ctx, n_p));
+  const BeamCounts bc = counts ? BeamCounts{ ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam }
+                               : BeamCounts{ nullptr, nullptr, 0.0f, nullptr };
   if (tail && tail->pending)
   {
     // launch_measure left the tiled kernel's per-tile partials where they are: lik_finalize_kernel's sum and pf_partial_kernel's
@@ -597,11 +605,8 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
     const int n_waves = static_cast<int>((n_p + 63) / 64), nb = pf_blocks(n_p);
     TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
     TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 16 * nb));  // (whole blocks of four wavefront partials)
-    const bool counts = tail->beam_pending;  // the beam score from the penalty counts on the way (beam_finalize_kernel's step)
     const LikTiles lt{ ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), tail->n_tiles, static_cast<int>(ctx->n_s),
-                       d_lik, d_ratio, tail->beam_fill ? d_beam : static_cast<float*>(nullptr),
-                       counts ? ctx->penalty.as<unsigned>() : static_cast<unsigned*>(nullptr),
-                       counts ? ctx->pow_table.as<float>() : static_cast<const float*>(nullptr), ctx->beam_likelihood_min, d_beam };
+                       d_lik, d_ratio, tail->beam_fill ? d_beam : static_cast<float*>(nullptr), bc };
     EventPair ep{};
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(lik_pf_partial_kernel, dim3(n_waves), dim3(256), 0, ctx->stream, lt, d_weight, d_beam, d_extra,
@@ -610,12 +615,12 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
                        static_cast<int>(n_p), 1, static_cast<const double*>(nullptr), d_stats4, emit, d_lik, d_ratio, d_beam,
                        ctx->block_partials.as<double>(), nb, n_waves, ctx->partial4.as<double>());
     if (counts)
-      ctx->penalty_clean_n = n_p;  // (lik_pf_partial_kernel zeroes every counter it reads)
+      ctx->penalty_clean_n = n_p;  // (launched: the kernel zeroes every counter it reads)
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  if (tail && tail->beam_pending)  // (no kernel below takes the penalty counts: the beam model's last step as a launch after all)
+  if (tail && tail->beam_pending && !counts)  // (the float-order split form: the beam model's last step as a launch after all)
     hipLaunchKernelGGL(beam_finalize_kernel, dim3((static_cast<unsigned>(n_p) + 255) / 256), dim3(256), 0, ctx->stream,
                        ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
                        static_cast<int>(n_p));
@@ -625,7 +630,9 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
     EventPair ep{};
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(pf_fused_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
-                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit, float_w ? 1 : 0);
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->partial4.as<double>(), d_stats4, emit, float_w ? 1 : 0, bc);
+    if (counts)
+      ctx->penalty_clean_n = n_p;  // (launched: the kernel zeroes every counter it reads)
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -638,10 +645,12 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
     EventPair ep{};
     TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
     hipLaunchKernelGGL(pf_partial_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
-                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>(), bc);
     hipLaunchKernelGGL(pf_apply_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, ctx->wnew.as<float>(),
                        static_cast<int>(n_p), 1, static_cast<const double*>(nullptr), d_stats4, emit, d_lik, d_ratio, d_beam,
                        ctx->block_partials.as<double>(), nb, 0, ctx->partial4.as<double>());
+    if (counts)
+      ctx->penalty_clean_n = n_p;  // (launched: the kernel zeroes every counter it reads)
     TRY(timing_end(ctx, ep));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -672,6 +681,7 @@ int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
     return one < 0 ? one : 0;
   LikTail tail;
   tail.want = pf_takes_tiles(ctx, n_p) && d_lik && d_ratio && d_beam;
+  tail.want_beam = d_beam != nullptr;
   TRY(launch_measure(ctx, d_pose, n_p, d_lik, d_ratio, d_beam, false, nullptr, &tail));
   TRY(pf_measure_single(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, d_stats4, ho, &tail));
   return 0;

@@ -429,7 +429,7 @@ struct LikTail
   int n_tiles = 0;
   // the beam model's last step (penalty count -> score, beam_finalize_kernel) left to that kernel as well: ctx->penalty holds the
   // counts, d_beam is NOT written yet (pf_measure_single runs beam_finalize_kernel itself when its kernel cannot take the counts)
-  bool beam_pending = false;
+  bool want_beam = false, beam_pending = false;
 };
 
 int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_lik, float* d_ratio, float* d_beam,
@@ -548,7 +548,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                            ctx->scan_beam.as<float4>(), static_cast<int>(ctx->n_b), ctx->origins.as<float4>(), n_rays,
                            ctx->dg, bp, ctx->penalty.as<unsigned>(), static_cast<RayStats*>(nullptr), prepared,
                            static_cast<int>(ctx->n_o));
-        if (tail && tail->want)
+        if (tail && tail->want_beam)
           tail->beam_pending = true;
         else
           hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,

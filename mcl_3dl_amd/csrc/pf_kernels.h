@@ -27,19 +27,42 @@ struct PfEmit
   float* beam;
 };
 
+// The beam model's last step (beam_kernels.h: beam_finalize_kernel — score = table[penalised rays], clamped from below, beam.cpp:
+// 146-152) for the kernel that needs the score next, instead of a launch of its own in front of it (round 6): penalty != null —
+// the score is formed from the count, written to beam_out, and the counter is ZEROED behind the read (the next update's beam kernel
+// counts from 0 without a launch that clears: mcl3dl_hip_ctx::penalty_clean_n).
+struct BeamCounts
+{
+  unsigned* penalty;     // [n] penalised rays per particle
+  const float* pow_table;
+  float beam_likelihood_min;
+  float* beam_out;       // [n]
+};
+__device__ inline float beam_score_from_count(const BeamCounts& bc, int i)
+{
+  float sb = bc.pow_table[bc.penalty[i]];
+  bc.penalty[i] = 0u;
+  if (sb < bc.beam_likelihood_min)
+    sb = bc.beam_likelihood_min;
+  bc.beam_out[i] = sb;
+  return sb;
+}
+
 // w_new = w * (((1 * beam) * lik) * extra); per-block partials {sum w, sum w ln w, max ratio, -min ratio}.
 __global__ __launch_bounds__(PF_BLOCK) void pf_partial_kernel(const float* __restrict__ w, const float* __restrict__ lik,
                                                               const float* __restrict__ beam,
                                                               const float* __restrict__ extra,
                                                               const float* __restrict__ ratio, int n,
                                                               float* __restrict__ w_new,
-                                                              double* __restrict__ block_partials)
+                                                              double* __restrict__ block_partials, BeamCounts bc = BeamCounts{})
 {
   double s = 0.0, t = 0.0, rmax = 0.0, rneg = -1.0;  // match_ratio_max = 0, match_ratio_min = 1 (mcl_3dl.cpp:398-399)
   for (int i = blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += gridDim.x * PF_BLOCK)
   {
     float l = 1.0f;
-    if (beam)
+    if (bc.penalty)
+      l *= beam_score_from_count(bc, i);
+    else if (beam)
       l *= beam[i];
     l *= lik[i];
     if (extra)
@@ -104,11 +127,7 @@ struct LikTiles
   float* lik_out;        // [n]
   float* ratio_out;      // [n]
   float* beam_fill;      // [n] set to 1 (an update without beam points), or null
-  // the beam model's last step as well (beam_kernels.h: beam_finalize_kernel — table[count], clamped from below): penalty != null
-  unsigned* penalty;     // [n] penalised rays per particle; zeroed behind the read (the next update's beam kernel counts from 0)
-  const float* pow_table;
-  float beam_likelihood_min;
-  float* beam_out;       // [n]
+  BeamCounts bc;         // the beam model's last step as well (penalty != null)
 };
 __global__ __launch_bounds__(256) void lik_pf_partial_kernel(LikTiles lt, const float* __restrict__ w,
                                                              const float* __restrict__ beam, const float* __restrict__ extra,
@@ -166,15 +185,8 @@ __global__ __launch_bounds__(256) void lik_pf_partial_kernel(LikTiles lt, const 
     if (lt.beam_fill)
       lt.beam_fill[p] = 1.0f;
     float l = 1.0f;
-    if (lt.penalty)
-    {
-      float sb = lt.pow_table[lt.penalty[p]];
-      lt.penalty[p] = 0u;
-      if (sb < lt.beam_likelihood_min)
-        sb = lt.beam_likelihood_min;
-      lt.beam_out[p] = sb;
-      l *= sb;
-    }
+    if (lt.bc.penalty)
+      l *= beam_score_from_count(lt.bc, p);
     else if (beam)  // (1 * 1 for an update without beam points: what pf_partial_kernel reads back from the array filled with ones)
       l *= lt.beam_fill ? 1.0f : beam[p];
     l *= lk;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
                                                         const float* __restrict__ beam, const float* __restrict__ extra,
                                                         const float* __restrict__ ratio, int n, float* __restrict__ w_new,
                                                         double* __restrict__ packed, float* __restrict__ stats4,
-                                                        PfEmit emit = PfEmit{}, int float_order = 0)
+                                                        PfEmit emit = PfEmit{}, int float_order = 0, BeamCounts bc = BeamCounts{})
 {
   // float_order: pf::measure's `sum += p.probability_` (pf.h:255-260) as the reference runs it — float, sequentially, in
   // particle order (float_chain.h) — instead of the fp64 tree: the weights are divided by exactly the reference's float
@@ -399,7 +411,9 @@ __global__ __launch_bounds__(1024) void pf_fused_kernel(float* __restrict__ w, c
     if (vb < nb && i < n)
     {
       float l = 1.0f;
-      if (beam)
+      if (bc.penalty)  // (beam == bc.beam_out: the apply loop below re-reads what THIS thread writes here)
+        l *= beam_score_from_count(bc, i);
+      else if (beam)
         l *= beam[i];
       l *= lik[i];
       if (extra)

@@ -96,8 +96,9 @@ def test_the_two_launch_tail_behind_the_tiled_kernel_equals_the_launches_apart(e
 def test_beam_counters_stay_consistent_across_the_paths_that_share_them(engine):
     """Round 6: with the update's tail kernel behind it the beam kernel prepares its per-(particle, origin) constants per work-group
     in LDS and finds its penalty counters zeroed by the PREVIOUS update's tail kernel (no beam_origin / fill launch). The counters
-    are shared with every other path (measure_batch, other particle counts, the per-particle likelihood kernels whose updates run
-    beam_finalize on its own): whatever the order of calls, every beam score equals the one of a plain measure_batch."""
+    are shared with every other path (measure_batch, other particle counts, pf_partial_kernel / pf_fused_kernel taking the counts
+    behind the per-particle likelihood kernels): whatever the order of calls, every beam score equals the one of a plain
+    measure_batch."""
     from mcl_3dl_amd.synthetic import make_scene
     sc = make_scene(n=91, n_p=6000, n_s=4500, n_b=600, seed=77)
     engine.set_map(sc.map_xyz, sc.map_label, stamp=6700, dist_weight=(1.0, 1.0, 1.0))
@@ -113,10 +114,13 @@ def test_beam_counters_stay_consistent_across_the_paths_that_share_them(engine):
                                      sc.origins)
 
     want = {}
-    for shape in [(4100, 4500, 600), (6000, 4500, 600), (4100, 300, 600), (2000, 4500, 64), (4100, 4500, 64)]:
+    for shape in [(4100, 4500, 600), (6000, 4500, 600), (4100, 300, 600), (2000, 4500, 64), (4100, 4500, 64), (700, 300, 600),
+                  (1000, 4500, 64), (300, 300, 64)]:
         want[shape] = batch(*shape)
     order = [(4100, 4500, 600), (4100, 4500, 600), (6000, 4500, 600), (4100, 4500, 600), (4100, 300, 600), (4100, 4500, 600),
-             (2000, 4500, 64), (4100, 4500, 64), (4100, 4500, 600), (6000, 4500, 600)]
+             (2000, 4500, 64), (4100, 4500, 64), (4100, 4500, 600), (6000, 4500, 600),
+             # 513 .. 1024 particles: pf_fused_kernel takes the counts; <= 512: the one-launch update counts for itself
+             (700, 300, 600), (700, 300, 600), (4100, 4500, 600), (1000, 4500, 64), (300, 300, 64), (1000, 4500, 64), (6000, 4500, 600)]
     for k, shape in enumerate(order):
         got = update(*shape)
         np.testing.assert_array_equal(got["beam"], want[shape][2], err_msg="update %d %r" % (k, shape))
