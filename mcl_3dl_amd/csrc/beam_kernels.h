@@ -336,14 +336,16 @@ __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, con
 // its own begin point (small launches, where one more kernel launch costs more than it saves). (Round 6 measured a third form —
 // every work-group prepares the entries of ITS particles in LDS, no launch, no trip through memory — level at C3 and 4.6 % slower
 // at the C5 shard: one or two lanes computing while four wavefronts wait cost more than a 64-byte load: profiles/r06q_beam_tail_ab.txt.)
+// (the body as a device function of the work-group's index: beam_kernel is it with blockIdx.x; lik_beam_kernel, update_kernels.h,
+// interleaves it with the tiled likelihood kernel's work-groups in one launch)
 template <bool STATS, bool OVERLAY = true>
-__global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
-                                                   int n_b, const float4* __restrict__ origins, long long n_rays,
-                                                   DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
-                                                   RayStats* __restrict__ stats,
-                                                   const BeamOrigin* __restrict__ prepared, int n_o)
+__device__ __forceinline__ void beam_body(const long long block_index, const float* __restrict__ pose7,
+                                          const float4* __restrict__ scan, int n_b, const float4* __restrict__ origins,
+                                          long long n_rays, const DdaGrid& g, const BeamParams& bp,
+                                          unsigned* __restrict__ penalty_count, RayStats* __restrict__ stats,
+                                          const BeamOrigin* __restrict__ prepared, int n_o)
 {
-  const long long ray0 = static_cast<long long>(blockIdx.x) * 256;
+  const long long ray0 = block_index * 256;
   const long long ray = ray0 + threadIdx.x;
   unsigned st_steps = 0, st_occ = 0, st_tested = 0;
   // Penalised rays are counted per particle. Thousands of rays of one particle bumping one global counter serialise in
@@ -404,6 +406,17 @@ __global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pos
     atomicAdd(&stats->occupied, static_cast<unsigned long long>(st_occ));
     atomicAdd(&stats->tested, static_cast<unsigned long long>(st_tested));
   }
+}
+
+template <bool STATS, bool OVERLAY = true>
+__global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ pose7, const float4* __restrict__ scan,
+                                                   int n_b, const float4* __restrict__ origins, long long n_rays,
+                                                   DdaGrid g, BeamParams bp, unsigned* __restrict__ penalty_count,
+                                                   RayStats* __restrict__ stats,
+                                                   const BeamOrigin* __restrict__ prepared, int n_o)
+{
+  beam_body<STATS, OVERLAY>(static_cast<long long>(blockIdx.x), pose7, scan, n_b, origins, n_rays, g, bp, penalty_count, stats, prepared,
+                            n_o);
 }
 
 // score_beam = beam_likelihood_^k by k float multiplications (table built on the host the same way), then the

@@ -446,6 +446,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   TRY(ensure_structures(ctx, want_lik && ctx->n_s > 0, want_beam && ctx->n_b > 0, stats));
   const int np = static_cast<int>(n_p);
   bool beam_forked = false, beam_ones_by_finalize = false;
+  bool merged = false;  // the beam kernel's work-groups ride in the tiled likelihood kernel's launch (lik_beam_kernel)
+  struct
+  {
+    long long n_rays = 0, blocks = 0;
+    BeamParams bp{};
+    const BeamOrigin* prepared = nullptr;
+  } merged_beam;
   // any return between the fork and the join below (a failing HIP call) first waits for the second stream, so the caller
   // never gets control back with beam kernels still writing its buffers
   struct ForkGuard
@@ -498,9 +505,18 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
         TRY(ensure(ctx, ctx->beam_origin, sizeof(BeamOrigin) * n_p * ctx->n_o));
       if (stats)
         TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
+      // Both models in ONE launch (lik_beam_kernel, update_kernels.h: the two kernels' work-groups interleaved, so that every CU
+      // hosts both all the way) whenever the likelihood side is the tiled kernel's C2 instantiation and the beam side is large
+      // enough to be worth interleaving: the beam kernel is NOT launched here but with the tiled kernel below.
+      // Not with the caller-order replay behind the tiled kernel (plan.strict_terms): on two streams the replay — memory-bound,
+      // VALU idle — overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5 shard: 3.09 against 3.14 ms).
+      // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
+      merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
+               !plan.strict_terms && plan.group_size == 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
+               blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL;
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
       // 52 us per update with them, 17 without), the overlap itself is worth ~5 % at C3 (2.1 M rays)
-      const bool overlap = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
+      const bool overlap = !merged && ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
       hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
       if (overlap)
       {
@@ -542,6 +558,16 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                              ctx->beam_origin.as<BeamOrigin>(), ctx->penalty.as<unsigned>());
           prepared = ctx->beam_origin.as<BeamOrigin>();
         }
+        if (merged)
+        {
+          // (the rays ride in the tiled kernel's launch below; the beam model's last step comes behind that launch)
+          merged_beam.n_rays = n_rays;
+          merged_beam.blocks = blocks;
+          merged_beam.bp = bp;
+          merged_beam.prepared = prepared;
+        }
+        else
+        {
         // (a map update rides on the DDA grid as an overlay: the kernel that looks it up is chosen only then)
         const auto kernel = ctx->dg.ov_n > 0 ? beam_kernel<false, true> : beam_kernel<false, false>;
         hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, bs, d_pose,
@@ -554,6 +580,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, bs,
                              ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam,
                              np);
+        }
         TRY(timing_end(ctx, ep, bs));
       }
       if (overlap)
@@ -721,6 +748,65 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           {
             const long long full = t_tiles & ~7, rem = static_cast<long long>(t_tiles - full) * n_groups;
             const long long t_blocks = 8 * ((full / 8) * n_groups + (rem + 7) / 8);  // (plan_lik's count, for this many tiles)
+            if (merged)
+            {
+              // rounds of beam8 x 8 beam work-groups + tiled8 x 8 tiled ones, beam8 : tiled8 ~ the two grids' ratio (each at most 8)
+              const long long nbb = merged_beam.blocks;
+              uint32_t beam8 = 1, tiled8 = 1;
+              if (nbb >= t_blocks)
+                beam8 = static_cast<uint32_t>(std::min<long long>(8, (nbb + t_blocks / 2) / t_blocks));
+              else
+                tiled8 = static_cast<uint32_t>(std::min<long long>(8, (t_blocks + nbb / 2) / nbb));
+              const long long rounds = std::max((nbb + 8 * beam8 - 1) / (8 * beam8), (t_blocks + 8 * tiled8 - 1) / (8 * tiled8));
+              const long long grid = rounds * 8 * (beam8 + tiled8);
+              LikBeamArgs a{};
+              a.pose7 = d_pose;
+              a.n_p = np;
+              a.scan = t_scan;
+              a.n_s = t_ns;
+              a.n_tiles = t_tiles;
+              a.n_groups = n_groups;
+              a.g = ctx->lg;
+              a.rg = ctx->rg;
+              a.prm = lp;
+              a.partial_sum = t_psum;
+              a.partial_cnt = t_pcnt;
+              a.scan_perm = t_perm;
+              a.strict_terms = t_terms;
+              a.strict_skew4 = STRICT_SKEW4;
+              a.scan_beam = ctx->scan_beam.as<float4>();
+              a.n_b = static_cast<int>(ctx->n_b);
+              a.origins = ctx->origins.as<float4>();
+              a.n_rays = merged_beam.n_rays;
+              a.dg = ctx->dg;
+              a.bp = merged_beam.bp;
+              a.penalty = ctx->penalty.as<unsigned>();
+              a.prepared = merged_beam.prepared;
+              a.n_o = static_cast<int>(ctx->n_o);
+              a.beam8 = beam8;
+              a.tiled8 = tiled8;
+              a.n_beam_blocks = static_cast<uint32_t>(nbb);
+              a.n_tiled_blocks = static_cast<uint32_t>(t_blocks);
+              const bool ov = ctx->dg.ov_n > 0;
+#define LAUNCH_MERGED(DD, OV) \
+  hipLaunchKernelGGL((lik_beam_kernel<16, DD, OV>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a)
+              if (defer && ov)
+                LAUNCH_MERGED(true, true);
+              else if (defer)
+                LAUNCH_MERGED(true, false);
+              else if (ov)
+                LAUNCH_MERGED(false, true);
+              else
+                LAUNCH_MERGED(false, false);
+#undef LAUNCH_MERGED
+              // the beam model's last step: left to the update's tail kernel, or a launch of its own
+              if (tail && tail->want_beam)
+                tail->beam_pending = true;
+              else
+                hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, ctx->penalty.as<unsigned>(),
+                                   ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam, np);
+              return;
+            }
             switch (G)
             {
               case 4:

@@ -921,15 +921,15 @@ __device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, cons
 // terms, bit for bit. MINW = wavefronts per SIMD the register allocation must leave room for (G = 32 holds 33 KB of LDS:
 // 4 at most).
 // DEFER (COOP only; packed 64-byte records): overflow rounds queued per wavefront and run densely (above).
+// (the kernel's body as a device function of the work-group's index: likelihood_tiled_kernel below is it with blockIdx.x, the
+// heterogeneous launch of both models — lik_beam_kernel, update_kernels.h — calls it with the index it assigns)
 template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false, bool CHAIN = false>
-__global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
-                                                               const float4* __restrict__ scan, int n_s, int n_tiles,
-                                                               int n_groups, LikGrid g, RecGrid rg,
-                                                               LikParams prm, double* __restrict__ partial_sum,
-                                                               unsigned* __restrict__ partial_cnt,
-                                                               const uint32_t* __restrict__ scan_perm,
-                                                               float* __restrict__ strict_terms, int strict_skew4 = 0,
-                                                               LikChain ch = LikChain{})
+__device__ __forceinline__ void likelihood_tiled_body(const uint32_t block_index, const float* __restrict__ pose7, int n_p,
+                                                      const float4* __restrict__ scan, int n_s, int n_tiles, int n_groups,
+                                                      const LikGrid& g, const RecGrid& rg, const LikParams& prm,
+                                                      double* __restrict__ partial_sum, unsigned* __restrict__ partial_cnt,
+                                                      const uint32_t* __restrict__ scan_perm, float* __restrict__ strict_terms,
+                                                      int strict_skew4, const LikChain& ch)
 {
   // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
   // [particle group][original scan index][G] so that lik_strict_sum_rows_kernel can add them in the reference's own order.
@@ -945,8 +945,8 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
   // ranges of tiles per XCD were measured 7 % (C2) to 13 % (C5) slower. The remaining n_tiles % 8 tiles — all of them
   // for a scan shorter than 2048 points — are cut into eight contiguous ranges of (tile, group) pairs, so that a short
   // scan still uses every XCD (32-bit arithmetic: the launch has fewer than 2^31 work-groups, plan_lik checks).
-  const uint32_t xcd = blockIdx.x & 7u;
-  const uint32_t seq = blockIdx.x >> 3;
+  const uint32_t xcd = block_index & 7u;
+  const uint32_t seq = block_index >> 3;
   const uint32_t ng = static_cast<uint32_t>(n_groups);
   const uint32_t full_tiles = static_cast<uint32_t>(n_tiles) & ~7u;
   const uint32_t per_xcd_full = (full_tiles >> 3) * ng;
@@ -1204,6 +1204,20 @@ __global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float
     partial_sum[o] = acc;
     partial_cnt[o] = s_cnt[pk][0] + s_cnt[pk][1] + s_cnt[pk][2] + s_cnt[pk][3];
   }
+}
+
+template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false, bool CHAIN = false>
+__global__ __launch_bounds__(256, MINW) void likelihood_tiled_kernel(const float* __restrict__ pose7, int n_p,
+                                                               const float4* __restrict__ scan, int n_s, int n_tiles,
+                                                               int n_groups, LikGrid g, RecGrid rg,
+                                                               LikParams prm, double* __restrict__ partial_sum,
+                                                               unsigned* __restrict__ partial_cnt,
+                                                               const uint32_t* __restrict__ scan_perm,
+                                                               float* __restrict__ strict_terms, int strict_skew4 = 0,
+                                                               LikChain ch = LikChain{})
+{
+  likelihood_tiled_body<G, MODE, MINW, COOP, DEFER, CHAIN>(blockIdx.x, pose7, n_p, scan, n_s, n_tiles, n_groups, g, rg, prm, partial_sum,
+                                                           partial_cnt, scan_perm, strict_terms, strict_skew4, ch);
 }
 
 // Sums the per-tile partials of each particle: 32 particles per work-group, 8 lanes per particle each walk every 8th tile

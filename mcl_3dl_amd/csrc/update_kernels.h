@@ -361,4 +361,63 @@ __global__ __launch_bounds__(BLOCK) void update_small_kernel(UpdateSmallArgs a)
   for (int k = threadIdx.x; k < nvb * VB_TREE + ticket_tree_size(nvb); k += BLOCK)
     a.tickets[k] = 0u;  // ready for the next launch
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Both models of a large update in ONE launch (round 6): the tiled likelihood kernel's work-groups and the beam kernel's,
+// INTERLEAVED over the block index — rounds of `beam8` x 8 beam work-groups followed by `tiled8` x 8 tiled ones, the two counts in the
+// ratio of the two kernels' grids, so both run out together and every CU hosts wavefronts of both all the way: the beam model's
+// traversal waits on dependent loads (VALU issue 0.52 alone), the tiled kernel on the L2's request rate (0.61 alone), and what one
+// leaves idle the other uses. (Two streams do not give this: the second kernel's work-groups only get the slots the first one's
+// free at its end.) Rounds are multiples of eight blocks, so a tiled work-group keeps the XCD its index is congruent to
+// (likelihood_tiled_body's tile -> XCD mapping). Each work-group runs exactly the code of its own kernel: same bits.
+struct LikBeamArgs
+{
+  // tiled likelihood kernel (likelihood_tiled_body<16, 2, 8, true, DEFER, false>)
+  const float* pose7;
+  int n_p;
+  const float4* scan;
+  int n_s, n_tiles, n_groups;
+  LikGrid g;
+  RecGrid rg;
+  LikParams prm;
+  double* partial_sum;
+  unsigned* partial_cnt;
+  const uint32_t* scan_perm;
+  float* strict_terms;
+  int strict_skew4;
+  // beam kernel (beam_body<false, OVERLAY>)
+  const float4* scan_beam;
+  int n_b;
+  const float4* origins;
+  long long n_rays;
+  DdaGrid dg;
+  BeamParams bp;
+  unsigned* penalty;
+  const BeamOrigin* prepared;
+  int n_o;
+  // the interleave
+  uint32_t beam8, tiled8;
+  uint32_t n_beam_blocks, n_tiled_blocks;
+};
+
+template <int G, bool DEFER, bool OVERLAY>
+__global__ __launch_bounds__(256, 8) void lik_beam_kernel(LikBeamArgs a)
+{
+  const uint32_t nb8 = 8u * a.beam8, round = nb8 + 8u * a.tiled8;
+  const uint32_t k = blockIdx.x / round, r = blockIdx.x - k * round;
+  if (r < nb8)
+  {
+    const uint32_t bi = k * nb8 + r;
+    if (bi < a.n_beam_blocks)
+      beam_body<false, OVERLAY>(static_cast<long long>(bi), a.pose7, a.scan_beam, a.n_b, a.origins, a.n_rays, a.dg, a.bp, a.penalty,
+                                static_cast<RayStats*>(nullptr), a.prepared, a.n_o);
+  }
+  else
+  {
+    const uint32_t ti = k * 8u * a.tiled8 + (r - nb8);
+    if (ti < a.n_tiled_blocks)
+      likelihood_tiled_body<G, 2, 8, true, DEFER, false>(ti, a.pose7, a.n_p, a.scan, a.n_s, a.n_tiles, a.n_groups, a.g, a.rg, a.prm,
+                                                         a.partial_sum, a.partial_cnt, a.scan_perm, a.strict_terms, a.strict_skew4,
+                                                         LikChain{});
+  }
+}
 }  // namespace mcl3dl
