@@ -341,7 +341,7 @@ __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, con
 template <bool STATS, bool OVERLAY = true>
 __device__ __forceinline__ void beam_body(const long long block_index, const float* __restrict__ pose7,
                                           const float4* __restrict__ scan, int n_b, const float4* __restrict__ origins,
-                                          long long n_rays, const DdaGrid& g, const BeamParams& bp,
+                                          long long n_rays, DdaGrid g, BeamParams bp,
                                           unsigned* __restrict__ penalty_count, RayStats* __restrict__ stats,
                                           const BeamOrigin* __restrict__ prepared, int n_o)
 {

@@ -506,13 +506,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       if (stats)
         TRY(ensure(ctx, ctx->ray_stats, sizeof(RayStats)));
       // Both models in ONE launch (lik_beam_kernel, update_kernels.h: the two kernels' work-groups interleaved, so that every CU
-      // hosts both all the way) whenever the likelihood side is the tiled kernel's C2 instantiation and the beam side is large
+      // hosts both all the way) whenever the likelihood side is the tiled kernel's cooperative fp64-tree form (G <= 16) and the beam side is large
       // enough to be worth interleaving: the beam kernel is NOT launched here but with the tiled kernel below.
       // Not with the caller-order replay behind the tiled kernel (plan.strict_terms): on two streams the replay — memory-bound,
       // VALU idle — overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5 shard: 3.09 against 3.14 ms).
       // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
-               !plan.strict_terms && plan.group_size == 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
+               !plan.strict_terms && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
                blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL;
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
       // 52 us per update with them, 17 without), the overlap itself is worth ~5 % at C3 (2.1 M rays)
@@ -788,16 +788,33 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
               a.n_beam_blocks = static_cast<uint32_t>(nbb);
               a.n_tiled_blocks = static_cast<uint32_t>(t_blocks);
               const bool ov = ctx->dg.ov_n > 0;
-#define LAUNCH_MERGED(DD, OV) \
-  hipLaunchKernelGGL((lik_beam_kernel<16, DD, OV>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a)
-              if (defer && ov)
-                LAUNCH_MERGED(true, true);
-              else if (defer)
-                LAUNCH_MERGED(true, false);
-              else if (ov)
-                LAUNCH_MERGED(false, true);
-              else
-                LAUNCH_MERGED(false, false);
+#define LAUNCH_MERGED(GG, DD, OV) \
+  hipLaunchKernelGGL((lik_beam_kernel<GG, DD, OV>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a)
+#define LAUNCH_MERGED_G(GG)             \
+  do                                    \
+  {                                     \
+    if (defer && ov)                    \
+      LAUNCH_MERGED(GG, true, true);    \
+    else if (defer)                     \
+      LAUNCH_MERGED(GG, true, false);   \
+    else if (ov)                        \
+      LAUNCH_MERGED(GG, false, true);   \
+    else                                \
+      LAUNCH_MERGED(GG, false, false);  \
+  } while (0)
+              switch (G)
+              {
+                case 4:
+                  LAUNCH_MERGED_G(4);
+                  break;
+                case 8:
+                  LAUNCH_MERGED_G(8);
+                  break;
+                default:
+                  LAUNCH_MERGED_G(16);
+                  break;
+              }
+#undef LAUNCH_MERGED_G
 #undef LAUNCH_MERGED
               // the beam model's last step: left to the update's tail kernel, or a launch of its own
               if (tail && tail->want_beam)

@@ -849,7 +849,13 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
     // bounded records (RecGrid::bound_step): no overflow candidate is nearer than the voxel's skip bound to ANY query inside
     // the voxel, so a best inline d2 within it is final — the evaluation is not queued
     if (rg.bound_step > 0.0f && wave_any(over))
+    {
+      // (a real branch on the ballot: on the lattice map almost no wavefront holds an overflowing voxel. The empty asm keeps the
+      // compiler from turning the five instructions into unconditional code + selects, which it did as soon as this function was
+      // inlined into a body instead of a kernel: + 3 % on the whole kernel, profiles/r06t_refactor_check.txt)
+      asm volatile("");
       over = over && best > rec_bound2(rg, mine);
+    }
     if (valid && !over && best < prm.r2)
     {
       const float s = sqrt_in_radius(best);
@@ -926,10 +932,10 @@ __device__ inline void defer_drain(const RecGrid& rg, const LikParams& prm, cons
 template <int G, int MODE, int MINW = 8, bool COOP = false, bool DEFER = false, bool CHAIN = false>
 __device__ __forceinline__ void likelihood_tiled_body(const uint32_t block_index, const float* __restrict__ pose7, int n_p,
                                                       const float4* __restrict__ scan, int n_s, int n_tiles, int n_groups,
-                                                      const LikGrid& g, const RecGrid& rg, const LikParams& prm,
+                                                      LikGrid g, RecGrid rg, LikParams prm,
                                                       double* __restrict__ partial_sum, unsigned* __restrict__ partial_cnt,
                                                       const uint32_t* __restrict__ scan_perm, float* __restrict__ strict_terms,
-                                                      int strict_skew4, const LikChain& ch)
+                                                      int strict_skew4, LikChain ch)
 {
   // strict_terms != nullptr ("strict_order" option): besides the fp64 partials, every float term is stored at
   // [particle group][original scan index][G] so that lik_strict_sum_rows_kernel can add them in the reference's own order.
