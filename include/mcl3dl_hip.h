@@ -535,7 +535,9 @@ int mcl3dl_hip_memory_footprint(mcl3dl_hip_ctx* ctx, uint64_t* bytes8);
  *                       kernels serve the scans; "update_small_conformant" = its arrival tickets as acq_rel RMWs (the memory
  *                       model's form; slower; a mitigation switch, tests/test_gpu_soak.py runs both)
  *   "pf_fused"          1 = pf::measure as ONE work-group up to 1024 particles; 0 = partial + reduce + apply
- *   "overlap_models"    1 = beam kernels on a second stream beside the likelihood kernels (large launches)
+ *   "overlap_models"    1 = the two models of a large update run side by side: in ONE launch whose work-groups interleave the
+ *                       tiled likelihood kernel's and the beam kernel's (fp64-tree sums, >= 64 beam work-groups), else on two
+ *                       streams (from 262 144 rays); 0 = behind each other. Same bits either way
  *   "beam_prepare"      1 = launches of >= 32 768 rays take per-(particle, origin) constants from a small kernel
  * -- the likelihood index (same bits)
  *   "cand_voxel_ratio"  voxel edge / match_dist_min; 0 (default) = per map: 0.5, or 0.36 on maps of voxel-filter centroids
