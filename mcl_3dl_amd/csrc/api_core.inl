@@ -668,6 +668,48 @@ int pf_measure_single(mcl3dl_hip_ctx* ctx, float* d_weight, float* d_lik, float*
   return 0;
 }
 
+// The first half of pf::measure behind launch_measure for a rank of a device group (rank / world: the packed layout of the update's
+// one all-reduce): what mcl3dl_hip_pf_partial_device launches, with the two steps launch_measure may have left to it (tail):
+// lik_finalize_kernel's sum over the tiled kernel's per-tile partials (lik_pf_partial_kernel, wavefront partials) and the beam
+// model's penalty count -> score (BeamCounts). Same arithmetic in the same association: the same bits.
+int pf_partial_behind_measure(mcl3dl_hip_ctx* ctx, const float* d_weight, float* d_lik, float* d_beam, const float* d_extra,
+                              float* d_ratio, size_t n_p, int rank, int world, double* d_packed, const LikTail& tail)
+{
+  if (!tail.pending && !tail.beam_pending)
+    return mcl3dl_hip_pf_partial_device(ctx, d_weight, d_lik, d_beam, d_extra, d_ratio, n_p, rank, world, d_packed);
+  const int nb = pf_blocks(n_p), n_waves = static_cast<int>((n_p + 63) / 64);
+  TRY(ensure(ctx, ctx->wnew, sizeof(float) * n_p));
+  TRY(ensure(ctx, ctx->block_partials, sizeof(double) * 16 * nb));
+  const BeamCounts bc = tail.beam_pending ? BeamCounts{ ctx->penalty.as<unsigned>(), ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam }
+                                          : BeamCounts{ nullptr, nullptr, 0.0f, nullptr };
+  EventPair ep{};
+  TRY(timing_begin(ctx, MCL3DL_KERNEL_PF, &ep));
+  if (tail.pending)
+  {
+    const LikTiles lt{ ctx->lik_partial_sum.as<double>(), ctx->lik_partial_cnt.as<unsigned>(), tail.n_tiles, static_cast<int>(ctx->n_s),
+                       d_lik, d_ratio, tail.beam_fill ? d_beam : static_cast<float*>(nullptr), bc };
+    hipLaunchKernelGGL(lik_pf_partial_kernel, dim3(n_waves), dim3(256), 0, ctx->stream, lt, d_weight, d_beam, d_extra,
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>());
+    hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank, world,
+                       d_packed, n_waves);
+  }
+  else
+  {
+    hipLaunchKernelGGL(pf_partial_kernel, dim3(nb), dim3(PF_BLOCK), 0, ctx->stream, d_weight, d_lik, d_beam, d_extra, d_ratio,
+                       static_cast<int>(n_p), ctx->wnew.as<float>(), ctx->block_partials.as<double>(), bc);
+    hipLaunchKernelGGL(pf_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->block_partials.as<double>(), nb, rank, world,
+                       d_packed);
+  }
+  if (world == 1 && pf_float_order(ctx, n_p))
+    hipLaunchKernelGGL(pf_strict_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->wnew.as<float>(), static_cast<int>(n_p),
+                       d_packed);
+  if (tail.beam_pending)
+    ctx->penalty_clean_n = n_p;  // (launched: the kernel zeroes every counter it reads)
+  TRY(timing_end(ctx, ep));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ho (optional): page-locked arrays for the results; *host_written comes back true when the update's last kernel wrote
 // them — otherwise the caller copies the device arrays home.
 int enqueue_update(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* d_weight, const float* d_extra,

@@ -633,11 +633,16 @@ int group_update_impl(mcl3dl_hip_group* g, bool resident, const float* pose, con
             rank_weights[r] = d_w;
             if (extra && !staged)
               TRY(h2d(ctx, ctx->extra.p, extra + lo, fb));
+            // (the sum over the tiled kernel's per-tile partials and the beam model's last step ride in the first pf::measure kernel,
+            // as on one GPU: one launch less per model and rank)
+            LikTail tail;
+            tail.want = n <= static_cast<size_t>(1024) * PF_BLOCK;
+            tail.want_beam = true;
             TRY(launch_measure(ctx, ctx->pose.as<float>(), n, ctx->lik.as<float>(), ctx->ratio.as<float>(),
-                               ctx->beam.as<float>(), false, nullptr));
-            TRY(mcl3dl_hip_pf_partial_device(ctx, d_w, ctx->lik.as<float>(), ctx->beam.as<float>(),
-                                             extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n, r, N,
-                                             ctx->packed.as<double>()));
+                               ctx->beam.as<float>(), false, nullptr, &tail));
+            TRY(pf_partial_behind_measure(ctx, d_w, ctx->lik.as<float>(), ctx->beam.as<float>(),
+                                          extra ? ctx->extra.as<float>() : nullptr, ctx->ratio.as<float>(), n, r, N,
+                                          ctx->packed.as<double>(), tail));
           }
           else
             TRY(pack_empty(ctx, r, N, ctx->packed.as<double>()));

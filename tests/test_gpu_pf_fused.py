@@ -54,9 +54,10 @@ def test_larger_filters_still_take_the_split_path(engine):
 def test_the_two_launch_tail_behind_the_tiled_kernel_equals_the_launches_apart(engine, n_p, n_s, n_b):
     """Round 6: behind the tiled likelihood kernel (default mode, 4097 .. 28 146 points, more than 1024 particles) lik_finalize's
     sum and pf_partial's product are ONE launch (lik_pf_partial_kernel: wavefront partials) and pf_reduce runs inside pf_apply.
-    Same arithmetic in the same association as the kernels apart — measure_batch, then pf_measure on its results; a one-device
-    group runs partial / reduce / apply as three launches with the collective's slot between them — so every output is the
-    same bits: likelihoods, ratios, beam scores, weights, entropy, ratio bounds."""
+    Same arithmetic in the same association as the kernels apart — measure_batch (lik_finalize, beam_finalize), then pf_measure
+    on its results (pf_partial, reduce inside apply); a one-device group runs the sharded protocol (lik_pf_partial, pf_reduce over
+    the wavefront partials into the all-reduce's layout, the collective, pf_apply) — so every output is the same bits:
+    likelihoods, ratios, beam scores, weights, entropy, ratio bounds."""
     from mcl_3dl_amd import capi
     from mcl_3dl_amd.synthetic import make_scene
     sc = make_scene(n=91, n_p=n_p, n_s=n_s, n_b=max(n_b, 1), seed=900 + n_b)
