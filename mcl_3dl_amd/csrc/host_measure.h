@@ -513,7 +513,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
                !plan.strict_terms && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
-               blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL;
+               blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL &&
+               ctx->dg.ov_n == 0;  // (the beam kernel's map-update-overlay form needs 66 VGPRs: it would spill inside the 64 of the merged launch)
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
       // 52 us per update with them, 17 without), the overlap itself is worth ~5 % at C3 (2.1 M rays)
       const bool overlap = !merged && ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
@@ -787,20 +788,13 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
               a.tiled8 = tiled8;
               a.n_beam_blocks = static_cast<uint32_t>(nbb);
               a.n_tiled_blocks = static_cast<uint32_t>(t_blocks);
-              const bool ov = ctx->dg.ov_n > 0;
-#define LAUNCH_MERGED(GG, DD, OV) \
-  hipLaunchKernelGGL((lik_beam_kernel<GG, DD, OV>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a)
-#define LAUNCH_MERGED_G(GG)             \
-  do                                    \
-  {                                     \
-    if (defer && ov)                    \
-      LAUNCH_MERGED(GG, true, true);    \
-    else if (defer)                     \
-      LAUNCH_MERGED(GG, true, false);   \
-    else if (ov)                        \
-      LAUNCH_MERGED(GG, false, true);   \
-    else                                \
-      LAUNCH_MERGED(GG, false, false);  \
+#define LAUNCH_MERGED_G(GG)                                                                                              \
+  do                                                                                                                     \
+  {                                                                                                                      \
+    if (defer)                                                                                                           \
+      hipLaunchKernelGGL((lik_beam_kernel<GG, true, false>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a);  \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((lik_beam_kernel<GG, false, false>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a); \
   } while (0)
               switch (G)
               {
@@ -815,7 +809,6 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                   break;
               }
 #undef LAUNCH_MERGED_G
-#undef LAUNCH_MERGED
               // the beam model's last step: left to the update's tail kernel, or a launch of its own
               if (tail && tail->want_beam)
                 tail->beam_pending = true;
