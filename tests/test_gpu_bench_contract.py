@@ -95,8 +95,8 @@ def test_headline_workload_gates():
     round 3's review asked for a gate (generous enough for the box-to-box spread of +-10 %):
       * SURVEY.md 8d's region (host arrays in, host arrays out) within 0.075 ms of the device-resident update (measured
         0.041-0.048 over the boxes of round 5; ten timed steps inside a busy pytest process are noisier than the bench's own);
-      * the realistic map (voxel-filter centroids, +-0.045 m) within 1.40 x the lattice map's likelihood kernel (measured
-        1.30: profiles/r04k_bounded_records_ab.txt; the 1.2 the review asked for is not reached);
+      * the realistic map (voxel-filter centroids, +-0.045 m) within 1.45 x the lattice map's likelihood kernel (measured
+        1.29 - 1.34: profiles/r04k_bounded_records_ab.txt; the 1.2 the review asked for is not reached);
       * a replacing map update under 2 ms of wall time and nothing left to rebuild for the measurement behind it;
       * the node's own call site through the drop-in classes under 0.70 ms (measured 0.48-0.49; two thirds of it the
         reference's own per-particle loop on the host, i.e. the box's CPU)."""
@@ -122,7 +122,7 @@ def test_headline_workload_gates():
     assert r["frac"] is not None and r["counters_source"].startswith("profiles/r06"), (r["counters_source"], r["counters_note"])
     assert r["bound"] == "valu_issue" and 0.4 < r["frac"] < 0.8, r["frac"]
     mj = d["map_jitter"]
-    assert mj["vs_lattice"] < 1.40, mj
+    assert mj["vs_lattice"] < 1.45, mj   # (1.29 .. 1.34 over the boxes of round 6; the likelihood bucket no longer holds lik_finalize)
     mu = d["map_update"]
     assert mu["wall_ms"] < 2.0 and all(o == 0 for o in mu["outcomes"]), mu
     assert mu["first_measure_after_update_ms"] < 2.0 * mu["same_measure_steady_ms"] + 0.1, mu
