@@ -64,7 +64,7 @@ def world():
     """Two small maps (a lattice cube and a cube of displaced points), a pool of poses and scans for each."""
     out = []
     for k, (n, jitter) in enumerate(((41, 0.0), (45, 0.03))):
-        sc = make_scene(n=n, n_p=700, n_s=2600, n_b=64, seed=500 + k, map_jitter=jitter, label_wall=2,
+        sc = make_scene(n=n, n_p=2300, n_s=2600, n_b=64, seed=500 + k, map_jitter=jitter, label_wall=2,
                         lik_clip=(0.5, 4.0, -2.0, 2.0), beam_clip=(0.5, 3.0, -2.0, 2.0))
         out.append(sc)
     return out
@@ -309,6 +309,40 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         if not want["restored"]:
             np.testing.assert_allclose(got["entropy"], want["entropy"], rtol=1e-4, atol=1e-5)
 
+    def do_large_update():
+        """Round 6: an update of more than 1024 particles — the split pf::measure with its fusions (the tiled kernel's per-tile
+        partials and the beam model's counts taken by the first pf kernel, the reduction inside pf_apply), both models in one
+        launch where the options of the moment allow it, the beam kernel's counters left zeroed for the next call. The models are
+        checked on a sample of the particles, pf::measure on the engine's own factors."""
+        sc = world[m.map_id]
+        n_p = int(rng.integers(1030, 2300))
+        n_s = int(rng.choice([300, 1100, 2048, 2600]))
+        n_b = int(rng.choice([0, 3, 17, 64]))
+        poses = np.ascontiguousarray(sc.poses[:n_p])
+        scan = np.ascontiguousarray(sc.scan_lik[rng.permutation(2600)[:n_s]])
+        beam, lab, org = np.ascontiguousarray(sc.scan_beam[:n_b]), np.ascontiguousarray(sc.scan_beam_label[:n_b]), sc.origins
+        w0 = rng.uniform(0.5, 1.5, n_p).astype(np.float32)
+        extra = rng.uniform(0.2, 0.4, n_p).astype(np.float32)
+        log.append("large measure_update %d x %d + %d" % (n_p, n_s, n_b))
+        got = eng.measure_update(poses, w0, scan, beam if n_b else None, lab if n_b else None, org if n_b else None, extra=extra)
+        order = lik_order(eng, n_s)
+        sel = sample_of(n_p)
+        wl, wq, wb = want_models(poses[sel], scan, beam, lab, org, order)
+        # (from 2048 particles the exact sum of a short scan is the term array's, which strict_auto_max_bytes may rule out: the
+        # engine says which sum the launch took — lik_exact — and is held to it)
+        exact = bool(eng.get_option("lik_exact")) if n_s else True
+        if m.opt["strict_order"] == 3:
+            assert exact, "the in-kernel chain is the reference's sum at every size"
+        check_lik(3 if exact else 0, got["lik"][sel], got["quality"][sel], wl, wq, "large update", n_s)
+        np.testing.assert_array_equal(got["beam"][sel], wb, err_msg="large update: beam")
+        wn = w0 * (((np.float32(1.0) * got["beam"]) * got["lik"]) * extra)
+        total = wn.sum(dtype=np.float64)
+        if total > 0:
+            np.testing.assert_allclose(got["weights"], wn / np.float32(total), rtol=2e-5, err_msg="large update: weights")
+            assert not got["restored"]
+        else:
+            np.testing.assert_array_equal(got["weights"], w0)
+
     def do_scan_prep():
         sc = world[m.map_id]
         n_raw = int(rng.integers(200, 3000))
@@ -399,7 +433,7 @@ def run_sequence(seed, eng, grp, fresh, world, kind, log):
         np.testing.assert_allclose(got["weights"], want["weights"], rtol=1e-4, atol=1e-12, err_msg="group: weights")
 
     ops = [(do_set_map, 2), (do_map_update, 2), (do_params, 3), (do_option, 8), (do_measure_batch, 6), (do_progressive, 5),
-           (do_measure_update, 6), (do_scan_prep, 3), (do_resample, 2), (do_expectation, 1), (do_group, 2)]
+           (do_measure_update, 6), (do_large_update, 2), (do_scan_prep, 3), (do_resample, 2), (do_expectation, 1), (do_group, 2)]
     fns = [f for f, _ in ops]
     p = np.array([w for _, w in ops], np.float64)
     p /= p.sum()
