@@ -508,11 +508,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       // Both models in ONE launch (lik_beam_kernel, update_kernels.h: the two kernels' work-groups interleaved, so that every CU
       // hosts both all the way) whenever the likelihood side is the tiled kernel's cooperative fp64-tree form (G <= 16) and the beam side is large
       // enough to be worth interleaving: the beam kernel is NOT launched here but with the tiled kernel below.
-      // Not with the caller-order replay behind the tiled kernel (plan.strict_terms): on two streams the replay — memory-bound,
-      // VALU idle — overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5 shard: 3.09 against 3.14 ms).
+      // Not with the caller-order replay behind the tiled kernel (plan.strict_terms) where two streams would be used: there the
+      // replay — memory-bound, VALU idle — overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5
+      // shard: 3.09 against 3.14 ms); below overlap_min_rays the alternative is the two kernels behind each other.
       // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
-               !plan.strict_terms && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
+               (!plan.strict_terms || n_rays < ctx->overlap_min_rays) && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
                blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL &&
                ctx->dg.ov_n == 0;  // (the beam kernel's map-update-overlay form needs 66 VGPRs: it would spill inside the 64 of the merged launch)
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
