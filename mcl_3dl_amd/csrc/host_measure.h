@@ -447,6 +447,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   const int np = static_cast<int>(n_p);
   bool beam_forked = false, beam_ones_by_finalize = false;
   bool merged = false;  // the beam kernel's work-groups ride in the tiled likelihood kernel's launch (lik_beam_kernel)
+  bool merged_particle = false;  // ... in the per-particle likelihood kernel's (lik_particle_beam_kernel)
   struct
   {
     long long n_rays = 0, blocks = 0;
@@ -512,13 +513,18 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       // replay — memory-bound, VALU idle — overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5
       // shard: 3.09 against 3.14 ms); below overlap_min_rays the alternative is the two kernels behind each other.
       // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
+      // (the per-particle likelihood kernel's 256-thread form takes the beam kernel's work-groups along the same way:
+      // lik_particle_beam_kernel)
+      merged_particle = ctx->overlap_models && !stats && want_lik && ctx->n_s > 128 && !plan.tiled && !plan.small && !plan.chain &&
+                        ctx->lik_index == 2 && !(np <= ctx->lik_wide_max_particles && ctx->n_s > 512) && blocks >= 16 &&
+                        blocks < 0x3fffffffLL && ctx->dg.ov_n == 0;
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
                (!plan.strict_terms || n_rays < ctx->overlap_min_rays) && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
                blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL &&
                ctx->dg.ov_n == 0;  // (the beam kernel's map-update-overlay form needs 66 VGPRs: it would spill inside the 64 of the merged launch)
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
       // 52 us per update with them, 17 without), the overlap itself is worth ~5 % at C3 (2.1 M rays)
-      const bool overlap = !merged && ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
+      const bool overlap = !merged && !merged_particle && ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
       hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
       if (overlap)
       {
@@ -560,9 +566,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                              ctx->beam_origin.as<BeamOrigin>(), ctx->penalty.as<unsigned>());
           prepared = ctx->beam_origin.as<BeamOrigin>();
         }
-        if (merged)
+        if (merged || merged_particle)
         {
-          // (the rays ride in the tiled kernel's launch below; the beam model's last step comes behind that launch)
+          // (the rays ride in the likelihood kernel's launch below; the beam model's last step comes behind that launch)
           merged_beam.n_rays = n_rays;
           merged_beam.blocks = blocks;
           merged_beam.bp = bp;
@@ -921,7 +927,48 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
 #define LAUNCH_LIK(BLOCK, MODE)                                                                                   \
   hipLaunchKernelGGL((likelihood_kernel<BLOCK, MODE, false>), dim3(np), dim3(BLOCK), row_bytes, ctx->stream, d_pose, scan, ns, \
                      ctx->lg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg, row_perm)
-        if (ctx->lik_index == 2)
+        if (merged_particle)
+        {
+          const long long nbb = merged_beam.blocks, npl = np;
+          uint32_t beam8 = 1, lik8 = 1;
+          if (nbb >= npl)
+            beam8 = static_cast<uint32_t>(std::min<long long>(8, (nbb + npl / 2) / npl));
+          else
+            lik8 = static_cast<uint32_t>(std::min<long long>(8, (npl + nbb / 2) / nbb));
+          const long long rounds = std::max((nbb + 8 * beam8 - 1) / (8 * beam8), (npl + 8 * lik8 - 1) / (8 * lik8));
+          LikParticleBeamArgs a{};
+          a.pose7 = d_pose;
+          a.n_p = np;
+          a.scan = scan;
+          a.n_s = ns;
+          a.g = ctx->lg;
+          a.rg = ctx->rg;
+          a.prm = lp;
+          a.out_lik = d_lik;
+          a.out_ratio = d_ratio;
+          a.coop = coop_arg;
+          a.perm = row_perm;
+          a.scan_beam = ctx->scan_beam.as<float4>();
+          a.n_b = static_cast<int>(ctx->n_b);
+          a.origins = ctx->origins.as<float4>();
+          a.n_rays = merged_beam.n_rays;
+          a.dg = ctx->dg;
+          a.bp = merged_beam.bp;
+          a.penalty = ctx->penalty.as<unsigned>();
+          a.prepared = merged_beam.prepared;
+          a.n_o = static_cast<int>(ctx->n_o);
+          a.beam8 = beam8;
+          a.lik8 = lik8;
+          a.n_beam_blocks = static_cast<uint32_t>(nbb);
+          hipLaunchKernelGGL(lik_particle_beam_kernel, dim3(static_cast<unsigned>(rounds * 8 * (beam8 + lik8))), dim3(256), row_bytes,
+                             ctx->stream, a);
+          if (tail && tail->want_beam)
+            tail->beam_pending = true;
+          else
+            hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, ctx->penalty.as<unsigned>(),
+                               ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam, np);
+        }
+        else if (ctx->lik_index == 2)
         {
           if (ns <= 128)
             LAUNCH_LIK(64, 2);

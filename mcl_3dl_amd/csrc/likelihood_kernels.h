@@ -643,16 +643,15 @@ __device__ __forceinline__ void lik_particle(const Vec3f pos, const Quat rot, co
 // (the caller-order term row of lik_particle / the one-launch update: dynamic LDS, sized by the launch)
 extern __shared__ __attribute__((aligned(16))) float dyn_row[];
 
+// (the body as a device function of the particle: likelihood_kernel is it with blockIdx.x; lik_particle_beam_kernel, update_kernels.h,
+// interleaves its work-groups with the beam kernel's in one launch)
 template <int BLOCK, int MODE, bool STATS>
-__global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
-                                                           const float4* __restrict__ scan, int n_s, LikGrid g,
-                                                           RecGrid rg, LikParams prm,
-                                                           float* __restrict__ out_lik,
-                                                           float* __restrict__ out_ratio,
-                                                           double* __restrict__ out_tested, int coop,
-                                                           const uint32_t* __restrict__ perm = nullptr)
+__device__ __forceinline__ void likelihood_particle_body(const int p, const float* __restrict__ pose7,
+                                                         const float4* __restrict__ scan, int n_s, LikGrid g, RecGrid rg,
+                                                         LikParams prm, float* __restrict__ out_lik,
+                                                         float* __restrict__ out_ratio, double* __restrict__ out_tested,
+                                                         int coop, const uint32_t* __restrict__ perm)
 {
-  const int p = blockIdx.x;
   const float* ps = pose7 + 7 * static_cast<size_t>(p);
   const Vec3f pos = { ps[0], ps[1], ps[2] };
   const Quat rot = qnormalized(Quat{ ps[3], ps[4], ps[5], ps[6] });  // state_6dof.h:217
@@ -668,6 +667,19 @@ __global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restri
     if (STATS && out_tested)
       out_tested[p] = static_cast<double>(tt);
   }
+}
+
+template <int BLOCK, int MODE, bool STATS>
+__global__ __launch_bounds__(BLOCK) void likelihood_kernel(const float* __restrict__ pose7,
+                                                           const float4* __restrict__ scan, int n_s, LikGrid g,
+                                                           RecGrid rg, LikParams prm,
+                                                           float* __restrict__ out_lik,
+                                                           float* __restrict__ out_ratio,
+                                                           double* __restrict__ out_tested, int coop,
+                                                           const uint32_t* __restrict__ perm = nullptr)
+{
+  likelihood_particle_body<BLOCK, MODE, STATS>(static_cast<int>(blockIdx.x), pose7, scan, n_s, g, rg, prm, out_lik, out_ratio,
+                                               out_tested, coop, perm);
 }
 
 // Measured and NOT kept: a wavefront-per-particle kernel for scans of 96-1000 points with thousands of particles (no LDS,

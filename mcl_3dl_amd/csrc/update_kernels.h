@@ -420,4 +420,55 @@ __global__ __launch_bounds__(256, 8) void lik_beam_kernel(LikBeamArgs a)
                                                          LikChain{});
   }
 }
+
+// The same interleave for the PER-PARTICLE likelihood kernel (likelihood_kernel<256, 2>: one work-group per particle, scans of 129
+// points up to where the tiled kernel takes over, and every scan below 2048 particles in the default mode — the caller-order
+// rows) and the beam kernel: both are bound by dependent loads at a fraction of the chip's wavefront slots, so run side by side
+// they take about what the longer one takes alone. Dynamic LDS: the caller-order term row of lik_particle (the beam work-groups
+// carry it unused).
+struct LikParticleBeamArgs
+{
+  const float* pose7;
+  int n_p;
+  const float4* scan;
+  int n_s;
+  LikGrid g;
+  RecGrid rg;
+  LikParams prm;
+  float* out_lik;
+  float* out_ratio;
+  int coop;
+  const uint32_t* perm;
+  const float4* scan_beam;
+  int n_b;
+  const float4* origins;
+  long long n_rays;
+  DdaGrid dg;
+  BeamParams bp;
+  unsigned* penalty;
+  const BeamOrigin* prepared;
+  int n_o;
+  uint32_t beam8, lik8;  // per round: beam8 x 8 beam work-groups, then lik8 x 8 particles
+  uint32_t n_beam_blocks;
+};
+
+__global__ __launch_bounds__(256) void lik_particle_beam_kernel(LikParticleBeamArgs a)
+{
+  const uint32_t nb8 = 8u * a.beam8, round = nb8 + 8u * a.lik8;
+  const uint32_t k = blockIdx.x / round, r = blockIdx.x - k * round;
+  if (r < nb8)
+  {
+    const uint32_t bi = k * nb8 + r;
+    if (bi < a.n_beam_blocks)
+      beam_body<false, false>(static_cast<long long>(bi), a.pose7, a.scan_beam, a.n_b, a.origins, a.n_rays, a.dg, a.bp, a.penalty,
+                              static_cast<RayStats*>(nullptr), a.prepared, a.n_o);
+  }
+  else
+  {
+    const uint32_t p = k * 8u * a.lik8 + (r - nb8);
+    if (p < static_cast<uint32_t>(a.n_p))
+      likelihood_particle_body<256, 2, false>(static_cast<int>(p), a.pose7, a.scan, a.n_s, a.g, a.rg, a.prm, a.out_lik, a.out_ratio,
+                                              static_cast<double*>(nullptr), a.coop, a.perm);
+  }
+}
 }  // namespace mcl3dl

@@ -1,6 +1,6 @@
-"""Round 6, the launches around the kernels: above 1024 particles an update is (beam origins,) ONE launch of both models when the
-likelihood side is the tiled kernel (lik_beam_kernel: the tiled kernel's and the beam kernel's work-groups interleaved; particle
-groups of 4 / 8 / 16), the first pf::measure kernel — which also adds up the tiled kernel's per-tile partials and turns the beam
+"""Round 6, the launches around the kernels: above 1024 particles an update is (beam origins,) ONE launch of both models (the beam
+kernel's work-groups interleaved with the tiled likelihood kernel's — lik_beam_kernel, particle groups of 4 / 8 / 16 — or with the
+per-particle likelihood kernel's — lik_particle_beam_kernel), the first pf::measure kernel — which also adds up the tiled kernel's per-tile partials and turns the beam
 model's penalty counts into scores — and pf_apply with the reduction inside. Every one of these is the kernels' own arithmetic in
 the same association, so whatever route an update takes the results are the same bits: the merged launch against the kernels
 behind each other (overlap_models = 0), against the sharded protocol of a one-rank device group, and — on a sample of particles —
@@ -22,7 +22,10 @@ SHAPES = [(1500, 4200, 40),    # G = 4: 94 beam work-groups ride with the tiled 
           (5000, 6000, 0),     # no beam points: the tail kernel fills the ones
           (1100, 5000, 700),   # more beam work-groups than tiled ones
           (3000, 4100, 5),     # 59 beam work-groups: below the merged launch's threshold, counters cleared by the tail
-          (1025, 4097, 64)]
+          (1025, 4097, 64),
+          # the per-particle likelihood kernel (caller-order rows below 2048 particles; every scan below 768 points) with the beam
+          # kernel's work-groups interleaved: lik_particle_beam_kernel
+          (1500, 2048, 48), (4096, 512, 16), (1100, 300, 64), (1900, 4096, 9)]
 
 
 @pytest.fixture(scope="module")
