@@ -338,14 +338,15 @@ __global__ void beam_origin_kernel(const float* __restrict__ pose7, int n_p, con
 // at the C5 shard: one or two lanes computing while four wavefronts wait cost more than a 64-byte load: profiles/r06q_beam_tail_ab.txt.)
 // (the body as a device function of the work-group's index: beam_kernel is it with blockIdx.x; lik_beam_kernel, update_kernels.h,
 // interleaves it with the tiled likelihood kernel's work-groups in one launch)
-template <bool STATS, bool OVERLAY = true>
+// (BLOCK: rays per work-group = its thread count; 256 for beam_kernel, 64 where the launch it rides in has 64-thread work-groups)
+template <bool STATS, bool OVERLAY = true, int BLOCK = 256>
 __device__ __forceinline__ void beam_body(const long long block_index, const float* __restrict__ pose7,
                                           const float4* __restrict__ scan, int n_b, const float4* __restrict__ origins,
                                           long long n_rays, DdaGrid g, BeamParams bp,
                                           unsigned* __restrict__ penalty_count, RayStats* __restrict__ stats,
                                           const BeamOrigin* __restrict__ prepared, int n_o)
 {
-  const long long ray0 = block_index * 256;
+  const long long ray0 = block_index * BLOCK;
   const long long ray = ray0 + threadIdx.x;
   unsigned st_steps = 0, st_occ = 0, st_tested = 0;
   // Penalised rays are counted per particle. Thousands of rays of one particle bumping one global counter serialise in

@@ -515,9 +515,9 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
       // (the per-particle likelihood kernel's 256-thread form takes the beam kernel's work-groups along the same way:
       // lik_particle_beam_kernel)
-      merged_particle = ctx->overlap_models && !stats && want_lik && ctx->n_s > 128 && !plan.tiled && !plan.small && !plan.chain &&
+      merged_particle = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && !plan.tiled && !plan.small && !plan.chain &&
                         ctx->lik_index == 2 && !(np <= ctx->lik_wide_max_particles && ctx->n_s > 512) && blocks >= 16 &&
-                        blocks < 0x3fffffffLL && ctx->dg.ov_n == 0;
+                        blocks < 0x0fffffffLL && ctx->dg.ov_n == 0;
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
                (!plan.strict_terms || n_rays < ctx->overlap_min_rays) && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
                blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL &&
@@ -929,7 +929,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                      ctx->lg, ctx->rg, lp, d_lik, d_ratio, nullptr, coop_arg, row_perm)
         if (merged_particle)
         {
-          const long long nbb = merged_beam.blocks, npl = np;
+          const int lik_block = ns <= 128 ? 64 : 256;  // (the work-group size LAUNCH_LIK below would take)
+          const long long nbb = (merged_beam.n_rays + lik_block - 1) / lik_block, npl = np;
           uint32_t beam8 = 1, lik8 = 1;
           if (nbb >= npl)
             beam8 = static_cast<uint32_t>(std::min<long long>(8, (nbb + npl / 2) / npl));
@@ -960,8 +961,12 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
           a.beam8 = beam8;
           a.lik8 = lik8;
           a.n_beam_blocks = static_cast<uint32_t>(nbb);
-          hipLaunchKernelGGL(lik_particle_beam_kernel, dim3(static_cast<unsigned>(rounds * 8 * (beam8 + lik8))), dim3(256), row_bytes,
-                             ctx->stream, a);
+          if (lik_block == 64)
+            hipLaunchKernelGGL(lik_particle_beam_kernel<64>, dim3(static_cast<unsigned>(rounds * 8 * (beam8 + lik8))), dim3(64), row_bytes,
+                               ctx->stream, a);
+          else
+            hipLaunchKernelGGL(lik_particle_beam_kernel<256>, dim3(static_cast<unsigned>(rounds * 8 * (beam8 + lik8))), dim3(256), row_bytes,
+                               ctx->stream, a);
           if (tail && tail->want_beam)
             tail->beam_pending = true;
           else

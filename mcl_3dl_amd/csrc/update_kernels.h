@@ -452,7 +452,9 @@ struct LikParticleBeamArgs
   uint32_t n_beam_blocks;
 };
 
-__global__ __launch_bounds__(256) void lik_particle_beam_kernel(LikParticleBeamArgs a)
+// BLOCK = the likelihood kernel's work-group size (launch_measure: 64 threads up to 128 points, 256 beyond) = rays per beam work-group
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lik_particle_beam_kernel(LikParticleBeamArgs a)
 {
   const uint32_t nb8 = 8u * a.beam8, round = nb8 + 8u * a.lik8;
   const uint32_t k = blockIdx.x / round, r = blockIdx.x - k * round;
@@ -460,14 +462,14 @@ __global__ __launch_bounds__(256) void lik_particle_beam_kernel(LikParticleBeamA
   {
     const uint32_t bi = k * nb8 + r;
     if (bi < a.n_beam_blocks)
-      beam_body<false, false>(static_cast<long long>(bi), a.pose7, a.scan_beam, a.n_b, a.origins, a.n_rays, a.dg, a.bp, a.penalty,
-                              static_cast<RayStats*>(nullptr), a.prepared, a.n_o);
+      beam_body<false, false, BLOCK>(static_cast<long long>(bi), a.pose7, a.scan_beam, a.n_b, a.origins, a.n_rays, a.dg, a.bp, a.penalty,
+                                     static_cast<RayStats*>(nullptr), a.prepared, a.n_o);
   }
   else
   {
     const uint32_t p = k * 8u * a.lik8 + (r - nb8);
     if (p < static_cast<uint32_t>(a.n_p))
-      likelihood_particle_body<256, 2, false>(static_cast<int>(p), a.pose7, a.scan, a.n_s, a.g, a.rg, a.prm, a.out_lik, a.out_ratio,
+      likelihood_particle_body<BLOCK, 2, false>(static_cast<int>(p), a.pose7, a.scan, a.n_s, a.g, a.rg, a.prm, a.out_lik, a.out_ratio,
                                               static_cast<double*>(nullptr), a.coop, a.perm);
   }
 }

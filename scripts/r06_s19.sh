@@ -15,7 +15,7 @@ PY
 }
 Q="--steps 40 --warmup 5 --no-extras --no-cpu-baseline"
 for r in 1 2; do
-for shape in "1500 2048 48" "1000 1000 16" "4096 512 16" "1800 4096 96" "3000 300 64" "4096 200 3"; do
+for shape in "4096 96 3" "2000 96 3" "1100 64 16" "8192 128 8" "1000 1000 16"; do
   set -- $shape
   run p$1x$2+$3_serial_$r 0 "--workload C3 --particles $1 --scan-points $2 --beam-points $3 $Q"
   run p$1x$2+$3_merged_$r 1 "--workload C3 --particles $1 --scan-points $2 --beam-points $3 $Q"

@@ -25,7 +25,8 @@ SHAPES = [(1500, 4200, 40),    # G = 4: 94 beam work-groups ride with the tiled 
           (1025, 4097, 64),
           # the per-particle likelihood kernel (caller-order rows below 2048 particles; every scan below 768 points) with the beam
           # kernel's work-groups interleaved: lik_particle_beam_kernel
-          (1500, 2048, 48), (4096, 512, 16), (1100, 300, 64), (1900, 4096, 9)]
+          (1500, 2048, 48), (4096, 512, 16), (1100, 300, 64), (1900, 4096, 9),
+          (4096, 96, 3), (1300, 128, 40), (2500, 33, 7)]   # up to 128 points: 64-thread work-groups, 64 rays per beam work-group
 
 
 @pytest.fixture(scope="module")
