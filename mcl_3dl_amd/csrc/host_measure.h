@@ -448,6 +448,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
   bool beam_forked = false, beam_ones_by_finalize = false;
   bool merged = false;  // the beam kernel's work-groups ride in the tiled likelihood kernel's launch (lik_beam_kernel)
   bool merged_particle = false;  // ... in the per-particle likelihood kernel's (lik_particle_beam_kernel)
+  bool merged_chain = false;     // ... in the tiled kernel's in-kernel-chain form (strict_order 3)
   struct
   {
     long long n_rays = 0, blocks = 0;
@@ -518,13 +519,17 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       merged_particle = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && !plan.tiled && !plan.small && !plan.chain &&
                         ctx->lik_index == 2 && !(np <= ctx->lik_wide_max_particles && ctx->n_s > 512) && blocks >= 16 &&
                         blocks < 0x0fffffffLL && ctx->dg.ov_n == 0;
+      // (the in-kernel chain's single-tile form, strict_order 3, rides the same way: a consumer's producer keeps its lower block index)
+      merged_chain = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && plan.chain && plan.chain_ppl != 4 &&
+                     plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f && blocks >= 64 &&
+                     blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL && ctx->dg.ov_n == 0;
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
                (!plan.strict_terms || n_rays < ctx->overlap_min_rays) && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
                blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL &&
                ctx->dg.ov_n == 0;  // (the beam kernel's map-update-overlay form needs 66 VGPRs: it would spill inside the 64 of the merged launch)
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
       // 52 us per update with them, 17 without), the overlap itself is worth ~5 % at C3 (2.1 M rays)
-      const bool overlap = !merged && !merged_particle && ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
+      const bool overlap = !merged && !merged_particle && !merged_chain && ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && n_rays >= ctx->overlap_min_rays;
       hipStream_t bs = overlap ? ctx->aux_stream : ctx->stream;
       if (overlap)
       {
@@ -566,7 +571,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                              ctx->beam_origin.as<BeamOrigin>(), ctx->penalty.as<unsigned>());
           prepared = ctx->beam_origin.as<BeamOrigin>();
         }
-        if (merged || merged_particle)
+        if (merged || merged_particle || merged_chain)
         {
           // (the rays ride in the likelihood kernel's launch below; the beam model's last step comes behind that launch)
           merged_beam.n_rays = n_rays;
@@ -671,6 +676,48 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                      t_perm, t_terms, STRICT_SKEW4)
           const bool coop = coop_arg != 0;
           const bool defer = coop && lik_defer_active(ctx);
+          // the launch of both models (lik_beam_kernel): the beam side and the interleave for a tiled grid of t_blocks work-groups —
+          // rounds of beam8 x 8 beam work-groups + tiled8 x 8 tiled ones, beam8 : tiled8 ~ the two grids' ratio (each at most 8)
+          const auto merged_args = [&](long long t_blocks, LikBeamArgs& a) -> long long
+          {
+            const long long nbb = merged_beam.blocks;
+            uint32_t beam8 = 1, tiled8 = 1;
+            if (nbb >= t_blocks)
+              beam8 = static_cast<uint32_t>(std::min<long long>(8, (nbb + t_blocks / 2) / t_blocks));
+            else
+              tiled8 = static_cast<uint32_t>(std::min<long long>(8, (t_blocks + nbb / 2) / nbb));
+            const long long rounds = std::max((nbb + 8 * beam8 - 1) / (8 * beam8), (t_blocks + 8 * tiled8 - 1) / (8 * tiled8));
+            a.pose7 = d_pose;
+            a.n_p = np;
+            a.n_groups = plan.n_groups;
+            a.g = ctx->lg;
+            a.rg = ctx->rg;
+            a.prm = lp;
+            a.strict_skew4 = STRICT_SKEW4;
+            a.scan_beam = ctx->scan_beam.as<float4>();
+            a.n_b = static_cast<int>(ctx->n_b);
+            a.origins = ctx->origins.as<float4>();
+            a.n_rays = merged_beam.n_rays;
+            a.dg = ctx->dg;
+            a.bp = merged_beam.bp;
+            a.penalty = ctx->penalty.as<unsigned>();
+            a.prepared = merged_beam.prepared;
+            a.n_o = static_cast<int>(ctx->n_o);
+            a.beam8 = beam8;
+            a.tiled8 = tiled8;
+            a.n_beam_blocks = static_cast<uint32_t>(nbb);
+            a.n_tiled_blocks = static_cast<uint32_t>(t_blocks);
+            return rounds * 8 * (beam8 + tiled8);
+          };
+          // the beam model's last step behind such a launch: left to the update's tail kernel, or a launch of its own
+          const auto merged_beam_done = [&]()
+          {
+            if (tail && tail->want_beam)
+              tail->beam_pending = true;
+            else
+              hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, ctx->penalty.as<unsigned>(),
+                                 ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam, np);
+          };
           if (plan.chain)
           {
             ChainSerial& cs = chain_serial(ctx->device);
@@ -700,6 +747,37 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             {
               hipLaunchKernelGGL((likelihood_chain_multi_kernel<4, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream,
                                  d_pose, np, scan, ns, n_tiles, plan.n_super, n_groups, ctx->rg, lp, lc);
+            }
+            else if (merged_chain)
+            {
+              LikBeamArgs a{};
+              const long long grid = merged_args(blocks, a);
+              a.scan = scan;
+              a.n_s = ns;
+              a.n_tiles = n_tiles;
+              a.ch = lc;
+#define LAUNCH_MERGED_CHAIN(GG)                                                                                                 \
+  do                                                                                                                            \
+  {                                                                                                                             \
+    if (defer)                                                                                                                  \
+      hipLaunchKernelGGL((lik_beam_kernel<GG, true, false, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a);  \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((lik_beam_kernel<GG, false, false, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream, a); \
+  } while (0)
+              switch (G)
+              {
+                case 4:
+                  LAUNCH_MERGED_CHAIN(4);
+                  break;
+                case 8:
+                  LAUNCH_MERGED_CHAIN(8);
+                  break;
+                default:
+                  LAUNCH_MERGED_CHAIN(16);
+                  break;
+              }
+#undef LAUNCH_MERGED_CHAIN
+              merged_beam_done();
             }
             else
             {
@@ -758,43 +836,15 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
             const long long t_blocks = 8 * ((full / 8) * n_groups + (rem + 7) / 8);  // (plan_lik's count, for this many tiles)
             if (merged)
             {
-              // rounds of beam8 x 8 beam work-groups + tiled8 x 8 tiled ones, beam8 : tiled8 ~ the two grids' ratio (each at most 8)
-              const long long nbb = merged_beam.blocks;
-              uint32_t beam8 = 1, tiled8 = 1;
-              if (nbb >= t_blocks)
-                beam8 = static_cast<uint32_t>(std::min<long long>(8, (nbb + t_blocks / 2) / t_blocks));
-              else
-                tiled8 = static_cast<uint32_t>(std::min<long long>(8, (t_blocks + nbb / 2) / nbb));
-              const long long rounds = std::max((nbb + 8 * beam8 - 1) / (8 * beam8), (t_blocks + 8 * tiled8 - 1) / (8 * tiled8));
-              const long long grid = rounds * 8 * (beam8 + tiled8);
               LikBeamArgs a{};
-              a.pose7 = d_pose;
-              a.n_p = np;
+              const long long grid = merged_args(t_blocks, a);
               a.scan = t_scan;
               a.n_s = t_ns;
               a.n_tiles = t_tiles;
-              a.n_groups = n_groups;
-              a.g = ctx->lg;
-              a.rg = ctx->rg;
-              a.prm = lp;
               a.partial_sum = t_psum;
               a.partial_cnt = t_pcnt;
               a.scan_perm = t_perm;
               a.strict_terms = t_terms;
-              a.strict_skew4 = STRICT_SKEW4;
-              a.scan_beam = ctx->scan_beam.as<float4>();
-              a.n_b = static_cast<int>(ctx->n_b);
-              a.origins = ctx->origins.as<float4>();
-              a.n_rays = merged_beam.n_rays;
-              a.dg = ctx->dg;
-              a.bp = merged_beam.bp;
-              a.penalty = ctx->penalty.as<unsigned>();
-              a.prepared = merged_beam.prepared;
-              a.n_o = static_cast<int>(ctx->n_o);
-              a.beam8 = beam8;
-              a.tiled8 = tiled8;
-              a.n_beam_blocks = static_cast<uint32_t>(nbb);
-              a.n_tiled_blocks = static_cast<uint32_t>(t_blocks);
 #define LAUNCH_MERGED_G(GG)                                                                                              \
   do                                                                                                                     \
   {                                                                                                                      \
@@ -816,12 +866,7 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
                   break;
               }
 #undef LAUNCH_MERGED_G
-              // the beam model's last step: left to the update's tail kernel, or a launch of its own
-              if (tail && tail->want_beam)
-                tail->beam_pending = true;
-              else
-                hipLaunchKernelGGL(beam_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, ctx->penalty.as<unsigned>(),
-                                   ctx->pow_table.as<float>(), ctx->beam_likelihood_min, d_beam, np);
+              merged_beam_done();
               return;
             }
             switch (G)

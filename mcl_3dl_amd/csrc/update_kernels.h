@@ -397,9 +397,11 @@ struct LikBeamArgs
   // the interleave
   uint32_t beam8, tiled8;
   uint32_t n_beam_blocks, n_tiled_blocks;
+  // CHAIN: the float recurrence inside the tiled kernel (strict_order 3); a work-group's producer keeps its lower block index
+  LikChain ch;
 };
 
-template <int G, bool DEFER, bool OVERLAY>
+template <int G, bool DEFER, bool OVERLAY, bool CHAIN = false>
 __global__ __launch_bounds__(256, 8) void lik_beam_kernel(LikBeamArgs a)
 {
   const uint32_t nb8 = 8u * a.beam8, round = nb8 + 8u * a.tiled8;
@@ -415,9 +417,9 @@ __global__ __launch_bounds__(256, 8) void lik_beam_kernel(LikBeamArgs a)
   {
     const uint32_t ti = k * 8u * a.tiled8 + (r - nb8);
     if (ti < a.n_tiled_blocks)
-      likelihood_tiled_body<G, 2, 8, true, DEFER, false>(ti, a.pose7, a.n_p, a.scan, a.n_s, a.n_tiles, a.n_groups, a.g, a.rg, a.prm,
+      likelihood_tiled_body<G, 2, 8, true, DEFER, CHAIN>(ti, a.pose7, a.n_p, a.scan, a.n_s, a.n_tiles, a.n_groups, a.g, a.rg, a.prm,
                                                          a.partial_sum, a.partial_cnt, a.scan_perm, a.strict_terms, a.strict_skew4,
-                                                         LikChain{});
+                                                         a.ch);
   }
 }
 
