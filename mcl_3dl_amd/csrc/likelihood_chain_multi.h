@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 8) void likelihood_chain_multi_kernel(const fl
       bool matched, over;
       float best;
       uint32_t mine;
-      const float term = eval_coop_first(rg, prm, pos, rot, v, have_point, lane, matched, over, best, mine);
+      unsigned long long over_m;
+      const float term = eval_coop_first(rg, prm, pos, rot, v, have_point, lane, matched, over, best, mine, over_m);
       s_term[m][k][t] = over ? best : term;
       const unsigned long long mm = __builtin_amdgcn_ballot_w64(matched);
       if (lane == 0)

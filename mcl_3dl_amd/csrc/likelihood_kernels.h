@@ -837,8 +837,11 @@ struct DeferQueue
 // The first four candidates of one evaluation on the cooperative path (all lanes of the wavefront arrive): like eval_coop,
 // but a lane whose record holds more than four candidates returns `over` = true with its best-so-far in `best` and the
 // record's packed word in `mine` instead of running the overflow rounds.
+// over_m = the wavefront's lanes with `over` as a 64-bit mask, built from compare MASKS with scalar operations: a ballot of a
+// combined boolean costs a v_cndmask + v_cmp round trip through a VGPR per use (two uses per evaluation: four of 159 instructions).
 __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm, const Vec3f pos, const Quat rot, const float4 v,
-                                        bool have_point, int lane, bool& matched, bool& over, float& best, uint32_t& mine)
+                                        bool have_point, int lane, bool& matched, bool& over, float& best, uint32_t& mine,
+                                        unsigned long long& over_m)
 {
   const Vec3f tp = vadd(qrot_trim(rot, Vec3f{ v.x, v.y, v.z }), pos);
   const float qx = tp.x * prm.wx, qy = tp.y * prm.wy, qz = tp.z * prm.wz;
@@ -848,26 +851,29 @@ __device__ inline float eval_coop_first(const RecGrid& rg, const LikParams& prm,
   const bool valid = b >= 0;
   float dist = -1.0f;
   over = false;
+  over_m = 0ull;
   best = 0.0f;
   mine = 0u;
-  if (wave_any(valid))
+  const unsigned long long valid_m = __builtin_amdgcn_ballot_w64(valid);  // (straight from the compare)
+  if (valid_m != 0ull)
   {
     const uint32_t rec = (static_cast<uint32_t>(b) << 9) | sub;
     const uint32_t vrec = rg.rec_bytes32 ? rec : (valid ? rec : 0u);
     uint32_t w[4];
     best = quad_round(rg.rec, rg.rec_bytes32, vrec, qx, qy, qz, lane & 3, w);
     mine = own_word(w, lane & 3);
-    over = valid && mine > rg.over_thr;
+    over_m = valid_m & lanes_gt_u32(mine, rg.over_thr);
     // bounded records (RecGrid::bound_step): no overflow candidate is nearer than the voxel's skip bound to ANY query inside
     // the voxel, so a best inline d2 within it is final — the evaluation is not queued
-    if (rg.bound_step > 0.0f && wave_any(over))
+    if (rg.bound_step > 0.0f && over_m != 0ull)
     {
-      // (a real branch on the ballot: on the lattice map almost no wavefront holds an overflowing voxel. The empty asm keeps the
-      // compiler from turning the five instructions into unconditional code + selects, which it did as soon as this function was
-      // inlined into a body instead of a kernel: + 3 % on the whole kernel, profiles/r06t_refactor_check.txt)
+      // (a real branch: on the lattice map almost no wavefront holds an overflowing voxel. The empty asm keeps the compiler from
+      // turning the five instructions into unconditional code + selects, which it did as soon as this function was inlined into a
+      // body instead of a kernel: + 3 % on the whole kernel, profiles/r06t_refactor_check.txt)
       asm volatile("");
-      over = over && best > rec_bound2(rg, mine);
+      over_m &= __builtin_amdgcn_fcmpf(best, rec_bound2(rg, mine), 2 /* FCMP_OGT: false for a NaN, like `>` */);
     }
+    over = __builtin_amdgcn_inverse_ballot_w64(over_m);
     if (valid && !over && best < prm.r2)
     {
       const float s = sqrt_in_radius(best);
@@ -1033,12 +1039,12 @@ __device__ __forceinline__ void likelihood_tiled_body(const uint32_t block_index
       bool matched, over;
       float best;
       uint32_t mine;
-      const float term = eval_coop_first(rg, prm, pos, rot, v, have_point, lane, matched, over, best, mine);
+      unsigned long long om;
+      const float term = eval_coop_first(rg, prm, pos, rot, v, have_point, lane, matched, over, best, mine, om);
       s_term[k][t] = over ? best : term;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(matched);
       if (lane == 0)
         s_cnt[k][wave] = static_cast<unsigned>(__popcll(m));
-      const unsigned long long om = __builtin_amdgcn_ballot_w64(over);
       if (om != 0ull)
       {
         const uint32_t n_new = static_cast<uint32_t>(__popcll(om));

@@ -166,26 +166,31 @@ def test_group_form(scene, devices, collective):
         # caller-order rows instead of the replay, same bits — and the first launch of a kernel loads its code object)
         g.measure_batch_begin(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, slice_particles=1000)
         g.measure_batch_end()
-        t0 = time.perf_counter()
-        got = g.measure_batch_begin(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, slice_particles=1000)
-        t_begin = time.perf_counter()
-        n = g.measure_batch_wait(0)
-        t_first = time.perf_counter()
-        assert 1000 <= n < n_p                      # the first slice of the first shard, not the batch
-        np.testing.assert_array_equal(got[0][:n], ref[0][:n])
-        if N > 1:
-            # a particle of the LAST shard: everything in front of it has arrived by then
-            m = g.measure_batch_wait(n_p - 2999)
-            assert m > n_p - 2999
-            np.testing.assert_array_equal(got[0][:m], ref[0][:m])
-            np.testing.assert_array_equal(got[2][:m], ref[2][:m])
-        assert g.measure_batch_wait(n_p - 1) == n_p
-        t_last = time.perf_counter()
-        with pytest.raises(EngineError, match="not part of the batch"):
-            g.measure_batch_wait(n_p)
-        g.measure_batch_end()
-        for a, b in zip(got, ref):
-            np.testing.assert_array_equal(a, b)
+        # (the timestamps are wall clock on a box that is not ours alone, and the whole batch is a few hundred microseconds long
+        # since round 6: up to three rounds, every one checked for its results, the first with clean timestamps counts)
+        for attempt in range(3):
+            t0 = time.perf_counter()
+            got = g.measure_batch_begin(poses, sc.scan_lik, sc.scan_beam, sc.scan_beam_label, sc.origins, slice_particles=1000)
+            t_begin = time.perf_counter()
+            n = g.measure_batch_wait(0)
+            t_first = time.perf_counter()
+            assert 1000 <= n < n_p                      # the first slice of the first shard, not the batch
+            np.testing.assert_array_equal(got[0][:n], ref[0][:n])
+            if N > 1:
+                # a particle of the LAST shard: everything in front of it has arrived by then
+                m = g.measure_batch_wait(n_p - 2999)
+                assert m > n_p - 2999
+                np.testing.assert_array_equal(got[0][:m], ref[0][:m])
+                np.testing.assert_array_equal(got[2][:m], ref[2][:m])
+            assert g.measure_batch_wait(n_p - 1) == n_p
+            t_last = time.perf_counter()
+            with pytest.raises(EngineError, match="not part of the batch"):
+                g.measure_batch_wait(n_p)
+            g.measure_batch_end()
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b)
+            if (t_first - t0) < 0.8 * (t_last - t0):
+                break
         # the first _wait returned before the last results arrived (timestamps; the batch is ~N x 3 slices long)
         assert (t_first - t0) < 0.8 * (t_last - t0), (t_begin - t0, t_first - t0, t_last - t0)
         # a new _begin ends an open batch; fewer particles than devices
