@@ -510,9 +510,8 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       // Both models in ONE launch (lik_beam_kernel, update_kernels.h: the two kernels' work-groups interleaved, so that every CU
       // hosts both all the way) whenever the likelihood side is the tiled kernel's cooperative fp64-tree form (G <= 16) and the beam side is large
       // enough to be worth interleaving: the beam kernel is NOT launched here but with the tiled kernel below.
-      // Not with the caller-order replay behind the tiled kernel (plan.strict_terms) where two streams would be used: there the
-      // replay — memory-bound, VALU idle — overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5
-      // shard: 3.09 against 3.14 ms); below overlap_min_rays the alternative is the two kernels behind each other.
+      // Not in front of a LONG caller-order replay (replay_is_long below): on two streams that replay — memory-bound, VALU idle —
+      // overlaps the rest of the beam kernel, which the lock-step interleave cannot offer (C5 shard: 3.09 against 3.14 ms).
       // Measured, C3: 0.3446 (two streams) -> 0.3313 ms; 4096 rays per particle: 1.0855 -> 1.0070 (profiles/r06s_lik_beam_one_launch.txt).
       // (the per-particle likelihood kernel's 256-thread form takes the beam kernel's work-groups along the same way:
       // lik_particle_beam_kernel)
@@ -523,8 +522,14 @@ int launch_measure(mcl3dl_hip_ctx* ctx, const float* d_pose, size_t n_p, float* 
       merged_chain = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && plan.chain && plan.chain_ppl != 4 &&
                      plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f && blocks >= 64 &&
                      blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL && ctx->dg.ov_n == 0;
+      // (in front of the caller-order replay: two streams only where they would be used — from overlap_min_rays rays — AND the replay
+      // is long enough to hide the beam kernel's tail behind: a term array of at least half a gigabyte. Measured, merged against
+      // streams: 4096 x 4096 + 128 rays - 12 %, 16384 x 4096 + 512 (268 MB) - 3 %, 8192 x 32768 + 512 (1 GB) + 1 %, the C5 shard + 2 %:
+      // profiles/r06s_lik_beam_one_launch.txt)
+      const bool replay_is_long = plan.strict_terms != nullptr && n_rays >= ctx->overlap_min_rays &&
+                                  strict_terms_bytes(n_p, static_cast<int>(ctx->n_s), plan.group_size) >= (static_cast<size_t>(512) << 20);
       merged = ctx->overlap_models && !stats && want_lik && ctx->n_s > 0 && plan.tiled && !plan.chain && !plan.chunk &&
-               (!plan.strict_terms || n_rays < ctx->overlap_min_rays) && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
+               !replay_is_long && plan.group_size <= 16 && ctx->lik_coop && ctx->lik_index == 2 && ctx->match_dist_min > 1e-5f &&
                blocks >= 64 && blocks < 0x3fffffffLL && plan.blocks < 0x3fffffffLL &&
                ctx->dg.ov_n == 0;  // (the beam kernel's map-update-overlay form needs 66 VGPRs: it would spill inside the 64 of the merged launch)
       // the second stream pays only for large launches: the fork / join events cost ~35 us (64 particles x 96 + 3 points:
